@@ -1,0 +1,218 @@
+/*
+ * okx.h — C-ABI of the MI355X-native batched suspension-kinematics constraint solver.
+ *
+ * This is the drop-in boundary for ONE hot path of nickmccleery/open-kinematics: the
+ * per-sweep-step nonlinear least-squares solve.  The reference has no FFI for this path
+ * (it is pure Python); the entry points below are what a binding for it would bind, and
+ * each cites the reference interface it replaces (paths relative to the reference root,
+ * src/kinematics/core/...).  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void*.
+ *   - every pointer named d_* is a DEVICE pointer (HBM); everything else is host memory
+ *     that is only read during the call.
+ *   - all entry points return OKX_OK (0) or a negative okx_status; they never throw.
+ *     okx_last_error() returns a thread-local message for the last failure.
+ *   - all floating point is IEEE fp64; lengths in millimetres, angles in radians.
+ *
+ * The "constraint program" is the flattened form of what the reference passes to
+ * solve_suspension_sweep() (solver.py:654-660): initial SuspensionState (state.py:23-72),
+ * list[Constraint] (constraints.py), DerivedPointsManager spec (points/derived/) and the
+ * target rows of a SweepConfig (targeting.py:51-104).
+ */
+#ifndef OKX_H
+#define OKX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OKX_ABI_VERSION 1
+
+/* Hard limits of one problem (one wavefront owns one problem). */
+#define OKX_MAX_VARS 96      /* n = 3 * free points                                  */
+#define OKX_MAX_ROWS 128     /* m = constraint rows + target rows                    */
+#define OKX_MAX_POINTS 96    /* fixed + free + derived                               */
+#define OKX_MAX_TARGETS 8
+#define OKX_ROW_PARAMS 8     /* doubles per constraint row                           */
+#define OKX_ROW_POINTS 4     /* point slots per constraint row                       */
+
+typedef enum okx_status {
+  OKX_OK = 0,
+  OKX_ERR_INVALID = -1,      /* malformed program / argument                         */
+  OKX_ERR_LIMIT = -2,        /* exceeds an OKX_MAX_* limit                           */
+  OKX_ERR_UNDERDETERMINED = -3, /* n_vars > n_rows (solver.py:116-121)               */
+  OKX_ERR_DEVICE = -4,       /* HIP runtime failure (no GPU, launch error, ...)      */
+  OKX_ERR_ALLOC = -5
+} okx_status;
+
+/*
+ * Constraint row types.  One scalar residual per row, defined exactly as
+ * constraints.py does (softnorm(s) = sqrt(s + 1e-12) - 1e-6, soft_math.py:16-27);
+ * Jacobian rows follow jacobians.py / tools/generate_jacobians.py.
+ * Point slots p0..p3 and params q0..q7 per type:
+ */
+typedef enum okx_row_type {
+  OKX_ROW_DISTANCE = 0,          /* constraints.py:89-134   p0=p1,p1=p2        q0=L                */
+  OKX_ROW_SPHERICAL = 1,         /* constraints.py:137-170  p0,p1              —                   */
+  OKX_ROW_ANGLE = 2,             /* constraints.py:173-243  v1s,v1e,v2s,v2e    q0=alpha            */
+  OKX_ROW_THREE_POINT_ANGLE = 3, /* constraints.py:246-308  p1,p2(vertex),p3   q0=alpha            */
+  OKX_ROW_VECTORS_PARALLEL = 4,  /* constraints.py:311-371  v1s,v1e,v2s,v2e    —                   */
+  OKX_ROW_VECTORS_PERPENDICULAR = 5, /* constraints.py:374-429 same            —                   */
+  OKX_ROW_EQUAL_DISTANCE = 6,    /* constraints.py:432-477  p1,p2,p3,p4        —                   */
+  OKX_ROW_FIXED_AXIS = 7,        /* constraints.py:480-516  p0                 q0=axis(0/1/2) q1=value */
+  OKX_ROW_POINT_ON_LINE = 8,     /* constraints.py:519-576  p0                 q0..2=line point q3..5=line dir */
+  OKX_ROW_POINT_ON_PLANE = 9,    /* constraints.py:579-627  p0                 q0..2=plane point q3..5=normal  */
+  OKX_ROW_MIDPOINT_ON_PLANE = 10,/* constraints.py:630-666  a,b                q0..2=plane point q3..5=normal  */
+  OKX_ROW_COPLANAR = 11,         /* constraints.py:669-709  p1..p4             —                   */
+  OKX_ROW_SCALAR_TRIPLE = 12,    /* constraints.py:712-733  p1..p4             q0=V q1=scale       */
+  /*
+   * Extension (not a reference class): one Cartesian component of
+   * cross(p - line_point, line_dir).  Three such rows replace one POINT_ON_LINE row
+   * when the host flattens with line_mode="pinned"; sum of squares = d^2 instead of
+   * softnorm(d^2)^2.  Same minimiser whenever the point can reach the line;
+   * it removes the reference row's zero-gradient degeneracy (sensitivity.py:83-87,146-174
+   * does the same with explicit pins).
+   */
+  OKX_ROW_LINE_PIN = 13,         /* p0  q0..2=line point q3..5=line dir q6=component(0/1/2)        */
+  OKX_ROW_TYPE_COUNT = 14
+} okx_row_type;
+
+/*
+ * Derived-point ops (points/derived/definitions.py), evaluated in the given
+ * (topological) order; closed-form 3x3 chain-rule blocks replace the reference's
+ * dual-number pass (manager.py:271-324).
+ */
+typedef enum okx_dop_type {
+  OKX_DOP_MIDPOINT = 0,      /* definitions.py:76-89    out = a + (b - a)/2               pts=(a,b)           */
+  OKX_DOP_ALONG = 1,         /* definitions.py:24-33,92-155 out = base + normalize(a - b)*c pts=(base,a,b) q=c */
+  OKX_DOP_CONTACT_PATCH = 2, /* definitions.py:36-73,158-180 out = wc + normalize(-Z - ((-Z).ax)ax)*R,
+                                ax = normalize(axo - axi)   pts=(wc,axi,axo) q=R                              */
+  OKX_DOP_TYPE_COUNT = 3
+} okx_dop_type;
+
+/* Flattened constraint program (host arrays; copied by okx_program_create). */
+typedef struct okx_program_desc {
+  int32_t abi_version;        /* = OKX_ABI_VERSION */
+  int32_t n_points;           /* P: all points, any order */
+  int32_t n_free;             /* F: free points; n_vars = 3F */
+  int32_t n_derived;          /* D */
+  int32_t n_rows;             /* Mc: constraint rows (targets excluded) */
+  int32_t n_targets;          /* T: target rows appended after the constraint rows */
+  int32_t n_out;              /* points written per solved problem */
+  int32_t reserved;
+  const int32_t* free_point;  /* [F]      point index of variable block k (state.py:46-50 order) */
+  const int32_t* dop_type;    /* [D]      okx_dop_type */
+  const int32_t* dop_out;     /* [D]      output point index */
+  const int32_t* dop_pts;     /* [D][4]   input point indices, -1 = unused */
+  const double* dop_param;    /* [D]      scalar parameter */
+  const int32_t* row_type;    /* [Mc]     okx_row_type */
+  const int32_t* row_pts;     /* [Mc][4]  point indices, -1 = unused */
+  const double* row_param;    /* [Mc][8]  design-state parameters (geometry 0) */
+  const int32_t* tgt_point;   /* [T]      targeted point */
+  const double* tgt_dir;      /* [T][3]   unit direction (targeting.py:135-148) */
+  const int32_t* out_point;   /* [n_out]  output point indices (Suspension.output_points()) */
+  const double* design_pos;   /* [P][3]   design positions incl. derived (geometry 0) */
+} okx_program_desc;
+
+typedef struct okx_program okx_program; /* opaque, device-resident */
+
+/* Levenberg–Marquardt controls.  Zero-initialise then call okx_default_opts(). */
+typedef struct okx_solve_opts {
+  int32_t max_iter;       /* LM iterations per problem (default 64)                        */
+  int32_t chain;          /* 0: every problem starts from its geometry's design state
+                             (independent problems, one wavefront each);
+                             1: reference semantics (solver.py:716,774): problems of one
+                             geometry form a sequential chain, step k starts at step k-1's
+                             solution; one wavefront walks one chain.                      */
+  int64_t steps_per_geometry; /* problems [g*S, (g+1)*S) use geometry g; 0 = single geometry */
+  double step_tol;        /* stop when max|dx| <= step_tol (mm, default 1e-11)             */
+  double grad_tol;        /* stop when max|J^T r| <= grad_tol (default 0: unused)          */
+  double lambda0;         /* initial damping relative to max diag(J^T J) (default 1e-6)    */
+  double residual_tolerance; /* informational: info.flags bit1 set if max|r| exceeds it
+                                (solver.py:735-747, default 1e-3)                          */
+} okx_solve_opts;
+
+/* Per-problem result, the device analogue of SolverInfo (solver.py:83-96). */
+typedef struct okx_info {
+  double max_residual;    /* max |r_i| at the returned state, reference row definitions    */
+  double cost;            /* 0.5 * sum r_i^2 at the returned state                         */
+  double last_step;       /* max|dx| of the last accepted step                             */
+  int32_t iterations;     /* LM iterations used                                            */
+  int32_t nfev;           /* residual evaluations (SolverInfo.nfev analogue)               */
+  int32_t flags;          /* bit0 converged, bit1 max_residual > residual_tolerance,
+                             bit2 damping failure / non-finite                             */
+  int32_t reserved;
+} okx_info;
+
+#define OKX_INFO_CONVERGED 1
+#define OKX_INFO_RESIDUAL_EXCEEDED 2
+#define OKX_INFO_FAILED 4
+
+int32_t okx_abi_version(void);
+const char* okx_last_error(void);
+void okx_default_opts(okx_solve_opts* opts);
+
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int32_t okx_device_count(void);
+
+/*
+ * Replaces ResidualComputer.__init__/build_jac_plan (solver.py:187-214, :281-500):
+ * validates the program, uploads it to the current HIP device and precomputes the
+ * sparsity plan.  Returns OKX_ERR_UNDERDETERMINED like validate_least_squares_dimensions
+ * (solver.py:99-121).
+ */
+int32_t okx_program_create(const okx_program_desc* desc, okx_program** out);
+void okx_program_destroy(okx_program* prog);
+
+/*
+ * Replaces solve_suspension_sweep (solver.py:654-776) for a batch of B sweep-step
+ * problems.  d_targets holds the ABSOLUTE target scalars (convert_targets_to_absolute,
+ * solver.py:584-627, is host work).  For a perturbed-geometry ensemble pass G geometries:
+ * d_geom_pos [G][P][3] design positions and d_geom_row_param [G][Mc][8] row parameters
+ * (see okx_rebind_design); pass NULL for both to use the program's own geometry.
+ * Outputs: d_out_pos [B][n_out][3] solved positions of the output points
+ * (SuspensionState.positions, state.py:119-126) and d_info [B].
+ */
+int32_t okx_solve_batch(okx_program* prog, const okx_solve_opts* opts, int64_t n_problems,
+                        const double* d_targets,          /* [B][T] */
+                        const double* d_geom_pos,         /* [G][P][3] or NULL */
+                        const double* d_geom_row_param,   /* [G][Mc][8] or NULL */
+                        double* d_out_pos,                /* [B][n_out][3] */
+                        okx_info* d_info,                 /* [B] */
+                        void* stream);
+
+/*
+ * Replaces ResidualComputer.compute / compute_jacobian (solver.py:226-275, :502-581)
+ * for B free-coordinate vectors: d_x [B][n] -> d_r [B][m], d_jac [B][m][n] (row-major,
+ * dense).  d_jac may be NULL.  Used by the parity tests (rung R1).
+ */
+int32_t okx_eval_batch(okx_program* prog, int64_t n_problems,
+                       const double* d_x,                 /* [B][n] */
+                       const double* d_targets,           /* [B][T] */
+                       double* d_r,                       /* [B][m] */
+                       double* d_jac,                     /* [B][m][n] or NULL */
+                       void* stream);
+
+/*
+ * Per-geometry problem emission on device (reference: topology constraints() computing
+ * design lengths/angles/volumes from the initial state, e.g. double_wishbone.py:259-308,
+ * track_rod.py:60-97, attachments.py:23-121).  d_hardpoints [G][P][3] holds design
+ * positions of the fixed and free points (derived entries are ignored and recomputed).
+ * Writes d_geom_pos [G][P][3] (derived points filled in) and d_geom_row_param [G][Mc][8]
+ * with every row's design-state target recomputed (distance L, angle alpha, triple
+ * product V and scale=|V|, point-on-line / line-pin anchor = the point's design position);
+ * rows whose parameters are authored constants (fixed axis, planes) are copied through.
+ */
+int32_t okx_rebind_design(okx_program* prog, int64_t n_geometries,
+                          const double* d_hardpoints,     /* [G][P][3] */
+                          double* d_geom_pos,             /* [G][P][3] */
+                          double* d_geom_row_param,       /* [G][Mc][8] */
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OKX_H */

@@ -1,0 +1,131 @@
+"""ctypes mirror of ``include/okx.h`` (struct layouts and the program descriptor)."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .program import ConstraintProgram
+
+ABI_VERSION = 1
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+class ProgramDesc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_points", C.c_int32),
+        ("n_free", C.c_int32),
+        ("n_derived", C.c_int32),
+        ("n_rows", C.c_int32),
+        ("n_targets", C.c_int32),
+        ("n_out", C.c_int32),
+        ("reserved", C.c_int32),
+        ("free_point", _i32p),
+        ("dop_type", _i32p),
+        ("dop_out", _i32p),
+        ("dop_pts", _i32p),
+        ("dop_param", _f64p),
+        ("row_type", _i32p),
+        ("row_pts", _i32p),
+        ("row_param", _f64p),
+        ("tgt_point", _i32p),
+        ("tgt_dir", _f64p),
+        ("out_point", _i32p),
+        ("design_pos", _f64p),
+    ]
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [
+        ("max_iter", C.c_int32),
+        ("chain", C.c_int32),
+        ("steps_per_geometry", C.c_int64),
+        ("step_tol", C.c_double),
+        ("grad_tol", C.c_double),
+        ("lambda0", C.c_double),
+        ("residual_tolerance", C.c_double),
+    ]
+
+
+class Info(C.Structure):
+    _fields_ = [
+        ("max_residual", C.c_double),
+        ("cost", C.c_double),
+        ("last_step", C.c_double),
+        ("iterations", C.c_int32),
+        ("nfev", C.c_int32),
+        ("flags", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+INFO_DTYPE = np.dtype(
+    [
+        ("max_residual", "<f8"),
+        ("cost", "<f8"),
+        ("last_step", "<f8"),
+        ("iterations", "<i4"),
+        ("nfev", "<i4"),
+        ("flags", "<i4"),
+        ("reserved", "<i4"),
+    ]
+)
+assert INFO_DTYPE.itemsize == C.sizeof(Info) == 40
+
+INFO_CONVERGED = 1
+INFO_RESIDUAL_EXCEEDED = 2
+INFO_FAILED = 4
+
+
+class HostProgram:
+    """Keeps the numpy buffers behind a ``ProgramDesc`` alive."""
+
+    def __init__(self, program: ConstraintProgram):
+        program.validate()
+        self.program = program
+        self._keep = []
+
+        def i32(a) -> _i32p:
+            arr = np.ascontiguousarray(a, dtype=np.int32).reshape(-1)
+            if arr.size == 0:
+                arr = np.zeros(1, dtype=np.int32)
+            self._keep.append(arr)
+            return arr.ctypes.data_as(_i32p)
+
+        def f64(a) -> _f64p:
+            arr = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+            if arr.size == 0:
+                arr = np.zeros(1, dtype=np.float64)
+            self._keep.append(arr)
+            return arr.ctypes.data_as(_f64p)
+
+        p = program
+        self.desc = ProgramDesc(
+            abi_version=ABI_VERSION,
+            n_points=p.n_points,
+            n_free=p.n_free,
+            n_derived=p.n_derived,
+            n_rows=p.n_rows,
+            n_targets=p.n_targets,
+            n_out=p.n_out,
+            reserved=0,
+            free_point=i32(p.free_point),
+            dop_type=i32(p.dop_type),
+            dop_out=i32(p.dop_out),
+            dop_pts=i32(p.dop_pts),
+            dop_param=f64(p.dop_param),
+            row_type=i32(p.row_type),
+            row_pts=i32(p.row_pts),
+            row_param=f64(p.row_param),
+            tgt_point=i32(p.tgt_point),
+            tgt_dir=f64(p.tgt_dir),
+            out_point=i32(p.out_point),
+            design_pos=f64(p.design_pos),
+        )
+
+    def byref(self):
+        return C.byref(self.desc)

@@ -1,0 +1,176 @@
+"""
+ctypes front end of the CPU oracle (``oracle/okx_oracle.c``).  TEST INFRASTRUCTURE ONLY:
+imported by ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg,
+never by ``open_kinematics_amd`` itself.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+from open_kinematics_amd._abi import HostProgram, ProgramDesc
+from open_kinematics_amd.program import ConstraintProgram
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libokx_oracle.so")
+_f64p = C.POINTER(C.c_double)
+
+
+class OracleOpts(C.Structure):
+    _fields_ = [
+        ("ftol", C.c_double),
+        ("xtol", C.c_double),
+        ("gtol", C.c_double),
+        ("residual_tolerance", C.c_double),
+        ("max_nfev", C.c_int32),
+        ("warm_start", C.c_int32),
+    ]
+
+
+ORACLE_INFO_DTYPE = np.dtype(
+    [
+        ("max_residual", "<f8"),
+        ("nfev", "<i4"),
+        ("njev", "<i4"),
+        ("minpack_info", "<i4"),
+        ("success", "<i4"),
+    ]
+)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (also called from ``__graft_entry__.build``)."""
+    src = os.path.join(_HERE, "okx_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "okx.h")
+    stale = (
+        force
+        or not os.path.exists(_LIB_PATH)
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    )
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libokx_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.okx_oracle_eval.restype = C.c_int32
+        _lib.okx_oracle_eval.argtypes = [C.POINTER(ProgramDesc), C.c_int64, _f64p, _f64p, _f64p, _f64p]
+        _lib.okx_oracle_positions.restype = C.c_int32
+        _lib.okx_oracle_positions.argtypes = [C.POINTER(ProgramDesc), _f64p, _f64p]
+        _lib.okx_oracle_sweep.restype = C.c_int32
+        _lib.okx_oracle_sweep.argtypes = [
+            C.POINTER(ProgramDesc),
+            C.POINTER(OracleOpts),
+            C.c_int64,
+            _f64p,
+            _f64p,
+            _f64p,
+            _f64p,
+            C.c_void_p,
+        ]
+        _lib.okx_oracle_rebind.restype = C.c_int32
+        _lib.okx_oracle_rebind.argtypes = [C.POINTER(ProgramDesc), _f64p, _f64p, _f64p]
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_f64p)
+
+
+@dataclass
+class SweepResult:
+    positions: np.ndarray  # [S, n_out, 3]
+    x: np.ndarray  # [S, n]
+    info: np.ndarray  # structured ORACLE_INFO_DTYPE [S]
+    first_failed_step: int  # -1 if all accepted
+
+
+class Oracle:
+    """CPU oracle bound to one constraint program."""
+
+    def __init__(self, program: ConstraintProgram):
+        self.program = program
+        self.host = HostProgram(program)
+
+    def eval(self, x: np.ndarray, targets: np.ndarray, jac: bool = True):
+        p = self.program
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+        b = x.shape[0]
+        t = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(targets), (b, p.n_targets)), dtype=np.float64)
+        r = np.empty((b, p.n_residuals))
+        j = np.empty((b, p.n_residuals, p.n_vars)) if jac else None
+        rc = lib().okx_oracle_eval(self.host.byref(), b, _p(x), _p(t), _p(r), _p(j) if jac else None)
+        if rc != 0:
+            raise RuntimeError(f"okx_oracle_eval failed: {rc}")
+        return r, j
+
+    def positions(self, x: np.ndarray) -> np.ndarray:
+        p = self.program
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty((p.n_points, 3))
+        rc = lib().okx_oracle_positions(self.host.byref(), _p(x), _p(out))
+        if rc != 0:
+            raise RuntimeError(f"okx_oracle_positions failed: {rc}")
+        return out
+
+    def sweep(
+        self,
+        targets: np.ndarray,
+        ftol: float = 1e-5,
+        xtol: float = 1e-9,
+        gtol: float = 1e-9,
+        residual_tolerance: float = 1e-3,
+        warm_start: bool = True,
+        max_nfev: int = 0,
+        x_start: np.ndarray | None = None,
+    ) -> SweepResult:
+        """``solve_suspension_sweep`` (reference ``solver.py:654-776``) on absolute targets."""
+        p = self.program
+        t = np.ascontiguousarray(targets, dtype=np.float64).reshape(-1, p.n_targets)
+        s = t.shape[0]
+        pos = np.empty((s, p.n_out, 3))
+        xs = np.empty((s, p.n_vars))
+        info = np.zeros(s, dtype=ORACLE_INFO_DTYPE)
+        opts = OracleOpts(ftol, xtol, gtol, residual_tolerance, max_nfev, 1 if warm_start else 0)
+        x0 = None
+        if x_start is not None:
+            x0 = np.ascontiguousarray(x_start, dtype=np.float64)
+        rc = lib().okx_oracle_sweep(
+            self.host.byref(),
+            C.byref(opts),
+            s,
+            _p(t),
+            _p(x0) if x0 is not None else None,
+            _p(pos),
+            _p(xs),
+            info.ctypes.data_as(C.c_void_p),
+        )
+        if rc < 0:
+            if rc == -3:
+                raise ValueError(
+                    f"System is underdetermined (n_vars={p.n_vars} > m_res={p.n_residuals})."
+                )
+            raise RuntimeError(f"okx_oracle_sweep failed: {rc}")
+        return SweepResult(pos, xs, info, rc - 1)
+
+    def rebind(self, hardpoints: np.ndarray):
+        p = self.program
+        hp = np.ascontiguousarray(hardpoints, dtype=np.float64).reshape(p.n_points, 3)
+        pos = np.empty((p.n_points, 3))
+        rp = np.empty((p.n_rows, 8))
+        rc = lib().okx_oracle_rebind(self.host.byref(), _p(hp), _p(pos), _p(rp))
+        if rc != 0:
+            raise RuntimeError(f"okx_oracle_rebind failed: {rc}")
+        return pos, rp

@@ -1,0 +1,49 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name: str):
+    """(arrays, softnorm ConstraintProgram) of one committed fixture."""
+    from open_kinematics_amd.program import ConstraintProgram
+
+    arrays = dict(np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=False))
+    program = ConstraintProgram.from_arrays(arrays, prefix="prog_")
+    return arrays, program
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name: str):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+
+    return get
+
+
+STEERED = ["c1_dw_corner", "c2_dw_subset", "c3_axle_grid", "c4_macpherson_grid", "e2e_sweep"]
+UNSTEERED = ["u_dw_corner", "u_macpherson", "u_axle"]
+
+
+def gpu_available() -> bool:
+    try:
+        from open_kinematics_amd import _lib
+
+        return _lib.device_count() > 0
+    except Exception:
+        return False
