@@ -32,7 +32,7 @@ extern "C" {
 #define OKX_ABI_VERSION 1
 
 /* Hard limits of one problem (one wavefront owns one problem). */
-#define OKX_MAX_VARS 96      /* n = 3 * free points                                  */
+#define OKX_MAX_VARS 63      /* n = 3 * free points (one lane per variable)          */
 #define OKX_MAX_ROWS 128     /* m = constraint rows + target rows                    */
 #define OKX_MAX_POINTS 96    /* fixed + free + derived                               */
 #define OKX_MAX_TARGETS 8

@@ -1,0 +1,106 @@
+"""
+Loader of ``libokx.so`` (HIP kernels + C-ABI, ``include/okx.h``).
+
+The product path has no CPU fallback: if the library is missing or no GPU is visible the
+solve entry points raise ``RuntimeError``.  ``torch`` is imported first so that the
+library binds to the same HIP runtime (same ``libamdhip64.so.7`` SONAME) that owns torch's
+device allocations and streams.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from ._abi import Info, ProgramDesc, SolveOpts
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libokx.so")
+
+EXPORTS = (
+    "okx_abi_version",
+    "okx_last_error",
+    "okx_default_opts",
+    "okx_device_count",
+    "okx_program_create",
+    "okx_program_destroy",
+    "okx_solve_batch",
+    "okx_eval_batch",
+    "okx_rebind_design",
+)
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C open_kinematics_amd/csrc)"
+        )
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; see module docstring)
+    except Exception:  # pragma: no cover - torch is part of the image
+        pass
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+    lib.okx_abi_version.restype = i32
+    lib.okx_last_error.restype = C.c_char_p
+    lib.okx_default_opts.argtypes = [C.POINTER(SolveOpts)]
+    lib.okx_default_opts.restype = None
+    lib.okx_device_count.restype = i32
+    lib.okx_program_create.argtypes = [C.POINTER(ProgramDesc), C.POINTER(vp)]
+    lib.okx_program_create.restype = i32
+    lib.okx_program_destroy.argtypes = [vp]
+    lib.okx_program_destroy.restype = None
+    lib.okx_solve_batch.argtypes = [vp, C.POINTER(SolveOpts), i64, vp, vp, vp, vp, vp, vp]
+    lib.okx_solve_batch.restype = i32
+    lib.okx_eval_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    lib.okx_eval_batch.restype = i32
+    lib.okx_debug_normal_equations.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp]
+    lib.okx_debug_normal_equations.restype = i32
+    lib.okx_rebind_design.argtypes = [vp, i64, vp, vp, vp, vp]
+    lib.okx_rebind_design.restype = i32
+    lib.okx_plan_stats.argtypes = [C.POINTER(ProgramDesc), C.POINTER(i32)]
+    lib.okx_plan_stats.restype = i32
+    if lib.okx_abi_version() != 1:
+        raise RuntimeError("libokx.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().okx_last_error().decode("utf-8", "replace")
+
+
+def device_count() -> int:
+    return int(load().okx_device_count())
+
+
+def check(rc: int, what: str) -> None:
+    """Map okx_status to the reference's exception types (solver.py:116-121)."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == -3:
+        raise ValueError(msg)
+    if rc in (-1, -2):
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+__all__ = ["load", "build", "check", "device_count", "last_error", "Info", "SolveOpts", "LIB_PATH", "EXPORTS"]

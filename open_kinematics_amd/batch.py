@@ -1,0 +1,184 @@
+"""
+Batched device solve on PyTorch-ROCm tensors: the host side of ``okx_solve_batch``.
+
+``DeviceProgram`` uploads one constraint program to the current GPU and exposes
+``solve`` (B independent sweep-step problems, or geometry-major chains), ``eval``
+(residual + dense Jacobian, for parity tests) and ``rebind`` (per-geometry design targets
+for perturbed-hardpoint ensembles).  Tensors stay in HBM; nothing here copies to the host.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._abi import INFO_CONVERGED, INFO_DTYPE, INFO_FAILED, INFO_RESIDUAL_EXCEEDED, HostProgram, SolveOpts
+from .program import ConstraintProgram
+
+
+@dataclass
+class BatchResult:
+    positions: torch.Tensor  # [B, n_out, 3] float64, device
+    info_raw: torch.Tensor  # [B, 40] uint8, device (okx_info records)
+
+    def info(self) -> np.ndarray:
+        """Host copy of the per-problem records as a structured array (``_abi.INFO_DTYPE``)."""
+        return self.info_raw.cpu().numpy().view(INFO_DTYPE).reshape(-1)
+
+    @staticmethod
+    def converged(info: np.ndarray) -> np.ndarray:
+        return (info["flags"] & INFO_CONVERGED) != 0
+
+    @staticmethod
+    def accepted(info: np.ndarray) -> np.ndarray:
+        """Converged and within the residual tolerance (reference ``solver.py:726-747``)."""
+        f = info["flags"]
+        return ((f & INFO_CONVERGED) != 0) & ((f & (INFO_RESIDUAL_EXCEEDED | INFO_FAILED)) == 0)
+
+
+def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _as_f64(t, device) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t, dtype=np.float64))
+    return t.to(device=device, dtype=torch.float64).contiguous()
+
+
+class DeviceProgram:
+    """A constraint program resident on one GPU."""
+
+    def __init__(self, program: ConstraintProgram, device: torch.device | str | None = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "open_kinematics_amd needs a ROCm GPU: torch.cuda.is_available() is False "
+                "(there is no CPU fallback for the solve path)"
+            )
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.program = program
+        self.host = HostProgram(program)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.okx_program_create(self.host.byref(), C.byref(handle)), "okx_program_create")
+        self._handle = handle
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self.lib.okx_program_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def default_opts(self) -> SolveOpts:
+        opts = SolveOpts()
+        self.lib.okx_default_opts(C.byref(opts))
+        return opts
+
+    def solve(
+        self,
+        targets,
+        *,
+        geom_pos: torch.Tensor | None = None,
+        geom_row_param: torch.Tensor | None = None,
+        steps_per_geometry: int = 0,
+        chain: bool = False,
+        max_iter: int | None = None,
+        step_tol: float | None = None,
+        lambda0: float | None = None,
+        residual_tolerance: float | None = None,
+        out: torch.Tensor | None = None,
+        info_out: torch.Tensor | None = None,
+    ) -> BatchResult:
+        """Solve ``B`` problems; ``targets`` is ``[B, T]`` of absolute target scalars."""
+        p = self.program
+        targets = _as_f64(targets, self.device).reshape(-1, max(p.n_targets, 1))
+        b = targets.shape[0] if p.n_targets > 0 else int(targets.numel())
+        opts = self.default_opts()
+        opts.chain = 1 if chain else 0
+        opts.steps_per_geometry = int(steps_per_geometry)
+        if max_iter is not None:
+            opts.max_iter = int(max_iter)
+        if step_tol is not None:
+            opts.step_tol = float(step_tol)
+        if lambda0 is not None:
+            opts.lambda0 = float(lambda0)
+        if residual_tolerance is not None:
+            opts.residual_tolerance = float(residual_tolerance)
+        if geom_pos is not None:
+            geom_pos = _as_f64(geom_pos, self.device)
+            geom_row_param = _as_f64(geom_row_param, self.device)
+            g = geom_pos.shape[0]
+            if geom_pos.shape[1:] != (p.n_points, 3) or geom_row_param.shape != (g, p.n_rows, 8):
+                raise ValueError("geometry table has the wrong shape")
+            if steps_per_geometry <= 0 or g * steps_per_geometry != b:
+                raise ValueError("B must equal n_geometries * steps_per_geometry")
+        if out is None:
+            out = torch.empty((b, p.n_out, 3), dtype=torch.float64, device=self.device)
+        if info_out is None:
+            info_out = torch.empty((b, INFO_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_solve_batch(
+                self._handle, C.byref(opts), b, _ptr(targets), _ptr(geom_pos), _ptr(geom_row_param),
+                _ptr(out), _ptr(info_out), C.c_void_p(stream),
+            )
+        _lib.check(rc, "okx_solve_batch")
+        return BatchResult(out, info_out)
+
+    def eval(self, x, targets, jac: bool = True):
+        """Residuals ``[B, m]`` and dense Jacobians ``[B, m, n]`` at free vectors ``x [B, n]``."""
+        p = self.program
+        x = _as_f64(x, self.device).reshape(-1, p.n_vars)
+        b = x.shape[0]
+        targets = _as_f64(targets, self.device).reshape(-1, max(p.n_targets, 1))
+        if targets.shape[0] == 1 and b > 1:
+            targets = targets.expand(b, -1).contiguous()
+        r = torch.empty((b, p.n_residuals), dtype=torch.float64, device=self.device)
+        j = torch.empty((b, p.n_residuals, p.n_vars), dtype=torch.float64, device=self.device) if jac else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_eval_batch(self._handle, b, _ptr(x), _ptr(targets), _ptr(r), _ptr(j), C.c_void_p(stream))
+        _lib.check(rc, "okx_eval_batch")
+        return r, j
+
+    def normal_equations(self, x, targets):
+        """Test hook: ``J^T J [B, n, n]`` and ``J^T r [B, n]`` exactly as the solver forms them."""
+        p = self.program
+        x = _as_f64(x, self.device).reshape(-1, p.n_vars)
+        b = x.shape[0]
+        targets = _as_f64(targets, self.device).reshape(-1, max(p.n_targets, 1))
+        if targets.shape[0] == 1 and b > 1:
+            targets = targets.expand(b, -1).contiguous()
+        r = torch.empty((b, p.n_residuals), dtype=torch.float64, device=self.device)
+        ata = torch.empty((b, p.n_vars, p.n_vars), dtype=torch.float64, device=self.device)
+        atr = torch.empty((b, p.n_vars), dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_debug_normal_equations(
+                self._handle, b, _ptr(x), _ptr(targets), _ptr(r), _ptr(ata), _ptr(atr), C.c_void_p(stream)
+            )
+        _lib.check(rc, "okx_debug_normal_equations")
+        return r, ata, atr
+
+    def rebind(self, hardpoints):
+        """Per-geometry design positions ``[G, P, 3]`` and row parameters ``[G, Mc, 8]``."""
+        p = self.program
+        hp = _as_f64(hardpoints, self.device).reshape(-1, p.n_points, 3)
+        g = hp.shape[0]
+        pos = torch.empty_like(hp)
+        rq = torch.empty((g, p.n_rows, 8), dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_rebind_design(self._handle, g, _ptr(hp), _ptr(pos), _ptr(rq), C.c_void_p(stream))
+        _lib.check(rc, "okx_rebind_design")
+        return pos, rq

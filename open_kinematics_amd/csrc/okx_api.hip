@@ -1,0 +1,247 @@
+// okx_api.hip — the C-ABI of include/okx.h on top of the gfx950 kernels.
+// Thin by design: argument validation, program upload, launch geometry, error strings.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "okx_kernels.hip"
+
+struct okx_program {
+  okx::DevProgram host;        // host copy (dimensions, launch sizing)
+  okx::DevProgram* dev;        // device copy
+  int device;
+  int n_cu;
+  size_t lds_bytes;
+  int blocks_per_cu;
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(OKX_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));         \
+  } while (0)
+
+int grid_for(const okx_program* p, long long units) {
+  long long cap = (long long)p->n_cu * p->blocks_per_cu;
+  if (cap < 1) cap = 1;
+  return (int)(units < cap ? (units < 1 ? 1 : units) : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t okx_abi_version(void) { return OKX_ABI_VERSION; }
+
+const char* okx_last_error(void) { return g_err; }
+
+void okx_default_opts(okx_solve_opts* o) {
+  if (!o) return;
+  o->max_iter = 64;
+  o->chain = 0;
+  o->steps_per_geometry = 0;
+  o->step_tol = 1e-11;
+  o->grad_tol = 0.0;
+  o->lambda0 = 1e-6;
+  o->residual_tolerance = 1e-3;
+}
+
+int32_t okx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
+  if (!out) return fail(OKX_ERR_INVALID, "out is null");
+  *out = nullptr;
+  okx_program* p = new (std::nothrow) okx_program;
+  if (!p) return fail(OKX_ERR_ALLOC, "out of host memory");
+  std::memset(p, 0, sizeof(*p));
+  int rc = okx::build_dev_program(desc, &p->host, g_err, (int)sizeof(g_err));
+  if (rc != OKX_OK) {
+    delete p;
+    return rc;
+  }
+  p->host.lds_doubles = okx::lds_doubles(p->host);
+  p->lds_bytes = sizeof(double) * (size_t)p->host.lds_doubles;
+  if (p->lds_bytes > 160 * 1024) {
+    delete p;
+    return fail(OKX_ERR_LIMIT, "problem needs %zu bytes of LDS (max 163840)", p->lds_bytes);
+  }
+  hipError_t e = hipGetDevice(&p->device);
+  if (e != hipSuccess) {
+    delete p;
+    return fail(OKX_ERR_DEVICE, "hipGetDevice failed: %s (no GPU?)", hipGetErrorString(e));
+  }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, p->device);
+  if (e != hipSuccess) {
+    delete p;
+    return fail(OKX_ERR_DEVICE, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+  }
+  p->n_cu = prop.multiProcessorCount;
+  e = hipMalloc((void**)&p->dev, sizeof(okx::DevProgram));
+  if (e != hipSuccess) {
+    delete p;
+    return fail(OKX_ERR_DEVICE, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  e = hipMemcpy(p->dev, &p->host, sizeof(okx::DevProgram), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(p->dev);
+    delete p;
+    return fail(OKX_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(e));
+  }
+  // >64 KiB of dynamic LDS needs the opt-in attribute
+  (void)hipFuncSetAttribute((const void*)okx::okx_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)p->lds_bytes);
+  (void)hipFuncSetAttribute((const void*)okx::okx_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)p->lds_bytes);
+  (void)hipFuncSetAttribute((const void*)okx::okx_rebind_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                      (int)p->lds_bytes);
+  int occ = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, okx::okx_solve_kernel, okx::kWave,
+                                                   p->lds_bytes);
+  if (e != hipSuccess || occ < 1) occ = 1;
+  if (occ > 32) occ = 32;
+  p->blocks_per_cu = occ;
+  *out = p;
+  return OKX_OK;
+}
+
+void okx_program_destroy(okx_program* p) {
+  if (!p) return;
+  if (p->dev) (void)hipFree(p->dev);
+  delete p;
+}
+
+int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_problems,
+                        const double* d_targets, const double* d_geom_pos,
+                        const double* d_geom_row_param, double* d_out_pos, okx_info* d_info,
+                        void* stream) {
+  if (!p || !opts) return fail(OKX_ERR_INVALID, "null program or options");
+  if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
+  if (n_problems == 0) return OKX_OK;
+  if (!d_out_pos || !d_info) return fail(OKX_ERR_INVALID, "null output pointer");
+  if (p->host.n_targets > 0 && !d_targets) return fail(OKX_ERR_INVALID, "null targets");
+  if ((d_geom_pos == nullptr) != (d_geom_row_param == nullptr))
+    return fail(OKX_ERR_INVALID, "geometry positions and row parameters must be given together");
+  const long long spg = opts->steps_per_geometry;
+  if (spg < 0 || (spg > 0 && n_problems % spg != 0))
+    return fail(OKX_ERR_INVALID, "n_problems must be a multiple of steps_per_geometry");
+  if (d_geom_pos && spg == 0 )
+    return fail(OKX_ERR_INVALID, "a geometry table needs steps_per_geometry > 0");
+  if (opts->max_iter < 1) return fail(OKX_ERR_INVALID, "max_iter must be >= 1");
+  okx::SolveArgs a;
+  a.targets = d_targets;
+  a.geom_pos = d_geom_pos;
+  a.geom_row_param = d_geom_row_param;
+  a.out_pos = d_out_pos;
+  a.info = d_info;
+  a.n_problems = n_problems;
+  a.steps_per_geometry = spg;
+  a.max_iter = opts->max_iter;
+  a.chain = opts->chain ? 1 : 0;
+  a.step_tol = opts->step_tol;
+  a.grad_tol = opts->grad_tol;
+  a.lambda0 = opts->lambda0;
+  a.residual_tolerance = opts->residual_tolerance;
+  const long long units = a.chain ? (spg > 0 ? n_problems / spg : 1) : n_problems;
+  const int grid = grid_for(p, units);
+  hipLaunchKernelGGL(okx::okx_solve_kernel, dim3(grid), dim3(okx::kWave), p->lds_bytes,
+                     (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
+  HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
+int32_t okx_eval_batch(okx_program* p, int64_t n_problems, const double* d_x,
+                       const double* d_targets, double* d_r, double* d_jac, void* stream) {
+  if (!p) return fail(OKX_ERR_INVALID, "null program");
+  if (n_problems <= 0) return n_problems == 0 ? OKX_OK : fail(OKX_ERR_INVALID, "negative count");
+  if (!d_x || !d_r) return fail(OKX_ERR_INVALID, "null pointer");
+  okx::EvalArgs a;
+  a.x = d_x;
+  a.targets = d_targets;
+  a.r = d_r;
+  a.jac = d_jac;
+  a.ata = nullptr;
+  a.atr = nullptr;
+  a.n_problems = n_problems;
+  hipLaunchKernelGGL(okx::okx_eval_kernel, dim3(grid_for(p, n_problems)), dim3(okx::kWave),
+                     p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
+  HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
+/* Test hook (not part of the reference boundary): J^T J and J^T r as the solver forms them. */
+int32_t okx_debug_normal_equations(okx_program* p, int64_t n_problems, const double* d_x,
+                                   const double* d_targets, double* d_r, double* d_ata,
+                                   double* d_atr, void* stream) {
+  if (!p || !d_x || !d_r) return fail(OKX_ERR_INVALID, "null pointer");
+  if (n_problems <= 0) return OKX_OK;
+  okx::EvalArgs a;
+  a.x = d_x;
+  a.targets = d_targets;
+  a.r = d_r;
+  a.jac = nullptr;
+  a.ata = d_ata;
+  a.atr = d_atr;
+  a.n_problems = n_problems;
+  hipLaunchKernelGGL(okx::okx_eval_kernel, dim3(grid_for(p, n_problems)), dim3(okx::kWave),
+                     p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
+  HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
+int32_t okx_rebind_design(okx_program* p, int64_t n_geometries, const double* d_hardpoints,
+                          double* d_geom_pos, double* d_geom_row_param, void* stream) {
+  if (!p) return fail(OKX_ERR_INVALID, "null program");
+  if (n_geometries <= 0) return n_geometries == 0 ? OKX_OK : fail(OKX_ERR_INVALID, "negative count");
+  if (!d_hardpoints || !d_geom_pos || !d_geom_row_param) return fail(OKX_ERR_INVALID, "null pointer");
+  okx::RebindArgs a;
+  a.hardpoints = d_hardpoints;
+  a.geom_pos = d_geom_pos;
+  a.geom_row_param = d_geom_row_param;
+  a.n_geometries = n_geometries;
+  hipLaunchKernelGGL(okx::okx_rebind_kernel, dim3(grid_for(p, n_geometries)), dim3(okx::kWave),
+                     p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
+  HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
+/* Plan introspection for CPU-side tests: fills counts without touching a device. */
+int32_t okx_plan_stats(const okx_program_desc* desc, int32_t* out8) {
+  okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
+  if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
+  int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
+  if (rc == OKX_OK && out8) {
+    out8[0] = tmp->n;
+    out8[1] = tmp->m;
+    out8[2] = tmp->n_pairs;
+    out8[3] = tmp->pair_start[tmp->n_pairs];
+    out8[4] = tmp->n_active;
+    out8[5] = tmp->js_stride;
+    out8[6] = tmp->lda;
+    out8[7] = okx::lds_doubles(*tmp) * 8;
+  }
+  delete tmp;
+  return rc;
+}
+
+}  // extern "C"

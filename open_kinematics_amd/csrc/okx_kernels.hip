@@ -1,0 +1,858 @@
+// okx_kernels.hip — hand-written gfx950 (CDNA4) kernels of the batched constraint solver.
+//
+// Execution model: ONE WAVEFRONT (64 lanes) OWNS ONE SWEEP-STEP PROBLEM, one wavefront per
+// workgroup, persistent workgroups striding over the batch.  Everything a problem needs
+// between its first and last Levenberg-Marquardt iteration lives in that workgroup's LDS
+// slice (positions, block-sparse Jacobian, n x n normal matrix) or in lane registers
+// (lane j owns variable j: x_j, g_j, dx_j); HBM is touched only to read the targets
+// (8*T bytes) and to write the solved points (24*n_out bytes) and the info record.
+//
+//   rows        lane i evaluates constraint row i (and i+64): residual + partials
+//               (reference constraints.py / jacobians.py), chain rule through derived
+//               points with closed-form 3x3 blocks (reference manager.py:271-324 uses
+//               dual numbers), scattered into a block-sparse row (<= 6 blocks of 3).
+//   normal eq.  J^T J and J^T r from host-built contribution plans (okx_plan.cpp): only
+//               structurally non-zero 3x3 blocks are formed.
+//   solve       wavefront-cooperative Cholesky of (J^T J + lambda I) in LDS, lane i owns
+//               row i; triangular solves broadcast the pivot unknown with v_readlane.
+//   LM          Nielsen gain-ratio damping; accept/reject decided uniformly by the wave.
+//
+// No MFMA: systems are tens of unknowns, fp64, block-sparse — see DESIGN.md §5.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "okx_plan.hpp"
+
+namespace okx {
+
+#define OKX_EPS_SQ 1e-12
+#define OKX_EPS 1e-6
+
+struct SolveArgs {
+  const double* targets;         // [B][T]
+  const double* geom_pos;        // [G][P][3] or null
+  const double* geom_row_param;  // [G][Mc][8] or null
+  double* out_pos;               // [B][n_out][3]
+  okx_info* info;                // [B]
+  long long n_problems;
+  long long steps_per_geometry;  // 0: single geometry
+  int max_iter;
+  int chain;
+  double step_tol, grad_tol, lambda0, residual_tolerance;
+};
+
+// ------------------------------------------------------------------------------------
+// wave-level helpers
+// ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Broadcast lane `k`'s value; k must be wave-uniform.
+__device__ __forceinline__ double wave_bcast(double v, int k) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, k);
+  hi = __builtin_amdgcn_readlane(hi, k);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+__device__ __forceinline__ double sel3(int r, double a, double b, double c) {
+  return r == 0 ? a : (r == 1 ? b : c);
+}
+
+__device__ __forceinline__ double softnorm(double s) { return sqrt(s + OKX_EPS_SQ) - OKX_EPS; }
+
+struct V3 {
+  double x, y, z;
+};
+__device__ __forceinline__ V3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// ------------------------------------------------------------------------------------
+// LDS carve-up (offsets in doubles; sizes from DevProgram)
+// ------------------------------------------------------------------------------------
+
+struct Lds {
+  double* pos;    // [P][3]
+  double* rowq;   // [m][8]   row parameters of the current geometry
+  double* dblk;   // [n_active][kDepMax][3][3]
+  double* js;     // [2][m][js_stride]
+  double* rb;     // [2][m]
+  double* A;      // [n][lda]  strict upper: J^T J; lower + diag: Cholesky factor
+  double* dA;     // [n]       diag(J^T J)
+  double* tv;     // [T]       targets of the current problem
+};
+
+__host__ __device__ inline int lds_doubles(const DevProgram& P) {
+  int s = 0;
+  s += P.n_points * 3;
+  s += P.m * 8;
+  s += (P.n_active > 0 ? P.n_active : 1) * kDepMax * 9;
+  s += 2 * P.m * P.js_stride;
+  s += 2 * P.m;
+  s += P.n * P.lda;
+  s += P.n;
+  s += kMaxTargets;
+  return (s + 1) & ~1;
+}
+
+__device__ __forceinline__ Lds carve(double* base, const DevProgram* P) {
+  Lds S;
+  double* p = base;
+  S.pos = p;
+  p += P->n_points * 3;
+  S.rowq = p;
+  p += P->m * 8;
+  S.dblk = p;
+  p += (P->n_active > 0 ? P->n_active : 1) * kDepMax * 9;
+  S.js = p;
+  p += 2 * P->m * P->js_stride;
+  S.rb = p;
+  p += 2 * P->m;
+  S.A = p;
+  p += P->n * P->lda;
+  S.dA = p;
+  p += P->n;
+  S.tv = p;
+  return S;
+}
+
+// ------------------------------------------------------------------------------------
+// derived points
+// ------------------------------------------------------------------------------------
+
+// Position of one derived op (reference points/derived/definitions.py); uniform over lanes.
+__device__ __forceinline__ V3 dop_position(int type, const int* pts, double c, const double* pos,
+                                           V3* u_out, double* nrm_out, V3* a_out,
+                                           double* vn_out, double* ga_out) {
+  if (type == OKX_DOP_MIDPOINT) {  // definitions.py:76-89
+    V3 a = ld3(pos + 3 * pts[0]), b = ld3(pos + 3 * pts[1]);
+    return {a.x + (b.x - a.x) / 2, a.y + (b.y - a.y) / 2, a.z + (b.z - a.z) / 2};
+  }
+  if (type == OKX_DOP_ALONG) {  // definitions.py:24-33, :92-155
+    V3 base = ld3(pos + 3 * pts[0]);
+    V3 v = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[2]));
+    double nrm = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    V3 u = {v.x / nrm, v.y / nrm, v.z / nrm};
+    *u_out = u;
+    *nrm_out = nrm;
+    return {base.x + u.x * c, base.y + u.y * c, base.z + u.z * c};
+  }
+  // OKX_DOP_CONTACT_PATCH: definitions.py:36-73, :158-180
+  V3 wc = ld3(pos + 3 * pts[0]);
+  V3 v = sub(ld3(pos + 3 * pts[2]), ld3(pos + 3 * pts[1]));
+  double vn = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+  V3 a = {v.x / vn, v.y / vn, v.z / vn};
+  double ga = -a.z;  // (0,0,-1) . a
+  V3 wd = {-ga * a.x, -ga * a.y, -1.0 - ga * a.z};
+  double wn = sqrt(wd.x * wd.x + wd.y * wd.y + wd.z * wd.z);
+  V3 wu = {wd.x / wn, wd.y / wn, wd.z / wn};
+  *u_out = wu;
+  *nrm_out = wn;
+  *a_out = a;
+  *vn_out = vn;
+  *ga_out = ga;
+  return {wc.x + wu.x * c, wc.y + wu.y * c, wc.z + wu.z * c};
+}
+
+// Row r of the local 3x3 block d(out)/d(input s) of a derived op.
+__device__ __forceinline__ V3 dop_local_row(int type, int s, int r, double c, V3 u, double nrm,
+                                            V3 a, double vn, double ga) {
+  V3 e = {r == 0 ? 1.0 : 0.0, r == 1 ? 1.0 : 0.0, r == 2 ? 1.0 : 0.0};
+  if (type == OKX_DOP_MIDPOINT) return {0.5 * e.x, 0.5 * e.y, 0.5 * e.z};
+  if (type == OKX_DOP_ALONG) {
+    if (s == 0) return e;
+    // d normalize(v)/dv = (I - u u^T)/|v|, scaled by c; input 2 enters v with a minus sign
+    double ur = sel3(r, u.x, u.y, u.z);
+    double k = (s == 1 ? c : -c) / nrm;
+    return {k * (e.x - ur * u.x), k * (e.y - ur * u.y), k * (e.z - ur * u.z)};
+  }
+  // contact patch: input 0 = wheel centre (identity), 1 = axle inboard (-T), 2 = axle outboard (+T)
+  if (s == 0) return e;
+  // T = c * Nw * Wa * Na,  Nw = (I - wu wu^T)/wn (u,nrm hold wu,wn), Wa = a e_z^T - ga I,
+  // Na = (I - a a^T)/vn
+  double wr = sel3(r, u.x, u.y, u.z);
+  V3 nw = {(e.x - wr * u.x) / nrm, (e.y - wr * u.y) / nrm, (e.z - wr * u.z) / nrm};
+  double nwa = dot(nw, a);
+  V3 mrow = {-ga * nw.x, -ga * nw.y, nwa - ga * nw.z};  // M[r][q] = d_q2 (Nw_r.a) - ga Nw[r][q]
+  double ma = dot(mrow, a);
+  double k = (s == 2 ? c : -c) / vn;
+  return {k * (mrow.x - ma * a.x), k * (mrow.y - ma * a.y), k * (mrow.z - ma * a.z)};
+}
+
+// Evaluate the listed derived ops in order.  WITH_BLOCKS also fills the chain-rule blocks
+// d(out)/d(free block) of active ops: lane (je*9 + r*3 + col) computes one entry.
+template <bool WITH_BLOCKS>
+__device__ __forceinline__ void derived_update(const DevProgram* P, const Lds& S, int lane,
+                                               bool active_only) {
+  const int count = active_only ? P->n_active : P->n_derived;
+  for (int idx = 0; idx < count; ++idx) {
+    const int e = active_only ? P->active_op[idx] : idx;
+    const int type = P->dop_type[e];
+    const double c = P->dop_param[e];
+    V3 u = {0, 0, 0}, a = {0, 0, 0};
+    double nrm = 1.0, vn = 1.0, ga = 0.0;
+    V3 o = dop_position(type, P->dop_pts[e], c, S.pos, &u, &nrm, &a, &vn, &ga);
+    if (WITH_BLOCKS) {
+      const int act = P->dop_active[e];
+      const int nblk = P->dop_nblk[e];
+      const int je = lane / 9, rc = lane % 9, r = rc / 3, col = rc % 3;
+      if (act >= 0 && je < nblk) {
+        double val = 0.0;
+        const int nin = type == OKX_DOP_MIDPOINT ? 2 : 3;
+        for (int s = 0; s < nin; ++s) {
+          const PointRef ref = P->dop_in[e][s];
+          if (ref.kind() == kRefFixed) continue;
+          V3 row = dop_local_row(type, s, r, c, u, nrm, a, vn, ga);
+          if (ref.kind() == kRefFree) {
+            if (ref.slot() == je) val += sel3(col, row.x, row.y, row.z);
+          } else {
+            const double* src = S.dblk + P->dop_active[ref.src()] * (kDepMax * 9);
+            for (int js = 0; js < ref.nsrc(); ++js)
+              if (ref.map(js) == je) {
+                const double* B = src + js * 9;
+                val += row.x * B[0 + col] + row.y * B[3 + col] + row.z * B[6 + col];
+              }
+          }
+        }
+        S.dblk[act * (kDepMax * 9) + lane] = val;
+      }
+    }
+    wave_sync();  // inputs of this op were read by every lane before its output is written
+    if (lane < 3) S.pos[3 * P->dop_out[e] + lane] = sel3(lane, o.x, o.y, o.z);
+    wave_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// constraint rows
+// ------------------------------------------------------------------------------------
+
+// Residual and partial derivatives of one row (reference constraints.py / jacobians.py).
+// dp[3*s + k] = d r / d (coordinate k of the row's point slot s).
+template <bool WITH_J>
+__device__ __forceinline__ double row_eval(int type, const int* pts, const double* q,
+                                           const double* pos, const double* tv, double* dp) {
+#pragma unroll
+  for (int k = 0; k < 12; ++k) dp[k] = 0.0;
+  switch (type) {
+    case OKX_ROW_DISTANCE:
+    case OKX_ROW_SPHERICAL: {  // constraints.py:125-134,162-170; jacobians.py:35-51
+      V3 d = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[0]));
+      double s = d.x * d.x + d.y * d.y + d.z * d.z;
+      double root = sqrt(s + OKX_EPS_SQ);
+      if (WITH_J) {
+        double inv = 1.0 / root;
+        dp[0] = -d.x * inv, dp[1] = -d.y * inv, dp[2] = -d.z * inv;
+        dp[3] = d.x * inv, dp[4] = d.y * inv, dp[5] = d.z * inv;
+      }
+      double r = root - OKX_EPS;
+      return type == OKX_ROW_DISTANCE ? r - q[0] : r;
+    }
+    case OKX_ROW_ANGLE:
+    case OKX_ROW_THREE_POINT_ANGLE: {  // constraints.py:223-243,287-308; jacobians.py:55-188
+      V3 v1, v2;
+      if (type == OKX_ROW_ANGLE) {
+        v1 = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[0]));
+        v2 = sub(ld3(pos + 3 * pts[3]), ld3(pos + 3 * pts[2]));
+      } else {
+        v1 = sub(ld3(pos + 3 * pts[0]), ld3(pos + 3 * pts[1]));
+        v2 = sub(ld3(pos + 3 * pts[2]), ld3(pos + 3 * pts[1]));
+      }
+      V3 c = cross(v1, v2);
+      double c2 = c.x * c.x + c.y * c.y + c.z * c.z;
+      double t15 = OKX_EPS_SQ + c2;
+      double s = sqrt(t15);
+      double dt = dot(v1, v2);
+      if (WITH_J) {
+        double inv = 1.0 / (t15 + dt * dt);
+        double ka = dt * inv / s, kb = s * inv;
+        V3 w1 = cross(v2, c), w2 = cross(c, v1);
+        V3 g1 = {ka * w1.x - kb * v2.x, ka * w1.y - kb * v2.y, ka * w1.z - kb * v2.z};
+        V3 g2 = {ka * w2.x - kb * v1.x, ka * w2.y - kb * v1.y, ka * w2.z - kb * v1.z};
+        if (type == OKX_ROW_ANGLE) {
+          dp[0] = -g1.x, dp[1] = -g1.y, dp[2] = -g1.z;
+          dp[3] = g1.x, dp[4] = g1.y, dp[5] = g1.z;
+          dp[6] = -g2.x, dp[7] = -g2.y, dp[8] = -g2.z;
+          dp[9] = g2.x, dp[10] = g2.y, dp[11] = g2.z;
+        } else {
+          dp[0] = g1.x, dp[1] = g1.y, dp[2] = g1.z;
+          dp[3] = -g1.x - g2.x, dp[4] = -g1.y - g2.y, dp[5] = -g1.z - g2.z;
+          dp[6] = g2.x, dp[7] = g2.y, dp[8] = g2.z;
+        }
+      }
+      return atan2(s - OKX_EPS, dt) - q[0];
+    }
+    case OKX_ROW_VECTORS_PARALLEL: {  // constraints.py:351-371; jacobians.py:192-262
+      V3 v1 = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[0]));
+      V3 v2 = sub(ld3(pos + 3 * pts[3]), ld3(pos + 3 * pts[2]));
+      V3 c = cross(v1, v2);
+      double c2 = dot(c, c), n1 = dot(v1, v1), n2 = dot(v2, v2);
+      double sc = sqrt(OKX_EPS_SQ + c2), s1 = sqrt(OKX_EPS_SQ + n1), s2 = sqrt(OKX_EPS_SQ + n2);
+      if (WITH_J) {
+        V3 w1 = cross(v2, c), w2 = cross(c, v1);
+        double k26 = 1.0 / (s1 * s2 * sc), k19 = sc / (s2 * s1 * s1 * s1),
+               k31 = sc / (s1 * s2 * s2 * s2);
+        V3 g1 = {k26 * w1.x - k19 * v1.x, k26 * w1.y - k19 * v1.y, k26 * w1.z - k19 * v1.z};
+        V3 g2 = {k26 * w2.x - k31 * v2.x, k26 * w2.y - k31 * v2.y, k26 * w2.z - k31 * v2.z};
+        dp[0] = -g1.x, dp[1] = -g1.y, dp[2] = -g1.z, dp[3] = g1.x, dp[4] = g1.y, dp[5] = g1.z;
+        dp[6] = -g2.x, dp[7] = -g2.y, dp[8] = -g2.z, dp[9] = g2.x, dp[10] = g2.y, dp[11] = g2.z;
+      }
+      return (sc - OKX_EPS) / ((s1 - OKX_EPS) * (s2 - OKX_EPS));
+    }
+    case OKX_ROW_VECTORS_PERPENDICULAR: {  // constraints.py:414-429; jacobians.py:266-318
+      V3 v1 = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[0]));
+      V3 v2 = sub(ld3(pos + 3 * pts[3]), ld3(pos + 3 * pts[2]));
+      double n1 = dot(v1, v1), n2 = dot(v2, v2), dt = dot(v1, v2);
+      double s1 = sqrt(OKX_EPS_SQ + n1), s2 = sqrt(OKX_EPS_SQ + n2);
+      if (WITH_J) {
+        double k16 = 1.0 / (s1 * s2), k18 = dt / (s2 * s1 * s1 * s1),
+               k19 = dt / (s1 * s2 * s2 * s2);
+        V3 g1 = {k16 * v2.x - k18 * v1.x, k16 * v2.y - k18 * v1.y, k16 * v2.z - k18 * v1.z};
+        V3 g2 = {k16 * v1.x - k19 * v2.x, k16 * v1.y - k19 * v2.y, k16 * v1.z - k19 * v2.z};
+        dp[0] = -g1.x, dp[1] = -g1.y, dp[2] = -g1.z, dp[3] = g1.x, dp[4] = g1.y, dp[5] = g1.z;
+        dp[6] = -g2.x, dp[7] = -g2.y, dp[8] = -g2.z, dp[9] = g2.x, dp[10] = g2.y, dp[11] = g2.z;
+      }
+      return dt / ((s1 - OKX_EPS) * (s2 - OKX_EPS));
+    }
+    case OKX_ROW_EQUAL_DISTANCE: {  // constraints.py:466-477; jacobians.py:322-367
+      V3 d1 = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[0]));
+      V3 d2 = sub(ld3(pos + 3 * pts[3]), ld3(pos + 3 * pts[2]));
+      double r1 = sqrt(OKX_EPS_SQ + dot(d1, d1)), r2 = sqrt(OKX_EPS_SQ + dot(d2, d2));
+      if (WITH_J) {
+        double i1 = 1.0 / r1, i2 = 1.0 / r2;
+        dp[0] = -d1.x * i1, dp[1] = -d1.y * i1, dp[2] = -d1.z * i1;
+        dp[3] = d1.x * i1, dp[4] = d1.y * i1, dp[5] = d1.z * i1;
+        dp[6] = d2.x * i2, dp[7] = d2.y * i2, dp[8] = d2.z * i2;
+        dp[9] = -d2.x * i2, dp[10] = -d2.y * i2, dp[11] = -d2.z * i2;
+      }
+      return (r1 - OKX_EPS) - (r2 - OKX_EPS);
+    }
+    case OKX_ROW_FIXED_AXIS: {  // constraints.py:508-516; solver.py:407-416
+      int ax = (int)q[0];
+      if (WITH_J) dp[0] = ax == 0 ? 1.0 : 0.0, dp[1] = ax == 1 ? 1.0 : 0.0, dp[2] = ax == 2 ? 1.0 : 0.0;
+      V3 p = ld3(pos + 3 * pts[0]);
+      return sel3(ax, p.x, p.y, p.z) - q[1];
+    }
+    case OKX_ROW_POINT_ON_LINE:
+    case OKX_ROW_LINE_PIN: {  // constraints.py:560-576; jacobians.py:372-403; okx.h (pin)
+      V3 w = sub(ld3(pos + 3 * pts[0]), ld3(q));
+      V3 ld = ld3(q + 3);
+      V3 c = cross(w, ld);
+      if (type == OKX_ROW_POINT_ON_LINE) {
+        double c2 = dot(c, c);
+        double root = sqrt(OKX_EPS_SQ + c2);
+        if (WITH_J) {
+          double inv = 1.0 / root;
+          V3 g = cross(ld, c);
+          dp[0] = inv * g.x, dp[1] = inv * g.y, dp[2] = inv * g.z;
+        }
+        return root - OKX_EPS;
+      }
+      int comp = (int)q[6];
+      if (WITH_J) {
+        // c = w x ld: dc_x = (0, ld.z, -ld.y), dc_y = (-ld.z, 0, ld.x), dc_z = (ld.y, -ld.x, 0)
+        dp[0] = sel3(comp, 0.0, -ld.z, ld.y);
+        dp[1] = sel3(comp, ld.z, 0.0, -ld.x);
+        dp[2] = sel3(comp, -ld.y, ld.x, 0.0);
+      }
+      return sel3(comp, c.x, c.y, c.z);
+    }
+    case OKX_ROW_POINT_ON_PLANE: {  // constraints.py:616-627; solver.py:429-437
+      V3 w = sub(ld3(pos + 3 * pts[0]), ld3(q));
+      V3 nn = ld3(q + 3);
+      if (WITH_J) dp[0] = nn.x, dp[1] = nn.y, dp[2] = nn.z;
+      return dot(w, nn);
+    }
+    case OKX_ROW_MIDPOINT_ON_PLANE: {  // constraints.py:657-666; solver.py:439-448
+      V3 a = ld3(pos + 3 * pts[0]), b = ld3(pos + 3 * pts[1]);
+      V3 mid = {a.x + (b.x - a.x) / 2.0, a.y + (b.y - a.y) / 2.0, a.z + (b.z - a.z) / 2.0};
+      V3 nn = ld3(q + 3);
+      if (WITH_J) {
+        dp[0] = dp[3] = 0.5 * nn.x;
+        dp[1] = dp[4] = 0.5 * nn.y;
+        dp[2] = dp[5] = 0.5 * nn.z;
+      }
+      return dot(sub(mid, ld3(q)), nn);
+    }
+    case OKX_ROW_COPLANAR:
+    case OKX_ROW_SCALAR_TRIPLE: {  // constraints.py:698-709,731-733; jacobians.py:426-483
+      V3 p1 = ld3(pos + 3 * pts[0]);
+      V3 v1 = sub(ld3(pos + 3 * pts[1]), p1), v2 = sub(ld3(pos + 3 * pts[2]), p1),
+         v3 = sub(ld3(pos + 3 * pts[3]), p1);
+      V3 c23 = cross(v2, v3);
+      double vol = dot(v1, c23);
+      double sc = type == OKX_ROW_SCALAR_TRIPLE ? q[1] : 1.0;
+      if (WITH_J) {
+        V3 c31 = cross(v3, v1), c12 = cross(v1, v2);
+        dp[3] = c23.x / sc, dp[4] = c23.y / sc, dp[5] = c23.z / sc;
+        dp[6] = c31.x / sc, dp[7] = c31.y / sc, dp[8] = c31.z / sc;
+        dp[9] = c12.x / sc, dp[10] = c12.y / sc, dp[11] = c12.z / sc;
+        dp[0] = -(c23.x + c31.x + c12.x) / sc;
+        dp[1] = -(c23.y + c31.y + c12.y) / sc;
+        dp[2] = -(c23.z + c31.z + c12.z) / sc;
+      }
+      return type == OKX_ROW_SCALAR_TRIPLE ? (vol - q[0]) / q[1] : vol;
+    }
+    case kRowTarget: {  // solver.py:264-270, :560-579
+      V3 dir = ld3(q);
+      if (WITH_J) dp[0] = dir.x, dp[1] = dir.y, dp[2] = dir.z;
+      return dot(ld3(pos + 3 * pts[0]), dir) - tv[(int)q[3]];
+    }
+    default:
+      return 0.0;
+  }
+}
+
+// Evaluate row i into buffer `buf`: residual -> rb, block-sparse Jacobian row -> js.
+template <bool WITH_J>
+__device__ __forceinline__ double row_pass(const DevProgram* P, const Lds& S, int i, int buf) {
+  if (i >= P->m) return 0.0;
+  double dp[12];
+  const int type = P->row_type[i];
+  const int* pts = P->row_pts[i];
+  const double* q = S.rowq + 8 * i;
+  double r = row_eval<WITH_J>(type, pts, q, S.pos, S.tv, dp);
+  S.rb[buf * P->m + i] = r;
+  if (WITH_J) {
+    double* jr = S.js + (size_t)(buf * P->m + i) * P->js_stride;
+    const int nb3 = 3 * P->row_nblk[i];
+    for (int k = 0; k < nb3; ++k) jr[k] = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const PointRef ref = P->row_in[i][s];
+      if (ref.kind() == kRefFixed) continue;
+      const double d0 = dp[3 * s], d1 = dp[3 * s + 1], d2 = dp[3 * s + 2];
+      if (ref.kind() == kRefFree) {
+        double* dst = jr + 3 * ref.slot();
+        dst[0] += d0;
+        dst[1] += d1;
+        dst[2] += d2;
+      } else {  // point_partial @ block (solver.py:554-558)
+        const double* src = S.dblk + P->dop_active[ref.src()] * (kDepMax * 9);
+        for (int js = 0; js < ref.nsrc(); ++js) {
+          const double* B = src + 9 * js;
+          double* dst = jr + 3 * ref.map(js);
+          dst[0] += d0 * B[0] + d1 * B[3] + d2 * B[6];
+          dst[1] += d0 * B[1] + d1 * B[4] + d2 * B[7];
+          dst[2] += d0 * B[2] + d1 * B[5] + d2 * B[8];
+        }
+      }
+    }
+  }
+  return r;
+}
+
+// Full evaluation at the free vector held one-variable-per-lane in `x`.
+// Returns 0.5 * sum r^2 (uniform).
+template <bool WITH_J>
+__device__ __forceinline__ double evaluate(const DevProgram* P, const Lds& S, int lane, double x,
+                                           int xaddr, int buf) {
+  wave_sync();
+  if (lane < P->n) S.pos[xaddr] = x;
+  wave_sync();
+  derived_update<WITH_J>(P, S, lane, true);
+  double ss = 0.0;
+  for (int i = lane; i < P->m; i += kWave) {
+    const double r = row_pass<WITH_J>(P, S, i, buf);
+    ss += r * r;
+  }
+  wave_sync();
+  return 0.5 * wave_sum(ss);
+}
+
+// ------------------------------------------------------------------------------------
+// normal equations:  A (strict upper) + dA (diag) = J^T J,   g = J^T r   (lane j owns g_j)
+// ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double build_normal(const DevProgram* P, const Lds& S, int lane,
+                                               int buf) {
+  const double* js = S.js + (size_t)buf * P->m * P->js_stride;
+  const double* rb = S.rb + buf * P->m;
+  const int stride = P->js_stride;
+  for (int w = lane; w < P->n_items; w += kWave) {
+    const int pair = w / 9, e = w % 9, a = e / 3, b = e % 3;
+    const int bp = P->pair_p[pair], bq = P->pair_q[pair];
+    if (bp == bq && a > b) continue;
+    double acc = 0.0;
+    const int c1 = P->pair_start[pair + 1];
+    for (int c = P->pair_start[pair]; c < c1; ++c) {
+      const int pk = P->contrib[c];
+      const double* jr = js + (pk & 127) * stride;
+      acc += jr[3 * ((pk >> 7) & 7) + a] * jr[3 * ((pk >> 10) & 7) + b];
+    }
+    const int row = 3 * bp + a, col = 3 * bq + b;
+    if (row == col)
+      S.dA[row] = acc;
+    else
+      S.A[row * P->lda + col] = acc;
+  }
+  double g = 0.0;
+  if (lane < P->n) {
+    const int blk = lane / 3, a = lane % 3;
+    const int c1 = P->g_start[blk + 1];
+    for (int c = P->g_start[blk]; c < c1; ++c) {
+      const int pk = P->g_contrib[c];
+      const int row = pk & 127;
+      g += js[row * stride + 3 * ((pk >> 7) & 7) + a] * rb[row];
+    }
+  }
+  wave_sync();
+  return g;
+}
+
+// Cholesky of (A + lambda I) into the lower triangle (diag holds 1/L_kk).  Lane i owns row i.
+// Returns false (uniformly) when a pivot is not positive.
+__device__ __forceinline__ bool factorize(const DevProgram* P, const Lds& S, int lane,
+                                          double lambda) {
+  const int n = P->n, lda = P->lda;
+  double* A = S.A;
+  // lower <- upper (structural zeros of the factor's fill-in are reset here)
+  if (lane < n)
+    for (int j = 0; j < lane; ++j) A[lane * lda + j] = A[j * lda + lane];
+  wave_sync();
+  bool ok = true;
+  for (int k = 0; k < n; ++k) {
+    double s = 0.0;
+    if (lane >= k && lane < n) {
+      s = lane == k ? S.dA[k] + lambda : A[lane * lda + k];
+      const double* rowi = A + lane * lda;
+      const double* rowk = A + k * lda;
+      for (int j = 0; j < k; ++j) s -= rowi[j] * rowk[j];
+    }
+    const double pivot = wave_bcast(s, k);
+    if (!(pivot > 0.0)) {
+      ok = false;
+      break;
+    }
+    const double inv = 1.0 / sqrt(pivot);
+    if (lane > k && lane < n) A[lane * lda + k] = s * inv;
+    if (lane == k) A[k * lda + k] = inv;
+    wave_sync();
+  }
+  return ok;
+}
+
+// Solve (L L^T) d = rhs with lane i holding rhs_i; returns d_i in lane i.
+__device__ __forceinline__ double chol_solve(const DevProgram* P, const Lds& S, int lane,
+                                             double rhs) {
+  const int n = P->n, lda = P->lda;
+  const double* A = S.A;
+  const double invd = lane < n ? A[lane * lda + lane] : 0.0;
+  double b = lane < n ? rhs : 0.0;
+  for (int k = 0; k < n; ++k) {  // forward: L y = rhs
+    const double yk = wave_bcast(b * invd, k);
+    if (lane > k && lane < n) b -= A[lane * lda + k] * yk;
+    if (lane == k) b = yk;
+  }
+  for (int k = n - 1; k >= 0; --k) {  // backward: L^T d = y
+    const double dk = wave_bcast(b * invd, k);
+    if (lane < k) b -= A[k * lda + lane] * dk;
+    if (lane == k) b = dk;
+  }
+  return b;
+}
+
+// ------------------------------------------------------------------------------------
+// problem setup helpers
+// ------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void load_geometry(const DevProgram* P, const Lds& S, int lane,
+                                              const double* gpos, const double* gparam) {
+  wave_sync();
+  const double* src = gpos ? gpos : &P->design_pos[0][0];
+  for (int e = lane; e < 3 * P->n_points; e += kWave) S.pos[e] = src[e];
+  const int nc = 8 * P->n_crows;
+  if (gparam) {
+    for (int e = lane; e < nc; e += kWave) S.rowq[e] = gparam[e];
+  } else {
+    for (int e = lane; e < nc; e += kWave) S.rowq[e] = P->row_param[0][e];
+  }
+  for (int e = nc + lane; e < 8 * P->m; e += kWave) S.rowq[e] = P->row_param[0][e];
+  wave_sync();
+}
+
+// max |r_i| in the reference's row definitions: the three pin components of a line are
+// reported as the single softnorm point-on-line residual (constraints.py:560-576).
+__device__ __forceinline__ double reference_abs_residual(const DevProgram* P, const Lds& S,
+                                                         int i, int buf) {
+  double r = S.rb[buf * P->m + i];
+  if (P->row_type[i] == OKX_ROW_LINE_PIN) {
+    const double* q = S.rowq + 8 * i;
+    if ((int)q[6] != 0) return 0.0;
+    V3 c = cross(sub(ld3(S.pos + 3 * P->row_pts[i][0]), ld3(q)), ld3(q + 3));
+    r = softnorm(dot(c, c));
+  }
+  return fabs(r);
+}
+
+// ------------------------------------------------------------------------------------
+// the solve kernel
+// ------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __restrict__ P,
+                                                          SolveArgs args) {
+  extern __shared__ double lds_base[];
+  const int lane = threadIdx.x;
+  const Lds S = carve(lds_base, P);
+  const int n = P->n, m = P->m, T = P->n_targets;
+  const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
+
+  for (int e = lane; e < n * P->lda; e += kWave) S.A[e] = 0.0;
+
+  const long long spg = args.steps_per_geometry;
+  const long long n_units = args.chain ? (spg > 0 ? args.n_problems / spg : 1) : args.n_problems;
+  const long long unit_len = args.chain ? (spg > 0 ? spg : args.n_problems) : 1;
+  long long loaded_geom = -1;
+
+  for (long long unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    double x = 0.0;
+    for (long long step = 0; step < unit_len; ++step) {
+      const long long b = unit * unit_len + step;
+      const long long geom = spg > 0 ? b / spg : 0;
+      if (geom != loaded_geom) {
+        load_geometry(P, S, lane,
+                      args.geom_pos ? args.geom_pos + geom * 3 * P->n_points : nullptr,
+                      args.geom_row_param ? args.geom_row_param + geom * 8 * P->n_crows : nullptr);
+        loaded_geom = geom;
+        // a new geometry always restarts from its own design state
+        if (lane < n) x = S.pos[xaddr];
+      } else if (!args.chain || step == 0) {
+        const double* src = args.geom_pos ? args.geom_pos + geom * 3 * P->n_points
+                                          : &P->design_pos[0][0];
+        if (lane < n) x = src[xaddr];
+      }
+      wave_sync();
+      if (lane < T) S.tv[lane] = args.targets[b * T + lane];
+      wave_sync();
+
+      // Levenberg-Marquardt.  One evaluation site: `xt` is the point being evaluated,
+      // `x` the last accepted point; the first pass accepts unconditionally.
+      int cur = 1;  // buffer of the accepted point (first evaluation writes buffer 0)
+      int nfev = 0, iters = 0, flags = 0;
+      double F = 0.0, g = 0.0, dx = 0.0, lambda = 0.0, dmax = 0.0, nu = 2.0;
+      double last_step = 0.0, step_len = 0.0;
+      double xt = x;
+      bool first = true;
+      for (;;) {
+        const double Ft = evaluate<true>(P, S, lane, xt, xaddr, cur ^ 1);
+        ++nfev;
+        bool accept;
+        bool stop = false;
+        double rho = 1.0;
+        if (first) {
+          accept = true;
+        } else {
+          const double pred = 0.5 * wave_sum(lane < n ? dx * (lambda * dx - g) : 0.0);
+          const bool finite = Ft == Ft && step_len == step_len && Ft < 1e300;
+          const bool small = finite && step_len <= 1e-8 && Ft <= F * (1.0 + 1e-6) + 1e-28;
+          rho = (finite && pred > 0.0) ? (F - Ft) / pred : -1.0;
+          accept = rho > 1e-4 || small;
+          if (finite && step_len <= args.step_tol) {
+            accept = small;
+            flags |= OKX_INFO_CONVERGED;
+            stop = true;
+          }
+        }
+        if (accept) {
+          x = xt;
+          F = Ft;
+          cur ^= 1;
+          if (!first) last_step = step_len;
+          if (!stop) {
+            g = build_normal(P, S, lane, cur);
+            if (first) {
+              dmax = wave_max(lane < n ? S.dA[lane] : 0.0);
+              lambda = args.lambda0 * dmax;
+            } else if (rho > 1e-4) {
+              const double t = 2.0 * rho - 1.0;
+              lambda *= fmax(1.0 / 3.0, 1.0 - t * t * t);
+            }
+            nu = 2.0;
+            if (args.grad_tol > 0.0 && wave_max(lane < n ? fabs(g) : 0.0) <= args.grad_tol) {
+              flags |= OKX_INFO_CONVERGED;
+              stop = true;
+            }
+          }
+        } else if (!stop) {
+          lambda *= nu;
+          nu *= 2.0;
+        }
+        first = false;
+        if (stop) break;
+        if (iters >= args.max_iter) break;
+        ++iters;
+        // damped normal equations; enlarge lambda until the factorisation succeeds
+        bool ok = false;
+        for (int tries = 0; tries < 60; ++tries) {
+          if (!(lambda < 1e30)) break;
+          if (factorize(P, S, lane, lambda)) {
+            ok = true;
+            break;
+          }
+          lambda = fmax(lambda * 10.0, 1e-12 * dmax);
+        }
+        if (!ok) {
+          flags |= OKX_INFO_FAILED;
+          break;
+        }
+        dx = chol_solve(P, S, lane, -g);
+        step_len = wave_max(lane < n ? fabs(dx) : 0.0);
+        xt = x + dx;
+      }
+
+      // final state: free points, then every derived point (incl. output-only ones)
+      wave_sync();
+      if (lane < n) S.pos[xaddr] = x;
+      wave_sync();
+      derived_update<false>(P, S, lane, false);
+      double ra = 0.0;
+      for (int i = lane; i < m; i += kWave) ra = fmax(ra, reference_abs_residual(P, S, i, cur));
+      const double max_res = wave_max(ra);
+      if (max_res > args.residual_tolerance) flags |= OKX_INFO_RESIDUAL_EXCEEDED;
+      double* out = args.out_pos + b * 3 * P->n_out;
+      for (int e = lane; e < 3 * P->n_out; e += kWave) out[e] = S.pos[3 * P->out_point[e / 3] + e % 3];
+      if (lane == 0) {
+        okx_info inf;
+        inf.max_residual = max_res;
+        inf.cost = F;
+        inf.last_step = last_step;
+        inf.iterations = iters;
+        inf.nfev = nfev;
+        inf.flags = flags;
+        inf.reserved = 0;
+        args.info[b] = inf;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// residual / dense Jacobian evaluation (parity rung R1) and normal equations (debug)
+// ------------------------------------------------------------------------------------
+
+struct EvalArgs {
+  const double* x;        // [B][n]
+  const double* targets;  // [B][T]
+  double* r;              // [B][m]
+  double* jac;            // [B][m][n] or null
+  double* ata;            // [B][n][n] or null  (J^T J, full symmetric)
+  double* atr;            // [B][n] or null     (J^T r)
+  long long n_problems;
+};
+
+__global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __restrict__ P,
+                                                         EvalArgs args) {
+  extern __shared__ double lds_base[];
+  const int lane = threadIdx.x;
+  const Lds S = carve(lds_base, P);
+  const int n = P->n, m = P->m, T = P->n_targets;
+  const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
+  for (int e = lane; e < n * P->lda; e += kWave) S.A[e] = 0.0;
+  load_geometry(P, S, lane, nullptr, nullptr);
+  for (long long b = blockIdx.x; b < args.n_problems; b += gridDim.x) {
+    wave_sync();
+    if (lane < T) S.tv[lane] = args.targets[b * T + lane];
+    const double x = lane < n ? args.x[b * n + lane] : 0.0;
+    evaluate<true>(P, S, lane, x, xaddr, 0);
+    for (int i = lane; i < m; i += kWave) args.r[b * m + i] = S.rb[i];
+    if (args.jac) {
+      double* J = args.jac + b * (long long)m * n;
+      for (int e = lane; e < m * n; e += kWave) J[e] = 0.0;
+      wave_sync();
+      for (int i = lane; i < m; i += kWave) {
+        const double* jr = S.js + (size_t)i * P->js_stride;
+        for (int s = 0; s < P->row_nblk[i]; ++s)
+          for (int k = 0; k < 3; ++k) J[(long long)i * n + 3 * P->row_blk[i][s] + k] = jr[3 * s + k];
+      }
+    }
+    if (args.ata || args.atr) {
+      const double g = build_normal(P, S, lane, 0);
+      if (args.atr && lane < n) args.atr[b * n + lane] = g;
+      if (args.ata) {
+        double* M = args.ata + b * (long long)n * n;
+        for (int e = lane; e < n * n; e += kWave) {
+          const int i = e / n, j = e % n;
+          M[e] = i == j ? S.dA[i] : (i < j ? S.A[i * P->lda + j] : S.A[j * P->lda + i]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// per-geometry problem emission (okx_rebind_design)
+// ------------------------------------------------------------------------------------
+
+struct RebindArgs {
+  const double* hardpoints;  // [G][P][3]
+  double* geom_pos;          // [G][P][3]
+  double* geom_row_param;    // [G][Mc][8]
+  long long n_geometries;
+};
+
+__global__ void __launch_bounds__(kWave) okx_rebind_kernel(const DevProgram* __restrict__ P,
+                                                           RebindArgs args) {
+  extern __shared__ double lds_base[];
+  const int lane = threadIdx.x;
+  const Lds S = carve(lds_base, P);
+  for (long long gidx = blockIdx.x; gidx < args.n_geometries; gidx += gridDim.x) {
+    load_geometry(P, S, lane, args.hardpoints + gidx * 3 * P->n_points, nullptr);
+    derived_update<false>(P, S, lane, false);
+    double* gp = args.geom_pos + gidx * 3 * P->n_points;
+    for (int e = lane; e < 3 * P->n_points; e += kWave) gp[e] = S.pos[e];
+    for (int i = lane; i < P->n_crows; i += kWave) {
+      double q[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q[k] = S.rowq[8 * i + k];
+      const int* pts = P->row_pts[i];
+      const int type = P->row_type[i];
+      if (type == OKX_ROW_DISTANCE) {  // geometric.py:17-28
+        V3 d = sub(ld3(S.pos + 3 * pts[1]), ld3(S.pos + 3 * pts[0]));
+        q[0] = sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
+      } else if (type == OKX_ROW_ANGLE || type == OKX_ROW_THREE_POINT_ANGLE) {
+        // geometric.py:71-104 compute_vector_vector_angle
+        V3 v1, v2;
+        if (type == OKX_ROW_ANGLE) {
+          v1 = sub(ld3(S.pos + 3 * pts[1]), ld3(S.pos + 3 * pts[0]));
+          v2 = sub(ld3(S.pos + 3 * pts[3]), ld3(S.pos + 3 * pts[2]));
+        } else {
+          v1 = sub(ld3(S.pos + 3 * pts[0]), ld3(S.pos + 3 * pts[1]));
+          v2 = sub(ld3(S.pos + 3 * pts[2]), ld3(S.pos + 3 * pts[1]));
+        }
+        double n1 = sqrt(dot(v1, v1)), n2 = sqrt(dot(v2, v2));
+        V3 u1 = {v1.x / n1, v1.y / n1, v1.z / n1}, u2 = {v2.x / n2, v2.y / n2, v2.z / n2};
+        V3 c = cross(u1, u2);
+        q[0] = atan2(sqrt(dot(c, c)), dot(u1, u2));
+      } else if (type == OKX_ROW_SCALAR_TRIPLE) {  // attachments.py:45-74
+        V3 p1 = ld3(S.pos + 3 * pts[0]);
+        V3 v1 = sub(ld3(S.pos + 3 * pts[1]), p1), v2 = sub(ld3(S.pos + 3 * pts[2]), p1),
+           v3 = sub(ld3(S.pos + 3 * pts[3]), p1);
+        q[0] = dot(v1, cross(v2, v3));
+        q[1] = fabs(q[0]);
+      } else if (type == OKX_ROW_POINT_ON_LINE || type == OKX_ROW_LINE_PIN) {  // track_rod.py:92-96
+        q[0] = S.pos[3 * pts[0]], q[1] = S.pos[3 * pts[0] + 1], q[2] = S.pos[3 * pts[0] + 2];
+      }
+      double* dst = args.geom_row_param + (gidx * P->n_crows + i) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dst[k] = q[k];
+    }
+  }
+}
+
+}  // namespace okx

@@ -45,7 +45,7 @@ DOP_CONTACT_PATCH = 2
 
 ROW_PARAMS = 8
 ROW_POINTS = 4
-MAX_VARS = 96
+MAX_VARS = 63
 MAX_ROWS = 128
 MAX_POINTS = 96
 MAX_TARGETS = 8
