@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: constraint solves/sec on the double-wishbone bump sweep (BASELINE.json).
+
+One "step" = one pass of the hot path over one batch: every rank solves a 16384-step fp64
+bump sweep (BASELINE config 2; inputs already resident in HBM) with ONE launch of the solve
+kernel; with N > 1 ranks the global sweep (N x 16384 steps) is sharded by index and the solved
+positions are all-gathered over RCCL inside the timed step.  Prints one JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+STEPS_PER_RANK = 16384
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor fp64 vector peak, secondary ceiling
+
+
+def algorithmic_bytes_per_solve(program) -> int:
+    """8*T targets in + 24*P_out positions out + 16 B info (we write 40)."""
+    return 8 * program.n_targets + 24 * program.n_out + 16
+
+
+def estimated_flops_per_evaluation(program, stats) -> float:
+    """Analytic fp64 flop count of one LM iteration: rows + J^T J + Cholesky + solves."""
+    n, m = program.n_vars, program.n_residuals
+    rows = 60.0 * m
+    normal = 2.0 * 9.0 * stats["contrib"] + 2.0 * 3.0 * stats["contrib"]
+    chol = n ** 3 / 3.0 + 2.0 * n * n
+    return rows + normal + chol
+
+
+def cpu_baseline(n_steps: int) -> dict:
+    """Oracle = reference-shaped CPU path: sequential warm-started MINPACK LM, default tolerances."""
+    from open_kinematics_amd.workloads import bump_sweep_problem
+    from oracle.oracle import Oracle
+
+    program, targets = bump_sweep_problem(n_steps, line_mode="softnorm")
+    orc = Oracle(program)
+    orc.sweep(targets[:64])  # warm the library / caches
+    t0 = time.perf_counter()
+    res = orc.sweep(targets)
+    dt = time.perf_counter() - t0
+    if res.first_failed_step != -1:
+        raise RuntimeError("cpu baseline: oracle sweep failed")
+    return {
+        "value": n_steps / dt,
+        "unit": "constraint solves/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"full {n_steps}-step bump sweep, sequential warm start, MINPACK LM "
+                  f"ftol=1e-5 xtol=gtol=1e-9 (reference defaults), {dt:.1f} s, "
+                  f"mean nfev {float(res.info['nfev'].mean()):.1f}",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the solve path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from open_kinematics_amd import _lib
+    from open_kinematics_amd._abi import HostProgram
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.dist import all_gather_rows, shard_range
+    from open_kinematics_amd.workloads import bump_sweep_problem
+
+    n_total = STEPS_PER_RANK * world
+    program, targets_all = bump_sweep_problem(n_total)
+    lo, hi = shard_range(n_total, rank, world)
+    dp = DeviceProgram(program, device)
+    targets = torch.as_tensor(targets_all[lo:hi], device=device).contiguous()
+    out = torch.empty((hi - lo, program.n_out, 3), dtype=torch.float64, device=device)
+    info = torch.empty((hi - lo, 40), dtype=torch.uint8, device=device)
+
+    def step():
+        res = dp.solve(targets, out=out, info_out=info)
+        if world > 1:
+            return all_gather_rows(res.positions, n_total)
+        return res.positions
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        starts[k].record()
+        res = dp.solve(targets, out=out, info_out=info)
+        ends[k].record()  # brackets exactly the solve-kernel launch on the launch stream
+        if world > 1:
+            all_gather_rows(res.positions, n_total)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    host_info = info.cpu().numpy().view(np.dtype([("max_residual", "<f8"), ("cost", "<f8"), ("last_step", "<f8"),
+                                                  ("iterations", "<i4"), ("nfev", "<i4"), ("flags", "<i4"),
+                                                  ("reserved", "<i4")])).reshape(-1)
+    ok = bool(np.all((host_info["flags"] & 7) == 1))
+
+    if rank == 0:
+        import ctypes as C
+
+        stats_raw = (C.c_int32 * 8)()
+        _lib.load().okx_plan_stats(HostProgram(program).byref(), stats_raw)
+        stats = dict(zip(["n", "m", "pairs", "contrib", "active", "js_stride", "lda", "lds_bytes"], list(stats_raw)))
+        bytes_per_solve = algorithmic_bytes_per_solve(program)
+        achieved_gbs = bytes_per_solve * (hi - lo) / (kernel_ms * 1e-3) / 1e9
+        nfev_mean = float(host_info["nfev"].mean())
+        flops = estimated_flops_per_evaluation(program, stats) * nfev_mean * (hi - lo)
+        line = {
+            "metric": "constraint solves/sec (sweep steps/sec), double-wishbone bump sweep",
+            "value": n_total * args.steps / elapsed,
+            "unit": "constraint solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "double-wishbone corner (tests/data/geometry.yaml), 16384-step fp64 bump sweep "
+                            "-60..+80 mm per GPU, rack held (BASELINE config 2)",
+                "problems_per_gpu": STEPS_PER_RANK,
+                "n_vars": program.n_vars,
+                "n_residual_rows": program.n_residuals,
+                "line_mode": program.line_mode,
+                "start": "cold (design state), one wavefront per sweep step",
+                "lm_evaluations_mean": nfev_mean,
+                "all_converged": ok,
+                "exchange": "RCCL all-gather of solved positions" if world > 1 else "none",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "okx_solve_kernel",
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_solve": bytes_per_solve,
+                "note": "path is latency/fp64-issue bound, not HBM bound (SURVEY.md §7 H4): see compute",
+            },
+            "compute": {
+                "unit": "TFLOP/s",
+                "achieved": flops / (kernel_ms * 1e-3) / 1e12,
+                "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "frac": flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                "flops_per_solve_estimate": flops / (hi - lo),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(STEPS_PER_RANK)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

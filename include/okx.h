@@ -121,7 +121,7 @@ typedef struct okx_program okx_program; /* opaque, device-resident */
 
 /* Levenberg–Marquardt controls.  Zero-initialise then call okx_default_opts(). */
 typedef struct okx_solve_opts {
-  int32_t max_iter;       /* LM iterations per problem (default 64)                        */
+  int32_t max_iter;       /* LM iterations per problem (default 100)                       */
   int32_t chain;          /* 0: every problem starts from its geometry's design state
                              (independent problems, one wavefront each);
                              1: reference semantics (solver.py:716,774): problems of one
@@ -130,6 +130,11 @@ typedef struct okx_solve_opts {
   int64_t steps_per_geometry; /* problems [g*S, (g+1)*S) use geometry g; 0 = single geometry */
   double step_tol;        /* stop when max|dx| <= step_tol (mm, default 1e-11)             */
   double grad_tol;        /* stop when max|J^T r| <= grad_tol (default 0: unused)          */
+  double ftol;            /* stop when an accepted step reduces the cost by <= ftol*cost,
+                             actual and predicted (MINPACK's ftol test; default 1e-10):
+                             terminates infeasible targets at their compromise point so
+                             that the residual_tolerance check can reject them
+                             (solver.py:732-747)                                           */
   double lambda0;         /* initial damping relative to max diag(J^T J) (default 1e-6)    */
   double residual_tolerance; /* informational: info.flags bit1 set if max|r| exceeds it
                                 (solver.py:735-747, default 1e-3)                          */

@@ -46,6 +46,7 @@ class SolveOpts(C.Structure):
         ("steps_per_geometry", C.c_int64),
         ("step_tol", C.c_double),
         ("grad_tol", C.c_double),
+        ("ftol", C.c_double),
         ("lambda0", C.c_double),
         ("residual_tolerance", C.c_double),
     ]

@@ -95,6 +95,7 @@ class DeviceProgram:
         max_iter: int | None = None,
         step_tol: float | None = None,
         lambda0: float | None = None,
+        ftol: float | None = None,
         residual_tolerance: float | None = None,
         out: torch.Tensor | None = None,
         info_out: torch.Tensor | None = None,
@@ -112,6 +113,8 @@ class DeviceProgram:
             opts.step_tol = float(step_tol)
         if lambda0 is not None:
             opts.lambda0 = float(lambda0)
+        if ftol is not None:
+            opts.ftol = float(ftol)
         if residual_tolerance is not None:
             opts.residual_tolerance = float(residual_tolerance)
         if geom_pos is not None:

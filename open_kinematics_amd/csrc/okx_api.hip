@@ -53,11 +53,12 @@ const char* okx_last_error(void) { return g_err; }
 
 void okx_default_opts(okx_solve_opts* o) {
   if (!o) return;
-  o->max_iter = 64;
+  o->max_iter = 100;
   o->chain = 0;
   o->steps_per_geometry = 0;
   o->step_tol = 1e-11;
   o->grad_tol = 0.0;
+  o->ftol = 1e-10;
   o->lambda0 = 1e-6;
   o->residual_tolerance = 1e-3;
 }
@@ -160,6 +161,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   a.chain = opts->chain ? 1 : 0;
   a.step_tol = opts->step_tol;
   a.grad_tol = opts->grad_tol;
+  a.ftol = opts->ftol;
   a.lambda0 = opts->lambda0;
   a.residual_tolerance = opts->residual_tolerance;
   const long long units = a.chain ? (spg > 0 ? n_problems / spg : 1) : n_problems;

@@ -38,7 +38,7 @@ struct SolveArgs {
   long long steps_per_geometry;  // 0: single geometry
   int max_iter;
   int chain;
-  double step_tol, grad_tol, lambda0, residual_tolerance;
+  double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
 };
 
 // ------------------------------------------------------------------------------------
@@ -665,6 +665,11 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
           accept = rho > 1e-4 || small;
           if (finite && step_len <= args.step_tol) {
             accept = small;
+            flags |= OKX_INFO_CONVERGED;
+            stop = true;
+          } else if (accept && finite && F - Ft <= args.ftol * F && pred <= args.ftol * F) {
+            // cost has stopped moving (MINPACK's ftol test): a compromise point of an
+            // infeasible target, or the rounding floor of a feasible one
             flags |= OKX_INFO_CONVERGED;
             stop = true;
           }

@@ -1,0 +1,63 @@
+"""
+Multi-GPU: the batch (sweep steps x geometries) shards by contiguous index range, one process
+per GPU; there is no data-path collective while solving.  The single exchange step is an
+all-gather of the solved positions (RCCL over xGMI on the GPU box; gloo in the CPU tests).
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world_size: int) -> tuple[int, int]:
+    """Contiguous, balanced ``[lo, hi)`` block of ``n_items`` for ``rank`` (first ranks get the remainder)."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank out of range")
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """
+    Gather per-rank row blocks (sharded with ``shard_range``) into the full ``[n_total, ...]``
+    tensor on every rank.  Uneven shards are padded to the largest block for the collective.
+    """
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if local.shape[0] != n_total:
+            raise ValueError("single-process gather expects the full batch")
+        return local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_range(n_total, rank, world)
+    if local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank}: expected {hi - lo} rows, got {local.shape[0]}")
+    biggest = -(-n_total // world)
+    if hi - lo < biggest:
+        pad = torch.zeros((biggest - (hi - lo), *local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    local = local.contiguous()
+    gathered = torch.empty((world * biggest, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local, group=group)
+    if n_total == world * biggest:
+        return gathered
+    pieces = []
+    for r in range(world):
+        rlo, rhi = shard_range(n_total, r, world)
+        pieces.append(gathered[r * biggest : r * biggest + (rhi - rlo)])
+    return torch.cat(pieces, dim=0)
+
+
+def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = True, group=None, **solve_kw):
+    """
+    Solve this rank's index block of ``targets_full [B, T]`` and (optionally) all-gather the
+    solved positions.  Returns ``(positions, local_result)``.
+    """
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    n_total = targets_full.shape[0]
+    lo, hi = shard_range(n_total, rank, world)
+    result = device_program.solve(targets_full[lo:hi], **solve_kw)
+    positions = all_gather_rows(result.positions, n_total, group) if gather else result.positions
+    return positions, result

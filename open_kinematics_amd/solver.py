@@ -1,0 +1,212 @@
+"""
+Drop-in for the reference's ``kinematics.core.solver`` entry points
+(``solve_suspension_sweep``, ``SolverConfig``, ``SolverInfo``, ``convert_targets_to_absolute``)
+on top of the device solver.  Inputs may be the reference's own objects (duck-typed) or
+this package's; the returned states are built with the same classes as the input state.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, NamedTuple
+
+import numpy as np
+
+from .enums import TargetPositionMode
+from .program import ConstraintProgram, flatten_problem, resolve_direction
+from .state import Point3, SuspensionState
+
+SOLVE_TOLERANCE_VALUE = 1e-5
+SOLVE_TOLERANCE_STEP = 1e-9
+SOLVE_TOLERANCE_GRAD = 1e-9
+SOLVE_ACCEPT_RESIDUAL = 1e-3
+
+
+class SolverConfig(NamedTuple):
+    """
+    Reference fields first (``solver.py:65-80``).  ``ftol``/``xtol``/``gtol`` steer MINPACK in
+    the reference; the device solver always iterates to its fixed point and uses the extra
+    fields instead.
+    """
+
+    ftol: float = SOLVE_TOLERANCE_VALUE
+    xtol: float = SOLVE_TOLERANCE_STEP
+    gtol: float = SOLVE_TOLERANCE_GRAD
+    verbose: int = 0
+    residual_tolerance: float = SOLVE_ACCEPT_RESIDUAL
+    # device-solver controls
+    line_mode: str = "pinned"   # "pinned" | "softnorm" (include/okx.h, OKX_ROW_LINE_PIN)
+    warm_start: bool = True     # reference semantics: step k starts from step k-1 (solver.py:774)
+    step_tol: float = 1e-11     # mm
+    max_iter: int = 100
+
+
+@dataclass
+class SolverInfo:
+    """``solver.py:83-96``; ``nfev`` counts device residual evaluations."""
+
+    converged: bool
+    nfev: int
+    max_residual: float
+
+
+def validate_least_squares_dimensions(n_vars: int, n_residuals: int, *, method: str = "lm") -> None:
+    if method == "lm" and n_vars > n_residuals:
+        raise ValueError(
+            f"System is underdetermined (n_vars={n_vars} > m_res={n_residuals}). "
+            "The solve method (Levenberg-Marquardt) requires at least as "
+            "many residuals as variables."
+        )
+
+
+def _is_absolute(mode) -> bool:
+    return str(getattr(mode, "value", mode)).lower() == "absolute"
+
+
+def convert_targets_to_absolute(targets, initial_state):
+    """Relative displacement -> absolute scalar along the direction (``solver.py:584-627``)."""
+    resolved = []
+    for target in targets:
+        if _is_absolute(target.mode):
+            resolved.append(target)
+            continue
+        unit = resolve_direction(target.direction)
+        position = initial_state.positions[target.point_id]
+        coordinate = float(np.dot(np.asarray(getattr(position, "data", position)), unit))
+        resolved.append(type(target)(
+            point_id=target.point_id, direction=target.direction,
+            value=coordinate + target.value,
+            mode=_absolute_like(target.mode),
+        ))
+    return resolved
+
+
+def _absolute_like(mode):
+    try:
+        return type(mode)("absolute")
+    except Exception:
+        return TargetPositionMode.ABSOLUTE
+
+
+def absolute_target_table(sweep_config, initial_state) -> tuple[list, np.ndarray]:
+    """``([(point, direction)] per dimension, values [S, T])`` with the reference's arithmetic."""
+    dims = sweep_config.target_sweeps
+    heads, columns = [], []
+    for dim in dims:
+        first = dim[0]
+        unit0 = resolve_direction(first.direction)
+        for t in dim:
+            if t.point_id != first.point_id or not np.array_equal(resolve_direction(t.direction), unit0):
+                raise NotImplementedError(
+                    "a sweep dimension must keep one point and direction for all steps "
+                    "(the batched solver shares target rows across the sweep)"
+                )
+        position = initial_state.positions[first.point_id]
+        base = float(np.dot(np.asarray(getattr(position, "data", position)), unit0))
+        columns.append([t.value if _is_absolute(t.mode) else base + t.value for t in dim])
+        heads.append((first.point_id, first.direction))
+    table = np.asarray(columns, dtype=np.float64).T.reshape(sweep_config.n_steps, len(dims))
+    return heads, np.ascontiguousarray(table)
+
+
+def describe_worst_residual(program: ConstraintProgram, residuals: np.ndarray) -> str:
+    """``solver.py:640-651`` on the flattened row table."""
+    worst = int(np.argmax(np.abs(residuals)))
+    if worst < program.n_rows:
+        return f"constraint {program.constraint_desc[int(program.row_source[worst])]}"
+    return program.target_desc[worst - program.n_rows]
+
+
+_PROGRAM_CACHE: dict = {}
+
+
+def _device_program(program: ConstraintProgram, device=None):
+    from .batch import DeviceProgram
+
+    return DeviceProgram(program, device)
+
+
+def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_manager,
+                           solver_config=SolverConfig(), *, output_points=None, device=None):
+    """
+    Solve every step of a sweep on the GPU (reference ``solver.py:654-776``).
+
+    Returns ``(states, infos)`` like the reference.  Raises ``ValueError`` for an
+    underdetermined system and ``RuntimeError`` at the first step that did not converge or
+    whose worst residual exceeds ``residual_tolerance`` — with the reference's messages.
+    """
+    import torch
+
+    spec = getattr(derived_manager, "spec", derived_manager)
+    cfg = _coerce_config(solver_config)
+    heads, table = absolute_target_table(sweep_config, initial_state)
+    n_vars = 3 * len(initial_state.free_points)
+    validate_least_squares_dimensions(n_vars, len(constraints) + len(heads))
+    program = flatten_problem(initial_state, constraints, spec, heads, output_points=None,
+                              line_mode="softnorm").with_line_mode(cfg.line_mode)
+    dp = _device_program(program, device)
+    n_steps = table.shape[0]
+    if n_steps == 0:
+        return [], []
+    result = dp.solve(torch.as_tensor(table), chain=bool(cfg.warm_start), max_iter=cfg.max_iter,
+                      step_tol=cfg.step_tol, residual_tolerance=cfg.residual_tolerance)
+    torch.cuda.synchronize(dp.device)
+    positions = result.positions.cpu().numpy()
+    info = result.info()
+    _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg)
+    states = _states_from_positions(initial_state, program, positions)
+    infos = [SolverInfo(bool(f & 1), int(n), float(r))
+             for f, n, r in zip(info["flags"], info["nfev"], info["max_residual"])]
+    dp.close()
+    return states, infos
+
+
+def _coerce_config(config) -> SolverConfig:
+    if isinstance(config, SolverConfig):
+        return config
+    fields = {k: getattr(config, k) for k in SolverConfig._fields if hasattr(config, k)}
+    return SolverConfig(**fields)
+
+
+def _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg) -> None:
+    import torch
+
+    flags = info["flags"]
+    bad = np.nonzero(((flags & 1) == 0) | ((flags & 6) != 0))[0]
+    if bad.size == 0:
+        return
+    step = int(bad[0])
+    step_targets = convert_targets_to_absolute([dim[step] for dim in sweep_config.target_sweeps], initial_state)
+    # A step that stalls far from feasibility is the reference's "converged to a compromise"
+    # case (MINPACK stops on ftol=1e-5 there): report it through the residual check.
+    exceeded = (flags[step] & 2) != 0 and (flags[step] & 4) == 0
+    if not exceeded:
+        raise RuntimeError(
+            f"Solver failed to converge for targets: {step_targets}."
+            f"\nMessage: device Levenberg-Marquardt stopped after {int(info['iterations'][step])} iterations"
+        )
+    x = positions[step][program.free_point].reshape(1, -1)
+    r, _ = dp.eval(torch.as_tensor(x), torch.as_tensor(table[step : step + 1]), jac=False)
+    worst = describe_worst_residual(program, r.cpu().numpy()[0])
+    value = float(info["max_residual"][step])
+    raise RuntimeError(
+        f"Solve at sweep step {step} did not reach an acceptable residual: worst residual "
+        f"{value:.6g} exceeds the acceptance tolerance {cfg.residual_tolerance:.6g}. "
+        f"Worst residual row: {worst}. The mechanism likely cannot reach the requested targets "
+        "(kinematic lock-out / infeasible target combination)."
+    )
+
+
+def _states_from_positions(initial_state, program: ConstraintProgram, positions: np.ndarray) -> list:
+    """One independent state per step, typed like the input state (``solver.py:763``)."""
+    sample = next(iter(initial_state.positions.values()))
+    point_cls = type(sample) if hasattr(sample, "data") else Point3
+    state_cls = type(initial_state) if hasattr(initial_state, "free_points_order") else SuspensionState
+    keys = program.point_keys
+    free = set(initial_state.free_points)
+    states = []
+    for step in range(positions.shape[0]):
+        block = positions[step]
+        states.append(state_cls(positions={k: point_cls(block[i].copy()) for i, k in enumerate(keys)},
+                                free_points=set(free)))
+    return states

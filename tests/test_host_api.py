@@ -1,0 +1,140 @@
+"""Host-side mirror of the reference API: loader, problem emission, targets, error contract."""
+
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from conftest import GOLDEN, STEERED, UNSTEERED
+from open_kinematics_amd import input as okin
+from open_kinematics_amd.enums import Axis, PointID, PointRef, Side
+from open_kinematics_amd.program import flatten_problem
+from open_kinematics_amd.solver import absolute_target_table, convert_targets_to_absolute
+from open_kinematics_amd.state import Point3, SuspensionState
+from open_kinematics_amd.sweep import sweep_program
+from open_kinematics_amd.targeting import PointTarget, PointTargetAxis, SweepConfig, validate_sweep_controls
+
+GEOM = os.path.join(GOLDEN, "geometry")
+
+
+@pytest.mark.parametrize("name", [n for n in STEERED + UNSTEERED])
+def test_own_loader_emits_the_reference_problem_bitwise(golden, name):
+    """rows, order, point indices and design parameters are identical to
+    what the reference's build_suspension/constraints()/initial_state() produced."""
+    arrays, ref_program = golden(name)
+    sus = okin.build_suspension(yaml.safe_load(str(arrays["geometry_yaml"])))
+    sweep = okin.build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)
+    heads, table = absolute_target_table(sweep, sus.initial_state())
+    mine = flatten_problem(sus.initial_state(), sus.constraints(), sus.derived_spec(), heads, sus.output_points())
+    a, b = mine.to_arrays(), ref_program.to_arrays()
+    for key in a:
+        if key == "target_desc":
+            continue
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(table, arrays["targets_abs"])  # np.linspace + design projection, bitwise
+
+
+def test_yaml_files_load_and_describe_the_baseline_shapes():
+    dw = okin.load_geometry(os.path.join(GEOM, "geometry.yaml"))
+    assert [p.name for p in dw.initial_state().free_points_order] == [
+        "LOWER_WISHBONE_OUTBOARD", "UPPER_WISHBONE_OUTBOARD", "TRACKROD_INBOARD",
+        "TRACKROD_OUTBOARD", "AXLE_INBOARD", "AXLE_OUTBOARD"]
+    assert len(dw.constraints()) == 17 and len(dw.output_points()) == 15
+    sweep = okin.load_sweep(os.path.join(GEOM, "bump_sweep.yaml"), dw)
+    assert sweep.n_steps == 36 and len(sweep.target_sweeps) == 2
+    axle = okin.load_geometry(os.path.join(GEOM, "axle_geometry_rocker.yaml"))
+    assert len(axle.initial_state().positions) == 44 and len(axle.constraints()) == 65
+    assert len(axle.output_points()) == 38
+    assert axle.initial_state().free_points_order[0] == PointRef(Side.LEFT, PointID.LOWER_WISHBONE_OUTBOARD)
+    right = axle.initial_state().positions[PointRef(Side.RIGHT, PointID.AXLE_OUTBOARD)]
+    assert right.y == -950.0  # mirrored through Y = 0 (build.py:344-354)
+    mac = okin.load_geometry(os.path.join(GEOM, "macpherson_geometry.yaml"))
+    assert len(mac.constraints()) == 15 and PointID.STRUT_BOTTOM in mac.derived_spec().functions
+    program, table = sweep_program(dw, sweep)
+    assert program.line_mode == "pinned" and program.n_rows == 19 and table.shape == (36, 2)
+
+
+def test_loader_validation_errors():
+    base = yaml.safe_load(open(os.path.join(GEOM, "geometry.yaml")))
+    bad = dict(base, type="five_link")
+    with pytest.raises(ValueError, match="Unsupported geometry type"):
+        okin.build_suspension(bad)
+    missing = yaml.safe_load(open(os.path.join(GEOM, "geometry.yaml")))
+    del missing["hardpoints"]["axle_inboard"]
+    with pytest.raises(ValueError, match="Missing required hardpoints"):
+        okin.build_suspension(missing)
+    flipped = yaml.safe_load(open(os.path.join(GEOM, "geometry.yaml")))
+    flipped["hardpoints"]["axle_outboard"]["y"] = -950
+    with pytest.raises(ValueError, match="AXLE_OUTBOARD Y > 0"):
+        okin.build_suspension(flipped)
+    unsteered = yaml.safe_load(open(os.path.join(GEOM, "geometry.yaml")))
+    unsteered["config"]["steering"] = {"type": "none"}
+    with pytest.raises(ValueError, match="Missing required hardpoints:.*TOE_LINK"):
+        okin.build_suspension(unsteered)
+    with pytest.raises(ValueError, match="unexpected keys"):
+        okin.build_sweep({"version": 1, "steps": 3, "targets": [], "bogus": 1})
+    with pytest.raises(ValueError, match="Unsupported sweep version"):
+        okin.build_sweep({"version": 2, "targets": []})
+
+
+def test_sweep_control_validation():
+    """targeting.py:168-186: a rack-steered corner needs exactly one rack target per step."""
+    dw = okin.load_geometry(os.path.join(GEOM, "geometry.yaml"))
+    only_bump = {"version": 1, "steps": 3, "targets": [
+        {"point": "wheel_center", "direction": {"axis": "z"}, "start": -10, "stop": 10}]}
+    with pytest.raises(ValueError, match="exactly one target for actuator 'steering rack'"):
+        okin.build_sweep(only_bump, dw)
+    doubled = {"version": 1, "steps": 3, "targets": [
+        {"point": "trackrod_inboard", "direction": {"axis": "y"}, "start": 0, "stop": 0},
+        {"point": "trackrod_inboard", "direction": {"vector": [0, 2, 0]}, "start": 0, "stop": 0}]}
+    with pytest.raises(ValueError, match="found 2 at step 0"):
+        okin.build_sweep(doubled, dw)
+    fixed = {"version": 1, "steps": 3, "targets": [
+        {"point": "lower_wishbone_inboard_front", "direction": {"axis": "z"}, "start": 0, "stop": 1}]}
+    with pytest.raises(ValueError, match="is fixed"):
+        okin.build_sweep(fixed, dw)
+    with pytest.raises(ValueError, match="same length"):
+        SweepConfig([[PointTarget(PointID.WHEEL_CENTER, PointTargetAxis(Axis.Z), 0.0)] * 2,
+                     [PointTarget(PointID.TRACKROD_INBOARD, PointTargetAxis(Axis.Y), 0.0)] * 3])
+
+
+def test_absolute_target_conversion_and_modes():
+    dw = okin.load_geometry(os.path.join(GEOM, "geometry.yaml"))
+    state = dw.initial_state()
+    from open_kinematics_amd.enums import TargetPositionMode as M
+
+    rel = PointTarget(PointID.WHEEL_CENTER, PointTargetAxis(Axis.Z), 12.5)
+    absolute = PointTarget(PointID.WHEEL_CENTER, PointTargetAxis(Axis.Z), 300.0, M.ABSOLUTE)
+    out = convert_targets_to_absolute([rel, absolute], state)
+    assert out[0].value == state.positions[PointID.WHEEL_CENTER].z + 12.5 and out[0].mode == M.ABSOLUTE
+    assert out[1] is absolute
+    cfg = SweepConfig([[rel, absolute]])
+    heads, table = absolute_target_table(cfg, state)
+    assert table.shape == (2, 1) and table[1, 0] == 300.0
+
+
+def test_state_container_semantics():
+    """state.py:46-126: sorted variable order, flat pack/unpack, independent copies."""
+    s = SuspensionState({PointID.AXLE_OUTBOARD: Point3([1, 2, 3]), PointID.AXLE_INBOARD: Point3([4, 5, 6]),
+                         PointID.STRUT_TOP: Point3([7, 8, 9])}, {PointID.AXLE_OUTBOARD, PointID.AXLE_INBOARD})
+    assert s.free_points_order == [PointID.AXLE_INBOARD, PointID.AXLE_OUTBOARD]
+    assert s.fixed_points == {PointID.STRUT_TOP}
+    assert np.array_equal(s.get_free_array(), [4, 5, 6, 1, 2, 3])
+    c = s.copy()
+    c.update_from_array(np.arange(6, dtype=float))
+    assert s[PointID.AXLE_INBOARD].x == 4.0 and c[PointID.AXLE_INBOARD].x == 0.0
+    with pytest.raises(ValueError):
+        c.update_from_array(np.zeros(5))
+
+
+def test_flatten_rejects_unknown_pieces():
+    dw = okin.load_geometry(os.path.join(GEOM, "geometry.yaml"))
+
+    class Mystery:
+        involved_points = set()
+
+    with pytest.raises(TypeError, match="No device implementation"):
+        flatten_problem(dw.initial_state(), [Mystery()], dw.derived_spec())
+    with pytest.raises(ValueError, match="line_mode"):
+        flatten_problem(dw.initial_state(), dw.constraints(), dw.derived_spec(), line_mode="magic")
