@@ -138,3 +138,27 @@ def test_flatten_rejects_unknown_pieces():
         flatten_problem(dw.initial_state(), [Mystery()], dw.derived_spec())
     with pytest.raises(ValueError, match="line_mode"):
         flatten_problem(dw.initial_state(), dw.constraints(), dw.derived_spec(), line_mode="magic")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/kinematics"),
+                    reason="the reference only exists in the build container")
+def test_reference_objects_pass_through_the_drop_in_front_end(golden):
+    """the reference's own Suspension / SweepConfig objects are accepted as they
+    are (duck typing) and flatten to the same program as the committed golden."""
+    from oracle import ref_shim
+
+    ref_shim.install()
+    from kinematics.core.input import build_suspension, build_sweep  # the REAL reference
+
+    for name in ("c1_dw_corner", "c3_axle_grid", "c4_macpherson_grid"):
+        arrays, ref_program = golden(name)
+        sus = build_suspension(yaml.safe_load(str(arrays["geometry_yaml"])))
+        sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)
+        program, table = sweep_program(sus, sweep, line_mode="softnorm")
+        a, b = program.to_arrays(), ref_program.to_arrays()
+        for key in a:
+            if key not in ("target_desc", "point_names"):
+                assert np.array_equal(a[key], b[key]), key
+        assert np.array_equal(table, arrays["targets_abs"])
+        # the reference's own ActuatorDOF objects drive the control validation
+        validate_sweep_controls(sweep, sus.actuator_dofs())
