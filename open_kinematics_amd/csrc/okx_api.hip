@@ -16,6 +16,8 @@ struct okx_program {
   int n_cu;
   size_t lds_bytes;
   int blocks_per_cu;
+  int nreg;              // padded size of the register-resident factorisation, 0 = LDS path
+  const void* solve_fn;  // selected okx_solve_kernel<NREG> instantiation
 };
 
 namespace {
@@ -36,6 +38,31 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess)                                                                 \
       return fail(OKX_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));         \
   } while (0)
+
+typedef void (*solve_kernel_t)(const okx::DevProgram*, okx::SolveArgs);
+
+// Small systems factorise in registers (template on the padded size); larger ones in LDS.
+void select_solve_kernel(okx_program* p) {
+  const int n = p->host.n;
+  solve_kernel_t fn;
+  if (n <= 15) {
+    fn = okx::okx_solve_kernel<15, false>;
+    p->nreg = 15;
+  } else if (n <= 18) {
+    fn = okx::okx_solve_kernel<18, false>;
+    p->nreg = 18;
+  } else if (n <= 21) {
+    fn = okx::okx_solve_kernel<21, false>;
+    p->nreg = 21;
+  } else if (n <= 24) {
+    fn = okx::okx_solve_kernel<24, false>;
+    p->nreg = 24;
+  } else {
+    fn = okx::okx_solve_kernel<0, false>;
+    p->nreg = 0;
+  }
+  p->solve_fn = (const void*)fn;
+}
 
 int grid_for(const okx_program* p, long long units) {
   long long cap = (long long)p->n_cu * p->blocks_per_cu;
@@ -81,6 +108,7 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
     return rc;
   }
   p->host.lds_doubles = okx::lds_doubles(p->host);
+  select_solve_kernel(p);
   p->lds_bytes = sizeof(double) * (size_t)p->host.lds_doubles;
   if (p->lds_bytes > 160 * 1024) {
     delete p;
@@ -110,15 +138,13 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
     return fail(OKX_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(e));
   }
   // >64 KiB of dynamic LDS needs the opt-in attribute
-  (void)hipFuncSetAttribute((const void*)okx::okx_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)p->lds_bytes);
+  (void)hipFuncSetAttribute(p->solve_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
   (void)hipFuncSetAttribute((const void*)okx::okx_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)p->lds_bytes);
   (void)hipFuncSetAttribute((const void*)okx::okx_rebind_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)p->lds_bytes);
   int occ = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, okx::okx_solve_kernel, okx::kWave,
-                                                   p->lds_bytes);
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, p->solve_fn, okx::kWave, p->lds_bytes);
   if (e != hipSuccess || occ < 1) occ = 1;
   if (occ > 32) occ = 32;
   p->blocks_per_cu = occ;
@@ -164,11 +190,13 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   a.ftol = opts->ftol;
   a.lambda0 = opts->lambda0;
   a.residual_tolerance = opts->residual_tolerance;
+  a.phase_cycles = nullptr;
   const long long units = a.chain ? (spg > 0 ? n_problems / spg : 1) : n_problems;
   const int grid = grid_for(p, units);
-  hipLaunchKernelGGL(okx::okx_solve_kernel, dim3(grid), dim3(okx::kWave), p->lds_bytes,
-                     (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
-  HIP_TRY(hipGetLastError());
+  const okx::DevProgram* dev = p->dev;
+  void* kargs[] = {(void*)&dev, (void*)&a};
+  HIP_TRY(hipLaunchKernel(p->solve_fn, dim3(grid), dim3(okx::kWave), kargs, p->lds_bytes,
+                          (hipStream_t)stream));
   return OKX_OK;
 }
 
@@ -224,6 +252,39 @@ int32_t okx_rebind_design(okx_program* p, int64_t n_geometries, const double* d_
   hipLaunchKernelGGL(okx::okx_rebind_kernel, dim3(grid_for(p, n_geometries)), dim3(okx::kWave),
                      p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
   HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
+/* Diagnostic (not part of the reference boundary): same as okx_solve_batch for an n = 18
+   program, but runs the stamped kernel instantiation and returns per-phase cycle sums of
+   workgroup 0 in d_phase_cycles[8]: 0 staging, 1 problem setup, 2 evaluate, 3 LM logic,
+   4 normal equations, 5 factor + solve, 6 output. */
+int32_t okx_debug_phase_profile(okx_program* p, const okx_solve_opts* opts, int64_t n_problems,
+                                const double* d_targets, double* d_out_pos, okx_info* d_info,
+                                unsigned long long* d_phase_cycles, void* stream) {
+  if (!p || !opts || p->nreg != 18) return fail(OKX_ERR_INVALID, "phase profile needs an n = 18 program");
+  okx::SolveArgs a;
+  a.targets = d_targets;
+  a.geom_pos = nullptr;
+  a.geom_row_param = nullptr;
+  a.out_pos = d_out_pos;
+  a.info = d_info;
+  a.n_problems = n_problems;
+  a.steps_per_geometry = 0;
+  a.max_iter = opts->max_iter;
+  a.chain = 0;
+  a.step_tol = opts->step_tol;
+  a.grad_tol = opts->grad_tol;
+  a.ftol = opts->ftol;
+  a.lambda0 = opts->lambda0;
+  a.residual_tolerance = opts->residual_tolerance;
+  a.phase_cycles = d_phase_cycles;
+  const okx::DevProgram* dev = p->dev;
+  void* kargs[] = {(void*)&dev, (void*)&a};
+  solve_kernel_t fn = okx::okx_solve_kernel<18, true>;
+  (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
+  HIP_TRY(hipLaunchKernel((const void*)fn, dim3(grid_for(p, n_problems)), dim3(okx::kWave), kargs,
+                          p->lds_bytes, (hipStream_t)stream));
   return OKX_OK;
 }
 

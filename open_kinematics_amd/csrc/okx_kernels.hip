@@ -39,30 +39,50 @@ struct SolveArgs {
   int max_iter;
   int chain;
   double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
+  unsigned long long* phase_cycles;  // diagnostic build only: [8] per-phase cycle sums of block 0
 };
 
 // ------------------------------------------------------------------------------------
 // wave-level helpers
 // ------------------------------------------------------------------------------------
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-  return v;
-}
-
-// Broadcast lane `k`'s value; k must be wave-uniform.
+// Broadcast lane `k`'s value; k must be wave-uniform (v_readlane_b32 x2).
 __device__ __forceinline__ double wave_bcast(double v, int k) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, k);
   hi = __builtin_amdgcn_readlane(hi, k);
   return __hiloint2double(hi, lo);
+}
+
+// One DPP data movement of a double; lanes without a valid source (or masked rows) get 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Wave-wide reductions in the DPP network (no LDS crossbar): row_shr 1/2/4/8 builds the
+// per-16-lane row totals, row_bcast:15 / row_bcast:31 chain them into lane 63.
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_move<0x111, 0xf>(v);
+  v += dpp_move<0x112, 0xf>(v);
+  v += dpp_move<0x114, 0xf>(v);
+  v += dpp_move<0x118, 0xf>(v);
+  v += dpp_move<0x142, 0xa>(v);
+  v += dpp_move<0x143, 0xc>(v);
+  return wave_bcast(v, 63);
+}
+
+// Maximum of NON-NEGATIVE values (identity 0).
+__device__ __forceinline__ double wave_max(double v) {
+  v = fmax(v, dpp_move<0x111, 0xf>(v));
+  v = fmax(v, dpp_move<0x112, 0xf>(v));
+  v = fmax(v, dpp_move<0x114, 0xf>(v));
+  v = fmax(v, dpp_move<0x118, 0xf>(v));
+  v = fmax(v, dpp_move<0x142, 0xa>(v));
+  v = fmax(v, dpp_move<0x143, 0xc>(v));
+  return wave_bcast(v, 63);
 }
 
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
@@ -87,16 +107,29 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 // LDS carve-up (offsets in doubles; sizes from DevProgram)
 // ------------------------------------------------------------------------------------
 
+constexpr int kRowMetaStride = 15;  // ints per row: type, pts[4], nblk, 4 x PointRef (odd stride)
+
 struct Lds {
   double* pos;    // [P][3]
   double* rowq;   // [m][8]   row parameters of the current geometry
   double* dblk;   // [n_active][kDepMax][3][3]
   double* js;     // [2][m][js_stride]
   double* rb;     // [2][m]
-  double* A;      // [n][lda]  strict upper: J^T J; lower + diag: Cholesky factor
+  double* A;      // [n][lda]  strict upper: J^T J; lower: factor L (unit lower for LDL^T)
   double* dA;     // [n]       diag(J^T J)
   double* tv;     // [T]       targets of the current problem
+  // program tables staged once per workgroup (static for the whole launch)
+  int* rowmeta;              // [m][kRowMetaStride]
+  int* item_dst;             // [n_work]
+  unsigned int* item_desc;   // [n_work]
+  unsigned short* contrib;   // [n_contrib]
+  unsigned short* gcontrib;  // [n_gcontrib]
 };
+
+__host__ __device__ inline int lds_table_doubles(const DevProgram& P) {
+  int ints = P.m * kRowMetaStride + 2 * P.n_work + (P.n_contrib + 1) / 2 + (P.n_gcontrib + 1) / 2 + 2;
+  return (ints + 1) / 2;
+}
 
 __host__ __device__ inline int lds_doubles(const DevProgram& P) {
   int s = 0;
@@ -108,6 +141,7 @@ __host__ __device__ inline int lds_doubles(const DevProgram& P) {
   s += P.n * P.lda;
   s += P.n;
   s += kMaxTargets;
+  s += lds_table_doubles(P);
   return (s + 1) & ~1;
 }
 
@@ -129,7 +163,42 @@ __device__ __forceinline__ Lds carve(double* base, const DevProgram* P) {
   S.dA = p;
   p += P->n;
   S.tv = p;
+  p += kMaxTargets;
+  int* q = reinterpret_cast<int*>(p);
+  S.rowmeta = q;
+  q += P->m * kRowMetaStride;
+  S.item_dst = q;
+  q += P->n_work;
+  S.item_desc = reinterpret_cast<unsigned int*>(q);
+  q += P->n_work;
+  S.contrib = reinterpret_cast<unsigned short*>(q);
+  q += (P->n_contrib + 1) / 2;
+  S.gcontrib = reinterpret_cast<unsigned short*>(q);
   return S;
+}
+
+// Copy the static program tables into LDS (once per persistent workgroup).
+__device__ __forceinline__ void stage_program(const DevProgram* P, const Lds& S, int lane) {
+  for (int i = lane; i < P->m; i += kWave) {
+    int* r = S.rowmeta + i * kRowMetaStride;
+    r[0] = P->row_type[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[1 + k] = P->row_pts[i][k];
+    r[5] = P->row_nblk[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      r[6 + 2 * k] = (int)P->row_in[i][k].w0;
+      r[7 + 2 * k] = (int)P->row_in[i][k].w1;
+    }
+  }
+  for (int w = lane; w < P->n_work; w += kWave) {
+    S.item_dst[w] = P->item_dst[w];
+    S.item_desc[w] = P->item_desc[w];
+  }
+  for (int c = lane; c < P->n_contrib; c += kWave) S.contrib[c] = P->contrib[c];
+  for (int c = lane; c < P->n_gcontrib; c += kWave) S.gcontrib[c] = P->g_contrib[c];
+  for (int e = lane; e < P->n * P->lda; e += kWave) S.A[e] = 0.0;
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------
@@ -422,20 +491,22 @@ __device__ __forceinline__ double row_eval(int type, const int* pts, const doubl
 // Evaluate row i into buffer `buf`: residual -> rb, block-sparse Jacobian row -> js.
 template <bool WITH_J>
 __device__ __forceinline__ double row_pass(const DevProgram* P, const Lds& S, int i, int buf) {
-  if (i >= P->m) return 0.0;
   double dp[12];
-  const int type = P->row_type[i];
-  const int* pts = P->row_pts[i];
+  const int* meta = S.rowmeta + i * kRowMetaStride;
+  const int type = meta[0];
+  const int pts[4] = {meta[1], meta[2], meta[3], meta[4]};
   const double* q = S.rowq + 8 * i;
   double r = row_eval<WITH_J>(type, pts, q, S.pos, S.tv, dp);
   S.rb[buf * P->m + i] = r;
   if (WITH_J) {
     double* jr = S.js + (size_t)(buf * P->m + i) * P->js_stride;
-    const int nb3 = 3 * P->row_nblk[i];
+    const int nb3 = 3 * meta[5];
     for (int k = 0; k < nb3; ++k) jr[k] = 0.0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const PointRef ref = P->row_in[i][s];
+      PointRef ref;
+      ref.w0 = (unsigned)meta[6 + 2 * s];
+      ref.w1 = (unsigned)meta[7 + 2 * s];
       if (ref.kind() == kRefFixed) continue;
       const double d0 = dp[3 * s], d1 = dp[3 * s + 1], d2 = dp[3 * s + 2];
       if (ref.kind() == kRefFree) {
@@ -481,36 +552,32 @@ __device__ __forceinline__ double evaluate(const DevProgram* P, const Lds& S, in
 // ------------------------------------------------------------------------------------
 
 __device__ __forceinline__ double build_normal(const DevProgram* P, const Lds& S, int lane,
-                                               int buf) {
+                                               int buf, int g_begin, int g_end) {
   const double* js = S.js + (size_t)buf * P->m * P->js_stride;
   const double* rb = S.rb + buf * P->m;
   const int stride = P->js_stride;
-  for (int w = lane; w < P->n_items; w += kWave) {
-    const int pair = w / 9, e = w % 9, a = e / 3, b = e % 3;
-    const int bp = P->pair_p[pair], bq = P->pair_q[pair];
-    if (bp == bq && a > b) continue;
+  for (int w = lane; w < P->n_work; w += kWave) {
+    const unsigned desc = S.item_desc[w];
+    const int dst = S.item_dst[w];
+    const int start = desc & 0xfff, count = (desc >> 12) & 0xff;
+    const int a = (desc >> 20) & 3, b = (desc >> 22) & 3;
     double acc = 0.0;
-    const int c1 = P->pair_start[pair + 1];
-    for (int c = P->pair_start[pair]; c < c1; ++c) {
-      const int pk = P->contrib[c];
+    for (int c = start; c < start + count; ++c) {
+      const int pk = S.contrib[c];
       const double* jr = js + (pk & 127) * stride;
       acc += jr[3 * ((pk >> 7) & 7) + a] * jr[3 * ((pk >> 10) & 7) + b];
     }
-    const int row = 3 * bp + a, col = 3 * bq + b;
-    if (row == col)
-      S.dA[row] = acc;
+    if (dst < 0)
+      S.dA[-dst - 1] = acc;
     else
-      S.A[row * P->lda + col] = acc;
+      S.A[dst] = acc;
   }
   double g = 0.0;
-  if (lane < P->n) {
-    const int blk = lane / 3, a = lane % 3;
-    const int c1 = P->g_start[blk + 1];
-    for (int c = P->g_start[blk]; c < c1; ++c) {
-      const int pk = P->g_contrib[c];
-      const int row = pk & 127;
-      g += js[row * stride + 3 * ((pk >> 7) & 7) + a] * rb[row];
-    }
+  const int a = lane % 3;
+  for (int c = g_begin; c < g_end; ++c) {  // empty range for lanes >= n
+    const int pk = S.gcontrib[c];
+    const int row = pk & 127;
+    g += js[row * stride + 3 * ((pk >> 7) & 7) + a] * rb[row];
   }
   wave_sync();
   return g;
@@ -568,6 +635,66 @@ __device__ __forceinline__ double chol_solve(const DevProgram* P, const Lds& S, 
   return b;
 }
 
+// Register-resident LDL^T for small systems (n <= N <= 24).  Lane i keeps row i of the
+// matrix in N statically indexed registers; every cross-lane operand is a v_readlane
+// broadcast, so the factorisation never waits on LDS.  Rows >= n are padded with identity.
+// The unit-lower factor is also streamed to LDS (fire and forget) because the backward
+// substitution needs COLUMN access, i.e. row k of L as seen by lane i < k.
+// Returns false (uniformly) when a pivot is not positive; otherwise *dx = -(A + lambda I)^-1 g.
+template <int N>
+__device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S, int lane,
+                                               double lambda, double g, double* dx) {
+  const int n = P->n, lda = P->lda;
+  double a[N];
+  const bool live = lane < n;
+  const double diag = live ? S.dA[live ? lane : 0] + lambda : 1.0;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double v = 0.0;
+    if (live && j < lane) v = S.A[j * lda + lane];  // upper-triangle storage of the symmetric matrix
+    if (j == lane) v = diag;
+    a[j] = v;
+  }
+  double dinv = 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const double pivot = wave_bcast(a[k], k);
+    if (!(pivot > 0.0)) {
+      ok = false;
+      break;
+    }
+    const double rinv = 1.0 / pivot;
+    const double lk = a[k] * rinv;  // L[lane][k] for lanes > k
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) a[j] -= lk * wave_bcast(a[k], j);
+    if (lane == k) dinv = rinv;
+    if (lane > k) {
+      a[k] = lk;
+      if (live) S.A[lane * lda + k] = lk;
+    }
+  }
+  if (!ok) return false;
+  wave_sync();  // factor visible for the row reads below
+  double lt[N];  // lt[k] = L[k][lane] for k > lane
+#pragma unroll
+  for (int k = 0; k < N; ++k) lt[k] = (k < n && lane < k) ? S.A[k * lda + lane] : 0.0;
+  double b = live ? -g : 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {  // L y = -g (unit lower)
+    const double yk = wave_bcast(b, k);
+    if (lane > k) b -= a[k] * yk;
+  }
+  b *= dinv;  // D z = y
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {  // L^T dx = z
+    const double dk = wave_bcast(b, k);
+    b -= lt[k] * dk;  // lt[k] is zero for lanes >= k
+  }
+  *dx = b;
+  return true;
+}
+
 // ------------------------------------------------------------------------------------
 // problem setup helpers
 // ------------------------------------------------------------------------------------
@@ -592,10 +719,11 @@ __device__ __forceinline__ void load_geometry(const DevProgram* P, const Lds& S,
 __device__ __forceinline__ double reference_abs_residual(const DevProgram* P, const Lds& S,
                                                          int i, int buf) {
   double r = S.rb[buf * P->m + i];
-  if (P->row_type[i] == OKX_ROW_LINE_PIN) {
+  const int* meta = S.rowmeta + i * kRowMetaStride;
+  if (meta[0] == OKX_ROW_LINE_PIN) {
     const double* q = S.rowq + 8 * i;
     if ((int)q[6] != 0) return 0.0;
-    V3 c = cross(sub(ld3(S.pos + 3 * P->row_pts[i][0]), ld3(q)), ld3(q + 3));
+    V3 c = cross(sub(ld3(S.pos + 3 * meta[1]), ld3(q)), ld3(q + 3));
     r = softnorm(dot(c, c));
   }
   return fabs(r);
@@ -605,15 +733,31 @@ __device__ __forceinline__ double reference_abs_residual(const DevProgram* P, co
 // the solve kernel
 // ------------------------------------------------------------------------------------
 
+// PROFILE = true is a separate diagnostic instantiation: s_memtime stamps around the phases of
+// block 0, summed into args.phase_cycles (never used by the product path or the bench).
+#define OKX_STAMP(slot)                                         \
+  if constexpr (PROFILE) {                                      \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    phase[slot] += now_ - t_last;                               \
+    t_last = now_;                                              \
+  }
+
+template <int NREG, bool PROFILE>
 __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __restrict__ P,
                                                           SolveArgs args) {
+  unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = 0;
+  if constexpr (PROFILE) t_last = __builtin_readcyclecounter();
   extern __shared__ double lds_base[];
   const int lane = threadIdx.x;
   const Lds S = carve(lds_base, P);
   const int n = P->n, m = P->m, T = P->n_targets;
   const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
+  const int g_begin = lane < n ? P->g_start[lane / 3] : 0;
+  const int g_end = lane < n ? P->g_start[lane / 3 + 1] : 0;
 
-  for (int e = lane; e < n * P->lda; e += kWave) S.A[e] = 0.0;
+  stage_program(P, S, lane);
+  OKX_STAMP(0)
 
   const long long spg = args.steps_per_geometry;
   const long long n_units = args.chain ? (spg > 0 ? args.n_problems / spg : 1) : args.n_problems;
@@ -640,6 +784,7 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
       wave_sync();
       if (lane < T) S.tv[lane] = args.targets[b * T + lane];
       wave_sync();
+      OKX_STAMP(1)
 
       // Levenberg-Marquardt.  One evaluation site: `xt` is the point being evaluated,
       // `x` the last accepted point; the first pass accepts unconditionally.
@@ -652,6 +797,7 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
       for (;;) {
         const double Ft = evaluate<true>(P, S, lane, xt, xaddr, cur ^ 1);
         ++nfev;
+        OKX_STAMP(2)
         bool accept;
         bool stop = false;
         double rho = 1.0;
@@ -680,7 +826,9 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
           cur ^= 1;
           if (!first) last_step = step_len;
           if (!stop) {
-            g = build_normal(P, S, lane, cur);
+            OKX_STAMP(3)
+            g = build_normal(P, S, lane, cur, g_begin, g_end);
+            OKX_STAMP(4)
             if (first) {
               dmax = wave_max(lane < n ? S.dA[lane] : 0.0);
               lambda = args.lambda0 * dmax;
@@ -702,24 +850,29 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
         if (stop) break;
         if (iters >= args.max_iter) break;
         ++iters;
+        OKX_STAMP(3)
         // damped normal equations; enlarge lambda until the factorisation succeeds
         bool ok = false;
         for (int tries = 0; tries < 60; ++tries) {
           if (!(lambda < 1e30)) break;
-          if (factorize(P, S, lane, lambda)) {
-            ok = true;
-            break;
+          if constexpr (NREG > 0) {
+            ok = ldlt_solve_reg<NREG>(P, S, lane, lambda, g, &dx);
+          } else {
+            ok = factorize(P, S, lane, lambda);
+            if (ok) dx = chol_solve(P, S, lane, -g);
           }
+          if (ok) break;
           lambda = fmax(lambda * 10.0, 1e-12 * dmax);
         }
         if (!ok) {
           flags |= OKX_INFO_FAILED;
           break;
         }
-        dx = chol_solve(P, S, lane, -g);
+        OKX_STAMP(5)
         step_len = wave_max(lane < n ? fabs(dx) : 0.0);
         xt = x + dx;
       }
+      OKX_STAMP(3)
 
       // final state: free points, then every derived point (incl. output-only ones)
       wave_sync();
@@ -743,7 +896,12 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
         inf.reserved = 0;
         args.info[b] = inf;
       }
+      OKX_STAMP(6)
     }
+  }
+  if constexpr (PROFILE) {
+    if (blockIdx.x == 0 && lane == 0 && args.phase_cycles)
+      for (int k = 0; k < 8; ++k) args.phase_cycles[k] = phase[k];
   }
 }
 
@@ -768,7 +926,9 @@ __global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __res
   const Lds S = carve(lds_base, P);
   const int n = P->n, m = P->m, T = P->n_targets;
   const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
-  for (int e = lane; e < n * P->lda; e += kWave) S.A[e] = 0.0;
+  const int g_begin = lane < n ? P->g_start[lane / 3] : 0;
+  const int g_end = lane < n ? P->g_start[lane / 3 + 1] : 0;
+  stage_program(P, S, lane);
   load_geometry(P, S, lane, nullptr, nullptr);
   for (long long b = blockIdx.x; b < args.n_problems; b += gridDim.x) {
     wave_sync();
@@ -787,7 +947,7 @@ __global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __res
       }
     }
     if (args.ata || args.atr) {
-      const double g = build_normal(P, S, lane, 0);
+      const double g = build_normal(P, S, lane, 0, g_begin, g_end);
       if (args.atr && lane < n) args.atr[b * n + lane] = g;
       if (args.ata) {
         double* M = args.ata + b * (long long)n * n;

@@ -286,6 +286,26 @@ int build_dev_program(const okx_program_desc* d, DevProgram* out, char* err, int
   int lda = n;
   while (lda % 4 != 2) ++lda;                        // lda = 2 (mod 4): see okx_kernels.hip
   out->lda = lda;
+
+  // ---- flattened work items ----
+  int nw = 0;
+  for (int pr = 0; pr < np; ++pr) {
+    const int bp = out->pair_p[pr], bq = out->pair_q[pr];
+    const int start = out->pair_start[pr], count = out->pair_start[pr + 1] - start;
+    if (start >= (1 << 12) || count >= (1 << 8)) FAIL(OKX_ERR_LIMIT, "plan item out of packing range");
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        if (bp == bq && a > b) continue;
+        const int row = 3 * bp + a, col = 3 * bq + b;
+        out->item_dst[nw] = row == col ? -(1 + row) : row * lda + col;
+        out->item_desc[nw] = (uint32_t)start | ((uint32_t)count << 12) | ((uint32_t)a << 20) |
+                             ((uint32_t)b << 22);
+        ++nw;
+      }
+  }
+  out->n_work = nw;
+  out->n_contrib = nc;
+  out->n_gcontrib = ng;
   return OKX_OK;
 }
 

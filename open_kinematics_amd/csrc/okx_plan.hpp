@@ -86,6 +86,15 @@ struct DevProgram {
   int32_t g_start[kMaxFree + 1];
   uint16_t g_contrib[kMaxGContrib]; // row | slot << 7
 
+  // Flattened J^T J work items (one per structurally non-zero scalar entry of the upper
+  // triangle incl. diagonal); staged into LDS by the solve kernel.
+  int32_t n_work;                       // number of valid items
+  int32_t n_contrib;                    // entries used in contrib[]
+  int32_t n_gcontrib;                   // entries used in g_contrib[]
+  int32_t pad2;
+  int32_t item_dst[kMaxPairs * 9];      // >= 0: offset into A (row * lda + col); < 0: -(1 + diag index)
+  uint32_t item_desc[kMaxPairs * 9];    // start | count << 12 | a << 20 | b << 22
+
   double design_pos[kMaxPoints][3];
 };
 
