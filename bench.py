@@ -29,6 +29,7 @@ import torch
 import torch.distributed as dist
 
 STEPS_PER_RANK = 16384
+CHAIN_LEN = -1                # one warm-started chunk of consecutive sweep steps per resident wavefront
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor fp64 vector peak, secondary ceiling
 
@@ -77,8 +78,12 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain-len", type=int, default=None, help="override: 1 = independent cold starts")
     args = ap.parse_args()
 
+    global CHAIN_LEN
+    if args.chain_len is not None:
+        CHAIN_LEN = args.chain_len
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,7 +113,7 @@ def main() -> None:
     info = torch.empty((hi - lo, 40), dtype=torch.uint8, device=device)
 
     def step():
-        res = dp.solve(targets, out=out, info_out=info)
+        res = dp.solve(targets, out=out, info_out=info, chain_len=CHAIN_LEN)
         if world > 1:
             return all_gather_rows(res.positions, n_total)
         return res.positions
@@ -125,7 +130,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for k in range(args.steps):
         starts[k].record()
-        res = dp.solve(targets, out=out, info_out=info)
+        res = dp.solve(targets, out=out, info_out=info, chain_len=CHAIN_LEN)
         ends[k].record()  # brackets exactly the solve-kernel launch on the launch stream
         if world > 1:
             all_gather_rows(res.positions, n_total)
@@ -175,7 +180,9 @@ def main() -> None:
                 "n_vars": program.n_vars,
                 "n_residual_rows": program.n_residuals,
                 "line_mode": program.line_mode,
-                "start": "cold (design state), one wavefront per sweep step",
+                "start": "sweep split into contiguous chunks, one per resident wavefront; chunk head cold "
+                         "(design state), later steps warm-started from their predecessor "
+                         "(reference semantics, solver.py:774)",
                 "lm_evaluations_mean": nfev_mean,
                 "all_converged": ok,
                 "exchange": "RCCL all-gather of solved positions" if world > 1 else "none",

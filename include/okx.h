@@ -128,6 +128,12 @@ typedef struct okx_solve_opts {
                              geometry form a sequential chain, step k starts at step k-1's
                              solution; one wavefront walks one chain.                      */
   int64_t steps_per_geometry; /* problems [g*S, (g+1)*S) use geometry g; 0 = single geometry */
+  int64_t chain_len;      /* > 0: consecutive problems are grouped into chains of this length
+                             (never across geometries); one wavefront walks one chain and
+                             warm-starts each problem from its predecessor, the chain head
+                             starts from the design state.  1 = independent cold starts,
+                             0 = take the length from `chain` (0 -> 1, 1 -> whole sweep),
+                             -1 = auto: one chain per resident wavefront.                  */
   double step_tol;        /* stop when max|dx| <= step_tol (mm, default 1e-11)             */
   double grad_tol;        /* stop when max|J^T r| <= grad_tol (default 0: unused)          */
   double ftol;            /* stop when an accepted step reduces the cost by <= ftol*cost,

@@ -44,6 +44,7 @@ class SolveOpts(C.Structure):
         ("max_iter", C.c_int32),
         ("chain", C.c_int32),
         ("steps_per_geometry", C.c_int64),
+        ("chain_len", C.c_int64),
         ("step_tol", C.c_double),
         ("grad_tol", C.c_double),
         ("ftol", C.c_double),

@@ -92,6 +92,7 @@ class DeviceProgram:
         geom_row_param: torch.Tensor | None = None,
         steps_per_geometry: int = 0,
         chain: bool = False,
+        chain_len: int | None = None,
         max_iter: int | None = None,
         step_tol: float | None = None,
         lambda0: float | None = None,
@@ -100,13 +101,21 @@ class DeviceProgram:
         out: torch.Tensor | None = None,
         info_out: torch.Tensor | None = None,
     ) -> BatchResult:
-        """Solve ``B`` problems; ``targets`` is ``[B, T]`` of absolute target scalars."""
+        """
+        Solve ``B`` problems; ``targets`` is ``[B, T]`` of absolute target scalars.
+
+        ``chain_len`` groups consecutive problems into warm-started chains walked by one
+        wavefront each (``1`` independent cold starts, ``-1`` one chain per resident wavefront,
+        ``None`` follows ``chain``: whole-sweep chain or independent).
+        """
         p = self.program
         targets = _as_f64(targets, self.device).reshape(-1, max(p.n_targets, 1))
         b = targets.shape[0] if p.n_targets > 0 else int(targets.numel())
         opts = self.default_opts()
         opts.chain = 1 if chain else 0
         opts.steps_per_geometry = int(steps_per_geometry)
+        if chain_len is not None:
+            opts.chain_len = int(chain_len)
         if max_iter is not None:
             opts.max_iter = int(max_iter)
         if step_tol is not None:

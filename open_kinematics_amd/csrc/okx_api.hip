@@ -4,20 +4,25 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
 #include "okx_kernels.hip"
+#include "okx_packed.hip"
 
 struct okx_program {
   okx::DevProgram host;        // host copy (dimensions, launch sizing)
   okx::DevProgram* dev;        // device copy
   int device;
   int n_cu;
-  size_t lds_bytes;
+  size_t lds_bytes;        // eval / rebind / single-problem solve kernels
+  size_t solve_lds_bytes;  // selected solve kernel
   int blocks_per_cu;
   int nreg;              // padded size of the register-resident factorisation, 0 = LDS path
-  const void* solve_fn;  // selected okx_solve_kernel<NREG> instantiation
+  int groups;            // problems per wavefront (1 = okx_solve_kernel, >1 = packed kernel)
+  int group_width;       // lanes per problem in the packed kernel
+  const void* solve_fn;  // selected kernel instantiation
 };
 
 namespace {
@@ -40,10 +45,46 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 typedef void (*solve_kernel_t)(const okx::DevProgram*, okx::SolveArgs);
+typedef void (*packed_kernel_t)(const okx::DevProgram*, okx::SolveArgs, int);
 
-// Small systems factorise in registers (template on the padded size); larger ones in LDS.
+// Kernel selection: systems with n <= 24 factorise in registers (template on the padded
+// size); when a problem needs at most 32 lanes, G = 64 / W problems share a wavefront
+// (okx_packed.hip).  OKX_FORCE_SINGLE=1 in the environment pins the one-problem kernel.
 void select_solve_kernel(okx_program* p) {
-  const int n = p->host.n;
+  const int n = p->host.n, m = p->host.m;
+  const int width = m > n + 1 ? m : n + 1;
+  int groups = 64 / width;
+  if (groups > 4) groups = 4;
+  // The packed kernel is opt-in (OKX_PACKED=1): on MI355X it is LDS-capacity limited to
+  // 4-6 wavefronts per CU and loses to the single-problem kernel at 12 (profiles/r01).
+  const char* packed = getenv("OKX_PACKED");
+  if (!(packed && packed[0] == '1')) groups = 1;
+  p->groups = 1;
+  p->group_width = 64;
+  if (groups >= 2 && n <= 24) {
+    packed_kernel_t fn = nullptr;
+    if (n <= 15) {
+      fn = groups == 4 ? okx::okx_solve_packed_kernel<15, 4, false>
+         : groups == 3 ? okx::okx_solve_packed_kernel<15, 3, false> : okx::okx_solve_packed_kernel<15, 2, false>;
+      p->nreg = 15;
+    } else if (n <= 18) {
+      fn = groups >= 3 ? okx::okx_solve_packed_kernel<18, 3, false> : okx::okx_solve_packed_kernel<18, 2, false>;
+      if (groups > 3) groups = 3;
+      p->nreg = 18;
+    } else if (n <= 21) {
+      fn = okx::okx_solve_packed_kernel<21, 2, false>;
+      groups = 2;
+      p->nreg = 21;
+    } else {
+      fn = okx::okx_solve_packed_kernel<24, 2, false>;
+      groups = 2;
+      p->nreg = 24;
+    }
+    p->groups = groups;
+    p->group_width = width;
+    p->solve_fn = (const void*)fn;
+    return;
+  }
   solve_kernel_t fn;
   if (n <= 15) {
     fn = okx::okx_solve_kernel<15, false>;
@@ -83,6 +124,7 @@ void okx_default_opts(okx_solve_opts* o) {
   o->max_iter = 100;
   o->chain = 0;
   o->steps_per_geometry = 0;
+  o->chain_len = 0;
   o->step_tol = 1e-11;
   o->grad_tol = 0.0;
   o->ftol = 1e-10;
@@ -110,7 +152,9 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   p->host.lds_doubles = okx::lds_doubles(p->host);
   select_solve_kernel(p);
   p->lds_bytes = sizeof(double) * (size_t)p->host.lds_doubles;
-  if (p->lds_bytes > 160 * 1024) {
+  p->solve_lds_bytes = p->groups > 1 ? sizeof(double) * (size_t)okx::packed_lds_doubles(p->host, p->groups)
+                                     : p->lds_bytes;
+  if (p->lds_bytes > 160 * 1024 || p->solve_lds_bytes > 160 * 1024) {
     delete p;
     return fail(OKX_ERR_LIMIT, "problem needs %zu bytes of LDS (max 163840)", p->lds_bytes);
   }
@@ -138,15 +182,30 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
     return fail(OKX_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(e));
   }
   // >64 KiB of dynamic LDS needs the opt-in attribute
-  (void)hipFuncSetAttribute(p->solve_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
+  (void)hipFuncSetAttribute(p->solve_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->solve_lds_bytes);
   (void)hipFuncSetAttribute((const void*)okx::okx_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)p->lds_bytes);
   (void)hipFuncSetAttribute((const void*)okx::okx_rebind_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                       (int)p->lds_bytes);
-  int occ = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, p->solve_fn, okx::kWave, p->lds_bytes);
-  if (e != hipSuccess || occ < 1) occ = 1;
-  if (occ > 32) occ = 32;
+  // Resident single-wave workgroups per CU.  The occupancy API assumes 64 KiB of LDS per CU
+  // on this stack, so the limit is derived here: 512 VGPRs per SIMD lane (8-register
+  // granules), 160 KiB LDS per CU, 8 waves per SIMD.
+  int occ = 32;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, p->solve_fn) == hipSuccess && fa.numRegs > 0) {
+    const int alloc = (fa.numRegs + 7) / 8 * 8;
+    int per_simd = 512 / alloc;
+    if (per_simd > 8) per_simd = 8;
+    if (per_simd < 1) per_simd = 1;
+    occ = 4 * per_simd;
+  }
+  const int by_lds = (int)((160 * 1024) / (p->solve_lds_bytes ? p->solve_lds_bytes : 1));
+  if (by_lds < occ) occ = by_lds;
+  if (occ < 1) occ = 1;
+  if (const char* cap = getenv("OKX_BLOCKS_PER_CU")) {  // tuning knob: cap resident workgroups per CU
+    const int c = atoi(cap);
+    if (c >= 1 && c < occ) occ = c;
+  }
   p->blocks_per_cu = occ;
   *out = p;
   return OKX_OK;
@@ -184,16 +243,37 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   a.n_problems = n_problems;
   a.steps_per_geometry = spg;
   a.max_iter = opts->max_iter;
-  a.chain = opts->chain ? 1 : 0;
+  a.pad_ = 0;
+  {
+    const long long span = spg > 0 ? spg : n_problems;
+    long long len = opts->chain_len;
+    if (len == 0) len = opts->chain ? span : 1;
+    if (len < 0) {  // auto: one chain per resident wavefront (packed: per lane group)
+      const long long slots = (long long)p->n_cu * p->blocks_per_cu * p->groups;
+      len = (n_problems + slots - 1) / slots;
+    }
+    if (len < 1) len = 1;
+    if (len > span) len = span;
+    a.chain_len = len;
+  }
   a.step_tol = opts->step_tol;
   a.grad_tol = opts->grad_tol;
   a.ftol = opts->ftol;
   a.lambda0 = opts->lambda0;
   a.residual_tolerance = opts->residual_tolerance;
   a.phase_cycles = nullptr;
-  const long long units = a.chain ? (spg > 0 ? n_problems / spg : 1) : n_problems;
-  const int grid = grid_for(p, units);
+  const long long span_ = spg > 0 ? spg : n_problems;
+  const long long units = (n_problems / span_) * ((span_ + a.chain_len - 1) / a.chain_len);
   const okx::DevProgram* dev = p->dev;
+  if (p->groups > 1) {
+    int width = p->group_width;
+    const int grid = grid_for(p, (units + p->groups - 1) / p->groups);
+    void* kargs[] = {(void*)&dev, (void*)&a, (void*)&width};
+    HIP_TRY(hipLaunchKernel(p->solve_fn, dim3(grid), dim3(okx::kWave), kargs, p->solve_lds_bytes,
+                            (hipStream_t)stream));
+    return OKX_OK;
+  }
+  const int grid = grid_for(p, units);
   void* kargs[] = {(void*)&dev, (void*)&a};
   HIP_TRY(hipLaunchKernel(p->solve_fn, dim3(grid), dim3(okx::kWave), kargs, p->lds_bytes,
                           (hipStream_t)stream));
@@ -272,7 +352,8 @@ int32_t okx_debug_phase_profile(okx_program* p, const okx_solve_opts* opts, int6
   a.n_problems = n_problems;
   a.steps_per_geometry = 0;
   a.max_iter = opts->max_iter;
-  a.chain = 0;
+  a.pad_ = 0;
+  a.chain_len = 1;
   a.step_tol = opts->step_tol;
   a.grad_tol = opts->grad_tol;
   a.ftol = opts->ftol;
@@ -280,6 +361,16 @@ int32_t okx_debug_phase_profile(okx_program* p, const okx_solve_opts* opts, int6
   a.residual_tolerance = opts->residual_tolerance;
   a.phase_cycles = d_phase_cycles;
   const okx::DevProgram* dev = p->dev;
+  if (p->groups == 3) {
+    int width = p->group_width;
+    void* kargs[] = {(void*)&dev, (void*)&a, (void*)&width};
+    packed_kernel_t fn = okx::okx_solve_packed_kernel<18, 3, true>;
+    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)p->solve_lds_bytes);
+    HIP_TRY(hipLaunchKernel((const void*)fn, dim3(grid_for(p, (n_problems + 2) / 3)), dim3(okx::kWave),
+                            kargs, p->solve_lds_bytes, (hipStream_t)stream));
+    return OKX_OK;
+  }
   void* kargs[] = {(void*)&dev, (void*)&a};
   solve_kernel_t fn = okx::okx_solve_kernel<18, true>;
   (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);

@@ -19,6 +19,7 @@
 //
 // No MFMA: systems are tens of unknowns, fp64, block-sparse — see DESIGN.md §5.
 #include <hip/hip_runtime.h>
+#pragma once
 #include <stdint.h>
 
 #include "okx_plan.hpp"
@@ -37,7 +38,8 @@ struct SolveArgs {
   long long n_problems;
   long long steps_per_geometry;  // 0: single geometry
   int max_iter;
-  int chain;
+  int pad_;
+  long long chain_len;           // problems per warm-started chain (>= 1)
   double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
   unsigned long long* phase_cycles;  // diagnostic build only: [8] per-phase cycle sums of block 0
 };
@@ -266,8 +268,10 @@ __device__ __forceinline__ V3 dop_local_row(int type, int s, int r, double c, V3
 
 // Evaluate the listed derived ops in order.  WITH_BLOCKS also fills the chain-rule blocks
 // d(out)/d(free block) of active ops: lane (je*9 + r*3 + col) computes one entry.
+// `l` is the lane's index inside its problem group and `W` the group width (64 when one
+// wavefront owns one problem); S carries the group's own LDS slice.
 template <bool WITH_BLOCKS>
-__device__ __forceinline__ void derived_update(const DevProgram* P, const Lds& S, int lane,
+__device__ __forceinline__ void derived_update(const DevProgram* P, const Lds& S, int l, int W,
                                                bool active_only) {
   const int count = active_only ? P->n_active : P->n_derived;
   for (int idx = 0; idx < count; ++idx) {
@@ -280,8 +284,8 @@ __device__ __forceinline__ void derived_update(const DevProgram* P, const Lds& S
     if (WITH_BLOCKS) {
       const int act = P->dop_active[e];
       const int nblk = P->dop_nblk[e];
-      const int je = lane / 9, rc = lane % 9, r = rc / 3, col = rc % 3;
-      if (act >= 0 && je < nblk) {
+      for (int ent = l; act >= 0 && ent < 9 * nblk; ent += W) {
+        const int je = ent / 9, rc = ent % 9, r = rc / 3, col = rc % 3;
         double val = 0.0;
         const int nin = type == OKX_DOP_MIDPOINT ? 2 : 3;
         for (int s = 0; s < nin; ++s) {
@@ -299,11 +303,11 @@ __device__ __forceinline__ void derived_update(const DevProgram* P, const Lds& S
               }
           }
         }
-        S.dblk[act * (kDepMax * 9) + lane] = val;
+        S.dblk[act * (kDepMax * 9) + ent] = val;
       }
     }
     wave_sync();  // inputs of this op were read by every lane before its output is written
-    if (lane < 3) S.pos[3 * P->dop_out[e] + lane] = sel3(lane, o.x, o.y, o.z);
+    if (l < 3) S.pos[3 * P->dop_out[e] + l] = sel3(l, o.x, o.y, o.z);
     wave_sync();
   }
 }
@@ -529,34 +533,41 @@ __device__ __forceinline__ double row_pass(const DevProgram* P, const Lds& S, in
   return r;
 }
 
-// Full evaluation at the free vector held one-variable-per-lane in `x`.
-// Returns 0.5 * sum r^2 (uniform).
+// Evaluate every row of one problem at the free vector held one-variable-per-lane in `x`.
+// Returns this lane's partial sum of squared residuals (the caller reduces over the group).
 template <bool WITH_J>
-__device__ __forceinline__ double evaluate(const DevProgram* P, const Lds& S, int lane, double x,
-                                           int xaddr, int buf) {
+__device__ __forceinline__ double eval_rows(const DevProgram* P, const Lds& S, int l, int W,
+                                            double x, int xaddr, int buf) {
   wave_sync();
-  if (lane < P->n) S.pos[xaddr] = x;
+  if (l < P->n) S.pos[xaddr] = x;
   wave_sync();
-  derived_update<WITH_J>(P, S, lane, true);
+  derived_update<WITH_J>(P, S, l, W, true);
   double ss = 0.0;
-  for (int i = lane; i < P->m; i += kWave) {
+  for (int i = l; i < P->m; i += W) {
     const double r = row_pass<WITH_J>(P, S, i, buf);
     ss += r * r;
   }
   wave_sync();
-  return 0.5 * wave_sum(ss);
+  return ss;
+}
+
+// One problem per wavefront: returns 0.5 * sum r^2 (uniform).
+template <bool WITH_J>
+__device__ __forceinline__ double evaluate(const DevProgram* P, const Lds& S, int lane, double x,
+                                           int xaddr, int buf) {
+  return 0.5 * wave_sum(eval_rows<WITH_J>(P, S, lane, kWave, x, xaddr, buf));
 }
 
 // ------------------------------------------------------------------------------------
 // normal equations:  A (strict upper) + dA (diag) = J^T J,   g = J^T r   (lane j owns g_j)
 // ------------------------------------------------------------------------------------
 
-__device__ __forceinline__ double build_normal(const DevProgram* P, const Lds& S, int lane,
+__device__ __forceinline__ double build_normal(const DevProgram* P, const Lds& S, int l, int W,
                                                int buf, int g_begin, int g_end) {
   const double* js = S.js + (size_t)buf * P->m * P->js_stride;
   const double* rb = S.rb + buf * P->m;
   const int stride = P->js_stride;
-  for (int w = lane; w < P->n_work; w += kWave) {
+  for (int w = l; w < P->n_work; w += W) {
     const unsigned desc = S.item_desc[w];
     const int dst = S.item_dst[w];
     const int start = desc & 0xfff, count = (desc >> 12) & 0xff;
@@ -573,7 +584,7 @@ __device__ __forceinline__ double build_normal(const DevProgram* P, const Lds& S
       S.A[dst] = acc;
   }
   double g = 0.0;
-  const int a = lane % 3;
+  const int a = l % 3;
   for (int c = g_begin; c < g_end; ++c) {  // empty range for lanes >= n
     const int pk = S.gcontrib[c];
     const int row = pk & 127;
@@ -699,18 +710,18 @@ __device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S
 // problem setup helpers
 // ------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void load_geometry(const DevProgram* P, const Lds& S, int lane,
-                                              const double* gpos, const double* gparam) {
+__device__ __forceinline__ void load_geometry(const DevProgram* P, const Lds& S, int l, int W,
+                                              const double* gpos, const double* gparam,
+                                              bool enable = true) {
   wave_sync();
   const double* src = gpos ? gpos : &P->design_pos[0][0];
-  for (int e = lane; e < 3 * P->n_points; e += kWave) S.pos[e] = src[e];
+  const double* par = gparam ? gparam : &P->row_param[0][0];
   const int nc = 8 * P->n_crows;
-  if (gparam) {
-    for (int e = lane; e < nc; e += kWave) S.rowq[e] = gparam[e];
-  } else {
-    for (int e = lane; e < nc; e += kWave) S.rowq[e] = P->row_param[0][e];
+  if (enable) {
+    for (int e = l; e < 3 * P->n_points; e += W) S.pos[e] = src[e];
+    for (int e = l; e < nc; e += W) S.rowq[e] = par[e];
+    for (int e = nc + l; e < 8 * P->m; e += W) S.rowq[e] = P->row_param[0][e];
   }
-  for (int e = nc + lane; e < 8 * P->m; e += kWave) S.rowq[e] = P->row_param[0][e];
   wave_sync();
 }
 
@@ -742,8 +753,12 @@ __device__ __forceinline__ double reference_abs_residual(const DevProgram* P, co
     t_last = now_;                                              \
   }
 
+#ifndef OKX_WAVES_PER_SIMD
+#define OKX_WAVES_PER_SIMD 2
+#endif
+
 template <int NREG, bool PROFILE>
-__global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __restrict__ P,
+__global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(const DevProgram* __restrict__ P,
                                                           SolveArgs args) {
   unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = 0;
@@ -760,23 +775,29 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
   OKX_STAMP(0)
 
   const long long spg = args.steps_per_geometry;
-  const long long n_units = args.chain ? (spg > 0 ? args.n_problems / spg : 1) : args.n_problems;
-  const long long unit_len = args.chain ? (spg > 0 ? spg : args.n_problems) : 1;
+  // chains of `chain_len` consecutive problems, never across a geometry boundary
+  const long long span = spg > 0 ? spg : args.n_problems;           // problems per geometry
+  const long long unit_len = args.chain_len;                        // 1 <= chain_len <= span
+  const long long chains_per_span = (span + unit_len - 1) / unit_len;
+  const long long n_units = (args.n_problems / span) * chains_per_span;
   long long loaded_geom = -1;
 
   for (long long unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     double x = 0.0;
-    for (long long step = 0; step < unit_len; ++step) {
-      const long long b = unit * unit_len + step;
+    const long long span_idx = unit / chains_per_span;
+    const long long first = span_idx * span + (unit % chains_per_span) * unit_len;
+    const long long last = first + unit_len < (span_idx + 1) * span ? first + unit_len : (span_idx + 1) * span;
+    for (long long b = first; b < last; ++b) {
+      const long long step = b - first;
       const long long geom = spg > 0 ? b / spg : 0;
       if (geom != loaded_geom) {
-        load_geometry(P, S, lane,
+        load_geometry(P, S, lane, kWave,
                       args.geom_pos ? args.geom_pos + geom * 3 * P->n_points : nullptr,
                       args.geom_row_param ? args.geom_row_param + geom * 8 * P->n_crows : nullptr);
         loaded_geom = geom;
         // a new geometry always restarts from its own design state
         if (lane < n) x = S.pos[xaddr];
-      } else if (!args.chain || step == 0) {
+      } else if (step == 0) {
         const double* src = args.geom_pos ? args.geom_pos + geom * 3 * P->n_points
                                           : &P->design_pos[0][0];
         if (lane < n) x = src[xaddr];
@@ -827,7 +848,7 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
           if (!first) last_step = step_len;
           if (!stop) {
             OKX_STAMP(3)
-            g = build_normal(P, S, lane, cur, g_begin, g_end);
+            g = build_normal(P, S, lane, kWave, cur, g_begin, g_end);
             OKX_STAMP(4)
             if (first) {
               dmax = wave_max(lane < n ? S.dA[lane] : 0.0);
@@ -870,6 +891,13 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
         }
         OKX_STAMP(5)
         step_len = wave_max(lane < n ? fabs(dx) : 0.0);
+        if (step_len <= args.step_tol) {
+          // the Newton-type correction is already below tolerance: x is the answer and the
+          // residuals in hand belong to it (no confirming evaluation of x + dx)
+          flags |= OKX_INFO_CONVERGED;
+          last_step = step_len;
+          break;
+        }
         xt = x + dx;
       }
       OKX_STAMP(3)
@@ -878,7 +906,7 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
       wave_sync();
       if (lane < n) S.pos[xaddr] = x;
       wave_sync();
-      derived_update<false>(P, S, lane, false);
+      derived_update<false>(P, S, lane, kWave, false);
       double ra = 0.0;
       for (int i = lane; i < m; i += kWave) ra = fmax(ra, reference_abs_residual(P, S, i, cur));
       const double max_res = wave_max(ra);
@@ -895,6 +923,12 @@ __global__ void __launch_bounds__(kWave) okx_solve_kernel(const DevProgram* __re
         inf.flags = flags;
         inf.reserved = 0;
         args.info[b] = inf;
+      }
+      // a chain never continues from a state that failed to converge
+      if (!(flags & OKX_INFO_CONVERGED) || (flags & OKX_INFO_FAILED)) {
+        const double* src = args.geom_pos ? args.geom_pos + geom * 3 * P->n_points
+                                          : &P->design_pos[0][0];
+        if (lane < n) x = src[xaddr];
       }
       OKX_STAMP(6)
     }
@@ -929,7 +963,7 @@ __global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __res
   const int g_begin = lane < n ? P->g_start[lane / 3] : 0;
   const int g_end = lane < n ? P->g_start[lane / 3 + 1] : 0;
   stage_program(P, S, lane);
-  load_geometry(P, S, lane, nullptr, nullptr);
+  load_geometry(P, S, lane, kWave, nullptr, nullptr);
   for (long long b = blockIdx.x; b < args.n_problems; b += gridDim.x) {
     wave_sync();
     if (lane < T) S.tv[lane] = args.targets[b * T + lane];
@@ -947,7 +981,7 @@ __global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __res
       }
     }
     if (args.ata || args.atr) {
-      const double g = build_normal(P, S, lane, 0, g_begin, g_end);
+      const double g = build_normal(P, S, lane, kWave, 0, g_begin, g_end);
       if (args.atr && lane < n) args.atr[b * n + lane] = g;
       if (args.ata) {
         double* M = args.ata + b * (long long)n * n;
@@ -977,8 +1011,8 @@ __global__ void __launch_bounds__(kWave) okx_rebind_kernel(const DevProgram* __r
   const int lane = threadIdx.x;
   const Lds S = carve(lds_base, P);
   for (long long gidx = blockIdx.x; gidx < args.n_geometries; gidx += gridDim.x) {
-    load_geometry(P, S, lane, args.hardpoints + gidx * 3 * P->n_points, nullptr);
-    derived_update<false>(P, S, lane, false);
+    load_geometry(P, S, lane, kWave, args.hardpoints + gidx * 3 * P->n_points, nullptr);
+    derived_update<false>(P, S, lane, kWave, false);
     double* gp = args.geom_pos + gidx * 3 * P->n_points;
     for (int e = lane; e < 3 * P->n_points; e += kWave) gp[e] = S.pos[e];
     for (int i = lane; i < P->n_crows; i += kWave) {

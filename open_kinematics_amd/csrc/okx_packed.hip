@@ -1,0 +1,415 @@
+// okx_packed.hip — lane-group packed solve kernel for small systems.
+//
+// A double-wishbone corner has 18 unknowns and 21 residual rows: one problem keeps at most
+// 21 of a wavefront's 64 lanes busy and the one-problem-per-wavefront kernel
+// (okx_kernels.hip) is instruction-issue bound at that utilisation (profiles/r01).  Here a
+// wavefront hosts G = floor(64 / W) INDEPENDENT problems side by side, W = max(m, n + 1)
+// lanes each (3 for the DW corner, 4 for n <= 15 variants, 2 up to W = 32).  Each group has its
+// own LDS slice and its own Levenberg-Marquardt state; the groups run the same instruction
+// stream in lockstep (a finished group idles until its neighbours are done).
+//
+// Cross-lane traffic is group-local, so the v_readlane broadcasts of the single-problem
+// kernel do not apply.  The factorisation instead publishes each pivot column through LDS
+// (one ds_write per column, broadcast reads back), and carries the right-hand side as row n
+// of the matrix so that the forward substitution and the D^-1 scaling fall out of the
+// trailing updates; only the backward substitution broadcasts one unknown per step
+// (G v_readlane pairs + a select).  Group-wide sums/maxima are accumulated from an LDS
+// scratch line in a fixed order, so every lane of a group sees bit-identical values and
+// takes identical accept/reject decisions.
+#pragma once
+
+#include "okx_kernels.hip"
+
+namespace okx {
+
+// Extra per-group LDS behind the single-problem layout: column buffer + rhs/z buffer.
+__host__ __device__ inline int packed_group_doubles(const DevProgram& P) {
+  int s = 0;
+  s += P.n_points * 3;
+  s += P.m * 8;
+  s += (P.n_active > 0 ? P.n_active : 1) * kDepMax * 9;
+  s += 2 * P.m * P.js_stride;
+  s += 2 * P.m;
+  s += P.n * P.lda;
+  s += P.n;
+  s += kMaxTargets;
+  s += 2 * (P.n + 2);  // col[n + 1], zbuf[n + 1] (+ pad)
+  return (s + 1) & ~1;
+}
+
+__host__ __device__ inline int packed_lds_doubles(const DevProgram& P, int groups) {
+  return groups * packed_group_doubles(P) + 2 * kWave + lds_table_doubles(P) + 2;
+}
+
+struct PackedLds {
+  Lds S;           // group slice (per-lane pointers) + shared tables
+  double* col;     // [n + 1] pivot column of the group
+  double* zbuf;    // [n + 1] rhs in / z out of the group
+  double* scratch; // [2][64] wave-wide reduction scratch
+};
+
+__device__ __forceinline__ PackedLds carve_packed(double* base, const DevProgram* P, int g,
+                                                  int groups) {
+  PackedLds L;
+  double* p = base + (size_t)g * packed_group_doubles(*P);
+  L.S.pos = p;
+  p += P->n_points * 3;
+  L.S.rowq = p;
+  p += P->m * 8;
+  L.S.dblk = p;
+  p += (P->n_active > 0 ? P->n_active : 1) * kDepMax * 9;
+  L.S.js = p;
+  p += 2 * P->m * P->js_stride;
+  L.S.rb = p;
+  p += 2 * P->m;
+  L.S.A = p;
+  p += P->n * P->lda;
+  L.S.dA = p;
+  p += P->n;
+  L.S.tv = p;
+  p += kMaxTargets;
+  L.col = p;
+  p += P->n + 2;
+  L.zbuf = p;
+  double* shared = base + (size_t)groups * packed_group_doubles(*P);
+  L.scratch = shared;
+  int* q = reinterpret_cast<int*>(shared + 2 * kWave);
+  L.S.rowmeta = q;
+  q += P->m * kRowMetaStride;
+  L.S.item_dst = q;
+  q += P->n_work;
+  L.S.item_desc = reinterpret_cast<unsigned int*>(q);
+  q += P->n_work;
+  L.S.contrib = reinterpret_cast<unsigned short*>(q);
+  q += (P->n_contrib + 1) / 2;
+  L.S.gcontrib = reinterpret_cast<unsigned short*>(q);
+  return L;
+}
+
+// Sum / max of `v` over the lanes of each group; every lane of a group gets the same bits.
+__device__ __forceinline__ double group_sum(double v, double* scratch, int lane, int gbase, int W) {
+  scratch[lane] = v;
+  wave_sync();
+  double s = 0.0;
+  for (int j = 0; j < W; ++j) s += scratch[gbase + j];
+  wave_sync();
+  return s;
+}
+
+__device__ __forceinline__ double group_max(double v, double* scratch, int lane, int gbase, int W) {
+  scratch[lane] = v;
+  wave_sync();
+  double s = 0.0;
+  for (int j = 0; j < W; ++j) s = fmax(s, scratch[gbase + j]);
+  wave_sync();
+  return s;
+}
+
+// Two sums in one LDS round trip.
+__device__ __forceinline__ void group_sum2(double v0, double v1, double* scratch, int lane,
+                                           int gbase, int W, double* s0, double* s1) {
+  scratch[lane] = v0;
+  scratch[kWave + lane] = v1;
+  wave_sync();
+  double a = 0.0, b = 0.0;
+  for (int j = 0; j < W; ++j) {
+    a += scratch[gbase + j];
+    b += scratch[kWave + gbase + j];
+  }
+  wave_sync();
+  *s0 = a;
+  *s1 = b;
+}
+
+// Value of local lane k of every lane's own group (k wave-uniform).
+template <int G>
+__device__ __forceinline__ double group_bcast(double v, int k, int W, int g) {
+  double r = wave_bcast(v, k);
+  if (G > 1) {
+    const double r1 = wave_bcast(v, W + k);
+    r = g == 1 ? r1 : r;
+  }
+  if (G > 2) {
+    const double r2 = wave_bcast(v, 2 * W + k);
+    r = g == 2 ? r2 : r;
+  }
+  if (G > 3) {
+    const double r3 = wave_bcast(v, 3 * W + k);
+    r = g == 3 ? r3 : r;
+  }
+  return r;
+}
+
+// LDL^T of (A + lambda I) and solve for dx = -(A + lambda I)^-1 g, one system per lane group.
+// Local lane l < n owns matrix row l (N statically indexed registers); local lane n owns the
+// right-hand-side row.  Returns false for a group whose pivots are not all positive.
+template <int N, int G>
+__device__ __forceinline__ bool ldlt_solve_packed(const DevProgram* P, const PackedLds& L, int l,
+                                                  int W, int g, double lambda, double grad,
+                                                  double* dx) {
+  const int n = P->n, lda = P->lda;
+  const Lds& S = L.S;
+  const bool is_row = l < n, is_rhs = l == n;
+  if (is_row) L.zbuf[l] = -grad;
+  wave_sync();
+  double a[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double v = 0.0;
+    if (is_row && j < l) v = S.A[j * lda + l];
+    if (is_row && j == l) v = S.dA[l] + lambda;
+    if (is_rhs && j < n) v = L.zbuf[j];
+    a[j] = v;
+  }
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (k < n) {  // padded columns do not exist (uniform skip keeps the loop fully unrolled)
+      if (l >= k && l <= n) L.col[l] = a[k];
+      wave_sync();
+      const double pivot = L.col[k];
+      const bool good = pivot > 0.0;
+      ok = ok && good;
+      const double rinv = good ? 1.0 / pivot : 0.0;
+      const double lk = a[k] * rinv;
+#pragma unroll
+      for (int j = k + 1; j < N; ++j)
+        if (j < n) a[j] -= lk * L.col[j];
+      if (l > k) {
+        a[k] = lk;  // L[l][k]; for the rhs row this is z_k = (D^-1 L^-1 rhs)_k
+        if (is_row) S.A[l * lda + k] = lk;
+      }
+      wave_sync();  // column buffer is reused by the next column
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    if (is_rhs && k < n) L.zbuf[k] = a[k];
+  wave_sync();
+  double b = is_row ? L.zbuf[l] : 0.0;
+  double lt[N];  // lt[k] = L[k][l] for k > l (row k of the factor, read column-wise)
+#pragma unroll
+  for (int k = 0; k < N; ++k) lt[k] = (is_row && k < n && l < k) ? S.A[k * lda + l] : 0.0;
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {  // L^T dx = z
+    if (k < n) {
+      const double dk = group_bcast<G>(b, k, W, g);
+      b -= lt[k] * dk;
+    }
+  }
+  *dx = b;
+  return ok;
+}
+
+template <int N, int G, bool PROFILE>
+__global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_kernel(const DevProgram* __restrict__ P,
+                                                                 SolveArgs args, int W) {
+  unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = 0;
+  if constexpr (PROFILE) t_last = __builtin_readcyclecounter();
+  extern __shared__ double lds_base[];
+  const int lane = threadIdx.x;
+  const bool valid = lane < G * W;
+  const int g = valid ? lane / W : G - 1;
+  const int gbase = g * W;
+  const int l = valid ? lane - gbase : (1 << 20);  // idle lanes fall out of every l-bounded loop
+  const PackedLds L = carve_packed(lds_base, P, g, G);
+  const Lds& S = L.S;
+  const int n = P->n, m = P->m, T = P->n_targets;
+  const bool is_var = l < n;
+  const int xaddr = is_var ? 3 * P->free_point[l / 3] + l % 3 : 0;
+  const int g_begin = is_var ? P->g_start[l / 3] : 0;
+  const int g_end = is_var ? P->g_start[l / 3 + 1] : 0;
+
+  // shared tables (all lanes cooperate), then zero every group's matrix
+  {
+    Lds T0 = S;
+    stage_program(P, T0, lane);  // also zeroes group G-1.. matrices via S.A of each lane's group
+    for (int e = l; e < n * P->lda; e += W) S.A[e] = 0.0;
+    wave_sync();
+  }
+  OKX_STAMP(0)
+
+  const long long spg = args.steps_per_geometry;
+  // chains of `chain_len` consecutive problems, never across a geometry boundary
+  const long long span = spg > 0 ? spg : args.n_problems;           // problems per geometry
+  const long long unit_len = args.chain_len;                        // 1 <= chain_len <= span
+  const long long chains_per_span = (span + unit_len - 1) / unit_len;
+  const long long n_units = (args.n_problems / span) * chains_per_span;
+  long long loaded_geom = -1;
+
+  for (long long unit0 = (long long)blockIdx.x * G; unit0 < n_units;
+       unit0 += (long long)gridDim.x * G) {
+    const long long unit = unit0 + g;
+    const bool unit_ok = valid && unit < n_units;
+    double x = 0.0;
+    const long long span_idx = unit_ok ? unit / chains_per_span : 0;
+    const long long first = span_idx * span + (unit_ok ? unit % chains_per_span : 0) * unit_len;
+    const long long last = first + unit_len < (span_idx + 1) * span ? first + unit_len : (span_idx + 1) * span;
+    for (long long step = 0; step < unit_len; ++step) {
+      const bool has_unit = unit_ok && first + step < last;
+      const long long b = has_unit ? first + step : 0;
+      const long long geom = spg > 0 ? b / spg : 0;
+      const bool reload = has_unit && geom != loaded_geom;
+      const double* gp = args.geom_pos ? args.geom_pos + geom * 3 * P->n_points : nullptr;
+      const double* gq = args.geom_row_param ? args.geom_row_param + geom * 8 * P->n_crows : nullptr;
+      if (__any(reload)) load_geometry(P, S, l, W, gp, gq, reload);
+      if (reload) {
+        loaded_geom = geom;
+        if (is_var) x = S.pos[xaddr];  // a new geometry restarts from its own design state
+      } else if (has_unit && step == 0) {
+        const double* src = gp ? gp : &P->design_pos[0][0];
+        if (is_var) x = src[xaddr];
+      }
+      wave_sync();
+      if (has_unit && l < T) S.tv[l] = args.targets[b * T + l];
+      wave_sync();
+      OKX_STAMP(1)
+
+      int cur = 1, nfev = 0, iters = 0, flags = 0;
+      double F = 0.0, grad = 0.0, dx = 0.0, lambda = 0.0, dmax = 0.0, nu = 2.0;
+      double last_step = 0.0, step_len = 0.0;
+      double xt = x;
+      bool first = true;
+      bool done = !has_unit;
+      for (;;) {
+        const double ss = eval_rows<true>(P, S, l, W, xt, xaddr, cur ^ 1);
+        OKX_STAMP(2)
+        double Ft, pred;
+        group_sum2(valid ? ss : 0.0, is_var ? dx * (lambda * dx - grad) : 0.0, L.scratch, lane, gbase,
+                   W, &Ft, &pred);
+        Ft *= 0.5;
+        pred *= 0.5;
+        if (!done) ++nfev;
+        bool accept, stop = false;
+        double rho = 1.0;
+        if (first) {
+          accept = true;
+        } else {
+          const bool finite = Ft == Ft && step_len == step_len && Ft < 1e300;
+          const bool small = finite && step_len <= 1e-8 && Ft <= F * (1.0 + 1e-6) + 1e-28;
+          rho = (finite && pred > 0.0) ? (F - Ft) / pred : -1.0;
+          accept = rho > 1e-4 || small;
+          if (finite && step_len <= args.step_tol) {
+            accept = small;
+            if (!done) flags |= OKX_INFO_CONVERGED;
+            stop = true;
+          } else if (accept && finite && F - Ft <= args.ftol * F && pred <= args.ftol * F) {
+            if (!done) flags |= OKX_INFO_CONVERGED;
+            stop = true;
+          }
+        }
+        accept = accept && !done;
+        if (accept) {
+          x = xt;
+          F = Ft;
+          cur ^= 1;
+          if (!first) last_step = step_len;
+        }
+        const bool rebuild = accept && !stop;
+        OKX_STAMP(3)
+        if (__any(rebuild)) {
+          // groups that did not accept keep their matrix: evaluate into a dummy predicate
+          const double gnew = build_normal(P, S, rebuild ? l : (1 << 20), W, cur,
+                                           rebuild ? g_begin : 0, rebuild ? g_end : 0);
+          if (rebuild) grad = gnew;
+        }
+        OKX_STAMP(4)
+        if (rebuild) {
+          nu = 2.0;
+          if (!first && rho > 1e-4) {
+            const double t = 2.0 * rho - 1.0;
+            lambda *= fmax(1.0 / 3.0, 1.0 - t * t * t);
+          }
+        }
+        if (first) {
+          dmax = group_max(is_var ? S.dA[is_var ? l : 0] : 0.0, L.scratch, lane, gbase, W);
+          lambda = args.lambda0 * dmax;
+        }
+        if (!accept && !stop && !done && !first) {
+          lambda *= nu;
+          nu *= 2.0;
+        }
+        first = false;
+        if (stop) done = true;
+        if (!done && iters >= args.max_iter) done = true;
+        if (__all(done)) break;
+        if (!done) ++iters;
+        OKX_STAMP(3)
+        // damped normal equations; a group whose factorisation fails retries with more damping
+        bool have = done;
+        double dx_new = 0.0;
+        for (int tries = 0; tries < 60; ++tries) {
+          double cand;
+          const bool ok = ldlt_solve_packed<N, G>(P, L, l, W, g, lambda, grad, &cand);
+          if (!have) {
+            if (ok) {
+              dx_new = cand;
+              have = true;
+            } else {
+              lambda = fmax(lambda * 10.0, 1e-12 * dmax);
+              if (!(lambda < 1e30)) {
+                flags |= OKX_INFO_FAILED;
+                done = true;
+                have = true;
+              }
+            }
+          }
+          if (__all(have)) break;
+        }
+        if (!have) {
+          flags |= OKX_INFO_FAILED;
+          done = true;
+        }
+        OKX_STAMP(5)
+        dx = done ? 0.0 : dx_new;
+        step_len = group_max(is_var ? fabs(dx) : 0.0, L.scratch, lane, gbase, W);
+        if (!done && step_len <= args.step_tol) {  // correction below tolerance: x is the answer
+          flags |= OKX_INFO_CONVERGED;
+          last_step = step_len;
+          done = true;
+          dx = 0.0;
+        }
+        if (__all(done)) break;
+        xt = x + dx;
+      }
+
+      OKX_STAMP(3)
+      // final state: free points, then every derived point (incl. output-only ones)
+      wave_sync();
+      if (is_var) S.pos[xaddr] = x;
+      wave_sync();
+      derived_update<false>(P, S, l, W, false);
+      double ra = 0.0;
+      for (int i = l; i < m; i += W) ra = fmax(ra, reference_abs_residual(P, S, i, cur));
+      const double max_res = group_max(valid ? ra : 0.0, L.scratch, lane, gbase, W);
+      if (max_res > args.residual_tolerance) flags |= OKX_INFO_RESIDUAL_EXCEEDED;
+      if (has_unit) {
+        double* out = args.out_pos + b * 3 * P->n_out;
+        for (int e = l; e < 3 * P->n_out; e += W) out[e] = S.pos[3 * P->out_point[e / 3] + e % 3];
+        if (l == 0) {
+          okx_info inf;
+          inf.max_residual = max_res;
+          inf.cost = F;
+          inf.last_step = last_step;
+          inf.iterations = iters;
+          inf.nfev = nfev;
+          inf.flags = flags;
+          inf.reserved = 0;
+          args.info[b] = inf;
+        }
+        if (!(flags & OKX_INFO_CONVERGED) || (flags & OKX_INFO_FAILED)) {
+          const double* src = gp ? gp : &P->design_pos[0][0];
+          if (is_var) x = src[xaddr];
+        }
+      }
+      OKX_STAMP(6)
+    }
+  }
+  if constexpr (PROFILE) {
+    if (blockIdx.x == 0 && lane == 0 && args.phase_cycles)
+      for (int k = 0; k < 8; ++k) args.phase_cycles[k] = phase[k];
+  }
+}
+
+}  // namespace okx

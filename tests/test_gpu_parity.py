@@ -131,6 +131,32 @@ def test_chain_mode_follows_reference_warm_start(golden):
     assert info_c["iterations"].mean() < info_i["iterations"].mean()
 
 
+@pytest.mark.parametrize("chain_len", [-1, 1, 7, 50, 101, 1000])
+def test_chunked_chains_give_the_same_answers(golden, chain_len):
+    """Consecutive steps grouped into warm-started chains of any length (incl. ragged tails)."""
+    arrays, program = golden("c1_dw_corner")
+    pinned = program.with_line_mode("pinned")
+    pos_i, _ = _solve(pinned, arrays["targets_abs"], chain_len=1)
+    pos_c, info = _solve(pinned, arrays["targets_abs"], chain_len=chain_len)
+    assert np.all((info["flags"] & 7) == 1)
+    assert np.max(np.abs(pos_c - pos_i)) <= 1e-9
+
+
+def test_chains_never_cross_geometries(golden):
+    arrays, program = golden("c5_ensemble")
+    pinned = program.with_line_mode("pinned")
+    dp = _device_program(pinned)
+    gpos, gparam = dp.rebind(torch.as_tensor(arrays["hardpoints"]))
+    g, s = arrays["targets_abs"].shape[:2]
+    t = torch.as_tensor(arrays["targets_abs"].reshape(g * s, -1))
+    ref = dp.solve(t, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=s, chain_len=1)
+    for chain_len in (4, 9, 100):
+        res = dp.solve(t, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=s, chain_len=chain_len)
+        torch.cuda.synchronize()
+        assert np.all((res.info()["flags"] & 7) == 1)
+        assert float((res.positions - ref.positions).abs().max()) <= 1e-9
+
+
 def test_e2e_golden_csv_of_the_reference(golden):
     arrays, program = golden("e2e_sweep")
     pos, info = _solve(program.with_line_mode("pinned"), arrays["targets_abs"])
