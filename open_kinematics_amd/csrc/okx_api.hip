@@ -52,7 +52,8 @@ typedef void (*packed_kernel_t)(const okx::DevProgram*, okx::SolveArgs, int);
 // (okx_packed.hip).  OKX_FORCE_SINGLE=1 in the environment pins the one-problem kernel.
 void select_solve_kernel(okx_program* p) {
   const int n = p->host.n, m = p->host.m;
-  const int width = m > n + 1 ? m : n + 1;
+  const int npad = n <= 15 ? 15 : n <= 18 ? 18 : n <= 21 ? 21 : 24;  // register row length
+  const int width = m > npad + 1 ? m : npad + 1;                      // rhs row lives at lane npad
   int groups = 64 / width;
   if (groups > 4) groups = 4;
   // The packed kernel is opt-in (OKX_PACKED=1): on MI355X it is LDS-capacity limited to
@@ -337,8 +338,9 @@ int32_t okx_rebind_design(okx_program* p, int64_t n_geometries, const double* d_
 
 /* Diagnostic (not part of the reference boundary): same as okx_solve_batch for an n = 18
    program, but runs the stamped kernel instantiation and returns per-phase cycle sums of
-   workgroup 0 in d_phase_cycles[8]: 0 staging, 1 problem setup, 2 evaluate, 3 LM logic,
-   4 normal equations, 5 factor + solve, 6 output. */
+   workgroup 0 in d_phase_cycles[12]: 0 staging, 1 problem setup, 2 x->pos + derived points,
+   3 rows, 4 reductions + LM logic, 5 normal equations, 6 factorisation, 7 substitutions,
+   8 output. */
 int32_t okx_debug_phase_profile(okx_program* p, const okx_solve_opts* opts, int64_t n_problems,
                                 const double* d_targets, double* d_out_pos, okx_info* d_info,
                                 unsigned long long* d_phase_cycles, void* stream) {

@@ -89,11 +89,60 @@ __device__ __forceinline__ double wave_max(double v) {
 
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
+// Diagnostic phase timer (only alive in the PROFILE instantiation; a null pointer folds away).
+struct Prof {
+  unsigned long long phase[12];
+  unsigned long long t;
+};
+__device__ __forceinline__ void stamp(Prof* prof, int slot) {
+  if (prof) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    prof->phase[slot] += now - prof->t;
+    prof->t = now;
+  }
+}
+
 __device__ __forceinline__ double sel3(int r, double a, double b, double c) {
   return r == 0 ? a : (r == 1 ? b : c);
 }
 
 __device__ __forceinline__ double softnorm(double s) { return sqrt(s + OKX_EPS_SQ) - OKX_EPS; }
+
+// 1/x to ~1 ulp from the v_rcp_f64 seed and two Newton steps.  The IEEE divide sequence
+// (v_div_scale / v_div_fmas / v_div_fixup) sits on every dependent chain of this kernel at
+// ~200 cycles; operands here are well-scaled lengths and pivots (never denormal, never huge),
+// which is all the scaling/fix-up steps protect against.
+__device__ __forceinline__ double fast_rcp(double x) {
+#if defined(OKX_IEEE_MATH)
+  return 1.0 / x;
+#endif
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(e, r, r);
+  e = fma(-x, r, 1.0);
+  return fma(e, r, r);
+}
+
+// sqrt(x) and 1/sqrt(x) together (Goldschmidt from the v_rsq_f64 seed), x > 0 well scaled.
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double* root, double* inv) {
+#if defined(OKX_IEEE_MATH)
+  *root = sqrt(x);
+  *inv = 1.0 / *root;
+  return;
+#endif
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  *root = g;
+  *inv = h + h;
+}
 
 struct V3 {
   double x, y, z;
@@ -109,6 +158,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 // LDS carve-up (offsets in doubles; sizes from DevProgram)
 // ------------------------------------------------------------------------------------
 
+constexpr int kColBuf = 26;         // N + 1 entries for N <= 24, padded to an even count
 constexpr int kRowMetaStride = 15;  // ints per row: type, pts[4], nblk, 4 x PointRef (odd stride)
 
 struct Lds {
@@ -120,16 +170,22 @@ struct Lds {
   double* A;      // [n][lda]  strict upper: J^T J; lower: factor L (unit lower for LDL^T)
   double* dA;     // [n]       diag(J^T J)
   double* tv;     // [T]       targets of the current problem
+  double* col;    // [kColBuf] pivot column being broadcast by the factorisation
+  double* zbuf;   // [kColBuf] right-hand side in / z out
   // program tables staged once per workgroup (static for the whole launch)
   int* rowmeta;              // [m][kRowMetaStride]
   int* item_dst;             // [n_work]
-  unsigned int* item_desc;   // [n_work]
-  unsigned short* contrib;   // [n_contrib]
-  unsigned short* gcontrib;  // [n_gcontrib]
+  unsigned int* item_terms;  // [n_work][kc]  offA | offB << 16 into one Jacobian buffer
+  unsigned int* grad_terms;  // [n][kg]       offJ | row << 16
 };
 
+// One Jacobian buffer = m rows + the always-zero slot the padded plan terms point at; one
+// residual buffer = m residuals + a zero.
+__host__ __device__ inline int js_buf_doubles(const DevProgram& P) { return P.zero_off + 1; }
+__host__ __device__ inline int rb_buf_doubles(const DevProgram& P) { return P.m + 1; }
+
 __host__ __device__ inline int lds_table_doubles(const DevProgram& P) {
-  int ints = P.m * kRowMetaStride + 2 * P.n_work + (P.n_contrib + 1) / 2 + (P.n_gcontrib + 1) / 2 + 2;
+  int ints = P.m * kRowMetaStride + P.n_work + P.n_work * P.kc + P.n * P.kg + 6;
   return (ints + 1) / 2;
 }
 
@@ -138,13 +194,26 @@ __host__ __device__ inline int lds_doubles(const DevProgram& P) {
   s += P.n_points * 3;
   s += P.m * 8;
   s += (P.n_active > 0 ? P.n_active : 1) * kDepMax * 9;
-  s += 2 * P.m * P.js_stride;
-  s += 2 * P.m;
+  s += 2 * js_buf_doubles(P);
+  s += 2 * rb_buf_doubles(P);
   s += P.n * P.lda;
   s += P.n;
   s += kMaxTargets;
+  s += 2 * kColBuf;
+  s = (s + 1) & ~1;
   s += lds_table_doubles(P);
   return (s + 1) & ~1;
+}
+
+// Shared, launch-static tables: 16-byte aligned term tables first (read with ds_read_b128).
+__device__ __forceinline__ void carve_tables(int* q, const DevProgram* P, Lds* S) {
+  S->item_terms = reinterpret_cast<unsigned int*>(q);
+  q += P->n_work * P->kc;
+  S->grad_terms = reinterpret_cast<unsigned int*>(q);
+  q += P->n * P->kg;
+  S->item_dst = q;
+  q += P->n_work;
+  S->rowmeta = q;
 }
 
 __device__ __forceinline__ Lds carve(double* base, const DevProgram* P) {
@@ -157,25 +226,21 @@ __device__ __forceinline__ Lds carve(double* base, const DevProgram* P) {
   S.dblk = p;
   p += (P->n_active > 0 ? P->n_active : 1) * kDepMax * 9;
   S.js = p;
-  p += 2 * P->m * P->js_stride;
+  p += 2 * js_buf_doubles(*P);
   S.rb = p;
-  p += 2 * P->m;
+  p += 2 * rb_buf_doubles(*P);
   S.A = p;
   p += P->n * P->lda;
   S.dA = p;
   p += P->n;
   S.tv = p;
   p += kMaxTargets;
-  int* q = reinterpret_cast<int*>(p);
-  S.rowmeta = q;
-  q += P->m * kRowMetaStride;
-  S.item_dst = q;
-  q += P->n_work;
-  S.item_desc = reinterpret_cast<unsigned int*>(q);
-  q += P->n_work;
-  S.contrib = reinterpret_cast<unsigned short*>(q);
-  q += (P->n_contrib + 1) / 2;
-  S.gcontrib = reinterpret_cast<unsigned short*>(q);
+  S.col = p;
+  p += kColBuf;
+  S.zbuf = p;
+  p += kColBuf;
+  p = base + (((p - base) + 1) & ~1);
+  carve_tables(reinterpret_cast<int*>(p), P, &S);
   return S;
 }
 
@@ -192,14 +257,21 @@ __device__ __forceinline__ void stage_program(const DevProgram* P, const Lds& S,
       r[6 + 2 * k] = (int)P->row_in[i][k].w0;
       r[7 + 2 * k] = (int)P->row_in[i][k].w1;
     }
+    r[14] = (int)P->row_first[i];
   }
-  for (int w = lane; w < P->n_work; w += kWave) {
-    S.item_dst[w] = P->item_dst[w];
-    S.item_desc[w] = P->item_desc[w];
+  for (int w = lane; w < P->n_work; w += kWave) S.item_dst[w] = P->item_dst[w];
+  for (int e = lane; e < P->n_work * P->kc; e += kWave) S.item_terms[e] = P->item_terms[e];
+  for (int e = lane; e < P->n * P->kg; e += kWave) S.grad_terms[e] = P->grad_terms[e];
+  __syncthreads();
+}
+
+// Per-problem slice: zero the matrix (structural zeros stay zero) and the padding slots.
+__device__ __forceinline__ void init_slice(const DevProgram* P, const Lds& S, int l, int W) {
+  for (int e = l; e < P->n * P->lda; e += W) S.A[e] = 0.0;
+  if (l < 2) {
+    S.js[l * js_buf_doubles(*P) + P->zero_off] = 0.0;
+    S.rb[l * rb_buf_doubles(*P) + P->m] = 0.0;
   }
-  for (int c = lane; c < P->n_contrib; c += kWave) S.contrib[c] = P->contrib[c];
-  for (int c = lane; c < P->n_gcontrib; c += kWave) S.gcontrib[c] = P->g_contrib[c];
-  for (int e = lane; e < P->n * P->lda; e += kWave) S.A[e] = 0.0;
   __syncthreads();
 }
 
@@ -218,39 +290,42 @@ __device__ __forceinline__ V3 dop_position(int type, const int* pts, double c, c
   if (type == OKX_DOP_ALONG) {  // definitions.py:24-33, :92-155
     V3 base = ld3(pos + 3 * pts[0]);
     V3 v = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[2]));
-    double nrm = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
-    V3 u = {v.x / nrm, v.y / nrm, v.z / nrm};
+    double nrm, inrm;
+    fast_sqrt_rsqrt(v.x * v.x + v.y * v.y + v.z * v.z, &nrm, &inrm);
+    V3 u = {v.x * inrm, v.y * inrm, v.z * inrm};
     *u_out = u;
-    *nrm_out = nrm;
+    *nrm_out = inrm;  // callers want 1/|v|
     return {base.x + u.x * c, base.y + u.y * c, base.z + u.z * c};
   }
   // OKX_DOP_CONTACT_PATCH: definitions.py:36-73, :158-180
   V3 wc = ld3(pos + 3 * pts[0]);
   V3 v = sub(ld3(pos + 3 * pts[2]), ld3(pos + 3 * pts[1]));
-  double vn = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
-  V3 a = {v.x / vn, v.y / vn, v.z / vn};
+  double vn, ivn;
+  fast_sqrt_rsqrt(v.x * v.x + v.y * v.y + v.z * v.z, &vn, &ivn);
+  V3 a = {v.x * ivn, v.y * ivn, v.z * ivn};
   double ga = -a.z;  // (0,0,-1) . a
   V3 wd = {-ga * a.x, -ga * a.y, -1.0 - ga * a.z};
-  double wn = sqrt(wd.x * wd.x + wd.y * wd.y + wd.z * wd.z);
-  V3 wu = {wd.x / wn, wd.y / wn, wd.z / wn};
+  double wn, iwn;
+  fast_sqrt_rsqrt(wd.x * wd.x + wd.y * wd.y + wd.z * wd.z, &wn, &iwn);
+  V3 wu = {wd.x * iwn, wd.y * iwn, wd.z * iwn};
   *u_out = wu;
-  *nrm_out = wn;
+  *nrm_out = iwn;  // callers want the inverse norms
   *a_out = a;
-  *vn_out = vn;
+  *vn_out = ivn;
   *ga_out = ga;
   return {wc.x + wu.x * c, wc.y + wu.y * c, wc.z + wu.z * c};
 }
 
-// Row r of the local 3x3 block d(out)/d(input s) of a derived op.
-__device__ __forceinline__ V3 dop_local_row(int type, int s, int r, double c, V3 u, double nrm,
-                                            V3 a, double vn, double ga) {
+// Row r of the local 3x3 block d(out)/d(input s) of a derived op (inrm, ivn: INVERSE norms).
+__device__ __forceinline__ V3 dop_local_row(int type, int s, int r, double c, V3 u, double inrm,
+                                            V3 a, double ivn, double ga) {
   V3 e = {r == 0 ? 1.0 : 0.0, r == 1 ? 1.0 : 0.0, r == 2 ? 1.0 : 0.0};
   if (type == OKX_DOP_MIDPOINT) return {0.5 * e.x, 0.5 * e.y, 0.5 * e.z};
   if (type == OKX_DOP_ALONG) {
     if (s == 0) return e;
     // d normalize(v)/dv = (I - u u^T)/|v|, scaled by c; input 2 enters v with a minus sign
     double ur = sel3(r, u.x, u.y, u.z);
-    double k = (s == 1 ? c : -c) / nrm;
+    double k = (s == 1 ? c : -c) * inrm;
     return {k * (e.x - ur * u.x), k * (e.y - ur * u.y), k * (e.z - ur * u.z)};
   }
   // contact patch: input 0 = wheel centre (identity), 1 = axle inboard (-T), 2 = axle outboard (+T)
@@ -258,11 +333,11 @@ __device__ __forceinline__ V3 dop_local_row(int type, int s, int r, double c, V3
   // T = c * Nw * Wa * Na,  Nw = (I - wu wu^T)/wn (u,nrm hold wu,wn), Wa = a e_z^T - ga I,
   // Na = (I - a a^T)/vn
   double wr = sel3(r, u.x, u.y, u.z);
-  V3 nw = {(e.x - wr * u.x) / nrm, (e.y - wr * u.y) / nrm, (e.z - wr * u.z) / nrm};
+  V3 nw = {(e.x - wr * u.x) * inrm, (e.y - wr * u.y) * inrm, (e.z - wr * u.z) * inrm};
   double nwa = dot(nw, a);
   V3 mrow = {-ga * nw.x, -ga * nw.y, nwa - ga * nw.z};  // M[r][q] = d_q2 (Nw_r.a) - ga Nw[r][q]
   double ma = dot(mrow, a);
-  double k = (s == 2 ? c : -c) / vn;
+  double k = (s == 2 ? c : -c) * ivn;
   return {k * (mrow.x - ma * a.x), k * (mrow.y - ma * a.y), k * (mrow.z - ma * a.z)};
 }
 
@@ -328,9 +403,9 @@ __device__ __forceinline__ double row_eval(int type, const int* pts, const doubl
     case OKX_ROW_SPHERICAL: {  // constraints.py:125-134,162-170; jacobians.py:35-51
       V3 d = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[0]));
       double s = d.x * d.x + d.y * d.y + d.z * d.z;
-      double root = sqrt(s + OKX_EPS_SQ);
+      double root, inv;
+      fast_sqrt_rsqrt(s + OKX_EPS_SQ, &root, &inv);
       if (WITH_J) {
-        double inv = 1.0 / root;
         dp[0] = -d.x * inv, dp[1] = -d.y * inv, dp[2] = -d.z * inv;
         dp[3] = d.x * inv, dp[4] = d.y * inv, dp[5] = d.z * inv;
       }
@@ -350,11 +425,12 @@ __device__ __forceinline__ double row_eval(int type, const int* pts, const doubl
       V3 c = cross(v1, v2);
       double c2 = c.x * c.x + c.y * c.y + c.z * c.z;
       double t15 = OKX_EPS_SQ + c2;
-      double s = sqrt(t15);
+      double s, is;
+      fast_sqrt_rsqrt(t15, &s, &is);
       double dt = dot(v1, v2);
       if (WITH_J) {
-        double inv = 1.0 / (t15 + dt * dt);
-        double ka = dt * inv / s, kb = s * inv;
+        double inv = fast_rcp(t15 + dt * dt);
+        double ka = dt * inv * is, kb = s * inv;
         V3 w1 = cross(v2, c), w2 = cross(c, v1);
         V3 g1 = {ka * w1.x - kb * v2.x, ka * w1.y - kb * v2.y, ka * w1.z - kb * v2.z};
         V3 g2 = {ka * w2.x - kb * v1.x, ka * w2.y - kb * v1.y, ka * w2.z - kb * v1.z};
@@ -429,9 +505,9 @@ __device__ __forceinline__ double row_eval(int type, const int* pts, const doubl
       V3 c = cross(w, ld);
       if (type == OKX_ROW_POINT_ON_LINE) {
         double c2 = dot(c, c);
-        double root = sqrt(OKX_EPS_SQ + c2);
+        double root, inv;
+        fast_sqrt_rsqrt(OKX_EPS_SQ + c2, &root, &inv);
         if (WITH_J) {
-          double inv = 1.0 / root;
           V3 g = cross(ld, c);
           dp[0] = inv * g.x, dp[1] = inv * g.y, dp[2] = inv * g.z;
         }
@@ -501,11 +577,10 @@ __device__ __forceinline__ double row_pass(const DevProgram* P, const Lds& S, in
   const int pts[4] = {meta[1], meta[2], meta[3], meta[4]};
   const double* q = S.rowq + 8 * i;
   double r = row_eval<WITH_J>(type, pts, q, S.pos, S.tv, dp);
-  S.rb[buf * P->m + i] = r;
+  S.rb[buf * rb_buf_doubles(*P) + i] = r;
   if (WITH_J) {
-    double* jr = S.js + (size_t)(buf * P->m + i) * P->js_stride;
-    const int nb3 = 3 * meta[5];
-    for (int k = 0; k < nb3; ++k) jr[k] = 0.0;
+    double* jr = S.js + (size_t)buf * js_buf_doubles(*P) + (size_t)i * P->js_stride;
+    const unsigned first = (unsigned)meta[14];  // bit (4 s + j): this write is the first to its slot
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       PointRef ref;
@@ -515,17 +590,32 @@ __device__ __forceinline__ double row_pass(const DevProgram* P, const Lds& S, in
       const double d0 = dp[3 * s], d1 = dp[3 * s + 1], d2 = dp[3 * s + 2];
       if (ref.kind() == kRefFree) {
         double* dst = jr + 3 * ref.slot();
-        dst[0] += d0;
-        dst[1] += d1;
-        dst[2] += d2;
+        if ((first >> (4 * s)) & 1) {  // plain stores: no LDS read on the dependent chain
+          dst[0] = d0;
+          dst[1] = d1;
+          dst[2] = d2;
+        } else {
+          dst[0] += d0;
+          dst[1] += d1;
+          dst[2] += d2;
+        }
       } else {  // point_partial @ block (solver.py:554-558)
         const double* src = S.dblk + P->dop_active[ref.src()] * (kDepMax * 9);
         for (int js = 0; js < ref.nsrc(); ++js) {
           const double* B = src + 9 * js;
           double* dst = jr + 3 * ref.map(js);
-          dst[0] += d0 * B[0] + d1 * B[3] + d2 * B[6];
-          dst[1] += d0 * B[1] + d1 * B[4] + d2 * B[7];
-          dst[2] += d0 * B[2] + d1 * B[5] + d2 * B[8];
+          const double v0 = d0 * B[0] + d1 * B[3] + d2 * B[6];
+          const double v1 = d0 * B[1] + d1 * B[4] + d2 * B[7];
+          const double v2 = d0 * B[2] + d1 * B[5] + d2 * B[8];
+          if ((first >> (4 * s + js)) & 1) {
+            dst[0] = v0;
+            dst[1] = v1;
+            dst[2] = v2;
+          } else {
+            dst[0] += v0;
+            dst[1] += v1;
+            dst[2] += v2;
+          }
         }
       }
     }
@@ -537,25 +627,27 @@ __device__ __forceinline__ double row_pass(const DevProgram* P, const Lds& S, in
 // Returns this lane's partial sum of squared residuals (the caller reduces over the group).
 template <bool WITH_J>
 __device__ __forceinline__ double eval_rows(const DevProgram* P, const Lds& S, int l, int W,
-                                            double x, int xaddr, int buf) {
+                                            double x, int xaddr, int buf, Prof* prof = nullptr) {
   wave_sync();
   if (l < P->n) S.pos[xaddr] = x;
   wave_sync();
   derived_update<WITH_J>(P, S, l, W, true);
+  stamp(prof, 2);
   double ss = 0.0;
   for (int i = l; i < P->m; i += W) {
     const double r = row_pass<WITH_J>(P, S, i, buf);
     ss += r * r;
   }
   wave_sync();
+  stamp(prof, 3);
   return ss;
 }
 
 // One problem per wavefront: returns 0.5 * sum r^2 (uniform).
 template <bool WITH_J>
 __device__ __forceinline__ double evaluate(const DevProgram* P, const Lds& S, int lane, double x,
-                                           int xaddr, int buf) {
-  return 0.5 * wave_sum(eval_rows<WITH_J>(P, S, lane, kWave, x, xaddr, buf));
+                                           int xaddr, int buf, Prof* prof = nullptr) {
+  return 0.5 * wave_sum(eval_rows<WITH_J>(P, S, lane, kWave, x, xaddr, buf, prof));
 }
 
 // ------------------------------------------------------------------------------------
@@ -563,32 +655,42 @@ __device__ __forceinline__ double evaluate(const DevProgram* P, const Lds& S, in
 // ------------------------------------------------------------------------------------
 
 __device__ __forceinline__ double build_normal(const DevProgram* P, const Lds& S, int l, int W,
-                                               int buf, int g_begin, int g_end) {
-  const double* js = S.js + (size_t)buf * P->m * P->js_stride;
-  const double* rb = S.rb + buf * P->m;
-  const int stride = P->js_stride;
+                                               int buf, bool is_var) {
+  const double* js = S.js + (size_t)buf * js_buf_doubles(*P);
+  const double* rb = S.rb + buf * rb_buf_doubles(*P);
+  const int kc = P->kc, kg = P->kg;
   for (int w = l; w < P->n_work; w += W) {
-    const unsigned desc = S.item_desc[w];
-    const int dst = S.item_dst[w];
-    const int start = desc & 0xfff, count = (desc >> 12) & 0xff;
-    const int a = (desc >> 20) & 3, b = (desc >> 22) & 3;
+    const uint4* terms = reinterpret_cast<const uint4*>(S.item_terms + (size_t)w * kc);
     double acc = 0.0;
-    for (int c = start; c < start + count; ++c) {
-      const int pk = S.contrib[c];
-      const double* jr = js + (pk & 127) * stride;
-      acc += jr[3 * ((pk >> 7) & 7) + a] * jr[3 * ((pk >> 10) & 7) + b];
+#pragma unroll
+    for (int c4 = 0; c4 < kItemTermsMax / 4; ++c4) {
+      if (4 * c4 < kc) {  // uniform
+        const uint4 t = terms[c4];
+        acc += js[t.x & 0xffff] * js[t.x >> 16];
+        acc += js[t.y & 0xffff] * js[t.y >> 16];
+        acc += js[t.z & 0xffff] * js[t.z >> 16];
+        acc += js[t.w & 0xffff] * js[t.w >> 16];
+      }
     }
+    const int dst = S.item_dst[w];
     if (dst < 0)
       S.dA[-dst - 1] = acc;
     else
       S.A[dst] = acc;
   }
   double g = 0.0;
-  const int a = l % 3;
-  for (int c = g_begin; c < g_end; ++c) {  // empty range for lanes >= n
-    const int pk = S.gcontrib[c];
-    const int row = pk & 127;
-    g += js[row * stride + 3 * ((pk >> 7) & 7) + a] * rb[row];
+  if (is_var) {
+    const uint4* terms = reinterpret_cast<const uint4*>(S.grad_terms + (size_t)l * kg);
+#pragma unroll
+    for (int c4 = 0; c4 < kGradTermsMax / 4; ++c4) {
+      if (4 * c4 < kg) {
+        const uint4 t = terms[c4];
+        g += js[t.x & 0xffff] * rb[t.x >> 16];
+        g += js[t.y & 0xffff] * rb[t.y >> 16];
+        g += js[t.z & 0xffff] * rb[t.z >> 16];
+        g += js[t.w & 0xffff] * rb[t.w >> 16];
+      }
+    }
   }
   wave_sync();
   return g;
@@ -652,6 +754,12 @@ __device__ __forceinline__ double chol_solve(const DevProgram* P, const Lds& S, 
 // The unit-lower factor is also streamed to LDS (fire and forget) because the backward
 // substitution needs COLUMN access, i.e. row k of L as seen by lane i < k.
 // Returns false (uniformly) when a pivot is not positive; otherwise *dx = -(A + lambda I)^-1 g.
+//
+// Measured alternatives (profiles/r01/ldlt_variants.md): carrying the right-hand side as an
+// extra row, a branch-free pivot test, a software-pipelined pivot reciprocal and broadcasting
+// the pivot column through LDS were all slower in this kernel — each v_readlane operand needs an
+// SGPR pair, and without the per-column exit branch below acting as a scheduling fence hipcc
+// hoists later columns' broadcasts until the scalar file spills (v_writelane) inside the loop.
 template <int N>
 __device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S, int lane,
                                                double lambda, double g, double* dx) {
@@ -675,7 +783,7 @@ __device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S
       ok = false;
       break;
     }
-    const double rinv = 1.0 / pivot;
+    const double rinv = fast_rcp(pivot);
     const double lk = a[k] * rinv;  // L[lane][k] for lanes > k
 #pragma unroll
     for (int j = k + 1; j < N; ++j) a[j] -= lk * wave_bcast(a[k], j);
@@ -729,7 +837,7 @@ __device__ __forceinline__ void load_geometry(const DevProgram* P, const Lds& S,
 // reported as the single softnorm point-on-line residual (constraints.py:560-576).
 __device__ __forceinline__ double reference_abs_residual(const DevProgram* P, const Lds& S,
                                                          int i, int buf) {
-  double r = S.rb[buf * P->m + i];
+  double r = S.rb[buf * rb_buf_doubles(*P) + i];
   const int* meta = S.rowmeta + i * kRowMetaStride;
   if (meta[0] == OKX_ROW_LINE_PIN) {
     const double* q = S.rowq + 8 * i;
@@ -746,32 +854,30 @@ __device__ __forceinline__ double reference_abs_residual(const DevProgram* P, co
 
 // PROFILE = true is a separate diagnostic instantiation: s_memtime stamps around the phases of
 // block 0, summed into args.phase_cycles (never used by the product path or the bench).
-#define OKX_STAMP(slot)                                         \
-  if constexpr (PROFILE) {                                      \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    phase[slot] += now_ - t_last;                               \
-    t_last = now_;                                              \
-  }
+#define OKX_STAMP(slot) stamp(prof, slot);
 
 #ifndef OKX_WAVES_PER_SIMD
 #define OKX_WAVES_PER_SIMD 2
 #endif
 
+
 template <int NREG, bool PROFILE>
 __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(const DevProgram* __restrict__ P,
                                                           SolveArgs args) {
-  unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t_last = 0;
-  if constexpr (PROFILE) t_last = __builtin_readcyclecounter();
+  Prof prof_store;
+  Prof* prof = nullptr;
+  if constexpr (PROFILE) {
+    for (int k = 0; k < 12; ++k) prof_store.phase[k] = 0;
+    prof_store.t = __builtin_readcyclecounter();
+    prof = &prof_store;
+  }
   extern __shared__ double lds_base[];
   const int lane = threadIdx.x;
   const Lds S = carve(lds_base, P);
   const int n = P->n, m = P->m, T = P->n_targets;
   const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
-  const int g_begin = lane < n ? P->g_start[lane / 3] : 0;
-  const int g_end = lane < n ? P->g_start[lane / 3 + 1] : 0;
-
   stage_program(P, S, lane);
+  init_slice(P, S, lane, kWave);
   OKX_STAMP(0)
 
   const long long spg = args.steps_per_geometry;
@@ -816,9 +922,8 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(co
       double xt = x;
       bool first = true;
       for (;;) {
-        const double Ft = evaluate<true>(P, S, lane, xt, xaddr, cur ^ 1);
+        const double Ft = evaluate<true>(P, S, lane, xt, xaddr, cur ^ 1, prof);
         ++nfev;
-        OKX_STAMP(2)
         bool accept;
         bool stop = false;
         double rho = 1.0;
@@ -847,9 +952,9 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(co
           cur ^= 1;
           if (!first) last_step = step_len;
           if (!stop) {
-            OKX_STAMP(3)
-            g = build_normal(P, S, lane, kWave, cur, g_begin, g_end);
             OKX_STAMP(4)
+            g = build_normal(P, S, lane, kWave, cur, lane < n);
+            OKX_STAMP(5)
             if (first) {
               dmax = wave_max(lane < n ? S.dA[lane] : 0.0);
               lambda = args.lambda0 * dmax;
@@ -871,13 +976,14 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(co
         if (stop) break;
         if (iters >= args.max_iter) break;
         ++iters;
-        OKX_STAMP(3)
+        OKX_STAMP(4)
         // damped normal equations; enlarge lambda until the factorisation succeeds
         bool ok = false;
         for (int tries = 0; tries < 60; ++tries) {
           if (!(lambda < 1e30)) break;
           if constexpr (NREG > 0) {
             ok = ldlt_solve_reg<NREG>(P, S, lane, lambda, g, &dx);
+            stamp(prof, 6);
           } else {
             ok = factorize(P, S, lane, lambda);
             if (ok) dx = chol_solve(P, S, lane, -g);
@@ -889,7 +995,7 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(co
           flags |= OKX_INFO_FAILED;
           break;
         }
-        OKX_STAMP(5)
+        OKX_STAMP(7)
         step_len = wave_max(lane < n ? fabs(dx) : 0.0);
         if (step_len <= args.step_tol) {
           // the Newton-type correction is already below tolerance: x is the answer and the
@@ -900,7 +1006,7 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(co
         }
         xt = x + dx;
       }
-      OKX_STAMP(3)
+      OKX_STAMP(4)
 
       // final state: free points, then every derived point (incl. output-only ones)
       wave_sync();
@@ -930,12 +1036,12 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(co
                                           : &P->design_pos[0][0];
         if (lane < n) x = src[xaddr];
       }
-      OKX_STAMP(6)
+      OKX_STAMP(8)
     }
   }
   if constexpr (PROFILE) {
     if (blockIdx.x == 0 && lane == 0 && args.phase_cycles)
-      for (int k = 0; k < 8; ++k) args.phase_cycles[k] = phase[k];
+      for (int k = 0; k < 12; ++k) args.phase_cycles[k] = prof_store.phase[k];
   }
 }
 
@@ -960,9 +1066,8 @@ __global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __res
   const Lds S = carve(lds_base, P);
   const int n = P->n, m = P->m, T = P->n_targets;
   const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
-  const int g_begin = lane < n ? P->g_start[lane / 3] : 0;
-  const int g_end = lane < n ? P->g_start[lane / 3 + 1] : 0;
   stage_program(P, S, lane);
+  init_slice(P, S, lane, kWave);
   load_geometry(P, S, lane, kWave, nullptr, nullptr);
   for (long long b = blockIdx.x; b < args.n_problems; b += gridDim.x) {
     wave_sync();
@@ -981,7 +1086,7 @@ __global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __res
       }
     }
     if (args.ata || args.atr) {
-      const double g = build_normal(P, S, lane, kWave, 0, g_begin, g_end);
+      const double g = build_normal(P, S, lane, kWave, 0, lane < n);
       if (args.atr && lane < n) args.atr[b * n + lane] = g;
       if (args.ata) {
         double* M = args.ata + b * (long long)n * n;

@@ -28,12 +28,12 @@ __host__ __device__ inline int packed_group_doubles(const DevProgram& P) {
   s += P.n_points * 3;
   s += P.m * 8;
   s += (P.n_active > 0 ? P.n_active : 1) * kDepMax * 9;
-  s += 2 * P.m * P.js_stride;
-  s += 2 * P.m;
+  s += 2 * js_buf_doubles(P);
+  s += 2 * rb_buf_doubles(P);
   s += P.n * P.lda;
   s += P.n;
   s += kMaxTargets;
-  s += 2 * (P.n + 2);  // col[n + 1], zbuf[n + 1] (+ pad)
+  s += 2 * kColBuf;
   return (s + 1) & ~1;
 }
 
@@ -43,8 +43,6 @@ __host__ __device__ inline int packed_lds_doubles(const DevProgram& P, int group
 
 struct PackedLds {
   Lds S;           // group slice (per-lane pointers) + shared tables
-  double* col;     // [n + 1] pivot column of the group
-  double* zbuf;    // [n + 1] rhs in / z out of the group
   double* scratch; // [2][64] wave-wide reduction scratch
 };
 
@@ -59,30 +57,21 @@ __device__ __forceinline__ PackedLds carve_packed(double* base, const DevProgram
   L.S.dblk = p;
   p += (P->n_active > 0 ? P->n_active : 1) * kDepMax * 9;
   L.S.js = p;
-  p += 2 * P->m * P->js_stride;
+  p += 2 * js_buf_doubles(*P);
   L.S.rb = p;
-  p += 2 * P->m;
+  p += 2 * rb_buf_doubles(*P);
   L.S.A = p;
   p += P->n * P->lda;
   L.S.dA = p;
   p += P->n;
   L.S.tv = p;
   p += kMaxTargets;
-  L.col = p;
-  p += P->n + 2;
-  L.zbuf = p;
+  L.S.col = p;
+  p += kColBuf;
+  L.S.zbuf = p;
   double* shared = base + (size_t)groups * packed_group_doubles(*P);
   L.scratch = shared;
-  int* q = reinterpret_cast<int*>(shared + 2 * kWave);
-  L.S.rowmeta = q;
-  q += P->m * kRowMetaStride;
-  L.S.item_dst = q;
-  q += P->n_work;
-  L.S.item_desc = reinterpret_cast<unsigned int*>(q);
-  q += P->n_work;
-  L.S.contrib = reinterpret_cast<unsigned short*>(q);
-  q += (P->n_contrib + 1) / 2;
-  L.S.gcontrib = reinterpret_cast<unsigned short*>(q);
+  carve_tables(reinterpret_cast<int*>(shared + 2 * kWave), P, &L.S);
   return L;
 }
 
@@ -140,73 +129,78 @@ __device__ __forceinline__ double group_bcast(double v, int k, int W, int g) {
   return r;
 }
 
-// LDL^T of (A + lambda I) and solve for dx = -(A + lambda I)^-1 g, one system per lane group.
-// Local lane l < n owns matrix row l (N statically indexed registers); local lane n owns the
-// right-hand-side row.  Returns false for a group whose pivots are not all positive.
-template <int N, int G>
-__device__ __forceinline__ bool ldlt_solve_packed(const DevProgram* P, const PackedLds& L, int l,
-                                                  int W, int g, double lambda, double grad,
-                                                  double* dx) {
+// LDL^T with the pivot column broadcast through LDS.  Lane i keeps row i in N statically
+// indexed registers; per column every lane publishes its entry with one ds_write and reads the
+// column back as broadcast ds_reads, so all operands stay in VGPRs (the v_readlane variant
+// below needs an SGPR pair per operand and spills scalars inside the loop).  Lanes n..N-1 are
+// identity padding rows, lane N carries the right-hand side -g, so the forward substitution and
+// the D^-1 scaling fall out of the trailing updates.  Branch-free, statically indexed.
+// BCAST(v, k): value of (group-local) lane k.
+template <int N, typename Bcast>
+__device__ __forceinline__ bool ldlt_solve_lds(const DevProgram* P, const Lds& S, int l,
+                                               double lambda, double grad, double* dx, Bcast bcast,
+                                               Prof* prof = nullptr) {
   const int n = P->n, lda = P->lda;
-  const Lds& S = L.S;
-  const bool is_row = l < n, is_rhs = l == n;
-  if (is_row) L.zbuf[l] = -grad;
+  const bool is_row = l < n, is_pad = l >= n && l < N, is_rhs = l == N;
+  if (l < N) S.zbuf[l] = is_row ? -grad : 0.0;
   wave_sync();
   double a[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     double v = 0.0;
-    if (is_row && j < l) v = S.A[j * lda + l];
+    if (is_row && j < l) v = S.A[j * lda + l];  // upper-triangle storage of the symmetric matrix
     if (is_row && j == l) v = S.dA[l] + lambda;
-    if (is_rhs && j < n) v = L.zbuf[j];
+    if (is_pad && j == l) v = 1.0;
+    if (is_rhs) v = S.zbuf[j];
     a[j] = v;
   }
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    if (k < n) {  // padded columns do not exist (uniform skip keeps the loop fully unrolled)
-      if (l >= k && l <= n) L.col[l] = a[k];
-      wave_sync();
-      const double pivot = L.col[k];
-      const bool good = pivot > 0.0;
-      ok = ok && good;
-      const double rinv = good ? 1.0 / pivot : 0.0;
-      const double lk = a[k] * rinv;
+    if (l >= k && l <= N) S.col[l] = a[k];
+    wave_sync();
+    const double pivot = S.col[k];
+    const bool good = pivot > 0.0;
+    ok = ok && good;
+    const double rinv = fast_rcp(good ? pivot : 1.0);
+    const double lk = a[k] * rinv;  // L[l][k] for rows > k; z_k for the rhs row
 #pragma unroll
-      for (int j = k + 1; j < N; ++j)
-        if (j < n) a[j] -= lk * L.col[j];
-      if (l > k) {
-        a[k] = lk;  // L[l][k]; for the rhs row this is z_k = (D^-1 L^-1 rhs)_k
-        if (is_row) S.A[l * lda + k] = lk;
-      }
-      wave_sync();  // column buffer is reused by the next column
+    for (int j = k + 1; j < N; ++j) a[j] -= lk * S.col[j];
+    if (l > k) {
+      a[k] = lk;
+      if (is_row) S.A[l * lda + k] = lk;
     }
+    wave_sync();  // the column buffer is reused by the next column
   }
+  stamp(prof, 6);
 #pragma unroll
   for (int k = 0; k < N; ++k)
-    if (is_rhs && k < n) L.zbuf[k] = a[k];
+    if (is_rhs) S.zbuf[k] = a[k];
   wave_sync();
-  double b = is_row ? L.zbuf[l] : 0.0;
+  double b = is_row ? S.zbuf[l] : 0.0;
   double lt[N];  // lt[k] = L[k][l] for k > l (row k of the factor, read column-wise)
 #pragma unroll
   for (int k = 0; k < N; ++k) lt[k] = (is_row && k < n && l < k) ? S.A[k * lda + l] : 0.0;
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {  // L^T dx = z
-    if (k < n) {
-      const double dk = group_bcast<G>(b, k, W, g);
-      b -= lt[k] * dk;
-    }
+    const double dk = bcast(b, k);
+    b -= lt[k] * dk;
   }
   *dx = b;
+  stamp(prof, 7);
   return ok;
 }
 
 template <int N, int G, bool PROFILE>
 __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_kernel(const DevProgram* __restrict__ P,
                                                                  SolveArgs args, int W) {
-  unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t_last = 0;
-  if constexpr (PROFILE) t_last = __builtin_readcyclecounter();
+  Prof prof_store;
+  Prof* prof = nullptr;
+  if constexpr (PROFILE) {
+    for (int k = 0; k < 12; ++k) prof_store.phase[k] = 0;
+    prof_store.t = __builtin_readcyclecounter();
+    prof = &prof_store;
+  }
   extern __shared__ double lds_base[];
   const int lane = threadIdx.x;
   const bool valid = lane < G * W;
@@ -218,16 +212,10 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_ke
   const int n = P->n, m = P->m, T = P->n_targets;
   const bool is_var = l < n;
   const int xaddr = is_var ? 3 * P->free_point[l / 3] + l % 3 : 0;
-  const int g_begin = is_var ? P->g_start[l / 3] : 0;
-  const int g_end = is_var ? P->g_start[l / 3 + 1] : 0;
 
-  // shared tables (all lanes cooperate), then zero every group's matrix
-  {
-    Lds T0 = S;
-    stage_program(P, T0, lane);  // also zeroes group G-1.. matrices via S.A of each lane's group
-    for (int e = l; e < n * P->lda; e += W) S.A[e] = 0.0;
-    wave_sync();
-  }
+  // shared tables (all lanes cooperate), then every group initialises its own slice
+  stage_program(P, S, lane);
+  init_slice(P, S, l, W);
   OKX_STAMP(0)
 
   const long long spg = args.steps_per_geometry;
@@ -273,8 +261,7 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_ke
       bool first = true;
       bool done = !has_unit;
       for (;;) {
-        const double ss = eval_rows<true>(P, S, l, W, xt, xaddr, cur ^ 1);
-        OKX_STAMP(2)
+        const double ss = eval_rows<true>(P, S, l, W, xt, xaddr, cur ^ 1, prof);
         double Ft, pred;
         group_sum2(valid ? ss : 0.0, is_var ? dx * (lambda * dx - grad) : 0.0, L.scratch, lane, gbase,
                    W, &Ft, &pred);
@@ -307,14 +294,13 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_ke
           if (!first) last_step = step_len;
         }
         const bool rebuild = accept && !stop;
-        OKX_STAMP(3)
+        OKX_STAMP(4)
         if (__any(rebuild)) {
           // groups that did not accept keep their matrix: evaluate into a dummy predicate
-          const double gnew = build_normal(P, S, rebuild ? l : (1 << 20), W, cur,
-                                           rebuild ? g_begin : 0, rebuild ? g_end : 0);
+          const double gnew = build_normal(P, S, rebuild ? l : (1 << 20), W, cur, rebuild && is_var);
           if (rebuild) grad = gnew;
         }
-        OKX_STAMP(4)
+        OKX_STAMP(5)
         if (rebuild) {
           nu = 2.0;
           if (!first && rho > 1e-4) {
@@ -335,13 +321,14 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_ke
         if (!done && iters >= args.max_iter) done = true;
         if (__all(done)) break;
         if (!done) ++iters;
-        OKX_STAMP(3)
+        OKX_STAMP(4)
         // damped normal equations; a group whose factorisation fails retries with more damping
         bool have = done;
         double dx_new = 0.0;
         for (int tries = 0; tries < 60; ++tries) {
           double cand;
-          const bool ok = ldlt_solve_packed<N, G>(P, L, l, W, g, lambda, grad, &cand);
+          const bool ok = ldlt_solve_lds<N>(P, S, l, lambda, grad, &cand,
+                                            [W, g](double v, int k) { return group_bcast<G>(v, k, W, g); });
           if (!have) {
             if (ok) {
               dx_new = cand;
@@ -361,7 +348,7 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_ke
           flags |= OKX_INFO_FAILED;
           done = true;
         }
-        OKX_STAMP(5)
+        OKX_STAMP(6)
         dx = done ? 0.0 : dx_new;
         step_len = group_max(is_var ? fabs(dx) : 0.0, L.scratch, lane, gbase, W);
         if (!done && step_len <= args.step_tol) {  // correction below tolerance: x is the answer
@@ -374,7 +361,7 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_ke
         xt = x + dx;
       }
 
-      OKX_STAMP(3)
+      OKX_STAMP(4)
       // final state: free points, then every derived point (incl. output-only ones)
       wave_sync();
       if (is_var) S.pos[xaddr] = x;
@@ -403,12 +390,12 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_ke
           if (is_var) x = src[xaddr];
         }
       }
-      OKX_STAMP(6)
+      OKX_STAMP(8)
     }
   }
   if constexpr (PROFILE) {
     if (blockIdx.x == 0 && lane == 0 && args.phase_cycles)
-      for (int k = 0; k < 8; ++k) args.phase_cycles[k] = phase[k];
+      for (int k = 0; k < 12; ++k) args.phase_cycles[k] = prof_store.phase[k];
   }
 }
 

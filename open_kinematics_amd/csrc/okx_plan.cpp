@@ -306,6 +306,65 @@ int build_dev_program(const okx_program_desc* d, DevProgram* out, char* err, int
   out->n_work = nw;
   out->n_contrib = nc;
   out->n_gcontrib = ng;
+
+  // ---- batched-load tables ----
+  const int stride = out->js_stride;
+  out->zero_off = m * stride;
+  int kc = 1, kg = 1;
+  for (int pr = 0; pr < np; ++pr) kc = std::max(kc, out->pair_start[pr + 1] - out->pair_start[pr]);
+  for (int k = 0; k < F; ++k) kg = std::max(kg, out->g_start[k + 1] - out->g_start[k]);
+  kc = (kc + 3) / 4 * 4;
+  kg = (kg + 3) / 4 * 4;
+  if (kc > kItemTermsMax || kg > kGradTermsMax)
+    FAIL(OKX_ERR_LIMIT, "a free point takes part in too many rows (%d / %d product terms)", kc, kg);
+  if (out->zero_off + 1 >= (1 << 16)) FAIL(OKX_ERR_LIMIT, "Jacobian buffer too large for 16-bit offsets");
+  out->kc = kc;
+  out->kg = kg;
+  for (int w = 0; w < nw; ++w) {
+    const uint32_t desc = out->item_desc[w];
+    const int start = desc & 0xfff, count = (desc >> 12) & 0xff, a = (desc >> 20) & 3, b = (desc >> 22) & 3;
+    for (int c = 0; c < kc; ++c) {
+      uint32_t term = (uint32_t)out->zero_off | ((uint32_t)out->zero_off << 16);
+      if (c < count) {
+        const int pk = out->contrib[start + c];
+        const int row = pk & 127, sp = (pk >> 7) & 7, sq = (pk >> 10) & 7;
+        term = (uint32_t)(row * stride + 3 * sp + a) | ((uint32_t)(row * stride + 3 * sq + b) << 16);
+      }
+      out->item_terms[w * kc + c] = term;
+    }
+  }
+  for (int v = 0; v < n; ++v) {
+    const int blk = v / 3, a = v % 3;
+    const int start = out->g_start[blk], count = out->g_start[blk + 1] - start;
+    for (int c = 0; c < kg; ++c) {
+      uint32_t term = (uint32_t)out->zero_off | ((uint32_t)m << 16);
+      if (c < count) {
+        const int pk = out->g_contrib[start + c];
+        const int row = pk & 127, sl = (pk >> 7) & 7;
+        term = (uint32_t)(row * stride + 3 * sl + a) | ((uint32_t)row << 16);
+      }
+      out->grad_terms[v * kg + c] = term;
+    }
+  }
+  // first-writer masks of the row scatter (program order: point slot, then producer block)
+  for (int i = 0; i < m; ++i) {
+    bool written[kRowBlkMax] = {false, false, false, false, false, false};
+    uint32_t mask = 0;
+    const int npts = points_of_row_type(out->row_type[i]);
+    for (int sl = 0; sl < npts; ++sl) {
+      const PointRef ref = out->row_in[i][sl];
+      if (ref.kind() == kRefFree) {
+        if (!written[ref.slot()]) mask |= 1u << (4 * sl);
+        written[ref.slot()] = true;
+      } else if (ref.kind() == kRefDerived) {
+        for (int j = 0; j < ref.nsrc(); ++j) {
+          if (!written[ref.map(j)]) mask |= 1u << (4 * sl + j);
+          written[ref.map(j)] = true;
+        }
+      }
+    }
+    out->row_first[i] = mask;
+  }
   return OKX_OK;
 }
 

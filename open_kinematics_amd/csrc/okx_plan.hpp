@@ -34,6 +34,8 @@ constexpr int kMaxPairs = kMaxFree * (kMaxFree + 1) / 2;
 constexpr int kMaxContrib = kMaxRows * (kRowBlkMax * (kRowBlkMax + 1) / 2);
 constexpr int kMaxGContrib = kMaxRows * kRowBlkMax;
 constexpr int kRowTarget = OKX_ROW_TYPE_COUNT;  // internal row type of a target row
+constexpr int kItemTermsMax = 16;
+constexpr int kGradTermsMax = 16;
 
 enum : int { kRefFixed = 0, kRefFree = 1, kRefDerived = 2 };
 
@@ -94,6 +96,17 @@ struct DevProgram {
   int32_t pad2;
   int32_t item_dst[kMaxPairs * 9];      // >= 0: offset into A (row * lda + col); < 0: -(1 + diag index)
   uint32_t item_desc[kMaxPairs * 9];    // start | count << 12 | a << 20 | b << 22
+
+  // Batched-load form of the same plans: every product term is a pair of absolute offsets
+  // into one Jacobian buffer, padded per item to `kc` terms with the always-zero slot, so a
+  // lane can issue all loads of an item at once instead of walking a dependent list.
+  int32_t kc;                            // terms per J^T J item (multiple of 4, <= kItemTermsMax)
+  int32_t kg;                            // terms per J^T r variable (multiple of 4, <= kGradTermsMax)
+  int32_t zero_off;                      // offset of the zero slot inside a Jacobian buffer (= m * js_stride)
+  int32_t pad3;
+  uint32_t row_first[kMaxRows];          // scatter: bit (4 s + j) set = that write is the first to its slot
+  uint32_t item_terms[kMaxPairs * 9 * kItemTermsMax];  // offA | offB << 16
+  uint32_t grad_terms[kMaxVars * kGradTermsMax];       // offJ | row << 16  (row = m: zero residual slot)
 
   double design_pos[kMaxPoints][3];
 };
