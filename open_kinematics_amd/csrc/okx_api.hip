@@ -99,9 +99,15 @@ void select_solve_kernel(okx_program* p) {
   } else if (n <= 24) {
     fn = okx::okx_solve_kernel<24, false>;
     p->nreg = 24;
+  } else if (n <= 36) {
+    fn = okx::okx_solve_kernel<36, false>;
+    p->nreg = 36;
+  } else if (n <= 48) {
+    fn = okx::okx_solve_kernel<48, false>;
+    p->nreg = 48;
   } else {
-    fn = okx::okx_solve_kernel<0, false>;
-    p->nreg = 0;
+    fn = okx::okx_solve_kernel<63, false>;
+    p->nreg = 63;
   }
   p->solve_fn = (const void*)fn;
 }

@@ -167,7 +167,8 @@ struct Lds {
   double* dblk;   // [n_active][kDepMax][3][3]
   double* js;     // [2][m][js_stride]
   double* rb;     // [2][m]
-  double* A;      // [n][lda]  strict upper: J^T J; lower: factor L (unit lower for LDL^T)
+  double* A;      // [n(n-1)/2] packed strict triangle, entry (i, j < i) at i(i-1)/2 + j:
+                  //            J^T J before the factorisation loads it, then the factor L in place
   double* dA;     // [n]       diag(J^T J)
   double* tv;     // [T]       targets of the current problem
   double* col;    // [kColBuf] pivot column being broadcast by the factorisation
@@ -175,17 +176,19 @@ struct Lds {
   // program tables staged once per workgroup (static for the whole launch)
   int* rowmeta;              // [m][kRowMetaStride]
   int* item_dst;             // [n_work]
-  unsigned int* item_terms;  // [n_work][kc]  offA | offB << 16 into one Jacobian buffer
-  unsigned int* grad_terms;  // [n][kg]       offJ | row << 16
+  const unsigned int* item_terms;  // GLOBAL (L1/L2 resident) [n_work][kc]  offA | offB << 16
+  const unsigned int* grad_terms;  // GLOBAL [n][kg]       offJ | row << 16
 };
 
 // One Jacobian buffer = m rows + the always-zero slot the padded plan terms point at; one
 // residual buffer = m residuals + a zero.
 __host__ __device__ inline int js_buf_doubles(const DevProgram& P) { return P.zero_off + 1; }
 __host__ __device__ inline int rb_buf_doubles(const DevProgram& P) { return P.m + 1; }
+__host__ __device__ inline int tri_doubles(const DevProgram& P) { return P.n * (P.n - 1) / 2 + 1; }
+__host__ __device__ inline int tri(int i, int j) { return i * (i - 1) / 2 + j; }  // j < i
 
 __host__ __device__ inline int lds_table_doubles(const DevProgram& P) {
-  int ints = P.m * kRowMetaStride + P.n_work + P.n_work * P.kc + P.n * P.kg + 6;
+  int ints = P.m * kRowMetaStride + P.n_work + 2;
   return (ints + 1) / 2;
 }
 
@@ -194,9 +197,9 @@ __host__ __device__ inline int lds_doubles(const DevProgram& P) {
   s += P.n_points * 3;
   s += P.m * 8;
   s += (P.n_active > 0 ? P.n_active : 1) * kDepMax * 9;
-  s += 2 * js_buf_doubles(P);
+  s += js_buf_doubles(P);
   s += 2 * rb_buf_doubles(P);
-  s += P.n * P.lda;
+  s += tri_doubles(P);
   s += P.n;
   s += kMaxTargets;
   s += 2 * kColBuf;
@@ -207,10 +210,8 @@ __host__ __device__ inline int lds_doubles(const DevProgram& P) {
 
 // Shared, launch-static tables: 16-byte aligned term tables first (read with ds_read_b128).
 __device__ __forceinline__ void carve_tables(int* q, const DevProgram* P, Lds* S) {
-  S->item_terms = reinterpret_cast<unsigned int*>(q);
-  q += P->n_work * P->kc;
-  S->grad_terms = reinterpret_cast<unsigned int*>(q);
-  q += P->n * P->kg;
+  S->item_terms = P->item_terms;  // launch-static: read straight from HBM through L1/L2,
+  S->grad_terms = P->grad_terms;  // every load of an item is issued at once (no dependent walk)
   S->item_dst = q;
   q += P->n_work;
   S->rowmeta = q;
@@ -226,11 +227,11 @@ __device__ __forceinline__ Lds carve(double* base, const DevProgram* P) {
   S.dblk = p;
   p += (P->n_active > 0 ? P->n_active : 1) * kDepMax * 9;
   S.js = p;
-  p += 2 * js_buf_doubles(*P);
+  p += js_buf_doubles(*P);
   S.rb = p;
   p += 2 * rb_buf_doubles(*P);
   S.A = p;
-  p += P->n * P->lda;
+  p += tri_doubles(*P);
   S.dA = p;
   p += P->n;
   S.tv = p;
@@ -260,18 +261,14 @@ __device__ __forceinline__ void stage_program(const DevProgram* P, const Lds& S,
     r[14] = (int)P->row_first[i];
   }
   for (int w = lane; w < P->n_work; w += kWave) S.item_dst[w] = P->item_dst[w];
-  for (int e = lane; e < P->n_work * P->kc; e += kWave) S.item_terms[e] = P->item_terms[e];
-  for (int e = lane; e < P->n * P->kg; e += kWave) S.grad_terms[e] = P->grad_terms[e];
   __syncthreads();
 }
 
 // Per-problem slice: zero the matrix (structural zeros stay zero) and the padding slots.
 __device__ __forceinline__ void init_slice(const DevProgram* P, const Lds& S, int l, int W) {
-  for (int e = l; e < P->n * P->lda; e += W) S.A[e] = 0.0;
-  if (l < 2) {
-    S.js[l * js_buf_doubles(*P) + P->zero_off] = 0.0;
-    S.rb[l * rb_buf_doubles(*P) + P->m] = 0.0;
-  }
+  for (int e = l; e < tri_doubles(*P); e += W) S.A[e] = 0.0;
+  if (l < 2) S.rb[l * rb_buf_doubles(*P) + P->m] = 0.0;
+  if (l == 0) S.js[P->zero_off] = 0.0;
   __syncthreads();
 }
 
@@ -579,7 +576,7 @@ __device__ __forceinline__ double row_pass(const DevProgram* P, const Lds& S, in
   double r = row_eval<WITH_J>(type, pts, q, S.pos, S.tv, dp);
   S.rb[buf * rb_buf_doubles(*P) + i] = r;
   if (WITH_J) {
-    double* jr = S.js + (size_t)buf * js_buf_doubles(*P) + (size_t)i * P->js_stride;
+    double* jr = S.js + (size_t)i * P->js_stride;  // one Jacobian buffer: a rejected trial never needs the old J
     const unsigned first = (unsigned)meta[14];  // bit (4 s + j): this write is the first to its slot
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -656,9 +653,12 @@ __device__ __forceinline__ double evaluate(const DevProgram* P, const Lds& S, in
 
 __device__ __forceinline__ double build_normal(const DevProgram* P, const Lds& S, int l, int W,
                                                int buf, bool is_var) {
-  const double* js = S.js + (size_t)buf * js_buf_doubles(*P);
+  const double* js = S.js;
   const double* rb = S.rb + buf * rb_buf_doubles(*P);
   const int kc = P->kc, kg = P->kg;
+  // the triangle still holds the previous factor: clear it, then scatter the new J^T J entries
+  for (int e = l; e < tri_doubles(*P); e += W) S.A[e] = 0.0;
+  wave_sync();
   for (int w = l; w < P->n_work; w += W) {
     const uint4* terms = reinterpret_cast<const uint4*>(S.item_terms + (size_t)w * kc);
     double acc = 0.0;
@@ -696,59 +696,7 @@ __device__ __forceinline__ double build_normal(const DevProgram* P, const Lds& S
   return g;
 }
 
-// Cholesky of (A + lambda I) into the lower triangle (diag holds 1/L_kk).  Lane i owns row i.
-// Returns false (uniformly) when a pivot is not positive.
-__device__ __forceinline__ bool factorize(const DevProgram* P, const Lds& S, int lane,
-                                          double lambda) {
-  const int n = P->n, lda = P->lda;
-  double* A = S.A;
-  // lower <- upper (structural zeros of the factor's fill-in are reset here)
-  if (lane < n)
-    for (int j = 0; j < lane; ++j) A[lane * lda + j] = A[j * lda + lane];
-  wave_sync();
-  bool ok = true;
-  for (int k = 0; k < n; ++k) {
-    double s = 0.0;
-    if (lane >= k && lane < n) {
-      s = lane == k ? S.dA[k] + lambda : A[lane * lda + k];
-      const double* rowi = A + lane * lda;
-      const double* rowk = A + k * lda;
-      for (int j = 0; j < k; ++j) s -= rowi[j] * rowk[j];
-    }
-    const double pivot = wave_bcast(s, k);
-    if (!(pivot > 0.0)) {
-      ok = false;
-      break;
-    }
-    const double inv = 1.0 / sqrt(pivot);
-    if (lane > k && lane < n) A[lane * lda + k] = s * inv;
-    if (lane == k) A[k * lda + k] = inv;
-    wave_sync();
-  }
-  return ok;
-}
-
-// Solve (L L^T) d = rhs with lane i holding rhs_i; returns d_i in lane i.
-__device__ __forceinline__ double chol_solve(const DevProgram* P, const Lds& S, int lane,
-                                             double rhs) {
-  const int n = P->n, lda = P->lda;
-  const double* A = S.A;
-  const double invd = lane < n ? A[lane * lda + lane] : 0.0;
-  double b = lane < n ? rhs : 0.0;
-  for (int k = 0; k < n; ++k) {  // forward: L y = rhs
-    const double yk = wave_bcast(b * invd, k);
-    if (lane > k && lane < n) b -= A[lane * lda + k] * yk;
-    if (lane == k) b = yk;
-  }
-  for (int k = n - 1; k >= 0; --k) {  // backward: L^T d = y
-    const double dk = wave_bcast(b * invd, k);
-    if (lane < k) b -= A[k * lda + lane] * dk;
-    if (lane == k) b = dk;
-  }
-  return b;
-}
-
-// Register-resident LDL^T for small systems (n <= N <= 24).  Lane i keeps row i of the
+// Register-resident LDL^T (n <= N <= 63).  Lane i keeps row i of the
 // matrix in N statically indexed registers; every cross-lane operand is a v_readlane
 // broadcast, so the factorisation never waits on LDS.  Rows >= n are padded with identity.
 // The unit-lower factor is also streamed to LDS (fire and forget) because the backward
@@ -763,14 +711,14 @@ __device__ __forceinline__ double chol_solve(const DevProgram* P, const Lds& S, 
 template <int N>
 __device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S, int lane,
                                                double lambda, double g, double* dx) {
-  const int n = P->n, lda = P->lda;
+  const int n = P->n;
   double a[N];
   const bool live = lane < n;
   const double diag = live ? S.dA[live ? lane : 0] + lambda : 1.0;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     double v = 0.0;
-    if (live && j < lane) v = S.A[j * lda + lane];  // upper-triangle storage of the symmetric matrix
+    if (live && j < lane) v = S.A[tri(lane, j)];
     if (j == lane) v = diag;
     a[j] = v;
   }
@@ -790,14 +738,11 @@ __device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S
     if (lane == k) dinv = rinv;
     if (lane > k) {
       a[k] = lk;
-      if (live) S.A[lane * lda + k] = lk;
+      if (live) S.A[tri(lane, k)] = lk;
     }
   }
   if (!ok) return false;
-  wave_sync();  // factor visible for the row reads below
-  double lt[N];  // lt[k] = L[k][lane] for k > lane
-#pragma unroll
-  for (int k = 0; k < N; ++k) lt[k] = (k < n && lane < k) ? S.A[k * lda + lane] : 0.0;
+  wave_sync();  // factor visible for the column reads of the backward substitution
   double b = live ? -g : 0.0;
 #pragma unroll
   for (int k = 0; k < N; ++k) {  // L y = -g (unit lower)
@@ -806,9 +751,10 @@ __device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S
   }
   b *= dinv;  // D z = y
 #pragma unroll
-  for (int k = N - 1; k >= 0; --k) {  // L^T dx = z
+  for (int k = N - 1; k >= 0; --k) {  // L^T dx = z; L[k][lane] (k > lane) read column-wise from LDS
     const double dk = wave_bcast(b, k);
-    b -= lt[k] * dk;  // lt[k] is zero for lanes >= k
+    const double lkl = (k < n && lane < k) ? S.A[tri(k, lane < k ? lane : 0)] : 0.0;
+    b -= lkl * dk;
   }
   *dx = b;
   return true;
@@ -861,8 +807,10 @@ __device__ __forceinline__ double reference_abs_residual(const DevProgram* P, co
 #endif
 
 
+// Register budget: rows of up to 24 entries fit 3 waves/SIMD (168 VGPRs); longer rows need the
+// 256-register budget of 2 waves/SIMD (the LDS slice of such problems allows <= 5 waves/CU anyway).
 template <int NREG, bool PROFILE>
-__global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(const DevProgram* __restrict__ P,
+__global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG <= 48 ? 2 : 1)) okx_solve_kernel(const DevProgram* __restrict__ P,
                                                           SolveArgs args) {
   Prof prof_store;
   Prof* prof = nullptr;
@@ -975,21 +923,24 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_kernel(co
         first = false;
         if (stop) break;
         if (iters >= args.max_iter) break;
+        if (!accept) {
+          // Rejected trial (rare): the single Jacobian buffer now holds J(xt) and the packed
+          // triangle holds the factor, so the accepted point's J and J^T J are rebuilt.
+          evaluate<true>(P, S, lane, x, xaddr, cur, prof);
+          ++nfev;
+          g = build_normal(P, S, lane, kWave, cur, lane < n);
+        }
         ++iters;
         OKX_STAMP(4)
         // damped normal equations; enlarge lambda until the factorisation succeeds
         bool ok = false;
         for (int tries = 0; tries < 60; ++tries) {
           if (!(lambda < 1e30)) break;
-          if constexpr (NREG > 0) {
-            ok = ldlt_solve_reg<NREG>(P, S, lane, lambda, g, &dx);
-            stamp(prof, 6);
-          } else {
-            ok = factorize(P, S, lane, lambda);
-            if (ok) dx = chol_solve(P, S, lane, -g);
-          }
+          ok = ldlt_solve_reg<NREG>(P, S, lane, lambda, g, &dx);
+          stamp(prof, 6);
           if (ok) break;
           lambda = fmax(lambda * 10.0, 1e-12 * dmax);
+          build_normal(P, S, lane, kWave, cur, lane < n);  // the failed factor overwrote J^T J
         }
         if (!ok) {
           flags |= OKX_INFO_FAILED;
@@ -1092,7 +1043,7 @@ __global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __res
         double* M = args.ata + b * (long long)n * n;
         for (int e = lane; e < n * n; e += kWave) {
           const int i = e / n, j = e % n;
-          M[e] = i == j ? S.dA[i] : (i < j ? S.A[i * P->lda + j] : S.A[j * P->lda + i]);
+          M[e] = i == j ? S.dA[i] : (i < j ? S.A[tri(j, i)] : S.A[tri(i, j)]);
         }
       }
     }

@@ -28,9 +28,9 @@ __host__ __device__ inline int packed_group_doubles(const DevProgram& P) {
   s += P.n_points * 3;
   s += P.m * 8;
   s += (P.n_active > 0 ? P.n_active : 1) * kDepMax * 9;
-  s += 2 * js_buf_doubles(P);
+  s += js_buf_doubles(P);
   s += 2 * rb_buf_doubles(P);
-  s += P.n * P.lda;
+  s += tri_doubles(P);
   s += P.n;
   s += kMaxTargets;
   s += 2 * kColBuf;
@@ -57,11 +57,11 @@ __device__ __forceinline__ PackedLds carve_packed(double* base, const DevProgram
   L.S.dblk = p;
   p += (P->n_active > 0 ? P->n_active : 1) * kDepMax * 9;
   L.S.js = p;
-  p += 2 * js_buf_doubles(*P);
+  p += js_buf_doubles(*P);
   L.S.rb = p;
   p += 2 * rb_buf_doubles(*P);
   L.S.A = p;
-  p += P->n * P->lda;
+  p += tri_doubles(*P);
   L.S.dA = p;
   p += P->n;
   L.S.tv = p;
@@ -140,7 +140,7 @@ template <int N, typename Bcast>
 __device__ __forceinline__ bool ldlt_solve_lds(const DevProgram* P, const Lds& S, int l,
                                                double lambda, double grad, double* dx, Bcast bcast,
                                                Prof* prof = nullptr) {
-  const int n = P->n, lda = P->lda;
+  const int n = P->n;
   const bool is_row = l < n, is_pad = l >= n && l < N, is_rhs = l == N;
   if (l < N) S.zbuf[l] = is_row ? -grad : 0.0;
   wave_sync();
@@ -148,7 +148,7 @@ __device__ __forceinline__ bool ldlt_solve_lds(const DevProgram* P, const Lds& S
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     double v = 0.0;
-    if (is_row && j < l) v = S.A[j * lda + l];  // upper-triangle storage of the symmetric matrix
+    if (is_row && j < l) v = S.A[tri(l, j)];
     if (is_row && j == l) v = S.dA[l] + lambda;
     if (is_pad && j == l) v = 1.0;
     if (is_rhs) v = S.zbuf[j];
@@ -168,7 +168,7 @@ __device__ __forceinline__ bool ldlt_solve_lds(const DevProgram* P, const Lds& S
     for (int j = k + 1; j < N; ++j) a[j] -= lk * S.col[j];
     if (l > k) {
       a[k] = lk;
-      if (is_row) S.A[l * lda + k] = lk;
+      if (is_row) S.A[tri(l, k)] = lk;
     }
     wave_sync();  // the column buffer is reused by the next column
   }
@@ -180,7 +180,7 @@ __device__ __forceinline__ bool ldlt_solve_lds(const DevProgram* P, const Lds& S
   double b = is_row ? S.zbuf[l] : 0.0;
   double lt[N];  // lt[k] = L[k][l] for k > l (row k of the factor, read column-wise)
 #pragma unroll
-  for (int k = 0; k < N; ++k) lt[k] = (is_row && k < n && l < k) ? S.A[k * lda + l] : 0.0;
+  for (int k = 0; k < N; ++k) lt[k] = (is_row && k < n && l < k) ? S.A[tri(k, l)] : 0.0;
 #pragma unroll
   for (int k = N - 1; k >= 0; --k) {  // L^T dx = z
     const double dk = bcast(b, k);
@@ -192,7 +192,7 @@ __device__ __forceinline__ bool ldlt_solve_lds(const DevProgram* P, const Lds& S
 }
 
 template <int N, int G, bool PROFILE>
-__global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_kernel(const DevProgram* __restrict__ P,
+__global__ void __launch_bounds__(kWave, 2) okx_solve_packed_kernel(const DevProgram* __restrict__ P,
                                                                  SolveArgs args, int W) {
   Prof prof_store;
   Prof* prof = nullptr;
@@ -316,10 +316,21 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_ke
           lambda *= nu;
           nu *= 2.0;
         }
+        const bool rejected = !accept && !stop && !done && !first;
         first = false;
         if (stop) done = true;
         if (!done && iters >= args.max_iter) done = true;
         if (__all(done)) break;
+        if (__any(rejected && !done)) {
+          // a group rejected its trial (rare): its Jacobian buffer holds J(xt) and its triangle
+          // the factor.  Every group re-evaluates at its accepted point (identical values for
+          // the groups that did accept) and the rejecting groups rebuild J^T J.
+          eval_rows<true>(P, S, l, W, x, xaddr, cur, prof);
+          if (rejected && !done) ++nfev;
+          const bool again = rejected && !done;
+          const double gnew = build_normal(P, S, again ? l : (1 << 20), W, cur, again && is_var);
+          if (again) grad = gnew;
+        }
         if (!done) ++iters;
         OKX_STAMP(4)
         // damped normal equations; a group whose factorisation fails retries with more damping
@@ -343,6 +354,8 @@ __global__ void __launch_bounds__(kWave, OKX_WAVES_PER_SIMD) okx_solve_packed_ke
             }
           }
           if (__all(have)) break;
+          // groups still without a factor re-scatter J^T J (the failed factor overwrote it)
+          build_normal(P, S, !have ? l : (1 << 20), W, cur, false);
         }
         if (!have) {
           flags |= OKX_INFO_FAILED;

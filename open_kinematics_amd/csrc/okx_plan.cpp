@@ -297,7 +297,7 @@ int build_dev_program(const okx_program_desc* d, DevProgram* out, char* err, int
       for (int b = 0; b < 3; ++b) {
         if (bp == bq && a > b) continue;
         const int row = 3 * bp + a, col = 3 * bq + b;
-        out->item_dst[nw] = row == col ? -(1 + row) : row * lda + col;
+        out->item_dst[nw] = row == col ? -(1 + row) : col * (col - 1) / 2 + row;
         out->item_desc[nw] = (uint32_t)start | ((uint32_t)count << 12) | ((uint32_t)a << 20) |
                              ((uint32_t)b << 22);
         ++nw;

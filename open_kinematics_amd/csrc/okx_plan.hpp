@@ -54,7 +54,7 @@ static_assert(sizeof(PointRef) == 8, "PointRef packs into 8 bytes");
 
 struct DevProgram {
   int32_t n_points, n_free, n, n_derived, n_crows, n_targets, m, n_out;
-  int32_t lda;          // leading dimension of the n x n normal matrix in LDS
+  int32_t lda;          // (unused since the packed-triangle layout; kept for ABI stability of tools)
   int32_t js_stride;    // doubles per row of the block-sparse Jacobian
   int32_t n_active;     // derived ops needed while iterating
   int32_t n_pairs, n_items;
@@ -94,7 +94,7 @@ struct DevProgram {
   int32_t n_contrib;                    // entries used in contrib[]
   int32_t n_gcontrib;                   // entries used in g_contrib[]
   int32_t pad2;
-  int32_t item_dst[kMaxPairs * 9];      // >= 0: offset into A (row * lda + col); < 0: -(1 + diag index)
+  int32_t item_dst[kMaxPairs * 9];      // >= 0: packed-triangle offset col*(col-1)/2 + row (row < col); < 0: -(1 + diag index)
   uint32_t item_desc[kMaxPairs * 9];    // start | count << 12 | a << 20 | b << 22
 
   // Batched-load form of the same plans: every product term is a pair of absolute offsets
@@ -105,8 +105,8 @@ struct DevProgram {
   int32_t zero_off;                      // offset of the zero slot inside a Jacobian buffer (= m * js_stride)
   int32_t pad3;
   uint32_t row_first[kMaxRows];          // scatter: bit (4 s + j) set = that write is the first to its slot
-  uint32_t item_terms[kMaxPairs * 9 * kItemTermsMax];  // offA | offB << 16
-  uint32_t grad_terms[kMaxVars * kGradTermsMax];       // offJ | row << 16  (row = m: zero residual slot)
+  alignas(16) uint32_t item_terms[kMaxPairs * 9 * kItemTermsMax];  // offA | offB << 16
+  alignas(16) uint32_t grad_terms[kMaxVars * kGradTermsMax];       // offJ | row << 16  (row = m: zero residual slot)
 
   double design_pos[kMaxPoints][3];
 };
