@@ -48,6 +48,22 @@ def estimated_flops_per_evaluation(program, stats) -> float:
     return rows + normal + chol
 
 
+def measured_traffic() -> tuple:
+    """
+    HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs of this same command, see
+    profiles/r01/bench_c2_pmc_traffic_v3.json for command, units and corrections).  bench.py
+    cannot run the profiler on itself, so the figure is read back from that summary.
+    """
+    path = os.path.join(REPO, "profiles", "r01", "bench_c2_pmc_traffic_v3.json")
+    try:
+        with open(path, "r", encoding="utf-8") as fh:
+            summary = json.load(fh)
+        return float(summary["traffic_bytes_per_launch"]), os.path.relpath(path, REPO)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(n_steps: int) -> dict:
     """Oracle = reference-shaped CPU path: sequential warm-started MINPACK LM, default tolerances."""
     from open_kinematics_amd.workloads import bump_sweep_problem
@@ -157,6 +173,7 @@ def main() -> None:
         _lib.load().okx_plan_stats(HostProgram(program).byref(), stats_raw)
         stats = dict(zip(["n", "m", "pairs", "contrib", "active", "js_stride", "lda", "lds_bytes"], list(stats_raw)))
         bytes_per_solve = algorithmic_bytes_per_solve(program)
+        traffic, traffic_src = measured_traffic() if world == 1 and CHAIN_LEN == -1 else (None, None)
         achieved_gbs = bytes_per_solve * (hi - lo) / (kernel_ms * 1e-3) / 1e9
         nfev_mean = float(host_info["nfev"].mean())
         flops = estimated_flops_per_evaluation(program, stats) * nfev_mean * (hi - lo)
@@ -193,7 +210,8 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "okx_solve_kernel",
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_solve": bytes_per_solve,

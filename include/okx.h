@@ -144,6 +144,10 @@ typedef struct okx_solve_opts {
   double lambda0;         /* initial damping relative to max diag(J^T J) (default 1e-6)    */
   double residual_tolerance; /* informational: info.flags bit1 set if max|r| exceeds it
                                 (solver.py:735-747, default 1e-3)                          */
+  int32_t kernel;         /* 0 auto, 1 one problem per wavefront, 2 lane-group packed (several
+                             small problems per wavefront; falls back to 1 when a problem
+                             needs more than 32 lanes)                                     */
+  int32_t reserved;
 } okx_solve_opts;
 
 /* Per-problem result, the device analogue of SolverInfo (solver.py:83-96). */

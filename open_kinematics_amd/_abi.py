@@ -50,6 +50,8 @@ class SolveOpts(C.Structure):
         ("ftol", C.c_double),
         ("lambda0", C.c_double),
         ("residual_tolerance", C.c_double),
+        ("kernel", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

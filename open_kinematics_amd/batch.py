@@ -97,6 +97,7 @@ class DeviceProgram:
         step_tol: float | None = None,
         lambda0: float | None = None,
         ftol: float | None = None,
+        kernel: int | str | None = None,
         residual_tolerance: float | None = None,
         out: torch.Tensor | None = None,
         info_out: torch.Tensor | None = None,
@@ -124,6 +125,8 @@ class DeviceProgram:
             opts.lambda0 = float(lambda0)
         if ftol is not None:
             opts.ftol = float(ftol)
+        if kernel is not None:
+            opts.kernel = {"auto": 0, "single": 1, "packed": 2}.get(kernel, kernel)
         if residual_tolerance is not None:
             opts.residual_tolerance = float(residual_tolerance)
         if geom_pos is not None:

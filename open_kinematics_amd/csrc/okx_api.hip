@@ -19,10 +19,13 @@ struct okx_program {
   size_t lds_bytes;        // eval / rebind / single-problem solve kernels
   size_t solve_lds_bytes;  // selected solve kernel
   int blocks_per_cu;
-  int nreg;              // padded size of the register-resident factorisation, 0 = LDS path
-  int groups;            // problems per wavefront (1 = okx_solve_kernel, >1 = packed kernel)
-  int group_width;       // lanes per problem in the packed kernel
-  const void* solve_fn;  // selected kernel instantiation
+  int nreg;                // padded row length of the register-resident factorisation
+  const void* solve_fn;    // okx_solve_kernel<NREG> (one problem per wavefront)
+  int groups;              // problems per wavefront of the packed kernel (1 = not available)
+  int group_width;         // lanes per problem in the packed kernel
+  const void* packed_fn;   // okx_solve_packed_kernel<NREG, G> or null
+  size_t packed_lds_bytes;
+  int packed_blocks_per_cu;
 };
 
 namespace {
@@ -47,45 +50,10 @@ int fail(int code, const char* fmt, ...) {
 typedef void (*solve_kernel_t)(const okx::DevProgram*, okx::SolveArgs);
 typedef void (*packed_kernel_t)(const okx::DevProgram*, okx::SolveArgs, int);
 
-// Kernel selection: systems with n <= 24 factorise in registers (template on the padded
-// size); when a problem needs at most 32 lanes, G = 64 / W problems share a wavefront
-// (okx_packed.hip).  OKX_FORCE_SINGLE=1 in the environment pins the one-problem kernel.
-void select_solve_kernel(okx_program* p) {
+// Every program gets the one-problem-per-wavefront kernel (register LDL^T, template on the
+// padded row length) and, when a problem fits 32 lanes, the lane-group packed kernel too.
+void select_solve_kernels(okx_program* p) {
   const int n = p->host.n, m = p->host.m;
-  const int npad = n <= 15 ? 15 : n <= 18 ? 18 : n <= 21 ? 21 : 24;  // register row length
-  const int width = m > npad + 1 ? m : npad + 1;                      // rhs row lives at lane npad
-  int groups = 64 / width;
-  if (groups > 4) groups = 4;
-  // The packed kernel is opt-in (OKX_PACKED=1): on MI355X it is LDS-capacity limited to
-  // 4-6 wavefronts per CU and loses to the single-problem kernel at 12 (profiles/r01).
-  const char* packed = getenv("OKX_PACKED");
-  if (!(packed && packed[0] == '1')) groups = 1;
-  p->groups = 1;
-  p->group_width = 64;
-  if (groups >= 2 && n <= 24) {
-    packed_kernel_t fn = nullptr;
-    if (n <= 15) {
-      fn = groups == 4 ? okx::okx_solve_packed_kernel<15, 4, false>
-         : groups == 3 ? okx::okx_solve_packed_kernel<15, 3, false> : okx::okx_solve_packed_kernel<15, 2, false>;
-      p->nreg = 15;
-    } else if (n <= 18) {
-      fn = groups >= 3 ? okx::okx_solve_packed_kernel<18, 3, false> : okx::okx_solve_packed_kernel<18, 2, false>;
-      if (groups > 3) groups = 3;
-      p->nreg = 18;
-    } else if (n <= 21) {
-      fn = okx::okx_solve_packed_kernel<21, 2, false>;
-      groups = 2;
-      p->nreg = 21;
-    } else {
-      fn = okx::okx_solve_packed_kernel<24, 2, false>;
-      groups = 2;
-      p->nreg = 24;
-    }
-    p->groups = groups;
-    p->group_width = width;
-    p->solve_fn = (const void*)fn;
-    return;
-  }
   solve_kernel_t fn;
   if (n <= 15) {
     fn = okx::okx_solve_kernel<15, false>;
@@ -110,6 +78,55 @@ void select_solve_kernel(okx_program* p) {
     p->nreg = 63;
   }
   p->solve_fn = (const void*)fn;
+
+  p->groups = 1;
+  p->group_width = 64;
+  p->packed_fn = nullptr;
+  if (n > 24) return;
+  const int width = m > p->nreg + 1 ? m : p->nreg + 1;  // the rhs row lives at local lane nreg
+  int groups = 64 / width;
+  if (groups > 4) groups = 4;
+  if (groups < 2) return;
+  packed_kernel_t pk;
+  if (p->nreg == 15) {
+    pk = groups == 4 ? okx::okx_solve_packed_kernel<15, 4, false>
+       : groups == 3 ? okx::okx_solve_packed_kernel<15, 3, false> : okx::okx_solve_packed_kernel<15, 2, false>;
+  } else if (p->nreg == 18) {
+    if (groups > 3) groups = 3;
+    pk = groups == 3 ? okx::okx_solve_packed_kernel<18, 3, false> : okx::okx_solve_packed_kernel<18, 2, false>;
+  } else if (p->nreg == 21) {
+    groups = 2;
+    pk = okx::okx_solve_packed_kernel<21, 2, false>;
+  } else {
+    groups = 2;
+    pk = okx::okx_solve_packed_kernel<24, 2, false>;
+  }
+  p->groups = groups;
+  p->group_width = width;
+  p->packed_fn = (const void*)pk;
+}
+
+// Resident single-wave workgroups per CU.  The occupancy API assumes 64 KiB of LDS per CU on
+// this stack, so the limit is derived here: 512 VGPRs per SIMD lane (8-register granules),
+// 160 KiB LDS per CU, 8 waves per SIMD.
+int resident_blocks_per_cu(const void* fn, size_t lds_bytes) {
+  int occ = 32;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {
+    const int alloc = (fa.numRegs + 7) / 8 * 8;
+    int per_simd = 512 / alloc;
+    if (per_simd > 8) per_simd = 8;
+    if (per_simd < 1) per_simd = 1;
+    occ = 4 * per_simd;
+  }
+  const int by_lds = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
+  if (by_lds < occ) occ = by_lds;
+  if (occ < 1) occ = 1;
+  if (const char* cap = getenv("OKX_BLOCKS_PER_CU")) {  // tuning knob
+    const int c = atoi(cap);
+    if (c >= 1 && c < occ) occ = c;
+  }
+  return occ;
 }
 
 int grid_for(const okx_program* p, long long units) {
@@ -137,6 +154,8 @@ void okx_default_opts(okx_solve_opts* o) {
   o->ftol = 1e-10;
   o->lambda0 = 1e-6;
   o->residual_tolerance = 1e-3;
+  o->kernel = 0;
+  o->reserved = 0;
 }
 
 int32_t okx_device_count(void) {
@@ -157,11 +176,12 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
     return rc;
   }
   p->host.lds_doubles = okx::lds_doubles(p->host);
-  select_solve_kernel(p);
+  select_solve_kernels(p);
   p->lds_bytes = sizeof(double) * (size_t)p->host.lds_doubles;
-  p->solve_lds_bytes = p->groups > 1 ? sizeof(double) * (size_t)okx::packed_lds_doubles(p->host, p->groups)
-                                     : p->lds_bytes;
-  if (p->lds_bytes > 160 * 1024 || p->solve_lds_bytes > 160 * 1024) {
+  p->solve_lds_bytes = p->lds_bytes;
+  p->packed_lds_bytes = p->packed_fn ? sizeof(double) * (size_t)okx::packed_lds_doubles(p->host, p->groups) : 0;
+  if (p->packed_lds_bytes > 160 * 1024) p->packed_fn = nullptr;
+  if (p->lds_bytes > 160 * 1024) {
     delete p;
     return fail(OKX_ERR_LIMIT, "problem needs %zu bytes of LDS (max 163840)", p->lds_bytes);
   }
@@ -191,29 +211,15 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   // >64 KiB of dynamic LDS needs the opt-in attribute
   (void)hipFuncSetAttribute(p->solve_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->solve_lds_bytes);
   (void)hipFuncSetAttribute((const void*)okx::okx_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)p->lds_bytes);
+                            (int)p->lds_bytes);
   (void)hipFuncSetAttribute((const void*)okx::okx_rebind_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                      (int)p->lds_bytes);
-  // Resident single-wave workgroups per CU.  The occupancy API assumes 64 KiB of LDS per CU
-  // on this stack, so the limit is derived here: 512 VGPRs per SIMD lane (8-register
-  // granules), 160 KiB LDS per CU, 8 waves per SIMD.
-  int occ = 32;
-  hipFuncAttributes fa;
-  if (hipFuncGetAttributes(&fa, p->solve_fn) == hipSuccess && fa.numRegs > 0) {
-    const int alloc = (fa.numRegs + 7) / 8 * 8;
-    int per_simd = 512 / alloc;
-    if (per_simd > 8) per_simd = 8;
-    if (per_simd < 1) per_simd = 1;
-    occ = 4 * per_simd;
+                            (int)p->lds_bytes);
+  p->blocks_per_cu = resident_blocks_per_cu(p->solve_fn, p->solve_lds_bytes);
+  p->packed_blocks_per_cu = 0;
+  if (p->packed_fn) {
+    (void)hipFuncSetAttribute(p->packed_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->packed_lds_bytes);
+    p->packed_blocks_per_cu = resident_blocks_per_cu(p->packed_fn, p->packed_lds_bytes);
   }
-  const int by_lds = (int)((160 * 1024) / (p->solve_lds_bytes ? p->solve_lds_bytes : 1));
-  if (by_lds < occ) occ = by_lds;
-  if (occ < 1) occ = 1;
-  if (const char* cap = getenv("OKX_BLOCKS_PER_CU")) {  // tuning knob: cap resident workgroups per CU
-    const int c = atoi(cap);
-    if (c >= 1 && c < occ) occ = c;
-  }
-  p->blocks_per_cu = occ;
   *out = p;
   return OKX_OK;
 }
@@ -251,13 +257,31 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   a.steps_per_geometry = spg;
   a.max_iter = opts->max_iter;
   a.pad_ = 0;
+  // Kernel choice (profiles/r01/config_sweep_v3.txt).  The packed kernel keeps more problems in
+  // flight per CU (G lane groups x resident waves): measured 1.5x on saturating batches of
+  // n <= 15 systems (MacPherson grid), no gain for n = 18 (DW corner), so auto = packed only
+  // for n <= 15 and batches of at least 8 problems per resident slot.
+  const long long single_slots = (long long)p->n_cu * p->blocks_per_cu;
+  const long long packed_slots = (long long)p->n_cu * p->packed_blocks_per_cu * p->groups;
+  bool use_packed = false;
+  if (p->packed_fn) {
+    if (opts->kernel == 2) use_packed = true;
+    else if (opts->kernel == 0) use_packed = p->nreg <= 15 && n_problems >= 8 * single_slots;
+    if (const char* env = getenv("OKX_PACKED")) use_packed = env[0] == '1';
+  }
   {
     const long long span = spg > 0 ? spg : n_problems;
     long long len = opts->chain_len;
     if (len == 0) len = opts->chain ? span : 1;
-    if (len < 0) {  // auto: one chain per resident wavefront (packed: per lane group)
-      const long long slots = (long long)p->n_cu * p->blocks_per_cu * p->groups;
-      len = (n_problems + slots - 1) / slots;
+    if (len < 0) {  // auto: about one chain per resident problem slot, balanced inside a geometry
+      const long long slots = use_packed ? packed_slots : single_slots;
+      const long long ideal = (n_problems + slots - 1) / slots;
+      if (ideal >= span) {
+        len = span;
+      } else {
+        const long long per_span = (span + ideal - 1) / ideal;
+        len = (span + per_span - 1) / per_span;
+      }
     }
     if (len < 1) len = 1;
     if (len > span) len = span;
@@ -272,11 +296,13 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   const long long span_ = spg > 0 ? spg : n_problems;
   const long long units = (n_problems / span_) * ((span_ + a.chain_len - 1) / a.chain_len);
   const okx::DevProgram* dev = p->dev;
-  if (p->groups > 1) {
+  if (use_packed) {
     int width = p->group_width;
-    const int grid = grid_for(p, (units + p->groups - 1) / p->groups);
+    long long cap = (long long)p->n_cu * p->packed_blocks_per_cu;
+    const long long wave_units = (units + p->groups - 1) / p->groups;
+    const int grid = (int)(wave_units < cap ? (wave_units < 1 ? 1 : wave_units) : cap);
     void* kargs[] = {(void*)&dev, (void*)&a, (void*)&width};
-    HIP_TRY(hipLaunchKernel(p->solve_fn, dim3(grid), dim3(okx::kWave), kargs, p->solve_lds_bytes,
+    HIP_TRY(hipLaunchKernel(p->packed_fn, dim3(grid), dim3(okx::kWave), kargs, p->packed_lds_bytes,
                             (hipStream_t)stream));
     return OKX_OK;
   }
@@ -369,14 +395,14 @@ int32_t okx_debug_phase_profile(okx_program* p, const okx_solve_opts* opts, int6
   a.residual_tolerance = opts->residual_tolerance;
   a.phase_cycles = d_phase_cycles;
   const okx::DevProgram* dev = p->dev;
-  if (p->groups == 3) {
+  if (p->groups == 3 && opts->kernel == 2) {
     int width = p->group_width;
     void* kargs[] = {(void*)&dev, (void*)&a, (void*)&width};
     packed_kernel_t fn = okx::okx_solve_packed_kernel<18, 3, true>;
     (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)p->solve_lds_bytes);
+                              (int)p->packed_lds_bytes);
     HIP_TRY(hipLaunchKernel((const void*)fn, dim3(grid_for(p, (n_problems + 2) / 3)), dim3(okx::kWave),
-                            kargs, p->solve_lds_bytes, (hipStream_t)stream));
+                            kargs, p->packed_lds_bytes, (hipStream_t)stream));
     return OKX_OK;
   }
   void* kargs[] = {(void*)&dev, (void*)&a};

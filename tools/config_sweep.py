@@ -13,16 +13,22 @@ def timed(fn, reps=5):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps, out
 
+KERNELS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["auto"]
+
 def report(name, dp, targets, **kw):
-    for cl in (1, -1):
-        dt, res = timed(lambda: dp.solve(targets, chain_len=cl, **kw))
-        info = res.info()
-        ok = bool(np.all((info["flags"] & 7) == 1))
-        print(f"{name:34s} chain_len={cl:2d}  B={targets.shape[0]:8d}  {targets.shape[0]/dt/1e6:8.3f} M solves/s  "
-              f"{dt*1e3:8.3f} ms  evals {info['nfev'].mean():.2f}  max_res {info['max_residual'].max():.2e}  converged={ok}")
+    for kern in KERNELS:
+        for cl in (1, -1):
+            dt, res = timed(lambda: dp.solve(targets, chain_len=cl, kernel=kern, **kw))
+            info = res.info()
+            ok = bool(np.all((info["flags"] & 7) == 1))
+            print(f"{name:34s} {kern:6s} chain_len={cl:2d}  B={targets.shape[0]:8d}  {targets.shape[0]/dt/1e6:8.3f} M solves/s  "
+                  f"{dt*1e3:8.3f} ms  evals {info['nfev'].mean():.2f}  max_res {info['max_residual'].max():.2e}  converged={ok}")
 
 p, t = W.bump_sweep_problem(16384)
 report("C2 DW corner 16384-step bump", DeviceProgram(p), torch.as_tensor(t, device="cuda"))
+for steps in (65536, 262144, 1048576):
+    p, t = W.bump_sweep_problem(steps)
+    report(f"   DW corner {steps}-step bump", DeviceProgram(p), torch.as_tensor(t, device="cuda"))
 p, t = W.macpherson_grid_problem(512, 512)
 report("C4 MacPherson 512x512 bump x rack", DeviceProgram(p), torch.as_tensor(t, device="cuda"))
 p, t = W.axle_grid_problem(256, 256)
