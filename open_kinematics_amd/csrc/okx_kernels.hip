@@ -123,6 +123,52 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return fma(e, r, r);
 }
 
+// atan2(y, x) for y >= 0 (the angle rows pass y = softnorm(|v1 x v2|^2) >= 0), result in
+// [0, pi].  The math-library atan2 costs 44 VGPRs in this kernel (182 -> 138 without it,
+// measured with -Rpass-analysis), which alone decides between 3 waves/SIMD with spills and
+// without.  This is the classic fdlibm scheme (Sun Microsystems' freely distributable
+// s_atan.c / e_atan2.c): four-interval argument reduction and an odd polynomial of degree 21,
+// < 1 ulp, evaluated with Horner chains so it needs a handful of registers.
+__device__ __forceinline__ double lean_atan2_pos(double y, double x) {
+  const double ax = fabs(x);
+  if (!(y > 0.0)) return x >= 0.0 ? 0.0 : 3.14159265358979311600e+00;
+  if (ax == 0.0) return 1.57079632679489655800e+00;
+  double t = y * fast_rcp(ax);  // t = |y / x| >= 0
+  double hi, lo;
+  if (t < 0.4375) {
+    hi = 0.0;
+    lo = 0.0;
+  } else if (t < 0.6875) {
+    hi = 4.63647609000806093515e-01;
+    lo = 2.26987774529616870924e-17;
+    t = (2.0 * t - 1.0) * fast_rcp(2.0 + t);
+  } else if (t < 1.1875) {
+    hi = 7.85398163397448278999e-01;
+    lo = 3.06161699786838301793e-17;
+    t = (t - 1.0) * fast_rcp(t + 1.0);
+  } else if (t < 2.4375) {
+    hi = 9.82793723247329054082e-01;
+    lo = 1.39033110312309984516e-17;
+    t = (t - 1.5) * fast_rcp(1.0 + 1.5 * t);
+  } else {
+    hi = 1.57079632679489655800e+00;
+    lo = 6.12323399573676603587e-17;
+    t = -fast_rcp(t);
+  }
+  const double z = t * t, w = z * z;
+  const double s1 = z * (3.33333333333329318027e-01 +
+                         w * (1.42857142725034663711e-01 +
+                              w * (9.09088713343650656196e-02 +
+                                   w * (6.66107313738753120669e-02 +
+                                        w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+  const double s2 = w * (-1.99999999998764832476e-01 +
+                         w * (-1.11111104054623557880e-01 +
+                              w * (-7.69187620504482999495e-02 +
+                                   w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+  const double at = hi - ((t * (s1 + s2) - lo) - t);  // atan(|y/x|) in [0, pi/2]
+  return x > 0.0 ? at : 3.14159265358979311600e+00 - (at - 1.2246467991473531772e-16);
+}
+
 // sqrt(x) and 1/sqrt(x) together (Goldschmidt from the v_rsq_f64 seed), x > 0 well scaled.
 __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double* root, double* inv) {
 #if defined(OKX_IEEE_MATH)
@@ -442,7 +488,7 @@ __device__ __forceinline__ double row_eval(int type, const int* pts, const doubl
           dp[6] = g2.x, dp[7] = g2.y, dp[8] = g2.z;
         }
       }
-      return atan2(s - OKX_EPS, dt) - q[0];
+      return lean_atan2_pos(s - OKX_EPS, dt) - q[0];
     }
     case OKX_ROW_VECTORS_PARALLEL: {  // constraints.py:351-371; jacobians.py:192-262
       V3 v1 = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[0]));
@@ -837,7 +883,8 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
   long long loaded_geom = -1;
 
   for (long long unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
-    double x = 0.0;
+    double x = 0.0, x_prev = 0.0;
+    int hist = 0;  // consecutive solved predecessors in this chain (predictor needs two)
     const long long span_idx = unit / chains_per_span;
     const long long first = span_idx * span + (unit % chains_per_span) * unit_len;
     const long long last = first + unit_len < (span_idx + 1) * span ? first + unit_len : (span_idx + 1) * span;
@@ -857,7 +904,29 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
         if (lane < n) x = src[xaddr];
       }
       wave_sync();
-      if (lane < T) S.tv[lane] = args.targets[b * T + lane];
+      // Secant predictor inside a chain: with two solved predecessors, start from the linear
+      // extrapolation x_{k-1} + alpha (x_{k-1} - x_{k-2}), alpha = projection of this step's
+      // target increment on the previous one (1 for a uniform sweep, clamped to [0, 2]; a grid
+      // wrap-around gives alpha <= 0 -> plain warm start).  The start point only changes the
+      // iteration count, never the minimiser.
+      double t_new = 0.0, t_old = 0.0, t_old2 = 0.0;
+      if (lane < T) {
+        t_new = args.targets[b * T + lane];
+        t_old = step >= 1 ? args.targets[(b - 1) * T + lane] : t_new;
+        t_old2 = step >= 2 ? args.targets[(b - 2) * T + lane] : t_old;
+        S.tv[lane] = t_new;
+      }
+      if (hist >= 2) {
+        const double num = wave_sum((t_new - t_old) * (t_old - t_old2));
+        const double den = wave_sum((t_old - t_old2) * (t_old - t_old2));
+        double alpha = den > 0.0 ? num / den : 0.0;
+        alpha = fmin(fmax(alpha, 0.0), 2.0);
+        const double xp = x + alpha * (x - x_prev);
+        x_prev = x;
+        x = xp;
+      } else {
+        x_prev = x;
+      }
       wave_sync();
       OKX_STAMP(1)
 
@@ -986,6 +1055,9 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
         const double* src = args.geom_pos ? args.geom_pos + geom * 3 * P->n_points
                                           : &P->design_pos[0][0];
         if (lane < n) x = src[xaddr];
+        hist = 0;
+      } else if (hist < 2) {
+        ++hist;
       }
       OKX_STAMP(8)
     }
