@@ -230,7 +230,8 @@ __global__ void __launch_bounds__(kWave, 2) okx_solve_packed_kernel(const DevPro
        unit0 += (long long)gridDim.x * G) {
     const long long unit = unit0 + g;
     const bool unit_ok = valid && unit < n_units;
-    double x = 0.0;
+    double x = 0.0, x_prev = 0.0;
+    int hist = 0;  // consecutive solved predecessors of this group's chain
     const long long span_idx = unit_ok ? unit / chains_per_span : 0;
     const long long first = span_idx * span + (unit_ok ? unit % chains_per_span : 0) * unit_len;
     const long long last = first + unit_len < (span_idx + 1) * span ? first + unit_len : (span_idx + 1) * span;
@@ -250,7 +251,28 @@ __global__ void __launch_bounds__(kWave, 2) okx_solve_packed_kernel(const DevPro
         if (is_var) x = src[xaddr];
       }
       wave_sync();
-      if (has_unit && l < T) S.tv[l] = args.targets[b * T + l];
+      // secant predictor per group (see okx_solve_kernel): extrapolate from two solved predecessors
+      double t_new = 0.0, t_old = 0.0, t_old2 = 0.0;
+      if (has_unit && l < T) {
+        t_new = args.targets[b * T + l];
+        t_old = step >= 1 ? args.targets[(b - 1) * T + l] : t_new;
+        t_old2 = step >= 2 ? args.targets[(b - 2) * T + l] : t_old;
+        S.tv[l] = t_new;
+      }
+      {
+        double num, den;
+        group_sum2((t_new - t_old) * (t_old - t_old2), (t_old - t_old2) * (t_old - t_old2), L.scratch,
+                   lane, gbase, W, &num, &den);
+        if (hist >= 2) {
+          double alpha = den > 0.0 ? num / den : 0.0;
+          alpha = fmin(fmax(alpha, 0.0), 2.0);
+          const double xp = x + alpha * (x - x_prev);
+          x_prev = x;
+          x = xp;
+        } else {
+          x_prev = x;
+        }
+      }
       wave_sync();
       OKX_STAMP(1)
 
@@ -401,6 +423,9 @@ __global__ void __launch_bounds__(kWave, 2) okx_solve_packed_kernel(const DevPro
         if (!(flags & OKX_INFO_CONVERGED) || (flags & OKX_INFO_FAILED)) {
           const double* src = gp ? gp : &P->design_pos[0][0];
           if (is_var) x = src[xaddr];
+          hist = 0;
+        } else if (hist < 2) {
+          ++hist;
         }
       }
       OKX_STAMP(8)
