@@ -52,10 +52,10 @@ def measured_traffic() -> tuple:
     """
     HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs of this same command, see
-    profiles/r01/bench_c2_pmc_traffic_v3.json for command, units and corrections).  bench.py
+    profiles/r01/bench_c2_pmc_traffic_final.json for command, units and corrections).  bench.py
     cannot run the profiler on itself, so the figure is read back from that summary.
     """
-    path = os.path.join(REPO, "profiles", "r01", "bench_c2_pmc_traffic_v3.json")
+    path = os.path.join(REPO, "profiles", "r01", "bench_c2_pmc_traffic_final.json")
     try:
         with open(path, "r", encoding="utf-8") as fh:
             summary = json.load(fh)
