@@ -77,6 +77,16 @@ def load() -> C.CDLL:
     lib.okx_rebind_design.restype = i32
     lib.okx_plan_stats.argtypes = [C.POINTER(ProgramDesc), C.POINTER(i32)]
     lib.okx_plan_stats.restype = i32
+    lib.okx_program_kernel.argtypes = [vp]
+    lib.okx_program_kernel.restype = C.c_char_p
+    lib.okx_program_kernel_note.argtypes = [vp]
+    lib.okx_program_kernel_note.restype = C.c_char_p
+    lib.okx_quad_source.argtypes = [C.POINTER(ProgramDesc), C.c_char_p, i64]
+    lib.okx_quad_source.restype = i64
+    lib.okx_precompile.argtypes = [C.POINTER(ProgramDesc)]
+    lib.okx_precompile.restype = i32
+    lib.okx_debug_quad_eval.argtypes = [vp, i64, vp, vp, C.c_double, vp, vp, vp, vp, vp]
+    lib.okx_debug_quad_eval.restype = i32
     if lib.okx_abi_version() != 1:
         raise RuntimeError("libokx.so ABI version mismatch")
     _lib = lib

@@ -68,6 +68,16 @@ class DeviceProgram:
             _lib.check(self.lib.okx_program_create(self.host.byref(), C.byref(handle)), "okx_program_create")
         self._handle = handle
 
+    @property
+    def kernel(self) -> str:
+        """``"quad"`` when the runtime-specialised kernel is loaded, else ``"wave"`` (generic interpreter)."""
+        return self.lib.okx_program_kernel(self._handle).decode()
+
+    @property
+    def kernel_note(self) -> str:
+        """Why the quad kernel is not in use (empty when it is)."""
+        return self.lib.okx_program_kernel_note(self._handle).decode()
+
     def close(self) -> None:
         if getattr(self, "_handle", None):
             self.lib.okx_program_destroy(self._handle)
@@ -126,7 +136,7 @@ class DeviceProgram:
         if ftol is not None:
             opts.ftol = float(ftol)
         if kernel is not None:
-            opts.kernel = {"auto": 0, "single": 1, "packed": 2}.get(kernel, kernel)
+            opts.kernel = {"auto": 0, "single": 1, "packed": 2, "quad": 3}.get(kernel, kernel)
         if residual_tolerance is not None:
             opts.residual_tolerance = float(residual_tolerance)
         if geom_pos is not None:
@@ -184,6 +194,34 @@ class DeviceProgram:
             )
         _lib.check(rc, "okx_debug_normal_equations")
         return r, ata, atr
+
+    def quad_eval(self, x, targets, lam: float = 0.0):
+        """
+        Test hook for the runtime-specialised kernel: residuals ``[B, m]``, ``J^T J [B, n, n]``
+        (symmetrised from the lane-owned lower rows), ``J^T r [B, n]`` and the damped step
+        ``dx = -(J^T J + lam I)^-1 J^T r`` from its in-register LDL^T, at free vectors ``x [B, n]``.
+        """
+        p = self.program
+        x = _as_f64(x, self.device).reshape(-1, p.n_vars)
+        b = x.shape[0]
+        targets = _as_f64(targets, self.device).reshape(-1, max(p.n_targets, 1))
+        if targets.shape[0] == 1 and b > 1:
+            targets = targets.expand(b, -1).contiguous()
+        n = p.n_vars
+        r = torch.empty((b, p.n_residuals), dtype=torch.float64, device=self.device)
+        ata = torch.zeros((b, n, n), dtype=torch.float64, device=self.device)
+        atr = torch.empty((b, n), dtype=torch.float64, device=self.device)
+        dx = torch.empty((b, n), dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_debug_quad_eval(
+                self._handle, b, _ptr(x), _ptr(targets), float(lam), _ptr(r), _ptr(ata), _ptr(atr), _ptr(dx),
+                C.c_void_p(stream),
+            )
+        _lib.check(rc, "okx_debug_quad_eval")
+        low = torch.tril(ata)
+        ata = low + torch.tril(ata, -1).transpose(1, 2)
+        return r, ata, atr, dx
 
     def rebind(self, hardpoints):
         """Per-geometry design positions ``[G, P, 3]`` and row parameters ``[G, Mc, 8]``."""

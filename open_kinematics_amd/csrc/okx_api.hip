@@ -8,8 +8,11 @@
 #include <cstring>
 #include <new>
 
+#include <string>
+
 #include "okx_kernels.hip"
 #include "okx_packed.hip"
+#include "okx_quad.hpp"
 
 struct okx_program {
   okx::DevProgram host;        // host copy (dimensions, launch sizing)
@@ -26,6 +29,13 @@ struct okx_program {
   const void* packed_fn;   // okx_solve_packed_kernel<NREG, G> or null
   size_t packed_lds_bytes;
   int packed_blocks_per_cu;
+  // runtime-specialised quad kernel (okx_quadgen.cpp / okx_jit.cpp); null when not available
+  hipModule_t quad_mod;
+  hipFunction_t quad_fn_u;  // program's own geometry
+  hipFunction_t quad_fn_g;  // per-geometry tables
+  hipFunction_t quad_fn_eval;  // parity kernel
+  int quad_waves_per_cu;
+  char quad_note[256];      // why the quad kernel is not in use (empty when it is)
 };
 
 namespace {
@@ -129,6 +139,71 @@ int resident_blocks_per_cu(const void* fn, size_t lds_bytes) {
   return occ;
 }
 
+int quad_waves_per_simd() {
+  if (const char* env = getenv("OKX_QUAD_WAVES")) {
+    const int w = atoi(env);
+    if (w >= 1 && w <= 8) return w;
+  }
+  return 1;
+}
+
+// Generate, compile (or fetch from the cache) and load the kernel specialised to this program.
+// Failure is not an error of okx_program_create: the generic kernels stay in charge and
+// okx_program_kernel_note() says why.
+void attach_quad_kernel(okx_program* p) {
+  p->quad_mod = nullptr;
+  p->quad_fn_u = p->quad_fn_g = nullptr;
+  p->quad_fn_eval = nullptr;
+  p->quad_waves_per_cu = 0;
+  p->quad_note[0] = 0;
+  if (const char* env = getenv("OKX_QUAD")) {
+    if (env[0] == '0') {
+      std::snprintf(p->quad_note, sizeof(p->quad_note), "disabled by OKX_QUAD=0");
+      return;
+    }
+  }
+  std::string src, why, code, err;
+  if (!okx::quad_generate(p->host, quad_waves_per_simd(), &src, &why)) {
+    std::snprintf(p->quad_note, sizeof(p->quad_note), "not generated: %s", why.c_str());
+    return;
+  }
+  if (!okx::quad_compile(src, &code, &err)) {
+    std::snprintf(p->quad_note, sizeof(p->quad_note), "compile failed: %.200s", err.c_str());
+    if (getenv("OKX_VERBOSE")) std::fprintf(stderr, "okx: quad kernel: %s\n", err.c_str());
+    return;
+  }
+  hipModule_t mod = nullptr;
+  hipError_t e = hipModuleLoadData(&mod, code.data());
+  if (e != hipSuccess) {
+    std::snprintf(p->quad_note, sizeof(p->quad_note), "hipModuleLoadData: %s", hipGetErrorString(e));
+    return;
+  }
+  hipFunction_t fu = nullptr, fg = nullptr;
+  if (hipModuleGetFunction(&fu, mod, "okx_quad_solve_u") != hipSuccess ||
+      hipModuleGetFunction(&fg, mod, "okx_quad_solve_g") != hipSuccess) {
+    (void)hipModuleUnload(mod);
+    std::snprintf(p->quad_note, sizeof(p->quad_note), "kernel symbols missing in the code object");
+    return;
+  }
+  int regs = 0;
+  int per_simd = quad_waves_per_simd();
+  if (hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fg) == hipSuccess && regs > 0) {
+    const int alloc = (regs + 7) / 8 * 8;
+    per_simd = 512 / alloc;
+    if (per_simd > 8) per_simd = 8;
+    if (per_simd < 1) per_simd = 1;
+  }
+  if (const char* cap = getenv("OKX_QUAD_RESIDENT")) {
+    const int c = atoi(cap);
+    if (c >= 1 && c < per_simd) per_simd = c;
+  }
+  p->quad_mod = mod;
+  p->quad_fn_u = fu;
+  p->quad_fn_g = fg;
+  if (hipModuleGetFunction(&p->quad_fn_eval, mod, "okx_quad_eval") != hipSuccess) p->quad_fn_eval = nullptr;
+  p->quad_waves_per_cu = 4 * per_simd;
+}
+
 int grid_for(const okx_program* p, long long units) {
   long long cap = (long long)p->n_cu * p->blocks_per_cu;
   if (cap < 1) cap = 1;
@@ -220,14 +295,57 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
     (void)hipFuncSetAttribute(p->packed_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->packed_lds_bytes);
     p->packed_blocks_per_cu = resident_blocks_per_cu(p->packed_fn, p->packed_lds_bytes);
   }
+  attach_quad_kernel(p);
   *out = p;
   return OKX_OK;
 }
 
 void okx_program_destroy(okx_program* p) {
   if (!p) return;
+  if (p->quad_mod) (void)hipModuleUnload(p->quad_mod);
   if (p->dev) (void)hipFree(p->dev);
   delete p;
+}
+
+const char* okx_program_kernel(const okx_program* p) {
+  if (!p) return "";
+  return p->quad_fn_u ? "quad" : "wave";
+}
+
+const char* okx_program_kernel_note(const okx_program* p) { return p ? p->quad_note : ""; }
+
+/* Generated source of the quad kernel for a program (no device needed).  Returns the number of
+   bytes the full text needs (including the terminator) or a negative okx_status. */
+int64_t okx_quad_source(const okx_program_desc* desc, char* buf, int64_t buflen) {
+  okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
+  if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
+  int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
+  std::string src, why;
+  if (rc == OKX_OK && !okx::quad_generate(*tmp, quad_waves_per_simd(), &src, &why))
+    rc = fail(OKX_ERR_LIMIT, "no quad kernel for this program: %s", why.c_str());
+  delete tmp;
+  if (rc != OKX_OK) return rc;
+  if (buf && buflen > 0) {
+    const size_t ncopy = src.size() < (size_t)buflen - 1 ? src.size() : (size_t)buflen - 1;
+    std::memcpy(buf, src.data(), ncopy);
+    buf[ncopy] = 0;
+  }
+  return (int64_t)src.size() + 1;
+}
+
+/* Generates and compiles the quad kernel of a program into the on-disk cache (no device needed):
+   what __graft_entry__.build() calls for the BASELINE topologies. */
+int32_t okx_precompile(const okx_program_desc* desc) {
+  okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
+  if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
+  int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
+  std::string src, why, code, err;
+  if (rc == OKX_OK && !okx::quad_generate(*tmp, quad_waves_per_simd(), &src, &why))
+    rc = fail(OKX_ERR_LIMIT, "no quad kernel for this program: %s", why.c_str());
+  delete tmp;
+  if (rc != OKX_OK) return rc;
+  if (!okx::quad_compile(src, &code, &err)) return fail(OKX_ERR_DEVICE, "%s", err.c_str());
+  return OKX_OK;
 }
 
 int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_problems,
@@ -263,8 +381,12 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   // for n <= 15 and batches of at least 8 problems per resident slot.
   const long long single_slots = (long long)p->n_cu * p->blocks_per_cu;
   const long long packed_slots = (long long)p->n_cu * p->packed_blocks_per_cu * p->groups;
+  bool use_quad = p->quad_fn_u != nullptr && (opts->kernel == 0 || opts->kernel == 3);
+  if (opts->kernel == 3 && !use_quad)
+    return fail(OKX_ERR_INVALID, "quad kernel requested but not available: %s", p->quad_note);
+  const long long quad_slots = (long long)p->n_cu * p->quad_waves_per_cu * 16;
   bool use_packed = false;
-  if (p->packed_fn) {
+  if (p->packed_fn && !use_quad) {
     if (opts->kernel == 2) use_packed = true;
     else if (opts->kernel == 0) use_packed = p->nreg <= 15 && n_problems >= 8 * single_slots;
     if (const char* env = getenv("OKX_PACKED")) use_packed = env[0] == '1';
@@ -274,7 +396,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     long long len = opts->chain_len;
     if (len == 0) len = opts->chain ? span : 1;
     if (len < 0) {  // auto: about one chain per resident problem slot, balanced inside a geometry
-      const long long slots = use_packed ? packed_slots : single_slots;
+      const long long slots = use_quad ? quad_slots : (use_packed ? packed_slots : single_slots);
       const long long ideal = (n_problems + slots - 1) / slots;
       if (ideal >= span) {
         len = span;
@@ -296,6 +418,35 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   const long long span_ = spg > 0 ? spg : n_problems;
   const long long units = (n_problems / span_) * ((span_ + a.chain_len - 1) / a.chain_len);
   const okx::DevProgram* dev = p->dev;
+  if (use_quad) {
+    okx::QuadArgs q;
+    q.targets = a.targets;
+    q.geom_pos = a.geom_pos;
+    q.geom_row_param = a.geom_row_param;
+    q.out_pos = a.out_pos;
+    q.info = a.info;
+    q.n_problems = a.n_problems;
+    q.steps_per_geometry = a.steps_per_geometry;
+    q.chain_len = a.chain_len;
+    q.max_iter = a.max_iter;
+    q.pad = 0;
+    q.step_tol = a.step_tol;
+    q.grad_tol = a.grad_tol;
+    q.ftol = a.ftol;
+    q.lambda0 = a.lambda0;
+    q.residual_tolerance = a.residual_tolerance;
+    const char* base = reinterpret_cast<const char*>(p->dev);
+    q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
+    q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
+    q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
+    const long long wave_units = (units + 15) / 16;
+    const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
+    const int grid = (int)(wave_units < cap ? (wave_units < 1 ? 1 : wave_units) : cap);
+    void* kargs[] = {(void*)&q};
+    HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->quad_fn_g : p->quad_fn_u, grid, 1, 1, okx::kWave, 1, 1, 0,
+                                  (hipStream_t)stream, kargs, nullptr));
+    return OKX_OK;
+  }
   if (use_packed) {
     int width = p->group_width;
     long long cap = (long long)p->n_cu * p->packed_blocks_per_cu;
@@ -365,6 +516,36 @@ int32_t okx_rebind_design(okx_program* p, int64_t n_geometries, const double* d_
   hipLaunchKernelGGL(okx::okx_rebind_kernel, dim3(grid_for(p, n_geometries)), dim3(okx::kWave),
                      p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
   HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
+/* Test hook: what the quad kernel's straight-line code computes at given free vectors d_x [B][n]:
+   d_r [B][m], d_ata [B][n][n] (only the structurally non-zero LOWER entries are written: clear the
+   buffer first), d_atr [B][n] and the damped step d_dx [B][n] = -(J^T J + lambda I)^-1 J^T r from
+   its LDL^T (NaN when a pivot is not positive). */
+int32_t okx_debug_quad_eval(okx_program* p, int64_t n_problems, const double* d_x, const double* d_targets,
+                            double lambda, double* d_r, double* d_ata, double* d_atr, double* d_dx,
+                            void* stream) {
+  if (!p || !d_x || !d_r || !d_ata || !d_atr || !d_dx) return fail(OKX_ERR_INVALID, "null pointer");
+  if (!p->quad_fn_eval) return fail(OKX_ERR_INVALID, "no quad kernel: %s", p->quad_note);
+  if (n_problems <= 0) return OKX_OK;
+  okx::QuadEvalArgs q;
+  q.x = d_x;
+  q.targets = d_targets;
+  q.r = d_r;
+  q.ata = d_ata;
+  q.atr = d_atr;
+  q.dx = d_dx;
+  q.lambda = lambda;
+  q.n_problems = n_problems;
+  const char* base = reinterpret_cast<const char*>(p->dev);
+  q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
+  q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
+  q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
+  const long long waves = (n_problems + 15) / 16;
+  void* kargs[] = {(void*)&q};
+  HIP_TRY(hipModuleLaunchKernel(p->quad_fn_eval, (int)(waves < 4096 ? waves : 4096), 1, 1, okx::kWave, 1, 1, 0,
+                                (hipStream_t)stream, kargs, nullptr));
   return OKX_OK;
 }
 

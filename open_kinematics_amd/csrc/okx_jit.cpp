@@ -1,0 +1,127 @@
+// okx_jit.cpp — hiprtc compilation and on-disk caching of the generated quad kernels.
+//
+// hiprtc needs no device (it is comgr + the bundled device headers), so the cache can be filled
+// by `__graft_entry__.build()` on a machine without a GPU; a miss at run time compiles in place.
+// Cache key = FNV-1a of (source text, compile options, hiprtc version).
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "okx_quad.hpp"
+
+namespace okx {
+namespace {
+
+const char* kOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
+constexpr int kNumOptions = 4;
+
+unsigned long long fnv1a(const std::string& s, unsigned long long h = 1469598103934665603ull) {
+  for (unsigned char ch : s) {
+    h ^= ch;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+std::string cache_dir() {
+  if (const char* env = getenv("OKX_KERNEL_CACHE")) return env;
+  Dl_info info;
+  if (dladdr((const void*)&fnv1a, &info) && info.dli_fname) {
+    std::string path = info.dli_fname;
+    const size_t slash = path.rfind('/');
+    path = slash == std::string::npos ? "." : path.substr(0, slash);
+    return path + "/_kcache";
+  }
+  return "/tmp/okx_kcache";
+}
+
+bool read_file(const std::string& path, std::string* data) {
+  FILE* fh = std::fopen(path.c_str(), "rb");
+  if (!fh) return false;
+  std::fseek(fh, 0, SEEK_END);
+  const long size = std::ftell(fh);
+  std::fseek(fh, 0, SEEK_SET);
+  if (size <= 0) {
+    std::fclose(fh);
+    return false;
+  }
+  data->resize((size_t)size);
+  const size_t got = std::fread(&(*data)[0], 1, (size_t)size, fh);
+  std::fclose(fh);
+  return got == (size_t)size;
+}
+
+void write_file_atomic(const std::string& path, const std::string& data) {
+  const std::string part = path + ".tmp" + std::to_string((long)getpid());
+  FILE* fh = std::fopen(part.c_str(), "wb");
+  if (!fh) return;  // a read-only cache directory only costs recompilation
+  const size_t put = std::fwrite(data.data(), 1, data.size(), fh);
+  std::fclose(fh);
+  if (put == data.size())
+    std::rename(part.c_str(), path.c_str());
+  else
+    std::remove(part.c_str());
+}
+
+}  // namespace
+
+bool quad_compile(const std::string& src, std::string* code, std::string* err) {
+  int major = 0, minor = 0;
+  (void)hiprtcVersion(&major, &minor);
+  unsigned long long h = fnv1a(src);
+  for (int k = 0; k < kNumOptions; ++k) h = fnv1a(kOptions[k], h);
+  h = fnv1a(std::to_string(major) + "." + std::to_string(minor), h);
+  char name[64];
+  std::snprintf(name, sizeof(name), "/okxq_%016llx", h);
+  const std::string dir = cache_dir();
+  const std::string path = dir + name + ".hsaco";
+  const bool no_cache = getenv("OKX_KERNEL_NOCACHE") != nullptr;
+  if (!no_cache && read_file(path, code)) return true;
+
+  hiprtcProgram prog;
+  hiprtcResult rc = hiprtcCreateProgram(&prog, src.c_str(), "okx_quad.hip", 0, nullptr, nullptr);
+  if (rc != HIPRTC_SUCCESS) {
+    *err = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(rc);
+    return false;
+  }
+  rc = hiprtcCompileProgram(prog, kNumOptions, kOptions);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t log_size = 0;
+    (void)hiprtcGetProgramLogSize(prog, &log_size);
+    std::string log(log_size, '\0');
+    if (log_size) (void)hiprtcGetProgramLog(prog, &log[0]);
+    if (log.size() > 3000) log.resize(3000);
+    *err = std::string("hiprtcCompileProgram: ") + hiprtcGetErrorString(rc) + "\n" + log;
+    (void)hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  size_t size = 0;
+  rc = hiprtcGetCodeSize(prog, &size);
+  if (rc != HIPRTC_SUCCESS || size == 0) {
+    *err = "hiprtcGetCodeSize failed";
+    (void)hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  code->resize(size);
+  rc = hiprtcGetCode(prog, &(*code)[0]);
+  (void)hiprtcDestroyProgram(&prog);
+  if (rc != HIPRTC_SUCCESS) {
+    *err = "hiprtcGetCode failed";
+    return false;
+  }
+  if (!no_cache) {
+    (void)mkdir(dir.c_str(), 0777);
+    write_file_atomic(path, *code);
+    if (getenv("OKX_KERNEL_KEEP_SOURCE")) write_file_atomic(dir + name + ".hip", src);
+  }
+  return true;
+}
+
+}  // namespace okx

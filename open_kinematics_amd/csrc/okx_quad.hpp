@@ -1,0 +1,53 @@
+// okx_quad.hpp — runtime-specialised "quad" solve kernel: source generation (okx_quadgen.cpp)
+// and hiprtc compilation / caching / loading (okx_jit.cpp).
+#pragma once
+
+#include <string>
+
+#include "okx_plan.hpp"
+
+namespace okx {
+
+constexpr int kQuadMaxFree = 8;  // n <= 24 unknowns: the lane-owned rows of J^T J stay in registers
+
+// Kernel arguments of the generated kernels (mirrors `struct QArgs` in the generated source).
+struct QuadArgs {
+  const double* targets;
+  const double* geom_pos;
+  const double* geom_row_param;
+  double* out_pos;
+  okx_info* info;
+  long long n_problems, steps_per_geometry, chain_len;
+  int max_iter, pad;
+  double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
+  const double* design_pos;
+  const double* row_param;
+  const double* dop_param;
+};
+
+// Arguments of the generated parity kernel `okx_quad_eval` (mirrors `struct QEvalArgs`).
+struct QuadEvalArgs {
+  const double* x;
+  const double* targets;
+  double* r;
+  double* ata;
+  double* atr;
+  double* dx;
+  double lambda;
+  long long n_problems;
+  const double* design_pos;
+  const double* row_param;
+  const double* dop_param;
+};
+
+// Emits the HIP source of the kernel specialised to `P`.  Returns false (and says why) when the
+// program uses a feature the generator has no code path for; the caller then keeps the generic
+// interpreter kernels of okx_kernels.hip.
+bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why);
+
+// Compiles `src` for gfx950 with hiprtc (no device needed) or fetches it from the on-disk cache
+// (<dir of libokx.so>/_kcache/<hash>.hsaco, override with OKX_KERNEL_CACHE).  Returns the code
+// object in `code`; false + message on failure.
+bool quad_compile(const std::string& src, std::string* code, std::string* err);
+
+}  // namespace okx

@@ -1,0 +1,1010 @@
+// okx_quadgen.cpp — source generator of the "quad" solve kernel: a gfx950 kernel specialised to
+// ONE constraint program, compiled at okx_program_create time with hiprtc (okx_jit.cpp).
+//
+// Why generate code.  The reference itself generates its Jacobian rows (tools/generate_jacobians.py
+// -> core/jacobians.py) and then interprets the problem structure in Python on every call
+// (ResidualComputer.compute / compute_jacobian, core/solver.py:226-275, :502-581).  The generic
+// kernels in okx_kernels.hip interpret the same structure on the GPU (one wavefront per problem,
+// tables in LDS); here the structure is resolved at program-creation time instead, so that the
+// kernel is straight-line fp64 code with every operand in a statically named register.
+//
+// Execution model of the generated kernel (CDNA4, 64-wide wavefronts):
+//   * FOUR LANES OWN ONE PROBLEM ("quad"), 16 problems per wavefront, all in lockstep.
+//     Lane c in {0,1,2} of a quad owns Cartesian component c of every point and therefore the
+//     variables x[3F+c], the Jacobian columns 3F+c and the rows 3F+c of J^T J / of its LDL^T
+//     factor, for every free point F.  Lane 3 carries zeros.
+//   * All three lanes run the same instruction stream on the same block structure, so there
+//     is no index table, no LDS and no divergence inside a problem.  Cross-lane operands
+//     (dot products, cross products, J^T J columns, pivots) move through DPP quad_perm
+//     (v_mov_b32_dpp, 2 per double), never through LDS.
+//   * Structural zeros of J^T J and of the factor (block level, symbolic fill-in) are
+//     resolved here: the emitted LDL^T touches only blocks that can be non-zero.
+//   * Levenberg-Marquardt control flow is predicated per quad; a wavefront iterates until its
+//     16 problems are done.
+//
+// Same objective, same residual/Jacobian definitions and same LM policy as okx_solve_kernel
+// (DESIGN.md §4); only the parallel decomposition differs.
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "okx_plan.hpp"
+#include "okx_quad.hpp"
+
+namespace okx {
+namespace {
+
+// A per-lane fp64 value held in a named variable, with a sign folded into its uses.
+struct LV {
+  std::string n;
+  int sg = 1;
+};
+
+// d(derived point)/d(free block) as seen by the quad: lane c holds COLUMN c of the 3x3 block
+// (col[r] = B[r][c]), or the block is s * I.
+struct Blk {
+  bool scaled = true;
+  std::string s;       // scaled: scalar expression
+  std::string col[3];  // general: variable names
+};
+
+struct BlkTerm {
+  Blk b;
+  int sg;
+};
+
+class Gen {
+ public:
+  explicit Gen(const DevProgram& prog) : P(prog) {
+    blk_of_point.assign(P.n_points, -1);
+    dop_of_point.assign(P.n_points, -1);
+    for (int k = 0; k < P.n_free; ++k) blk_of_point[P.free_point[k]] = k;
+    for (int e = 0; e < P.n_derived; ++e) dop_of_point[P.dop_out[e]] = e;
+  }
+
+  const DevProgram& P;
+  std::string out;
+  std::string why;
+  std::vector<int> blk_of_point, dop_of_point;
+  int uid = 0;
+  std::map<std::string, std::string> rot1_, rot2_;
+  std::map<std::string, std::vector<std::string>> bc_;
+  std::map<int, std::map<int, Blk>> dblk;  // active derived op -> free block -> chain block
+  bool nz[kMaxFree][kMaxFree] = {};
+
+  void f(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    out += buf;
+    out += '\n';
+  }
+  std::string tmp(const char* base) { return "_" + std::string(base) + std::to_string(uid++); }
+  static std::string sx(const LV& v) { return (v.sg < 0 ? "-" : "") + v.n; }
+  static std::string pn(int p) { return "p" + std::to_string(p); }
+  void reset_caches() {
+    rot1_.clear();
+    rot2_.clear();
+    bc_.clear();
+  }
+
+  // ---- quad data movement ----
+  std::string bcast(const std::string& n, int r) {
+    std::vector<std::string>& slot = bc_[n];
+    if (slot.empty()) slot.resize(3);
+    if (slot[r].empty()) {
+      std::string t = tmp("b");
+      f("    const double %s = QB%d(%s);", t.c_str(), r, n.c_str());
+      slot[r] = t;
+    }
+    return slot[r];
+  }
+  std::string rot1(const std::string& n) {
+    auto it = rot1_.find(n);
+    if (it != rot1_.end()) return it->second;
+    std::string t = tmp("ra");
+    f("    const double %s = QR1(%s);", t.c_str(), n.c_str());
+    rot1_[n] = t;
+    return t;
+  }
+  std::string rot2(const std::string& n) {
+    auto it = rot2_.find(n);
+    if (it != rot2_.end()) return it->second;
+    std::string t = tmp("rb");
+    f("    const double %s = QR2(%s);", t.c_str(), n.c_str());
+    rot2_[n] = t;
+    return t;
+  }
+  // lane c: (a x b)_c = a_{c+1} b_{c+2} - a_{c+2} b_{c+1}
+  std::string cross(const std::string& a, const std::string& b) {
+    std::string a1 = rot1(a), a2 = rot2(a), b1 = rot1(b), b2 = rot2(b);
+    std::string t = tmp("cx");
+    f("    const double %s = %s * %s - %s * %s;", t.c_str(), a1.c_str(), b2.c_str(), a2.c_str(), b1.c_str());
+    return t;
+  }
+  std::string vsub(const std::string& a, const std::string& b) {
+    std::string t = tmp("v");
+    f("    const double %s = %s - %s;", t.c_str(), a.c_str(), b.c_str());
+    return t;
+  }
+  std::string dot(const std::string& a, const std::string& b) {
+    std::string t = tmp("d");
+    f("    const double %s = qsum(%s * %s);", t.c_str(), a.c_str(), b.c_str());
+    return t;
+  }
+
+  // ---- derived points ----
+  std::map<int, Blk> blocks_of_point(int p) {
+    std::map<int, Blk> r;
+    if (blk_of_point[p] >= 0) {
+      Blk b;
+      b.scaled = true;
+      b.s = "1.0";
+      r[blk_of_point[p]] = b;
+    } else if (dop_of_point[p] >= 0) {
+      auto it = dblk.find(dop_of_point[p]);
+      if (it != dblk.end()) r = it->second;
+    }
+    return r;
+  }
+
+  // Sum block terms per free block into one Blk each.
+  std::map<int, Blk> combine(std::map<int, std::vector<BlkTerm>>& acc) {
+    std::map<int, Blk> res;
+    for (auto& kv : acc) {
+      std::string ssum;
+      std::vector<BlkTerm*> gen;
+      for (auto& t : kv.second) {
+        if (t.b.scaled) {
+          if (!ssum.empty()) ssum += t.sg < 0 ? " - " : " + ";
+          else if (t.sg < 0) ssum += "-";
+          ssum += "(" + t.b.s + ")";
+        } else {
+          gen.push_back(&t);
+        }
+      }
+      Blk b;
+      if (gen.empty()) {
+        b.scaled = true;
+        std::string t = tmp("ks");
+        f("    const double %s = %s;", t.c_str(), ssum.c_str());
+        b.s = t;
+      } else {
+        b.scaled = false;
+        for (int r = 0; r < 3; ++r) {
+          std::string e;
+          for (auto* t : gen) {
+            if (!e.empty()) e += t->sg < 0 ? " - " : " + ";
+            else if (t->sg < 0) e += "-";
+            e += t->b.col[r];
+          }
+          if (!ssum.empty()) e += " + (" + ssum + ") * e" + std::to_string(r);
+          std::string t = tmp("B");
+          f("    const double %s = %s;", t.c_str(), e.c_str());
+          b.col[r] = t;
+        }
+      }
+      res[kv.first] = b;
+    }
+    return res;
+  }
+
+  bool derived_op(int e, bool with_blocks) {
+    const int type = P.dop_type[e];
+    const int* pts = P.dop_pts[e];
+    const std::string o = pn(P.dop_out[e]);
+    f("    // derived op %d (type %d) -> point %d", e, type, P.dop_out[e]);
+    if (type == OKX_DOP_MIDPOINT) {  // definitions.py:76-89
+      f("    %s = %s + (%s - %s) * 0.5;", o.c_str(), pn(pts[0]).c_str(), pn(pts[1]).c_str(), pn(pts[0]).c_str());
+      if (with_blocks) {
+        std::map<int, std::vector<BlkTerm>> acc;
+        for (int s = 0; s < 2; ++s)
+          for (auto& kv : blocks_of_point(pts[s])) {
+            Blk b = kv.second;
+            if (b.scaled) {
+              b.s = "0.5 * (" + b.s + ")";
+            } else {
+              for (int r = 0; r < 3; ++r) {
+                std::string t = tmp("B");
+                f("    const double %s = 0.5 * %s;", t.c_str(), b.col[r].c_str());
+                b.col[r] = t;
+              }
+            }
+            acc[kv.first].push_back({b, 1});
+          }
+        dblk[e] = combine(acc);
+      }
+      return true;
+    }
+    if (type == OKX_DOP_ALONG) {  // definitions.py:24-33, :92-155: out = base + normalize(a - b) * c
+      std::string v = vsub(pn(pts[1]), pn(pts[2]));
+      std::string s2 = dot(v, v);
+      std::string nrm = tmp("nr"), inrm = tmp("in"), u = tmp("u");
+      f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", nrm.c_str(), inrm.c_str(), s2.c_str(), nrm.c_str(),
+        inrm.c_str());
+      f("    const double %s = %s * %s;", u.c_str(), v.c_str(), inrm.c_str());
+      f("    %s = %s + %s * a.dop_param[%d];", o.c_str(), pn(pts[0]).c_str(), u.c_str(), e);
+      if (with_blocks) {
+        std::map<int, std::vector<BlkTerm>> acc;
+        for (auto& kv : blocks_of_point(pts[0])) acc[kv.first].push_back({kv.second, 1});
+        std::string k = tmp("k");
+        f("    const double %s = a.dop_param[%d] * %s;", k.c_str(), e, inrm.c_str());
+        std::string ub[3];
+        bool have_ub = false;
+        for (int s = 1; s <= 2; ++s) {
+          const int sg = s == 1 ? 1 : -1;
+          for (auto& kv : blocks_of_point(pts[s])) {
+            if (!have_ub) {
+              for (int r = 0; r < 3; ++r) ub[r] = bcast(u, r);
+              have_ub = true;
+            }
+            Blk nb;
+            nb.scaled = false;
+            const Blk& b = kv.second;
+            if (b.scaled) {  // k s (e_r - u_r u_c)
+              std::string ks = tmp("ks");
+              f("    const double %s = %s * (%s);", ks.c_str(), k.c_str(), b.s.c_str());
+              for (int r = 0; r < 3; ++r) {
+                std::string t = tmp("B");
+                f("    const double %s = %s * (e%d - %s * %s);", t.c_str(), ks.c_str(), r, ub[r].c_str(), u.c_str());
+                nb.col[r] = t;
+              }
+            } else {  // k (b_r - u_r (u . b))
+              std::string ud = tmp("ud");
+              f("    const double %s = %s * %s + %s * %s + %s * %s;", ud.c_str(), ub[0].c_str(), b.col[0].c_str(),
+                ub[1].c_str(), b.col[1].c_str(), ub[2].c_str(), b.col[2].c_str());
+              for (int r = 0; r < 3; ++r) {
+                std::string t = tmp("B");
+                f("    const double %s = %s * (%s - %s * %s);", t.c_str(), k.c_str(), b.col[r].c_str(), ub[r].c_str(),
+                  ud.c_str());
+                nb.col[r] = t;
+              }
+            }
+            acc[kv.first].push_back({nb, sg});
+          }
+        }
+        dblk[e] = combine(acc);
+      }
+      return true;
+    }
+    if (type == OKX_DOP_CONTACT_PATCH) {  // definitions.py:36-73, :158-180
+      if (with_blocks) {
+        why = "a constraint row depends on a contact-patch point";
+        return false;
+      }
+      std::string v = vsub(pn(pts[2]), pn(pts[1]));
+      std::string vv = dot(v, v);
+      std::string vn = tmp("vn"), ivn = tmp("iv"), ax = tmp("ax");
+      f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", vn.c_str(), ivn.c_str(), vv.c_str(), vn.c_str(),
+        ivn.c_str());
+      f("    const double %s = %s * %s;", ax.c_str(), v.c_str(), ivn.c_str());
+      std::string az = bcast(ax, 2);
+      std::string wd = tmp("wd");
+      f("    const double %s = %s * %s - e2;", wd.c_str(), az.c_str(), ax.c_str());  // -ga a - e_z, ga = -a_z
+      std::string ww = dot(wd, wd);
+      std::string wn = tmp("wn"), iwn = tmp("iw");
+      f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", wn.c_str(), iwn.c_str(), ww.c_str(), wn.c_str(),
+        iwn.c_str());
+      f("    %s = %s + (%s * %s) * a.dop_param[%d];", o.c_str(), pn(pts[0]).c_str(), wd.c_str(), iwn.c_str(), e);
+      return true;
+    }
+    why = "unknown derived op";
+    return false;
+  }
+
+  // ---- rows ----
+  struct RowOut {
+    std::string r;                            // residual (uniform in the quad)
+    std::vector<std::pair<int, LV>> partial;  // point -> d r / d point (lane component)
+    std::string absres;                       // |r| in the reference's row definition ("" = skip)
+  };
+
+  std::string rp(int i, int k) {
+    char b[64];
+    if (i < P.n_crows)
+      std::snprintf(b, sizeof(b), "gq[%d]", i * 8 + k);
+    else
+      std::snprintf(b, sizeof(b), "a.row_param[%d]", i * 8 + k);
+    return b;
+  }
+  // lane-component load of three consecutive row parameters (0 in lane 3)
+  std::string rpv(int i, int k0) {
+    std::string t = tmp("q");
+    if (i < P.n_crows)
+      f("    const double %s = c < 3 ? gq[%d + cc] : 0.0;", t.c_str(), i * 8 + k0);
+    else
+      f("    const double %s = c < 3 ? a.row_param[%d + cc] : 0.0;", t.c_str(), i * 8 + k0);
+    return t;
+  }
+
+  bool row(int i, RowOut* ro) {
+    const int type = P.row_type[i];
+    const int* pts = P.row_pts[i];
+    f("    // row %d (type %d)", i, type);
+    std::string r = "r" + std::to_string(i);
+    ro->r = r;
+    ro->absres = "fabs(" + r + ")";
+    switch (type) {
+      case OKX_ROW_DISTANCE:
+      case OKX_ROW_SPHERICAL: {  // constraints.py:125-134,162-170; jacobians.py:35-51
+        std::string d = vsub(pn(pts[1]), pn(pts[0]));
+        std::string s = dot(d, d);
+        std::string root = tmp("rt"), inv = tmp("iv"), g = tmp("g");
+        f("    double %s, %s; fast_sqrt_rsqrt(%s + EPS_SQ, &%s, &%s);", root.c_str(), inv.c_str(), s.c_str(),
+          root.c_str(), inv.c_str());
+        f("    const double %s = %s * %s;", g.c_str(), d.c_str(), inv.c_str());
+        if (type == OKX_ROW_DISTANCE)
+          f("    const double %s = (%s - EPS) - %s;", r.c_str(), root.c_str(), rp(i, 0).c_str());
+        else
+          f("    const double %s = %s - EPS;", r.c_str(), root.c_str());
+        ro->partial.push_back({pts[0], {g, -1}});
+        ro->partial.push_back({pts[1], {g, 1}});
+        return true;
+      }
+      case OKX_ROW_ANGLE:
+      case OKX_ROW_THREE_POINT_ANGLE: {  // constraints.py:223-243,287-308; jacobians.py:55-188
+        std::string v1, v2;
+        if (type == OKX_ROW_ANGLE) {
+          v1 = vsub(pn(pts[1]), pn(pts[0]));
+          v2 = vsub(pn(pts[3]), pn(pts[2]));
+        } else {
+          v1 = vsub(pn(pts[0]), pn(pts[1]));
+          v2 = vsub(pn(pts[2]), pn(pts[1]));
+        }
+        std::string cv = cross(v1, v2);
+        std::string c2 = dot(cv, cv);
+        std::string dt = dot(v1, v2);
+        std::string s = tmp("s"), is = tmp("is"), t15 = tmp("t");
+        f("    const double %s = EPS_SQ + %s;", t15.c_str(), c2.c_str());
+        f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", s.c_str(), is.c_str(), t15.c_str(), s.c_str(),
+          is.c_str());
+        std::string inv = tmp("iv"), ka = tmp("ka"), kb = tmp("kb");
+        f("    const double %s = fast_rcp(%s + %s * %s);", inv.c_str(), t15.c_str(), dt.c_str(), dt.c_str());
+        f("    const double %s = %s * %s * %s, %s = %s * %s;", ka.c_str(), dt.c_str(), inv.c_str(), is.c_str(),
+          kb.c_str(), s.c_str(), inv.c_str());
+        std::string w1 = cross(v2, cv), w2 = cross(cv, v1);
+        std::string g1 = tmp("g"), g2 = tmp("g");
+        f("    const double %s = %s * %s - %s * %s;", g1.c_str(), ka.c_str(), w1.c_str(), kb.c_str(), v2.c_str());
+        f("    const double %s = %s * %s - %s * %s;", g2.c_str(), ka.c_str(), w2.c_str(), kb.c_str(), v1.c_str());
+        f("    const double %s = lean_atan2_pos(%s - EPS, %s) - %s;", r.c_str(), s.c_str(), dt.c_str(),
+          rp(i, 0).c_str());
+        if (type == OKX_ROW_ANGLE) {
+          ro->partial.push_back({pts[0], {g1, -1}});
+          ro->partial.push_back({pts[1], {g1, 1}});
+          ro->partial.push_back({pts[2], {g2, -1}});
+          ro->partial.push_back({pts[3], {g2, 1}});
+        } else {
+          std::string gm = tmp("g");
+          f("    const double %s = -%s - %s;", gm.c_str(), g1.c_str(), g2.c_str());
+          ro->partial.push_back({pts[0], {g1, 1}});
+          ro->partial.push_back({pts[1], {gm, 1}});
+          ro->partial.push_back({pts[2], {g2, 1}});
+        }
+        return true;
+      }
+      case OKX_ROW_EQUAL_DISTANCE: {  // constraints.py:466-477; jacobians.py:322-367
+        std::string d1 = vsub(pn(pts[1]), pn(pts[0])), d2 = vsub(pn(pts[3]), pn(pts[2]));
+        std::string s1 = dot(d1, d1), s2 = dot(d2, d2);
+        std::string r1 = tmp("rt"), i1 = tmp("iv"), r2 = tmp("rt"), i2 = tmp("iv");
+        f("    double %s, %s, %s, %s; fast_sqrt_rsqrt(%s + EPS_SQ, &%s, &%s); fast_sqrt_rsqrt(%s + EPS_SQ, &%s, &%s);",
+          r1.c_str(), i1.c_str(), r2.c_str(), i2.c_str(), s1.c_str(), r1.c_str(), i1.c_str(), s2.c_str(),
+          r2.c_str(), i2.c_str());
+        std::string g1 = tmp("g"), g2 = tmp("g");
+        f("    const double %s = %s * %s, %s = %s * %s;", g1.c_str(), d1.c_str(), i1.c_str(), g2.c_str(), d2.c_str(),
+          i2.c_str());
+        f("    const double %s = (%s - EPS) - (%s - EPS);", r.c_str(), r1.c_str(), r2.c_str());
+        ro->partial.push_back({pts[0], {g1, -1}});
+        ro->partial.push_back({pts[1], {g1, 1}});
+        ro->partial.push_back({pts[2], {g2, 1}});
+        ro->partial.push_back({pts[3], {g2, -1}});
+        return true;
+      }
+      case OKX_ROW_FIXED_AXIS: {  // constraints.py:508-516; solver.py:407-416
+        const int ax = (int)P.row_param[i][0];
+        std::string pa = bcast(pn(pts[0]), ax);
+        f("    const double %s = %s - %s;", r.c_str(), pa.c_str(), rp(i, 1).c_str());
+        ro->partial.push_back({pts[0], {"e" + std::to_string(ax), 1}});
+        return true;
+      }
+      case OKX_ROW_POINT_ON_LINE:
+      case OKX_ROW_LINE_PIN: {  // constraints.py:560-576; jacobians.py:372-403; okx.h (pin)
+        std::string lp = rpv(i, 0), ld = rpv(i, 3);
+        std::string w = vsub(pn(pts[0]), lp);
+        std::string cv = cross(w, ld);
+        if (type == OKX_ROW_POINT_ON_LINE) {
+          std::string c2 = dot(cv, cv);
+          std::string root = tmp("rt"), inv = tmp("iv");
+          f("    double %s, %s; fast_sqrt_rsqrt(EPS_SQ + %s, &%s, &%s);", root.c_str(), inv.c_str(), c2.c_str(),
+            root.c_str(), inv.c_str());
+          std::string gx = cross(ld, cv);
+          std::string g = tmp("g");
+          f("    const double %s = %s * %s;", g.c_str(), inv.c_str(), gx.c_str());
+          f("    const double %s = %s - EPS;", r.c_str(), root.c_str());
+          ro->partial.push_back({pts[0], {g, 1}});
+          return true;
+        }
+        const int comp = (int)P.row_param[i][6];
+        // r = e_comp . (w x ld) = w . (ld x e_comp)
+        std::string g = cross(ld, "e" + std::to_string(comp));
+        std::string rc = bcast(cv, comp);
+        f("    const double %s = %s;", r.c_str(), rc.c_str());
+        ro->partial.push_back({pts[0], {g, 1}});
+        if (comp == 0) {
+          // reported as the reference's single softnorm residual (constraints.py:560-576)
+          std::string c2 = dot(cv, cv);
+          ro->absres = "fabs(sqrt(" + c2 + " + EPS_SQ) - EPS)";
+        } else {
+          ro->absres.clear();
+        }
+        return true;
+      }
+      case OKX_ROW_POINT_ON_PLANE: {  // constraints.py:616-627; solver.py:429-437
+        std::string pp = rpv(i, 0), nn = rpv(i, 3);
+        std::string w = vsub(pn(pts[0]), pp);
+        std::string d = dot(w, nn);
+        f("    const double %s = %s;", r.c_str(), d.c_str());
+        ro->partial.push_back({pts[0], {nn, 1}});
+        return true;
+      }
+      case OKX_ROW_MIDPOINT_ON_PLANE: {  // constraints.py:657-666; solver.py:439-448
+        std::string pp = rpv(i, 0), nn = rpv(i, 3);
+        std::string mid = tmp("m");
+        f("    const double %s = %s + (%s - %s) * 0.5;", mid.c_str(), pn(pts[0]).c_str(), pn(pts[1]).c_str(),
+          pn(pts[0]).c_str());
+        std::string w = vsub(mid, pp);
+        std::string d = dot(w, nn);
+        std::string h = tmp("h");
+        f("    const double %s = 0.5 * %s;", h.c_str(), nn.c_str());
+        f("    const double %s = %s;", r.c_str(), d.c_str());
+        ro->partial.push_back({pts[0], {h, 1}});
+        ro->partial.push_back({pts[1], {h, 1}});
+        return true;
+      }
+      case OKX_ROW_COPLANAR:
+      case OKX_ROW_SCALAR_TRIPLE: {  // constraints.py:698-709,731-733; jacobians.py:426-483
+        std::string v1 = vsub(pn(pts[1]), pn(pts[0])), v2 = vsub(pn(pts[2]), pn(pts[0])),
+                    v3 = vsub(pn(pts[3]), pn(pts[0]));
+        std::string c23 = cross(v2, v3), c31 = cross(v3, v1), c12 = cross(v1, v2);
+        std::string vol = dot(v1, c23);
+        std::string g1 = c23, g2 = c31, g3 = c12;
+        if (type == OKX_ROW_SCALAR_TRIPLE) {
+          std::string isc = tmp("is");
+          f("    const double %s = 1.0 / %s;", isc.c_str(), rp(i, 1).c_str());
+          g1 = tmp("g"), g2 = tmp("g"), g3 = tmp("g");
+          f("    const double %s = %s * %s, %s = %s * %s, %s = %s * %s;", g1.c_str(), c23.c_str(), isc.c_str(),
+            g2.c_str(), c31.c_str(), isc.c_str(), g3.c_str(), c12.c_str(), isc.c_str());
+          f("    const double %s = (%s - %s) * %s;", r.c_str(), vol.c_str(), rp(i, 0).c_str(), isc.c_str());
+        } else {
+          f("    const double %s = %s;", r.c_str(), vol.c_str());
+        }
+        std::string g0 = tmp("g");
+        f("    const double %s = -(%s + %s + %s);", g0.c_str(), g1.c_str(), g2.c_str(), g3.c_str());
+        ro->partial.push_back({pts[0], {g0, 1}});
+        ro->partial.push_back({pts[1], {g1, 1}});
+        ro->partial.push_back({pts[2], {g2, 1}});
+        ro->partial.push_back({pts[3], {g3, 1}});
+        return true;
+      }
+      case kRowTarget: {  // solver.py:264-270, :560-579
+        std::string dir = rpv(i, 0);
+        std::string d = dot(pn(pts[0]), dir);
+        f("    const double %s = %s - tv%d;", r.c_str(), d.c_str(), (int)P.row_param[i][3]);
+        ro->partial.push_back({pts[0], {dir, 1}});
+        return true;
+      }
+      default:
+        why = "row type " + std::to_string(type) + " has no quad code path yet";
+        return false;
+    }
+  }
+
+  static std::string A(int F, int G, int k) {
+    return "A" + std::to_string(F) + "_" + std::to_string(G) + "_" + std::to_string(k);
+  }
+  static std::string Ln(int F, int G, int k) {
+    return "L" + std::to_string(F) + "_" + std::to_string(G) + "_" + std::to_string(k);
+  }
+
+  // Rows + normal equations: r_i, cost, max |r|, J^T J blocks A{F}_{G}_{k}, gradient gn{F}.
+  bool emit_rows() {
+    const int nf = P.n_free;
+    for (int F = 0; F < nf; ++F) {
+      f("    double gn%d = 0.0;", F);
+      nz[F][F] = true;
+    }
+    f("    double ss = 0.0, mres_new = 0.0;");
+    std::set<std::string> declared;
+    for (int i = 0; i < P.m; ++i) {
+      RowOut ro;
+      if (!row(i, &ro)) return false;
+      f("    ss = fma(%s, %s, ss);", ro.r.c_str(), ro.r.c_str());
+      if (!ro.absres.empty()) f("    mres_new = fmax(mres_new, %s);", ro.absres.c_str());
+      // point partials -> free blocks
+      std::map<int, std::vector<LV>> terms;
+      for (auto& pp : ro.partial) {
+        const int pt = pp.first;
+        const LV& gp = pp.second;
+        if (blk_of_point[pt] >= 0) {
+          terms[blk_of_point[pt]].push_back(gp);
+        } else if (dop_of_point[pt] >= 0) {
+          auto it = dblk.find(dop_of_point[pt]);
+          if (it == dblk.end()) {
+            why = "row reads a derived point without chain blocks";
+            return false;
+          }
+          for (auto& kv : it->second) {
+            const Blk& b = kv.second;
+            std::string t = tmp("j");
+            if (b.scaled) {
+              f("    const double %s = (%s) * %s;", t.c_str(), b.s.c_str(), gp.n.c_str());
+            } else {  // point_partial @ block (solver.py:554-558): lane c forms column c
+              std::string b0 = bcast(gp.n, 0), b1 = bcast(gp.n, 1), b2 = bcast(gp.n, 2);
+              f("    const double %s = %s * %s + %s * %s + %s * %s;", t.c_str(), b0.c_str(), b.col[0].c_str(),
+                b1.c_str(), b.col[1].c_str(), b2.c_str(), b.col[2].c_str());
+            }
+            terms[kv.first].push_back({t, gp.sg});
+          }
+        }
+      }
+      std::vector<std::pair<int, LV>> jv;
+      for (auto& kv : terms) {
+        if (kv.second.size() == 1) {
+          jv.push_back({kv.first, kv.second[0]});
+        } else {
+          std::string e;
+          for (auto& t : kv.second) {
+            if (!e.empty()) e += t.sg < 0 ? " - " : " + ";
+            else if (t.sg < 0) e += "-";
+            e += t.n;
+          }
+          std::string t = tmp("j");
+          f("    const double %s = %s;", t.c_str(), e.c_str());
+          jv.push_back({kv.first, {t, 1}});
+        }
+      }
+      // J^T r and J^T J (lower block triangle: F >= G)
+      for (auto& fv : jv) f("    gn%d = fma(%s, %s, gn%d);", fv.first, sx(fv.second).c_str(), ro.r.c_str(), fv.first);
+      for (size_t ia = 0; ia < jv.size(); ++ia)
+        for (size_t ib = 0; ib <= ia; ++ib) {
+          const int F = jv[ia].first, G = jv[ib].first;
+          const LV& jF = jv[ia].second;
+          const LV& jG = jv[ib].second;
+          nz[F][G] = true;
+          for (int k = 0; k < 3; ++k) {
+            std::string b = bcast(jG.n, k);
+            const int sg = jF.sg * jG.sg;
+            std::string an = A(F, G, k);
+            if (!declared.count(an)) {
+              declared.insert(an);
+              f("    double %s = %s%s * %s;", an.c_str(), sg < 0 ? "-" : "", jF.n.c_str(), b.c_str());
+            } else {
+              f("    %s = fma(%s%s, %s, %s);", an.c_str(), sg < 0 ? "-" : "", jF.n.c_str(), b.c_str(), an.c_str());
+            }
+          }
+        }
+    }
+    // diagonal blocks that no row touched still exist (as zeros)
+    for (int F = 0; F < nf; ++F)
+      for (int k = 0; k < 3; ++k)
+        if (!declared.count(A(F, F, k))) f("    double %s = 0.0;", A(F, F, k).c_str());
+    return true;
+  }
+
+  // LDL^T of (J^T J + lambda I), forward / diagonal / backward substitution -> dx{F}.
+  void emit_solve() {
+    const int nf = P.n_free;
+    bool fill[kMaxFree][kMaxFree];
+    for (int F = 0; F < nf; ++F)
+      for (int G = 0; G < nf; ++G) fill[F][G] = nz[F][G];
+    f("    // ---- damped normal equations: LDL^T, lane c owns rows 3F+c ----");
+    for (int F = 0; F < nf; ++F)
+      for (int k = 0; k < 3; ++k) f("    %s = fma(lambda, e%d, %s);", A(F, F, k).c_str(), k, A(F, F, k).c_str());
+    f("    bool ok = true;");
+    for (int F = 0; F < nf; ++F) f("    double dinv%d = 0.0;", F);
+    for (int G = 0; G < nf; ++G)
+      for (int k = 0; k < 3; ++k) {
+        f("    { // column %d", 3 * G + k);
+        f("    double piv = QB%d(%s);", k, A(G, G, k).c_str());
+        f("    ok = ok && piv > 0.0; piv = ok ? piv : 1.0;");
+        f("    const double rinv = fast_rcp(piv);");
+        f("    dinv%d = c == %d ? rinv : dinv%d;", G, k, G);
+        // factor entries of this column (rows below the pivot)
+        if (k < 2) f("    %s = c > %d ? %s * rinv : 0.0;", Ln(G, G, k).c_str(), k, A(G, G, k).c_str());
+        for (int F = G + 1; F < nf; ++F)
+          if (fill[F][G]) f("    %s = %s * rinv;", Ln(F, G, k).c_str(), A(F, G, k).c_str());
+        // trailing update: A[v][u] -= L[v][w] * A[u][w]
+        for (int H = G; H < nf; ++H) {
+          if (H > G && !fill[H][G]) continue;
+          for (int j = (H == G ? k + 1 : 0); j < 3; ++j) {
+            f("    { const double cu = QB%d(%s);", j, A(H, G, k).c_str());
+            for (int F = H; F < nf; ++F) {
+              if (F > G && !fill[F][G]) continue;
+              if (F == G && k == 2) continue;
+              if (!fill[F][H]) {
+                // fill-in: the block becomes structurally non-zero; its columns start from zero
+                fill[F][H] = true;
+              }
+              f("      %s = fma(-%s, cu, %s);", A(F, H, j).c_str(), Ln(F, G, k).c_str(), A(F, H, j).c_str());
+            }
+            f("    }");
+          }
+        }
+        f("    }");
+      }
+    for (int F = 0; F < nf; ++F)
+      for (int G = 0; G < nf; ++G) fillf[F][G] = fill[F][G];
+    // forward substitution, block by block (unit lower factor)
+    f("    // ---- L y = -g ----");
+    for (int F = 0; F < nf; ++F) f("    double y%d = -g%d;", F, F);
+    for (int G = 0; G < nf; ++G) {
+      f("    { const double yb0 = QB0(y%d); y%d = fma(-%s, yb0, y%d);", G, G, Ln(G, G, 0).c_str(), G);
+      f("      const double yb1 = QB1(y%d); y%d = fma(-%s, yb1, y%d);", G, G, Ln(G, G, 1).c_str(), G);
+      f("      const double yb2 = QB2(y%d);", G);
+      for (int F = G + 1; F < nf; ++F)
+        if (fill[F][G])
+          f("      y%d = fma(-%s, yb0, fma(-%s, yb1, fma(-%s, yb2, y%d)));", F, Ln(F, G, 0).c_str(), Ln(F, G, 1).c_str(),
+            Ln(F, G, 2).c_str(), F);
+      f("    }");
+    }
+    f("    // ---- D z = y, L^T dx = z ----");
+    for (int G = nf - 1; G >= 0; --G) {
+      f("    double nx%d = y%d * dinv%d;", G, G, G);
+      bool any = false;
+      for (int F = G + 1; F < nf; ++F) any = any || fill[F][G];
+      if (any) {
+        f("    { double s0 = 0.0, s1 = 0.0, s2 = 0.0;");
+        for (int F = G + 1; F < nf; ++F)
+          if (fill[F][G])
+            f("      s0 = fma(%s, nx%d, s0); s1 = fma(%s, nx%d, s1); s2 = fma(%s, nx%d, s2);", Ln(F, G, 0).c_str(), F,
+              Ln(F, G, 1).c_str(), F, Ln(F, G, 2).c_str(), F);
+        f("      s0 = qsum(s0); s1 = qsum(s1); s2 = qsum(s2);");
+        f("      nx%d -= c == 0 ? s0 : (c == 1 ? s1 : (c == 2 ? s2 : 0.0)); }", G);  // lane 3 stays 0
+      }
+      f("    { const double xb2 = QB2(nx%d), l21 = QB2(%s), l20 = QB2(%s);", G, Ln(G, G, 1).c_str(),
+        Ln(G, G, 0).c_str());
+      f("      nx%d = fma(-(c == 1 ? l21 : (c == 0 ? l20 : 0.0)), xb2, nx%d);", G, G);
+      f("      const double xb1 = QB1(nx%d), l10 = QB1(%s);", G, Ln(G, G, 0).c_str());
+      f("      nx%d = fma(-(c == 0 ? l10 : 0.0), xb1, nx%d); }", G, G);
+    }
+  }
+
+  bool fillf[kMaxFree][kMaxFree] = {};
+};
+
+const char* kPreamble = R"SRC(
+// Generated by okx_quadgen.cpp for one constraint program — do not edit.
+typedef struct { double max_residual, cost, last_step; int iterations, nfev, flags, reserved; } okx_info;
+struct QArgs {
+  const double* targets; const double* geom_pos; const double* geom_row_param;
+  double* out_pos; okx_info* info;
+  long long n_problems, steps_per_geometry, chain_len;
+  int max_iter, pad;
+  double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
+  const double* design_pos; const double* row_param; const double* dop_param;
+};
+#define EPS_SQ 1e-12
+#define EPS 1e-6
+#define DEV __device__ __forceinline__
+#define INFO_CONVERGED 1
+#define INFO_RESIDUAL_EXCEEDED 2
+#define INFO_FAILED 4
+
+// DPP quad_perm of a double (2 x v_mov_b32_dpp): lane l of every quad reads lane sel[l].
+template <int CTRL> DEV double qperm(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+#define QB0(v) qperm<0x00>(v)   /* broadcast lane 0 of the quad */
+#define QB1(v) qperm<0x55>(v)
+#define QB2(v) qperm<0xAA>(v)
+#define QR1(v) qperm<0xC9>(v)   /* lane c reads component (c+1)%3; lane 3 reads itself */
+#define QR2(v) qperm<0xD2>(v)   /* lane c reads component (c+2)%3 */
+// Sum / max over the quad, bit-identical in its four lanes (butterfly of commutative ops).
+DEV double qsum(double v) { v += qperm<0xB1>(v); v += qperm<0x4E>(v); return v; }
+DEV double qmax(double v) { v = fmax(v, qperm<0xB1>(v)); v = fmax(v, qperm<0x4E>(v)); return v; }
+
+DEV double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(e, r, r);
+  e = fma(-x, r, 1.0);
+  return fma(e, r, r);
+}
+DEV void fast_sqrt_rsqrt(double x, double* root, double* inv) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  *root = g;
+  *inv = h + h;
+}
+// atan2(y, x), y >= 0, result in [0, pi]: fdlibm-style reduction + odd polynomial (see okx_kernels.hip).
+DEV double lean_atan2_pos(double y, double x) {
+  const double ax = fabs(x);
+  if (!(y > 0.0)) return x >= 0.0 ? 0.0 : 3.14159265358979311600e+00;
+  if (ax == 0.0) return 1.57079632679489655800e+00;
+  double t = y * fast_rcp(ax);
+  double hi, lo;
+  if (t < 0.4375) { hi = 0.0; lo = 0.0; }
+  else if (t < 0.6875) { hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; t = (2.0 * t - 1.0) * fast_rcp(2.0 + t); }
+  else if (t < 1.1875) { hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; t = (t - 1.0) * fast_rcp(t + 1.0); }
+  else if (t < 2.4375) { hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; t = (t - 1.5) * fast_rcp(1.0 + 1.5 * t); }
+  else { hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; t = -fast_rcp(t); }
+  const double z = t * t, w = z * z;
+  const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+                    w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+  const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+                    w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+  const double at = hi - ((t * (s1 + s2) - lo) - t);
+  return x > 0.0 ? at : 3.14159265358979311600e+00 - (at - 1.2246467991473531772e-16);
+}
+DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+)SRC";
+
+}  // namespace
+
+bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why) {
+  if (P.n_free > kQuadMaxFree) {
+    *why = "more than " + std::to_string(kQuadMaxFree) + " free points";
+    return false;
+  }
+  if (P.n_targets > kMaxTargets) {
+    *why = "too many targets";
+    return false;
+  }
+  Gen g(P);
+  const int nf = P.n_free, NP = P.n_points, T = P.n_targets;
+
+  // ---- evaluation body (rows + normal equations), generated first to learn the sparsity ----
+  Gen ev(P);
+  ev.f("    // ---- active derived points with chain-rule blocks ----");
+  for (int idx = 0; idx < P.n_active; ++idx)
+    if (!ev.derived_op(P.active_op[idx], true)) {
+      *why = ev.why;
+      return false;
+    }
+  if (!ev.emit_rows()) {
+    *why = ev.why;
+    return false;
+  }
+  std::string eval_src = ev.out;
+  ev.out.clear();
+  ev.emit_solve();
+  std::string solve_src = ev.out;
+
+  // which points must live in registers
+  std::vector<bool> used(NP, false);
+  for (int k = 0; k < P.n_out; ++k) used[P.out_point[k]] = true;
+  for (int i = 0; i < P.m; ++i)
+    for (int s = 0; s < 4; ++s)
+      if (P.row_pts[i][s] >= 0) used[P.row_pts[i][s]] = true;
+  for (int e = 0; e < P.n_derived; ++e) {
+    used[P.dop_out[e]] = true;
+    for (int s = 0; s < 4; ++s)
+      if (P.dop_pts[e][s] >= 0) used[P.dop_pts[e][s]] = true;
+  }
+  for (int k = 0; k < nf; ++k) used[P.free_point[k]] = true;
+
+  g.out += kPreamble;
+  g.f("");
+  g.f("template <bool PG> DEV void okx_quad_body(const QArgs& a) {");
+  g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+  g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+  g.f("  const long long spg = a.steps_per_geometry;");
+  g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
+  g.f("  const long long unit_len = a.chain_len;");
+  g.f("  const long long chains_per_span = (span + unit_len - 1) / unit_len;");
+  g.f("  const long long n_units = (a.n_problems / span) * chains_per_span;");
+  g.f("  for (long long wu = blockIdx.x; wu * 16 < n_units; wu += gridDim.x) {");
+  g.f("    long long unit = wu * 16 + quad;");
+  g.f("    const bool have = unit < n_units;");
+  g.f("    if (!have) unit = n_units - 1;");
+  g.f("    const long long span_idx = unit / chains_per_span;");
+  g.f("    const long long first_b = span_idx * span + (unit %% chains_per_span) * unit_len;");
+  g.f("    const long long last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
+  g.f("    const long long geom = spg > 0 ? first_b / spg : 0;");
+  g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * NP);
+  g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * P.n_crows);
+  // point registers
+  for (int p = 0; p < NP; ++p)
+    if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
+  for (int F = 0; F < nf; ++F) g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0, g%d = 0.0;", F, P.free_point[F], F, F, F, F);
+  g.f("    int hist = 0;");
+  g.f("    for (long long b = first_b; wave_any(have && b < last_b); ++b) {");
+  g.f("      const bool valid = have && b < last_b;");
+  g.f("      const long long bb = valid ? b : last_b - 1;");
+  g.f("      const long long step = bb - first_b;");
+  for (int t = 0; t < T; ++t) g.f("      const double tv%d = a.targets[bb * %d + %d];", t, T, t);
+  // secant predictor: x + alpha (x - xp), alpha from the target increments
+  g.f("      if (hist >= 2) {");
+  g.f("        double num = 0.0, den = 0.0;");
+  for (int t = 0; t < T; ++t) {
+    g.f("        { const double t1 = a.targets[(bb - 1) * %d + %d], t2 = a.targets[(bb - 2) * %d + %d];", T, t, T, t);
+    g.f("          num = fma(tv%d - t1, t1 - t2, num); den = fma(t1 - t2, t1 - t2, den); }", t);
+  }
+  g.f("        double alpha = den > 0.0 ? num / den : 0.0;");
+  g.f("        alpha = fmin(fmax(alpha, 0.0), 2.0);");
+  for (int F = 0; F < nf; ++F)
+    g.f("        { const double xn = fma(alpha, x%d - xp%d, x%d); xp%d = x%d; x%d = xn; }", F, F, F, F, F, F);
+  g.f("      } else {");
+  for (int F = 0; F < nf; ++F) g.f("        xp%d = x%d;", F, F);
+  g.f("      }");
+  g.f("      double Fc = 0.0, lambda = 0.0, nu = 2.0, dmax = 0.0, step_len = 0.0, last_step = 0.0, mres = 0.0;");
+  g.f("      int nfev = 0, iters = 0, flags = 0, nfail = 0;");
+  g.f("      int mode = 0;  // 0 first evaluation, 1 trial point, 2 re-evaluation of the accepted point");
+  g.f("      bool done = !valid;");
+  for (int F = 0; F < nf; ++F) g.f("      dx%d = 0.0;", F);
+  g.f("      while (wave_any(!done)) {");
+  // evaluation point
+  for (int F = 0; F < nf; ++F) g.f("    p%d = mode == 2 ? x%d : x%d + dx%d;", P.free_point[F], F, F, F);
+  g.out += eval_src;
+  g.f("    const double Ft = 0.5 * ss;");
+  // LM decision (mirrors okx_solve_kernel)
+  g.f("    bool accept = true, stop = false;");
+  g.f("    double rho = 1.0;");
+  g.f("    if (mode == 1) {");
+  g.f("      double pr = 0.0;");
+  for (int F = 0; F < nf; ++F) g.f("      pr = fma(dx%d, fma(lambda, dx%d, -g%d), pr);", F, F, F);
+  g.f("      const double pred = 0.5 * qsum(pr);");
+  g.f("      const bool finite = Ft == Ft && step_len == step_len && Ft < 1e300;");
+  g.f("      const bool small = finite && step_len <= 1e-8 && Ft <= Fc * (1.0 + 1e-6) + 1e-28;");
+  g.f("      rho = (finite && pred > 0.0) ? (Fc - Ft) / pred : -1.0;");
+  g.f("      accept = rho > 1e-4 || small;");
+  g.f("      if (finite && step_len <= a.step_tol) { accept = small; stop = true; }");
+  g.f("      else if (accept && finite && Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) stop = true;");
+  g.f("    }");
+  g.f("    double diag = 0.0;");
+  for (int F = 0; F < nf; ++F)
+    g.f("    diag = fmax(diag, c == 0 ? %s : (c == 1 ? %s : (c == 2 ? %s : 0.0)));", Gen::A(F, F, 0).c_str(),
+        Gen::A(F, F, 1).c_str(), Gen::A(F, F, 2).c_str());
+  g.f("    diag = qmax(diag);");
+  g.f("    double gm = 0.0;");
+  for (int F = 0; F < nf; ++F) g.f("    gm = fmax(gm, fabs(gn%d));", F);
+  g.f("    gm = qmax(gm);");
+  g.f("    if (!done) {");
+  g.f("      ++nfev;");
+  g.f("      if (stop) flags |= INFO_CONVERGED;");
+  g.f("      if (accept) {");
+  g.f("        if (mode != 2) {");
+  for (int F = 0; F < nf; ++F) g.f("          x%d = p%d;", F, P.free_point[F]);
+  g.f("          if (mode == 1) last_step = step_len;");
+  g.f("          nu = 2.0;");
+  g.f("        }");
+  g.f("        Fc = Ft; mres = mres_new;");
+  for (int F = 0; F < nf; ++F) g.f("        g%d = gn%d;", F, F);
+  g.f("        if (!stop) {");
+  g.f("          if (mode == 0) { dmax = diag; lambda = a.lambda0 * dmax; }");
+  g.f("          else if (mode == 1 && rho > 1e-4) { const double t = 2.0 * rho - 1.0; lambda *= fmax(1.0 / 3.0, 1.0 - t * t * t); }");
+  g.f("          if (a.grad_tol > 0.0 && gm <= a.grad_tol) { flags |= INFO_CONVERGED; stop = true; }");
+  g.f("        }");
+  g.f("      } else if (!stop) {");
+  g.f("        lambda *= nu; nu *= 2.0;");
+  g.f("      }");
+  g.f("      if (stop || iters >= a.max_iter) done = true;");
+  g.f("    }");
+  g.f("    const bool solve_now = !done && accept;");
+  g.f("    if (!done && !accept) mode = 2;");
+  g.f("    if (!wave_any(solve_now)) continue;");
+  // declare factor / fill-in registers
+  for (int F = 0; F < nf; ++F)
+    for (int G = 0; G <= F; ++G)
+      if (ev.fillf[F][G]) {
+        for (int k = 0; k < 3; ++k) {
+          if (!(F == G && k == 2)) g.f("    double %s;", Gen::Ln(F, G, k).c_str());
+          if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
+        }
+      }
+  // the diagonal-block factor entry for k == 2 is never needed (no row below inside the block)
+  g.out += solve_src;
+  g.f("    double sl = 0.0;");
+  for (int F = 0; F < nf; ++F) g.f("    sl = fmax(sl, fabs(nx%d));", F);
+  g.f("    sl = qmax(sl);");
+  g.f("    if (solve_now) {");
+  g.f("      ++iters;");
+  g.f("      if (ok) {");
+  for (int F = 0; F < nf; ++F) g.f("        dx%d = nx%d;", F, F);
+  g.f("        step_len = sl;");
+  g.f("        if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
+  g.f("        mode = 1;");
+  g.f("      } else {");
+  g.f("        lambda = fmax(lambda * 10.0, 1e-12 * dmax);");
+  g.f("        if (++nfail > 60 || !(lambda < 1e30)) { flags |= INFO_FAILED; done = true; }");
+  g.f("        mode = 2;");
+  g.f("      }");
+  g.f("    }");
+  g.f("      }  // LM passes");
+  // final state and output
+  g.f("      {");
+  for (int F = 0; F < nf; ++F) g.f("    p%d = x%d;", P.free_point[F], F);
+  Gen fin(P);
+  fin.uid = 100000;
+  for (int e = 0; e < P.n_derived; ++e)
+    if (!fin.derived_op(e, false)) {
+      *why = fin.why;
+      return false;
+    }
+  g.out += fin.out;
+  g.f("    if (mres > a.residual_tolerance) flags |= INFO_RESIDUAL_EXCEEDED;");
+  g.f("    if (valid && c < 3) {");
+  g.f("      double* o = a.out_pos + bb * %d + c;", 3 * P.n_out);
+  for (int k = 0; k < P.n_out; ++k) g.f("      o[%d] = p%d;", 3 * k, P.out_point[k]);
+  g.f("    }");
+  g.f("    if (valid && c == 0) {");
+  g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
+  g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
+  g.f("      a.info[bb] = inf;");
+  g.f("    }");
+  // chains never continue from a state that failed to converge
+  g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
+  for (int F = 0; F < nf; ++F) g.f("      x%d = c < 3 ? gp[%d + cc] : 0.0;", F, 3 * P.free_point[F]);
+  g.f("      hist = 0;");
+  g.f("    } else if (hist < 2) ++hist;");
+  g.f("      }");
+  g.f("    }  // chain steps");
+  g.f("  }  // wave units");
+  g.f("}");
+  g.f("");
+  // ---- parity / debug kernel: r, J^T J, J^T r at given x, and the damped step for a given lambda ----
+  g.f("struct QEvalArgs { const double* x; const double* targets; double* r; double* ata; double* atr; double* dx;");
+  g.f("  double lambda; long long n_problems; const double* design_pos; const double* row_param; const double* dop_param; };");
+  g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_eval(QEvalArgs a) {", waves_per_simd);
+  g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+  g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+  g.f("  const double* gp = a.design_pos; const double* gq = a.row_param;");
+  g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_problems; wu += gridDim.x) {");
+  g.f("    long long bb = wu * 16 + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");
+  for (int p = 0; p < NP; ++p)
+    if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
+  for (int F = 0; F < nf; ++F) g.f("    p%d = c < 3 ? a.x[bb * %d + %d + cc] : 0.0;", P.free_point[F], 3 * nf, 3 * F);
+  for (int t = 0; t < T; ++t) g.f("    const double tv%d = a.targets[bb * %d + %d];", t, T, t);
+  g.out += eval_src;
+  g.f("    if (valid && c == 0) {");
+  for (int i = 0; i < P.m; ++i) g.f("      a.r[bb * %d + %d] = r%d;", P.m, i, i);
+  g.f("    }");
+  g.f("    if (valid && c < 3) {");
+  for (int F = 0; F < nf; ++F) {
+    g.f("      a.atr[bb * %d + %d + c] = gn%d;", 3 * nf, 3 * F, F);
+    for (int G = 0; G <= F; ++G)
+      if (ev.nz[F][G])
+        for (int k = 0; k < 3; ++k)
+          g.f("      a.ata[(bb * %d + %d + c) * %d + %d] = %s;", 3 * nf, 3 * F, 3 * nf, 3 * G + k, Gen::A(F, G, k).c_str());
+  }
+  g.f("    }");
+  g.f("    const double lambda = a.lambda;");
+  for (int F = 0; F < nf; ++F) g.f("    const double g%d = gn%d;", F, F);
+  for (int F = 0; F < nf; ++F)
+    for (int G = 0; G <= F; ++G)
+      if (ev.fillf[F][G]) {
+        for (int k = 0; k < 3; ++k) {
+          if (!(F == G && k == 2)) g.f("    double %s;", Gen::Ln(F, G, k).c_str());
+          if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
+        }
+      }
+  g.out += solve_src;
+  g.f("    if (valid && c < 3) {");
+  for (int F = 0; F < nf; ++F) g.f("      a.dx[bb * %d + %d + c] = ok ? nx%d : __builtin_nan(\"\");", 3 * nf, 3 * F, F);
+  g.f("    }");
+  g.f("  }");
+  g.f("}");
+  g.f("");
+  g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_solve_u(QArgs a) { okx_quad_body<false>(a); }",
+      waves_per_simd);
+  g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_solve_g(QArgs a) { okx_quad_body<true>(a); }",
+      waves_per_simd);
+  *src = g.out;
+  return true;
+}
+
+}  // namespace okx
