@@ -41,6 +41,8 @@ struct okx_program {
 namespace {
 
 thread_local char g_err[512] = "";
+double* g_quad_trace = nullptr;          // diagnostic hook, see okx_debug_quad_trace
+long long g_quad_trace_problem = -1;
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -439,6 +441,8 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
     q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
     q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
+    q.trace = g_quad_trace;
+    q.trace_problem = g_quad_trace_problem;
     const long long wave_units = (units + 15) / 16;
     const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
     const int grid = (int)(wave_units < cap ? (wave_units < 1 ? 1 : wave_units) : cap);
@@ -517,6 +521,14 @@ int32_t okx_rebind_design(okx_program* p, int64_t n_geometries, const double* d_
                      p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
   HIP_TRY(hipGetLastError());
   return OKX_OK;
+}
+
+/* Diagnostic: record the LM passes of ONE problem of subsequent quad-kernel solves into
+   d_trace [256][8] = (mode, trial cost, accepted cost, lambda, step, gain ratio, accepted, done);
+   pass a null pointer to switch it off. */
+void okx_debug_quad_trace(double* d_trace, int64_t problem) {
+  g_quad_trace = d_trace;
+  g_quad_trace_problem = problem;
 }
 
 /* Test hook: what the quad kernel's straight-line code computes at given free vectors d_x [B][n]:

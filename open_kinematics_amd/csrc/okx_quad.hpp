@@ -23,6 +23,8 @@ struct QuadArgs {
   const double* design_pos;
   const double* row_param;
   const double* dop_param;
+  double* trace;            // diagnostic: [256][8] per-pass record of one problem, or null
+  long long trace_problem;
 };
 
 // Arguments of the generated parity kernel `okx_quad_eval` (mirrors `struct QEvalArgs`).

@@ -686,6 +686,7 @@ struct QArgs {
   int max_iter, pad;
   double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
   const double* design_pos; const double* row_param; const double* dop_param;
+  double* trace; long long trace_problem;   // diagnostic: 8 doubles per LM pass of one problem (null: off)
 };
 #define EPS_SQ 1e-12
 #define EPS 1e-6
@@ -705,8 +706,16 @@ template <int CTRL> DEV double qperm(double v) {
 #define QB2(v) qperm<0xAA>(v)
 #define QR1(v) qperm<0xC9>(v)   /* lane c reads component (c+1)%3; lane 3 reads itself */
 #define QR2(v) qperm<0xD2>(v)   /* lane c reads component (c+2)%3 */
-// Sum / max over the quad, bit-identical in its four lanes (butterfly of commutative ops).
-DEV double qsum(double v) { v += qperm<0xB1>(v); v += qperm<0x4E>(v); return v; }
+// Sum / max over the quad, BIT-IDENTICAL in its four lanes: a butterfly of commutative adds.
+// Contraction must stay off here: fusing the caller's product into the first add
+// (fma(a, b, neighbour)) would round differently in the two lanes of a pair, and every
+// per-problem decision (accept / reject / stop) relies on the four lanes agreeing exactly.
+DEV double qsum(double v) {
+#pragma clang fp contract(off)
+  double w = v + qperm<0xB1>(v);
+  w = w + qperm<0x4E>(w);
+  return w;
+}
 DEV double qmax(double v) { v = fmax(v, qperm<0xB1>(v)); v = fmax(v, qperm<0x4E>(v)); return v; }
 
 DEV double fast_rcp(double x) {
@@ -894,9 +903,13 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("      }");
   g.f("      if (stop || iters >= a.max_iter) done = true;");
   g.f("    }");
+  g.f("    if (a.trace && valid && bb == a.trace_problem && c == 0 && nfev < 256) {");
+  g.f("      double* tr = a.trace + 8 * nfev;");
+  g.f("      tr[0] = mode; tr[1] = Ft; tr[2] = Fc; tr[3] = lambda; tr[4] = step_len; tr[5] = rho; tr[6] = accept ? 1.0 : 0.0; tr[7] = done ? 1.0 : 0.0;");
+  g.f("    }");
   g.f("    const bool solve_now = !done && accept;");
   g.f("    if (!done && !accept) mode = 2;");
-  g.f("    if (!wave_any(solve_now)) continue;");
+  g.f("    if (wave_any(solve_now)) {");
   // declare factor / fill-in registers
   for (int F = 0; F < nf; ++F)
     for (int G = 0; G <= F; ++G)
@@ -924,6 +937,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("        mode = 2;");
   g.f("      }");
   g.f("    }");
+  g.f("    }  // any quad solves");
   g.f("      }  // LM passes");
   // final state and output
   g.f("      {");

@@ -11,7 +11,8 @@ from open_kinematics_amd.batch import DeviceProgram
 from open_kinematics_amd.workloads import bump_sweep_problem, macpherson_grid_problem
 
 which = sys.argv[1] if len(sys.argv) > 1 else "dw"
-program, targets = bump_sweep_problem(40) if which == "dw" else macpherson_grid_problem(6, 6)
+mode = sys.argv[2] if len(sys.argv) > 2 else "pinned"
+program, targets = bump_sweep_problem(40, line_mode=mode) if which == "dw" else macpherson_grid_problem(6, 6, line_mode=mode)
 dp = DeviceProgram(program, "cuda:0")
 print("kernel", dp.kernel, dp.kernel_note)
 rng = np.random.default_rng(0)
