@@ -4,10 +4,11 @@ Headline benchmark: constraint solves/sec on the double-wishbone bump sweep (BAS
 
 One "step" = one pass of the hot path over one batch: every rank solves a 16384-step fp64
 bump sweep (BASELINE config 2; inputs already resident in HBM) with ONE launch of the solve
-kernel; with N > 1 ranks the global sweep (N x 16384 steps) is sharded by index and the solved
-positions are all-gathered over RCCL inside the timed step.  Prints one JSON line on rank 0.
+kernel (the runtime-specialised quad kernel `okx_quad_solve_u`); with N > 1 ranks
+the global sweep (N x 16384 steps) is sharded by index and the solved positions are all-gathered
+over RCCL inside the timed step.  Prints one JSON line on rank 0.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 200 --warmup 10
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
          --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 """
@@ -29,7 +30,7 @@ import torch
 import torch.distributed as dist
 
 STEPS_PER_RANK = 16384
-CHAIN_LEN = -1                # one warm-started chunk of consecutive sweep steps per resident wavefront
+CHAIN_LEN = -1                # auto: one chain per resident problem slot (16384 steps fit the chip: all cold starts)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor fp64 vector peak, secondary ceiling
 
@@ -48,14 +49,18 @@ def estimated_flops_per_evaluation(program, stats) -> float:
     return rows + normal + chol
 
 
+PROFILE_DIR = os.path.join("profiles", "r01")
+TRAFFIC_SUMMARY = os.path.join(PROFILE_DIR, "bench_c2_quad_pmc_traffic.json")
+
+
 def measured_traffic() -> tuple:
     """
     HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs of this same command, see
-    profiles/r01/bench_c2_pmc_traffic_final.json for command, units and corrections).  bench.py
+    profiles/r01/bench_c2_quad_pmc_traffic.json for command, units and corrections).  bench.py
     cannot run the profiler on itself, so the figure is read back from that summary.
     """
-    path = os.path.join(REPO, "profiles", "r01", "bench_c2_pmc_traffic_final.json")
+    path = os.path.join(REPO, TRAFFIC_SUMMARY)
     try:
         with open(path, "r", encoding="utf-8") as fh:
             summary = json.load(fh)
@@ -91,8 +96,8 @@ def cpu_baseline(n_steps: int) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-len", type=int, default=None, help="override: 1 = independent cold starts")
     args = ap.parse_args()
@@ -128,8 +133,11 @@ def main() -> None:
     out = torch.empty((hi - lo, program.n_out, 3), dtype=torch.float64, device=device)
     info = torch.empty((hi - lo, 40), dtype=torch.uint8, device=device)
 
+    # pre-bound launch: per step the host only makes the C-ABI call (the kernel is ~40 us long)
+    launch = dp.plan(targets, out=out, info_out=info, chain_len=CHAIN_LEN)
+
     def step():
-        res = dp.solve(targets, out=out, info_out=info, chain_len=CHAIN_LEN)
+        res = launch()
         if world > 1:
             return all_gather_rows(res.positions, n_total)
         return res.positions
@@ -141,14 +149,25 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize(device)
 
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # Kernel duration from HIP events on the launch stream (torch's current stream IS the stream
+    # the C-ABI call launches on).  One rank: a single event pair brackets the K back-to-back
+    # launches of the timed region (average = elapsed / K; per-launch pairs would add two stream
+    # markers per 40 us kernel to the region being timed).  Several ranks: per-launch pairs, so the
+    # all-gather between launches is excluded.
+    n_pairs = args.steps if world > 1 else 1
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        starts[k].record()
-        res = dp.solve(targets, out=out, info_out=info, chain_len=CHAIN_LEN)
-        ends[k].record()  # brackets exactly the solve-kernel launch on the launch stream
-        if world > 1:
+    if world == 1:
+        starts[0].record()
+        for k in range(args.steps):
+            launch()
+        ends[0].record()
+    else:
+        for k in range(args.steps):
+            starts[k].record()
+            res = launch()
+            ends[k].record()
             all_gather_rows(res.positions, n_total)
     torch.cuda.synchronize(device)
     if world > 1:
@@ -160,7 +179,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    # average launch duration over the timed region (one rank: includes the ~1 us launch-to-launch
+    # gaps of the back-to-back launches; agrees with the rocprofv3 kernel trace to < 1 %)
+    kernel_ms = float(np.sum([s.elapsed_time(e) for s, e in zip(starts, ends)])) / args.steps
     host_info = info.cpu().numpy().view(np.dtype([("max_residual", "<f8"), ("cost", "<f8"), ("last_step", "<f8"),
                                                   ("iterations", "<i4"), ("nfev", "<i4"), ("flags", "<i4"),
                                                   ("reserved", "<i4")])).reshape(-1)
@@ -173,7 +194,7 @@ def main() -> None:
         _lib.load().okx_plan_stats(HostProgram(program).byref(), stats_raw)
         stats = dict(zip(["n", "m", "pairs", "contrib", "active", "js_stride", "lda", "lds_bytes"], list(stats_raw)))
         bytes_per_solve = algorithmic_bytes_per_solve(program)
-        traffic, traffic_src = measured_traffic() if world == 1 and CHAIN_LEN == -1 else (None, None)
+        traffic, traffic_src = measured_traffic() if world == 1 and CHAIN_LEN == -1 and dp.kernel == "quad" else (None, None)
         achieved_gbs = bytes_per_solve * (hi - lo) / (kernel_ms * 1e-3) / 1e9
         nfev_mean = float(host_info["nfev"].mean())
         flops = estimated_flops_per_evaluation(program, stats) * nfev_mean * (hi - lo)
@@ -197,7 +218,12 @@ def main() -> None:
                 "n_vars": program.n_vars,
                 "n_residual_rows": program.n_residuals,
                 "line_mode": program.line_mode,
-                "start": "sweep split into contiguous chunks, one per resident wavefront; chunk head cold "
+                "kernel": dp.kernel,
+                "start": "chain_len=-1 (auto): one chain per resident problem slot; 16384 steps fit the "
+                         "chip's slots, so every step is an independent cold start from the design state "
+                         "(SURVEY.md §8d); longer sweeps become warm-started chains (solver.py:774)"
+                         if dp.kernel == "quad" else
+                         "sweep split into contiguous chunks, one per resident wavefront; chunk head cold "
                          "(design state), later steps warm-started from their predecessor "
                          "(reference semantics, solver.py:774)",
                 "lm_evaluations_mean": nfev_mean,
@@ -212,7 +238,7 @@ def main() -> None:
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "okx_solve_kernel",
+                "kernel": "okx_quad_solve_u" if dp.kernel == "quad" else "okx_solve_kernel",
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_solve": bytes_per_solve,
                 "note": "path is latency/fp64-issue bound, not HBM bound (SURVEY.md §7 H4): see compute",

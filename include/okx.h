@@ -144,9 +144,11 @@ typedef struct okx_solve_opts {
   double lambda0;         /* initial damping relative to max diag(J^T J) (default 1e-6)    */
   double residual_tolerance; /* informational: info.flags bit1 set if max|r| exceeds it
                                 (solver.py:735-747, default 1e-3)                          */
-  int32_t kernel;         /* 0 auto, 1 one problem per wavefront, 2 lane-group packed (several
-                             small problems per wavefront; falls back to 1 when a problem
-                             needs more than 32 lanes)                                     */
+  int32_t kernel;         /* 0 auto (the runtime-specialised quad kernel when the program has one,
+                             else 1 or 2 by size), 1 generic interpreter, one problem per
+                             wavefront, 2 generic lane-group packed (several small problems per
+                             wavefront; falls back to 1 when a problem needs more than 32
+                             lanes), 3 quad kernel (OKX_ERR_INVALID when the program has none) */
   int32_t reserved;
 } okx_solve_opts;
 
@@ -226,6 +228,32 @@ int32_t okx_rebind_design(okx_program* prog, int64_t n_geometries,
                           double* d_geom_pos,             /* [G][P][3] */
                           double* d_geom_row_param,       /* [G][Mc][8] */
                           void* stream);
+
+/*
+ * Runtime specialisation.  okx_program_create also GENERATES a HIP kernel for the program at
+ * hand (straight-line residual / Jacobian / normal-equation / LDL^T code, four lanes per
+ * problem), compiles it with hiprtc and loads it; the reference does the analogous thing
+ * offline for its Jacobian rows (tools/generate_jacobians.py -> core/jacobians.py) and
+ * interprets the rest per call (solver.py:226-275, :502-581).  Code objects are cached under
+ * <directory of libokx.so>/_kcache (override: OKX_KERNEL_CACHE), keyed by the generated source.
+ * Programs the generator has no code path for (more than 8 free points, unsupported row or
+ * derived-point types) keep the generic interpreter kernels; nothing else changes for them.
+ */
+
+/* "quad" when the specialised kernel of this program is loaded, "wave" when the generic
+ * interpreter kernels are in charge; okx_program_kernel_note() then says why (static strings
+ * owned by the program). */
+const char* okx_program_kernel(const okx_program* prog);
+const char* okx_program_kernel_note(const okx_program* prog);
+
+/* Generated source of a program's quad kernel (no device needed).  Copies at most buflen - 1
+ * bytes plus a terminator into buf (buf may be NULL) and returns the size the full text
+ * needs, or a negative okx_status (OKX_ERR_LIMIT: no quad kernel for this program). */
+int64_t okx_quad_source(const okx_program_desc* desc, char* buf, int64_t buflen);
+
+/* Generate + compile a program's quad kernel into the on-disk cache (no device needed), so
+ * that a later okx_program_create only loads it. */
+int32_t okx_precompile(const okx_program_desc* desc);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,10 @@ EXPORTS = (
     "okx_solve_batch",
     "okx_eval_batch",
     "okx_rebind_design",
+    "okx_program_kernel",
+    "okx_program_kernel_note",
+    "okx_quad_source",
+    "okx_precompile",
 )
 
 _lib = None

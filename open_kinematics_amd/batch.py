@@ -94,7 +94,7 @@ class DeviceProgram:
         self.lib.okx_default_opts(C.byref(opts))
         return opts
 
-    def solve(
+    def _prepare(
         self,
         targets,
         *,
@@ -152,13 +152,39 @@ class DeviceProgram:
         if info_out is None:
             info_out = torch.empty((b, INFO_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        args = (self._handle, C.byref(opts), b, _ptr(targets), _ptr(geom_pos), _ptr(geom_row_param),
+                _ptr(out), _ptr(info_out), C.c_void_p(stream))
+        keep = (opts, targets, geom_pos, geom_row_param)  # tensors / structs the raw pointers refer to
+        return args, keep, BatchResult(out, info_out)
+
+    def solve(self, targets, **kw) -> BatchResult:
+        """See ``_prepare`` for the arguments: validates, then launches ``okx_solve_batch`` once."""
+        args, _keep, result = self._prepare(targets, **kw)
         with torch.cuda.device(self.device):
-            rc = self.lib.okx_solve_batch(
-                self._handle, C.byref(opts), b, _ptr(targets), _ptr(geom_pos), _ptr(geom_row_param),
-                _ptr(out), _ptr(info_out), C.c_void_p(stream),
-            )
+            rc = self.lib.okx_solve_batch(*args)
         _lib.check(rc, "okx_solve_batch")
-        return BatchResult(out, info_out)
+        return result
+
+    def plan(self, targets, **kw):
+        """
+        Pre-bound launch for a hot loop: validates and converts the arguments once (same keywords
+        as ``solve``) and returns a zero-argument callable whose only work is the
+        ``okx_solve_batch`` call on the stream that was current when the plan was made — a few
+        microseconds of host time per launch, so back-to-back launches of a ~40 us kernel stay
+        GPU-bound.  Pass ``out=`` / ``info_out=`` to fix the output buffers.
+        """
+        args, keep, result = self._prepare(targets, **kw)
+        fn, check = self.lib.okx_solve_batch, _lib.check
+
+        def launch() -> BatchResult:
+            # the launch goes to the plan's stream, which carries its device: no device switch here
+            rc = fn(*args)
+            if rc != 0:
+                check(rc, "okx_solve_batch")
+            return result
+
+        launch.keep = keep
+        return launch
 
     def eval(self, x, targets, jac: bool = True):
         """Residuals ``[B, m]`` and dense Jacobians ``[B, m, n]`` at free vectors ``x [B, n]``."""

@@ -587,8 +587,11 @@ class Gen {
             }
           }
         }
+      f("    SCHED_FENCE;");
     }
     // diagonal blocks that no row touched still exist (as zeros)
+    // (SCHED_FENCE after every row keeps the scheduler from hoisting later rows' loads and
+    // broadcasts over this row's accumulation: live ranges stay one row long)
     for (int F = 0; F < nf; ++F)
       for (int k = 0; k < 3; ++k)
         if (!declared.count(A(F, F, k))) f("    double %s = 0.0;", A(F, F, k).c_str());
@@ -609,8 +612,8 @@ class Gen {
     for (int G = 0; G < nf; ++G)
       for (int k = 0; k < 3; ++k) {
         f("    { // column %d", 3 * G + k);
-        f("    double piv = QB%d(%s);", k, A(G, G, k).c_str());
-        f("    ok = ok && piv > 0.0; piv = ok ? piv : 1.0;");
+        f("    const double piv = QB%d(%s);", k, A(G, G, k).c_str());
+        f("    ok = ok && piv > 0.0;  // a failed factor is never used: no need to sanitise the pivot");
         f("    const double rinv = fast_rcp(piv);");
         f("    dinv%d = c == %d ? rinv : dinv%d;", G, k, G);
         // factor entries of this column (rows below the pivot)
@@ -634,13 +637,13 @@ class Gen {
             f("    }");
           }
         }
-        f("    }");
+        f("    SCHED_FENCE; }");
       }
     for (int F = 0; F < nf; ++F)
       for (int G = 0; G < nf; ++G) fillf[F][G] = fill[F][G];
     // forward substitution, block by block (unit lower factor)
     f("    // ---- L y = -g ----");
-    for (int F = 0; F < nf; ++F) f("    double y%d = -g%d;", F, F);
+    for (int F = 0; F < nf; ++F) f("    double y%d = -gn%d;", F, F);
     for (int G = 0; G < nf; ++G) {
       f("    { const double yb0 = QB0(y%d); y%d = fma(-%s, yb0, y%d);", G, G, Ln(G, G, 0).c_str(), G);
       f("      const double yb1 = QB1(y%d); y%d = fma(-%s, yb1, y%d);", G, G, Ln(G, G, 1).c_str(), G);
@@ -688,6 +691,9 @@ struct QArgs {
   const double* design_pos; const double* row_param; const double* dop_param;
   double* trace; long long trace_problem;   // diagnostic: 8 doubles per LM pass of one problem (null: off)
 };
+#ifndef SCHED_FENCE
+#define SCHED_FENCE __builtin_amdgcn_sched_barrier(0)
+#endif
 #define EPS_SQ 1e-12
 #define EPS 1e-6
 #define DEV __device__ __forceinline__
@@ -696,9 +702,11 @@ struct QArgs {
 #define INFO_FAILED 4
 
 // DPP quad_perm of a double (2 x v_mov_b32_dpp): lane l of every quad reads lane sel[l].
+// (mov_dpp, not update_dpp: every lane of a quad_perm has a valid source, so there is no "old"
+// value to preserve and no v_mov to initialise it.)
 template <int CTRL> DEV double qperm(double v) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 #define QB0(v) qperm<0x00>(v)   /* broadcast lane 0 of the quad */
@@ -829,7 +837,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   // point registers
   for (int p = 0; p < NP; ++p)
     if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
-  for (int F = 0; F < nf; ++F) g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0, g%d = 0.0;", F, P.free_point[F], F, F, F, F);
+  for (int F = 0; F < nf; ++F) g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0;", F, P.free_point[F], F, F, F);
   g.f("    int hist = 0;");
   g.f("    for (long long b = first_b; wave_any(have && b < last_b); ++b) {");
   g.f("      const bool valid = have && b < last_b;");
@@ -850,7 +858,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("      } else {");
   for (int F = 0; F < nf; ++F) g.f("        xp%d = x%d;", F, F);
   g.f("      }");
-  g.f("      double Fc = 0.0, lambda = 0.0, nu = 2.0, dmax = 0.0, step_len = 0.0, last_step = 0.0, mres = 0.0;");
+  g.f("      double Fc = 0.0, lambda = 0.0, nu = 2.0, dmax = 0.0, step_len = 0.0, last_step = 0.0, mres = 0.0, pred = 0.0;");
   g.f("      int nfev = 0, iters = 0, flags = 0, nfail = 0;");
   g.f("      int mode = 0;  // 0 first evaluation, 1 trial point, 2 re-evaluation of the accepted point");
   g.f("      bool done = !valid;");
@@ -864,9 +872,6 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("    bool accept = true, stop = false;");
   g.f("    double rho = 1.0;");
   g.f("    if (mode == 1) {");
-  g.f("      double pr = 0.0;");
-  for (int F = 0; F < nf; ++F) g.f("      pr = fma(dx%d, fma(lambda, dx%d, -g%d), pr);", F, F, F);
-  g.f("      const double pred = 0.5 * qsum(pr);");
   g.f("      const bool finite = Ft == Ft && step_len == step_len && Ft < 1e300;");
   g.f("      const bool small = finite && step_len <= 1e-8 && Ft <= Fc * (1.0 + 1e-6) + 1e-28;");
   g.f("      rho = (finite && pred > 0.0) ? (Fc - Ft) / pred : -1.0;");
@@ -874,14 +879,17 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("      if (finite && step_len <= a.step_tol) { accept = small; stop = true; }");
   g.f("      else if (accept && finite && Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) stop = true;");
   g.f("    }");
-  g.f("    double diag = 0.0;");
+  g.f("    double diag = 0.0, gm = 0.0;");
+  g.f("    if (wave_any(mode == 0)) {  // largest diagonal entry scales the first damping");
   for (int F = 0; F < nf; ++F)
-    g.f("    diag = fmax(diag, c == 0 ? %s : (c == 1 ? %s : (c == 2 ? %s : 0.0)));", Gen::A(F, F, 0).c_str(),
+    g.f("      diag = fmax(diag, c == 0 ? %s : (c == 1 ? %s : (c == 2 ? %s : 0.0)));", Gen::A(F, F, 0).c_str(),
         Gen::A(F, F, 1).c_str(), Gen::A(F, F, 2).c_str());
-  g.f("    diag = qmax(diag);");
-  g.f("    double gm = 0.0;");
-  for (int F = 0; F < nf; ++F) g.f("    gm = fmax(gm, fabs(gn%d));", F);
-  g.f("    gm = qmax(gm);");
+  g.f("      diag = qmax(diag);");
+  g.f("    }");
+  g.f("    if (a.grad_tol > 0.0) {");
+  for (int F = 0; F < nf; ++F) g.f("      gm = fmax(gm, fabs(gn%d));", F);
+  g.f("      gm = qmax(gm);");
+  g.f("    }");
   g.f("    if (!done) {");
   g.f("      ++nfev;");
   g.f("      if (stop) flags |= INFO_CONVERGED;");
@@ -892,7 +900,6 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("          nu = 2.0;");
   g.f("        }");
   g.f("        Fc = Ft; mres = mres_new;");
-  for (int F = 0; F < nf; ++F) g.f("        g%d = gn%d;", F, F);
   g.f("        if (!stop) {");
   g.f("          if (mode == 0) { dmax = diag; lambda = a.lambda0 * dmax; }");
   g.f("          else if (mode == 1 && rho > 1e-4) { const double t = 2.0 * rho - 1.0; lambda *= fmax(1.0 / 3.0, 1.0 - t * t * t); }");
@@ -921,14 +928,16 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
       }
   // the diagonal-block factor entry for k == 2 is never needed (no row below inside the block)
   g.out += solve_src;
-  g.f("    double sl = 0.0;");
+  g.f("    double sl = 0.0, pr = 0.0;");
   for (int F = 0; F < nf; ++F) g.f("    sl = fmax(sl, fabs(nx%d));", F);
   g.f("    sl = qmax(sl);");
+  for (int F = 0; F < nf; ++F) g.f("    pr = fma(nx%d, fma(lambda, nx%d, -gn%d), pr);", F, F, F);
+  g.f("    pr = 0.5 * qsum(pr);  // predicted cost reduction of this step (gain-ratio denominator)");
   g.f("    if (solve_now) {");
   g.f("      ++iters;");
   g.f("      if (ok) {");
   for (int F = 0; F < nf; ++F) g.f("        dx%d = nx%d;", F, F);
-  g.f("        step_len = sl;");
+  g.f("        step_len = sl; pred = pr;");
   g.f("        if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
   g.f("        mode = 1;");
   g.f("      } else {");
@@ -997,7 +1006,6 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   }
   g.f("    }");
   g.f("    const double lambda = a.lambda;");
-  for (int F = 0; F < nf; ++F) g.f("    const double g%d = gn%d;", F, F);
   for (int F = 0; F < nf; ++F)
     for (int G = 0; G <= F; ++G)
       if (ev.fillf[F][G]) {

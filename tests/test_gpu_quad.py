@@ -1,0 +1,151 @@
+"""
+GPU parity of the runtime-specialised quad kernel (4 lanes per problem, generated per program):
+its residuals / J^T J / J^T r / LDL^T step against the oracle, and its solves against the oracle,
+the generic wavefront kernel and the reference goldens.  Everything goes through the C-ABI.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import gpu_available
+
+pytestmark = pytest.mark.gpu
+
+QUAD_PROGRAMS = ["c1_dw_corner", "c4_macpherson_grid", "u_dw_corner", "u_macpherson"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not gpu_available():
+        pytest.skip("no GPU")
+
+
+def _dp(program):
+    from open_kinematics_amd.batch import DeviceProgram
+
+    dp = DeviceProgram(program, "cuda:0")
+    assert dp.kernel == "quad", f"quad kernel not loaded: {dp.kernel_note}"
+    return dp
+
+
+@pytest.mark.parametrize("name", QUAD_PROGRAMS)
+@pytest.mark.parametrize("mode", ["pinned", "softnorm"])
+def test_quad_normal_equations_and_step_match_the_oracle(golden, name, mode):
+    """R1/R1b for the generated code: r, J^T J, J^T r and the damped LDL^T step at seeded points."""
+    from oracle.oracle import Oracle
+
+    arrays, program = golden(name)
+    program = program.with_line_mode(mode)
+    dp = _dp(program)
+    x, t = arrays["eval_x"], arrays["eval_targets"]
+    lam = 1e-4
+    r, ata, atr, dx = [v.cpu().numpy() for v in dp.quad_eval(x, t, lam)]
+    r_o, jac_o = Oracle(program).eval(x, t)
+    ata_o = np.einsum("bij,bik->bjk", jac_o, jac_o)
+    atr_o = np.einsum("bij,bi->bj", jac_o, r_o)
+    assert np.max(np.abs(r - r_o)) <= 2.5e-13
+    assert np.max(np.abs(ata - ata_o)) <= 1e-11 * max(1.0, np.abs(ata_o).max())
+    assert np.max(np.abs(atr - atr_o)) <= 1e-11 * max(1.0, np.abs(atr_o).max())
+    n = program.n_vars
+    dx_o = np.stack([-np.linalg.solve(ata_o[k] + lam * np.eye(n), atr_o[k]) for k in range(len(x))])
+    assert np.max(np.abs(dx - dx_o)) <= 1e-9 * max(1.0, np.abs(dx_o).max())
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c2_dw_subset", "c4_macpherson_grid", "e2e_sweep"])
+def test_quad_solve_matches_oracle_wave_kernel_and_reference(golden, name):
+    from oracle.oracle import Oracle
+
+    arrays, program = golden(name)
+    pinned = program.with_line_mode("pinned")
+    dp = _dp(pinned)
+    t = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
+    quad = dp.solve(t, kernel="quad")
+    wave = dp.solve(t, kernel="single")
+    torch.cuda.synchronize()
+    info = quad.info()
+    assert np.all((info["flags"] & 7) == 1)
+    assert info["iterations"].max() <= 10
+    pos = quad.positions.cpu().numpy()
+    # same LM policy, other summation order: the two device kernels agree far below the tolerance
+    assert np.max(np.abs(pos - wave.positions.cpu().numpy())) <= 1e-10
+    assert np.array_equal(info["nfev"], wave.info()["nfev"])
+    sub = slice(None, None, max(1, t.shape[0] // 64))
+    orc = Oracle(pinned).sweep(arrays["targets_abs"][sub], 1e-15, 1e-15, 1e-15, warm_start=False)
+    assert np.max(np.abs(pos[sub] - orc.positions)) <= 1e-9  # north-star tolerance (mm)
+    assert np.max(np.abs(pos - arrays["ref_tight_pos"])) <= 6e-8  # reference's own floor
+    assert np.max(np.abs(info["max_residual"] - arrays["ref_tight_maxres"])) <= 1e-8
+
+
+@pytest.mark.parametrize("name", ["u_dw_corner", "u_macpherson"])
+def test_quad_solve_unsteered_matches_reference_to_1e9(golden, name):
+    arrays, program = golden(name)
+    dp = _dp(program)
+    res = dp.solve(torch.as_tensor(arrays["targets_abs"], device="cuda:0"), kernel="quad")
+    torch.cuda.synchronize()
+    assert np.all((res.info()["flags"] & 7) == 1)
+    pos = res.positions.cpu().numpy()
+    assert np.max(np.abs(pos - arrays["ref_tight_pos"])) <= 1e-9
+    assert np.max(np.abs(pos - arrays["ref_default_pos"])) <= 1e-9
+
+
+@pytest.mark.parametrize("chain_len", [-1, 1, 5, 16, 17, 101, 4096])
+def test_quad_chains_and_ragged_batches(golden, chain_len):
+    """Warm-started chains, secant predictor, batches that do not fill the last wavefront."""
+    arrays, program = golden("c1_dw_corner")
+    pinned = program.with_line_mode("pinned")
+    dp = _dp(pinned)
+    t_all = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
+    ref = dp.solve(t_all, kernel="quad", chain_len=1).positions
+    for b in (1, 3, 16, 17, 101):
+        guard = torch.full((b + 1, pinned.n_out, 3), -7.0, dtype=torch.float64, device="cuda:0")
+        res = dp.solve(t_all[:b], kernel="quad", chain_len=chain_len, out=guard[:b])
+        torch.cuda.synchronize()
+        assert np.all((res.info()["flags"] & 7) == 1)
+        assert float((res.positions - ref[:b]).abs().max()) <= 1e-9
+        assert float((guard[b] + 7.0).abs().max()) == 0.0, "wrote past the batch"
+    chained = dp.solve(t_all, kernel="quad", chain=True).info()
+    assert chained["nfev"].mean() < dp.solve(t_all, kernel="quad", chain_len=1).info()["nfev"].mean()
+
+
+def test_quad_ensemble_uses_per_geometry_tables(golden):
+    arrays, program = golden("c5_ensemble")
+    pinned = program.with_line_mode("pinned")
+    dp = _dp(pinned)
+    hp = torch.as_tensor(arrays["hardpoints"], device="cuda:0")
+    gpos, gparam = dp.rebind(hp)
+    g, s = arrays["targets_abs"].shape[:2]
+    t = torch.as_tensor(arrays["targets_abs"].reshape(g * s, -1), device="cuda:0")
+    quad = dp.solve(t, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=s, kernel="quad")
+    wave = dp.solve(t, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=s, kernel="single")
+    torch.cuda.synchronize()
+    assert np.all((quad.info()["flags"] & 7) == 1)
+    assert float((quad.positions - wave.positions).abs().max()) <= 1e-10
+    assert np.max(np.abs(quad.positions.cpu().numpy().reshape(g, s, -1, 3) - arrays["ref_tight_pos"])) <= 6e-8
+    for cl in (4, 100):
+        res = dp.solve(t, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=s, kernel="quad", chain_len=cl)
+        assert float((res.positions - quad.positions).abs().max()) <= 1e-9
+    assert g * s == t.shape[0]
+
+
+def test_quad_reports_infeasible_targets_like_the_wave_kernel(golden):
+    """An unreachable target stops on the ftol test with the residual flag set (solver.py:732-747)."""
+    arrays, program = golden("c1_dw_corner")
+    pinned = program.with_line_mode("pinned")
+    dp = _dp(pinned)
+    t = arrays["targets_abs"][:16].copy()
+    t[:, 1] += 2000.0  # wheel centre 2 m above anything the links allow
+    quad = dp.solve(t, kernel="quad").info()
+    wave = dp.solve(t, kernel="single").info()
+    assert np.all(quad["flags"] & 2) and np.all(wave["flags"] & 2)
+    assert np.allclose(quad["max_residual"], wave["max_residual"], rtol=1e-6)
+
+
+def test_axle_keeps_the_wave_kernel_and_says_why(golden):
+    from open_kinematics_amd.batch import DeviceProgram
+
+    _, program = golden("c3_axle_grid")
+    dp = DeviceProgram(program.with_line_mode("pinned"), "cuda:0")
+    assert dp.kernel == "wave" and "free points" in dp.kernel_note
+    with pytest.raises(ValueError, match="quad kernel requested but not available"):
+        dp.solve(np.zeros((1, program.n_targets)), kernel="quad")

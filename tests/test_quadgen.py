@@ -1,0 +1,85 @@
+"""
+The runtime-specialised "quad" kernel, CPU side: source generation from a constraint program,
+hiprtc compilation into the on-disk cache (no device needed) and the fall-back decisions.
+"""
+
+import ctypes as C
+import os
+
+import pytest
+
+from conftest import STEERED, UNSTEERED
+from open_kinematics_amd import _abi, _lib
+
+
+def _source(program) -> str:
+    lib = _lib.load()
+    host = _abi.HostProgram(program)
+    size = lib.okx_quad_source(host.byref(), None, 0)
+    if size < 0:
+        raise ValueError(_lib.last_error())
+    buf = C.create_string_buffer(size)
+    assert lib.okx_quad_source(host.byref(), buf, size) == size
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid", "u_dw_corner", "u_macpherson"])
+@pytest.mark.parametrize("mode", ["pinned", "softnorm"])
+def test_source_is_generated_for_corner_topologies(golden, name, mode):
+    _, program = golden(name)
+    p = program.with_line_mode(mode)
+    src = _source(p)
+    for kernel in ("okx_quad_solve_u", "okx_quad_solve_g", "okx_quad_eval"):
+        assert f"void __launch_bounds__(64, 1) {kernel}(" in src
+    # one residual per row, one J^T J accumulator per diagonal block entry
+    for i in range(p.n_residuals):
+        assert f"const double r{i} =" in src
+    for f in range(p.n_free):
+        for k in range(3):
+            assert f"double A{f}_{f}_{k}" in src
+    # the per-problem decisions rely on bit-identical quad reductions
+    assert "#pragma clang fp contract(off)" in src
+    # structure only: no geometry value is baked into the text
+    assert "471.69" not in src and "559.01" not in src
+
+
+def test_same_structure_gives_the_same_kernel_different_structure_does_not(golden):
+    _, a = golden("c1_dw_corner")
+    _, b = golden("c2_dw_subset")  # same topology, same geometry file, other targets
+    _, u = golden("u_dw_corner")   # toe link instead of the rack: other rows
+    assert _source(a.with_line_mode("pinned")) == _source(b.with_line_mode("pinned"))
+    assert _source(a.with_line_mode("pinned")) != _source(u.with_line_mode("pinned"))
+    assert _source(a.with_line_mode("pinned")) != _source(a.with_line_mode("softnorm"))
+
+
+@pytest.mark.parametrize("name", ["c3_axle_grid", "u_axle"])
+def test_large_programs_keep_the_generic_kernels(golden, name):
+    _, program = golden(name)
+    lib = _lib.load()
+    host = _abi.HostProgram(program.with_line_mode("pinned"))
+    assert lib.okx_quad_source(host.byref(), None, 0) == -2  # OKX_ERR_LIMIT
+    assert "free points" in _lib.last_error()
+    assert lib.okx_precompile(host.byref()) == -2
+
+
+def test_precompile_fills_the_cache_without_a_device(golden, tmp_path, monkeypatch):
+    _, program = golden("c1_dw_corner")
+    monkeypatch.setenv("OKX_KERNEL_CACHE", str(tmp_path))
+    lib = _lib.load()
+    host = _abi.HostProgram(program.with_line_mode("pinned"))
+    assert lib.okx_precompile(host.byref()) == 0, _lib.last_error()
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(files) == 1
+    blob = (tmp_path / files[0]).read_bytes()
+    assert blob[:4] == b"\x7fELF" and b"okx_quad_solve_u" in blob
+    stamp = os.path.getmtime(tmp_path / files[0])
+    assert lib.okx_precompile(host.byref()) == 0  # second call is a cache hit
+    assert os.path.getmtime(tmp_path / files[0]) == stamp
+
+
+def test_header_documents_the_kernel_choice():
+    from conftest import REPO
+
+    text = open(os.path.join(REPO, "include", "okx.h"), encoding="utf-8").read()
+    for name in ("okx_program_kernel", "okx_quad_source", "okx_precompile"):
+        assert name in text

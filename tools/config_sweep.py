@@ -6,8 +6,8 @@ import numpy as np, torch
 from open_kinematics_amd.batch import DeviceProgram
 from open_kinematics_amd import workloads as W
 
-def timed(fn, reps=5):
-    fn(); torch.cuda.synchronize()
+def timed(fn, reps=10):
+    fn(); fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps): out = fn()
     torch.cuda.synchronize()
@@ -18,7 +18,10 @@ KERNELS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["auto"]
 def report(name, dp, targets, **kw):
     for kern in KERNELS:
         for cl in (1, -1):
-            dt, res = timed(lambda: dp.solve(targets, chain_len=cl, kernel=kern, **kw))
+            b = targets.shape[0]
+            out = torch.empty((b, dp.program.n_out, 3), dtype=torch.float64, device="cuda")
+            info_out = torch.empty((b, 40), dtype=torch.uint8, device="cuda")
+            dt, res = timed(dp.plan(targets, chain_len=cl, kernel=kern, out=out, info_out=info_out, **kw))
             info = res.info()
             ok = bool(np.all((info["flags"] & 7) == 1))
             print(f"{name:34s} {kern:6s} chain_len={cl:2d}  B={targets.shape[0]:8d}  {targets.shape[0]/dt/1e6:8.3f} M solves/s  "
