@@ -312,15 +312,41 @@ class Gen {
       std::snprintf(b, sizeof(b), "a.row_param[%d]", i * 8 + k);
     return b;
   }
-  // lane-component load of three consecutive row parameters (0 in lane 3)
+  // Lane-component load of three consecutive row parameters (0 in lane 3).  These are constant
+  // for a whole chain (geometry), so they are emitted into `hoisted`, which the kernel places
+  // in front of the Levenberg-Marquardt loop, one load per distinct (row, offset).
+  std::string hoisted;
+  std::map<std::pair<int, int>, std::string> hoisted_names;
   std::string rpv(int i, int k0) {
-    std::string t = tmp("q");
+    i = pin_leader(i);
+    auto key = std::make_pair(i, k0);
+    auto it = hoisted_names.find(key);
+    if (it != hoisted_names.end()) return it->second;
+    char name[48], line[160];
+    std::snprintf(name, sizeof(name), "hq%d_%d", i, k0);
     if (i < P.n_crows)
-      f("    const double %s = c < 3 ? gq[%d + cc] : 0.0;", t.c_str(), i * 8 + k0);
+      std::snprintf(line, sizeof(line), "      const double %s = c < 3 ? gq[%d + cc] : 0.0;\n", name, i * 8 + k0);
     else
-      f("    const double %s = c < 3 ? a.row_param[%d + cc] : 0.0;", t.c_str(), i * 8 + k0);
-    return t;
+      std::snprintf(line, sizeof(line), "      const double %s = c < 3 ? a.row_param[%d + cc] : 0.0;\n", name, i * 8 + k0);
+    hoisted += line;
+    hoisted_names[key] = name;
+    return name;
   }
+  // The three LINE_PIN rows that one point-on-line constraint flattens into (same point, same
+  // line in the program's own geometry, components 0/1/2) share their line parameters and their
+  // cross product: the first of them is the group's leader.  Per-geometry tables keep them equal
+  // (okx_rebind_design writes the same anchor for every pin of a point).
+  int pin_leader(int i) const {
+    if (i >= P.n_crows || P.row_type[i] != OKX_ROW_LINE_PIN) return i;
+    for (int j = 0; j < i; ++j) {
+      if (P.row_type[j] != OKX_ROW_LINE_PIN || P.row_pts[j][0] != P.row_pts[i][0]) continue;
+      bool same = true;
+      for (int k = 0; k < 6; ++k) same = same && P.row_param[j][k] == P.row_param[i][k];
+      if (same) return j;
+    }
+    return i;
+  }
+  std::map<int, std::string> pin_cross_;  // leader row -> (p - line point) x line dir
 
   bool row(int i, RowOut* ro) {
     const int type = P.row_type[i];
@@ -414,8 +440,15 @@ class Gen {
       case OKX_ROW_POINT_ON_LINE:
       case OKX_ROW_LINE_PIN: {  // constraints.py:560-576; jacobians.py:372-403; okx.h (pin)
         std::string lp = rpv(i, 0), ld = rpv(i, 3);
-        std::string w = vsub(pn(pts[0]), lp);
-        std::string cv = cross(w, ld);
+        std::string cv;
+        const int leader = pin_leader(i);
+        if (type == OKX_ROW_LINE_PIN && pin_cross_.count(leader)) {
+          cv = pin_cross_[leader];
+        } else {
+          std::string w = vsub(pn(pts[0]), lp);
+          cv = cross(w, ld);
+          if (type == OKX_ROW_LINE_PIN) pin_cross_[leader] = cv;
+        }
         if (type == OKX_ROW_POINT_ON_LINE) {
           std::string c2 = dot(cv, cv);
           std::string root = tmp("rt"), inv = tmp("iv");
@@ -587,11 +620,8 @@ class Gen {
             }
           }
         }
-      f("    SCHED_FENCE;");
     }
     // diagonal blocks that no row touched still exist (as zeros)
-    // (SCHED_FENCE after every row keeps the scheduler from hoisting later rows' loads and
-    // broadcasts over this row's accumulation: live ranges stay one row long)
     for (int F = 0; F < nf; ++F)
       for (int k = 0; k < 3; ++k)
         if (!declared.count(A(F, F, k))) f("    double %s = 0.0;", A(F, F, k).c_str());
@@ -615,7 +645,7 @@ class Gen {
         f("    const double piv = QB%d(%s);", k, A(G, G, k).c_str());
         f("    ok = ok && piv > 0.0;  // a failed factor is never used: no need to sanitise the pivot");
         f("    const double rinv = fast_rcp(piv);");
-        f("    dinv%d = c == %d ? rinv : dinv%d;", G, k, G);
+        f("    dinv%d = fma(e%d, rinv, dinv%d);", G, k, G);
         // factor entries of this column (rows below the pivot)
         if (k < 2) f("    %s = c > %d ? %s * rinv : 0.0;", Ln(G, G, k).c_str(), k, A(G, G, k).c_str());
         for (int F = G + 1; F < nf; ++F)
@@ -637,7 +667,7 @@ class Gen {
             f("    }");
           }
         }
-        f("    SCHED_FENCE; }");
+        f("    }");
       }
     for (int F = 0; F < nf; ++F)
       for (int G = 0; G < nf; ++G) fillf[F][G] = fill[F][G];
@@ -666,13 +696,13 @@ class Gen {
             f("      s0 = fma(%s, nx%d, s0); s1 = fma(%s, nx%d, s1); s2 = fma(%s, nx%d, s2);", Ln(F, G, 0).c_str(), F,
               Ln(F, G, 1).c_str(), F, Ln(F, G, 2).c_str(), F);
         f("      s0 = qsum(s0); s1 = qsum(s1); s2 = qsum(s2);");
-        f("      nx%d -= c == 0 ? s0 : (c == 1 ? s1 : (c == 2 ? s2 : 0.0)); }", G);  // lane 3 stays 0
+        f("      nx%d = fma(-e0, s0, fma(-e1, s1, fma(-e2, s2, nx%d))); }", G, G);  // lane 3 stays 0
       }
       f("    { const double xb2 = QB2(nx%d), l21 = QB2(%s), l20 = QB2(%s);", G, Ln(G, G, 1).c_str(),
         Ln(G, G, 0).c_str());
-      f("      nx%d = fma(-(c == 1 ? l21 : (c == 0 ? l20 : 0.0)), xb2, nx%d);", G, G);
+      f("      nx%d = fma(-fma(e1, l21, e0 * l20), xb2, nx%d);", G, G);
       f("      const double xb1 = QB1(nx%d), l10 = QB1(%s);", G, Ln(G, G, 0).c_str());
-      f("      nx%d = fma(-(c == 0 ? l10 : 0.0), xb1, nx%d); }", G, G);
+      f("      nx%d = fma(-(e0 * l10), xb1, nx%d); }", G, G);
     }
   }
 
@@ -691,9 +721,6 @@ struct QArgs {
   const double* design_pos; const double* row_param; const double* dop_param;
   double* trace; long long trace_problem;   // diagnostic: 8 doubles per LM pass of one problem (null: off)
 };
-#ifndef SCHED_FENCE
-#define SCHED_FENCE __builtin_amdgcn_sched_barrier(0)
-#endif
 #define EPS_SQ 1e-12
 #define EPS 1e-6
 #define DEV __device__ __forceinline__
@@ -834,6 +861,8 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("    const long long geom = spg > 0 ? first_b / spg : 0;");
   g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * NP);
   g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * P.n_crows);
+  g.f("    // chain-constant lane-component parameters (line points / directions, target directions)");
+  g.out += ev.hoisted;
   // point registers
   for (int p = 0; p < NP; ++p)
     if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
@@ -986,6 +1015,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
   g.f("  const double* gp = a.design_pos; const double* gq = a.row_param;");
+  g.out += ev.hoisted;
   g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_problems; wu += gridDim.x) {");
   g.f("    long long bb = wu * 16 + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");
   for (int p = 0; p < NP; ++p)
