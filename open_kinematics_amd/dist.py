@@ -49,6 +49,55 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     return torch.cat(pieces, dim=0)
 
 
+class GatherPipeline:
+    """
+    Overlaps the exchange step with the next solve: the all-gather of step ``k`` runs on the
+    collective's own stream (RCCL over xGMI) while the solve kernel of step ``k + 1`` fills the
+    other of two output slots.  In steady state a step costs ``max(solve, all-gather)`` instead of
+    their sum.  Equal shards only (``n_total`` divisible by the world size).
+
+        pipe = GatherPipeline(rows_per_rank, (n_out, 3), torch.float64, device)
+        for k in range(steps):
+            out = pipe.begin(k)        # local buffer of this step (waits for the gather that last read it)
+            ... launch the solve into ``out`` on the current stream ...
+            pipe.submit(k)             # asynchronous all-gather of ``out``
+        full = pipe.drain()            # gathered positions of the last step, all exchanges complete
+    """
+
+    def __init__(self, rows_per_rank: int, tail_shape, dtype, device, group=None, depth: int = 2):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.depth = depth
+        self.local = [torch.empty((rows_per_rank, *tail_shape), dtype=dtype, device=device) for _ in range(depth)]
+        self.full = [torch.empty((rows_per_rank * self.world, *tail_shape), dtype=dtype, device=device)
+                     if self.world > 1 else None for _ in range(depth)]
+        self.work = [None] * depth
+        self.last = -1
+
+    def begin(self, k: int) -> torch.Tensor:
+        slot = k % self.depth
+        if self.work[slot] is not None:
+            self.work[slot].wait()  # NCCL: the current stream waits; gloo: the host does
+            self.work[slot] = None
+        return self.local[slot]
+
+    def submit(self, k: int) -> None:
+        slot = k % self.depth
+        self.last = slot
+        if self.world > 1:
+            self.work[slot] = dist.all_gather_into_tensor(self.full[slot], self.local[slot], group=self.group,
+                                                          async_op=True)
+
+    def drain(self) -> torch.Tensor:
+        for slot in range(self.depth):
+            if self.work[slot] is not None:
+                self.work[slot].wait()
+                self.work[slot] = None
+        if self.last < 0:
+            raise RuntimeError("nothing was submitted")
+        return self.local[self.last] if self.world == 1 else self.full[self.last]
+
+
 def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = True, group=None, **solve_kw):
     """
     Solve this rank's index block of ``targets_full [B, T]`` and (optionally) all-gather the

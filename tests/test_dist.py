@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import REPO
-from open_kinematics_amd.dist import all_gather_rows, shard_range
+from open_kinematics_amd.dist import GatherPipeline, all_gather_rows, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -41,6 +41,14 @@ def _worker(rank: int, world: int, port: int, n_total: int, out_dir: str) -> Non
     local = _fake_solve(targets[lo:hi])
     full = all_gather_rows(local, n_total)
     torch.save(full, os.path.join(out_dir, f"rank{rank}.pt"))
+    if n_total % world == 0:
+        # the bench's pipelined exchange: gather of step k overlaps the "solve" of step k + 1
+        pipe = GatherPipeline(hi - lo, (5, 3), torch.float64, "cpu")
+        for k in range(5):
+            out = pipe.begin(k)
+            out.copy_(_fake_solve(targets[lo:hi] + float(k)))
+            pipe.submit(k)
+        torch.save(pipe.drain().clone(), os.path.join(out_dir, f"pipe{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,6 +61,17 @@ def test_two_rank_gloo_gather_reassembles_the_sweep(tmp_path, n_total):
     for rank in range(2):
         got = torch.load(os.path.join(tmp_path, f"rank{rank}.pt"))
         assert got.shape == expect.shape and torch.equal(got, expect)
+        if n_total % 2 == 0:
+            last = _fake_solve(torch.linspace(-60.0, 80.0, n_total, dtype=torch.float64).reshape(-1, 1) + 4.0)
+            assert torch.equal(torch.load(os.path.join(tmp_path, f"pipe{rank}.pt")), last)
+
+
+def test_single_process_pipeline_degenerates_to_the_local_buffer():
+    pipe = GatherPipeline(4, (3,), torch.float64, "cpu")
+    for k in range(3):
+        pipe.begin(k).fill_(float(k))
+        pipe.submit(k)
+    assert torch.equal(pipe.drain(), torch.full((4, 3), 2.0, dtype=torch.float64))
 
 
 def test_single_process_gather_is_identity():
