@@ -229,6 +229,41 @@ int32_t okx_rebind_design(okx_program* prog, int64_t n_geometries,
                           double* d_geom_row_param,       /* [G][Mc][8] */
                           void* stream);
 
+/* Health of one tangent solve, the device analogue of TangentSolveInfo (sensitivity.py:44-55):
+ * the pivots of the LDL^T of J^T J stand in for the singular values of J: they lie inside
+ * [s_min^2, s_max^2], so sqrt(max_pivot / min_pivot) is a lower bound of J's condition number
+ * and a non-positive or vanishing pivot signals rank deficiency. */
+typedef struct okx_tangent_info {
+  double min_pivot;       /* smallest pivot of the LDL^T of J^T J                          */
+  double max_pivot;       /* largest pivot                                                 */
+  int32_t flags;          /* bit0 factorisation succeeded, bit1 rank deficient
+                             (min_pivot <= n * eps * max_pivot or a non-positive pivot)    */
+  int32_t reserved;
+} okx_tangent_info;
+
+#define OKX_TANGENT_OK 1
+#define OKX_TANGENT_RANK_DEFICIENT 2
+
+/*
+ * Replaces compute_state_tangents / compute_sweep_tangents (sensitivity.py:57-143,
+ * sweep.py:113-141) for B solved states: with J the analytical Jacobian at the state
+ * (constraint rows + target rows; the pinned line rows play the role of the reference's
+ * _degenerate_constraint_pins, sensitivity.py:146-174), solves J q_t = e_t in the
+ * least-squares sense for every target row t (q_t = (J^T J)^-1 J^T e_t) and propagates the
+ * free-point velocities to every derived point in forward mode.  d_pos [B][n_out][3] are
+ * solved positions as written by okx_solve_batch (every free point must be an output
+ * point); d_tangents [B][T][n_out][3] receives d(point)/d(target t); fixed points get 0.
+ * Geometry tables as in okx_solve_batch.  Needs the program's quad kernel
+ * (OKX_ERR_INVALID otherwise).
+ */
+int32_t okx_tangent_batch(okx_program* prog, int64_t n_problems, int64_t steps_per_geometry,
+                          const double* d_pos,            /* [B][n_out][3] */
+                          const double* d_geom_pos,       /* [G][P][3] or NULL */
+                          const double* d_geom_row_param, /* [G][Mc][8] or NULL */
+                          double* d_tangents,             /* [B][T][n_out][3] */
+                          okx_tangent_info* d_tinfo,      /* [B] */
+                          void* stream);
+
 /*
  * Runtime specialisation.  okx_program_create also GENERATES a HIP kernel for the program at
  * hand (straight-line residual / Jacobian / normal-equation / LDL^T code, four lanes per

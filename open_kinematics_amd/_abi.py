@@ -80,6 +80,11 @@ INFO_DTYPE = np.dtype(
 )
 assert INFO_DTYPE.itemsize == C.sizeof(Info) == 40
 
+TANGENT_INFO_DTYPE = np.dtype([("min_pivot", "<f8"), ("max_pivot", "<f8"), ("flags", "<i4"), ("reserved", "<i4")])
+assert TANGENT_INFO_DTYPE.itemsize == 24
+TANGENT_OK = 1
+TANGENT_RANK_DEFICIENT = 2
+
 INFO_CONVERGED = 1
 INFO_RESIDUAL_EXCEEDED = 2
 INFO_FAILED = 4

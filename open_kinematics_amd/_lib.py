@@ -32,6 +32,7 @@ EXPORTS = (
     "okx_program_kernel_note",
     "okx_quad_source",
     "okx_precompile",
+    "okx_tangent_batch",
 )
 
 _lib = None
@@ -89,6 +90,8 @@ def load() -> C.CDLL:
     lib.okx_quad_source.restype = i64
     lib.okx_precompile.argtypes = [C.POINTER(ProgramDesc)]
     lib.okx_precompile.restype = i32
+    lib.okx_tangent_batch.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp]
+    lib.okx_tangent_batch.restype = i32
     lib.okx_debug_quad_eval.argtypes = [vp, i64, vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.okx_debug_quad_eval.restype = i32
     if lib.okx_abi_version() != 1:

@@ -16,7 +16,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._abi import INFO_CONVERGED, INFO_DTYPE, INFO_FAILED, INFO_RESIDUAL_EXCEEDED, HostProgram, SolveOpts
+from ._abi import (INFO_CONVERGED, INFO_DTYPE, INFO_FAILED, INFO_RESIDUAL_EXCEEDED, TANGENT_INFO_DTYPE, HostProgram,
+                   SolveOpts)
 from .program import ConstraintProgram
 
 
@@ -220,6 +221,37 @@ class DeviceProgram:
             )
         _lib.check(rc, "okx_debug_normal_equations")
         return r, ata, atr
+
+    def tangents(self, positions, *, geom_pos=None, geom_row_param=None, steps_per_geometry: int = 0):
+        """
+        Solution-manifold tangents of ``B`` solved states (reference ``compute_state_tangents``,
+        ``sensitivity.py:57-143``): ``positions [B, n_out, 3]`` as returned by ``solve`` ->
+        ``(tangents [B, T, n_out, 3], info)`` with ``tangents[b, t, k] = d point_k / d target_t`` and
+        ``info`` a structured array (``_abi.TANGENT_INFO_DTYPE``: pivot range of the LDL^T of
+        ``J^T J``, ok / rank-deficient flags).  Stays in HBM; one kernel launch.
+        """
+        p = self.program
+        pos = _as_f64(positions, self.device).reshape(-1, p.n_out, 3)
+        b = pos.shape[0]
+        if geom_pos is not None:
+            geom_pos = _as_f64(geom_pos, self.device)
+            geom_row_param = _as_f64(geom_row_param, self.device)
+            if geom_pos.shape[1:] != (p.n_points, 3) or geom_row_param.shape != (geom_pos.shape[0], p.n_rows, 8):
+                raise ValueError("geometry table has the wrong shape")
+            if steps_per_geometry <= 0 or geom_pos.shape[0] * steps_per_geometry != b:
+                raise ValueError("B must equal n_geometries * steps_per_geometry")
+        tan = torch.empty((b, p.n_targets, p.n_out, 3), dtype=torch.float64, device=self.device)
+        tinfo = torch.empty((b, TANGENT_INFO_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_tangent_batch(self._handle, b, int(steps_per_geometry), _ptr(pos), _ptr(geom_pos),
+                                            _ptr(geom_row_param), _ptr(tan), _ptr(tinfo), C.c_void_p(stream))
+        _lib.check(rc, "okx_tangent_batch")
+        return tan, tinfo
+
+    @staticmethod
+    def tangent_info(tinfo: torch.Tensor) -> np.ndarray:
+        return tinfo.cpu().numpy().view(TANGENT_INFO_DTYPE).reshape(-1)
 
     def quad_eval(self, x, targets, lam: float = 0.0):
         """

@@ -34,6 +34,7 @@ struct okx_program {
   hipFunction_t quad_fn_u;  // program's own geometry
   hipFunction_t quad_fn_g;  // per-geometry tables
   hipFunction_t quad_fn_eval;  // parity kernel
+  hipFunction_t quad_fn_tan_u, quad_fn_tan_g;  // tangents (null when a free point is not an output point)
   int quad_waves_per_cu;
   char quad_note[256];      // why the quad kernel is not in use (empty when it is)
 };
@@ -156,6 +157,7 @@ void attach_quad_kernel(okx_program* p) {
   p->quad_mod = nullptr;
   p->quad_fn_u = p->quad_fn_g = nullptr;
   p->quad_fn_eval = nullptr;
+  p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
   p->quad_waves_per_cu = 0;
   p->quad_note[0] = 0;
   if (const char* env = getenv("OKX_QUAD")) {
@@ -203,6 +205,9 @@ void attach_quad_kernel(okx_program* p) {
   p->quad_fn_u = fu;
   p->quad_fn_g = fg;
   if (hipModuleGetFunction(&p->quad_fn_eval, mod, "okx_quad_eval") != hipSuccess) p->quad_fn_eval = nullptr;
+  if (hipModuleGetFunction(&p->quad_fn_tan_u, mod, "okx_quad_tangent_u") != hipSuccess ||
+      hipModuleGetFunction(&p->quad_fn_tan_g, mod, "okx_quad_tangent_g") != hipSuccess)
+    p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
   p->quad_waves_per_cu = 4 * per_simd;
 }
 
@@ -520,6 +525,41 @@ int32_t okx_rebind_design(okx_program* p, int64_t n_geometries, const double* d_
   hipLaunchKernelGGL(okx::okx_rebind_kernel, dim3(grid_for(p, n_geometries)), dim3(okx::kWave),
                      p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
   HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
+int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_geometry, const double* d_pos,
+                          const double* d_geom_pos, const double* d_geom_row_param, double* d_tangents,
+                          okx_tangent_info* d_tinfo, void* stream) {
+  if (!p) return fail(OKX_ERR_INVALID, "null program");
+  if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
+  if (n_problems == 0) return OKX_OK;
+  if (!p->quad_fn_tan_u)
+    return fail(OKX_ERR_INVALID, "tangents need the program's quad kernel%s%s", p->quad_note[0] ? ": " : "",
+                p->quad_note[0] ? p->quad_note : " (and every free point among the output points, and a target)");
+  if (!d_pos || !d_tangents || !d_tinfo) return fail(OKX_ERR_INVALID, "null pointer");
+  if ((d_geom_pos == nullptr) != (d_geom_row_param == nullptr))
+    return fail(OKX_ERR_INVALID, "geometry positions and row parameters must be given together");
+  if (steps_per_geometry < 0 || (d_geom_pos && steps_per_geometry == 0) ||
+      (steps_per_geometry > 0 && n_problems % steps_per_geometry != 0))
+    return fail(OKX_ERR_INVALID, "bad steps_per_geometry");
+  okx::QuadTanArgs q;
+  q.pos = d_pos;
+  q.geom_pos = d_geom_pos;
+  q.geom_row_param = d_geom_row_param;
+  q.tan = d_tangents;
+  q.tinfo = d_tinfo;
+  q.n_problems = n_problems;
+  q.steps_per_geometry = steps_per_geometry;
+  const char* base = reinterpret_cast<const char*>(p->dev);
+  q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
+  q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
+  q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
+  const long long waves = (n_problems + 15) / 16;
+  const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
+  void* kargs[] = {(void*)&q};
+  HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->quad_fn_tan_g : p->quad_fn_tan_u, (int)(waves < cap ? waves : cap), 1, 1,
+                                okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
   return OKX_OK;
 }
 

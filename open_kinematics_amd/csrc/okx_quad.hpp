@@ -42,6 +42,19 @@ struct QuadEvalArgs {
   const double* dop_param;
 };
 
+// Arguments of the generated tangent kernels `okx_quad_tangent_u/_g` (mirrors `struct QTanArgs`).
+struct QuadTanArgs {
+  const double* pos;
+  const double* geom_pos;
+  const double* geom_row_param;
+  double* tan;
+  okx_tangent_info* tinfo;
+  long long n_problems, steps_per_geometry;
+  const double* design_pos;
+  const double* row_param;
+  const double* dop_param;
+};
+
 // Emits the HIP source of the kernel specialised to `P`.  Returns false (and says why) when the
 // program uses a feature the generator has no code path for; the caller then keeps the generic
 // interpreter kernels of okx_kernels.hip.

@@ -600,6 +600,7 @@ class Gen {
           jv.push_back({kv.first, {t, 1}});
         }
       }
+      if (P.row_type[i] == kRowTarget) target_j[(int)P.row_param[i][3]] = jv;
       // J^T r and J^T J (lower block triangle: F >= G)
       for (auto& fv : jv) f("    gn%d = fma(%s, %s, gn%d);", fv.first, sx(fv.second).c_str(), ro.r.c_str(), fv.first);
       for (size_t ia = 0; ia < jv.size(); ++ia)
@@ -630,6 +631,15 @@ class Gen {
 
   // LDL^T of (J^T J + lambda I), forward / diagonal / backward substitution -> dx{F}.
   void emit_solve() {
+    emit_factor();
+    // right-hand side -g, result nx{F}
+    std::vector<std::string> rhs;
+    for (int F = 0; F < P.n_free; ++F) rhs.push_back("-gn" + std::to_string(F));
+    emit_substitute(rhs, "nx");
+  }
+
+  // LDL^T of (J^T J + lambda I) in registers; leaves L{F}_{G}_{k}, dinv{F}, ok, pmin, pmax.
+  void emit_factor() {
     const int nf = P.n_free;
     bool fill[kMaxFree][kMaxFree];
     for (int F = 0; F < nf; ++F)
@@ -638,12 +648,14 @@ class Gen {
     for (int F = 0; F < nf; ++F)
       for (int k = 0; k < 3; ++k) f("    %s = fma(lambda, e%d, %s);", A(F, F, k).c_str(), k, A(F, F, k).c_str());
     f("    bool ok = true;");
+    f("    double pmin = 1e300, pmax = 0.0;  // smallest / largest pivot (conditioning of the tangent solve)");
     for (int F = 0; F < nf; ++F) f("    double dinv%d = 0.0;", F);
     for (int G = 0; G < nf; ++G)
       for (int k = 0; k < 3; ++k) {
         f("    { // column %d", 3 * G + k);
         f("    const double piv = QB%d(%s);", k, A(G, G, k).c_str());
         f("    ok = ok && piv > 0.0;  // a failed factor is never used: no need to sanitise the pivot");
+        f("    pmin = fmin(pmin, piv); pmax = fmax(pmax, piv);");
         f("    const double rinv = fast_rcp(piv);");
         f("    dinv%d = fma(e%d, rinv, dinv%d);", G, k, G);
         // factor entries of this column (rows below the pivot)
@@ -658,10 +670,7 @@ class Gen {
             for (int F = H; F < nf; ++F) {
               if (F > G && !fill[F][G]) continue;
               if (F == G && k == 2) continue;
-              if (!fill[F][H]) {
-                // fill-in: the block becomes structurally non-zero; its columns start from zero
-                fill[F][H] = true;
-              }
+              fill[F][H] = true;  // fill-in: the block becomes structurally non-zero
               f("      %s = fma(-%s, cu, %s);", A(F, H, j).c_str(), Ln(F, G, k).c_str(), A(F, H, j).c_str());
             }
             f("    }");
@@ -671,40 +680,98 @@ class Gen {
       }
     for (int F = 0; F < nf; ++F)
       for (int G = 0; G < nf; ++G) fillf[F][G] = fill[F][G];
-    // forward substitution, block by block (unit lower factor)
-    f("    // ---- L y = -g ----");
-    for (int F = 0; F < nf; ++F) f("    double y%d = -gn%d;", F, F);
+  }
+
+  // Forward / diagonal / backward substitution with the factor in registers:
+  // {out}{F} = (J^T J + lambda I)^-1 rhs[F]   (rhs: expression per free block, lane component).
+  void emit_substitute(const std::vector<std::string>& rhs, const char* out) {
+    const int nf = P.n_free;
+    f("    // ---- L y = rhs (unit lower, block by block) ----");
+    for (int F = 0; F < nf; ++F) f("    double y%d = %s;", F, rhs[F].c_str());
     for (int G = 0; G < nf; ++G) {
       f("    { const double yb0 = QB0(y%d); y%d = fma(-%s, yb0, y%d);", G, G, Ln(G, G, 0).c_str(), G);
       f("      const double yb1 = QB1(y%d); y%d = fma(-%s, yb1, y%d);", G, G, Ln(G, G, 1).c_str(), G);
       f("      const double yb2 = QB2(y%d);", G);
       for (int F = G + 1; F < nf; ++F)
-        if (fill[F][G])
+        if (fillf[F][G])
           f("      y%d = fma(-%s, yb0, fma(-%s, yb1, fma(-%s, yb2, y%d)));", F, Ln(F, G, 0).c_str(), Ln(F, G, 1).c_str(),
             Ln(F, G, 2).c_str(), F);
       f("    }");
     }
-    f("    // ---- D z = y, L^T dx = z ----");
+    f("    // ---- D z = y, L^T x = z ----");
     for (int G = nf - 1; G >= 0; --G) {
-      f("    double nx%d = y%d * dinv%d;", G, G, G);
+      f("    double %s%d = y%d * dinv%d;", out, G, G, G);
       bool any = false;
-      for (int F = G + 1; F < nf; ++F) any = any || fill[F][G];
+      for (int F = G + 1; F < nf; ++F) any = any || fillf[F][G];
       if (any) {
         f("    { double s0 = 0.0, s1 = 0.0, s2 = 0.0;");
         for (int F = G + 1; F < nf; ++F)
-          if (fill[F][G])
-            f("      s0 = fma(%s, nx%d, s0); s1 = fma(%s, nx%d, s1); s2 = fma(%s, nx%d, s2);", Ln(F, G, 0).c_str(), F,
-              Ln(F, G, 1).c_str(), F, Ln(F, G, 2).c_str(), F);
+          if (fillf[F][G])
+            f("      s0 = fma(%s, %s%d, s0); s1 = fma(%s, %s%d, s1); s2 = fma(%s, %s%d, s2);", Ln(F, G, 0).c_str(), out, F,
+              Ln(F, G, 1).c_str(), out, F, Ln(F, G, 2).c_str(), out, F);
         f("      s0 = qsum(s0); s1 = qsum(s1); s2 = qsum(s2);");
-        f("      nx%d = fma(-e0, s0, fma(-e1, s1, fma(-e2, s2, nx%d))); }", G, G);  // lane 3 stays 0
+        f("      %s%d = fma(-e0, s0, fma(-e1, s1, fma(-e2, s2, %s%d))); }", out, G, out, G);  // lane 3 stays 0
       }
-      f("    { const double xb2 = QB2(nx%d), l21 = QB2(%s), l20 = QB2(%s);", G, Ln(G, G, 1).c_str(),
+      f("    { const double xb2 = QB2(%s%d), l21 = QB2(%s), l20 = QB2(%s);", out, G, Ln(G, G, 1).c_str(),
         Ln(G, G, 0).c_str());
-      f("      nx%d = fma(-fma(e1, l21, e0 * l20), xb2, nx%d);", G, G);
-      f("      const double xb1 = QB1(nx%d), l10 = QB1(%s);", G, Ln(G, G, 0).c_str());
-      f("      nx%d = fma(-(e0 * l10), xb1, nx%d); }", G, G);
+      f("      %s%d = fma(-fma(e1, l21, e0 * l20), xb2, %s%d);", out, G, out, G);
+      f("      const double xb1 = QB1(%s%d), l10 = QB1(%s);", out, G, Ln(G, G, 0).c_str());
+      f("      %s%d = fma(-(e0 * l10), xb1, %s%d); }", out, G, out, G);
     }
   }
+
+  // Directional derivative of one derived op (forward mode, closed form): velocity of the output
+  // point from the velocities `vn(p)` of its inputs, at the positions p{k}.  Replaces the
+  // reference's dual-number pass (sensitivity.py:127-131, primitives/dual.py).
+  bool derived_jvp(int e, const std::string& vp) {
+    const int type = P.dop_type[e];
+    const int* pts = P.dop_pts[e];
+    auto vn = [&](int p) { return vp + std::to_string(p); };
+    const std::string o = vn(P.dop_out[e]);
+    if (type == OKX_DOP_MIDPOINT) {
+      f("    const double %s = %s + (%s - %s) * 0.5;", o.c_str(), vn(pts[0]).c_str(), vn(pts[1]).c_str(), vn(pts[0]).c_str());
+      return true;
+    }
+    if (type == OKX_DOP_ALONG) {  // out = base + c u, u = w / |w|, w = a - b
+      std::string w = vsub(pn(pts[1]), pn(pts[2]));
+      std::string dw = vsub(vn(pts[1]), vn(pts[2]));
+      std::string ww = dot(w, w);
+      std::string nrm = tmp("nr"), inrm = tmp("in"), u = tmp("u");
+      f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", nrm.c_str(), inrm.c_str(), ww.c_str(), nrm.c_str(), inrm.c_str());
+      f("    const double %s = %s * %s;", u.c_str(), w.c_str(), inrm.c_str());
+      std::string ud = dot(u, dw);
+      f("    const double %s = %s + a.dop_param[%d] * %s * (%s - %s * %s);", o.c_str(), vn(pts[0]).c_str(), e, inrm.c_str(),
+        dw.c_str(), u.c_str(), ud.c_str());
+      return true;
+    }
+    if (type == OKX_DOP_CONTACT_PATCH) {  // out = wc + R wu, wu = wd / |wd|, wd = -ga ax - e_z, ga = -ax_z
+      std::string v = vsub(pn(pts[2]), pn(pts[1]));
+      std::string dv = vsub(vn(pts[2]), vn(pts[1]));
+      std::string vv = dot(v, v);
+      std::string vnm = tmp("vn"), ivn = tmp("iv"), ax = tmp("ax");
+      f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", vnm.c_str(), ivn.c_str(), vv.c_str(), vnm.c_str(), ivn.c_str());
+      f("    const double %s = %s * %s;", ax.c_str(), v.c_str(), ivn.c_str());
+      std::string adv = dot(ax, dv);
+      std::string dax = tmp("da");
+      f("    const double %s = %s * (%s - %s * %s);", dax.c_str(), ivn.c_str(), dv.c_str(), ax.c_str(), adv.c_str());
+      std::string az = bcast(ax, 2), daz = bcast(dax, 2);
+      std::string wd = tmp("wd"), dwd = tmp("dw");
+      f("    const double %s = %s * %s - e2;", wd.c_str(), az.c_str(), ax.c_str());
+      f("    const double %s = %s * %s + %s * %s;", dwd.c_str(), daz.c_str(), ax.c_str(), az.c_str(), dax.c_str());
+      std::string ww = dot(wd, wd);
+      std::string wn = tmp("wn"), iwn = tmp("iw"), wu = tmp("wu");
+      f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", wn.c_str(), iwn.c_str(), ww.c_str(), wn.c_str(), iwn.c_str());
+      f("    const double %s = %s * %s;", wu.c_str(), wd.c_str(), iwn.c_str());
+      std::string wdw = dot(wu, dwd);
+      f("    const double %s = %s + a.dop_param[%d] * %s * (%s - %s * %s);", o.c_str(), vn(pts[0]).c_str(), e, iwn.c_str(),
+        dwd.c_str(), wu.c_str(), wdw.c_str());
+      return true;
+    }
+    why = "unknown derived op";
+    return false;
+  }
+
+  std::map<int, std::vector<std::pair<int, LV>>> target_j;  // target index -> (free block, d r / d block)
 
   bool fillf[kMaxFree][kMaxFree] = {};
 };
@@ -1051,6 +1118,95 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("  }");
   g.f("}");
   g.f("");
+  // ---- solution-manifold tangents (reference sensitivity.py:57-143): one kernel, B solved states ----
+  std::vector<int> out_index(NP, -1);
+  for (int k = 0; k < P.n_out; ++k) out_index[P.out_point[k]] = k;
+  bool tangent_ok = T > 0;
+  for (int F = 0; F < nf; ++F) tangent_ok = tangent_ok && out_index[P.free_point[F]] >= 0;
+  if (tangent_ok) {
+    ev.out.clear();
+    ev.uid = 200000;
+    for (int e = 0; e < P.n_derived; ++e)
+      if (P.dop_active[e] < 0 && !ev.derived_op(e, false)) {
+        *why = ev.why;
+        return false;
+      }
+    std::string rest_src = ev.out;
+    ev.out.clear();
+    ev.emit_factor();
+    std::string factor_src = ev.out;
+    g.f("typedef struct { double min_pivot, max_pivot; int flags, reserved; } okx_tangent_info;");
+    g.f("struct QTanArgs { const double* pos; const double* geom_pos; const double* geom_row_param; double* tan;");
+    g.f("  okx_tangent_info* tinfo; long long n_problems, steps_per_geometry;");
+    g.f("  const double* design_pos; const double* row_param; const double* dop_param; };");
+    g.f("template <bool PG> DEV void okx_quad_tangent_body(const QTanArgs& a) {");
+    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+    g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+    g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_problems; wu += gridDim.x) {");
+    g.f("    long long bb = wu * 16 + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");
+    g.f("    const long long geom = a.steps_per_geometry > 0 ? bb / a.steps_per_geometry : 0;");
+    g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * NP);
+    g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * P.n_crows);
+    g.out += ev.hoisted;
+    for (int p = 0; p < NP; ++p)
+      if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
+    for (int F = 0; F < nf; ++F)
+      g.f("    p%d = c < 3 ? a.pos[bb * %d + %d + cc] : 0.0;", P.free_point[F], 3 * P.n_out, 3 * out_index[P.free_point[F]]);
+    for (int t = 0; t < T; ++t) g.f("    const double tv%d = 0.0;  // target values do not enter the Jacobian", t);
+    g.out += eval_src;
+    g.out += rest_src;
+    g.f("    const double lambda = 0.0;");
+    for (int F = 0; F < nf; ++F)
+      for (int G = 0; G <= F; ++G)
+        if (ev.fillf[F][G]) {
+          for (int k = 0; k < 3; ++k) {
+            if (!(F == G && k == 2)) g.f("    double %s;", Gen::Ln(F, G, k).c_str());
+            if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
+          }
+        }
+    g.out += factor_src;
+    for (int t = 0; t < T; ++t) {
+      g.f("    {  // target %d: (J^T J) q = J^T e_t, then the velocity of every point", t);
+      std::vector<std::string> rhs(nf, "0.0");
+      auto it = ev.target_j.find(t);
+      if (it != ev.target_j.end())
+        for (auto& fv : it->second) rhs[fv.first] = Gen::sx(fv.second);
+      ev.out.clear();
+      ev.emit_substitute(rhs, "q");
+      const std::string vp = "w" + std::to_string(t) + "_";
+      std::vector<bool> have_v(NP, false);
+      for (int p = 0; p < NP; ++p) {
+        if (!used[p] || ev.dop_of_point[p] >= 0) continue;
+        if (ev.blk_of_point[p] >= 0)
+          ev.f("    const double %s%d = q%d;", vp.c_str(), p, ev.blk_of_point[p]);
+        else
+          ev.f("    const double %s%d = 0.0;", vp.c_str(), p);
+      }
+      for (int e = 0; e < P.n_derived; ++e)
+        if (!ev.derived_jvp(e, vp)) {
+          *why = ev.why;
+          return false;
+        }
+      g.out += ev.out;
+      g.f("    if (valid && c < 3) {");
+      g.f("      double* o = a.tan + (bb * %d + %d) * %d + c;", T, t, 3 * P.n_out);
+      for (int k = 0; k < P.n_out; ++k) g.f("      o[%d] = ok ? %s%d : __builtin_nan(\"\");", 3 * k, vp.c_str(), P.out_point[k]);
+      g.f("    }");
+      g.f("    }");
+    }
+    g.f("    if (valid && c == 0) {");
+    g.f("      okx_tangent_info ti; ti.min_pivot = pmin; ti.max_pivot = pmax; ti.reserved = 0;");
+    g.f("      ti.flags = (ok ? 1 : 0) | ((!ok || pmin <= %d * 2.220446049250313e-16 * pmax) ? 2 : 0);", 3 * nf);
+    g.f("      a.tinfo[bb] = ti;");
+    g.f("    }");
+    g.f("  }");
+    g.f("}");
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_tangent_u(QTanArgs a) { okx_quad_tangent_body<false>(a); }",
+        waves_per_simd);
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_tangent_g(QTanArgs a) { okx_quad_tangent_body<true>(a); }",
+        waves_per_simd);
+    g.f("");
+  }
   g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_solve_u(QArgs a) { okx_quad_body<false>(a); }",
       waves_per_simd);
   g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_solve_g(QArgs a) { okx_quad_body<true>(a); }",

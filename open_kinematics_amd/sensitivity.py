@@ -1,0 +1,169 @@
+"""
+Drop-in for ``kinematics.core.sensitivity`` (reference ``core/sensitivity.py:27-143``) and
+``kinematics.core.sweep.compute_sweep_tangents`` (``core/sweep.py:113-141``): solution-manifold
+tangents of solved sweep states, computed for the whole sweep by ONE launch of the generated
+tangent kernel (``okx_tangent_batch``; ``csrc/okx_quadgen.cpp``).
+
+Same math as the reference: with ``J`` the analytical residual Jacobian at a solved state,
+``J q_t = e_t`` in the least-squares sense for every target row ``t``; the pinned line rows of the
+device program play the role of ``_degenerate_constraint_pins`` (``sensitivity.py:146-174``) — they
+span the same plane with the same Gram matrix, so ``J^T J`` and the velocities are identical
+(``tests/test_tangents_oracle.py``).  Derived-point velocities come from closed-form forward-mode
+derivatives instead of the dual-number pass.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Sequence
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class TangentField:
+    """First-order response of every point position to one sweep target (``sensitivity.py:27-40``)."""
+
+    target_index: int
+    target: Any
+    velocities: dict
+
+    def velocity(self, point_id) -> np.ndarray:
+        velocity = self.velocities.get(point_id)
+        if velocity is None:
+            return np.zeros(3, dtype=np.float64)
+        return velocity
+
+
+@dataclass(frozen=True)
+class TangentSolveInfo:
+    """
+    Numerical health of one state's tangent solve (``sensitivity.py:43-55``).  The device factors
+    ``J^T J`` (LDL^T) instead of taking an SVD of ``J``: its pivots lie inside ``[s_min^2, s_max^2]``,
+    so ``smallest_singular_value`` is reported as ``sqrt(min_pivot)`` (never below ``s_min``) and
+    ``condition_number`` as ``sqrt(max_pivot / min_pivot)`` (never above ``cond(J)``); ``rank`` is
+    ``n_variables`` unless a pivot vanished.
+    """
+
+    n_variables: int
+    rank: int
+    smallest_singular_value: float
+    condition_number: float
+
+    @property
+    def rank_deficient(self) -> bool:
+        return self.rank < self.n_variables
+
+
+@dataclass(frozen=True)
+class SweepTangents:
+    """``core/sweep.py:68-76``."""
+
+    per_step: list
+    solve_infos: list
+
+
+def _positions_array(states, out_keys) -> np.ndarray:
+    rows = []
+    for state in states:
+        rows.append([np.asarray(getattr(state.positions[k], "data", state.positions[k]), dtype=np.float64)
+                     for k in out_keys])
+    return np.asarray(rows, dtype=np.float64).reshape(len(states), len(out_keys), 3)
+
+
+def compute_sweep_tangents(suspension, sweep_config, states, *, device=None) -> SweepTangents:
+    """
+    Tangent fields of every solved state of a sweep (``core/sweep.py:113-141``): one
+    ``TangentField`` per target and step, velocities keyed like ``state.positions``.
+    """
+    import torch
+
+    from .batch import DeviceProgram
+    from .solver import convert_targets_to_absolute
+    from .sweep import sweep_program
+    from ._abi import TANGENT_RANK_DEFICIENT
+
+    program, _ = sweep_program(suspension, sweep_config)
+    dp = DeviceProgram(program, device)
+    try:
+        out_keys = [program.point_keys[k] for k in program.out_point]
+        pos = _positions_array(states, out_keys)
+        tan, tinfo = dp.tangents(torch.as_tensor(pos, device=dp.device))
+        tan = tan.cpu().numpy()
+        info = dp.tangent_info(tinfo)
+    finally:
+        dp.close()
+    initial = suspension.initial_state()
+    per_step, infos = [], []
+    n = program.n_vars
+    for s in range(len(states)):
+        step_targets = convert_targets_to_absolute([sweep[s] for sweep in sweep_config.target_sweeps], initial)
+        fields = []
+        for t, target in enumerate(step_targets):
+            velocities = {key: tan[s, t, k].copy() for k, key in enumerate(out_keys)}
+            fields.append(TangentField(target_index=t, target=target, velocities=velocities))
+        per_step.append(fields)
+        deficient = bool(info["flags"][s] & TANGENT_RANK_DEFICIENT)
+        lo, hi = float(info["min_pivot"][s]), float(info["max_pivot"][s])
+        infos.append(TangentSolveInfo(
+            n_variables=n,
+            rank=n - 1 if deficient else n,
+            smallest_singular_value=float(np.sqrt(max(lo, 0.0))),
+            condition_number=float(np.sqrt(hi / lo)) if lo > 0.0 else float("inf"),
+        ))
+    return SweepTangents(per_step=per_step, solve_infos=infos)
+
+
+def compute_state_tangents(state, constraints, derived_manager, step_targets: Sequence[Any], *, device=None):
+    """
+    ``sensitivity.py:57-143`` for one state: ``(list[TangentField], TangentSolveInfo)``.
+    ``derived_manager`` may be the reference's ``DerivedPointsManager`` or a derived spec.
+    """
+    import torch
+
+    from .batch import DeviceProgram
+    from .program import flatten_problem
+    from ._abi import TANGENT_RANK_DEFICIENT
+
+    if not step_targets:
+        return [], TangentSolveInfo(n_variables=0, rank=0, smallest_singular_value=0.0, condition_number=1.0)
+    heads = [(t.point_id, t.direction) for t in step_targets]
+    out_keys = list(state.positions.keys())
+    program = flatten_problem(state, constraints, derived_manager, heads, out_keys,
+                              line_mode="softnorm").with_line_mode("pinned")
+    dp = DeviceProgram(program, device)
+    try:
+        keys = [program.point_keys[k] for k in program.out_point]
+        pos = _positions_array([state], keys)
+        tan, tinfo = dp.tangents(torch.as_tensor(pos, device=dp.device))
+        tan = tan.cpu().numpy()[0]
+        info = dp.tangent_info(tinfo)[0]
+    finally:
+        dp.close()
+    fields = [TangentField(target_index=t, target=target,
+                           velocities={key: tan[t, k].copy() for k, key in enumerate(keys)})
+              for t, target in enumerate(step_targets)]
+    n = program.n_vars
+    lo, hi = float(info["min_pivot"]), float(info["max_pivot"])
+    deficient = bool(info["flags"] & TANGENT_RANK_DEFICIENT)
+    return fields, TangentSolveInfo(
+        n_variables=n, rank=n - 1 if deficient else n,
+        smallest_singular_value=float(np.sqrt(max(lo, 0.0))),
+        condition_number=float(np.sqrt(hi / lo)) if lo > 0.0 else float("inf"))
+
+
+def combine_tangents(fields: Sequence[TangentField], coefficients: Sequence[float]) -> dict:
+    """Linear combination of tangent fields (``sensitivity.py:177-196``)."""
+    if len(fields) != len(coefficients):
+        raise ValueError(
+            f"Field/coefficient count mismatch: {len(fields)} fields, {len(coefficients)} coefficients."
+        )
+    combined: dict = {}
+    for field, coefficient in zip(fields, coefficients):
+        for point_id, velocity in field.velocities.items():
+            accumulated = combined.get(point_id)
+            if accumulated is None:
+                combined[point_id] = coefficient * velocity
+            else:
+                accumulated += coefficient * velocity
+    return combined

@@ -165,6 +165,73 @@ class Oracle:
             raise RuntimeError(f"okx_oracle_sweep failed: {rc}")
         return SweepResult(pos, xs, info, rc - 1)
 
+    def tangents(self, x: np.ndarray):
+        """
+        ``compute_state_tangents`` (reference ``sensitivity.py:57-143``) restated with numpy at the
+        free vector ``x``: the analytical Jacobian (C oracle), plus the two smooth pins per
+        point-on-line row (``_degenerate_constraint_pins``, ``sensitivity.py:146-174``) when the
+        program carries the reference's softnorm line rows, ``numpy.linalg.lstsq`` against one unit
+        right-hand side per target row, then the forward-mode velocity of every derived point
+        (the reference's dual-number pass, ``points/derived/definitions.py:24-180``).
+        Returns ``(vel [T, P, 3] for ALL points, rank, singular_values)``.
+        """
+        from open_kinematics_amd import program as pm
+
+        p = self.program
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        _, jac = self.eval(x[None], np.zeros((1, p.n_targets)))
+        rows = [jac[0]]
+        block_of_point = {int(pt): k for k, pt in enumerate(p.free_point)}
+        for i in range(p.n_rows):
+            if int(p.row_type[i]) != pm.ROW_POINT_ON_LINE or int(p.row_pts[i][0]) not in block_of_point:
+                continue
+            d = p.row_param[i][3:6] / np.linalg.norm(p.row_param[i][3:6])
+            least = np.zeros(3)
+            least[int(np.argmin(np.abs(d)))] = 1.0
+            n1 = np.cross(d, least)
+            n1 /= np.linalg.norm(n1)
+            n2 = np.cross(d, n1)
+            for normal in (n1, n2):
+                row = np.zeros(p.n_vars)
+                off = 3 * block_of_point[int(p.row_pts[i][0])]
+                row[off:off + 3] = normal
+                rows.append(row[None])
+        jaug = np.vstack(rows)
+        rhs = np.zeros((jaug.shape[0], p.n_targets))
+        for t in range(p.n_targets):
+            rhs[p.n_rows + t, t] = 1.0
+        q, _res, rank, sv = np.linalg.lstsq(jaug, rhs, rcond=None)
+        pos = self.positions(x)
+        vel = np.zeros((p.n_targets, p.n_points, 3))
+        for k, pt in enumerate(p.free_point):
+            vel[:, int(pt)] = q[3 * k:3 * k + 3].T
+        for e in range(p.n_derived):
+            kind, out = int(p.dop_type[e]), int(p.dop_out[e])
+            a, b, c3 = (int(v) for v in p.dop_pts[e][:3])
+            par = float(p.dop_param[e])
+            for t in range(p.n_targets):
+                v = vel[t]
+                if kind == pm.DOP_MIDPOINT:  # definitions.py:76-89
+                    v[out] = v[a] + (v[b] - v[a]) / 2.0
+                elif kind == pm.DOP_ALONG:  # definitions.py:24-33: base + normalize(p_b - p_c) * par
+                    w, dw = pos[b] - pos[c3], v[b] - v[c3]
+                    n = np.linalg.norm(w)
+                    u = w / n
+                    v[out] = v[a] + par * (dw - u * (u @ dw)) / n
+                else:  # contact patch, definitions.py:36-73: wc + normalize(-Z - ((-Z).ax) ax) * R
+                    w, dw = pos[c3] - pos[b], v[c3] - v[b]
+                    n = np.linalg.norm(w)
+                    ax = w / n
+                    dax = (dw - ax * (ax @ dw)) / n
+                    down = np.array([0.0, 0.0, -1.0])
+                    ga, dga = down @ ax, down @ dax
+                    wd = down - ga * ax
+                    dwd = -dga * ax - ga * dax
+                    wn = np.linalg.norm(wd)
+                    wu = wd / wn
+                    v[out] = v[a] + par * (dwd - wu * (wu @ dwd)) / wn
+        return vel, int(rank), sv
+
     def rebind(self, hardpoints: np.ndarray):
         p = self.program
         hp = np.ascontiguousarray(hardpoints, dtype=np.float64).reshape(p.n_points, 3)
