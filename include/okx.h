@@ -149,7 +149,12 @@ typedef struct okx_solve_opts {
                              wavefront, 2 generic lane-group packed (several small problems per
                              wavefront; falls back to 1 when a problem needs more than 32
                              lanes), 3 quad kernel (OKX_ERR_INVALID when the program has none) */
-  int32_t reserved;
+  int32_t reserved;       /* quad kernel only.  0 (default): a step predicted to land within
+                             step_tol of the solution (damping contraction lambda / min pivot and
+                             the observed quadratic contraction, both with a 100x margin) is
+                             applied and confirmed by a residual-only evaluation (cost must not
+                             rise) instead of a full Jacobian / factorisation pass.
+                             non-zero: always end on a computed correction <= step_tol.        */
 } okx_solve_opts;
 
 /* Per-problem result, the device analogue of SolverInfo (solver.py:83-96). */

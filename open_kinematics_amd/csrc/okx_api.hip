@@ -436,7 +436,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     q.steps_per_geometry = a.steps_per_geometry;
     q.chain_len = a.chain_len;
     q.max_iter = a.max_iter;
-    q.pad = 0;
+    q.confirm = opts->reserved != 0 || getenv("OKX_QUAD_CONFIRM") != nullptr;
     q.step_tol = a.step_tol;
     q.grad_tol = a.grad_tol;
     q.ftol = a.ftol;

@@ -18,7 +18,7 @@ struct QuadArgs {
   double* out_pos;
   okx_info* info;
   long long n_problems, steps_per_geometry, chain_len;
-  int max_iter, pad;
+  int max_iter, confirm;
   double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
   const double* design_pos;
   const double* row_param;

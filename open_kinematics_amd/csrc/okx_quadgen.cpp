@@ -544,6 +544,19 @@ class Gen {
   }
 
   // Rows + normal equations: r_i, cost, max |r|, J^T J blocks A{F}_{G}_{k}, gradient gn{F}.
+  // Residuals only (cost and max |r|): the confirming evaluation of a step that is predicted to
+  // land within tolerance.  Row code is shared with emit_rows; the unused partials fold away.
+  bool emit_rows_residual_only() {
+    f("    double ss = 0.0, mres_new = 0.0;");
+    for (int i = 0; i < P.m; ++i) {
+      RowOut ro;
+      if (!row(i, &ro)) return false;
+      f("    ss = fma(%s, %s, ss);", ro.r.c_str(), ro.r.c_str());
+      if (!ro.absres.empty()) f("    mres_new = fmax(mres_new, %s);", ro.absres.c_str());
+    }
+    return true;
+  }
+
   bool emit_rows() {
     const int nf = P.n_free;
     for (int F = 0; F < nf; ++F) {
@@ -783,7 +796,7 @@ struct QArgs {
   const double* targets; const double* geom_pos; const double* geom_row_param;
   double* out_pos; okx_info* info;
   long long n_problems, steps_per_geometry, chain_len;
-  int max_iter, pad;
+  int max_iter, confirm;   // confirm != 0: never end on the predicted-convergence test (always a full pass)
   double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
   const double* design_pos; const double* row_param; const double* dop_param;
   double* trace; long long trace_problem;   // diagnostic: 8 doubles per LM pass of one problem (null: off)
@@ -895,6 +908,23 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   ev.emit_solve();
   std::string solve_src = ev.out;
 
+  // confirming evaluation (residuals only).  Not offered for programs with the reference's
+  // zero-gradient point-on-line row: along that row's valley the step length says nothing about
+  // the distance to the minimiser, so those always take full passes.
+  bool light_ok = true;
+  for (int i = 0; i < P.n_crows; ++i) light_ok = light_ok && P.row_type[i] != OKX_ROW_POINT_ON_LINE;
+  std::string light_src;
+  if (light_ok) {
+    Gen lt(P);
+    lt.uid = 300000;
+    lt.hoisted_names = ev.hoisted_names;  // same chain-constant loads, already emitted
+    for (int idx = 0; idx < P.n_active; ++idx)
+      if (!lt.derived_op(P.active_op[idx], false)) light_ok = false;
+    if (light_ok && !lt.emit_rows_residual_only()) light_ok = false;
+    if (!lt.hoisted.empty()) light_ok = false;  // would need loads the main body did not hoist
+    light_src = lt.out;
+  }
+
   // which points must live in registers
   std::vector<bool> used(NP, false);
   for (int k = 0; k < P.n_out; ++k) used[P.out_point[k]] = true;
@@ -935,6 +965,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
     if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
   for (int F = 0; F < nf; ++F) g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0;", F, P.free_point[F], F, F, F);
   g.f("    int hist = 0;");
+  g.f("    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)");
   g.f("    for (long long b = first_b; wave_any(have && b < last_b); ++b) {");
   g.f("      const bool valid = have && b < last_b;");
   g.f("      const long long bb = valid ? b : last_b - 1;");
@@ -957,9 +988,32 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("      double Fc = 0.0, lambda = 0.0, nu = 2.0, dmax = 0.0, step_len = 0.0, last_step = 0.0, mres = 0.0, pred = 0.0;");
   g.f("      int nfev = 0, iters = 0, flags = 0, nfail = 0;");
   g.f("      int mode = 0;  // 0 first evaluation, 1 trial point, 2 re-evaluation of the accepted point");
-  g.f("      bool done = !valid;");
+  g.f("      bool done = !valid, want_light = false;");
+  g.f("      double prev_sl = 0.0;");
   for (int F = 0; F < nf; ++F) g.f("      dx%d = 0.0;", F);
   g.f("      while (wave_any(!done)) {");
+  if (light_ok) {
+    // Confirming pass: every active problem of this wavefront has a step in hand that is
+    // predicted to land within step_tol of its solution.  Apply it, evaluate the residuals only
+    // (no Jacobian, no factorisation) and finish if the cost did not rise; otherwise the same
+    // point goes through a full pass next.
+    g.f("    if (a.confirm == 0 && !wave_any(!done && !want_light)) {");
+    for (int F = 0; F < nf; ++F) g.f("      p%d = x%d + dx%d;", P.free_point[F], F, F);
+    g.out += light_src;
+    g.f("      const double Fl = 0.5 * ss;");
+    g.f("      if (!done) {");
+    g.f("        ++nfev;");
+    g.f("        if (Fl == Fl && Fl <= Fc * (1.0 + 1e-6) + 1e-28) {");
+    for (int F = 0; F < nf; ++F) g.f("          x%d = p%d;", F, P.free_point[F]);
+    g.f("          Fc = Fl; mres = mres_new; last_step = step_len; flags |= INFO_CONVERGED; done = true;");
+    g.f("        } else {");
+    g.f("          want_light = false;");
+    g.f("        }");
+    g.f("      }");
+    g.f("      continue;");
+    g.f("    }");
+    g.f("    want_light = false;  // mixed wavefront: everybody takes the full pass");
+  }
   // evaluation point
   for (int F = 0; F < nf; ++F) g.f("    p%d = mode == 2 ? x%d : x%d + dx%d;", P.free_point[F], F, F, F);
   g.out += eval_src;
@@ -997,8 +1051,18 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("        }");
   g.f("        Fc = Ft; mres = mres_new;");
   g.f("        if (!stop) {");
-  g.f("          if (mode == 0) { dmax = diag; lambda = a.lambda0 * dmax; }");
-  g.f("          else if (mode == 1 && rho > 1e-4) { const double t = 2.0 * rho - 1.0; lambda *= fmax(1.0 / 3.0, 1.0 - t * t * t); }");
+  g.f("          if (mode == 0) {");
+  g.f("            // a warm-started chain step continues with the damping its predecessor ended with");
+  g.f("            dmax = diag; lambda = a.lambda0 * dmax;");
+  g.f("            if (lambda_carry > 0.0) lambda = fmin(lambda, lambda_carry);");
+  g.f("          }");
+  g.f("          else if (mode == 1 && rho > 1e-4) {");
+  g.f("            // Nielsen's update; a step whose gain ratio shows the quadratic model to be accurate");
+  g.f("            // (rho > 0.9) drops the damping by 10 (Marquardt) so that the final steps are");
+  g.f("            // Gauss-Newton steps without a linear contraction floor, like MINPACK's par = 0");
+  g.f("            const double t = 2.0 * rho - 1.0;");
+  g.f("            lambda *= rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t);");
+  g.f("          }");
   g.f("          if (a.grad_tol > 0.0 && gm <= a.grad_tol) { flags |= INFO_CONVERGED; stop = true; }");
   g.f("        }");
   g.f("      } else if (!stop) {");
@@ -1035,6 +1099,16 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   for (int F = 0; F < nf; ++F) g.f("        dx%d = nx%d;", F, F);
   g.f("        step_len = sl; pred = pr;");
   g.f("        if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
+  g.f("        else {");
+  g.f("          // Next correction predicted as rho |dx| + C |dx|^2: the damping's linear contraction");
+  g.f("          // rho = lambda / sigma_min(J^T J), bounded with the smallest pivot (x 100), plus the");
+  g.f("          // Gauss-Newton curvature term with C = 100 x the observed |dx| / |dx-|^2, or 1 / mm on a");
+  g.f("          // problem's first step (two orders above a linkage's curvature / stiffness ratio).");
+  g.f("          const double cq = prev_sl > 0.0 ? fmax(100.0 * sl / (prev_sl * prev_sl), 1e-3) : 1.0;");
+  g.f("          const double rho_lin = 100.0 * lambda / pmin;");
+  g.f("          want_light = sl <= 1e-3 && (rho_lin + cq * sl) * sl <= a.step_tol;");
+  g.f("          prev_sl = sl;");
+  g.f("        }");
   g.f("        mode = 1;");
   g.f("      } else {");
   g.f("        lambda = fmax(lambda * 10.0, 1e-12 * dmax);");
@@ -1068,8 +1142,11 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   // chains never continue from a state that failed to converge
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
   for (int F = 0; F < nf; ++F) g.f("      x%d = c < 3 ? gp[%d + cc] : 0.0;", F, 3 * P.free_point[F]);
-  g.f("      hist = 0;");
-  g.f("    } else if (hist < 2) ++hist;");
+  g.f("      hist = 0; lambda_carry = 0.0;");
+  g.f("    } else {");
+  g.f("      if (hist < 2) ++hist;");
+  g.f("      lambda_carry = lambda;");
+  g.f("    }");
   g.f("      }");
   g.f("    }  // chain steps");
   g.f("  }  // wave units");
