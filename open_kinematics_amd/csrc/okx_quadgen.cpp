@@ -228,12 +228,12 @@ class Gen {
       f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", nrm.c_str(), inrm.c_str(), s2.c_str(), nrm.c_str(),
         inrm.c_str());
       f("    const double %s = %s * %s;", u.c_str(), v.c_str(), inrm.c_str());
-      f("    %s = %s + %s * a.dop_param[%d];", o.c_str(), pn(pts[0]).c_str(), u.c_str(), e);
+      f("    %s = %s + %s * %s;", o.c_str(), pn(pts[0]).c_str(), u.c_str(), dp(e).c_str());
       if (with_blocks) {
         std::map<int, std::vector<BlkTerm>> acc;
         for (auto& kv : blocks_of_point(pts[0])) acc[kv.first].push_back({kv.second, 1});
         std::string k = tmp("k");
-        f("    const double %s = a.dop_param[%d] * %s;", k.c_str(), e, inrm.c_str());
+        f("    const double %s = %s * %s;", k.c_str(), dp(e).c_str(), inrm.c_str());
         std::string ub[3];
         bool have_ub = false;
         for (int s = 1; s <= 2; ++s) {
@@ -290,7 +290,7 @@ class Gen {
       std::string wn = tmp("wn"), iwn = tmp("iw");
       f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", wn.c_str(), iwn.c_str(), ww.c_str(), wn.c_str(),
         iwn.c_str());
-      f("    %s = %s + (%s * %s) * a.dop_param[%d];", o.c_str(), pn(pts[0]).c_str(), wd.c_str(), iwn.c_str(), e);
+      f("    %s = %s + (%s * %s) * %s;", o.c_str(), pn(pts[0]).c_str(), wd.c_str(), iwn.c_str(), dp(e).c_str());
       return true;
     }
     why = "unknown derived op";
@@ -304,13 +304,37 @@ class Gen {
     std::string absres;                       // |r| in the reference's row definition ("" = skip)
   };
 
+  // Derived-op parameter (axial offset, tyre radius ...): program constant, loaded once.
+  std::string dp(int e) {
+    auto key = std::make_pair(-1 - e, 0);
+    auto it = hoisted_names.find(key);
+    if (it != hoisted_names.end()) return it->second;
+    char name[48], line[160];
+    std::snprintf(name, sizeof(name), "hd%d", e);
+    std::snprintf(line, sizeof(line), "      const double %s = a.dop_param[%d];\n", name, e);
+    hoisted += line;
+    hoisted_names[key] = name;
+    return name;
+  }
+
+  // Scalar row parameter (length, angle, volume ...): constant for a whole chain, so it is loaded
+  // once in front of the LM loop like the lane-component parameters below.  (Left inside the loop
+  // these loads are vector loads - the kernel also stores to global memory, so the compiler may not
+  // use the scalar cache - and a lone wavefront per SIMD exposes their L2 latency every pass.)
   std::string rp(int i, int k) {
-    char b[64];
+    i = pin_leader(i);
+    auto key = std::make_pair(i, 100 + k);
+    auto it = hoisted_names.find(key);
+    if (it != hoisted_names.end()) return it->second;
+    char name[48], line[160];
+    std::snprintf(name, sizeof(name), "hs%d_%d", i, k);
     if (i < P.n_crows)
-      std::snprintf(b, sizeof(b), "gq[%d]", i * 8 + k);
+      std::snprintf(line, sizeof(line), "      const double %s = gq[%d];\n", name, i * 8 + k);
     else
-      std::snprintf(b, sizeof(b), "a.row_param[%d]", i * 8 + k);
-    return b;
+      std::snprintf(line, sizeof(line), "      const double %s = a.row_param[%d];\n", name, i * 8 + k);
+    hoisted += line;
+    hoisted_names[key] = name;
+    return name;
   }
   // Lane-component load of three consecutive row parameters (0 in lane 3).  These are constant
   // for a whole chain (geometry), so they are emitted into `hoisted`, which the kernel places
@@ -753,7 +777,7 @@ class Gen {
       f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", nrm.c_str(), inrm.c_str(), ww.c_str(), nrm.c_str(), inrm.c_str());
       f("    const double %s = %s * %s;", u.c_str(), w.c_str(), inrm.c_str());
       std::string ud = dot(u, dw);
-      f("    const double %s = %s + a.dop_param[%d] * %s * (%s - %s * %s);", o.c_str(), vn(pts[0]).c_str(), e, inrm.c_str(),
+      f("    const double %s = %s + %s * %s * (%s - %s * %s);", o.c_str(), vn(pts[0]).c_str(), dp(e).c_str(), inrm.c_str(),
         dw.c_str(), u.c_str(), ud.c_str());
       return true;
     }
@@ -776,7 +800,7 @@ class Gen {
       f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", wn.c_str(), iwn.c_str(), ww.c_str(), wn.c_str(), iwn.c_str());
       f("    const double %s = %s * %s;", wu.c_str(), wd.c_str(), iwn.c_str());
       std::string wdw = dot(wu, dwd);
-      f("    const double %s = %s + a.dop_param[%d] * %s * (%s - %s * %s);", o.c_str(), vn(pts[0]).c_str(), e, iwn.c_str(),
+      f("    const double %s = %s + %s * %s * (%s - %s * %s);", o.c_str(), vn(pts[0]).c_str(), dp(e).c_str(), iwn.c_str(),
         dwd.c_str(), wu.c_str(), wdw.c_str());
       return true;
     }
@@ -893,6 +917,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
 
   // ---- evaluation body (rows + normal equations), generated first to learn the sparsity ----
   Gen ev(P);
+  for (int e = 0; e < P.n_derived; ++e) ev.dp(e);  // every derived-op parameter is chain-constant
   ev.f("    // ---- active derived points with chain-rule blocks ----");
   for (int idx = 0; idx < P.n_active; ++idx)
     if (!ev.derived_op(P.active_op[idx], true)) {
@@ -966,18 +991,21 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   for (int F = 0; F < nf; ++F) g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0;", F, P.free_point[F], F, F, F);
   g.f("    int hist = 0;");
   g.f("    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)");
+  // targets: the next step's values are fetched while the current step is being solved, and the two
+  // previous steps' values (secant predictor) stay in registers
+  for (int t = 0; t < T; ++t)
+    g.f("    double tn%d = a.targets[first_b * %d + %d], tp%d = 0.0, tq%d = 0.0;", t, T, t, t, t);
   g.f("    for (long long b = first_b; wave_any(have && b < last_b); ++b) {");
   g.f("      const bool valid = have && b < last_b;");
   g.f("      const long long bb = valid ? b : last_b - 1;");
-  g.f("      const long long step = bb - first_b;");
-  for (int t = 0; t < T; ++t) g.f("      const double tv%d = a.targets[bb * %d + %d];", t, T, t);
+  g.f("      const long long nb = b + 1 < last_b ? b + 1 : last_b - 1;");
+  for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
+  for (int t = 0; t < T; ++t) g.f("      tn%d = a.targets[nb * %d + %d];", t, T, t);
   // secant predictor: x + alpha (x - xp), alpha from the target increments
   g.f("      if (hist >= 2) {");
   g.f("        double num = 0.0, den = 0.0;");
-  for (int t = 0; t < T; ++t) {
-    g.f("        { const double t1 = a.targets[(bb - 1) * %d + %d], t2 = a.targets[(bb - 2) * %d + %d];", T, t, T, t);
-    g.f("          num = fma(tv%d - t1, t1 - t2, num); den = fma(t1 - t2, t1 - t2, den); }", t);
-  }
+  for (int t = 0; t < T; ++t)
+    g.f("        num = fma(tv%d - tp%d, tp%d - tq%d, num); den = fma(tp%d - tq%d, tp%d - tq%d, den);", t, t, t, t, t, t, t, t);
   g.f("        double alpha = den > 0.0 ? num / den : 0.0;");
   g.f("        alpha = fmin(fmax(alpha, 0.0), 2.0);");
   for (int F = 0; F < nf; ++F)
@@ -1123,6 +1151,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   for (int F = 0; F < nf; ++F) g.f("    p%d = x%d;", P.free_point[F], F);
   Gen fin(P);
   fin.uid = 100000;
+  fin.hoisted_names = ev.hoisted_names;
   for (int e = 0; e < P.n_derived; ++e)
     if (!fin.derived_op(e, false)) {
       *why = fin.why;
@@ -1140,6 +1169,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("      a.info[bb] = inf;");
   g.f("    }");
   // chains never continue from a state that failed to converge
+  for (int t = 0; t < T; ++t) g.f("    tq%d = tp%d; tp%d = tv%d;", t, t, t, t);
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
   for (int F = 0; F < nf; ++F) g.f("      x%d = c < 3 ? gp[%d + cc] : 0.0;", F, 3 * P.free_point[F]);
   g.f("      hist = 0; lambda_carry = 0.0;");
