@@ -258,8 +258,9 @@ typedef struct okx_tangent_info {
  * free-point velocities to every derived point in forward mode.  d_pos [B][n_out][3] are
  * solved positions as written by okx_solve_batch (every free point must be an output
  * point); d_tangents [B][T][n_out][3] receives d(point)/d(target t); fixed points get 0.
- * Geometry tables as in okx_solve_batch.  Needs the program's quad kernel
- * (OKX_ERR_INVALID otherwise).
+ * Geometry tables as in okx_solve_batch.  Programs with a quad kernel use its generated
+ * tangent kernel (16 states per wavefront); all others the generic interpreter form (one
+ * wavefront per state).
  */
 int32_t okx_tangent_batch(okx_program* prog, int64_t n_problems, int64_t steps_per_geometry,
                           const double* d_pos,            /* [B][n_out][3] */

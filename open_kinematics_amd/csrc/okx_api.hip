@@ -24,6 +24,7 @@ struct okx_program {
   int blocks_per_cu;
   int nreg;                // padded row length of the register-resident factorisation
   const void* solve_fn;    // okx_solve_kernel<NREG> (one problem per wavefront)
+  const void* tangent_fn;  // okx_tangent_kernel<NREG> (generic tangents)
   int groups;              // problems per wavefront of the packed kernel (1 = not available)
   int group_width;         // lanes per problem in the packed kernel
   const void* packed_fn;   // okx_solve_packed_kernel<NREG, G> or null
@@ -70,24 +71,31 @@ void select_solve_kernels(okx_program* p) {
   solve_kernel_t fn;
   if (n <= 15) {
     fn = okx::okx_solve_kernel<15, false>;
+    p->tangent_fn = (const void*)okx::okx_tangent_kernel<15>;
     p->nreg = 15;
   } else if (n <= 18) {
     fn = okx::okx_solve_kernel<18, false>;
+    p->tangent_fn = (const void*)okx::okx_tangent_kernel<18>;
     p->nreg = 18;
   } else if (n <= 21) {
     fn = okx::okx_solve_kernel<21, false>;
+    p->tangent_fn = (const void*)okx::okx_tangent_kernel<21>;
     p->nreg = 21;
   } else if (n <= 24) {
     fn = okx::okx_solve_kernel<24, false>;
+    p->tangent_fn = (const void*)okx::okx_tangent_kernel<24>;
     p->nreg = 24;
   } else if (n <= 36) {
     fn = okx::okx_solve_kernel<36, false>;
+    p->tangent_fn = (const void*)okx::okx_tangent_kernel<36>;
     p->nreg = 36;
   } else if (n <= 48) {
     fn = okx::okx_solve_kernel<48, false>;
+    p->tangent_fn = (const void*)okx::okx_tangent_kernel<48>;
     p->nreg = 48;
   } else {
     fn = okx::okx_solve_kernel<63, false>;
+    p->tangent_fn = (const void*)okx::okx_tangent_kernel<63>;
     p->nreg = 63;
   }
   p->solve_fn = (const void*)fn;
@@ -534,15 +542,40 @@ int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_
   if (!p) return fail(OKX_ERR_INVALID, "null program");
   if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
   if (n_problems == 0) return OKX_OK;
-  if (!p->quad_fn_tan_u)
-    return fail(OKX_ERR_INVALID, "tangents need the program's quad kernel%s%s", p->quad_note[0] ? ": " : "",
-                p->quad_note[0] ? p->quad_note : " (and every free point among the output points, and a target)");
   if (!d_pos || !d_tangents || !d_tinfo) return fail(OKX_ERR_INVALID, "null pointer");
   if ((d_geom_pos == nullptr) != (d_geom_row_param == nullptr))
     return fail(OKX_ERR_INVALID, "geometry positions and row parameters must be given together");
   if (steps_per_geometry < 0 || (d_geom_pos && steps_per_geometry == 0) ||
       (steps_per_geometry > 0 && n_problems % steps_per_geometry != 0))
     return fail(OKX_ERR_INVALID, "bad steps_per_geometry");
+  if (p->host.n_targets == 0) return OKX_OK;
+  if (!p->quad_fn_tan_u || getenv("OKX_TANGENT_GENERIC")) {
+    // generic interpreter form: one wavefront per state (programs without a quad kernel)
+    okx::TangentArgs t;
+    t.pos = d_pos;
+    t.geom_pos = d_geom_pos;
+    t.geom_row_param = d_geom_row_param;
+    t.tan = d_tangents;
+    t.tinfo = d_tinfo;
+    t.n_problems = n_problems;
+    t.steps_per_geometry = steps_per_geometry;
+    for (int k = 0; k < p->host.n_free; ++k) {
+      t.free_out[k] = -1;
+      for (int o = 0; o < p->host.n_out; ++o)
+        if (p->host.out_point[o] == p->host.free_point[k]) t.free_out[k] = o;
+      if (t.free_out[k] < 0)
+        return fail(OKX_ERR_INVALID, "tangents need every free point among the output points (point %d is not)",
+                    p->host.free_point[k]);
+    }
+    const size_t lds = p->lds_bytes + sizeof(double) * 3 * (size_t)p->host.n_points;
+    if (lds > 160 * 1024) return fail(OKX_ERR_LIMIT, "tangent kernel needs %zu bytes of LDS", lds);
+    (void)hipFuncSetAttribute(p->tangent_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const okx::DevProgram* dev = p->dev;
+    void* kargs[] = {(void*)&dev, (void*)&t};
+    HIP_TRY(hipLaunchKernel(p->tangent_fn, dim3(grid_for(p, n_problems)), dim3(okx::kWave), kargs, lds,
+                            (hipStream_t)stream));
+    return OKX_OK;
+  }
   okx::QuadTanArgs q;
   q.pos = d_pos;
   q.geom_pos = d_geom_pos;

@@ -756,7 +756,8 @@ __device__ __forceinline__ double build_normal(const DevProgram* P, const Lds& S
 // hoists later columns' broadcasts until the scalar file spills (v_writelane) inside the loop.
 template <int N>
 __device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S, int lane,
-                                               double lambda, double g, double* dx) {
+                                               double lambda, double g, double* dx,
+                                               double* pivot_min = nullptr, double* pivot_max = nullptr) {
   const int n = P->n;
   double a[N];
   const bool live = lane < n;
@@ -776,6 +777,10 @@ __device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S
     if (!(pivot > 0.0)) {
       ok = false;
       break;
+    }
+    if (pivot_min && k < n) {  // tangent solve only: conditioning record
+      *pivot_min = fmin(*pivot_min, pivot);
+      *pivot_max = fmax(*pivot_max, pivot);
     }
     const double rinv = fast_rcp(pivot);
     const double lk = a[k] * rinv;  // L[lane][k] for lanes > k
@@ -1118,6 +1123,126 @@ __global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __res
           M[e] = i == j ? S.dA[i] : (i < j ? S.A[tri(j, i)] : S.A[tri(i, j)]);
         }
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// solution-manifold tangents (reference sensitivity.py:57-143), generic interpreter form
+// ------------------------------------------------------------------------------------
+
+struct TangentArgs {
+  const double* pos;             // [B][n_out][3] solved positions (okx_solve_batch output)
+  const double* geom_pos;        // [G][P][3] or null
+  const double* geom_row_param;  // [G][Mc][8] or null
+  double* tan;                   // [B][T][n_out][3]
+  okx_tangent_info* tinfo;       // [B]
+  long long n_problems;
+  long long steps_per_geometry;
+  int free_out[kMaxFree];        // index of every free point inside the output point list
+};
+
+// Velocity of one derived point from the velocities of its inputs (forward mode, closed form;
+// the reference propagates dual numbers: sensitivity.py:127-131).  Uniform over lanes.
+__device__ __forceinline__ V3 dop_velocity(int type, const int* pts, double c, const double* pos,
+                                           const double* vel) {
+  if (type == OKX_DOP_MIDPOINT) {
+    V3 a = ld3(vel + 3 * pts[0]), b = ld3(vel + 3 * pts[1]);
+    return {a.x + (b.x - a.x) / 2, a.y + (b.y - a.y) / 2, a.z + (b.z - a.z) / 2};
+  }
+  if (type == OKX_DOP_ALONG) {  // out = base + c u,  u = w / |w|,  w = p1 - p2
+    V3 vb = ld3(vel + 3 * pts[0]);
+    V3 w = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[2]));
+    V3 dw = sub(ld3(vel + 3 * pts[1]), ld3(vel + 3 * pts[2]));
+    double nrm, inrm;
+    fast_sqrt_rsqrt(dot(w, w), &nrm, &inrm);
+    V3 u = {w.x * inrm, w.y * inrm, w.z * inrm};
+    const double ud = dot(u, dw), k = c * inrm;
+    return {vb.x + k * (dw.x - u.x * ud), vb.y + k * (dw.y - u.y * ud), vb.z + k * (dw.z - u.z * ud)};
+  }
+  // contact patch: out = wc + R wu, wu = wd / |wd|, wd = a_z a - e_z, a = (axo - axi) / |axo - axi|
+  V3 vw = ld3(vel + 3 * pts[0]);
+  V3 v = sub(ld3(pos + 3 * pts[2]), ld3(pos + 3 * pts[1]));
+  V3 dv = sub(ld3(vel + 3 * pts[2]), ld3(vel + 3 * pts[1]));
+  double vn, ivn;
+  fast_sqrt_rsqrt(dot(v, v), &vn, &ivn);
+  V3 a = {v.x * ivn, v.y * ivn, v.z * ivn};
+  const double adv = dot(a, dv);
+  V3 da = {ivn * (dv.x - a.x * adv), ivn * (dv.y - a.y * adv), ivn * (dv.z - a.z * adv)};
+  V3 wd = {a.z * a.x, a.z * a.y, a.z * a.z - 1.0};
+  V3 dwd = {da.z * a.x + a.z * da.x, da.z * a.y + a.z * da.y, da.z * a.z + a.z * da.z};
+  double wn, iwn;
+  fast_sqrt_rsqrt(dot(wd, wd), &wn, &iwn);
+  V3 wu = {wd.x * iwn, wd.y * iwn, wd.z * iwn};
+  const double wdw = dot(wu, dwd), k = c * iwn;
+  return {vw.x + k * (dwd.x - wu.x * wdw), vw.y + k * (dwd.y - wu.y * wdw), vw.z + k * (dwd.z - wu.z * wdw)};
+}
+
+// One wavefront per solved state: rows + J^T J at the state, undamped LDL^T, one solve per target
+// with right-hand side J^T e_t (the target row's own Jacobian entries), derived-point velocities.
+// Dynamic LDS = the solve kernel's slice + a [P][3] velocity table.
+template <int NREG>
+__global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG <= 48 ? 2 : 1))
+okx_tangent_kernel(const DevProgram* __restrict__ P, TangentArgs args) {
+  extern __shared__ double lds_base[];
+  const int lane = threadIdx.x;
+  const Lds S = carve(lds_base, P);
+  double* vel = lds_base + P->lds_doubles;
+  const int n = P->n, T = P->n_targets;
+  const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
+  stage_program(P, S, lane);
+  init_slice(P, S, lane, kWave);
+  long long loaded_geom = -1;
+  for (long long b = blockIdx.x; b < args.n_problems; b += gridDim.x) {
+    const long long geom = args.steps_per_geometry > 0 ? b / args.steps_per_geometry : 0;
+    if (geom != loaded_geom) {
+      load_geometry(P, S, lane, kWave, args.geom_pos ? args.geom_pos + geom * 3 * P->n_points : nullptr,
+                    args.geom_row_param ? args.geom_row_param + geom * 8 * P->n_crows : nullptr);
+      loaded_geom = geom;
+    }
+    wave_sync();
+    if (lane < T) S.tv[lane] = 0.0;  // target values do not enter the Jacobian
+    const double x = lane < n ? args.pos[(b * P->n_out + args.free_out[lane / 3]) * 3 + lane % 3] : 0.0;
+    evaluate<true>(P, S, lane, x, xaddr, 0);
+    derived_update<false>(P, S, lane, kWave, false);  // every derived point (inputs of the velocity pass)
+    double pmin = 1e300, pmax = 0.0;
+    bool all_ok = true;
+    for (int t = 0; t < T; ++t) {
+      build_normal(P, S, lane, kWave, 0, lane < n);  // the previous factorisation overwrote J^T J
+      // (J^T e_t)_j = J[target row t][j]
+      const int row = P->n_crows + t;
+      double rhs = 0.0;
+      if (lane < n) {
+        const int blk = lane / 3;
+        for (int s = 0; s < P->row_nblk[row]; ++s)
+          if (P->row_blk[row][s] == blk) rhs = S.js[(size_t)row * P->js_stride + 3 * s + lane % 3];
+      }
+      double q = 0.0;
+      const bool ok = ldlt_solve_reg<NREG>(P, S, lane, 0.0, -rhs, &q, &pmin, &pmax);
+      all_ok = all_ok && ok;
+      wave_sync();
+      for (int e = lane; e < 3 * P->n_points; e += kWave) vel[e] = 0.0;
+      wave_sync();
+      if (lane < n) vel[xaddr] = q;
+      wave_sync();
+      for (int e = 0; e < P->n_derived; ++e) {
+        V3 v = dop_velocity(P->dop_type[e], P->dop_pts[e], P->dop_param[e], S.pos, vel);
+        wave_sync();
+        if (lane < 3) vel[3 * P->dop_out[e] + lane] = sel3(lane, v.x, v.y, v.z);
+        wave_sync();
+      }
+      double* out = args.tan + ((b * T + t) * P->n_out) * 3;
+      for (int e = lane; e < 3 * P->n_out; e += kWave)
+        out[e] = ok ? vel[3 * P->out_point[e / 3] + e % 3] : __builtin_nan("");
+    }
+    if (lane == 0) {
+      okx_tangent_info ti;
+      ti.min_pivot = pmin;
+      ti.max_pivot = pmax;
+      ti.flags = (all_ok ? OKX_TANGENT_OK : 0) |
+                 ((!all_ok || pmin <= n * 2.220446049250313e-16 * pmax) ? OKX_TANGENT_RANK_DEFICIENT : 0);
+      ti.reserved = 0;
+      args.tinfo[b] = ti;
     }
   }
 }

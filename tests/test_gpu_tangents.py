@@ -105,13 +105,32 @@ def test_ensemble_tangents_use_per_geometry_tables(golden):
     assert float((wrong - tan).abs().max()) > 1e-6
 
 
-def test_tangents_need_the_quad_kernel(golden):
+def test_axle_tangents_from_the_generic_kernel_match_the_reference(golden):
+    """Programs without a quad kernel (rocker axle, n = 60, T = 3): one wavefront per state."""
     from open_kinematics_amd.batch import DeviceProgram
 
     _, program = golden("c3_axle_grid")
+    tg = _tg("c3_axle_grid")
     dp = DeviceProgram(program.with_line_mode("pinned"), "cuda:0")
-    with pytest.raises(ValueError, match="tangents need the program's quad kernel"):
-        dp.tangents(np.zeros((1, program.n_out, 3)))
+    assert dp.kernel == "wave"
+    tan, tinfo = dp.tangents(tg["pos"])
+    torch.cuda.synchronize()
+    info = dp.tangent_info(tinfo)
+    assert np.all(info["flags"] == 1) and np.all(info["min_pivot"] > 0)
+    assert np.max(np.abs(tan.cpu().numpy() - tg["vel"])) <= 1e-9
+
+
+def test_generic_and_generated_tangent_kernels_agree(golden, monkeypatch):
+    arrays, program = golden("c4_macpherson_grid")
+    dp = _dp(program.with_line_mode("pinned"))
+    tg = _tg("c4_macpherson_grid")
+    quad, _ = dp.tangents(tg["pos"])
+    monkeypatch.setenv("OKX_TANGENT_GENERIC", "1")
+    wave, tinfo = dp.tangents(tg["pos"])
+    torch.cuda.synchronize()
+    assert np.all(dp.tangent_info(tinfo)["flags"] == 1)
+    assert float((quad - wave).abs().max()) <= 1e-11
+    assert np.max(np.abs(wave.cpu().numpy() - tg["vel"])) <= 1e-9
 
 
 def test_sensitivity_dropin_mirrors_the_reference_module(golden):
