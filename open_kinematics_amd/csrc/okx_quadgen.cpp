@@ -971,16 +971,21 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("  const long long spg = a.steps_per_geometry;");
   g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
   g.f("  const long long unit_len = a.chain_len;");
-  g.f("  const long long chains_per_span = (span + unit_len - 1) / unit_len;");
-  g.f("  const long long n_units = (a.n_problems / span) * chains_per_span;");
+  g.f("  const long long chains_per_span = unit_len == 1 ? span : (span + unit_len - 1) / unit_len;");
+  g.f("  const long long n_units = spg > 0 ? (a.n_problems / span) * chains_per_span : chains_per_span;");
   g.f("  for (long long wu = blockIdx.x; wu * 16 < n_units; wu += gridDim.x) {");
   g.f("    long long unit = wu * 16 + quad;");
   g.f("    const bool have = unit < n_units;");
   g.f("    if (!have) unit = n_units - 1;");
-  g.f("    const long long span_idx = unit / chains_per_span;");
-  g.f("    const long long first_b = span_idx * span + (unit %% chains_per_span) * unit_len;");
+  // (64-bit divisions are ~100 instructions each: only ensembles with chains need them)
+  g.f("    long long span_idx = 0, chain_in_span = unit;");
+  g.f("    if (spg > 0) {");
+  g.f("      if (unit_len == 1) { span_idx = unit / spg; chain_in_span = unit - span_idx * spg; }");
+  g.f("      else { span_idx = unit / chains_per_span; chain_in_span = unit - span_idx * chains_per_span; }");
+  g.f("    }");
+  g.f("    const long long first_b = span_idx * span + chain_in_span * unit_len;");
   g.f("    const long long last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
-  g.f("    const long long geom = spg > 0 ? first_b / spg : 0;");
+  g.f("    const long long geom = span_idx;");
   g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * NP);
   g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * P.n_crows);
   g.f("    // chain-constant lane-component parameters (line points / directions, target directions)");
@@ -1159,7 +1164,25 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
     }
   g.out += fin.out;
   g.f("    if (mres > a.residual_tolerance) flags |= INFO_RESIDUAL_EXCEEDED;");
-  g.f("    if (valid && c < 3) {");
+  // Record stores.  Independent problems (chain_len 1): the 16 problems of a wavefront are
+  // consecutive, so their records form one contiguous block; it is transposed through LDS and
+  // written with full-width 16-byte-per-lane stores.  Chains: a quad's problems are far apart in
+  // memory, each lane stores its own 8-byte components.
+  g.f("    if (unit_len == 1) {");
+  g.f("      __shared__ double stage[16 * %d];", 3 * P.n_out);
+  g.f("      if (c < 3) {");
+  g.f("        double* st = stage + quad * %d + c;", 3 * P.n_out);
+  for (int k = 0; k < P.n_out; ++k) g.f("        st[%d] = p%d;", 3 * k, P.out_point[k]);
+  g.f("      }");
+  g.f("      __syncthreads();");
+  g.f("      const long long rem = a.n_problems - wu * 16;");
+  g.f("      const int n_doubles = (int)(rem < 16 ? rem : 16) * %d;", 3 * P.n_out);
+  g.f("      double2* dst = reinterpret_cast<double2*>(a.out_pos + wu * 16 * %d);", 3 * P.n_out);
+  g.f("      const double2* src = reinterpret_cast<const double2*>(stage);");
+  g.f("      for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
+  g.f("      if ((n_doubles & 1) && lane == 0) a.out_pos[wu * 16 * %d + n_doubles - 1] = stage[n_doubles - 1];", 3 * P.n_out);
+  g.f("      __syncthreads();  // stage is reused by the next unit of this wavefront");
+  g.f("    } else if (valid && c < 3) {");
   g.f("      double* o = a.out_pos + bb * %d + c;", 3 * P.n_out);
   for (int k = 0; k < P.n_out; ++k) g.f("      o[%d] = p%d;", 3 * k, P.out_point[k]);
   g.f("    }");
