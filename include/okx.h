@@ -271,6 +271,47 @@ int32_t okx_tangent_batch(okx_program* prog, int64_t n_problems, int64_t steps_p
                           void* stream);
 
 /*
+ * Corner state metrics: pure functions of solved points, evaluated for B
+ * states in one streaming launch.  Roles are indices into the OUTPUT point list of the
+ * program the positions come from (Suspension.wheel_axis_points(), steering_axis_points(),
+ * suspensions/corner/base.py role hooks).
+ */
+typedef struct okx_corner_roles {
+  int32_t wheel_center, contact_patch;   /* PointID.WHEEL_CENTER, CONTACT_PATCH_CENTER        */
+  int32_t axle_inboard, axle_outboard;   /* wheel_axis_points()                               */
+  int32_t steer_lower, steer_upper;      /* steering_axis_points() (lower, upper pivot)       */
+  double side_sign;                      /* +1 left, -1 right (Side.lateral_sign)             */
+  double design_wheel_center_z;          /* travel reference (metrics/context.py:42-45)       */
+} okx_corner_roles;
+
+enum {
+  OKX_METRIC_CAMBER = 0,           /* deg, metrics/angles.py:22-50            */
+  OKX_METRIC_CASTER = 1,           /* deg, angles.py:53-71                    */
+  OKX_METRIC_KPI = 2,              /* deg, angles.py:74-94                    */
+  OKX_METRIC_ROADWHEEL_ANGLE = 3,  /* deg (= toe), angles.py:97-132           */
+  OKX_METRIC_WHEEL_TRAVEL = 4,     /* mm, travel.py:19-32                     */
+  OKX_METRIC_HALF_TRACK = 5,       /* mm, travel.py:35-45                     */
+  OKX_METRIC_SCRUB_RADIUS = 6,     /* mm, steering_geometry.py:22-54          */
+  OKX_METRIC_MECHANICAL_TRAIL = 7, /* mm, steering_geometry.py:57-76          */
+  OKX_METRIC_COUNT = 8
+};
+
+/*
+ * Replaces compute_metrics_for_state's angle / travel / steering-geometry entries
+ * (metrics/main.py, catalog.py) and, given the tangents of okx_tangent_batch, the raw material of
+ * the derivative columns (metrics/derivatives.py): d_dmetrics[b][t][m] = d metric_m / d target_t,
+ * e.g. deriv_camber_wrt_hub_z = d_dmetrics[.][bump target][OKX_METRIC_CAMBER] and
+ * deriv_wheel_center_x_wrt_hub_z = d_tangents[.][bump target][wheel_center][0].
+ * d_tangents / d_dmetrics may both be NULL.
+ */
+int32_t okx_corner_metrics_batch(const okx_corner_roles* roles, int64_t n_states, int32_t n_out, int32_t n_targets,
+                                 const double* d_pos,       /* [B][n_out][3] */
+                                 const double* d_tangents,  /* [B][T][n_out][3] or NULL */
+                                 double* d_metrics,         /* [B][OKX_METRIC_COUNT] */
+                                 double* d_dmetrics,        /* [B][T][OKX_METRIC_COUNT] or NULL */
+                                 void* stream);
+
+/*
  * Runtime specialisation.  okx_program_create also GENERATES a HIP kernel for the program at
  * hand (straight-line residual / Jacobian / normal-equation / LDL^T code, four lanes per
  * problem), compiles it with hiprtc and loads it; the reference does the analogous thing

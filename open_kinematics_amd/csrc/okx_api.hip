@@ -12,6 +12,7 @@
 
 #include "okx_kernels.hip"
 #include "okx_packed.hip"
+#include "okx_metrics.hip"
 #include "okx_quad.hpp"
 
 struct okx_program {
@@ -593,6 +594,34 @@ int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_
   void* kargs[] = {(void*)&q};
   HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->quad_fn_tan_g : p->quad_fn_tan_u, (int)(waves < cap ? waves : cap), 1, 1,
                                 okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
+  return OKX_OK;
+}
+
+int32_t okx_corner_metrics_batch(const okx_corner_roles* roles, int64_t n_states, int32_t n_out, int32_t n_targets,
+                                 const double* d_pos, const double* d_tangents, double* d_metrics,
+                                 double* d_dmetrics, void* stream) {
+  if (!roles || !d_pos || !d_metrics) return fail(OKX_ERR_INVALID, "null pointer");
+  if (n_states < 0 || n_out <= 0 || n_targets < 0) return fail(OKX_ERR_INVALID, "bad dimension");
+  if ((d_tangents == nullptr) != (d_dmetrics == nullptr))
+    return fail(OKX_ERR_INVALID, "tangents and derivative output must be given together");
+  const int32_t idx[6] = {roles->wheel_center, roles->contact_patch, roles->axle_inboard,
+                          roles->axle_outboard, roles->steer_lower, roles->steer_upper};
+  for (int k = 0; k < 6; ++k)
+    if (idx[k] < 0 || idx[k] >= n_out) return fail(OKX_ERR_INVALID, "role %d is not an output point", k);
+  if (!(roles->side_sign == 1.0 || roles->side_sign == -1.0)) return fail(OKX_ERR_INVALID, "side_sign must be +-1");
+  if (n_states == 0) return OKX_OK;
+  okx::MetricsArgs a;
+  a.roles = *roles;
+  a.pos = d_pos;
+  a.tan = d_tangents;
+  a.metrics = d_metrics;
+  a.dmetrics = d_dmetrics;
+  a.n_states = n_states;
+  a.n_out = n_out;
+  a.n_targets = n_targets;
+  const long long blocks = (n_states + 255) / 256;
+  hipLaunchKernelGGL(okx::okx_corner_metrics_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
   return OKX_OK;
 }
 

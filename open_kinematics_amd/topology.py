@@ -310,6 +310,19 @@ class CornerSuspension(Suspension):
     def rack_attachment_point(self):
         return self.heading_link.inboard_point if self.steered else None
 
+    def wheel_axis_points(self) -> tuple:
+        """Wheel spin axis, inboard -> outboard (``corner/base.py`` role hook)."""
+        return (P.AXLE_INBOARD, P.AXLE_OUTBOARD)
+
+    def steering_axis_points(self) -> tuple:
+        """(lower, upper) steering pivots; architecture specific."""
+        raise NotImplementedError
+
+    @property
+    def lateral_sign(self) -> float:
+        """``Side.lateral_sign``: +1 left, -1 right."""
+        return 1.0 if self.side is Side.LEFT else -1.0
+
     def actuator_dofs(self) -> tuple:
         """``corner/base.py:80-91``."""
         point = self.rack_attachment_point()
@@ -379,6 +392,10 @@ class DoubleWishboneSuspension(CornerSuspension):
 
     def required_points(self) -> frozenset:
         return self.REQUIRED | self.heading_link.required_points | self.actuation.required_points | self.spring.required_points
+
+    def steering_axis_points(self) -> tuple:
+        """``double_wishbone.py:223-225``: the two outboard ball joints."""
+        return (P.LOWER_WISHBONE_OUTBOARD, P.UPPER_WISHBONE_OUTBOARD)
 
     def free_points(self) -> tuple:
         return (*self.FREE_POINTS, *self.heading_link.free_points, *self.actuation.free_points, *self.spring.free_points)
@@ -460,6 +477,10 @@ class MacPhersonSuspension(CornerSuspension):
 
     def required_points(self) -> frozenset:
         return self.REQUIRED | self.heading_link.required_points
+
+    def steering_axis_points(self) -> tuple:
+        """``macpherson.py:210-212``: lower ball joint to the strut top."""
+        return (P.LOWER_WISHBONE_OUTBOARD, P.STRUT_TOP)
 
     def free_points(self) -> tuple:
         return (*self.FREE_POINTS, *self.heading_link.free_points)
