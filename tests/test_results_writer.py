@@ -1,0 +1,107 @@
+"""Wide-form result files in the reference's format (results_writer.py / export.py), CPU only."""
+
+import csv
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from open_kinematics_amd.results_writer import (CsvWriter, ParquetWriter, SolutionFrame, flatten_positions,
+                                                frames_from_batch)
+from open_kinematics_amd.solver import SolverInfo
+
+
+def _golden_csv():
+    with open(os.path.join(GOLDEN, "e2e_output.csv"), encoding="utf-8") as fh:
+        lines = fh.read().splitlines()
+    meta = [ln for ln in lines if ln.startswith("#")]
+    rows = list(csv.DictReader(ln for ln in lines if not ln.startswith("#")))
+    return meta, rows
+
+
+def test_csv_layout_matches_the_reference_golden(golden, tmp_path):
+    """Same metadata comment block, same column order for the shared columns, same cell formatting."""
+    arrays, program = golden("e2e_sweep")
+    meta, rows = _golden_csv()
+    pos = arrays["ref_default_pos"]
+    info = np.zeros(pos.shape[0], dtype=[("flags", "<i4"), ("nfev", "<i4"), ("max_residual", "<f8")])
+    info["flags"], info["nfev"], info["max_residual"] = 1, arrays["ref_default_nfev"], arrays["ref_default_maxres"]
+    mg = dict(np.load(os.path.join(GOLDEN, "metrics_e2e_sweep.npz"), allow_pickle=False))
+    names = ("camber", "caster", "kpi", "scrub_radius", "mechanical_trail", "roadwheel_angle", "wheel_travel", "half_track")
+    order = ("camber", "caster", "kpi", "roadwheel_angle", "wheel_travel", "half_track", "scrub_radius", "mechanical_trail")
+    metrics = {n: mg["values"][:, order.index(n)] for n in names}
+    metrics["damper_length"] = np.full(pos.shape[0], np.nan)  # undefined for this topology: empty cells
+    out = tmp_path / "out.csv"
+    writer = CsvWriter(out, geometry_path=os.path.join(GOLDEN, "geometry", "geometry.yaml"),
+                       sweep_path=os.path.join(GOLDEN, "geometry", "sweep.yaml"))
+    for b, frame in enumerate(frames_from_batch(program, pos, info, metrics, {"damper_length": "mm"})):
+        writer.add_frame(b, frame)
+    writer.write()
+    lines = out.read_text().splitlines()
+    mine_meta = [ln for ln in lines if ln.startswith("#")]
+    assert [ln.split(":")[0] for ln in mine_meta] == [ln.split(":")[0] for ln in meta]
+    assert mine_meta[0] == "# format_version: 3" and mine_meta[-1] == "#"
+    # the reference's fixture files: same content hash as the golden's provenance block
+    assert mine_meta[3] == meta[3] and mine_meta[5] == meta[5]
+    units = json.loads(mine_meta[-2].split(": ", 1)[1])
+    ref_units = json.loads(meta[-2].split(": ", 1)[1])
+    assert all(ref_units[k] == v for k, v in units.items())
+    mine = list(csv.DictReader(ln for ln in lines if not ln.startswith("#")))
+    ref_cols, my_cols = list(rows[0].keys()), list(mine[0].keys())
+    assert my_cols[:4] == ref_cols[:4] == ["step_index", "solver_converged", "solver_max_residual", "solver_nfev"]
+    assert [c for c in ref_cols if c in my_cols] == my_cols  # same relative order, subset of the metric columns
+    point_names = {program.point_keys[k].lower_name for k in program.out_point}
+    position_cols = [c for c in ref_cols if c[:-2] in point_names and c.endswith(("_x", "_y", "_z"))]
+    assert len(position_cols) == 3 * program.n_out
+    assert my_cols[-len(position_cols):] == position_cols == ref_cols[-len(position_cols):]
+    assert len(mine) == len(rows)
+    for a, b in zip(mine, rows):
+        assert a["step_index"] == b["step_index"] and a["solver_converged"] == b["solver_converged"] == "True"
+        assert a["damper_length"] == b["damper_length"] == ""
+        for c in position_cols:
+            assert abs(float(a[c]) - float(b[c])) <= 5e-5  # other platform
+        for c in names:
+            assert abs(float(a[c]) - float(b[c])) <= 5e-5
+
+
+def test_parquet_carries_metadata_and_units(tmp_path):
+    import pyarrow.parquet as pq
+
+    out = tmp_path / "out.parquet"
+    writer = ParquetWriter(out, tool="unit-test")
+    for k in (1, 0):
+        writer.add_frame(k, SolutionFrame({"wheel_center": (1.0, 2.0, 3.0 + k)}, SolverInfo(True, 5 + k, 1e-7),
+                                          {"camber": -1.5, "damper_length": None}, {"damper_length": "mm"}))
+    writer.write()
+    table = pq.read_table(out)
+    meta = json.loads(table.schema.metadata[b"kinematics_meta"])
+    assert meta["format_version"] == "3" and meta["tool"] == "unit-test"
+    assert table.column("step_index").to_pylist() == [0, 1]  # sorted by step
+    assert table.schema.field("camber").metadata[b"unit"] == b"deg"
+    assert table.schema.field("wheel_center_z").metadata[b"unit"] == b"mm"
+    assert table.column("wheel_center_z").to_pylist() == [3.0, 4.0]
+    assert table.column("damper_length").to_pylist() == [None, None]
+
+
+def test_writer_errors_match_the_reference():
+    w = CsvWriter("/tmp/never.csv")
+    with pytest.raises(ValueError, match="No frames to write"):
+        w.write()
+    w.add_frame(0, SolutionFrame({"a": (0.0, 0.0, 0.0)}, SolverInfo(True, 1, 0.0)))
+    w.add_frame(1, SolutionFrame({"b": (0.0, 0.0, 0.0)}, SolverInfo(True, 1, 0.0)))
+    with pytest.raises(ValueError, match="Frame 1 has inconsistent columns"):
+        w.write()
+    w2 = CsvWriter("/tmp/never.csv")
+    w2.add_frame(0, SolutionFrame({"a": (0.0, 0.0, 0.0)}, SolverInfo(True, 1, 0.0), {"camber": 1.0}, {"camber": "deg"}))
+    with pytest.raises(ValueError, match="Conflicting units"):
+        w2.add_frame(1, SolutionFrame({"a": (0.0, 0.0, 0.0)}, SolverInfo(True, 1, 0.0), {"camber": 1.0}, {"camber": "mm"}))
+
+
+def test_flatten_positions_uses_public_names():
+    from open_kinematics_amd.enums import PointID
+    from open_kinematics_amd.state import Point3
+
+    flat = flatten_positions({PointID.WHEEL_CENTER: Point3([1, 2, 3])}, [PointID.WHEEL_CENTER, PointID.AXLE_INBOARD])
+    assert flat == {"wheel_center": (1.0, 2.0, 3.0)}
