@@ -390,7 +390,11 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   a.n_problems = n_problems;
   a.steps_per_geometry = spg;
   a.max_iter = opts->max_iter;
-  a.pad_ = 0;
+  // the predicted-convergence ending is not offered along the reference's zero-gradient
+  // point-on-line valley: the step length says nothing about the distance there
+  bool degenerate_line = false;
+  for (int i = 0; i < p->host.n_crows; ++i) degenerate_line = degenerate_line || p->host.row_type[i] == OKX_ROW_POINT_ON_LINE;
+  a.confirm = (opts->reserved != 0 || degenerate_line || getenv("OKX_QUAD_CONFIRM") != nullptr) ? 1 : 0;
   // Kernel choice (profiles/r01/config_sweep_v3.txt).  The packed kernel keeps more problems in
   // flight per CU (G lane groups x resident waves): measured 1.5x on saturating batches of
   // n <= 15 systems (MacPherson grid), no gain for n = 18 (DW corner), so auto = packed only
@@ -445,7 +449,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     q.steps_per_geometry = a.steps_per_geometry;
     q.chain_len = a.chain_len;
     q.max_iter = a.max_iter;
-    q.confirm = opts->reserved != 0 || getenv("OKX_QUAD_CONFIRM") != nullptr;
+    q.confirm = a.confirm;
     q.step_tol = a.step_tol;
     q.grad_tol = a.grad_tol;
     q.ftol = a.ftol;
@@ -681,7 +685,7 @@ int32_t okx_debug_phase_profile(okx_program* p, const okx_solve_opts* opts, int6
   a.n_problems = n_problems;
   a.steps_per_geometry = 0;
   a.max_iter = opts->max_iter;
-  a.pad_ = 0;
+  a.confirm = 1;
   a.chain_len = 1;
   a.step_tol = opts->step_tol;
   a.grad_tol = opts->grad_tol;

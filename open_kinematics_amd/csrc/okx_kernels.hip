@@ -38,7 +38,7 @@ struct SolveArgs {
   long long n_problems;
   long long steps_per_geometry;  // 0: single geometry
   int max_iter;
-  int pad_;
+  int confirm;                   // non-zero: always end on a computed correction (no predicted-convergence test)
   long long chain_len;           // problems per warm-started chain (>= 1)
   double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
   unsigned long long* phase_cycles;  // diagnostic build only: [8] per-phase cycle sums of block 0
@@ -890,6 +890,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
   for (long long unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
     double x = 0.0, x_prev = 0.0;
     int hist = 0;  // consecutive solved predecessors in this chain (predictor needs two)
+    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)
     const long long span_idx = unit / chains_per_span;
     const long long first = span_idx * span + (unit % chains_per_span) * unit_len;
     const long long last = first + unit_len < (span_idx + 1) * span ? first + unit_len : (span_idx + 1) * span;
@@ -940,7 +941,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
       int cur = 1;  // buffer of the accepted point (first evaluation writes buffer 0)
       int nfev = 0, iters = 0, flags = 0;
       double F = 0.0, g = 0.0, dx = 0.0, lambda = 0.0, dmax = 0.0, nu = 2.0;
-      double last_step = 0.0, step_len = 0.0;
+      double last_step = 0.0, step_len = 0.0, prev_step = 0.0;
       double xt = x;
       bool first = true;
       for (;;) {
@@ -980,9 +981,13 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
             if (first) {
               dmax = wave_max(lane < n ? S.dA[lane] : 0.0);
               lambda = args.lambda0 * dmax;
+              // a warm-started chain step continues with the damping its predecessor ended with
+              if (lambda_carry > 0.0) lambda = fmin(lambda, lambda_carry);
             } else if (rho > 1e-4) {
+              // Nielsen's update; an accurate quadratic model (gain ratio > 0.9) drops the damping
+              // by 10 (Marquardt), so the last steps are Gauss-Newton steps (MINPACK: par = 0)
               const double t = 2.0 * rho - 1.0;
-              lambda *= fmax(1.0 / 3.0, 1.0 - t * t * t);
+              lambda *= rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t);
             }
             nu = 2.0;
             if (args.grad_tol > 0.0 && wave_max(lane < n ? fabs(g) : 0.0) <= args.grad_tol) {
@@ -1008,9 +1013,11 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
         OKX_STAMP(4)
         // damped normal equations; enlarge lambda until the factorisation succeeds
         bool ok = false;
+        double pmin = 1e300, pmax = 0.0;
         for (int tries = 0; tries < 60; ++tries) {
           if (!(lambda < 1e30)) break;
-          ok = ldlt_solve_reg<NREG>(P, S, lane, lambda, g, &dx);
+          pmin = 1e300;
+          ok = ldlt_solve_reg<NREG>(P, S, lane, lambda, g, &dx, &pmin, &pmax);
           stamp(prof, 6);
           if (ok) break;
           lambda = fmax(lambda * 10.0, 1e-12 * dmax);
@@ -1030,6 +1037,28 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
           break;
         }
         xt = x + dx;
+        // Predicted next correction (rho |dx| + C |dx|^2: damping contraction lambda / min pivot and
+        // the observed quadratic contraction, both x 100; DESIGN.md §5.1 "Ending a solve"): when it is
+        // within step_tol the step is applied and confirmed by a residual-only evaluation instead of
+        // a full Jacobian / factorisation pass.
+        if (!args.confirm) {
+          const double cq = prev_step > 0.0 ? fmax(100.0 * step_len / (prev_step * prev_step), 1e-3) : 1.0;
+          const double rho_lin = 100.0 * lambda / pmin;
+          if (step_len <= 1e-3 && (rho_lin + cq * step_len) * step_len <= args.step_tol) {
+            const double Fl = evaluate<false>(P, S, lane, xt, xaddr, cur ^ 1, prof);
+            ++nfev;
+            if (Fl == Fl && Fl <= F * (1.0 + 1e-6) + 1e-28) {
+              x = xt;
+              F = Fl;
+              cur ^= 1;
+              last_step = step_len;
+              flags |= OKX_INFO_CONVERGED;
+              break;
+            }
+            // the cost rose: the same point goes through a full pass (its Jacobian is needed anyway)
+          }
+        }
+        prev_step = step_len;
       }
       OKX_STAMP(4)
 
@@ -1061,8 +1090,10 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
                                           : &P->design_pos[0][0];
         if (lane < n) x = src[xaddr];
         hist = 0;
-      } else if (hist < 2) {
-        ++hist;
+        lambda_carry = 0.0;
+      } else {
+        if (hist < 2) ++hist;
+        lambda_carry = lambda;
       }
       OKX_STAMP(8)
     }
