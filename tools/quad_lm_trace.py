@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Per-pass Levenberg-Marquardt record of ONE problem in the quad kernel (okx_debug_quad_trace):
+mode, trial cost, accepted cost, damping, step, gain ratio, accepted, done.  Usage:
+    python tools/quad_lm_trace.py [problem_index]    (reference softnorm line rows, 101-step C1 sweep)"""
 import os, sys, ctypes as C
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
