@@ -77,11 +77,20 @@ class Gen {
 
   void f(const char* fmt, ...) {
     char buf[1024];
-    va_list ap;
+    va_list ap, again;
     va_start(ap, fmt);
-    std::vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_copy(again, ap);
+    const int need = std::vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    out += buf;
+    if (need >= (int)sizeof(buf)) {  // a long combined expression: format again into an exact-size buffer
+      std::string big((size_t)need + 1, '\0');
+      std::vsnprintf(&big[0], big.size(), fmt, again);
+      big.resize((size_t)need);
+      out += big;
+    } else if (need > 0) {
+      out += buf;
+    }
+    va_end(again);
     out += '\n';
   }
   std::string tmp(const char* base) { return "_" + std::string(base) + std::to_string(uid++); }
@@ -435,6 +444,41 @@ class Gen {
           ro->partial.push_back({pts[1], {gm, 1}});
           ro->partial.push_back({pts[2], {g2, 1}});
         }
+        return true;
+      }
+      case OKX_ROW_VECTORS_PARALLEL:
+      case OKX_ROW_VECTORS_PERPENDICULAR: {  // constraints.py:351-371,414-429; jacobians.py:192-318
+        std::string v1 = vsub(pn(pts[1]), pn(pts[0])), v2 = vsub(pn(pts[3]), pn(pts[2]));
+        std::string n1 = dot(v1, v1), n2 = dot(v2, v2);
+        std::string s1 = tmp("s"), s2 = tmp("s"), g1 = tmp("g"), g2 = tmp("g");
+        f("    const double %s = sqrt(EPS_SQ + %s), %s = sqrt(EPS_SQ + %s);", s1.c_str(), n1.c_str(), s2.c_str(), n2.c_str());
+        if (type == OKX_ROW_VECTORS_PARALLEL) {
+          std::string cv = cross(v1, v2);
+          std::string c2 = dot(cv, cv);
+          std::string sc = tmp("s");
+          f("    const double %s = sqrt(EPS_SQ + %s);", sc.c_str(), c2.c_str());
+          std::string w1 = cross(v2, cv), w2 = cross(cv, v1);
+          std::string k26 = tmp("k"), k19 = tmp("k"), k31 = tmp("k");
+          f("    const double %s = 1.0 / (%s * %s * %s), %s = %s / (%s * %s * %s * %s), %s = %s / (%s * %s * %s * %s);",
+            k26.c_str(), s1.c_str(), s2.c_str(), sc.c_str(), k19.c_str(), sc.c_str(), s2.c_str(), s1.c_str(), s1.c_str(),
+            s1.c_str(), k31.c_str(), sc.c_str(), s1.c_str(), s2.c_str(), s2.c_str(), s2.c_str());
+          f("    const double %s = %s * %s - %s * %s, %s = %s * %s - %s * %s;", g1.c_str(), k26.c_str(), w1.c_str(),
+            k19.c_str(), v1.c_str(), g2.c_str(), k26.c_str(), w2.c_str(), k31.c_str(), v2.c_str());
+          f("    const double %s = (%s - EPS) / ((%s - EPS) * (%s - EPS));", r.c_str(), sc.c_str(), s1.c_str(), s2.c_str());
+        } else {
+          std::string dt = dot(v1, v2);
+          std::string k16 = tmp("k"), k18 = tmp("k"), k19 = tmp("k");
+          f("    const double %s = 1.0 / (%s * %s), %s = %s / (%s * %s * %s * %s), %s = %s / (%s * %s * %s * %s);",
+            k16.c_str(), s1.c_str(), s2.c_str(), k18.c_str(), dt.c_str(), s2.c_str(), s1.c_str(), s1.c_str(), s1.c_str(),
+            k19.c_str(), dt.c_str(), s1.c_str(), s2.c_str(), s2.c_str(), s2.c_str());
+          f("    const double %s = %s * %s - %s * %s, %s = %s * %s - %s * %s;", g1.c_str(), k16.c_str(), v2.c_str(),
+            k18.c_str(), v1.c_str(), g2.c_str(), k16.c_str(), v1.c_str(), k19.c_str(), v2.c_str());
+          f("    const double %s = %s / ((%s - EPS) * (%s - EPS));", r.c_str(), dt.c_str(), s1.c_str(), s2.c_str());
+        }
+        ro->partial.push_back({pts[0], {g1, -1}});
+        ro->partial.push_back({pts[1], {g1, 1}});
+        ro->partial.push_back({pts[2], {g2, -1}});
+        ro->partial.push_back({pts[3], {g2, 1}});
         return true;
       }
       case OKX_ROW_EQUAL_DISTANCE: {  // constraints.py:466-477; jacobians.py:322-367

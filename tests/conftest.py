@@ -38,6 +38,7 @@ def golden():
 
 STEERED = ["c1_dw_corner", "c2_dw_subset", "c3_axle_grid", "c4_macpherson_grid", "e2e_sweep"]
 UNSTEERED = ["u_dw_corner", "u_macpherson", "u_axle"]
+ALL_ROW_CLASSES = ["rows_all_classes"]  # synthetic: one row of each of the reference's 13 constraint classes
 
 
 def gpu_available() -> bool:

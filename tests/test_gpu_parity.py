@@ -16,7 +16,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, STEERED, UNSTEERED
+from conftest import ALL_ROW_CLASSES, GOLDEN, STEERED, UNSTEERED
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def _solve(program, targets, **kw):
     return res.positions.cpu().numpy(), res.info()
 
 
-@pytest.mark.parametrize("name", STEERED + UNSTEERED)
+@pytest.mark.parametrize("name", STEERED + UNSTEERED + ALL_ROW_CLASSES)
 @pytest.mark.parametrize("line_mode", ["softnorm", "pinned"])
 def test_eval_matches_oracle_and_reference(golden, name, line_mode):
     from oracle.oracle import Oracle
@@ -48,12 +48,13 @@ def test_eval_matches_oracle_and_reference(golden, name, line_mode):
     torch.cuda.synchronize()
     r, jac = r.cpu().numpy(), jac.cpu().numpy()
     r_o, jac_o = Oracle(program).eval(arrays["eval_x"], arrays["eval_targets"])
+    # absolute floors for mm-scale rows, relative for the large ones (unscaled volumes of the coplanar row)
     assert np.all(np.abs(r - r_o) <= 2.5e-13 + 1e-13 * np.abs(r_o))
-    assert np.max(np.abs(jac - jac_o)) <= 1e-13
+    assert np.all(np.abs(jac - jac_o) <= 1e-13 * np.maximum(1.0, np.abs(jac_o)))
     if line_mode == "softnorm":  # identical row set as the reference itself
         ref_r, ref_j = arrays["eval_r"], arrays["eval_jac"]
         assert np.all(np.abs(r - ref_r) <= 2.5e-13 + 1e-13 * np.abs(ref_r))
-        assert np.max(np.abs(jac - ref_j)) <= 1e-13
+        assert np.all(np.abs(jac - ref_j) <= 1e-13 * np.maximum(1.0, np.abs(ref_j)))
 
 
 @pytest.mark.parametrize("name", ["c1_dw_corner", "c3_axle_grid", "c4_macpherson_grid", "u_axle"])

@@ -12,7 +12,7 @@ from conftest import gpu_available
 
 pytestmark = pytest.mark.gpu
 
-QUAD_PROGRAMS = ["c1_dw_corner", "c4_macpherson_grid", "u_dw_corner", "u_macpherson"]
+QUAD_PROGRAMS = ["c1_dw_corner", "c4_macpherson_grid", "u_dw_corner", "u_macpherson", "rows_all_classes"]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -39,16 +39,19 @@ def test_quad_normal_equations_and_step_match_the_oracle(golden, name, mode):
     program = program.with_line_mode(mode)
     dp = _dp(program)
     x, t = arrays["eval_x"], arrays["eval_targets"]
-    lam = 1e-4
-    r, ata, atr, dx = [v.cpu().numpy() for v in dp.quad_eval(x, t, lam)]
     r_o, jac_o = Oracle(program).eval(x, t)
     ata_o = np.einsum("bij,bik->bjk", jac_o, jac_o)
+    lam = 1e-6 * float(np.max(np.diagonal(ata_o, axis1=1, axis2=2)))  # the solver's own initial damping (lambda0 * dmax)
+    r, ata, atr, dx = [v.cpu().numpy() for v in dp.quad_eval(x, t, lam)]
     atr_o = np.einsum("bij,bi->bj", jac_o, r_o)
-    assert np.max(np.abs(r - r_o)) <= 2.5e-13
+    assert np.all(np.abs(r - r_o) <= 2.5e-13 + 1e-13 * np.abs(r_o))
     assert np.max(np.abs(ata - ata_o)) <= 1e-11 * max(1.0, np.abs(ata_o).max())
     assert np.max(np.abs(atr - atr_o)) <= 1e-11 * max(1.0, np.abs(atr_o).max())
+    # the device's LDL^T step against a dense solve of ITS OWN normal equations (conditioning of the
+    # synthetic all-classes problem, with unscaled volume rows, would otherwise amplify the 1e-16
+    # differences between the two J^T J)
     n = program.n_vars
-    dx_o = np.stack([-np.linalg.solve(ata_o[k] + lam * np.eye(n), atr_o[k]) for k in range(len(x))])
+    dx_o = np.stack([-np.linalg.solve(ata[k] + lam * np.eye(n), atr[k]) for k in range(len(x))])
     assert np.max(np.abs(dx - dx_o)) <= 1e-9 * max(1.0, np.abs(dx_o).max())
 
 

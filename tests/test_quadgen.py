@@ -23,7 +23,7 @@ def _source(program) -> str:
     return buf.value.decode()
 
 
-@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid", "u_dw_corner", "u_macpherson"])
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid", "u_dw_corner", "u_macpherson", "rows_all_classes"])
 @pytest.mark.parametrize("mode", ["pinned", "softnorm"])
 def test_source_is_generated_for_corner_topologies(golden, name, mode):
     _, program = golden(name)
@@ -40,7 +40,7 @@ def test_source_is_generated_for_corner_topologies(golden, name, mode):
     # the per-problem decisions rely on bit-identical quad reductions
     assert "#pragma clang fp contract(off)" in src
     # structure only: no geometry value is baked into the text
-    assert "471.69" not in src and "559.01" not in src
+    assert "471.69" not in src and "559.01" not in src and "410.0" not in src
 
 
 def test_same_structure_gives_the_same_kernel_different_structure_does_not(golden):
