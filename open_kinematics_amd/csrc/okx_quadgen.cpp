@@ -282,10 +282,6 @@ class Gen {
       return true;
     }
     if (type == OKX_DOP_CONTACT_PATCH) {  // definitions.py:36-73, :158-180
-      if (with_blocks) {
-        why = "a constraint row depends on a contact-patch point";
-        return false;
-      }
       std::string v = vsub(pn(pts[2]), pn(pts[1]));
       std::string vv = dot(v, v);
       std::string vn = tmp("vn"), ivn = tmp("iv"), ax = tmp("ax");
@@ -300,6 +296,59 @@ class Gen {
       f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", wn.c_str(), iwn.c_str(), ww.c_str(), wn.c_str(),
         iwn.c_str());
       f("    %s = %s + (%s * %s) * %s;", o.c_str(), pn(pts[0]).c_str(), wd.c_str(), iwn.c_str(), dp(e).c_str());
+      if (with_blocks) {
+        // d out / d axo = T = R Nw Wa Na (axi: -T, wheel centre: I) with Na = (I - a a^T)/|v|,
+        // Wa = a_z I + a e_z^T, Nw = (I - wu wu^T)/|wd|.  Lane c forms column c: T applied to the
+        // lane-held column of the input's own block (e_c for a free input).
+        std::string wu = tmp("wu");
+        f("    const double %s = %s * %s;", wu.c_str(), wd.c_str(), iwn.c_str());
+        std::string ab[3], wb[3];
+        for (int r = 0; r < 3; ++r) ab[r] = bcast(ax, r), wb[r] = bcast(wu, r);
+        auto apply_t = [&](const std::string b[3], std::string t[3]) {
+          std::string adb = tmp("ad");
+          f("    const double %s = %s * %s + %s * %s + %s * %s;", adb.c_str(), ab[0].c_str(), b[0].c_str(), ab[1].c_str(),
+            b[1].c_str(), ab[2].c_str(), b[2].c_str());
+          std::string nn[3], w[3];
+          for (int r = 0; r < 3; ++r) {
+            nn[r] = tmp("n");
+            f("    const double %s = %s * (%s - %s * %s);", nn[r].c_str(), ivn.c_str(), b[r].c_str(), ab[r].c_str(), adb.c_str());
+          }
+          for (int r = 0; r < 3; ++r) {
+            w[r] = tmp("w");
+            f("    const double %s = %s * %s + %s * %s;", w[r].c_str(), az.c_str(), nn[r].c_str(), ab[r].c_str(), nn[2].c_str());
+          }
+          std::string wdw = tmp("ww");
+          f("    const double %s = %s * %s + %s * %s + %s * %s;", wdw.c_str(), wb[0].c_str(), w[0].c_str(), wb[1].c_str(),
+            w[1].c_str(), wb[2].c_str(), w[2].c_str());
+          for (int r = 0; r < 3; ++r) {
+            t[r] = tmp("B");
+            f("    const double %s = %s * %s * (%s - %s * %s);", t[r].c_str(), dp(e).c_str(), iwn.c_str(), w[r].c_str(),
+              wb[r].c_str(), wdw.c_str());
+          }
+        };
+        std::map<int, std::vector<BlkTerm>> acc;
+        for (auto& kv : blocks_of_point(pts[0])) acc[kv.first].push_back({kv.second, 1});
+        for (int sidx = 1; sidx <= 2; ++sidx) {
+          const int sg = sidx == 2 ? 1 : -1;  // pts[2] = axle outboard (+T), pts[1] = axle inboard (-T)
+          for (auto& kv : blocks_of_point(pts[sidx])) {
+            const Blk& b = kv.second;
+            std::string col[3];
+            if (b.scaled) {
+              for (int r = 0; r < 3; ++r) {
+                col[r] = tmp("c");
+                f("    const double %s = (%s) * e%d;", col[r].c_str(), b.s.c_str(), r);
+              }
+            } else {
+              for (int r = 0; r < 3; ++r) col[r] = b.col[r];
+            }
+            Blk nb;
+            nb.scaled = false;
+            apply_t(col, nb.col);
+            acc[kv.first].push_back({nb, sg});
+          }
+        }
+        dblk[e] = combine(acc);
+      }
       return true;
     }
     why = "unknown derived op";

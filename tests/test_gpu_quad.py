@@ -152,3 +152,33 @@ def test_axle_keeps_the_wave_kernel_and_says_why(golden):
     assert dp.kernel == "wave" and "free points" in dp.kernel_note
     with pytest.raises(ValueError, match="quad kernel requested but not available"):
         dp.solve(np.zeros((1, program.n_targets)), kernel="quad")
+
+
+def test_quad_rows_on_the_contact_patch(golden):
+    """A target on the contact-patch centre: its chain blocks T = R Nw Wa Na come from the generator."""
+    from oracle.oracle import Oracle
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden("c1_dw_corner")
+    pinned = program.with_line_mode("pinned")
+    names = [k.lower_name for k in pinned.point_keys]
+    cp = names.index("contact_patch_center")
+    prog = pinned.with_targets([pinned.tgt_point[0], cp], np.array([pinned.tgt_dir[0], [0.0, 0.0, 1.0]]))
+    dp = DeviceProgram(prog, "cuda:0")
+    assert dp.kernel == "quad", dp.kernel_note
+    x = arrays["eval_x"]
+    t = np.tile([[arrays["eval_targets"][0, 0], prog.design_pos[cp][2]]], (len(x), 1))
+    r_o, jac_o = Oracle(prog).eval(x, t)
+    ata_o = np.einsum("bij,bik->bjk", jac_o, jac_o)
+    r, ata, atr, _ = [v.cpu().numpy() for v in dp.quad_eval(x, t, 1e-6)]
+    assert np.all(np.abs(r - r_o) <= 2.5e-13 + 1e-13 * np.abs(r_o))
+    assert np.max(np.abs(ata - ata_o)) <= 1e-11 * max(1.0, np.abs(ata_o).max())
+    assert np.max(np.abs(atr - np.einsum("bij,bi->bj", jac_o, r_o))) <= 1e-11 * max(1.0, np.abs(r_o).max() * np.abs(jac_o).max())
+    # ground-relative bump sweep: contact patch z from -40 to +40 mm about design, rack held
+    sweep = np.stack([np.full(33, t[0, 0]), prog.design_pos[cp][2] + np.linspace(-40.0, 40.0, 33)], axis=1)
+    quad = dp.solve(sweep, kernel="quad")
+    wave = dp.solve(sweep, kernel="single")
+    assert np.all((quad.info()["flags"] & 7) == 1)
+    assert float((quad.positions - wave.positions).abs().max()) <= 1e-10
+    out_cp = list(prog.out_point).index(cp)
+    assert np.max(np.abs(quad.positions[:, out_cp, 2].cpu().numpy() - sweep[:, 1])) <= 1e-9
