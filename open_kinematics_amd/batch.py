@@ -277,8 +277,9 @@ class DeviceProgram:
                 C.c_void_p(stream),
             )
         _lib.check(rc, "okx_debug_quad_eval")
-        low = torch.tril(ata)
-        ata = low + torch.tril(ata, -1).transpose(1, 2)
+        # the kernel writes each structurally non-zero off-diagonal block once (rows of the block that
+        # is eliminated later) and the diagonal blocks in full: mirror what was not written
+        ata = torch.where(ata != 0.0, ata, ata.transpose(1, 2))
         return r, ata, atr, dx
 
     def rebind(self, hardpoints):

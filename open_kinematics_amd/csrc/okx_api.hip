@@ -638,7 +638,8 @@ void okx_debug_quad_trace(double* d_trace, int64_t problem) {
 }
 
 /* Test hook: what the quad kernel's straight-line code computes at given free vectors d_x [B][n]:
-   d_r [B][m], d_ata [B][n][n] (only the structurally non-zero LOWER entries are written: clear the
+   d_r [B][m], d_ata [B][n][n] (each structurally non-zero off-diagonal block is written ONCE, on one side of the
+   diagonal, and the diagonal blocks in full: clear the
    buffer first), d_atr [B][n] and the damped step d_dx [B][n] = -(J^T J + lambda I)^-1 J^T r from
    its LDL^T (NaN when a pivot is not positive). */
 int32_t okx_debug_quad_eval(okx_program* p, int64_t n_problems, const double* d_x, const double* d_targets,

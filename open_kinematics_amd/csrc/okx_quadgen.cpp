@@ -61,8 +61,39 @@ class Gen {
   explicit Gen(const DevProgram& prog) : P(prog) {
     blk_of_point.assign(P.n_points, -1);
     dop_of_point.assign(P.n_points, -1);
-    for (int k = 0; k < P.n_free; ++k) blk_of_point[P.free_point[k]] = k;
+    elimination_order();
+    for (int F = 0; F < P.n_free; ++F) blk_of_point[fp(F)] = F;
     for (int e = 0; e < P.n_derived; ++e) dop_of_point[P.dop_out[e]] = e;
+  }
+
+  // Block F of the generated code (x{F}, rows 3F+c of J^T J, elimination step F of the LDL^T) is
+  // the program's free point perm[F]: a greedy minimum-degree order on the block graph of J^T J
+  // (ties: program order), so that leaf chains (rack pickup, pushrod / rocker / drop-link) are
+  // eliminated before the upright's clique and create no fill-in.
+  std::vector<int> perm;
+  int fp(int F) const { return P.free_point[perm[F]]; }
+  void elimination_order() {
+    const int nf = P.n_free;
+    std::vector<std::set<int>> adj(nf);
+    for (int i = 0; i < P.m; ++i)
+      for (int a = 0; a < P.row_nblk[i]; ++a)
+        for (int b = 0; b < P.row_nblk[i]; ++b)
+          if (a != b) adj[P.row_blk[i][a]].insert(P.row_blk[i][b]);
+    std::vector<bool> gone(nf, false);
+    perm.clear();
+    for (int step = 0; step < nf; ++step) {
+      int best = -1;
+      for (int k = 0; k < nf; ++k)
+        if (!gone[k] && (best < 0 || adj[k].size() < adj[best].size())) best = k;
+      perm.push_back(best);
+      gone[best] = true;
+      for (int u : adj[best]) {
+        adj[u].erase(best);
+        for (int w : adj[best])
+          if (w != u) adj[u].insert(w);
+      }
+      adj[best].clear();
+    }
   }
 
   const DevProgram& P;
@@ -1086,7 +1117,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   // point registers
   for (int p = 0; p < NP; ++p)
     if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
-  for (int F = 0; F < nf; ++F) g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0;", F, P.free_point[F], F, F, F);
+  for (int F = 0; F < nf; ++F) g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0;", F, ev.fp(F), F, F, F);
   g.f("    int hist = 0;");
   g.f("    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)");
   // targets: the next step's values are fetched while the current step is being solved, and the two
@@ -1124,13 +1155,13 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
     // (no Jacobian, no factorisation) and finish if the cost did not rise; otherwise the same
     // point goes through a full pass next.
     g.f("    if (a.confirm == 0 && !wave_any(!done && !want_light)) {");
-    for (int F = 0; F < nf; ++F) g.f("      p%d = x%d + dx%d;", P.free_point[F], F, F);
+    for (int F = 0; F < nf; ++F) g.f("      p%d = x%d + dx%d;", ev.fp(F), F, F);
     g.out += light_src;
     g.f("      const double Fl = 0.5 * ss;");
     g.f("      if (!done) {");
     g.f("        ++nfev;");
     g.f("        if (Fl == Fl && Fl <= Fc * (1.0 + 1e-6) + 1e-28) {");
-    for (int F = 0; F < nf; ++F) g.f("          x%d = p%d;", F, P.free_point[F]);
+    for (int F = 0; F < nf; ++F) g.f("          x%d = p%d;", F, ev.fp(F));
     g.f("          Fc = Fl; mres = mres_new; last_step = step_len; flags |= INFO_CONVERGED; done = true;");
     g.f("        } else {");
     g.f("          want_light = false;");
@@ -1141,7 +1172,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
     g.f("    want_light = false;  // mixed wavefront: everybody takes the full pass");
   }
   // evaluation point
-  for (int F = 0; F < nf; ++F) g.f("    p%d = mode == 2 ? x%d : x%d + dx%d;", P.free_point[F], F, F, F);
+  for (int F = 0; F < nf; ++F) g.f("    p%d = mode == 2 ? x%d : x%d + dx%d;", ev.fp(F), F, F, F);
   g.out += eval_src;
   g.f("    const double Ft = 0.5 * ss;");
   // LM decision (mirrors okx_solve_kernel)
@@ -1171,7 +1202,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("      if (stop) flags |= INFO_CONVERGED;");
   g.f("      if (accept) {");
   g.f("        if (mode != 2) {");
-  for (int F = 0; F < nf; ++F) g.f("          x%d = p%d;", F, P.free_point[F]);
+  for (int F = 0; F < nf; ++F) g.f("          x%d = p%d;", F, ev.fp(F));
   g.f("          if (mode == 1) last_step = step_len;");
   g.f("          nu = 2.0;");
   g.f("        }");
@@ -1246,7 +1277,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("      }  // LM passes");
   // final state and output
   g.f("      {");
-  for (int F = 0; F < nf; ++F) g.f("    p%d = x%d;", P.free_point[F], F);
+  for (int F = 0; F < nf; ++F) g.f("    p%d = x%d;", ev.fp(F), F);
   Gen fin(P);
   fin.uid = 100000;
   fin.hoisted_names = ev.hoisted_names;
@@ -1287,7 +1318,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   // chains never continue from a state that failed to converge
   for (int t = 0; t < T; ++t) g.f("    tq%d = tp%d; tp%d = tv%d;", t, t, t, t);
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
-  for (int F = 0; F < nf; ++F) g.f("      x%d = c < 3 ? gp[%d + cc] : 0.0;", F, 3 * P.free_point[F]);
+  for (int F = 0; F < nf; ++F) g.f("      x%d = c < 3 ? gp[%d + cc] : 0.0;", F, 3 * ev.fp(F));
   g.f("      hist = 0; lambda_carry = 0.0;");
   g.f("    } else {");
   g.f("      if (hist < 2) ++hist;");
@@ -1310,7 +1341,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("    long long bb = wu * 16 + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");
   for (int p = 0; p < NP; ++p)
     if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
-  for (int F = 0; F < nf; ++F) g.f("    p%d = c < 3 ? a.x[bb * %d + %d + cc] : 0.0;", P.free_point[F], 3 * nf, 3 * F);
+  for (int F = 0; F < nf; ++F) g.f("    p%d = c < 3 ? a.x[bb * %d + %d + cc] : 0.0;", ev.fp(F), 3 * nf, 3 * ev.perm[F]);
   for (int t = 0; t < T; ++t) g.f("    const double tv%d = a.targets[bb * %d + %d];", t, T, t);
   g.out += eval_src;
   g.f("    if (valid && c == 0) {");
@@ -1318,11 +1349,12 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("    }");
   g.f("    if (valid && c < 3) {");
   for (int F = 0; F < nf; ++F) {
-    g.f("      a.atr[bb * %d + %d + c] = gn%d;", 3 * nf, 3 * F, F);
+    g.f("      a.atr[bb * %d + %d + c] = gn%d;", 3 * nf, 3 * ev.perm[F], F);
     for (int G = 0; G <= F; ++G)
       if (ev.nz[F][G])
         for (int k = 0; k < 3; ++k)
-          g.f("      a.ata[(bb * %d + %d + c) * %d + %d] = %s;", 3 * nf, 3 * F, 3 * nf, 3 * G + k, Gen::A(F, G, k).c_str());
+          g.f("      a.ata[(bb * %d + %d + c) * %d + %d] = %s;", 3 * nf, 3 * ev.perm[F], 3 * nf, 3 * ev.perm[G] + k,
+              Gen::A(F, G, k).c_str());
   }
   g.f("    }");
   g.f("    const double lambda = a.lambda;");
@@ -1336,7 +1368,8 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
       }
   g.out += solve_src;
   g.f("    if (valid && c < 3) {");
-  for (int F = 0; F < nf; ++F) g.f("      a.dx[bb * %d + %d + c] = ok ? nx%d : __builtin_nan(\"\");", 3 * nf, 3 * F, F);
+  for (int F = 0; F < nf; ++F)
+    g.f("      a.dx[bb * %d + %d + c] = ok ? nx%d : __builtin_nan(\"\");", 3 * nf, 3 * ev.perm[F], F);
   g.f("    }");
   g.f("  }");
   g.f("}");
@@ -1345,7 +1378,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   std::vector<int> out_index(NP, -1);
   for (int k = 0; k < P.n_out; ++k) out_index[P.out_point[k]] = k;
   bool tangent_ok = T > 0;
-  for (int F = 0; F < nf; ++F) tangent_ok = tangent_ok && out_index[P.free_point[F]] >= 0;
+  for (int F = 0; F < nf; ++F) tangent_ok = tangent_ok && out_index[ev.fp(F)] >= 0;
   if (tangent_ok) {
     ev.out.clear();
     ev.uid = 200000;
@@ -1374,7 +1407,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
     for (int p = 0; p < NP; ++p)
       if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
     for (int F = 0; F < nf; ++F)
-      g.f("    p%d = c < 3 ? a.pos[bb * %d + %d + cc] : 0.0;", P.free_point[F], 3 * P.n_out, 3 * out_index[P.free_point[F]]);
+      g.f("    p%d = c < 3 ? a.pos[bb * %d + %d + cc] : 0.0;", ev.fp(F), 3 * P.n_out, 3 * out_index[ev.fp(F)]);
     for (int t = 0; t < T; ++t) g.f("    const double tv%d = 0.0;  // target values do not enter the Jacobian", t);
     g.out += eval_src;
     g.out += rest_src;
