@@ -38,6 +38,7 @@ struct okx_program {
   hipFunction_t quad_fn_eval;  // parity kernel
   hipFunction_t quad_fn_tan_u, quad_fn_tan_g;  // tangents (null when a free point is not an output point)
   int quad_waves_per_cu;
+  int quad_ppw;             // problems per wavefront: 16 (one quad each) or 8 (pair mode: one quad per half)
   char quad_note[256];      // why the quad kernel is not in use (empty when it is)
 };
 
@@ -168,6 +169,7 @@ void attach_quad_kernel(okx_program* p) {
   p->quad_fn_eval = nullptr;
   p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
   p->quad_waves_per_cu = 0;
+  p->quad_ppw = p->host.n_free > okx::kQuadMaxFree ? 8 : 16;
   p->quad_note[0] = 0;
   if (const char* env = getenv("OKX_QUAD")) {
     if (env[0] == '0') {
@@ -217,6 +219,7 @@ void attach_quad_kernel(okx_program* p) {
   if (hipModuleGetFunction(&p->quad_fn_tan_u, mod, "okx_quad_tangent_u") != hipSuccess ||
       hipModuleGetFunction(&p->quad_fn_tan_g, mod, "okx_quad_tangent_g") != hipSuccess)
     p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
+  (void)hipGetLastError();  // optional kernels absent from a module must not leave a sticky error behind
   p->quad_waves_per_cu = 4 * per_simd;
 }
 
@@ -404,7 +407,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   bool use_quad = p->quad_fn_u != nullptr && (opts->kernel == 0 || opts->kernel == 3);
   if (opts->kernel == 3 && !use_quad)
     return fail(OKX_ERR_INVALID, "quad kernel requested but not available: %s", p->quad_note);
-  const long long quad_slots = (long long)p->n_cu * p->quad_waves_per_cu * 16;
+  const long long quad_slots = (long long)p->n_cu * p->quad_waves_per_cu * p->quad_ppw;
   bool use_packed = false;
   if (p->packed_fn && !use_quad) {
     if (opts->kernel == 2) use_packed = true;
@@ -461,7 +464,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
     q.trace = g_quad_trace;
     q.trace_problem = g_quad_trace_problem;
-    const long long wave_units = (units + 15) / 16;
+    const long long wave_units = (units + p->quad_ppw - 1) / p->quad_ppw;
     const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
     const int grid = (int)(wave_units < cap ? (wave_units < 1 ? 1 : wave_units) : cap);
     void* kargs[] = {(void*)&q};

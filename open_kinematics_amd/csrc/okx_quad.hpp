@@ -3,12 +3,14 @@
 #pragma once
 
 #include <string>
+#include <vector>
 
 #include "okx_plan.hpp"
 
 namespace okx {
 
-constexpr int kQuadMaxFree = 8;  // n <= 24 unknowns: the lane-owned rows of J^T J stay in registers
+constexpr int kQuadMaxFree = 8;          // n <= 24 unknowns: the lane-owned rows of J^T J stay in registers
+constexpr int kQuadMaxFreePerSide = 10;  // pair mode (two identical halves, one quad each): free points per half
 
 // Kernel arguments of the generated kernels (mirrors `struct QArgs` in the generated source).
 struct QuadArgs {
@@ -54,6 +56,23 @@ struct QuadTanArgs {
   const double* row_param;
   const double* dop_param;
 };
+
+// A program made of two structurally identical halves joined by one distance row (the composed
+// axle), seen as its half ("side") program plus the index maps of both sides (okx_pairview.cpp).
+struct PairView {
+  DevProgram side;             // side-0 sub-program in its own point / row numbering; targets = union of both sides
+  std::vector<int> pt[2];      // side point -> program point
+  std::vector<int> row[2];     // side constraint row -> program constraint row
+  std::vector<int> tgt[2];     // side target -> program target index, -1: that side has no such target
+  std::vector<int> dop[2];     // side derived op -> program derived op
+  std::vector<int> out[2];     // side output k -> index in the program's output list, -1: not written by that side
+  std::vector<int> shared_out; // output-list indices of fixed points neither half owns (written once)
+  std::vector<int> shared_pt;  // their program point indices
+  int couple_point;            // side point (free) joined to its mirror image by the coupling row
+  int couple_row;              // program constraint row of that distance
+  int n_prog_points, n_prog_crows, n_prog_targets, n_prog_out;
+};
+bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why);
 
 // Emits the HIP source of the kernel specialised to `P`.  Returns false (and says why) when the
 // program uses a feature the generator has no code path for; the caller then keeps the generic

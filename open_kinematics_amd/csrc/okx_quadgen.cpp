@@ -58,7 +58,7 @@ struct BlkTerm {
 
 class Gen {
  public:
-  explicit Gen(const DevProgram& prog) : P(prog) {
+  explicit Gen(const DevProgram& prog, const PairView* pair = nullptr) : P(prog), pv(pair) {
     blk_of_point.assign(P.n_points, -1);
     dop_of_point.assign(P.n_points, -1);
     elimination_order();
@@ -97,8 +97,45 @@ class Gen {
   }
 
   const DevProgram& P;
+  const PairView* pv;  // non-null: P is the side program of a two-sided problem (okx_pairview.cpp)
   std::string out;
   std::string why;
+
+  // Index of program data as seen by a lane: one literal, or in pair mode a select on the side bit
+  // q1 (all such accesses are chain-constant loads or record stores, never inside the LM passes).
+  static std::string sel(int i0, int i1) {
+    if (i0 == i1) return std::to_string(i0);
+    return "(q1 ? " + std::to_string(i1) + " : " + std::to_string(i0) + ")";
+  }
+  std::string point3(int p) const {  // 3 * point index into gp / design_pos
+    return pv ? sel(3 * pv->pt[0][p], 3 * pv->pt[1][p]) : std::to_string(3 * p);
+  }
+  std::string crow8(int i, int k) const {  // constraint row parameter offset into gq
+    return pv ? sel(8 * pv->row[0][i] + k, 8 * pv->row[1][i] + k) : std::to_string(8 * i + k);
+  }
+  int target_of_row(int i) const { return (int)P.row_param[i][3]; }
+  std::string trow8(int i, int k) const {  // target row parameter offset into a.row_param
+    if (!pv) return std::to_string(8 * i + k);
+    const int t = target_of_row(i);
+    int t0 = pv->tgt[0][t], t1 = pv->tgt[1][t];
+    if (t0 < 0) t0 = t1;
+    if (t1 < 0) t1 = t0;
+    return sel(8 * (pv->n_prog_crows + t0) + k, 8 * (pv->n_prog_crows + t1) + k);
+  }
+  std::string target_slot(int t) const {  // column of a.targets
+    if (!pv) return std::to_string(t);
+    int t0 = pv->tgt[0][t], t1 = pv->tgt[1][t];
+    if (t0 < 0) t0 = t1;
+    if (t1 < 0) t1 = t0;
+    return sel(t0, t1);
+  }
+  std::string target_enable(int t) const {  // 1.0 where this side really has target t
+    if (!pv) return "1.0";
+    const bool e0 = pv->tgt[0][t] >= 0, e1 = pv->tgt[1][t] >= 0;
+    if (e0 && e1) return "1.0";
+    return e0 ? "(q1 ? 0.0 : 1.0)" : "(q1 ? 1.0 : 0.0)";
+  }
+  std::string dop_slot(int e) const { return pv ? sel(pv->dop[0][e], pv->dop[1][e]) : std::to_string(e); }
   std::vector<int> blk_of_point, dop_of_point;
   int uid = 0;
   std::map<std::string, std::string> rot1_, rot2_;
@@ -398,9 +435,9 @@ class Gen {
     auto key = std::make_pair(-1 - e, 0);
     auto it = hoisted_names.find(key);
     if (it != hoisted_names.end()) return it->second;
-    char name[48], line[160];
+    char name[48], line[200];
     std::snprintf(name, sizeof(name), "hd%d", e);
-    std::snprintf(line, sizeof(line), "      const double %s = a.dop_param[%d];\n", name, e);
+    std::snprintf(line, sizeof(line), "      const double %s = a.dop_param[%s];\n", name, dop_slot(e).c_str());
     hoisted += line;
     hoisted_names[key] = name;
     return name;
@@ -415,12 +452,12 @@ class Gen {
     auto key = std::make_pair(i, 100 + k);
     auto it = hoisted_names.find(key);
     if (it != hoisted_names.end()) return it->second;
-    char name[48], line[160];
+    char name[48], line[200];
     std::snprintf(name, sizeof(name), "hs%d_%d", i, k);
     if (i < P.n_crows)
-      std::snprintf(line, sizeof(line), "      const double %s = gq[%d];\n", name, i * 8 + k);
+      std::snprintf(line, sizeof(line), "      const double %s = gq[%s];\n", name, crow8(i, k).c_str());
     else
-      std::snprintf(line, sizeof(line), "      const double %s = a.row_param[%d];\n", name, i * 8 + k);
+      std::snprintf(line, sizeof(line), "      const double %s = a.row_param[%s];\n", name, trow8(i, k).c_str());
     hoisted += line;
     hoisted_names[key] = name;
     return name;
@@ -435,12 +472,13 @@ class Gen {
     auto key = std::make_pair(i, k0);
     auto it = hoisted_names.find(key);
     if (it != hoisted_names.end()) return it->second;
-    char name[48], line[160];
+    char name[48], line[200];
     std::snprintf(name, sizeof(name), "hq%d_%d", i, k0);
     if (i < P.n_crows)
-      std::snprintf(line, sizeof(line), "      const double %s = c < 3 ? gq[%d + cc] : 0.0;\n", name, i * 8 + k0);
-    else
-      std::snprintf(line, sizeof(line), "      const double %s = c < 3 ? a.row_param[%d + cc] : 0.0;\n", name, i * 8 + k0);
+      std::snprintf(line, sizeof(line), "      const double %s = c < 3 ? gq[%s + cc] : 0.0;\n", name, crow8(i, k0).c_str());
+    else  // target direction; zero on a side that does not carry this target (pair mode)
+      std::snprintf(line, sizeof(line), "      const double %s = c < 3 ? a.row_param[%s + cc] * %s : 0.0;\n", name,
+                    trow8(i, k0).c_str(), target_enable(target_of_row(i)).c_str());
     hoisted += line;
     hoisted_names[key] = name;
     return name;
@@ -674,7 +712,8 @@ class Gen {
       case kRowTarget: {  // solver.py:264-270, :560-579
         std::string dir = rpv(i, 0);
         std::string d = dot(pn(pts[0]), dir);
-        f("    const double %s = %s - tv%d;", r.c_str(), d.c_str(), (int)P.row_param[i][3]);
+        f("    const double %s = %s - %s * tv%d;", r.c_str(), d.c_str(), target_enable(target_of_row(i)).c_str(),
+          target_of_row(i));
         ro->partial.push_back({pts[0], {dir, 1}});
         return true;
       }
@@ -1027,20 +1066,35 @@ DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 }  // namespace
 
-bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why) {
-  if (P.n_free > kQuadMaxFree) {
-    *why = "more than " + std::to_string(kQuadMaxFree) + " free points";
-    return false;
+bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* src, std::string* why) {
+  // Small programs: one quad per problem.  Larger ones only when they are two identical halves
+  // joined by one distance row (composed axle): one quad per half, Sherman-Morrison for the joint.
+  PairView pair_store;
+  const PairView* pv = nullptr;
+  if (program.n_free > kQuadMaxFree) {
+    std::string pair_why;
+    if (!build_pair_view(program, &pair_store, &pair_why) || pair_store.side.n_free > kQuadMaxFreePerSide) {
+      *why = "more than " + std::to_string(kQuadMaxFree) + " free points and not a pair of identical halves (" +
+             (pair_why.empty() ? "halves too large" : pair_why) + ")";
+      return false;
+    }
+    pv = &pair_store;
   }
+  const DevProgram& P = pv ? pv->side : program;
   if (P.n_targets > kMaxTargets) {
     *why = "too many targets";
     return false;
   }
-  Gen g(P);
+  Gen g(P, pv);
   const int nf = P.n_free, NP = P.n_points, T = P.n_targets;
+  const int PPW = pv ? 8 : 16;                                  // problems per wavefront
+  const int prog_points = pv ? pv->n_prog_points : NP;          // strides of the caller's tables
+  const int prog_crows = pv ? pv->n_prog_crows : P.n_crows;
+  const int prog_targets = pv ? pv->n_prog_targets : T;
+  const int prog_out = pv ? pv->n_prog_out : P.n_out;
 
   // ---- evaluation body (rows + normal equations), generated first to learn the sparsity ----
-  Gen ev(P);
+  Gen ev(P, pv);
   for (int e = 0; e < P.n_derived; ++e) ev.dp(e);  // every derived-op parameter is chain-constant
   ev.f("    // ---- active derived points with chain-rule blocks ----");
   for (int idx = 0; idx < P.n_active; ++idx)
@@ -1064,7 +1118,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   for (int i = 0; i < P.n_crows; ++i) light_ok = light_ok && P.row_type[i] != OKX_ROW_POINT_ON_LINE;
   std::string light_src;
   if (light_ok) {
-    Gen lt(P);
+    Gen lt(P, pv);
     lt.uid = 300000;
     lt.hoisted_names = ev.hoisted_names;  // same chain-constant loads, already emitted
     for (int idx = 0; idx < P.n_active; ++idx)
@@ -1072,6 +1126,33 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
     if (light_ok && !lt.emit_rows_residual_only()) light_ok = false;
     if (!lt.hoisted.empty()) light_ok = false;  // would need loads the main body did not hoist
     light_src = lt.out;
+  }
+
+  // ---- pair mode: the row joining the two halves (distance between a point and its mirror image) ----
+  // Each side sees d = partner - own; residual and cost terms are bit-identical on both sides
+  // (squares of opposite-signed differences, commutative sums), the Jacobian entries live in the
+  // joined point's block only and never enter the per-side J^T J: Sherman-Morrison handles them.
+  std::string couple_eval, couple_light, couple_hoist;
+  int FU = -1;
+  if (pv) {
+    FU = ev.blk_of_point[pv->couple_point];
+    char buf[1024];
+    std::snprintf(buf, sizeof(buf), "      const double hcL = gq[%d];  // length of the joining row\n", 8 * pv->couple_row);
+    couple_hoist = buf;
+    std::snprintf(buf, sizeof(buf),
+                  "    const double cd = xq(p%d) - p%d;\n"
+                  "    const double cs = qsum(cd * cd);\n"
+                  "    double crt, cinv; fast_sqrt_rsqrt(cs + EPS_SQ, &crt, &cinv);\n"
+                  "    const double rc = (crt - EPS) - hcL;\n",
+                  pv->couple_point, pv->couple_point);
+    couple_light = buf;
+    couple_light += "    ss = (ss + xq(ss)) + rc * rc;\n    mres_new = fmax(fmax(mres_new, xq(mres_new)), fabs(rc));\n";
+    couple_eval = buf;
+    std::snprintf(buf, sizeof(buf),
+                  "    const double cu = -cd * cinv;  // d rc / d (own joined point), lane component\n"
+                  "    gn%d = fma(cu, rc, gn%d);\n", FU, FU);
+    couple_eval += buf;
+    couple_eval += "    ss = (ss + xq(ss)) + rc * rc;\n    mres_new = fmax(fmax(mres_new, xq(mres_new)), fabs(rc));\n";
   }
 
   // which points must live in registers
@@ -1089,16 +1170,37 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
 
   g.out += kPreamble;
   g.f("");
+  if (pv) {
+    g.f("// Two quads own one problem: `xq` reads the other quad's lane with the same component");
+    g.f("// (ds_swizzle, lane ^ 4: data path only, no LDS memory); PSUM / PMAX reduce over both quads and");
+    g.f("// are bit-identical in all eight lanes (commutative combination of the two quad results).");
+    g.f("DEV double xq(double v) {");
+    g.f("  int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x101F);");
+    g.f("  int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x101F);");
+    g.f("  return __hiloint2double(hi, lo);");
+    g.f("}");
+    g.f("DEV double PSUM(double v) { const double s = qsum(v); return s + xq(s); }");
+    g.f("DEV double PMAX(double v) { const double s = qmax(v); return fmax(s, xq(s)); }");
+    g.f("#define PJOIN_SUM(v) ((v) + xq(v))");
+  } else {
+    g.f("#define PSUM(v) qsum(v)");
+    g.f("#define PMAX(v) qmax(v)");
+    g.f("#define PJOIN_SUM(v) (v)");
+  }
+  g.f("");
   g.f("template <bool PG> DEV void okx_quad_body(const QArgs& a) {");
-  g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+  if (pv)
+    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1 = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
+  else
+    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
   g.f("  const long long spg = a.steps_per_geometry;");
   g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
   g.f("  const long long unit_len = a.chain_len;");
   g.f("  const long long chains_per_span = unit_len == 1 ? span : (span + unit_len - 1) / unit_len;");
   g.f("  const long long n_units = spg > 0 ? (a.n_problems / span) * chains_per_span : chains_per_span;");
-  g.f("  for (long long wu = blockIdx.x; wu * 16 < n_units; wu += gridDim.x) {");
-  g.f("    long long unit = wu * 16 + quad;");
+  g.f("  for (long long wu = blockIdx.x; wu * %d < n_units; wu += gridDim.x) {", PPW);
+  g.f("    long long unit = wu * %d + quad;", PPW);
   g.f("    const bool have = unit < n_units;");
   g.f("    if (!have) unit = n_units - 1;");
   // (64-bit divisions are ~100 instructions each: only ensembles with chains need them)
@@ -1110,31 +1212,34 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("    const long long first_b = span_idx * span + chain_in_span * unit_len;");
   g.f("    const long long last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
   g.f("    const long long geom = span_idx;");
-  g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * NP);
-  g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * P.n_crows);
+  g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * prog_points);
+  g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * prog_crows);
   g.f("    // chain-constant lane-component parameters (line points / directions, target directions)");
   g.out += ev.hoisted;
+  g.out += couple_hoist;
   // point registers
   for (int p = 0; p < NP; ++p)
-    if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
+    if (used[p]) g.f("    double p%d = c < 3 ? gp[%s + cc] : 0.0;", p, ev.point3(p).c_str());
   for (int F = 0; F < nf; ++F) g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0;", F, ev.fp(F), F, F, F);
   g.f("    int hist = 0;");
   g.f("    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)");
   // targets: the next step's values are fetched while the current step is being solved, and the two
   // previous steps' values (secant predictor) stay in registers
   for (int t = 0; t < T; ++t)
-    g.f("    double tn%d = a.targets[first_b * %d + %d], tp%d = 0.0, tq%d = 0.0;", t, T, t, t, t);
+    g.f("    double tn%d = a.targets[first_b * %d + %s], tp%d = 0.0, tq%d = 0.0;", t, prog_targets, ev.target_slot(t).c_str(), t, t);
   g.f("    for (long long b = first_b; wave_any(have && b < last_b); ++b) {");
   g.f("      const bool valid = have && b < last_b;");
   g.f("      const long long bb = valid ? b : last_b - 1;");
   g.f("      const long long nb = b + 1 < last_b ? b + 1 : last_b - 1;");
   for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
-  for (int t = 0; t < T; ++t) g.f("      tn%d = a.targets[nb * %d + %d];", t, T, t);
+  for (int t = 0; t < T; ++t) g.f("      tn%d = a.targets[nb * %d + %s];", t, prog_targets, ev.target_slot(t).c_str());
   // secant predictor: x + alpha (x - xp), alpha from the target increments
   g.f("      if (hist >= 2) {");
   g.f("        double num = 0.0, den = 0.0;");
   for (int t = 0; t < T; ++t)
-    g.f("        num = fma(tv%d - tp%d, tp%d - tq%d, num); den = fma(tp%d - tq%d, tp%d - tq%d, den);", t, t, t, t, t, t, t, t);
+    g.f("        num = fma(%s * (tv%d - tp%d), tp%d - tq%d, num); den = fma(%s * (tp%d - tq%d), tp%d - tq%d, den);",
+        ev.target_enable(t).c_str(), t, t, t, t, ev.target_enable(t).c_str(), t, t, t, t);
+  g.f("        num = PJOIN_SUM(num); den = PJOIN_SUM(den);  // pair mode: targets of both halves");
   g.f("        double alpha = den > 0.0 ? num / den : 0.0;");
   g.f("        alpha = fmin(fmax(alpha, 0.0), 2.0);");
   for (int F = 0; F < nf; ++F)
@@ -1157,6 +1262,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
     g.f("    if (a.confirm == 0 && !wave_any(!done && !want_light)) {");
     for (int F = 0; F < nf; ++F) g.f("      p%d = x%d + dx%d;", ev.fp(F), F, F);
     g.out += light_src;
+    g.out += couple_light;
     g.f("      const double Fl = 0.5 * ss;");
     g.f("      if (!done) {");
     g.f("        ++nfev;");
@@ -1174,6 +1280,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   // evaluation point
   for (int F = 0; F < nf; ++F) g.f("    p%d = mode == 2 ? x%d : x%d + dx%d;", ev.fp(F), F, F, F);
   g.out += eval_src;
+  g.out += couple_eval;
   g.f("    const double Ft = 0.5 * ss;");
   // LM decision (mirrors okx_solve_kernel)
   g.f("    bool accept = true, stop = false;");
@@ -1191,11 +1298,11 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   for (int F = 0; F < nf; ++F)
     g.f("      diag = fmax(diag, c == 0 ? %s : (c == 1 ? %s : (c == 2 ? %s : 0.0)));", Gen::A(F, F, 0).c_str(),
         Gen::A(F, F, 1).c_str(), Gen::A(F, F, 2).c_str());
-  g.f("      diag = qmax(diag);");
+  g.f("      diag = PMAX(diag);");
   g.f("    }");
   g.f("    if (a.grad_tol > 0.0) {");
   for (int F = 0; F < nf; ++F) g.f("      gm = fmax(gm, fabs(gn%d));", F);
-  g.f("      gm = qmax(gm);");
+  g.f("      gm = PMAX(gm);");
   g.f("    }");
   g.f("    if (!done) {");
   g.f("      ++nfev;");
@@ -1244,12 +1351,39 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
         }
       }
   // the diagonal-block factor entry for k == 2 is never needed (no row below inside the block)
-  g.out += solve_src;
+  if (!pv) {
+    g.out += solve_src;
+  } else {
+    // (D + w w^T) dx = -g with D = blockdiag of the two halves' damped J^T J and w the joining row's
+    // Jacobian: dx = y - z (w.y) / (1 + w.z), D y = -g, D z = w (Sherman-Morrison).
+    ev.out.clear();
+    ev.emit_factor();
+    g.out += ev.out;
+    g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
+    g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
+    std::vector<std::string> rhs_g, rhs_w;
+    for (int F = 0; F < nf; ++F) rhs_g.push_back("-gn" + std::to_string(F)), rhs_w.push_back(F == FU ? "cu" : "0.0");
+    for (int F = 0; F < nf; ++F) g.f("    double ny%d, nz%d;", F, F);
+    ev.out.clear();
+    ev.emit_substitute(rhs_g, "sy");
+    g.f("    {");
+    g.out += ev.out;
+    for (int F = 0; F < nf; ++F) g.f("    ny%d = sy%d;", F, F);
+    g.f("    }");
+    ev.out.clear();
+    ev.emit_substitute(rhs_w, "sz");
+    g.f("    {");
+    g.out += ev.out;
+    for (int F = 0; F < nf; ++F) g.f("    nz%d = sz%d;", F, F);
+    g.f("    }");
+    g.f("    const double sm_k = PSUM(cu * ny%d) / (1.0 + PSUM(cu * nz%d));", FU, FU);
+    for (int F = 0; F < nf; ++F) g.f("    const double nx%d = fma(-nz%d, sm_k, ny%d);", F, F, F);
+  }
   g.f("    double sl = 0.0, pr = 0.0;");
   for (int F = 0; F < nf; ++F) g.f("    sl = fmax(sl, fabs(nx%d));", F);
-  g.f("    sl = qmax(sl);");
+  g.f("    sl = PMAX(sl);");
   for (int F = 0; F < nf; ++F) g.f("    pr = fma(nx%d, fma(lambda, nx%d, -gn%d), pr);", F, F, F);
-  g.f("    pr = 0.5 * qsum(pr);  // predicted cost reduction of this step (gain-ratio denominator)");
+  g.f("    pr = 0.5 * PSUM(pr);  // predicted cost reduction of this step (gain-ratio denominator)");
   g.f("    if (solve_now) {");
   g.f("      ++iters;");
   g.f("      if (ok) {");
@@ -1278,7 +1412,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   // final state and output
   g.f("      {");
   for (int F = 0; F < nf; ++F) g.f("    p%d = x%d;", ev.fp(F), F);
-  Gen fin(P);
+  Gen fin(P, pv);
   fin.uid = 100000;
   fin.hoisted_names = ev.hoisted_names;
   for (int e = 0; e < P.n_derived; ++e)
@@ -1292,6 +1426,21 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   // consecutive, so their records form one contiguous block; it is transposed through LDS and
   // written with full-width 16-byte-per-lane stores.  Chains: a quad's problems are far apart in
   // memory, each lane stores its own 8-byte components.
+  if (pv) {
+    g.f("    if (valid && c < 3) {");
+    g.f("      double* o = a.out_pos + bb * %d + c;", 3 * prog_out);
+    for (int k = 0; k < P.n_out; ++k) {
+      const int k0 = pv->out[0][k], k1 = pv->out[1][k];
+      if (k1 >= 0)
+        g.f("      o[%s] = p%d;", Gen::sel(3 * k0, 3 * k1).c_str(), P.out_point[k]);
+      else
+        g.f("      if (!q1) o[%d] = p%d;", 3 * k0, P.out_point[k]);
+    }
+    for (size_t k = 0; k < pv->shared_out.size(); ++k)
+      g.f("      if (!q1) o[%d] = gp[%d + c];", 3 * pv->shared_out[k], 3 * pv->shared_pt[k]);
+    g.f("    }");
+    g.f("    if (false) {");
+  } else {
   g.f("    if (unit_len == 1) {");
   g.f("      __shared__ double stage[16 * %d];", 3 * P.n_out);
   g.f("      if (c < 3) {");
@@ -1309,8 +1458,9 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("    } else if (valid && c < 3) {");
   g.f("      double* o = a.out_pos + bb * %d + c;", 3 * P.n_out);
   for (int k = 0; k < P.n_out; ++k) g.f("      o[%d] = p%d;", 3 * k, P.out_point[k]);
+  }
   g.f("    }");
-  g.f("    if (valid && c == 0) {");
+  g.f("    if (valid && c == 0%s) {", pv ? " && !q1" : "");
   g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
   g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
   g.f("      a.info[bb] = inf;");
@@ -1318,7 +1468,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   // chains never continue from a state that failed to converge
   for (int t = 0; t < T; ++t) g.f("    tq%d = tp%d; tp%d = tv%d;", t, t, t, t);
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
-  for (int F = 0; F < nf; ++F) g.f("      x%d = c < 3 ? gp[%d + cc] : 0.0;", F, 3 * ev.fp(F));
+  for (int F = 0; F < nf; ++F) g.f("      x%d = c < 3 ? gp[%s + cc] : 0.0;", F, ev.point3(ev.fp(F)).c_str());
   g.f("      hist = 0; lambda_carry = 0.0;");
   g.f("    } else {");
   g.f("      if (hist < 2) ++hist;");
@@ -1329,6 +1479,7 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("  }  // wave units");
   g.f("}");
   g.f("");
+  if (!pv) {
   // ---- parity / debug kernel: r, J^T J, J^T r at given x, and the damped step for a given lambda ----
   g.f("struct QEvalArgs { const double* x; const double* targets; double* r; double* ata; double* atr; double* dx;");
   g.f("  double lambda; long long n_problems; const double* design_pos; const double* row_param; const double* dop_param; };");
@@ -1374,10 +1525,11 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
   g.f("  }");
   g.f("}");
   g.f("");
+  }
   // ---- solution-manifold tangents (reference sensitivity.py:57-143): one kernel, B solved states ----
   std::vector<int> out_index(NP, -1);
   for (int k = 0; k < P.n_out; ++k) out_index[P.out_point[k]] = k;
-  bool tangent_ok = T > 0;
+  bool tangent_ok = T > 0 && !pv;  // pair mode: the interpreter's tangent kernel serves those programs
   for (int F = 0; F < nf; ++F) tangent_ok = tangent_ok && out_index[ev.fp(F)] >= 0;
   if (tangent_ok) {
     ev.out.clear();
