@@ -437,10 +437,11 @@ class Gen {
     if (it != hoisted_names.end()) return it->second;
     char name[48], line[200];
     std::snprintf(name, sizeof(name), "hd%d", e);
-    std::snprintf(line, sizeof(line), "      const double %s = a.dop_param[%s];\n", name, dop_slot(e).c_str());
+    const std::string home = scalar_home(name);
+    std::snprintf(line, sizeof(line), "      %s%s = a.dop_param[%s];\n", decl(), home.c_str(), dop_slot(e).c_str());
     hoisted += line;
-    hoisted_names[key] = name;
-    return name;
+    hoisted_names[key] = home;
+    return home;
   }
 
   // Scalar row parameter (length, angle, volume ...): constant for a whole chain, so it is loaded
@@ -454,19 +455,35 @@ class Gen {
     if (it != hoisted_names.end()) return it->second;
     char name[48], line[200];
     std::snprintf(name, sizeof(name), "hs%d_%d", i, k);
+    const std::string home = scalar_home(name);
     if (i < P.n_crows)
-      std::snprintf(line, sizeof(line), "      const double %s = gq[%s];\n", name, crow8(i, k).c_str());
+      std::snprintf(line, sizeof(line), "      %s%s = gq[%s];\n", decl(), home.c_str(), crow8(i, k).c_str());
     else
-      std::snprintf(line, sizeof(line), "      const double %s = a.row_param[%s];\n", name, trow8(i, k).c_str());
+      std::snprintf(line, sizeof(line), "      %s%s = a.row_param[%s];\n", decl(), home.c_str(), trow8(i, k).c_str());
     hoisted += line;
-    hoisted_names[key] = name;
-    return name;
+    hoisted_names[key] = home;
+    return home;
   }
   // Lane-component load of three consecutive row parameters (0 in lane 3).  These are constant
   // for a whole chain (geometry), so they are emitted into `hoisted`, which the kernel places
   // in front of the Levenberg-Marquardt loop, one load per distinct (row, offset).
   std::string hoisted;
   std::map<std::pair<int, int>, std::string> hoisted_names;
+  // Pair mode keeps the chain constants in LDS instead of registers (the half program of an axle
+  // has ~50 of them and the kernel is register-bound): scalars in hsl[slot][quad-side], lane
+  // components in hql[slot][lane]; a lane only ever reads what it (or a lane of its own quad, with
+  // the same value) wrote, in program order, so no barrier is involved.
+  bool lds_constants = false;
+  int n_scalar_slots = 0, n_lane_slots = 0;
+  std::string scalar_home(const char* name) {
+    if (!lds_constants) return name;
+    return "hsl[" + std::to_string(16 * n_scalar_slots++) + " + qs]";
+  }
+  std::string lane_home(const char* name) {
+    if (!lds_constants) return name;
+    return "hql[" + std::to_string(64 * n_lane_slots++) + " + lane]";
+  }
+  const char* decl() const { return lds_constants ? "" : "const double "; }
   std::string rpv(int i, int k0) {
     i = pin_leader(i);
     auto key = std::make_pair(i, k0);
@@ -474,14 +491,15 @@ class Gen {
     if (it != hoisted_names.end()) return it->second;
     char name[48], line[200];
     std::snprintf(name, sizeof(name), "hq%d_%d", i, k0);
+    const std::string home = lane_home(name);
     if (i < P.n_crows)
-      std::snprintf(line, sizeof(line), "      const double %s = c < 3 ? gq[%s + cc] : 0.0;\n", name, crow8(i, k0).c_str());
+      std::snprintf(line, sizeof(line), "      %s%s = c < 3 ? gq[%s + cc] : 0.0;\n", decl(), home.c_str(), crow8(i, k0).c_str());
     else  // target direction; zero on a side that does not carry this target (pair mode)
-      std::snprintf(line, sizeof(line), "      const double %s = c < 3 ? a.row_param[%s + cc] * %s : 0.0;\n", name,
+      std::snprintf(line, sizeof(line), "      %s%s = c < 3 ? a.row_param[%s + cc] * %s : 0.0;\n", decl(), home.c_str(),
                     trow8(i, k0).c_str(), target_enable(target_of_row(i)).c_str());
     hoisted += line;
-    hoisted_names[key] = name;
-    return name;
+    hoisted_names[key] = home;
+    return home;
   }
   // The three LINE_PIN rows that one point-on-line constraint flattens into (same point, same
   // line in the program's own geometry, components 0/1/2) share their line parameters and their
@@ -1095,6 +1113,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
 
   // ---- evaluation body (rows + normal equations), generated first to learn the sparsity ----
   Gen ev(P, pv);
+  ev.lds_constants = pv != nullptr;
   for (int e = 0; e < P.n_derived; ++e) ev.dp(e);  // every derived-op parameter is chain-constant
   ev.f("    // ---- active derived points with chain-rule blocks ----");
   for (int idx = 0; idx < P.n_active; ++idx)
@@ -1137,8 +1156,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   if (pv) {
     FU = ev.blk_of_point[pv->couple_point];
     char buf[1024];
-    std::snprintf(buf, sizeof(buf), "      const double hcL = gq[%d];  // length of the joining row\n", 8 * pv->couple_row);
+    const std::string hcl_home = ev.scalar_home("hcL");
+    std::snprintf(buf, sizeof(buf), "      %s = gq[%d];  // length of the joining row\n", hcl_home.c_str(), 8 * pv->couple_row);
     couple_hoist = buf;
+    couple_hoist += "#define hcL " + hcl_home + "\n";
     std::snprintf(buf, sizeof(buf),
                   "    const double cd = xq(p%d) - p%d;\n"
                   "    const double cs = qsum(cd * cd);\n"
@@ -1194,6 +1215,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   else
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+  if (pv) {
+    g.f("  const int qs = lane >> 2;  // quad-side slot of this lane inside the wavefront");
+    g.f("  __shared__ double hsl[%d];  // chain-constant scalars [slot][quad-side]", 16 * (ev.n_scalar_slots + 1));
+    g.f("  __shared__ double hql[%d];  // chain-constant lane components [slot][lane]", 64 * (ev.n_lane_slots + 1));
+    g.f("  __shared__ double xsl[%d];  // accepted point and chain history [block][lane]", 64 * 2 * nf);
+  }
   g.f("  const long long spg = a.steps_per_geometry;");
   g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
   g.f("  const long long unit_len = a.chain_len;");
@@ -1220,7 +1247,14 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // point registers
   for (int p = 0; p < NP; ++p)
     if (used[p]) g.f("    double p%d = c < 3 ? gp[%s + cc] : 0.0;", p, ev.point3(p).c_str());
-  for (int F = 0; F < nf; ++F) g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0;", F, ev.fp(F), F, F, F);
+  for (int F = 0; F < nf; ++F) {
+    if (pv) {  // cold per-pass state lives in LDS (register-bound kernel): plain references, same code below
+      g.f("    double& x%d = xsl[%d + lane]; double& xp%d = xsl[%d + lane];", F, 64 * (2 * F), F, 64 * (2 * F + 1));
+      g.f("    x%d = p%d; xp%d = x%d; double dx%d = 0.0;", F, ev.fp(F), F, F, F);
+    } else {
+      g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0;", F, ev.fp(F), F, F, F);
+    }
+  }
   g.f("    int hist = 0;");
   g.f("    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)");
   // targets: the next step's values are fetched while the current step is being solved, and the two

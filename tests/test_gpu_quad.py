@@ -144,14 +144,49 @@ def test_quad_reports_infeasible_targets_like_the_wave_kernel(golden):
     assert np.allclose(quad["max_residual"], wave["max_residual"], rtol=1e-6)
 
 
-def test_axle_keeps_the_wave_kernel_and_says_why(golden):
+@pytest.mark.parametrize("name", ["c3_axle_grid", "u_axle"])
+def test_axle_runs_in_pair_mode_one_quad_per_half(golden, name):
+    """
+    The composed axle (two identical corners joined by the rack length row) gets a generated kernel
+    too: one quad per corner, Sherman-Morrison for the joint.  Same answers as the interpreter, the
+    oracle and the reference.
+    """
+    from oracle.oracle import Oracle
     from open_kinematics_amd.batch import DeviceProgram
 
-    _, program = golden("c3_axle_grid")
-    dp = DeviceProgram(program.with_line_mode("pinned"), "cuda:0")
-    assert dp.kernel == "wave" and "free points" in dp.kernel_note
-    with pytest.raises(ValueError, match="quad kernel requested but not available"):
-        dp.solve(np.zeros((1, program.n_targets)), kernel="quad")
+    arrays, program = golden(name)
+    pinned = program.with_line_mode("pinned")
+    dp = DeviceProgram(pinned, "cuda:0")
+    if name == "u_axle":
+        # toe links instead of the rack: no row joins the halves, so there is no pair structure
+        assert dp.kernel == "wave" and "pair of identical halves" in dp.kernel_note
+        with pytest.raises(ValueError, match="quad kernel requested but not available"):
+            dp.solve(np.zeros((1, program.n_targets)), kernel="quad")
+        return
+    assert dp.kernel == "quad", dp.kernel_note
+    t = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
+    quad = dp.solve(t, kernel="quad")
+    wave = dp.solve(t, kernel="single")
+    torch.cuda.synchronize()
+    info = quad.info()
+    assert np.all((info["flags"] & 7) == 1)
+    pos = quad.positions.cpu().numpy()
+    assert np.max(np.abs(pos - wave.positions.cpu().numpy())) <= 1e-10
+    assert np.max(np.abs(info["nfev"] - wave.info()["nfev"])) <= 1
+    assert np.max(np.abs(info["max_residual"] - arrays["ref_tight_maxres"])) <= 1e-8
+    sub = slice(None, None, max(1, t.shape[0] // 32))
+    orc = Oracle(pinned).sweep(arrays["targets_abs"][sub], 1e-15, 1e-15, 1e-15, warm_start=False)
+    assert np.max(np.abs(pos[sub] - orc.positions)) <= 1e-9
+    assert np.max(np.abs(pos - arrays["ref_tight_pos"])) <= 6e-8
+    # chains, ragged batches, every record written exactly once
+    for b, cl in ((1, 1), (7, 3), (9, -1), (256, 16)):
+        guard = torch.full((b + 1, pinned.n_out, 3), -7.0, dtype=torch.float64, device="cuda:0")
+        res = dp.solve(t[:b], kernel="quad", chain_len=cl, out=guard[:b])
+        torch.cuda.synchronize()
+        assert np.all((res.info()["flags"] & 7) == 1)
+        assert float((res.positions - quad.positions[:b]).abs().max()) <= 1e-9
+        assert float((guard[b] + 7.0).abs().max()) == 0.0
+        assert float((res.positions + 7.0).abs().min()) > 0.0  # no slot left unwritten
 
 
 def test_quad_rows_on_the_contact_patch(golden):

@@ -52,14 +52,25 @@ def test_same_structure_gives_the_same_kernel_different_structure_does_not(golde
     assert _source(a.with_line_mode("pinned")) != _source(a.with_line_mode("softnorm"))
 
 
-@pytest.mark.parametrize("name", ["c3_axle_grid", "u_axle"])
-def test_large_programs_keep_the_generic_kernels(golden, name):
-    _, program = golden(name)
+def test_large_programs_without_pair_structure_keep_the_generic_kernels(golden):
+    _, program = golden("u_axle")  # 20 free points, the two corners are not joined by any row
     lib = _lib.load()
     host = _abi.HostProgram(program.with_line_mode("pinned"))
     assert lib.okx_quad_source(host.byref(), None, 0) == -2  # OKX_ERR_LIMIT
-    assert "free points" in _lib.last_error()
+    assert "free points" in _lib.last_error() and "pair of identical halves" in _lib.last_error()
     assert lib.okx_precompile(host.byref()) == -2
+
+
+def test_axle_is_generated_in_pair_mode(golden):
+    """Two identical corners joined by the rack row: the half program is generated, one quad per half."""
+    _, program = golden("c3_axle_grid")
+    src = _source(program.with_line_mode("pinned"))
+    assert "quad = lane >> 3, q1 = (lane >> 2) & 1" in src          # 8 problems per wavefront
+    assert "__builtin_amdgcn_ds_swizzle" in src and "sm_k" in src   # cross-quad exchange, Sherman-Morrison
+    for f in range(10):
+        assert f"double A{f}_{f}_0" in src                           # ten free points per half
+    assert "double A10_10_0" not in src
+    assert "okx_quad_eval" not in src                                # parity / tangent kernels: interpreter serves those
 
 
 def test_precompile_fills_the_cache_without_a_device(golden, tmp_path, monkeypatch):
