@@ -106,13 +106,13 @@ def test_ensemble_tangents_use_per_geometry_tables(golden):
 
 
 def test_axle_tangents_from_the_generic_kernel_match_the_reference(golden):
-    """Programs without a quad kernel (rocker axle, n = 60, T = 3): one wavefront per state."""
+    """Programs without a generated tangent kernel (rocker axle, n = 60, T = 3): one wavefront per state."""
     from open_kinematics_amd.batch import DeviceProgram
 
     _, program = golden("c3_axle_grid")
     tg = _tg("c3_axle_grid")
     dp = DeviceProgram(program.with_line_mode("pinned"), "cuda:0")
-    assert dp.kernel == "wave"
+    assert dp.kernel == "quad"  # pair-mode solve kernel; its module has no tangent kernel, the interpreter's is used
     tan, tinfo = dp.tangents(tg["pos"])
     torch.cuda.synchronize()
     info = dp.tangent_info(tinfo)
