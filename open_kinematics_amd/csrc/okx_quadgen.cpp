@@ -26,6 +26,7 @@
 // (DESIGN.md §4); only the parallel decomposition differs.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <set>
 #include <string>
@@ -1113,7 +1114,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
 
   // ---- evaluation body (rows + normal equations), generated first to learn the sparsity ----
   Gen ev(P, pv);
-  ev.lds_constants = pv != nullptr;
+  ev.lds_constants = pv != nullptr || getenv("OKX_QUAD_LDS") != nullptr;
   for (int e = 0; e < P.n_derived; ++e) ev.dp(e);  // every derived-op parameter is chain-constant
   ev.f("    // ---- active derived points with chain-rule blocks ----");
   for (int idx = 0; idx < P.n_active; ++idx)
@@ -1215,10 +1216,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   else
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
-  if (pv) {
-    g.f("  const int qs = lane >> 2;  // quad-side slot of this lane inside the wavefront");
-    g.f("  __shared__ double hsl[%d];  // chain-constant scalars [slot][quad-side]", 16 * (ev.n_scalar_slots + 1));
-    g.f("  __shared__ double hql[%d];  // chain-constant lane components [slot][lane]", 64 * (ev.n_lane_slots + 1));
+  const std::string lds_decl =
+      "  const int qs = lane >> 2;  // quad(-side) slot of this lane inside the wavefront\n"
+      "  __shared__ double hsl[" + std::to_string(16 * (ev.n_scalar_slots + 1)) + "];  // chain-constant scalars [slot][quad]\n"
+      "  __shared__ double hql[" + std::to_string(64 * (ev.n_lane_slots + 1)) + "];  // chain-constant lane components [slot][lane]\n";
+  if (ev.lds_constants) {
+    g.out += lds_decl;
     g.f("  __shared__ double xsl[%d];  // accepted point and chain history [block][lane]", 64 * 2 * nf);
   }
   g.f("  const long long spg = a.steps_per_geometry;");
@@ -1248,7 +1251,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int p = 0; p < NP; ++p)
     if (used[p]) g.f("    double p%d = c < 3 ? gp[%s + cc] : 0.0;", p, ev.point3(p).c_str());
   for (int F = 0; F < nf; ++F) {
-    if (pv) {  // cold per-pass state lives in LDS (register-bound kernel): plain references, same code below
+    if (ev.lds_constants) {  // cold per-pass state lives in LDS (register-bound kernel): plain references, same code below
       g.f("    double& x%d = xsl[%d + lane]; double& xp%d = xsl[%d + lane];", F, 64 * (2 * F), F, 64 * (2 * F + 1));
       g.f("    x%d = p%d; xp%d = x%d; double dx%d = 0.0;", F, ev.fp(F), F, F, F);
     } else {
@@ -1520,6 +1523,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_eval(QEvalArgs a) {", waves_per_simd);
   g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+  if (ev.lds_constants) g.out += lds_decl;
   g.f("  const double* gp = a.design_pos; const double* gq = a.row_param;");
   g.out += ev.hoisted;
   g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_problems; wu += gridDim.x) {");
@@ -1583,6 +1587,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("  const double* design_pos; const double* row_param; const double* dop_param; };");
     g.f("template <bool PG> DEV void okx_quad_tangent_body(const QTanArgs& a) {");
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+    if (ev.lds_constants) g.out += lds_decl;
     g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
     g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_problems; wu += gridDim.x) {");
     g.f("    long long bb = wu * 16 + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");

@@ -217,3 +217,32 @@ def test_quad_rows_on_the_contact_patch(golden):
     assert float((quad.positions - wave.positions).abs().max()) <= 1e-10
     out_cp = list(prog.out_point).index(cp)
     assert np.max(np.abs(quad.positions[:, out_cp, 2].cpu().numpy() - sweep[:, 1])) <= 1e-9
+
+
+def test_pair_mode_with_per_geometry_tables(golden):
+    """Perturbed axle geometries (rebind on device) through okx_quad_solve_g in pair mode vs the interpreter."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden("c3_axle_grid")
+    pinned = program.with_line_mode("pinned")
+    dp = DeviceProgram(pinned, "cuda:0")
+    assert dp.kernel == "quad"
+    rng = np.random.default_rng(3)
+    g, s = 5, 12
+    hard = np.repeat(pinned.design_pos[None], g, axis=0)
+    moving = np.array([i for i in range(pinned.n_points) if pinned.role[i] != 2])
+    hard[1:, moving] += rng.normal(0.0, 0.5, (g - 1, len(moving), 3))
+    gpos, gparam = dp.rebind(torch.as_tensor(hard, device="cuda:0"))
+    base = torch.stack([gpos[:, pinned.tgt_point[k]] @ torch.as_tensor(pinned.tgt_dir[k], device="cuda:0")
+                        for k in range(pinned.n_targets)], 1)
+    rel = np.zeros((s, pinned.n_targets))
+    rel[:, 0] = np.linspace(-20.0, 20.0, s)
+    rel[:, 1] = np.linspace(15.0, -15.0, s)
+    t = (base[:, None, :] + torch.as_tensor(rel, device="cuda:0")[None]).reshape(g * s, -1).contiguous()
+    kw = dict(geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=s)
+    wave = dp.solve(t, kernel="single", **kw)
+    for cl in (1, 5, -1):
+        quad = dp.solve(t, kernel="quad", chain_len=cl, **kw)
+        torch.cuda.synchronize()
+        assert np.all((quad.info()["flags"] & 7) == 1)
+        assert float((quad.positions - wave.positions).abs().max()) <= 1e-9
