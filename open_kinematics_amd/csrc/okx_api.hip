@@ -190,6 +190,12 @@ void attach_quad_kernel(okx_program* p) {
   hipModule_t mod = nullptr;
   hipError_t e = hipModuleLoadData(&mod, code.data());
   if (e != hipSuccess) {
+    // a damaged cache entry (truncated file, other toolchain): rebuild it once
+    (void)hipGetLastError();
+    if (okx::quad_compile(src, &code, &err, true)) e = hipModuleLoadData(&mod, code.data());
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
     std::snprintf(p->quad_note, sizeof(p->quad_note), "hipModuleLoadData: %s", hipGetErrorString(e));
     return;
   }

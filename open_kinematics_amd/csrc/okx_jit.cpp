@@ -60,6 +60,26 @@ bool read_file(const std::string& path, std::string* data) {
   return got == (size_t)size;
 }
 
+// Cache entries carry a header (magic, payload size, FNV-1a of the payload): the HIP runtime aborts
+// the process on a malformed code object, so a truncated or foreign file must be caught here.
+constexpr unsigned long long kCacheMagic = 0x314b43584b4fULL;  // "OKXCK1"
+
+std::string wrap_entry(const std::string& code) {
+  unsigned long long header[3] = {kCacheMagic, (unsigned long long)code.size(), fnv1a(code)};
+  std::string out(reinterpret_cast<const char*>(header), sizeof(header));
+  out += code;
+  return out;
+}
+
+bool unwrap_entry(const std::string& file, std::string* code) {
+  unsigned long long header[3];
+  if (file.size() < sizeof(header)) return false;
+  std::memcpy(header, file.data(), sizeof(header));
+  if (header[0] != kCacheMagic || header[1] != file.size() - sizeof(header)) return false;
+  code->assign(file, sizeof(header), std::string::npos);
+  return fnv1a(*code) == header[2];
+}
+
 void write_file_atomic(const std::string& path, const std::string& data) {
   const std::string part = path + ".tmp" + std::to_string((long)getpid());
   FILE* fh = std::fopen(part.c_str(), "wb");
@@ -74,7 +94,7 @@ void write_file_atomic(const std::string& path, const std::string& data) {
 
 }  // namespace
 
-bool quad_compile(const std::string& src, std::string* code, std::string* err) {
+bool quad_compile(const std::string& src, std::string* code, std::string* err, bool ignore_cached) {
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
   unsigned long long h = fnv1a(src);
@@ -83,9 +103,12 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err) {
   char name[64];
   std::snprintf(name, sizeof(name), "/okxq_%016llx", h);
   const std::string dir = cache_dir();
-  const std::string path = dir + name + ".hsaco";
+  const std::string path = dir + name + ".okxc";  // header + gfx950 code object
   const bool no_cache = getenv("OKX_KERNEL_NOCACHE") != nullptr;
-  if (!no_cache && read_file(path, code)) return true;
+  if (!no_cache && !ignore_cached) {
+    std::string file;
+    if (read_file(path, &file) && unwrap_entry(file, code)) return true;
+  }
 
   hiprtcProgram prog;
   hiprtcResult rc = hiprtcCreateProgram(&prog, src.c_str(), "okx_quad.hip", 0, nullptr, nullptr);
@@ -120,7 +143,7 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err) {
   }
   if (!no_cache) {
     (void)mkdir(dir.c_str(), 0777);
-    write_file_atomic(path, *code);
+    write_file_atomic(path, wrap_entry(*code));
     if (getenv("OKX_KERNEL_KEEP_SOURCE")) write_file_atomic(dir + name + ".hip", src);
   }
   return true;

@@ -80,8 +80,9 @@ bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why);
 bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why);
 
 // Compiles `src` for gfx950 with hiprtc (no device needed) or fetches it from the on-disk cache
-// (<dir of libokx.so>/_kcache/<hash>.hsaco, override with OKX_KERNEL_CACHE).  Returns the code
+// (<dir of libokx.so>/_kcache/<hash>.okxc, override with OKX_KERNEL_CACHE).  Returns the code
 // object in `code`; false + message on failure.
-bool quad_compile(const std::string& src, std::string* code, std::string* err);
+// `ignore_cached` recompiles and overwrites the cache entry (used once when a cached object fails to load).
+bool quad_compile(const std::string& src, std::string* code, std::string* err, bool ignore_cached = false);
 
 }  // namespace okx

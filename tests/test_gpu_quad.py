@@ -246,3 +246,25 @@ def test_pair_mode_with_per_geometry_tables(golden):
         torch.cuda.synchronize()
         assert np.all((quad.info()["flags"] & 7) == 1)
         assert float((quad.positions - wave.positions).abs().max()) <= 1e-9
+
+
+def test_a_damaged_cache_entry_is_rebuilt(golden, tmp_path, monkeypatch):
+    """A truncated code object in the kernel cache must not silently demote the program to the interpreter."""
+    import os
+
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden("u_dw_corner")
+    monkeypatch.setenv("OKX_KERNEL_CACHE", str(tmp_path))
+    dp = DeviceProgram(program, "cuda:0")
+    assert dp.kernel == "quad"
+    dp.close()
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".okxc")]
+    assert len(files) == 1
+    path = tmp_path / files[0]
+    path.write_bytes(path.read_bytes()[:1000])  # truncated: the header's size / checksum no longer match
+    dp = DeviceProgram(program, "cuda:0")
+    assert dp.kernel == "quad", dp.kernel_note
+    assert path.stat().st_size > 10000
+    res = dp.solve(arrays["targets_abs"])
+    assert np.all((res.info()["flags"] & 7) == 1)

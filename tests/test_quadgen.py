@@ -79,10 +79,10 @@ def test_precompile_fills_the_cache_without_a_device(golden, tmp_path, monkeypat
     lib = _lib.load()
     host = _abi.HostProgram(program.with_line_mode("pinned"))
     assert lib.okx_precompile(host.byref()) == 0, _lib.last_error()
-    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".okxc")]
     assert len(files) == 1
     blob = (tmp_path / files[0]).read_bytes()
-    assert blob[:4] == b"\x7fELF" and b"okx_quad_solve_u" in blob
+    assert blob[:6] == b"OKXCK1" and blob[24:28] == b"\x7fELF" and b"okx_quad_solve_u" in blob
     stamp = os.path.getmtime(tmp_path / files[0])
     assert lib.okx_precompile(host.byref()) == 0  # second call is a cache hit
     assert os.path.getmtime(tmp_path / files[0]) == stamp

@@ -16,8 +16,9 @@ program, _ = bump_sweep_problem(5) if sys.argv[1] == "dw" else macpherson_grid_p
 rc = lib.okx_precompile(HostProgram(program).byref())
 print("precompile", rc, _lib.last_error() if rc else "")
 PY
-/opt/rocm/lib/llvm/bin/llvm-objdump -d $OKX_KERNEL_CACHE/*.hsaco > /tmp/q/k.s
+tail -c +25 $OKX_KERNEL_CACHE/*.okxc > /tmp/q/k.hsaco   # strip the 24-byte cache header
+/opt/rocm/lib/llvm/bin/llvm-objdump -d /tmp/q/k.hsaco > /tmp/q/k.s
 awk '/<okx_quad_solve_u>:/{f=1} /<okx_quad_solve_g>:/{f=0} f' /tmp/q/k.s > /tmp/q/u.s
 echo "total instrs: $(grep -c '^\s*[a-z]' /tmp/q/u.s)"
 for pat in v_fma_f64 v_mul_f64 v_add_f64 v_fmac_f64 v_mov_b32_dpp v_accvgpr_read v_accvgpr_write v_cndmask v_mov_b32_e32 scratch_ s_waitcnt s_nop global_load v_rcp_f64 v_rsq_f64 v_cmp v_max_f64; do echo "  $pat: $(grep -c "$pat" /tmp/q/u.s)"; done
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes $OKX_KERNEL_CACHE/*.hsaco | grep -E "\.name:|vgpr_count|agpr_count|sgpr_count|private_segment_fixed|vgpr_spill" | paste - - - - - - | head -5
+/opt/rocm/lib/llvm/bin/llvm-readelf --notes /tmp/q/k.hsaco | grep -E "\.name:|vgpr_count|agpr_count|sgpr_count|private_segment_fixed|vgpr_spill" | paste - - - - - - | head -5
