@@ -280,10 +280,29 @@ typedef struct okx_corner_roles {
   int32_t wheel_center, contact_patch;   /* PointID.WHEEL_CENTER, CONTACT_PATCH_CENTER        */
   int32_t axle_inboard, axle_outboard;   /* wheel_axis_points()                               */
   int32_t steer_lower, steer_upper;      /* steering_axis_points() (lower, upper pivot)       */
+  /* Instant axis of the upright (compute_instant_axis): OKX_IA_TWO_PLANES = upper and lower wishbone
+   * planes, points (upper front, upper rear, upper outboard, lower front, lower rear, lower outboard)
+   * (corner/double_wishbone.py:376-403); OKX_IA_PLANE_AND_STRUT = lower-arm plane and the plane through
+   * the strut top normal to the strut, points (arm front, arm rear, ball joint, strut top, -, -)
+   * (corner/macpherson.py:325-355); OKX_IA_NONE: the instant-centre family reads NaN. */
+  int32_t instant_axis_kind;
+  int32_t instant_axis_point[6];
+  int32_t damper_top, damper_bottom;     /* damper_points() or -1, -1 (travel.py:48-62)        */
+  int32_t rack_attachment;               /* rack_attachment_point() or -1 (axle_metrics.py:60-70) */
+  int32_t axle_position, driven_axle;    /* OKX_AXLE_UNSET / _FRONT / _REAR (schema/config.py:79-80,140) */
   double side_sign;                      /* +1 left, -1 right (Side.lateral_sign)             */
   double design_wheel_center_z;          /* travel reference (metrics/context.py:42-45)       */
+  double design_contact_patch_z;         /* ride-height reference (axle_metrics.py:33-37)     */
+  double design_rack_y;                  /* rack reference (axle_metrics.py:66-69)            */
+  double wheelbase, cg_z;                /* config.wheelbase, config.cg_position.z            */
+  double front_brake_bias;               /* config.front_brake_bias, NaN when unset           */
 } okx_corner_roles;
 
+enum { OKX_IA_NONE = 0, OKX_IA_TWO_PLANES = 1, OKX_IA_PLANE_AND_STRUT = 2 };
+enum { OKX_AXLE_UNSET = 0, OKX_AXLE_FRONT = 1, OKX_AXLE_REAR = 2 };
+
+/* The reference's corner metric catalog (metrics/catalog.py:46-146).  A metric the reference
+ * reports as None (undefined geometry, unset configuration) reads NaN. */
 enum {
   OKX_METRIC_CAMBER = 0,           /* deg, metrics/angles.py:22-50            */
   OKX_METRIC_CASTER = 1,           /* deg, angles.py:53-71                    */
@@ -293,16 +312,29 @@ enum {
   OKX_METRIC_HALF_TRACK = 5,       /* mm, travel.py:35-45                     */
   OKX_METRIC_SCRUB_RADIUS = 6,     /* mm, steering_geometry.py:22-54          */
   OKX_METRIC_MECHANICAL_TRAIL = 7, /* mm, steering_geometry.py:57-76          */
-  OKX_METRIC_COUNT = 8
+  OKX_METRIC_SVIC_X = 8,           /* mm, side-view instant centre, catalog.py:95-100 */
+  OKX_METRIC_SVIC_Z = 9,
+  OKX_METRIC_SVSA_LENGTH = 10,     /* mm, swing_arms.py:45-59                 */
+  OKX_METRIC_FVIC_Y = 11,          /* mm, front-view instant centre, catalog.py:104-109 */
+  OKX_METRIC_FVIC_Z = 12,
+  OKX_METRIC_FVSA_LENGTH = 13,     /* mm, signed, swing_arms.py:62-88         */
+  OKX_METRIC_DAMPER_LENGTH = 14,   /* mm, travel.py:48-62                     */
+  OKX_METRIC_SVSA_ANGLE = 15,      /* deg, anti_geometry.py:32-58             */
+  OKX_METRIC_ANTI_DIVE = 16,       /* %, anti_geometry.py:75-116              */
+  OKX_METRIC_ANTI_LIFT = 17,       /* %, anti_geometry.py:119-160             */
+  OKX_METRIC_ANTI_SQUAT = 18,      /* %, anti_geometry.py:163-206             */
+  OKX_METRIC_COUNT = 19
 };
 
 /*
- * Replaces compute_metrics_for_state's angle / travel / steering-geometry entries
- * (metrics/main.py, catalog.py) and, given the tangents of okx_tangent_batch, the raw material of
- * the derivative columns (metrics/derivatives.py): d_dmetrics[b][t][m] = d metric_m / d target_t,
- * e.g. deriv_camber_wrt_hub_z = d_dmetrics[.][bump target][OKX_METRIC_CAMBER] and
+ * Replaces compute_metrics_for_state's catalog entries (metrics/main.py:150-185, catalog.py) and,
+ * given the tangents of okx_tangent_batch, the raw material of the derivative columns
+ * (metrics/derivatives.py): d_dmetrics[b][t][m] = d metric_m / d target_t,
+ * e.g. deriv_camber_wrt_hub_z = d_dmetrics[.][bump target][OKX_METRIC_CAMBER],
+ * deriv_damper_length_wrt_hub_z likewise, and
  * deriv_wheel_center_x_wrt_hub_z = d_tangents[.][bump target][wheel_center][0].
- * d_tangents / d_dmetrics may both be NULL.
+ * (The instant-centre family has no derivative column in the reference; its entries are the
+ * forward-mode derivatives of the same formulas.)  d_tangents / d_dmetrics may both be NULL.
  */
 int32_t okx_corner_metrics_batch(const okx_corner_roles* roles, int64_t n_states, int32_t n_out, int32_t n_targets,
                                  const double* d_pos,       /* [B][n_out][3] */
@@ -310,6 +342,25 @@ int32_t okx_corner_metrics_batch(const okx_corner_roles* roles, int64_t n_states
                                  double* d_metrics,         /* [B][OKX_METRIC_COUNT] */
                                  double* d_dmetrics,        /* [B][T][OKX_METRIC_COUNT] or NULL */
                                  void* stream);
+
+/* Axle-scope state metrics of a solved two-corner axle (metrics/axle_metrics.py:21-95). */
+enum {
+  OKX_AXLE_METRIC_HEAVE = 0,               /* mm, mean wheel-centre rise                        */
+  OKX_AXLE_METRIC_ROLL = 1,                /* deg, atan2(left - right rise, track)              */
+  OKX_AXLE_METRIC_RIDE_HEIGHT_CHANGE = 2,  /* mm, -mean contact-patch rise                      */
+  OKX_AXLE_METRIC_TRACK = 3,               /* mm, |CP_y left - CP_y right|                      */
+  OKX_AXLE_METRIC_ROLL_CENTER_Y = 4,       /* mm, the two contact-patch -> FVIC lines meet here */
+  OKX_AXLE_METRIC_ROLL_CENTER_Z = 5,
+  OKX_AXLE_METRIC_RACK_DISPLACEMENT = 6,   /* mm, left rack pickup y - design (NaN: no rack)    */
+  OKX_AXLE_METRIC_COUNT = 7
+};
+
+/* left / right: roles of the two corners as indices into the AXLE program's output points. */
+int32_t okx_axle_metrics_batch(const okx_corner_roles* left, const okx_corner_roles* right, int64_t n_states,
+                               int32_t n_out,
+                               const double* d_pos,  /* [B][n_out][3] */
+                               double* d_metrics,    /* [B][OKX_AXLE_METRIC_COUNT] */
+                               void* stream);
 
 /*
  * Runtime specialisation.  okx_program_create also GENERATES a HIP kernel for the program at

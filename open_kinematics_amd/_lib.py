@@ -34,6 +34,7 @@ EXPORTS = (
     "okx_precompile",
     "okx_tangent_batch",
     "okx_corner_metrics_batch",
+    "okx_axle_metrics_batch",
 )
 
 _lib = None
@@ -95,6 +96,8 @@ def load() -> C.CDLL:
     lib.okx_tangent_batch.restype = i32
     lib.okx_corner_metrics_batch.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp]
     lib.okx_corner_metrics_batch.restype = i32
+    lib.okx_axle_metrics_batch.argtypes = [vp, vp, i64, i32, vp, vp, vp]
+    lib.okx_axle_metrics_batch.restype = i32
     lib.okx_debug_quad_eval.argtypes = [vp, i64, vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.okx_debug_quad_eval.restype = i32
     if lib.okx_abi_version() != 1:

@@ -610,6 +610,51 @@ int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_
   return OKX_OK;
 }
 
+static_assert(sizeof(okx_corner_roles) == 128, "okx_corner_roles layout is part of the ABI (ctypes mirror in metrics.py)");
+
+static int32_t check_corner_roles(const okx_corner_roles* roles, int32_t n_out, const char* who) {
+  const int32_t idx[6] = {roles->wheel_center, roles->contact_patch, roles->axle_inboard,
+                          roles->axle_outboard, roles->steer_lower, roles->steer_upper};
+  for (int k = 0; k < 6; ++k)
+    if (idx[k] < 0 || idx[k] >= n_out) return fail(OKX_ERR_INVALID, "%s: role %d is not an output point", who, k);
+  if (!(roles->side_sign == 1.0 || roles->side_sign == -1.0))
+    return fail(OKX_ERR_INVALID, "%s: side_sign must be +-1", who);
+  const int n_axis = roles->instant_axis_kind == OKX_IA_TWO_PLANES ? 6
+                     : roles->instant_axis_kind == OKX_IA_PLANE_AND_STRUT ? 4
+                     : roles->instant_axis_kind == OKX_IA_NONE ? 0 : -1;
+  if (n_axis < 0) return fail(OKX_ERR_INVALID, "%s: unknown instant_axis_kind %d", who, roles->instant_axis_kind);
+  for (int k = 0; k < n_axis; ++k)
+    if (roles->instant_axis_point[k] < 0 || roles->instant_axis_point[k] >= n_out)
+      return fail(OKX_ERR_INVALID, "%s: instant-axis point %d is not an output point", who, k);
+  if ((roles->damper_top < 0) != (roles->damper_bottom < 0) || roles->damper_top >= n_out || roles->damper_bottom >= n_out)
+    return fail(OKX_ERR_INVALID, "%s: damper points must both be output points or both be -1", who);
+  if (roles->rack_attachment >= n_out) return fail(OKX_ERR_INVALID, "%s: rack attachment is not an output point", who);
+  for (int32_t v : {roles->axle_position, roles->driven_axle})
+    if (v != OKX_AXLE_UNSET && v != OKX_AXLE_FRONT && v != OKX_AXLE_REAR)
+      return fail(OKX_ERR_INVALID, "%s: axle_position / driven_axle must be OKX_AXLE_*", who);
+  return OKX_OK;
+}
+
+int32_t okx_axle_metrics_batch(const okx_corner_roles* left, const okx_corner_roles* right, int64_t n_states,
+                               int32_t n_out, const double* d_pos, double* d_metrics, void* stream) {
+  if (!left || !right || !d_pos || !d_metrics) return fail(OKX_ERR_INVALID, "null pointer");
+  if (n_states < 0 || n_out <= 0) return fail(OKX_ERR_INVALID, "bad dimension");
+  if (int32_t rc = check_corner_roles(left, n_out, "left")) return rc;
+  if (int32_t rc = check_corner_roles(right, n_out, "right")) return rc;
+  if (n_states == 0) return OKX_OK;
+  okx::AxleMetricsArgs a;
+  a.left = *left;
+  a.right = *right;
+  a.pos = d_pos;
+  a.metrics = d_metrics;
+  a.n_states = n_states;
+  a.n_out = n_out;
+  const long long blocks = (n_states + 255) / 256;
+  hipLaunchKernelGGL(okx::okx_axle_metrics_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
 int32_t okx_corner_metrics_batch(const okx_corner_roles* roles, int64_t n_states, int32_t n_out, int32_t n_targets,
                                  const double* d_pos, const double* d_tangents, double* d_metrics,
                                  double* d_dmetrics, void* stream) {
@@ -617,11 +662,7 @@ int32_t okx_corner_metrics_batch(const okx_corner_roles* roles, int64_t n_states
   if (n_states < 0 || n_out <= 0 || n_targets < 0) return fail(OKX_ERR_INVALID, "bad dimension");
   if ((d_tangents == nullptr) != (d_dmetrics == nullptr))
     return fail(OKX_ERR_INVALID, "tangents and derivative output must be given together");
-  const int32_t idx[6] = {roles->wheel_center, roles->contact_patch, roles->axle_inboard,
-                          roles->axle_outboard, roles->steer_lower, roles->steer_upper};
-  for (int k = 0; k < 6; ++k)
-    if (idx[k] < 0 || idx[k] >= n_out) return fail(OKX_ERR_INVALID, "role %d is not an output point", k);
-  if (!(roles->side_sign == 1.0 || roles->side_sign == -1.0)) return fail(OKX_ERR_INVALID, "side_sign must be +-1");
+  if (int32_t rc = check_corner_roles(roles, n_out, "roles")) return rc;
   if (n_states == 0) return OKX_OK;
   okx::MetricsArgs a;
   a.roles = *roles;

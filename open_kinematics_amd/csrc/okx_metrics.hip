@@ -7,8 +7,10 @@
 // (metrics/derivatives.py: d response / d driver along a tangent field) are forward-mode
 // derivatives of the same formulas, which is what `Dual` below carries.
 //
-// One thread per solved state: six role points in (144 B), eight scalars out (64 B), plus
-// 64 B per target when tangents are given — a pure streaming kernel (HBM-bound).
+// One thread per solved state: up to fourteen role points in (336 B), nineteen scalars out (152 B),
+// plus 152 B per target when tangents are given — a pure streaming kernel (HBM-bound).
+// Instant centres, swing arms and the anti-geometry follow swing_arms.py / anti_geometry.py over
+// the corner's instant axis; axle-scope metrics follow axle_metrics.py.
 #include <hip/hip_runtime.h>
 #pragma once
 #include <stdint.h>
@@ -51,7 +53,74 @@ __device__ __forceinline__ DVec load_point(const double* pos, const double* vel,
   return p;
 }
 
-// The eight metrics of one state as duals (value, derivative along `vel`).
+__device__ __forceinline__ Dual dnan() { return {__builtin_nan(""), __builtin_nan("")}; }
+__device__ __forceinline__ Dual datan(Dual q) { return {atan(q.v), q.d / (1.0 + q.v * q.v)}; }
+__device__ __forceinline__ DVec dcross(DVec a, DVec b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ Dual ddot(DVec a, DVec b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ DVec dscale(Dual s, DVec a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ DVec dadd(DVec a, DVec b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ DVec dunit(DVec a, Dual norm) { return {a.x / norm, a.y / norm, a.z / norm}; }
+
+constexpr double kEpsGeometric = 1e-6;  // primitives/constants.py:9
+
+// vector_utils/geometric.py:216-252: unit normal n and offset d of the plane n.x + d = 0 through a, b, c
+__device__ __forceinline__ bool plane_from_three_points(DVec a, DVec b, DVec c, DVec* n, Dual* d) {
+  const DVec raw = dcross(dsub(b, a), dsub(c, a));
+  const Dual mag = dsqrt(ddot(raw, raw));
+  if (!(mag.v >= kEpsGeometric)) return false;
+  *n = dunit(raw, mag);
+  *d = -ddot(*n, a);
+  return true;
+}
+
+// geometric.py:255-290: line (point, unit direction) where two planes meet
+__device__ __forceinline__ bool intersect_two_planes(DVec n1, Dual d1, DVec n2, Dual d2, DVec* point, DVec* dir) {
+  const DVec raw = dcross(n1, n2);
+  const Dual m2 = ddot(raw, raw);
+  if (!(m2.v >= kEpsGeometric * kEpsGeometric)) return false;
+  const DVec w = dsub(dscale(d2, n1), dscale(d1, n2));
+  const DVec pc = dcross(w, raw);
+  *point = {pc.x / m2, pc.y / m2, pc.z / m2};
+  *dir = dunit(raw, dsqrt(m2));
+  return true;
+}
+
+// corner/double_wishbone.py:376-403, corner/macpherson.py:325-355
+__device__ __forceinline__ bool instant_axis(const okx_corner_roles& R, const double* pos, const double* vel,
+                                             DVec* point, DVec* dir) {
+  const int32_t* ip = R.instant_axis_point;
+  DVec n1, n2;
+  Dual d1, d2;
+  if (R.instant_axis_kind == OKX_IA_TWO_PLANES) {
+    if (!plane_from_three_points(load_point(pos, vel, ip[0]), load_point(pos, vel, ip[1]), load_point(pos, vel, ip[2]),
+                                 &n1, &d1) ||
+        !plane_from_three_points(load_point(pos, vel, ip[3]), load_point(pos, vel, ip[4]), load_point(pos, vel, ip[5]),
+                                 &n2, &d2))
+      return false;
+  } else if (R.instant_axis_kind == OKX_IA_PLANE_AND_STRUT) {
+    const DVec ball = load_point(pos, vel, ip[2]), top = load_point(pos, vel, ip[3]);
+    if (!plane_from_three_points(load_point(pos, vel, ip[0]), load_point(pos, vel, ip[1]), ball, &n1, &d1)) return false;
+    const DVec strut = dsub(top, ball);
+    n2 = dunit(strut, dsqrt(ddot(strut, strut)));
+    d2 = -ddot(n2, top);
+  } else {
+    return false;
+  }
+  return intersect_two_planes(n1, d1, n2, d2, point, dir);
+}
+
+// geometric.py:316-352: the line meets the plane {coordinate `axis` = value}
+__device__ __forceinline__ bool line_at_coordinate(DVec point, DVec dir, int axis, Dual value, DVec* hit) {
+  const Dual comp = axis == 0 ? dir.x : (axis == 1 ? dir.y : dir.z);
+  if (!(fabs(comp.v) >= kEpsGeometric)) return false;
+  const Dual from = axis == 0 ? point.x : (axis == 1 ? point.y : point.z);
+  *hit = dadd(point, dscale((value - from) / comp, dir));
+  return true;
+}
+
+// The catalog's metrics of one state as duals (value, derivative along `vel`).
 __device__ __forceinline__ void corner_metrics(const okx_corner_roles& R, const double* pos, const double* vel,
                                                Dual out[OKX_METRIC_COUNT]) {
   const double kDeg = 57.29577951308232;  // 180 / pi (numpy rad2deg)
@@ -77,6 +146,48 @@ __device__ __forceinline__ void corner_metrics(const okx_corner_roles& R, const 
   const Dual an = dsqrt(axle.x * axle.x + axle.y * axle.y);
   out[OKX_METRIC_SCRUB_RADIUS] = -(((gx - cp.x) * axle.x + (gy - cp.y) * axle.y) / an);
   out[OKX_METRIC_MECHANICAL_TRAIL] = gx - cp.x;  // steering_geometry.py:57-76
+
+  // travel.py:48-62
+  if (R.damper_top >= 0 && R.damper_bottom >= 0) {
+    const DVec strut = dsub(load_point(pos, vel, R.damper_top), load_point(pos, vel, R.damper_bottom));
+    out[OKX_METRIC_DAMPER_LENGTH] = dsqrt(ddot(strut, strut));
+  } else {
+    out[OKX_METRIC_DAMPER_LENGTH] = dnan();
+  }
+
+  // instant centres: the instant axis cut at the wheel centre's y (side view) and x (front view)
+  for (int k = OKX_METRIC_SVIC_X; k <= OKX_METRIC_FVSA_LENGTH; ++k) out[k] = dnan();
+  for (int k = OKX_METRIC_SVSA_ANGLE; k <= OKX_METRIC_ANTI_SQUAT; ++k) out[k] = dnan();
+  DVec ap, ad, svic, fvic;
+  if (!instant_axis(R, pos, vel, &ap, &ad)) return;
+  if (line_at_coordinate(ap, ad, 0, wc.x, &fvic)) {  // double_wishbone.py:405-430
+    out[OKX_METRIC_FVIC_Y] = fvic.y;
+    out[OKX_METRIC_FVIC_Z] = fvic.z;
+    // swing_arms.py:62-88: distance in the front view, positive when the centre is inboard of the patch
+    const Dual dy = fvic.y - cp.y, dz = fvic.z - cp.z;
+    const double sgn = dy.v > 0.0 ? 1.0 : (dy.v < 0.0 ? -1.0 : 0.0);
+    out[OKX_METRIC_FVSA_LENGTH] = (-side * sgn) * dsqrt(dy * dy + dz * dz);
+  }
+  if (!line_at_coordinate(ap, ad, 1, wc.y, &svic)) return;  // double_wishbone.py:352-374
+  out[OKX_METRIC_SVIC_X] = svic.x;
+  out[OKX_METRIC_SVIC_Z] = svic.z;
+  out[OKX_METRIC_SVSA_LENGTH] = svic.x - cp.x;  // swing_arms.py:45-59
+  const Dual run = svic.x - cp.x, rise = svic.z - cp.z;
+  const bool run_ok = fabs(run.v) >= kEpsGeometric;
+  if (run_ok) out[OKX_METRIC_SVSA_ANGLE] = kDeg * datan(rise / run);  // anti_geometry.py:32-58
+  const Dual height = Dual{R.cg_z, 0.0} - cp.z;                       // anti_geometry.py:61-72
+  const bool height_ok = height.v > kEpsGeometric;
+  const bool bias_set = R.front_brake_bias == R.front_brake_bias;
+  const Dual lever = Dual{R.wheelbase, 0.0} / height;
+  if (run_ok && height_ok && bias_set && R.axle_position == OKX_AXLE_FRONT)  // anti_geometry.py:75-116
+    out[OKX_METRIC_ANTI_DIVE] = ((100.0 * R.front_brake_bias) * lever) * (rise / -run);
+  if (run_ok && height_ok && bias_set && R.axle_position == OKX_AXLE_REAR)   // anti_geometry.py:119-160
+    out[OKX_METRIC_ANTI_LIFT] = ((100.0 * (1.0 - R.front_brake_bias)) * lever) * (rise / run);
+  if (R.driven_axle != OKX_AXLE_UNSET && R.driven_axle == R.axle_position) {  // anti_geometry.py:163-206
+    const Dual drive_run = R.axle_position == OKX_AXLE_FRONT ? wc.x - svic.x : svic.x - wc.x;
+    if (fabs(drive_run.v) >= kEpsGeometric && height_ok)
+      out[OKX_METRIC_ANTI_SQUAT] = (100.0 * lever) * ((svic.z - wc.z) / drive_run);
+  }
 }
 
 struct MetricsArgs {
@@ -105,6 +216,61 @@ __global__ void __launch_bounds__(256) okx_corner_metrics_kernel(MetricsArgs a) 
 #pragma unroll
       for (int k = 0; k < OKX_METRIC_COUNT; ++k) dout[k] = m[k].d;
     }
+}
+
+struct AxleMetricsArgs {
+  okx_corner_roles left, right;
+  const double* pos;  // [B][n_out][3]
+  double* metrics;    // [B][OKX_AXLE_METRIC_COUNT]
+  long long n_states;
+  int n_out;
+};
+
+// metrics/axle_metrics.py:21-95: one thread per solved axle state.
+__global__ void __launch_bounds__(256) okx_axle_metrics_kernel(AxleMetricsArgs a) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.n_states) return;
+  const double* pos = a.pos + b * 3 * a.n_out;
+  const double kDeg = 57.29577951308232;
+  const double nan = __builtin_nan("");
+  double wheel_dz[2], contact_dz[2], line[2][4];
+  bool have_lines = true;
+  for (int s = 0; s < 2; ++s) {
+    const okx_corner_roles& R = s == 0 ? a.left : a.right;
+    const double* wc = pos + 3 * R.wheel_center;
+    const double* cp = pos + 3 * R.contact_patch;
+    wheel_dz[s] = wc[2] - R.design_wheel_center_z;
+    contact_dz[s] = cp[2] - R.design_contact_patch_z;
+    DVec ap, ad, fvic;
+    const DVec wcd = load_point(pos, nullptr, R.wheel_center);
+    if (instant_axis(R, pos, nullptr, &ap, &ad) && line_at_coordinate(ap, ad, 0, wcd.x, &fvic)) {
+      line[s][0] = cp[1];
+      line[s][1] = cp[2];
+      line[s][2] = fvic.y.v - cp[1];
+      line[s][3] = fvic.z.v - cp[2];
+    } else {
+      have_lines = false;
+    }
+  }
+  double* out = a.metrics + b * OKX_AXLE_METRIC_COUNT;
+  const double track = fabs(pos[3 * a.left.contact_patch + 1] - pos[3 * a.right.contact_patch + 1]);
+  out[OKX_AXLE_METRIC_HEAVE] = 0.5 * (wheel_dz[0] + wheel_dz[1]);
+  out[OKX_AXLE_METRIC_ROLL] = kDeg * atan2(wheel_dz[0] - wheel_dz[1], track);
+  out[OKX_AXLE_METRIC_RIDE_HEIGHT_CHANGE] = -0.5 * (contact_dz[0] + contact_dz[1]);
+  out[OKX_AXLE_METRIC_TRACK] = track;
+  double rcy = nan, rcz = nan;
+  if (have_lines) {  // axle_metrics.py:73-95: the two contact-patch -> FVIC lines in the YZ plane
+    const double den = line[0][2] * line[1][3] - line[0][3] * line[1][2];
+    if (fabs(den) >= kEpsGeometric) {
+      const double t = ((line[1][0] - line[0][0]) * line[1][3] - (line[1][1] - line[0][1]) * line[1][2]) / den;
+      rcy = line[0][0] + t * line[0][2];
+      rcz = line[0][1] + t * line[0][3];
+    }
+  }
+  out[OKX_AXLE_METRIC_ROLL_CENTER_Y] = rcy;
+  out[OKX_AXLE_METRIC_ROLL_CENTER_Z] = rcz;
+  out[OKX_AXLE_METRIC_RACK_DISPLACEMENT] =
+      a.left.rack_attachment >= 0 ? pos[3 * a.left.rack_attachment + 1] - a.left.design_rack_y : nan;
 }
 
 }  // namespace okx

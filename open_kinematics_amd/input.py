@@ -22,6 +22,7 @@ from .topology import (
     DoubleWishboneSuspension,
     MacPhersonSuspension,
     Suspension,
+    VehicleSetup,
     WheelConfig,
 )
 
@@ -66,6 +67,22 @@ def _wheel(config: Mapping[str, Any]) -> WheelConfig:
         section_width=float(tire["section_width"]),
         aspect_ratio=float(tire["aspect_ratio"]),
         rim_diameter=float(tire["rim_diameter"]),
+    )
+
+
+def _vehicle(vehicle: Mapping[str, Any], axle_position) -> VehicleSetup | None:
+    """``VehicleConfig`` + the axle's position (``schema/config.py:72-90,120,140``); None when not authored."""
+    if vehicle.get("wheelbase") is None or vehicle.get("cg_position") is None:
+        return None
+    cg = vehicle["cg_position"]
+    bias = vehicle.get("front_brake_bias")
+    lower = lambda v: None if v is None else str(v).lower()  # noqa: E731
+    return VehicleSetup(
+        wheelbase=float(vehicle["wheelbase"]),
+        cg_position=(float(cg["x"]), float(cg["y"]), float(cg["z"])),
+        front_brake_bias=None if bias is None else float(bias),
+        driven_axle=lower(vehicle.get("driven_axle")),
+        axle_position=lower(axle_position),
     )
 
 
@@ -114,14 +131,14 @@ def _mirror(points: dict) -> dict:
 
 
 def _build_corner(kind: str, name: str, side: Side, hardpoints: dict, config: Mapping[str, Any],
-                  actuation=None, spring=None, external_pickups: tuple = ()):
+                  actuation=None, spring=None, external_pickups: tuple = (), vehicle: VehicleSetup | None = None):
     if kind == "double_wishbone":
         act, spr = _mechanisms(actuation, spring, external_pickups)
         return DoubleWishboneSuspension(name=name, side=side, hardpoints=hardpoints, wheel=_wheel(config),
-                                        steered=_steered(config), actuation=act, spring=spr)
+                                        steered=_steered(config), vehicle=vehicle, actuation=act, spring=spr)
     if kind == "macpherson":
         return MacPhersonSuspension(name=name, side=side, hardpoints=hardpoints, wheel=_wheel(config),
-                                    steered=_steered(config))
+                                    steered=_steered(config), vehicle=vehicle)
     raise ValueError(f"Unsupported geometry type: '{kind}'")
 
 
@@ -137,7 +154,8 @@ def build_suspension(data: Mapping[str, Any]) -> Suspension:
         config = data["config"]
         _check_shim(config)
         return _build_corner(kind, str(data.get("name", "unnamed")), _side(data.get("side", "left")),
-                             _hardpoints(data["hardpoints"]), config, data.get("actuation"), data.get("spring"))
+                             _hardpoints(data["hardpoints"]), config, data.get("actuation"), data.get("spring"),
+                             vehicle=_vehicle(config, config.get("axle_position")))
     if scope != "axle":
         raise ValueError(f"Unsupported geometry scope: '{scope}'")
 
@@ -174,7 +192,8 @@ def build_suspension(data: Mapping[str, Any]) -> Suspension:
     corners = {}
     for side, points in ((Side.LEFT, left), (Side.RIGHT, right)):
         corners[side] = _build_corner(kind, f"{name}_{side.name.lower()}", side, points, axle_config,
-                                      axle_config.get("actuation"), axle_config.get("spring"), external)
+                                      axle_config.get("actuation"), axle_config.get("spring"), external,
+                                      vehicle=_vehicle(data["vehicle_config"] or {}, axle_config.get("axle_position")))
     return AxleSuspension(name=name, corners=corners, arb_center_points=center, arb_droplink_points=droplinks)
 
 

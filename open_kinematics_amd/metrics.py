@@ -1,7 +1,7 @@
 """
-Corner state metrics of solved sweep states on the device: camber, caster, KPI,
-roadwheel angle, wheel travel, half-track, scrub radius and mechanical trail — the reference's
-``core/metrics/angles.py``, ``travel.py`` and ``steering_geometry.py`` — and their derivatives along
+State metrics of solved sweep states on the device: the reference's whole corner
+catalog (``core/metrics/catalog.py``: angles, travel, steering geometry, instant centres, swing arms,
+damper length, anti-geometry) plus the axle-scope metrics (``axle_metrics.py``), and their derivatives along
 the solution-manifold tangents (the raw material of ``core/metrics/derivatives.py``'s
 ``deriv_<response>_wrt_<driver>`` columns).  One streaming kernel launch per batch
 (``okx_corner_metrics_batch``); tensors stay in HBM.
@@ -16,10 +16,23 @@ import numpy as np
 import torch
 
 from . import _lib
-from .enums import PointID
+from .enums import PointID, PointRef, Side
 
-METRIC_NAMES = ("camber", "caster", "kpi", "roadwheel_angle", "wheel_travel", "half_track", "scrub_radius",
-                "mechanical_trail")  # column order = OKX_METRIC_* (include/okx.h); names = metrics/catalog.py
+METRIC_NAMES = (
+    "camber", "caster", "kpi", "roadwheel_angle", "wheel_travel", "half_track", "scrub_radius", "mechanical_trail",
+    "svic_x", "svic_z", "svsa_length", "fvic_y", "fvic_z", "fvsa_length", "damper_length", "svsa_angle",
+    "anti_dive", "anti_lift", "anti_squat",
+)  # column order = OKX_METRIC_* (include/okx.h)
+# the reference's export order (metrics/catalog.py:71-146)
+CATALOG_ORDER = (
+    "camber", "caster", "kpi", "scrub_radius", "mechanical_trail", "roadwheel_angle", "svic_x", "svic_z",
+    "svsa_length", "fvic_y", "fvic_z", "fvsa_length", "wheel_travel", "half_track", "damper_length", "svsa_angle",
+    "anti_dive", "anti_lift", "anti_squat",
+)
+AXLE_METRIC_NAMES = ("heave", "roll", "ride_height_change", "track", "roll_center_y", "roll_center_z",
+                     "rack_displacement")  # = OKX_AXLE_METRIC_*, the order of metrics/axle_metrics.py:47-70
+_IA_KINDS = {None: 0, "two_planes": 1, "plane_and_strut": 2}
+_AXLE_POSITIONS = {None: 0, "front": 1, "rear": 2}
 
 
 class CornerRoles(C.Structure):
@@ -29,19 +42,58 @@ class CornerRoles(C.Structure):
         ("wheel_center", C.c_int32), ("contact_patch", C.c_int32),
         ("axle_inboard", C.c_int32), ("axle_outboard", C.c_int32),
         ("steer_lower", C.c_int32), ("steer_upper", C.c_int32),
+        ("instant_axis_kind", C.c_int32), ("instant_axis_point", C.c_int32 * 6),
+        ("damper_top", C.c_int32), ("damper_bottom", C.c_int32),
+        ("rack_attachment", C.c_int32),
+        ("axle_position", C.c_int32), ("driven_axle", C.c_int32),
         ("side_sign", C.c_double), ("design_wheel_center_z", C.c_double),
+        ("design_contact_patch_z", C.c_double), ("design_rack_y", C.c_double),
+        ("wheelbase", C.c_double), ("cg_z", C.c_double), ("front_brake_bias", C.c_double),
     ]
 
 
-def corner_roles(suspension, program) -> CornerRoles:
+def make_roles(*, wheel_center: int, contact_patch: int, axle_inboard: int, axle_outboard: int, steer_lower: int,
+               steer_upper: int, side_sign: float, design_wheel_center_z: float,
+               instant_axis: tuple | None = None, damper: tuple | None = None, rack_attachment: int = -1,
+               design_contact_patch_z: float = 0.0, design_rack_y: float = 0.0, wheelbase: float = float("nan"),
+               cg_z: float = float("nan"), front_brake_bias: float | None = None, axle_position: str | None = None,
+               driven_axle: str | None = None) -> CornerRoles:
+    """
+    ``okx_corner_roles`` from plain indices.  ``instant_axis`` = ``("two_planes", six indices)`` or
+    ``("plane_and_strut", four indices)``; ``damper`` = ``(top, bottom)``.
+    """
+    kind, points = instant_axis if instant_axis is not None else (None, ())
+    if kind not in _IA_KINDS:
+        raise ValueError(f"unknown instant-axis construction {kind!r}")
+    if axle_position not in _AXLE_POSITIONS or driven_axle not in _AXLE_POSITIONS:
+        raise ValueError("axle_position / driven_axle must be None, 'front' or 'rear'")
+    padded = [int(k) for k in points] + [-1] * (6 - len(points))
+    top, bottom = damper if damper is not None else (-1, -1)
+    return CornerRoles(
+        wheel_center=wheel_center, contact_patch=contact_patch, axle_inboard=axle_inboard, axle_outboard=axle_outboard,
+        steer_lower=steer_lower, steer_upper=steer_upper, instant_axis_kind=_IA_KINDS[kind],
+        instant_axis_point=(C.c_int32 * 6)(*padded), damper_top=int(top), damper_bottom=int(bottom),
+        rack_attachment=int(rack_attachment), axle_position=_AXLE_POSITIONS[axle_position],
+        driven_axle=_AXLE_POSITIONS[driven_axle], side_sign=float(side_sign),
+        design_wheel_center_z=float(design_wheel_center_z), design_contact_patch_z=float(design_contact_patch_z),
+        design_rack_y=float(design_rack_y), wheelbase=float(wheelbase), cg_z=float(cg_z),
+        front_brake_bias=float("nan") if front_brake_bias is None else float(front_brake_bias),
+    )
+
+
+def corner_roles(suspension, program, side=None) -> CornerRoles:
     """
     Role indices into ``program.out_point`` from the corner's role hooks
-    (``wheel_axis_points()``, ``steering_axis_points()``, ``side``; reference
-    ``suspensions/corner/base.py``, ``metrics/context.py:82-104``).
+    (``wheel_axis_points()``, ``steering_axis_points()``, ``damper_points()``, ``rack_attachment_point()``,
+    the instant-axis construction, ``side``; reference ``suspensions/corner/base.py``,
+    ``metrics/context.py:82-165``).  For one corner of an axle program pass the axle's corner and its
+    ``side``: the points are then looked up as ``PointRef(side, point)``.
     """
     out_keys = [program.point_keys[k] for k in program.out_point]
 
     def index(key) -> int:
+        if side is not None:
+            key = PointRef(side, key)
         try:
             return out_keys.index(key)
         except ValueError:
@@ -49,22 +101,41 @@ def corner_roles(suspension, program) -> CornerRoles:
 
     axle_in, axle_out = suspension.wheel_axis_points()
     lower, upper = suspension.steering_axis_points()
-    side = getattr(suspension, "lateral_sign", None)
-    if side is None:
-        side = suspension.side.lateral_sign
-    design = suspension.initial_state().positions[PointID.WHEEL_CENTER]
-    return CornerRoles(
+    sign = getattr(suspension, "lateral_sign", None)
+    if sign is None:
+        sign = suspension.side.lateral_sign
+    design = suspension.initial_state().positions
+    xyz = lambda key: np.asarray(getattr(design[key], "data", design[key]), dtype=np.float64)  # noqa: E731
+    axis = suspension.instant_axis_points() if hasattr(suspension, "instant_axis_points") else None
+    damper = suspension.damper_points() if hasattr(suspension, "damper_points") else None
+    rack = suspension.rack_attachment_point() if hasattr(suspension, "rack_attachment_point") else None
+    vehicle = getattr(suspension, "vehicle", None)
+    return make_roles(
         wheel_center=index(PointID.WHEEL_CENTER), contact_patch=index(PointID.CONTACT_PATCH_CENTER),
-        axle_inboard=index(axle_in), axle_outboard=index(axle_out),
-        steer_lower=index(lower), steer_upper=index(upper),
-        side_sign=float(side), design_wheel_center_z=float(np.asarray(getattr(design, "data", design))[2]),
+        axle_inboard=index(axle_in), axle_outboard=index(axle_out), steer_lower=index(lower), steer_upper=index(upper),
+        side_sign=float(sign), design_wheel_center_z=float(xyz(PointID.WHEEL_CENTER)[2]),
+        instant_axis=None if axis is None else (axis[0], tuple(index(k) for k in axis[1])),
+        damper=None if damper is None else (index(damper[0]), index(damper[1])),
+        rack_attachment=-1 if rack is None else index(rack),
+        design_contact_patch_z=float(xyz(PointID.CONTACT_PATCH_CENTER)[2]),
+        design_rack_y=0.0 if rack is None else float(xyz(rack)[1]),
+        wheelbase=float("nan") if vehicle is None else vehicle.wheelbase,
+        cg_z=float("nan") if vehicle is None else vehicle.cg_position[2],
+        front_brake_bias=None if vehicle is None else vehicle.front_brake_bias,
+        axle_position=None if vehicle is None else vehicle.axle_position,
+        driven_axle=None if vehicle is None else vehicle.driven_axle,
     )
+
+
+def axle_roles(axle, program) -> tuple[CornerRoles, CornerRoles]:
+    """(left, right) roles of an ``AxleSuspension``'s corners inside the axle program's output points."""
+    return corner_roles(axle.corners[Side.LEFT], program, Side.LEFT), corner_roles(axle.corners[Side.RIGHT], program, Side.RIGHT)
 
 
 @dataclass
 class CornerMetrics:
-    values: torch.Tensor              # [B, 8] float64, device
-    derivatives: torch.Tensor | None  # [B, T, 8]: d metric / d target (deg or mm per mm of target)
+    values: torch.Tensor              # [B, 19] float64, device (NaN where the reference reports None)
+    derivatives: torch.Tensor | None  # [B, T, 19]: d metric / d target (metric units per mm of target)
 
     def column(self, name: str) -> torch.Tensor:
         return self.values[:, METRIC_NAMES.index(name)]
@@ -78,7 +149,7 @@ class CornerMetrics:
 def corner_state_metrics(roles: CornerRoles, positions: torch.Tensor, tangents: torch.Tensor | None = None) -> CornerMetrics:
     """
     ``positions [B, n_out, 3]`` (device, as returned by ``DeviceProgram.solve``) and optionally
-    ``tangents [B, T, n_out, 3]`` (``DeviceProgram.tangents``) -> the eight state metrics per state
+    ``tangents [B, T, n_out, 3]`` (``DeviceProgram.tangents``) -> the catalog's state metrics per state
     and, with tangents, their derivative with respect to every sweep target.
     """
     if not positions.is_cuda:
@@ -102,3 +173,22 @@ def corner_state_metrics(roles: CornerRoles, positions: torch.Tensor, tangents: 
                                           ptr(deriv), C.c_void_p(stream))
     _lib.check(rc, "okx_corner_metrics_batch")
     return CornerMetrics(values, deriv)
+
+
+def axle_state_metrics(left: CornerRoles, right: CornerRoles, positions: torch.Tensor) -> torch.Tensor:
+    """
+    Axle-scope metrics (``metrics/axle_metrics.py:21-95``) of solved axle states ``positions [B, n_out, 3]``:
+    ``[B, 7]`` in ``AXLE_METRIC_NAMES`` order, NaN where the reference reports None.  The per-corner rows
+    of an axle are ``corner_state_metrics`` with ``axle_roles``' left / right roles.
+    """
+    if not positions.is_cuda:
+        raise RuntimeError("axle_state_metrics needs device tensors (there is no CPU fallback)")
+    lib = _lib.load()
+    pos = positions.to(torch.float64).contiguous()
+    values = torch.empty((pos.shape[0], len(AXLE_METRIC_NAMES)), dtype=torch.float64, device=pos.device)
+    stream = torch.cuda.current_stream(pos.device).cuda_stream
+    with torch.cuda.device(pos.device):
+        rc = lib.okx_axle_metrics_batch(C.byref(left), C.byref(right), pos.shape[0], pos.shape[1],
+                                        C.c_void_p(pos.data_ptr()), C.c_void_p(values.data_ptr()), C.c_void_p(stream))
+    _lib.check(rc, "okx_axle_metrics_batch")
+    return values

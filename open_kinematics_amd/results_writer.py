@@ -34,6 +34,11 @@ STANDARD_COLUMNS = ("step_index", "solver_converged", "solver_max_residual", "so
 METRIC_UNITS = {
     "camber": "deg", "caster": "deg", "kpi": "deg", "roadwheel_angle": "deg",
     "wheel_travel": "mm", "half_track": "mm", "scrub_radius": "mm", "mechanical_trail": "mm",
+    "svic_x": "mm", "svic_z": "mm", "svsa_length": "mm", "fvic_y": "mm", "fvic_z": "mm", "fvsa_length": "mm",
+    "damper_length": "mm", "svsa_angle": "deg", "anti_dive": "%", "anti_lift": "%", "anti_squat": "%",
+    # axle scope (metrics/axle_metrics.py, metrics/registry.py)
+    "heave": "mm", "roll": "deg", "ride_height_change": "mm", "track": "mm", "roll_center_y": "mm",
+    "roll_center_z": "mm", "rack_displacement": "mm",
 }
 
 

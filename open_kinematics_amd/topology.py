@@ -249,6 +249,24 @@ class WheelConfig:
         return (self.rim_diameter * MM_PER_INCH + 2 * (self.aspect_ratio * self.section_width)) / 2
 
 
+@dataclass(frozen=True)
+class VehicleSetup:
+    """Vehicle-wide numbers the anti-geometry metrics read (``schema/config.py:72-90,140``)."""
+
+    wheelbase: float
+    cg_position: tuple
+    front_brake_bias: float | None = None
+    driven_axle: str | None = None    # "front" / "rear"
+    axle_position: str | None = None  # "front" / "rear"
+
+    def __post_init__(self) -> None:
+        if self.front_brake_bias is not None and not 0.0 <= self.front_brake_bias <= 1.0:
+            raise ValueError(f"front_brake_bias must be in [0, 1], got {self.front_brake_bias}")
+        for value in (self.driven_axle, self.axle_position):
+            if value not in (None, "front", "rear"):
+                raise ValueError(f"axle position must be 'front' or 'rear', got {value!r}")
+
+
 WHEEL_OUTPUT_POINTS = (
     P.AXLE_INBOARD, P.AXLE_OUTBOARD, P.AXLE_MIDPOINT, P.WHEEL_CENTER,
     P.WHEEL_INBOARD, P.WHEEL_OUTBOARD, P.CONTACT_PATCH_CENTER,
@@ -287,6 +305,7 @@ class CornerSuspension(Suspension):
     hardpoints: dict
     wheel: WheelConfig
     steered: bool
+    vehicle: VehicleSetup | None = None
     _state: SuspensionState | None = field(default=None, init=False, repr=False)
 
     REQUIRED = frozenset()
@@ -317,6 +336,14 @@ class CornerSuspension(Suspension):
     def steering_axis_points(self) -> tuple:
         """(lower, upper) steering pivots; architecture specific."""
         raise NotImplementedError
+
+    def damper_points(self):
+        """(top, bottom) of an installed linear spring/damper, or None (``suspensions/base.py:188-190``)."""
+        return None
+
+    def instant_axis_points(self):
+        """(kind, points) the upright's instant axis is constructed from, or None (``compute_instant_axis``)."""
+        return None
 
     @property
     def lateral_sign(self) -> float:
@@ -396,6 +423,15 @@ class DoubleWishboneSuspension(CornerSuspension):
     def steering_axis_points(self) -> tuple:
         """``double_wishbone.py:223-225``: the two outboard ball joints."""
         return (P.LOWER_WISHBONE_OUTBOARD, P.UPPER_WISHBONE_OUTBOARD)
+
+    def damper_points(self):
+        """``double_wishbone.py:219-221``: the coil-over's mounts when one is installed."""
+        return (P.STRUT_TOP, P.STRUT_BOTTOM) if self.spring.coilover else None
+
+    def instant_axis_points(self):
+        """``double_wishbone.py:376-403``: where the upper and lower wishbone planes meet."""
+        return ("two_planes", (P.UPPER_WISHBONE_INBOARD_FRONT, P.UPPER_WISHBONE_INBOARD_REAR, P.UPPER_WISHBONE_OUTBOARD,
+                               P.LOWER_WISHBONE_INBOARD_FRONT, P.LOWER_WISHBONE_INBOARD_REAR, P.LOWER_WISHBONE_OUTBOARD))
 
     def free_points(self) -> tuple:
         return (*self.FREE_POINTS, *self.heading_link.free_points, *self.actuation.free_points, *self.spring.free_points)
@@ -481,6 +517,15 @@ class MacPhersonSuspension(CornerSuspension):
     def steering_axis_points(self) -> tuple:
         """``macpherson.py:210-212``: lower ball joint to the strut top."""
         return (P.LOWER_WISHBONE_OUTBOARD, P.STRUT_TOP)
+
+    def damper_points(self):
+        """``macpherson.py:220-222``: the strut is the spring/damper."""
+        return (P.STRUT_TOP, P.STRUT_BOTTOM)
+
+    def instant_axis_points(self):
+        """``macpherson.py:325-355``: lower-arm plane and the plane through the strut top normal to the strut."""
+        return ("plane_and_strut", (P.LOWER_WISHBONE_INBOARD_FRONT, P.LOWER_WISHBONE_INBOARD_REAR,
+                                    P.LOWER_WISHBONE_OUTBOARD, P.STRUT_TOP))
 
     def free_points(self) -> tuple:
         return (*self.FREE_POINTS, *self.heading_link.free_points)
