@@ -363,6 +363,48 @@ int32_t okx_axle_metrics_batch(const okx_corner_roles* left, const okx_corner_ro
                                void* stream);
 
 /*
+ * Camber-shim setup solve: the pose a double-wishbone corner takes when the split
+ * upright's shim stack is changed from its design to its setup thickness, for n_geometries
+ * geometries at once.  Replaces solve_camber_shim_assembly (suspensions/config/shims.py:284-501: 7 or 8
+ * variables, 10 or 11 residuals, scipy MINPACK `lm`) and DoubleWishboneSuspension.apply_camber_shim
+ * (corner/double_wishbone.py:501-570): the upper ball joint moves on the upper wishbone's arc, the
+ * upright's attachments rotate about the lower ball joint, an upright-mounted pushrod turns the
+ * rocker group.  Indices are rows of the point table the positions are given in (the program's
+ * point list: okx_program_desc.design_pos).  The table is rewritten in place and can go straight
+ * into okx_rebind_design.
+ */
+#define OKX_SHIM_MAX_POINTS 8
+#define OKX_SHIM_PARAMS 11 /* per geometry: face point a (3), face point b (3), face normal (3), design, setup thickness
+                              (CamberShimConfig, schema/config.py:52-70) */
+typedef struct okx_shim_roles {
+  int32_t upper_outboard, lower_outboard;            /* UPPER_/LOWER_WISHBONE_OUTBOARD (ball joints)      */
+  int32_t upper_inboard_front, upper_inboard_rear;   /* upper wishbone axis (shims.py:386-390)            */
+  int32_t heading_inboard, heading_outboard;         /* installed track rod / toe link (shims.py:399-403) */
+  int32_t n_upright_points;                          /* upright_attachment_points() (double_wishbone.py:572-581) */
+  int32_t upright_point[OKX_SHIM_MAX_POINTS];
+  int32_t rocker;                                    /* 1: upright-mounted pushrod (CamberShimRockerCoupling, shims.py:49-56) */
+  int32_t rocker_axis_a, rocker_axis_b, pushrod_inboard, pushrod_outboard;
+  int32_t n_rocker_points;                           /* rocker group (mechanisms.py:247-265)              */
+  int32_t rocker_point[OKX_SHIM_MAX_POINTS];
+} okx_shim_roles;
+
+typedef struct okx_shim_info {
+  double residual_norm;       /* CamberShimAssemblySolution.constraint_residual_norm             */
+  double max_residual;
+  double upright_angle_rad;   /* upright_body_rot_angle_rad                                      */
+  double rocker_angle_rad;
+  double wishbone_angle_rad;
+  int32_t converged;          /* max residual <= SOLVE_ACCEPT_RESIDUAL (shims.py:456-462)        */
+  int32_t iterations;
+} okx_shim_info;
+
+int32_t okx_camber_shim_batch(const okx_shim_roles* roles, int64_t n_geometries, int32_t n_points,
+                              double* d_points,        /* [G][n_points][3] in: authored, out: setup */
+                              const double* d_shim,    /* [G][OKX_SHIM_PARAMS] */
+                              okx_shim_info* d_info,   /* [G] or NULL */
+                              void* stream);
+
+/*
  * Runtime specialisation.  okx_program_create also GENERATES a HIP kernel for the program at
  * hand (straight-line residual / Jacobian / normal-equation / LDL^T code, four lanes per
  * problem), compiles it with hiprtc and loads it; the reference does the analogous thing

@@ -35,6 +35,7 @@ EXPORTS = (
     "okx_tangent_batch",
     "okx_corner_metrics_batch",
     "okx_axle_metrics_batch",
+    "okx_camber_shim_batch",
 )
 
 _lib = None
@@ -98,6 +99,8 @@ def load() -> C.CDLL:
     lib.okx_corner_metrics_batch.restype = i32
     lib.okx_axle_metrics_batch.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     lib.okx_axle_metrics_batch.restype = i32
+    lib.okx_camber_shim_batch.argtypes = [vp, i64, i32, vp, vp, vp, vp]
+    lib.okx_camber_shim_batch.restype = i32
     lib.okx_debug_quad_eval.argtypes = [vp, i64, vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.okx_debug_quad_eval.restype = i32
     if lib.okx_abi_version() != 1:

@@ -13,6 +13,7 @@
 #include "okx_kernels.hip"
 #include "okx_packed.hip"
 #include "okx_metrics.hip"
+#include "okx_shim.hip"
 #include "okx_quad.hpp"
 
 struct okx_program {
@@ -675,6 +676,42 @@ int32_t okx_corner_metrics_batch(const okx_corner_roles* roles, int64_t n_states
   a.n_targets = n_targets;
   const long long blocks = (n_states + 255) / 256;
   hipLaunchKernelGGL(okx::okx_corner_metrics_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
+int32_t okx_camber_shim_batch(const okx_shim_roles* roles, int64_t n_geometries, int32_t n_points, double* d_points,
+                              const double* d_shim, okx_shim_info* d_info, void* stream) {
+  if (!roles || !d_points || !d_shim) return fail(OKX_ERR_INVALID, "null pointer");
+  if (n_geometries < 0 || n_points <= 0) return fail(OKX_ERR_INVALID, "bad dimension");
+  auto bad = [&](int32_t k) { return k < 0 || k >= n_points; };
+  if (bad(roles->upper_outboard) || bad(roles->lower_outboard) || bad(roles->upper_inboard_front) ||
+      bad(roles->upper_inboard_rear) || bad(roles->heading_inboard) || bad(roles->heading_outboard))
+    return fail(OKX_ERR_INVALID, "shim role is not a point of the table");
+  if (roles->n_upright_points < 0 || roles->n_upright_points > OKX_SHIM_MAX_POINTS || roles->n_rocker_points < 0 ||
+      roles->n_rocker_points > OKX_SHIM_MAX_POINTS)
+    return fail(OKX_ERR_INVALID, "at most %d upright / rocker points", OKX_SHIM_MAX_POINTS);
+  for (int k = 0; k < roles->n_upright_points; ++k)
+    if (bad(roles->upright_point[k]) || roles->upright_point[k] == roles->lower_outboard)
+      return fail(OKX_ERR_INVALID, "upright point %d is not a movable point of the table", k);
+  if (roles->rocker != 0 && roles->rocker != 1) return fail(OKX_ERR_INVALID, "rocker must be 0 or 1");
+  if (roles->rocker) {
+    if (bad(roles->rocker_axis_a) || bad(roles->rocker_axis_b) || bad(roles->pushrod_inboard) ||
+        bad(roles->pushrod_outboard))
+      return fail(OKX_ERR_INVALID, "rocker coupling role is not a point of the table");
+    for (int k = 0; k < roles->n_rocker_points; ++k)
+      if (bad(roles->rocker_point[k])) return fail(OKX_ERR_INVALID, "rocker point %d is not a point of the table", k);
+  }
+  if (n_geometries == 0) return OKX_OK;
+  okx::shim::ShimArgs a;
+  a.roles = *roles;
+  a.points = d_points;
+  a.shim = d_shim;
+  a.info = d_info;
+  a.n_geometries = n_geometries;
+  a.n_points = n_points;
+  const long long blocks = (n_geometries + 63) / 64;
+  hipLaunchKernelGGL(okx::shim::okx_camber_shim_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return OKX_OK;
 }

@@ -13,6 +13,7 @@ from typing import Any, Mapping
 import numpy as np
 
 from .enums import Axis, PointID, Side, TargetPositionMode
+from .shims import CamberShimConfig
 from .state import Point3
 from .targeting import PointTarget, PointTargetAxis, PointTargetVector, SweepConfig, validate_sweep_controls
 from .topology import (
@@ -93,16 +94,20 @@ def _steered(config: Mapping[str, Any]) -> bool:
     return kind == "rack"
 
 
-def _check_shim(config: Mapping[str, Any]) -> None:
-    shim = config.get("camber_shim")
+def _shim(config: Mapping[str, Any], kind: str) -> CamberShimConfig | None:
+    """``CamberShimConfig`` (``schema/config.py:52-70``); only the double wishbone supports it (``build.py:378-391``)."""
+    shim = config.get("camber_shim") if config else None
     if shim is None:
-        return
-    # design == setup is the reference's early exit (config/shims.py:346-357): no pose change
-    if abs(float(shim["setup_thickness"]) - float(shim["design_thickness"])) >= 1e-6:
-        raise NotImplementedError(
-            "camber-shim setup solves are outside the accelerated path (SURVEY.md §8f #4); "
-            "author the geometry at its setup condition"
-        )
+        return None
+    if kind == "macpherson":
+        raise ValueError(f"Suspension type '{kind}' does not support outboard camber shims")
+    if kind != "double_wishbone":
+        return None  # unknown type: _build_corner reports it
+    _require_keys(shim, {"shim_face_point_a", "shim_face_point_b", "shim_face_normal", "design_thickness",
+                         "setup_thickness"}, "camber_shim")
+    xyz = lambda v: (float(v["x"]), float(v["y"]), float(v["z"]))  # noqa: E731
+    return CamberShimConfig(xyz(shim["shim_face_point_a"]), xyz(shim["shim_face_point_b"]), xyz(shim["shim_face_normal"]),
+                            float(shim["design_thickness"]), float(shim["setup_thickness"]))
 
 
 def _mechanisms(actuation: Mapping[str, Any] | None, spring: Mapping[str, Any] | None,
@@ -131,11 +136,13 @@ def _mirror(points: dict) -> dict:
 
 
 def _build_corner(kind: str, name: str, side: Side, hardpoints: dict, config: Mapping[str, Any],
-                  actuation=None, spring=None, external_pickups: tuple = (), vehicle: VehicleSetup | None = None):
+                  actuation=None, spring=None, external_pickups: tuple = (), vehicle: VehicleSetup | None = None,
+                  camber_shim: CamberShimConfig | None = None):
     if kind == "double_wishbone":
         act, spr = _mechanisms(actuation, spring, external_pickups)
         return DoubleWishboneSuspension(name=name, side=side, hardpoints=hardpoints, wheel=_wheel(config),
-                                        steered=_steered(config), vehicle=vehicle, actuation=act, spring=spr)
+                                        steered=_steered(config), vehicle=vehicle, actuation=act, spring=spr,
+                                        camber_shim=camber_shim)
     if kind == "macpherson":
         return MacPhersonSuspension(name=name, side=side, hardpoints=hardpoints, wheel=_wheel(config),
                                     steered=_steered(config), vehicle=vehicle)
@@ -152,19 +159,21 @@ def build_suspension(data: Mapping[str, Any]) -> Suspension:
         _require_keys(data, {"type", "scope", "side", "name", "version", "units", "actuation", "spring",
                              "hardpoints", "config"}, "geometry")
         config = data["config"]
-        _check_shim(config)
         return _build_corner(kind, str(data.get("name", "unnamed")), _side(data.get("side", "left")),
                              _hardpoints(data["hardpoints"]), config, data.get("actuation"), data.get("spring"),
-                             vehicle=_vehicle(config, config.get("axle_position")))
+                             vehicle=_vehicle(config, config.get("axle_position")), camber_shim=_shim(config, kind))
     if scope != "axle":
         raise ValueError(f"Unsupported geometry scope: '{scope}'")
 
     _require_keys(data, {"type", "scope", "name", "version", "units", "vehicle_config", "axle_config",
                          "hardpoints"}, "geometry")
     axle_config = data["axle_config"]
-    for setup in ("left_setup", "right_setup"):
-        if axle_config.get(setup):
-            _check_shim(axle_config[setup])
+    left_shim = _shim(axle_config.get("left_setup") or {}, kind)
+    if axle_config.get("right_setup") is not None:
+        right_shim = _shim(axle_config["right_setup"], kind)
+    else:  # mirrored right setup (build.py:310-318,357-375)
+        right_shim = None if left_shim is None else left_shim.mirrored()
+    shims = {Side.LEFT: left_shim, Side.RIGHT: right_shim}
     hp = data["hardpoints"]
     _require_keys(hp, {"left", "right", "center"}, "axle hardpoints")
     left = _hardpoints(hp["left"])
@@ -193,7 +202,8 @@ def build_suspension(data: Mapping[str, Any]) -> Suspension:
     for side, points in ((Side.LEFT, left), (Side.RIGHT, right)):
         corners[side] = _build_corner(kind, f"{name}_{side.name.lower()}", side, points, axle_config,
                                       axle_config.get("actuation"), axle_config.get("spring"), external,
-                                      vehicle=_vehicle(data["vehicle_config"] or {}, axle_config.get("axle_position")))
+                                      vehicle=_vehicle(data["vehicle_config"] or {}, axle_config.get("axle_position")),
+                                      camber_shim=shims[side])
     return AxleSuspension(name=name, corners=corners, arb_center_points=center, arb_droplink_points=droplinks)
 
 

@@ -10,8 +10,9 @@ Reference (``core/suspensions/``): ``corner/double_wishbone.py:233-308``,
 
 Scope: double-wishbone corner (direct or pushrod-rocker actuation; no spring, coil-over or
 torsion bar; rack or fixed toe link), MacPherson corner, and the composed axle with rack
-coupling and a U-bar anti-roll bar.  Camber-shim setup solves, T-bar ARBs and heave links are
-outside the hot path and raise ``NotImplementedError``.
+coupling and a U-bar anti-roll bar; a double wishbone's camber-shim setup solve runs on the device
+(``shims.py``).  T-bar ARBs and heave links are outside the hot path and raise
+``NotImplementedError``.
 """
 
 from __future__ import annotations
@@ -365,9 +366,13 @@ class CornerSuspension(Suspension):
     def initial_state(self) -> SuspensionState:
         if self._state is None:
             positions = {k: v.copy() for k, v in self.hardpoints.items()}
+            self.apply_setup(positions)
             DerivedPointsManager(self.derived_spec()).update_in_place(positions)
             self._state = SuspensionState(positions=positions, free_points=set(self.free_points()))
         return self._state
+
+    def apply_setup(self, positions: dict) -> None:
+        """Setup changes applied to the authored hardpoints before the design state is built (shims)."""
 
     def wheel_spec(self) -> DerivedPointsSpec:
         return build_wheel_derived_spec(self.wheel.offset, self.wheel.section_width, self.wheel.nominal_radius)
@@ -379,6 +384,7 @@ class DoubleWishboneSuspension(CornerSuspension):
 
     actuation: Actuation = None  # type: ignore[assignment]
     spring: CornerSpring = CornerSpring("none")
+    camber_shim: Any = None  # shims.CamberShimConfig or None
 
     REQUIRED = frozenset({
         P.LOWER_WISHBONE_INBOARD_FRONT, P.LOWER_WISHBONE_INBOARD_REAR, P.LOWER_WISHBONE_OUTBOARD,
@@ -423,6 +429,30 @@ class DoubleWishboneSuspension(CornerSuspension):
     def steering_axis_points(self) -> tuple:
         """``double_wishbone.py:223-225``: the two outboard ball joints."""
         return (P.LOWER_WISHBONE_OUTBOARD, P.UPPER_WISHBONE_OUTBOARD)
+
+    def upright_attachment_points(self) -> tuple:
+        """Points the upright carries through a camber-shim change (``double_wishbone.py:572-581``)."""
+        base = (P.AXLE_INBOARD, P.AXLE_OUTBOARD, self.heading_link.outboard_point)
+        if self.actuation.body == self.UPRIGHT_BODY:
+            pickup = P.PUSHROD_OUTBOARD if self.actuation.rocker else P.STRUT_BOTTOM
+            if pickup in self.hardpoints:
+                return (*base, pickup)
+        return base
+
+    def shim_rocker_points(self):
+        """Rocker group an upright-mounted pushrod turns during the shim solve, else None
+        (``double_wishbone.py:517-533,564-569``, ``mechanisms.py:198-200,247-265``)."""
+        if not (self.actuation.rocker and self.actuation.body == self.UPRIGHT_BODY):
+            return None
+        spring_points = (P.STRUT_BOTTOM,) if self.spring.coilover else ()
+        return tuple(dict.fromkeys((P.PUSHROD_INBOARD, *self.actuation.external_pickups, *spring_points)))
+
+    def apply_setup(self, positions: dict) -> None:
+        """``double_wishbone.py:232-244,501-570``: the camber-shim setup solve (on the device)."""
+        if self.camber_shim is not None and not self.camber_shim.unchanged:
+            from .shims import apply_camber_shim
+
+            apply_camber_shim(self, positions)
 
     def damper_points(self):
         """``double_wishbone.py:219-221``: the coil-over's mounts when one is installed."""

@@ -1,0 +1,190 @@
+"""GPU: camber-shim setup solve (okx_camber_shim_batch) against the reference's setup states and the oracle."""
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import gpu_available
+from test_shims_oracle import CASES, authored_hardpoints, load_shim_golden, oracle_roles, shim_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not gpu_available():
+        pytest.skip("no GPU")
+
+
+def _suspension(g, setup=None):
+    from open_kinematics_amd.input import build_suspension
+
+    geometry = yaml.safe_load(str(g["geometry_yaml"]))
+    if setup is not None:
+        geometry["config"]["camber_shim"]["setup_thickness"] = float(setup)
+    return build_suspension(geometry)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_device_setup_states_match_the_reference(case):
+    """One launch over all golden thicknesses: every hardpoint of the setup pose to 1e-9 mm."""
+    from open_kinematics_amd.shims import camber_shim_setup, shim_roles
+
+    g = load_shim_golden(case)
+    sus = _suspension(g)
+    keys = list(sus.hardpoints)
+    names = [k.name.lower() for k in keys]
+    rows = [g["names"].index(n) for n in names]
+    k_count = len(g["setup"])
+    table = torch.as_tensor(np.repeat(g["authored"][rows][None], k_count, axis=0), device="cuda:0").contiguous()
+    shim = torch.as_tensor(np.stack([sus.camber_shim.row(t) for t in g["setup"]]), device="cuda:0")
+    out, info = camber_shim_setup(shim_roles(sus, keys), table, shim)
+    assert out.data_ptr() == table.data_ptr()  # in place
+    got = out.cpu().numpy()
+    assert np.max(np.abs(got - g["positions"][:, rows])) <= 1e-9
+    assert np.all(info["converged"] == 1) and np.max(info["max_residual"]) <= 1e-10
+    angle = np.linalg.norm(g["upright_rotvec"], axis=1)
+    assert np.max(np.abs(info["upright_angle_rad"] - angle)) <= 1e-12
+    assert np.max(np.abs(info["rocker_angle_rad"] - g["rocker_angle"])) <= 1e-12
+    same = np.abs(g["setup"] - 30.0) < 1e-6
+    assert np.all(info["iterations"][same] == 0) and np.all(info["iterations"][~same] > 0)
+    if case == "dw_rocker":
+        assert np.all(np.abs(info["rocker_angle_rad"][~same]) > 1e-6)  # tests/test_camber_shims.py:254-307
+
+
+@pytest.mark.parametrize("case,setup", [("dw", 40.0), ("dw_rocker", 36.0), ("dw", 25.0)])
+def test_loader_builds_the_setup_state_on_the_device(case, setup):
+    """build_suspension(...).initial_state() with setup != design: authored + derived points as in the reference."""
+    g = load_shim_golden(case)
+    k = int(np.flatnonzero(np.abs(g["setup"] - setup) < 1e-9)[0])
+    state = _suspension(g, setup).initial_state()
+    assert [p.name.lower() for p in state.positions] == g["names"]
+    got = np.asarray([p.data for p in state.positions.values()])
+    assert np.max(np.abs(got - g["positions"][k])) <= 1e-9
+    moved = np.max(np.abs(got - g["authored"]), axis=1)
+    fixed = [n for n, m in zip(g["names"], moved) if m == 0.0]
+    # chassis-side points and the lower ball joint do not move (tests/test_camber_shims.py:401-449)
+    assert {"lower_wishbone_outboard", "upper_wishbone_inboard_front", "lower_wishbone_inboard_rear", "trackrod_inboard"} <= set(fixed)
+    assert moved[g["names"].index("axle_outboard")] > 0.1  # :452-475
+
+
+def test_batch_of_perturbed_geometries_keeps_the_assembly_invariants():
+    """4096 perturbed geometries x random setup thickness: invariants of tests/test_camber_shims.py + the oracle."""
+    from oracle.shim_oracle import apply
+    from open_kinematics_amd.shims import camber_shim_setup, shim_roles
+
+    g = load_shim_golden("dw_rocker")
+    sus = _suspension(g)
+    keys = list(sus.hardpoints)
+    names = [k.name.lower() for k in keys]
+    rows = [g["names"].index(n) for n in names]
+    rng = np.random.default_rng(7)
+    n_geo = 4096
+    authored = g["authored"][rows][None] + rng.normal(0.0, 0.5, size=(n_geo, len(rows), 3))
+    setup = rng.uniform(18.0, 44.0, size=n_geo)
+    setup[:8] = 30.0
+    shim = np.stack([sus.camber_shim.row(t) for t in setup])
+    table = torch.as_tensor(authored, device="cuda:0").contiguous()
+    out, info = camber_shim_setup(shim_roles(sus, keys), table, torch.as_tensor(shim, device="cuda:0"))
+    got = out.cpu().numpy()
+    assert np.all(info["converged"] == 1) and np.max(info["max_residual"]) <= 1e-9
+    assert np.array_equal(got[:8], authored[:8])
+    ix = names.index
+    dist = lambda p, a, b: np.linalg.norm(p[:, ix(a)] - p[:, ix(b)], axis=1)  # noqa: E731
+    for a, b in (("upper_wishbone_inboard_front", "upper_wishbone_outboard"),    # test_upper_arm_lengths_preserved
+                 ("upper_wishbone_inboard_rear", "upper_wishbone_outboard"),
+                 ("trackrod_inboard", "trackrod_outboard"),                       # test_trackrod_length_preserved
+                 ("pushrod_inboard", "pushrod_outboard"),                         # test_upright_pushrod_adds_solved_rocker_rotation
+                 ("lower_wishbone_outboard", "axle_inboard"), ("lower_wishbone_outboard", "axle_outboard"),
+                 ("lower_wishbone_outboard", "pushrod_outboard"),                 # upright points keep their LBJ distance
+                 ("rocker_axis_a", "pushrod_inboard"), ("rocker_axis_b", "strut_bottom")):
+        assert np.max(np.abs(dist(got, a, b) - dist(authored, a, b))) <= 1e-9, (a, b)
+    still = [ix(n) for n in names if n not in ("upper_wishbone_outboard", "trackrod_outboard", "axle_inboard", "axle_outboard",
+                                               "pushrod_outboard", "pushrod_inboard", "strut_bottom")]
+    assert np.array_equal(got[:, still], authored[:, still])
+    roles = oracle_roles(g)
+    for k in range(8, n_geo, 257):
+        cfg = shim_config(g, setup[k])
+        want, _ = apply({n: authored[k][ix(n)] for n in names}, cfg, roles, tight=True)
+        assert max(float(np.max(np.abs(want[n] - got[k][ix(n)]))) for n in names) <= 1e-9, k
+
+
+def test_shimmed_corner_sweeps_like_any_other():
+    """The setup state is the design state of the sweep: a bump sweep of the shimmed corner converges from it."""
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.input import build_sweep
+    from open_kinematics_amd.results_writer import point_key_name
+    from open_kinematics_amd.sweep import sweep_program
+
+    g = load_shim_golden("dw")
+    sus = _suspension(g, 40.0)
+    travel = [-30.0, -10.0, 0.0, 10.0, 30.0]
+    sweep = build_sweep({"version": 1, "targets": [
+        {"point": "trackrod_inboard", "direction": {"axis": "y"}, "mode": "relative", "values": [0.0] * len(travel)},
+        {"point": "wheel_center", "direction": {"axis": "z"}, "mode": "relative", "values": travel}]}, sus)
+    program, targets = sweep_program(sus, sweep)
+    res = DeviceProgram(program, "cuda:0").solve(torch.as_tensor(targets, device="cuda:0"))
+    assert np.all(res.accepted(res.info()))
+    pos = res.positions.cpu().numpy()
+    k = int(np.flatnonzero(np.abs(g["setup"] - 40.0) < 1e-9)[0])
+    mid = travel.index(0.0)  # the zero-travel step reproduces the setup state
+    out_names = [point_key_name(program.point_keys[p]) for p in program.out_point]
+    want = np.asarray([g["positions"][k][g["names"].index(n)] for n in out_names])
+    # the reference's softnorm distance rows leave a 1e-6 residual at the authored state, so the solved
+    # zero-travel state sits a few 1e-6 mm from it (same for an unshimmed corner)
+    assert np.max(np.abs(pos[mid] - want)) <= 1e-5
+    wc = out_names.index("wheel_center")
+    assert np.max(np.abs((pos[:, wc, 2] - want[wc, 2]) - np.asarray(travel))) <= 1e-9
+
+
+def test_shim_thickness_as_a_per_geometry_perturbation():
+    """C5 with shims: one program, a [G, P, 3] table shimmed in place on the device -> rebind -> geometry-major solve;
+    every geometry agrees with the loader-built corner of the same setup thickness."""
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.input import build_sweep
+    from open_kinematics_amd.shims import camber_shim_setup, shim_roles
+    from open_kinematics_amd.sweep import sweep_program
+
+    g = load_shim_golden("dw")
+    travel = [-20.0, 0.0, 25.0]
+    sweep_map = {"version": 1, "targets": [
+        {"point": "trackrod_inboard", "direction": {"axis": "y"}, "mode": "relative", "values": [0.0] * len(travel)},
+        {"point": "wheel_center", "direction": {"axis": "z"}, "mode": "relative", "values": travel}]}
+    base = _suspension(g)
+    program, targets = sweep_program(base, build_sweep(sweep_map, base))
+    setups = [24.0, 30.0, 37.5, 43.0]
+    dp = DeviceProgram(program, "cuda:0")
+    table = torch.as_tensor(np.repeat(program.design_pos[None], len(setups), axis=0), device="cuda:0").contiguous()
+    shim = torch.as_tensor(np.stack([base.camber_shim.row(t) for t in setups]), device="cuda:0")
+    camber_shim_setup(shim_roles(base, program.point_keys), table, shim)
+    gpos, gparam = dp.rebind(table)
+    wc = list(program.point_keys).index(program.point_keys[program.tgt_point[-1]])
+    t_abs = np.repeat(targets[None], len(setups), axis=0)
+    t_abs[:, :, -1] += (gpos[:, wc, 2].cpu().numpy() - program.design_pos[wc, 2])[:, None]  # relative to each setup state
+    res = dp.solve(torch.as_tensor(t_abs.reshape(-1, targets.shape[1]), device="cuda:0"), geom_pos=gpos,
+                   geom_row_param=gparam, steps_per_geometry=len(travel))
+    assert np.all(res.accepted(res.info()))
+    got = res.positions.cpu().numpy().reshape(len(setups), len(travel), -1, 3)
+    for k, t in enumerate(setups):
+        sus = _suspension(g, t)
+        prog_k, targets_k = sweep_program(sus, build_sweep(sweep_map, sus))
+        want = DeviceProgram(prog_k, "cuda:0").solve(torch.as_tensor(targets_k, device="cuda:0")).positions.cpu().numpy()
+        assert np.max(np.abs(got[k] - want)) <= 1e-9, t
+
+
+def test_bad_shim_roles_are_rejected():
+    from open_kinematics_amd.shims import ShimRoles, camber_shim_setup
+
+    pts = torch.zeros((2, 10, 3), dtype=torch.float64, device="cuda:0")
+    shim = torch.zeros((2, 11), dtype=torch.float64, device="cuda:0")
+    roles = ShimRoles(0, 1, 2, 3, 4, 5, 1)
+    roles.upright_point[0] = 12
+    with pytest.raises(ValueError, match="upright point 0"):
+        camber_shim_setup(roles, pts, shim)
+    with pytest.raises(ValueError, match="not a point of the table"):
+        camber_shim_setup(ShimRoles(0, 1, 2, 3, 4, 50, 0), pts, shim)
+    with pytest.raises(ValueError, match=r"\[G, 11\]"):
+        camber_shim_setup(ShimRoles(0, 1, 2, 3, 4, 5, 0), pts, shim[:, :5])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        camber_shim_setup(ShimRoles(0, 1, 2, 3, 4, 5, 0), pts.cpu(), shim.cpu())
