@@ -155,6 +155,10 @@ typedef struct okx_solve_opts {
                              applied and confirmed by a residual-only evaluation (cost must not
                              rise) instead of a full Jacobian / factorisation pass.
                              non-zero: always end on a computed correction <= step_tol.        */
+  int32_t predictor;      /* quad kernel, own-geometry launches.  non-zero: chain heads (cold starts) begin at
+                             the polynomial model of okx_program_fit_predictor instead of the design state
+                             (ignored until a predictor has been fitted).  Same solutions, fewer passes. */
+  int32_t pad;
 } okx_solve_opts;
 
 /* Per-problem result, the device analogue of SolverInfo (solver.py:83-96). */
@@ -361,6 +365,21 @@ int32_t okx_axle_metrics_batch(const okx_corner_roles* left, const okx_corner_ro
                                const double* d_pos,  /* [B][n_out][3] */
                                double* d_metrics,    /* [B][OKX_AXLE_METRIC_COUNT] */
                                void* stream);
+
+/*
+ * Chain-head predictor.  The reference warm-starts step k from step k-1 (solver.py:774) and starts a
+ * sweep at the design state; a batch that fills the chip solves every step as an independent cold
+ * start instead.  okx_program_fit_predictor solves the program once at the Chebyshev
+ * nodes of a target box [lo, hi] (host arrays of n_targets absolute target values; lo[t] == hi[t]
+ * holds target t), i.e. (degree + 1)^d cold solves for d varying targets in one synchronous launch,
+ * and keeps the Chebyshev coefficients of every free coordinate up to total degree `degree` (1..12;
+ * <= 0: 7).  Launches with opts.predictor != 0 on the program's own geometry start every chain head at that
+ * polynomial (targets clamped to the box).  The LM iteration, its stopping rules and the results (to
+ * step_tol) are unchanged; only the number of passes drops.  Needs the program's quad kernel and every
+ * free point among the output points.  Fitting again replaces the model.
+ */
+int32_t okx_program_fit_predictor(okx_program* prog, const double* lo, const double* hi, int32_t degree, void* stream);
+int32_t okx_program_has_predictor(const okx_program* prog);
 
 /*
  * Camber-shim setup solve: the pose a double-wishbone corner takes when the split

@@ -52,6 +52,8 @@ class SolveOpts(C.Structure):
         ("residual_tolerance", C.c_double),
         ("kernel", C.c_int32),
         ("reserved", C.c_int32),
+        ("predictor", C.c_int32),
+        ("pad", C.c_int32),
     ]
 
 

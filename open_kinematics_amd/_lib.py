@@ -36,6 +36,8 @@ EXPORTS = (
     "okx_corner_metrics_batch",
     "okx_axle_metrics_batch",
     "okx_camber_shim_batch",
+    "okx_program_fit_predictor",
+    "okx_program_has_predictor",
 )
 
 _lib = None
@@ -101,6 +103,10 @@ def load() -> C.CDLL:
     lib.okx_axle_metrics_batch.restype = i32
     lib.okx_camber_shim_batch.argtypes = [vp, i64, i32, vp, vp, vp, vp]
     lib.okx_camber_shim_batch.restype = i32
+    lib.okx_program_fit_predictor.argtypes = [vp, vp, vp, i32, vp]
+    lib.okx_program_fit_predictor.restype = i32
+    lib.okx_program_has_predictor.argtypes = [vp]
+    lib.okx_program_has_predictor.restype = i32
     lib.okx_debug_quad_eval.argtypes = [vp, i64, vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.okx_debug_quad_eval.restype = i32
     if lib.okx_abi_version() != 1:

@@ -68,6 +68,9 @@ class DeviceProgram:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.okx_program_create(self.host.byref(), C.byref(handle)), "okx_program_create")
         self._handle = handle
+        self._predictor: bool | None = None  # fitted lazily (fit_predictor)
+        self.predictor_box = None
+        self._predictor_note = ""
 
     @property
     def kernel(self) -> str:
@@ -112,9 +115,15 @@ class DeviceProgram:
         residual_tolerance: float | None = None,
         out: torch.Tensor | None = None,
         info_out: torch.Tensor | None = None,
+        predictor: bool | str | None = None,
     ) -> BatchResult:
         """
         Solve ``B`` problems; ``targets`` is ``[B, T]`` of absolute target scalars.
+
+        ``predictor``: chain heads start from the polynomial model of ``okx_program_fit_predictor`` instead of
+        the design state (own-geometry launches of the quad kernel).  ``None`` = use it when it can be
+        fitted (once, over the target box of the first such launch), ``True`` = require it, ``False`` = plain
+        cold starts, ``"all"`` = every chain step starts from the model (instead of the secant extrapolation).
 
         ``chain_len`` groups consecutive problems into warm-started chains walked by one
         wavefront each (``1`` independent cold starts, ``-1`` one chain per resident wavefront,
@@ -140,6 +149,10 @@ class DeviceProgram:
             opts.kernel = {"auto": 0, "single": 1, "packed": 2, "quad": 3}.get(kernel, kernel)
         if residual_tolerance is not None:
             opts.residual_tolerance = float(residual_tolerance)
+        if predictor is not False and geom_pos is None and opts.kernel in (0, 3):
+            # fitted once, over the box of the first launch's targets (later launches clamp to it; refit with fit_predictor)
+            if self.fit_predictor(targets if self._predictor is None else None, required=bool(predictor)):
+                opts.predictor = 2 if predictor == "all" else 1
         if geom_pos is not None:
             geom_pos = _as_f64(geom_pos, self.device)
             geom_row_param = _as_f64(geom_row_param, self.device)
@@ -281,6 +294,33 @@ class DeviceProgram:
         # is eliminated later) and the diagonal blocks in full: mirror what was not written
         ata = torch.where(ata != 0.0, ata, ata.transpose(1, 2))
         return r, ata, atr, dx
+
+    def fit_predictor(self, targets=None, *, lo=None, hi=None, degree: int = 0, required: bool = False) -> bool:
+        """
+        Fit the chain-head predictor (``okx_program_fit_predictor``) over the box of ``targets [B, T]`` (their
+        per-target min / max) or an explicit ``lo`` / ``hi``; without arguments an existing fit is kept.
+        Returns whether the program has one; programs without a quad kernel, with free points outside the
+        output list or with a node that does not converge simply go without unless ``required``.
+        """
+        if targets is not None or lo is not None:
+            if self.kernel != "quad" or self.program.n_targets == 0:
+                self._predictor, self._predictor_note = False, "no quad kernel / no targets"
+            else:
+                if lo is None:
+                    t = _as_f64(targets, self.device).reshape(-1, self.program.n_targets)
+                    lo, hi = t.min(dim=0).values.cpu().numpy(), t.max(dim=0).values.cpu().numpy()
+                lo = np.ascontiguousarray(lo, dtype=np.float64).reshape(self.program.n_targets)
+                hi = np.ascontiguousarray(hi, dtype=np.float64).reshape(self.program.n_targets)
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                with torch.cuda.device(self.device):
+                    rc = self.lib.okx_program_fit_predictor(self._handle, lo.ctypes.data_as(C.c_void_p),
+                                                            hi.ctypes.data_as(C.c_void_p), int(degree), C.c_void_p(stream))
+                self._predictor = rc == 0
+                self._predictor_note = "" if rc == 0 else _lib.last_error()
+                self.predictor_box = (lo, hi) if rc == 0 else None
+        if required and not self._predictor:
+            raise RuntimeError(f"no chain-head predictor for this program: {self._predictor_note or 'not fitted'}")
+        return bool(self._predictor)
 
     def rebind(self, hardpoints):
         """Per-geometry design positions ``[G, P, 3]`` and row parameters ``[G, Mc, 8]``."""

@@ -8,7 +8,10 @@
 #include <cstring>
 #include <new>
 
+#include <cmath>
+#include <functional>
 #include <string>
+#include <vector>
 
 #include "okx_kernels.hip"
 #include "okx_packed.hip"
@@ -41,6 +44,7 @@ struct okx_program {
   int quad_waves_per_cu;
   int quad_ppw;             // problems per wavefront: 16 (one quad each) or 8 (pair mode: one quad per half)
   char quad_note[256];      // why the quad kernel is not in use (empty when it is)
+  double* predictor_dev;    // chain-head Taylor model fitted by okx_program_fit_predictor, or null
 };
 
 namespace {
@@ -257,6 +261,8 @@ void okx_default_opts(okx_solve_opts* o) {
   o->residual_tolerance = 1e-3;
   o->kernel = 0;
   o->reserved = 0;
+  o->predictor = 0;
+  o->pad = 0;
 }
 
 int32_t okx_device_count(void) {
@@ -329,6 +335,7 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
 void okx_program_destroy(okx_program* p) {
   if (!p) return;
   if (p->quad_mod) (void)hipModuleUnload(p->quad_mod);
+  if (p->predictor_dev) (void)hipFree(p->predictor_dev);
   if (p->dev) (void)hipFree(p->dev);
   delete p;
 }
@@ -471,6 +478,8 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
     q.trace = g_quad_trace;
     q.trace_problem = g_quad_trace_problem;
+    q.predictor = (opts->predictor != 0 && !d_geom_pos) ? p->predictor_dev : nullptr;
+    q.predictor_mode = opts->predictor;
     const long long wave_units = (units + p->quad_ppw - 1) / p->quad_ppw;
     const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
     const int grid = (int)(wave_units < cap ? (wave_units < 1 ? 1 : wave_units) : cap);
@@ -493,6 +502,147 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   void* kargs[] = {(void*)&dev, (void*)&a};
   HIP_TRY(hipLaunchKernel(p->solve_fn, dim3(grid), dim3(okx::kWave), kargs, p->lds_bytes,
                           (hipStream_t)stream));
+  return OKX_OK;
+}
+
+int32_t okx_program_has_predictor(const okx_program* p) { return p && p->predictor_dev ? 1 : 0; }
+
+/* Fits the chain-head predictor of a program with a quad kernel over the target box [lo, hi] (absolute
+   target values, host arrays of n_targets; lo[t] == hi[t]: that target is held): solves the program at the
+   (degree + 1)^d Chebyshev nodes of the d varying targets (one cold-start launch, synchronous), takes the
+   tensor Chebyshev coefficients of every free coordinate by discrete orthogonality and keeps the terms up to
+   total degree `degree` (<= 0: 7).  Launches with opts.predictor != 0 on the program's own geometry start
+   every chain head at that polynomial (targets clamped to the box) instead of the design state.  Refitting
+   replaces the previous model. */
+int32_t okx_program_fit_predictor(okx_program* p, const double* lo, const double* hi, int32_t degree, void* stream) {
+  if (!p || !lo || !hi) return fail(OKX_ERR_INVALID, "null pointer");
+  if (!p->quad_fn_u) return fail(OKX_ERR_INVALID, "the predictor belongs to the quad kernel: %s", p->quad_note);
+  if (p->quad_ppw != 16) return fail(OKX_ERR_INVALID, "pair-mode kernels carry no predictor (register-bound)");
+  const okx::DevProgram& H = p->host;
+  const int T = H.n_targets;
+  if (T < 1) return fail(OKX_ERR_INVALID, "program has no targets");
+  const int D = degree <= 0 ? okx::kPredictorDegree : degree;
+  if (D > okx::kPredictorMaxDegree) return fail(OKX_ERR_INVALID, "degree must be <= %d", okx::kPredictorMaxDegree);
+  std::vector<int> out_of(H.n_points, -1);
+  for (int k = 0; k < H.n_out; ++k) out_of[H.out_point[k]] = k;
+  for (int f = 0; f < H.n_free; ++f)
+    if (out_of[H.free_point[f]] < 0) return fail(OKX_ERR_INVALID, "free point %d is not an output point", H.free_point[f]);
+  std::vector<double> mid(T), half(T);
+  std::vector<int> deg(T), vary;
+  for (int t = 0; t < T; ++t) {
+    if (!(hi[t] >= lo[t])) return fail(OKX_ERR_INVALID, "target %d: hi < lo", t);
+    mid[t] = 0.5 * (lo[t] + hi[t]);
+    half[t] = 0.5 * (hi[t] - lo[t]);
+    deg[t] = half[t] > 1e-9 ? D : 0;
+    if (deg[t]) vary.push_back(t);
+  }
+  const int d = (int)vary.size(), N = D + 1;
+  long long S = 1;
+  for (int k = 0; k < d; ++k) {
+    S *= N;
+    if (S > 32768) return fail(OKX_ERR_LIMIT, "%d varying targets at degree %d need too many nodes", d, D);
+  }
+  std::vector<double> node(N);
+  for (int a = 0; a < N; ++a) node[a] = cos(3.14159265358979323846 * (a + 0.5) / N);
+  // node k <-> digits a_0 .. a_{d-1} (dimension 0 slowest)
+  auto digit = [&](long long k, int j) {
+    for (int q = d - 1; q > j; --q) k /= N;
+    return (int)(k % N);
+  };
+  std::vector<double> targets((size_t)S * T);
+  for (long long k = 0; k < S; ++k) {
+    for (int t = 0; t < T; ++t) targets[(size_t)k * T + t] = mid[t];
+    for (int j = 0; j < d; ++j) targets[(size_t)k * T + vary[j]] = mid[vary[j]] + half[vary[j]] * node[digit(k, j)];
+  }
+  double *d_t = nullptr, *d_out = nullptr;
+  okx_info* d_info = nullptr;
+  const size_t out_doubles = (size_t)S * H.n_out * 3;
+  HIP_TRY(hipMalloc(&d_t, targets.size() * sizeof(double)));
+  hipError_t e1 = hipMalloc(&d_out, out_doubles * sizeof(double));
+  hipError_t e2 = hipMalloc(&d_info, (size_t)S * sizeof(okx_info));
+  std::vector<double> out(out_doubles);
+  std::vector<okx_info> info((size_t)S);
+  int32_t rc = OKX_OK;
+  if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(OKX_ERR_DEVICE, "hipMalloc failed");
+  if (rc == OKX_OK) {
+    okx_solve_opts o;
+    okx_default_opts(&o);
+    o.chain_len = 1;
+    o.kernel = 3;
+    o.reserved = 1;  // end on a computed correction: the fit wants every digit
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(d_t, targets.data(), targets.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+      rc = fail(OKX_ERR_DEVICE, "copy failed");
+    if (rc == OKX_OK) rc = okx_solve_batch(p, &o, S, d_t, nullptr, nullptr, d_out, d_info, stream);
+    if (rc == OKX_OK &&
+        (hipMemcpyAsync(out.data(), d_out, out_doubles * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+         hipMemcpyAsync(info.data(), d_info, (size_t)S * sizeof(okx_info), hipMemcpyDeviceToHost, st) != hipSuccess ||
+         hipStreamSynchronize(st) != hipSuccess))
+      rc = fail(OKX_ERR_DEVICE, "node solve failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  (void)hipFree(d_t);
+  (void)hipFree(d_out);
+  (void)hipFree(d_info);
+  if (rc != OKX_OK) return rc;
+  for (long long k = 0; k < S; ++k)
+    if (!(info[k].flags & OKX_INFO_CONVERGED) || (info[k].flags & (OKX_INFO_FAILED | OKX_INFO_RESIDUAL_EXCEEDED)))
+      return fail(OKX_ERR_INVALID, "node %lld of the target box did not converge", k);
+  // Chebyshev values at the nodes
+  std::vector<double> cheb((size_t)N * N);  // [i][a] = T_i(node_a)
+  for (int a = 0; a < N; ++a) {
+    cheb[a] = 1.0;
+    if (N > 1) cheb[(size_t)N + a] = node[a];
+    for (int i = 2; i < N; ++i) cheb[(size_t)i * N + a] = 2.0 * node[a] * cheb[(size_t)(i - 1) * N + a] - cheb[(size_t)(i - 2) * N + a];
+  }
+  // Table in the kernel's layout (okx_quadgen.cpp): per target (mid, 1 / half-range, degree), the
+  // total-degree cap, the table length, then one [free][4] block per term in the kernel's loop order:
+  // target 0 outermost, index i_t <= degree_t and <= the remaining total degree.
+  const int nv = H.n_free * 4;
+  std::vector<double> table((size_t)3 * T + 2, 0.0);
+  for (int t = 0; t < T; ++t) {
+    table[3 * t] = mid[t];
+    table[3 * t + 1] = deg[t] ? 1.0 / half[t] : 0.0;
+    table[3 * t + 2] = (double)deg[t];
+  }
+  table[3 * T] = (double)D;
+  std::vector<int> idx(T, 0), slot_of(T, -1);
+  for (int j = 0; j < d; ++j) slot_of[vary[j]] = j;
+  std::vector<double> block(nv);
+  std::function<void(int, int)> walk = [&](int t, int budget) {
+    if (t == T) {
+      std::fill(block.begin(), block.end(), 0.0);
+      double scale = 1.0;
+      for (int j = 0; j < d; ++j) scale *= (idx[vary[j]] == 0 ? 1.0 : 2.0) / N;
+      for (long long k = 0; k < S; ++k) {
+        double w = scale;
+        for (int j = 0; j < d; ++j) w *= cheb[(size_t)idx[vary[j]] * N + digit(k, j)];
+        for (int f = 0; f < H.n_free; ++f) {
+          const int o = out_of[H.free_point[f]];
+          for (int c = 0; c < 3; ++c) block[f * 4 + c] += w * out[((size_t)k * H.n_out + o) * 3 + c];
+        }
+      }
+      table.insert(table.end(), block.begin(), block.end());
+      return;
+    }
+    for (int i = 0; i <= deg[t] && i <= budget; ++i) {
+      idx[t] = i;
+      walk(t + 1, budget - i);
+    }
+    idx[t] = 0;
+  };
+  walk(0, D);
+  table[3 * T + 1] = (double)table.size();
+  double* d_table = nullptr;
+  HIP_TRY(hipMalloc(&d_table, table.size() * sizeof(double)));
+  if (hipMemcpy(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d_table);
+    return fail(OKX_ERR_DEVICE, "copy failed");
+  }
+  if (p->predictor_dev) {
+    HIP_TRY(hipDeviceSynchronize());  // launches in flight may still read the old table
+    (void)hipFree(p->predictor_dev);
+  }
+  p->predictor_dev = d_table;
   return OKX_OK;
 }
 

@@ -9,6 +9,10 @@
 
 namespace okx {
 
+// default / largest degree of the chain-head predictor's Chebyshev series
+constexpr int kPredictorDegree = 7;
+constexpr int kPredictorMaxDegree = 12;
+constexpr int kPredictorLdsDoubles = 1024;  // single mode: tables up to this size are staged through LDS (8 KB per wavefront)
 constexpr int kQuadMaxFree = 8;          // n <= 24 unknowns: the lane-owned rows of J^T J stay in registers
 constexpr int kQuadMaxFreePerSide = 10;  // pair mode (two identical halves, one quad each): free points per half
 
@@ -27,6 +31,8 @@ struct QuadArgs {
   const double* dop_param;
   double* trace;            // diagnostic: [256][8] per-pass record of one problem, or null
   long long trace_problem;
+  const double* predictor;  // chain-head polynomial model (okx_program_fit_predictor) or null
+  long long predictor_mode; // 2: every chain step starts from the model
 };
 
 // Arguments of the generated parity kernel `okx_quad_eval` (mirrors `struct QEvalArgs`).

@@ -111,6 +111,9 @@ class Gen {
   std::string point3(int p) const {  // 3 * point index into gp / design_pos
     return pv ? sel(3 * pv->pt[0][p], 3 * pv->pt[1][p]) : std::to_string(3 * p);
   }
+  std::string point4(int p) const {  // 4 * program point index (predictor table)
+    return pv ? sel(4 * pv->pt[0][p], 4 * pv->pt[1][p]) : std::to_string(4 * p);
+  }
   std::string crow8(int i, int k) const {  // constraint row parameter offset into gq
     return pv ? sel(8 * pv->row[0][i] + k, 8 * pv->row[1][i] + k) : std::to_string(8 * i + k);
   }
@@ -161,6 +164,14 @@ class Gen {
     }
     va_end(again);
     out += '\n';
+  }
+  static std::string f_str(const char* fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return buf;
   }
   std::string tmp(const char* base) { return "_" + std::string(base) + std::to_string(uid++); }
   static std::string sx(const LV& v) { return (v.sg < 0 ? "-" : "") + v.n; }
@@ -1006,6 +1017,8 @@ struct QArgs {
   double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
   const double* design_pos; const double* row_param; const double* dop_param;
   double* trace; long long trace_problem;   // diagnostic: 8 doubles per LM pass of one problem (null: off)
+  const double* predictor;  // polynomial model of the solution over the fitted target range for chain heads (null: off)
+  long long predictor_mode; // 2: every chain step starts from the model, not only the heads
 };
 #define EPS_SQ 1e-12
 #define EPS 1e-6
@@ -1216,6 +1229,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   else
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+  if (!pv) g.f("  __shared__ double pls[%d];  // LDS copy of the chain-head predictor's table", kPredictorLdsDoubles);
   const std::string lds_decl =
       "  const int qs = lane >> 2;  // quad(-side) slot of this lane inside the wavefront\n"
       "  __shared__ double hsl[" + std::to_string(16 * (ev.n_scalar_slots + 1)) + "];  // chain-constant scalars [slot][quad]\n"
@@ -1259,6 +1273,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     }
   }
   g.f("    int hist = 0;");
+  g.f("    bool cold = false;  // the previous chain step failed: restart from the design state, not the predictor");
   g.f("    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)");
   // targets: the next step's values are fetched while the current step is being solved, and the two
   // previous steps' values (secant predictor) stay in registers
@@ -1270,8 +1285,71 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      const long long nb = b + 1 < last_b ? b + 1 : last_b - 1;");
   for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
   for (int t = 0; t < T; ++t) g.f("      tn%d = a.targets[nb * %d + %s];", t, prog_targets, ev.target_slot(t).c_str());
+  // Chain heads (and the step after, which has no secant history yet) start from the polynomial model fitted
+  // by okx_program_fit_predictor instead of the design state / the previous solution:
+  // x(t) = sum_k coef_k prod_t T_{k_t}(u_t), Chebyshev polynomials in the targets normalised to the fitted box
+  // (clamped to it).  Table: per target (mid, 1 / half-range, degree), the total-degree cap, the table length
+  // (unused here), then one [free points][4] block per term in the loop order below (lane 3 reads the zero pad).  The loops
+  // are runtime loops on purpose: unrolled over two varying targets the evaluation costs the whole kernel
+  // ~20 % (registers, code size) whether it runs or not.  Own-geometry launches only; a restart after a failed
+  // step goes back to the design state.  Not generated in pair mode: that kernel is register-bound and the mere
+  // presence of the block cost the axle 18 % on chained grids for a 3 % gain (profiles/r01/config_sweep_pred.txt).
+  if (!pv) {
+    const int TT = prog_targets;
+    std::vector<int> ordinal(program.n_points, 0);  // program point -> its free ordinal
+    for (int k = 0; k < program.n_free; ++k) ordinal[program.free_point[k]] = k;
+    g.f("      if (!PG && a.predictor != nullptr && (hist < 2 || a.predictor_mode == 2) && !cold) {");
+    g.f("        const double* pp = a.predictor;");
+    for (int t = 0; t < TT; ++t) {
+      g.f("        const double pu%d = fmin(fmax((a.targets[bb * %d + %d] - pp[%d]) * pp[%d], -1.0), 1.0);", t, TT, t, 3 * t, 3 * t + 1);
+      g.f("        const int pD%d = (int)pp[%d];", t, 3 * t + 2);
+    }
+    g.f("        const int prS = (int)pp[%d];  // total-degree budget", 3 * TT);
+    g.f("        const double pwS = 1.0;");
+    for (int F = 0; F < nf; ++F) g.f("        double pa%d = 0.0;", F);
+    auto up = [&](int t, const char* what) { return t == 0 ? std::string(what) + "S" : std::string(what) + std::to_string(t - 1); };
+    // the term loops, reading the coefficient blocks through `ptr` (global memory or the LDS copy)
+    auto term_loops = [&](const char* decl) {
+      g.f("          %s;", decl);
+      for (int t = 0; t < TT; ++t) {  // one loop level per target: pc = T_i(u), pn = T_{i+1}(u)
+        g.f("          { double pc%d = 1.0, pn%d = pu%d;", t, t, t);
+        g.f("          for (int pi%d = 0; pi%d <= pD%d && pi%d <= %s; ++pi%d) {", t, t, t, t, up(t, "pr").c_str(), t);
+        g.f("            const double pw%d = %s * pc%d; const int pr%d = %s - pi%d;", t, up(t, "pw").c_str(), t, t, up(t, "pr").c_str(), t);
+      }
+      g.f("            (void)pr%d;", TT - 1);
+      for (int F = 0; F < nf; ++F) {
+        const int pt = ev.fp(F);
+        std::string off = pv ? Gen::sel(4 * ordinal[pv->pt[0][pt]], 4 * ordinal[pv->pt[1][pt]]) : std::to_string(4 * ordinal[pt]);
+        g.f("            pa%d = fma(pw%d, pq[%s + c], pa%d);", F, TT - 1, off.c_str(), F);
+      }
+      g.f("            pq += %d;", 4 * program.n_free);
+      for (int t = TT - 1; t >= 0; --t) {
+        g.f("            { const double nn = fma(2.0 * pu%d, pn%d, -pc%d); pc%d = pn%d; pn%d = nn; }", t, t, t, t, t, t);
+        g.f("          } }");
+      }
+    };
+    if (!pv) {
+      // one quad per problem: the kernel has LDS to spare, so a table of up to kPredictorLdsDoubles is copied there
+      // with coalesced reads first (one round trip to L2) and the dependent per-term reads come from LDS
+      g.f("        const int plen = (int)pp[%d];", 3 * TT + 1);
+      g.f("        if (plen <= %d) {", kPredictorLdsDoubles);
+      g.f("          for (int k = lane; k < plen; k += 64) pls[k] = pp[k];");
+      g.f("          __syncthreads();");
+      term_loops(Gen::f_str("const double* pq = pls + %d", 3 * TT + 2).c_str());
+      g.f("          __syncthreads();");
+      g.f("        } else {");
+      term_loops(Gen::f_str("const double* pq = pp + %d", 3 * TT + 2).c_str());
+      g.f("        }");
+    } else {
+      g.f("        {");
+      term_loops(Gen::f_str("const double* pq = pp + %d", 3 * TT + 2).c_str());
+      g.f("        }");
+    }
+    for (int F = 0; F < nf; ++F) g.f("        x%d = pa%d;", F, F);
+    g.f("      }");
+  }
   // secant predictor: x + alpha (x - xp), alpha from the target increments
-  g.f("      if (hist >= 2) {");
+  g.f("      if (hist >= 2 && !(!PG && a.predictor != nullptr && a.predictor_mode == 2 && !cold)) {");
   g.f("        double num = 0.0, den = 0.0;");
   for (int t = 0; t < T; ++t)
     g.f("        num = fma(%s * (tv%d - tp%d), tp%d - tq%d, num); den = fma(%s * (tp%d - tq%d), tp%d - tq%d, den);",
@@ -1506,9 +1584,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int t = 0; t < T; ++t) g.f("    tq%d = tp%d; tp%d = tv%d;", t, t, t, t);
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
   for (int F = 0; F < nf; ++F) g.f("      x%d = c < 3 ? gp[%s + cc] : 0.0;", F, ev.point3(ev.fp(F)).c_str());
-  g.f("      hist = 0; lambda_carry = 0.0;");
+  g.f("      hist = 0; lambda_carry = 0.0; cold = true;");
   g.f("    } else {");
   g.f("      if (hist < 2) ++hist;");
+  g.f("      cold = false;");
   g.f("      lambda_carry = lambda;");
   g.f("    }");
   g.f("      }");

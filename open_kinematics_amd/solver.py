@@ -149,7 +149,8 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     if n_steps == 0:
         return [], []
     result = dp.solve(torch.as_tensor(table), chain=bool(cfg.warm_start), max_iter=cfg.max_iter,
-                      step_tol=cfg.step_tol, residual_tolerance=cfg.residual_tolerance)
+                      step_tol=cfg.step_tol, residual_tolerance=cfg.residual_tolerance,
+                      predictor=False)  # one sweep = one chain (or explicit cold starts): nothing for a fitted model to save
     torch.cuda.synchronize(dp.device)
     positions = result.positions.cpu().numpy()
     info = result.info()

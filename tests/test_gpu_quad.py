@@ -63,7 +63,7 @@ def test_quad_solve_matches_oracle_wave_kernel_and_reference(golden, name):
     pinned = program.with_line_mode("pinned")
     dp = _dp(pinned)
     t = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
-    quad = dp.solve(t, kernel="quad")
+    quad = dp.solve(t, kernel="quad", predictor=False)  # same start as the wave kernel: the design state
     wave = dp.solve(t, kernel="single")
     torch.cuda.synchronize()
     info = quad.info()
@@ -108,7 +108,7 @@ def test_quad_chains_and_ragged_batches(golden, chain_len):
         assert float((res.positions - ref[:b]).abs().max()) <= 1e-9
         assert float((guard[b] + 7.0).abs().max()) == 0.0, "wrote past the batch"
     chained = dp.solve(t_all, kernel="quad", chain=True).info()
-    assert chained["nfev"].mean() < dp.solve(t_all, kernel="quad", chain_len=1).info()["nfev"].mean()
+    assert chained["nfev"].mean() < dp.solve(t_all, kernel="quad", chain_len=1, predictor=False).info()["nfev"].mean()
 
 
 def test_quad_ensemble_uses_per_geometry_tables(golden):
@@ -138,7 +138,7 @@ def test_quad_reports_infeasible_targets_like_the_wave_kernel(golden):
     dp = _dp(pinned)
     t = arrays["targets_abs"][:16].copy()
     t[:, 1] += 2000.0  # wheel centre 2 m above anything the links allow
-    quad = dp.solve(t, kernel="quad").info()
+    quad = dp.solve(t, kernel="quad", predictor=False).info()
     wave = dp.solve(t, kernel="single").info()
     assert np.all(quad["flags"] & 2) and np.all(wave["flags"] & 2)
     assert np.allclose(quad["max_residual"], wave["max_residual"], rtol=1e-6)
@@ -165,7 +165,7 @@ def test_axle_runs_in_pair_mode_one_quad_per_half(golden, name):
         return
     assert dp.kernel == "quad", dp.kernel_note
     t = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
-    quad = dp.solve(t, kernel="quad")
+    quad = dp.solve(t, kernel="quad", predictor=False)  # same start as the wave kernel: the design state
     wave = dp.solve(t, kernel="single")
     torch.cuda.synchronize()
     info = quad.info()
@@ -211,7 +211,7 @@ def test_quad_rows_on_the_contact_patch(golden):
     assert np.max(np.abs(atr - np.einsum("bij,bi->bj", jac_o, r_o))) <= 1e-11 * max(1.0, np.abs(r_o).max() * np.abs(jac_o).max())
     # ground-relative bump sweep: contact patch z from -40 to +40 mm about design, rack held
     sweep = np.stack([np.full(33, t[0, 0]), prog.design_pos[cp][2] + np.linspace(-40.0, 40.0, 33)], axis=1)
-    quad = dp.solve(sweep, kernel="quad")
+    quad = dp.solve(sweep, kernel="quad", predictor=False)
     wave = dp.solve(sweep, kernel="single")
     assert np.all((quad.info()["flags"] & 7) == 1)
     assert float((quad.positions - wave.positions).abs().max()) <= 1e-10

@@ -16,16 +16,21 @@ def timed(fn, reps=10):
 KERNELS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["auto"]
 
 def report(name, dp, targets, **kw):
+    # start of a chain head: "design" = cold start from the design state, "model" = fitted Chebyshev predictor
     for kern in KERNELS:
         for cl in (1, -1):
-            b = targets.shape[0]
-            out = torch.empty((b, dp.program.n_out, 3), dtype=torch.float64, device="cuda")
-            info_out = torch.empty((b, 40), dtype=torch.uint8, device="cuda")
-            dt, res = timed(dp.plan(targets, chain_len=cl, kernel=kern, out=out, info_out=info_out, **kw))
-            info = res.info()
-            ok = bool(np.all((info["flags"] & 7) == 1))
-            print(f"{name:34s} {kern:6s} chain_len={cl:2d}  B={targets.shape[0]:8d}  {targets.shape[0]/dt/1e6:8.3f} M solves/s  "
-                  f"{dt*1e3:8.3f} ms  evals {info['nfev'].mean():.2f}  max_res {info['max_residual'].max():.2e}  converged={ok}")
+            for start in ("design", "model"):
+                if start == "model" and ("geom_pos" in kw or kern not in ("auto", "quad") or not dp.fit_predictor(targets)):
+                    continue  # per-geometry launches, interpreter kernels and pair-mode programs have no predictor
+                b = targets.shape[0]
+                out = torch.empty((b, dp.program.n_out, 3), dtype=torch.float64, device="cuda")
+                info_out = torch.empty((b, 40), dtype=torch.uint8, device="cuda")
+                dt, res = timed(dp.plan(targets, chain_len=cl, kernel=kern, out=out, info_out=info_out,
+                                        predictor=start == "model", **kw))
+                info = res.info()
+                ok = bool(np.all((info["flags"] & 7) == 1))
+                print(f"{name:34s} {kern:6s} chain_len={cl:2d} start={start:6s}  B={targets.shape[0]:8d}  {targets.shape[0]/dt/1e6:8.3f} M solves/s  "
+                      f"{dt*1e3:8.3f} ms  evals {info['nfev'].mean():.2f}  max_res {info['max_residual'].max():.2e}  converged={ok}")
 
 p, t = W.bump_sweep_problem(16384)
 report("C2 DW corner 16384-step bump", DeviceProgram(p), torch.as_tensor(t, device="cuda"))
