@@ -367,6 +367,33 @@ int32_t okx_axle_metrics_batch(const okx_corner_roles* left, const okx_corner_ro
                                void* stream);
 
 /*
+ * Signed rotation of output points about fixed axes from their design positions, in degrees
+ * (metrics/kernels.py:58-76 rotation_about_fixed_axis_deg, vector_utils/geometric.py:31-52): the
+ * topology-specific state metrics rocker_angle / torsion_bar_twist (corner/mechanisms.py:378-407,611-623:
+ * PUSHROD_INBOARD about the rocker axis, times Side.lateral_sign) and arb_arm_angle / arb_twist
+ * (axle/mechanisms.py:402-430: DROPLINK_U_BAR of each side about the U-bar axis; twist = left - right),
+ * and with tangents their derivative columns (deriv_rocker_angle_wrt_hub_z, deriv_arb_twist_wrt_hub_z_*).
+ * A point on its axis (either perpendicular below 1e-6) reads NaN where the reference raises.
+ */
+#define OKX_MAX_ROTATIONS 8
+typedef struct okx_rotation_role {
+  int32_t point;         /* output-point index of the moving pickup   */
+  int32_t pad;
+  double design[3];      /* its design position                        */
+  double axis_point[3];  /* a point on the fixed axis                  */
+  double axis_dir[3];    /* unit direction of the axis                 */
+  double scale;          /* Side.lateral_sign, or 1                    */
+} okx_rotation_role;
+
+int32_t okx_axis_rotation_batch(const okx_rotation_role* roles, int32_t n_roles, int64_t n_states, int32_t n_out,
+                                int32_t n_targets,
+                                const double* d_pos,       /* [B][n_out][3] */
+                                const double* d_tangents,  /* [B][T][n_out][3] or NULL */
+                                double* d_angles,          /* [B][n_roles] */
+                                double* d_dangles,         /* [B][T][n_roles] or NULL */
+                                void* stream);
+
+/*
  * Chain-head predictor.  The reference warm-starts step k from step k-1 (solver.py:774) and starts a
  * sweep at the design state; a batch that fills the chip solves every step as an independent cold
  * start instead.  okx_program_fit_predictor solves the program once at the Chebyshev

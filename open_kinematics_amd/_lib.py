@@ -35,6 +35,7 @@ EXPORTS = (
     "okx_tangent_batch",
     "okx_corner_metrics_batch",
     "okx_axle_metrics_batch",
+    "okx_axis_rotation_batch",
     "okx_camber_shim_batch",
     "okx_program_fit_predictor",
     "okx_program_has_predictor",
@@ -101,6 +102,8 @@ def load() -> C.CDLL:
     lib.okx_corner_metrics_batch.restype = i32
     lib.okx_axle_metrics_batch.argtypes = [vp, vp, i64, i32, vp, vp, vp]
     lib.okx_axle_metrics_batch.restype = i32
+    lib.okx_axis_rotation_batch.argtypes = [vp, i32, i64, i32, i32, vp, vp, vp, vp, vp]
+    lib.okx_axis_rotation_batch.restype = i32
     lib.okx_camber_shim_batch.argtypes = [vp, i64, i32, vp, vp, vp, vp]
     lib.okx_camber_shim_batch.restype = i32
     lib.okx_program_fit_predictor.argtypes = [vp, vp, vp, i32, vp]

@@ -786,6 +786,37 @@ static int32_t check_corner_roles(const okx_corner_roles* roles, int32_t n_out, 
   return OKX_OK;
 }
 
+int32_t okx_axis_rotation_batch(const okx_rotation_role* roles, int32_t n_roles, int64_t n_states, int32_t n_out,
+                                int32_t n_targets, const double* d_pos, const double* d_tangents, double* d_angles,
+                                double* d_dangles, void* stream) {
+  if (!roles || !d_pos || !d_angles) return fail(OKX_ERR_INVALID, "null pointer");
+  if (n_roles < 1 || n_roles > OKX_MAX_ROTATIONS) return fail(OKX_ERR_INVALID, "1..%d rotations per call", OKX_MAX_ROTATIONS);
+  if (n_states < 0 || n_out <= 0 || n_targets < 0) return fail(OKX_ERR_INVALID, "bad dimension");
+  if ((d_tangents == nullptr) != (d_dangles == nullptr))
+    return fail(OKX_ERR_INVALID, "tangents and derivative output must be given together");
+  okx::RotationArgs a;
+  for (int k = 0; k < n_roles; ++k) {
+    if (roles[k].point < 0 || roles[k].point >= n_out) return fail(OKX_ERR_INVALID, "rotation %d: not an output point", k);
+    const double* d = roles[k].axis_dir;
+    const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (!(std::fabs(len - 1.0) <= 1e-9)) return fail(OKX_ERR_INVALID, "rotation %d: axis_dir must be a unit vector", k);
+    a.roles[k] = roles[k];
+  }
+  if (n_states == 0) return OKX_OK;
+  a.n_roles = n_roles;
+  a.pos = d_pos;
+  a.tan = d_tangents;
+  a.angles = d_angles;
+  a.dangles = d_dangles;
+  a.n_states = n_states;
+  a.n_out = n_out;
+  a.n_targets = n_targets;
+  const long long blocks = (n_states + 255) / 256;
+  hipLaunchKernelGGL(okx::okx_axis_rotation_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
 int32_t okx_axle_metrics_batch(const okx_corner_roles* left, const okx_corner_roles* right, int64_t n_states,
                                int32_t n_out, const double* d_pos, double* d_metrics, void* stream) {
   if (!left || !right || !d_pos || !d_metrics) return fail(OKX_ERR_INVALID, "null pointer");

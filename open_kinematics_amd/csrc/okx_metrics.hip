@@ -273,4 +273,40 @@ __global__ void __launch_bounds__(256) okx_axle_metrics_kernel(AxleMetricsArgs a
       a.left.rack_attachment >= 0 ? pos[3 * a.left.rack_attachment + 1] - a.left.design_rack_y : nan;
 }
 
+struct RotationArgs {
+  okx_rotation_role roles[OKX_MAX_ROTATIONS];
+  int n_roles;
+  const double* pos;   // [B][n_out][3]
+  const double* tan;   // [B][T][n_out][3] or null
+  double* angles;      // [B][n_roles]
+  double* dangles;     // [B][T][n_roles] or null
+  long long n_states;
+  int n_out, n_targets;
+};
+
+// metrics/kernels.py:58-76 on duals; geometric.py:47-51: undefined for a point on the axis
+__device__ __forceinline__ Dual axis_rotation_deg(const okx_rotation_role& R, const double* pos, const double* vel) {
+  const double kDeg = 57.29577951308232;
+  const DVec a = {{R.axis_dir[0], 0.0}, {R.axis_dir[1], 0.0}, {R.axis_dir[2], 0.0}};
+  const DVec origin = {{R.axis_point[0], 0.0}, {R.axis_point[1], 0.0}, {R.axis_point[2], 0.0}};
+  const DVec dr = {{R.design[0] - R.axis_point[0], 0.0}, {R.design[1] - R.axis_point[1], 0.0}, {R.design[2] - R.axis_point[2], 0.0}};
+  const DVec cr = dsub(load_point(pos, vel, R.point), origin);
+  const DVec dperp = dsub(dr, dscale(ddot(dr, a), a)), cperp = dsub(cr, dscale(ddot(cr, a), a));
+  if (!(sqrt(ddot(dperp, dperp).v) >= kEpsGeometric) || !(sqrt(ddot(cperp, cperp).v) >= kEpsGeometric)) return dnan();
+  return (R.scale * kDeg) * datan2(ddot(a, dcross(dr, cr)), ddot(dperp, cperp));
+}
+
+__global__ void __launch_bounds__(256) okx_axis_rotation_kernel(RotationArgs a) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.n_states) return;
+  const double* pos = a.pos + b * 3 * a.n_out;
+  for (int k = 0; k < a.n_roles; ++k) a.angles[b * a.n_roles + k] = axis_rotation_deg(a.roles[k], pos, nullptr).v;
+  if (a.tan && a.dangles)
+    for (int t = 0; t < a.n_targets; ++t) {
+      const double* vel = a.tan + (b * a.n_targets + t) * 3 * a.n_out;
+      for (int k = 0; k < a.n_roles; ++k)
+        a.dangles[(b * a.n_targets + t) * a.n_roles + k] = axis_rotation_deg(a.roles[k], pos, vel).d;
+    }
+}
+
 }  // namespace okx

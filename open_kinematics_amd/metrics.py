@@ -127,6 +127,106 @@ def corner_roles(suspension, program, side=None) -> CornerRoles:
     )
 
 
+class RotationRole(C.Structure):
+    """ctypes mirror of ``okx_rotation_role``."""
+
+    _fields_ = [("point", C.c_int32), ("pad", C.c_int32), ("design", C.c_double * 3), ("axis_point", C.c_double * 3),
+                ("axis_dir", C.c_double * 3), ("scale", C.c_double)]
+
+
+def rotation_role(point: int, design, axis_a, axis_b, scale: float = 1.0) -> RotationRole:
+    """Rotation of output point ``point`` from ``design`` about the fixed axis through ``axis_a`` towards ``axis_b``."""
+    a, b = np.asarray(axis_a, dtype=np.float64), np.asarray(axis_b, dtype=np.float64)
+    length = float(np.linalg.norm(b - a))
+    if length < 1e-6:
+        raise ValueError("rotation axis points must be distinct")
+    vec = lambda v: (C.c_double * 3)(*[float(x) for x in v])  # noqa: E731
+    return RotationRole(point=int(point), design=vec(design), axis_point=vec(a), axis_dir=vec((b - a) / length), scale=float(scale))
+
+
+def topology_rotation_roles(suspension, program, side=None) -> tuple[list[str], list[RotationRole]]:
+    """
+    The fixed-axis rotation metrics a topology declares, as ``(column names, roles)``:
+    a rocker-actuated corner -> ``rocker_angle`` (and ``torsion_bar_twist`` with a torsion-bar spring,
+    ``corner/mechanisms.py:378-407,611-623``); an axle -> both corners' columns with ``_left`` / ``_right`` suffixes
+    plus ``arb_arm_angle_left`` / ``_right`` for a U-bar (``axle/mechanisms.py:402-430``; ``arb_twist`` is their
+    difference, see ``axle_topology_metrics``).
+    """
+    out_keys = [program.point_keys[k] for k in program.out_point]
+    if hasattr(suspension, "corners"):  # axle
+        names, roles = [], []
+        for s in (Side.LEFT, Side.RIGHT):
+            n, r = topology_rotation_roles(suspension.corners[s], program, s)
+            names += [f"{k}_{s.name.lower()}" for k in n]
+            roles += r
+        if suspension.has_arb:
+            a, b = (suspension.arb_center_points[k].data for k in (PointID.ARB_U_BAR_AXIS_A, PointID.ARB_U_BAR_AXIS_B))
+            for s in (Side.LEFT, Side.RIGHT):
+                names.append(f"arb_arm_angle_{s.name.lower()}")
+                roles.append(rotation_role(out_keys.index(PointRef(s, PointID.DROPLINK_U_BAR)),
+                                           suspension.arb_droplink_points[s].data, a, b))
+        return names, roles
+    actuation = getattr(suspension, "actuation", None)
+    if actuation is None or not actuation.rocker:
+        return [], []
+    design = suspension.initial_state().positions
+    key = lambda p: PointRef(side, p) if side is not None else p  # noqa: E731
+    role = rotation_role(out_keys.index(key(PointID.PUSHROD_INBOARD)), design[PointID.PUSHROD_INBOARD].data,
+                         design[PointID.ROCKER_AXIS_A].data, design[PointID.ROCKER_AXIS_B].data, suspension.lateral_sign)
+    names = ["rocker_angle"] + (["torsion_bar_twist"] if suspension.spring.kind == "torsion_bar" else [])
+    return names, [role] * len(names)
+
+
+def axis_rotation_metrics(roles, positions: torch.Tensor, tangents: torch.Tensor | None = None):
+    """
+    ``okx_axis_rotation_batch``: ``positions [B, n_out, 3]`` (+ ``tangents [B, T, n_out, 3]``) ->
+    ``(angles [B, K] deg, d angles / d target [B, T, K] or None)`` for the K ``roles``.
+    """
+    if not positions.is_cuda:
+        raise RuntimeError("axis_rotation_metrics needs device tensors (there is no CPU fallback)")
+    roles = list(roles)
+    lib = _lib.load()
+    pos = positions.to(torch.float64).contiguous()
+    b, n_out, k = pos.shape[0], pos.shape[1], len(roles)
+    angles = torch.empty((b, k), dtype=torch.float64, device=pos.device)
+    tan = deriv = None
+    n_targets = 0
+    if tangents is not None:
+        tan = tangents.to(torch.float64).contiguous()
+        if tan.shape[0] != b or tan.shape[2:] != (n_out, 3):
+            raise ValueError("tangents must be [B, T, n_out, 3]")
+        n_targets = tan.shape[1]
+        deriv = torch.empty((b, n_targets, k), dtype=torch.float64, device=pos.device)
+    array = (RotationRole * max(k, 1))(*roles)
+    stream = torch.cuda.current_stream(pos.device).cuda_stream
+    ptr = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+    with torch.cuda.device(pos.device):
+        rc = lib.okx_axis_rotation_batch(array, k, b, n_out, n_targets, ptr(pos), ptr(tan), ptr(angles), ptr(deriv),
+                                         C.c_void_p(stream))
+    _lib.check(rc, "okx_axis_rotation_batch")
+    return angles, deriv
+
+
+def axle_topology_metrics(axle, program, positions: torch.Tensor, tangents: torch.Tensor | None = None) -> dict:
+    """
+    Column name -> device tensor ``[B]`` of an axle's topology-specific state metrics (``rocker_angle_left`` ...,
+    ``arb_arm_angle_left`` / ``_right``, ``arb_twist`` = left - right) and, with tangents, ``d_<name>`` ->
+    ``[B, T]`` derivatives with respect to every sweep target.
+    """
+    names, roles = topology_rotation_roles(axle, program)
+    if not names:
+        return {}
+    angles, deriv = axis_rotation_metrics(roles, positions, tangents)
+    out = {n: angles[:, k] for k, n in enumerate(names)}
+    if deriv is not None:
+        out.update({f"d_{n}": deriv[:, :, k] for k, n in enumerate(names)})
+    if "arb_arm_angle_left" in out:
+        out["arb_twist"] = out["arb_arm_angle_left"] - out["arb_arm_angle_right"]
+        if deriv is not None:
+            out["d_arb_twist"] = out["d_arb_arm_angle_left"] - out["d_arb_arm_angle_right"]
+    return out
+
+
 def axle_roles(axle, program) -> tuple[CornerRoles, CornerRoles]:
     """(left, right) roles of an ``AxleSuspension``'s corners inside the axle program's output points."""
     return corner_roles(axle.corners[Side.LEFT], program, Side.LEFT), corner_roles(axle.corners[Side.RIGHT], program, Side.RIGHT)

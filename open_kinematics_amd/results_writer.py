@@ -39,6 +39,8 @@ METRIC_UNITS = {
     # axle scope (metrics/axle_metrics.py, metrics/registry.py)
     "heave": "mm", "roll": "deg", "ride_height_change": "mm", "track": "mm", "roll_center_y": "mm",
     "roll_center_z": "mm", "rack_displacement": "mm",
+    # topology-specific rotations (corner/mechanisms.py:58-74, axle/mechanisms.py:76-91)
+    "rocker_angle": "deg", "torsion_bar_twist": "deg", "arb_arm_angle": "deg", "arb_twist": "deg",
 }
 
 

@@ -111,11 +111,28 @@ def emit_axle(name: str, out_name: str, stride: int) -> None:
         arrays.update({f"{tag}_{k}": v for k, v in meta.items()})
         rack = corner.rack_attachment_point()
         arrays[f"{tag}_rack"] = "" if rack is None else rack.name.lower()
+        # topology-specific extras (rocker_angle, torsion_bar_twist, arb_arm_angle) and every derivative column
+        extra = [k for k in rows[0].corners[side] if k not in NAMES and not k.startswith("deriv_")]
+        arrays[f"{tag}_extra_names"] = np.array(extra)
+        arrays[f"{tag}_extra_values"] = np.asarray([[_num(r.corners[side][k]) for k in extra] for r in rows])
+        dnames = [k for k in rows[0].corners[side] if k.startswith("deriv_")]
+        arrays[f"{tag}_deriv_names"] = np.array(dnames)
+        arrays[f"{tag}_deriv"] = np.asarray([[_num(r.corners[side][k]) for k in dnames] for r in rows])
+    extra = [k for k in rows[0].axle if k not in AXLE_NAMES and not k.startswith("deriv_")]
+    arrays["axle_extra_names"] = np.array(extra)
+    arrays["axle_extra_values"] = np.asarray([[_num(r.axle[k]) for k in extra] for r in rows])
+    dnames = [k for k in rows[0].axle if k.startswith("deriv_")]
+    arrays["axle_deriv_names"] = np.array(dnames)
+    arrays["axle_deriv"] = np.asarray([[_num(r.axle[k]) for k in dnames] for r in rows])
     np.savez_compressed(os.path.join(OUT, f"metrics_{out_name}.npz"), **arrays)
+    print(f"   extras: axle {extra} + {dnames}; left {list(arrays['left_extra_names'])} + {list(arrays['left_deriv_names'])}")
     print(f"metrics_{out_name}: {len(rows)} states; axle row {dict(zip(AXLE_NAMES, arrays['axle_values'][len(rows) // 3]))}")
 
 
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "axle":
+        emit_axle("c3_axle_grid", "axle_c3", stride=5)
+        return
     emit("c1_dw_corner")
     emit("c4_macpherson_grid")
     emit("e2e_sweep")

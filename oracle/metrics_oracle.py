@@ -239,3 +239,21 @@ def axle_metrics(sides: dict) -> np.ndarray:
         track, rcy, rcz,
         nan if rack is None else float(rack) - sides["left"]["design_rack_y"],
     ])
+
+
+def rotation_about_fixed_axis_deg(current, velocity, design, axis_point, axis_dir, scale: float = 1.0):
+    """
+    ``metrics/kernels.py:58-76`` (value, derivative along ``velocity``): signed rotation of ``current`` from
+    ``design`` about the fixed axis, degrees, times ``scale`` (``Side.lateral_sign`` for the rocker angle).
+    """
+    v = velocity if velocity is not None else (0.0, 0.0, 0.0)
+    cur = [D(float(current[k]) - float(axis_point[k]), float(v[k])) for k in range(3)]
+    dr = [float(design[k]) - float(axis_point[k]) for k in range(3)]
+    a = [float(x) for x in axis_dir]
+    dot = lambda p, q: p[0] * q[0] + p[1] * q[1] + p[2] * q[2]  # noqa: E731
+    dd, cd = dot(dr, a), dot(cur, a)
+    dperp = [dr[k] - dd * a[k] for k in range(3)]
+    cperp = [cur[k] - cd * a[k] for k in range(3)]
+    cross = [dr[1] * cur[2] - dr[2] * cur[1], dr[2] * cur[0] - dr[0] * cur[2], dr[0] * cur[1] - dr[1] * cur[0]]
+    angle = atan2(_lift(dot(a, cross)), _lift(dot(dperp, cperp)))
+    return scale * math.degrees(1.0) * angle.v, scale * math.degrees(1.0) * angle.d

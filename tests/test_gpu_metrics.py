@@ -167,6 +167,56 @@ def test_axle_roles_from_the_loader_hooks(golden):
     assert np.max(np.abs(values[:, :8] - mg["left_values"][:, :8])) <= 5e-5
 
 
+def test_axle_topology_rotations_and_their_derivative_columns(golden):
+    """rocker_angle / torsion_bar_twist / arb_arm_angle / arb_twist and deriv_*_wrt_hub_z(_left|_right) on the device."""
+    import yaml
+
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.input import build_suspension, build_sweep
+    from open_kinematics_amd.metrics import axle_topology_metrics, topology_rotation_roles
+    from open_kinematics_amd.sweep import sweep_program
+
+    arrays, program = golden("c3_axle_grid")
+    mg = load_metrics_golden("axle_c3")
+    axle = build_suspension(yaml.safe_load(str(arrays["geometry_yaml"])))
+    pinned, _ = sweep_program(axle, build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), axle))
+    assert list(pinned.out_point) == list(program.out_point)  # the loader's program = the golden's (typed keys)
+    names, roles = topology_rotation_roles(axle, pinned)
+    assert names == ["rocker_angle_left", "torsion_bar_twist_left", "rocker_angle_right", "torsion_bar_twist_right",
+                     "arb_arm_angle_left", "arb_arm_angle_right"]
+    dp = DeviceProgram(pinned, "cuda:0")
+    pos = torch.as_tensor(mg["pos"], device="cuda:0")
+    tan, tinfo = dp.tangents(pos)
+    m = axle_topology_metrics(axle, pinned, pos, tan)
+    torch.cuda.synchronize()
+    assert np.all(dp.tangent_info(tinfo)["flags"] == 1)
+    for tag in ("left", "right"):
+        for j, name in enumerate(str(n) for n in mg[f"{tag}_extra_names"]):
+            assert np.max(np.abs(m[f"{name}_{tag}"].cpu().numpy() - mg[f"{tag}_extra_values"][:, j])) <= 1e-9, (tag, name)
+    assert np.max(np.abs(m["arb_twist"].cpu().numpy() - mg["axle_extra_values"][:, 0])) <= 1e-9
+    # derivative columns: d / d (hub z of one side), the other hub and the rack held
+    from open_kinematics_amd.results_writer import point_key_name
+
+    tnames = [point_key_name(pinned.point_keys[p]) for p in pinned.tgt_point]
+    hub = {tag: next(t for t, (n, d) in enumerate(zip(tnames, pinned.tgt_dir)) if n == f"{tag}_wheel_center" and d[2] == 1.0)
+           for tag in ("left", "right")}
+    checked = 0
+    for tag in ("left", "right"):
+        for j, col in enumerate(str(c) for c in mg[f"{tag}_deriv_names"]):
+            response, driver = col[len("deriv_"):].split("_wrt_")
+            if driver == "hub_z" and f"d_{response}_{tag}" in m:
+                got = m[f"d_{response}_{tag}"][:, hub[tag]].cpu().numpy()
+                ref = mg[f"{tag}_deriv"][:, j]
+                assert np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) <= 1e-7, (tag, col)
+                checked += 1
+    for j, col in enumerate(str(c) for c in mg["axle_deriv_names"]):
+        tag = col.rsplit("_", 1)[1]
+        got = m["d_arb_twist"][:, hub[tag]].cpu().numpy()
+        assert np.max(np.abs(got - mg["axle_deriv"][:, j]) / np.maximum(1.0, np.abs(mg["axle_deriv"][:, j]))) <= 1e-7, col
+        checked += 1
+    assert checked == 6  # rocker_angle + torsion_bar_twist per side, arb_twist wrt each hub
+
+
 def test_bad_roles_are_rejected(golden):
     from open_kinematics_amd.metrics import axle_state_metrics, corner_state_metrics, make_roles
 
@@ -183,6 +233,14 @@ def test_bad_roles_are_rejected(golden):
         corner_state_metrics(make_roles(**base, damper=(3, 44)), pos)
     with pytest.raises(ValueError, match="right"):
         axle_state_metrics(make_roles(**base), make_roles(**{**base, "side_sign": 0.0}), pos)
+    from open_kinematics_amd.metrics import axis_rotation_metrics, rotation_role
+
+    with pytest.raises(ValueError, match="rotation 0: not an output point"):
+        axis_rotation_metrics([rotation_role(77, (1, 0, 0), (0, 0, 0), (0, 0, 1))], pos)
+    with pytest.raises(ValueError, match="distinct"):
+        rotation_role(0, (1, 0, 0), (0, 0, 0), (0, 0, 0))
+    on_axis = axis_rotation_metrics([rotation_role(0, (0, 0, 5), (0, 0, 0), (0, 0, 1))], pos)[0]
+    assert torch.isnan(on_axis).all()  # the reference raises for a point on its rotation axis
     # no instant-axis construction, no damper, no vehicle numbers: those columns read NaN, the rest are defined
     pos = torch.rand((4, 15, 3), dtype=torch.float64, device="cuda:0")
     values = corner_state_metrics(make_roles(**base), pos).values.cpu().numpy()

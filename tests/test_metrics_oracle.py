@@ -6,7 +6,14 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from oracle.metrics_oracle import AXLE_METRIC_NAMES, METRIC_NAMES, axle_metrics, corner_metrics, geometry_metrics
+from oracle.metrics_oracle import (
+    AXLE_METRIC_NAMES,
+    METRIC_NAMES,
+    axle_metrics,
+    corner_metrics,
+    geometry_metrics,
+    rotation_about_fixed_axis_deg,
+)
 from oracle.oracle import Oracle
 
 FIXTURES = ["c1_dw_corner", "c4_macpherson_grid", "e2e_sweep"]
@@ -162,6 +169,40 @@ def test_axle_metric_oracle_matches_the_reference(golden):
             values, _ = corner_metrics(pos, None, side, float(design[roles["wheel_center"]][2]))
             assert np.max(np.abs(values[:8] - mg[f"{tag}_values"][s][:8])) <= 1e-10
             assert close(oracle_geometry_row(mg["pos"][s], roles, side, geometry), mg[f"{tag}_values"][s][8:], 1e-11)
+
+
+def axle_rotation_specs(program):
+    """name -> (output index of the moving pickup, design position, axis point, unit axis, scale) of the C3 axle."""
+    pk = [program.point_keys[k].lower_name for k in range(program.n_points)]
+    names = out_names(program)
+    design = program.design_pos
+    specs = {}
+
+    def axis(a, b):
+        pa, pb = design[pk.index(a)], design[pk.index(b)]
+        return pa, (pb - pa) / np.linalg.norm(pb - pa)
+
+    for tag, sign in (("left", 1.0), ("right", -1.0)):
+        a, u = axis(f"{tag}_rocker_axis_a", f"{tag}_rocker_axis_b")
+        specs[f"rocker_angle_{tag}"] = (names.index(f"{tag}_pushrod_inboard"), design[pk.index(f"{tag}_pushrod_inboard")], a, u, sign)
+        specs[f"torsion_bar_twist_{tag}"] = specs[f"rocker_angle_{tag}"]
+        a, u = axis("center_arb_u_bar_axis_a", "center_arb_u_bar_axis_b")
+        specs[f"arb_arm_angle_{tag}"] = (names.index(f"{tag}_droplink_u_bar"), design[pk.index(f"{tag}_droplink_u_bar")], a, u, 1.0)
+    return specs
+
+
+def test_topology_rotation_metrics_match_the_reference(golden):
+    """rocker_angle / torsion_bar_twist / arb_arm_angle per corner, arb_twist per axle (values)."""
+    _, program = golden("c3_axle_grid")
+    mg = load_metrics_golden("axle_c3")
+    specs = axle_rotation_specs(program)
+    for s in range(mg["pos"].shape[0]):
+        angle = {k: rotation_about_fixed_axis_deg(mg["pos"][s][o], None, d, a, u, sc)[0] for k, (o, d, a, u, sc) in specs.items()}
+        for tag in ("left", "right"):
+            for j, name in enumerate(str(n) for n in mg[f"{tag}_extra_names"]):
+                assert abs(angle[f"{name}_{tag}"] - mg[f"{tag}_extra_values"][s][j]) <= 1e-10, (s, tag, name)
+        assert [str(n) for n in mg["axle_extra_names"]] == ["arb_twist"]
+        assert abs(angle["arb_arm_angle_left"] - angle["arb_arm_angle_right"] - mg["axle_extra_values"][s][0]) <= 1e-10
 
 
 def test_e2e_csv_metric_columns_are_the_same_numbers():
