@@ -44,7 +44,8 @@ struct okx_program {
   int quad_waves_per_cu;
   int quad_ppw;             // problems per wavefront: 16 (one quad each) or 8 (pair mode: one quad per half)
   char quad_note[256];      // why the quad kernel is not in use (empty when it is)
-  double* predictor_dev;    // chain-head Taylor model fitted by okx_program_fit_predictor, or null
+  double* predictor_dev;    // chain-head model fitted by okx_program_fit_predictor, or null
+  long long predictor_len;  // doubles in it
 };
 
 namespace {
@@ -480,6 +481,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     q.trace_problem = g_quad_trace_problem;
     q.predictor = (opts->predictor != 0 && !d_geom_pos) ? p->predictor_dev : nullptr;
     q.predictor_mode = opts->predictor;
+    q.predictor_len = p->predictor_len;
     const long long wave_units = (units + p->quad_ppw - 1) / p->quad_ppw;
     const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
     const int grid = (int)(wave_units < cap ? (wave_units < 1 ? 1 : wave_units) : cap);
@@ -643,6 +645,7 @@ int32_t okx_program_fit_predictor(okx_program* p, const double* lo, const double
     (void)hipFree(p->predictor_dev);
   }
   p->predictor_dev = d_table;
+  p->predictor_len = (long long)table.size();
   return OKX_OK;
 }
 

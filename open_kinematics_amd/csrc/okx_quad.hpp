@@ -33,6 +33,7 @@ struct QuadArgs {
   long long trace_problem;
   const double* predictor;  // chain-head polynomial model (okx_program_fit_predictor) or null
   long long predictor_mode; // 2: every chain step starts from the model
+  long long predictor_len;  // doubles in the table
 };
 
 // Arguments of the generated parity kernel `okx_quad_eval` (mirrors `struct QEvalArgs`).

@@ -505,9 +505,9 @@ class Gen {
     std::snprintf(name, sizeof(name), "hq%d_%d", i, k0);
     const std::string home = lane_home(name);
     if (i < P.n_crows)
-      std::snprintf(line, sizeof(line), "      %s%s = c < 3 ? gq[%s + cc] : 0.0;\n", decl(), home.c_str(), crow8(i, k0).c_str());
+      std::snprintf(line, sizeof(line), "      %s%s = ld3(gq + %s + cc, c);\n", decl(), home.c_str(), crow8(i, k0).c_str());
     else  // target direction; zero on a side that does not carry this target (pair mode)
-      std::snprintf(line, sizeof(line), "      %s%s = c < 3 ? a.row_param[%s + cc] * %s : 0.0;\n", decl(), home.c_str(),
+      std::snprintf(line, sizeof(line), "      %s%s = ld3(a.row_param + %s + cc, c) * %s;\n", decl(), home.c_str(),
                     trow8(i, k0).c_str(), target_enable(target_of_row(i)).c_str());
     hoisted += line;
     hoisted_names[key] = home;
@@ -1019,10 +1019,14 @@ struct QArgs {
   double* trace; long long trace_problem;   // diagnostic: 8 doubles per LM pass of one problem (null: off)
   const double* predictor;  // polynomial model of the solution over the fitted target range for chain heads (null: off)
   long long predictor_mode; // 2: every chain step starts from the model, not only the heads
+  long long predictor_len;  // doubles in the table
 };
 #define EPS_SQ 1e-12
 #define EPS 1e-6
 #define DEV __device__ __forceinline__
+// lane component load: lanes 0..2 read their component, lane 3 (address clamped to component 2 by the caller)
+// gets zero.  The load itself is unconditional: no exec-mask branch per value.
+DEV double ld3(const double* p, int c) { const double v = *p; return c < 3 ? v : 0.0; }
 #define INFO_CONVERGED 1
 #define INFO_RESIDUAL_EXCEEDED 2
 #define INFO_FAILED 4
@@ -1258,12 +1262,16 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    const long long geom = span_idx;");
   g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * prog_points);
   g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * prog_crows);
+  // Every load of the prologue is issued before the first dependent instruction: first-step targets, chain
+  // constants, points and (single mode) the predictor table's copy into LDS share one round trip.
+  for (int t = 0; t < T; ++t)
+    g.f("    double tn%d = a.targets[first_b * %d + %s], tp%d = 0.0, tq%d = 0.0;", t, prog_targets, ev.target_slot(t).c_str(), t, t);
   g.f("    // chain-constant lane-component parameters (line points / directions, target directions)");
   g.out += ev.hoisted;
   g.out += couple_hoist;
   // point registers
   for (int p = 0; p < NP; ++p)
-    if (used[p]) g.f("    double p%d = c < 3 ? gp[%s + cc] : 0.0;", p, ev.point3(p).c_str());
+    if (used[p]) g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
   for (int F = 0; F < nf; ++F) {
     if (ev.lds_constants) {  // cold per-pass state lives in LDS (register-bound kernel): plain references, same code below
       g.f("    double& x%d = xsl[%d + lane]; double& xp%d = xsl[%d + lane];", F, 64 * (2 * F), F, 64 * (2 * F + 1));
@@ -1277,8 +1285,13 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)");
   // targets: the next step's values are fetched while the current step is being solved, and the two
   // previous steps' values (secant predictor) stay in registers
-  for (int t = 0; t < T; ++t)
-    g.f("    double tn%d = a.targets[first_b * %d + %s], tp%d = 0.0, tq%d = 0.0;", t, prog_targets, ev.target_slot(t).c_str(), t, t);
+  if (!pv) {
+    g.f("    const bool model_lds = !PG && a.predictor != nullptr && a.predictor_len <= %d;", kPredictorLdsDoubles);
+    g.f("    if (model_lds) {");
+    g.f("      for (int k = lane; k < (int)a.predictor_len; k += 64) pls[k] = a.predictor[k];");
+    g.f("      __syncthreads();");
+    g.f("    }");
+  }
   g.f("    for (long long b = first_b; wave_any(have && b < last_b); ++b) {");
   g.f("      const bool valid = have && b < last_b;");
   g.f("      const long long bb = valid ? b : last_b - 1;");
@@ -1299,18 +1312,18 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     std::vector<int> ordinal(program.n_points, 0);  // program point -> its free ordinal
     for (int k = 0; k < program.n_free; ++k) ordinal[program.free_point[k]] = k;
     g.f("      if (!PG && a.predictor != nullptr && (hist < 2 || a.predictor_mode == 2) && !cold) {");
-    g.f("        const double* pp = a.predictor;");
-    for (int t = 0; t < TT; ++t) {
-      g.f("        const double pu%d = fmin(fmax((a.targets[bb * %d + %d] - pp[%d]) * pp[%d], -1.0), 1.0);", t, TT, t, 3 * t, 3 * t + 1);
-      g.f("        const int pD%d = (int)pp[%d];", t, 3 * t + 2);
-    }
-    g.f("        const int prS = (int)pp[%d];  // total-degree budget", 3 * TT);
-    g.f("        const double pwS = 1.0;");
     for (int F = 0; F < nf; ++F) g.f("        double pa%d = 0.0;", F);
     auto up = [&](int t, const char* what) { return t == 0 ? std::string(what) + "S" : std::string(what) + std::to_string(t - 1); };
-    // the term loops, reading the coefficient blocks through `ptr` (global memory or the LDS copy)
-    auto term_loops = [&](const char* decl) {
-      g.f("          %s;", decl);
+    // header + term loops, reading through `pp` (global memory or the LDS copy made in the prologue)
+    auto evaluate = [&](const char* base) {
+      g.f("          const double* pp = %s;", base);
+      for (int t = 0; t < TT; ++t) {
+        g.f("          const double pu%d = fmin(fmax((tv%d - pp[%d]) * pp[%d], -1.0), 1.0);", t, t, 3 * t, 3 * t + 1);
+        g.f("          const int pD%d = (int)pp[%d];", t, 3 * t + 2);
+      }
+      g.f("          const int prS = (int)pp[%d];  // total-degree budget", 3 * TT);
+      g.f("          const double pwS = 1.0;");
+      g.f("          const double* pq = pp + %d;", 3 * TT + 2);
       for (int t = 0; t < TT; ++t) {  // one loop level per target: pc = T_i(u), pn = T_{i+1}(u)
         g.f("          { double pc%d = 1.0, pn%d = pu%d;", t, t, t);
         g.f("          for (int pi%d = 0; pi%d <= pD%d && pi%d <= %s; ++pi%d) {", t, t, t, t, up(t, "pr").c_str(), t);
@@ -1328,23 +1341,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         g.f("          } }");
       }
     };
-    if (!pv) {
-      // one quad per problem: the kernel has LDS to spare, so a table of up to kPredictorLdsDoubles is copied there
-      // with coalesced reads first (one round trip to L2) and the dependent per-term reads come from LDS
-      g.f("        const int plen = (int)pp[%d];", 3 * TT + 1);
-      g.f("        if (plen <= %d) {", kPredictorLdsDoubles);
-      g.f("          for (int k = lane; k < plen; k += 64) pls[k] = pp[k];");
-      g.f("          __syncthreads();");
-      term_loops(Gen::f_str("const double* pq = pls + %d", 3 * TT + 2).c_str());
-      g.f("          __syncthreads();");
-      g.f("        } else {");
-      term_loops(Gen::f_str("const double* pq = pp + %d", 3 * TT + 2).c_str());
-      g.f("        }");
-    } else {
-      g.f("        {");
-      term_loops(Gen::f_str("const double* pq = pp + %d", 3 * TT + 2).c_str());
-      g.f("        }");
-    }
+    g.f("        if (model_lds) {");
+    evaluate("pls");
+    g.f("        } else {");
+    evaluate("a.predictor");
+    g.f("        }");
     for (int F = 0; F < nf; ++F) g.f("        x%d = pa%d;", F, F);
     g.f("      }");
   }
@@ -1583,7 +1584,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // chains never continue from a state that failed to converge
   for (int t = 0; t < T; ++t) g.f("    tq%d = tp%d; tp%d = tv%d;", t, t, t, t);
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
-  for (int F = 0; F < nf; ++F) g.f("      x%d = c < 3 ? gp[%s + cc] : 0.0;", F, ev.point3(ev.fp(F)).c_str());
+  for (int F = 0; F < nf; ++F) g.f("      x%d = ld3(gp + %s + cc, c);", F, ev.point3(ev.fp(F)).c_str());
   g.f("      hist = 0; lambda_carry = 0.0; cold = true;");
   g.f("    } else {");
   g.f("      if (hist < 2) ++hist;");
