@@ -1240,7 +1240,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       "  __shared__ double hql[" + std::to_string(64 * (ev.n_lane_slots + 1)) + "];  // chain-constant lane components [slot][lane]\n";
   if (ev.lds_constants) {
     g.out += lds_decl;
-    g.f("  __shared__ double xsl[%d];  // accepted point and chain history [block][lane]", 64 * 2 * nf);
+    g.f("  __shared__ double xsl[%d];  // accepted point and chain history [block][lane]", 64 * 3 * nf);
+  } else {
+    g.f("  __shared__ double xql[%d];  // third chain-history point [block][lane] (registers are full)", 64 * nf);
   }
   g.f("  const long long spg = a.steps_per_geometry;");
   g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
@@ -1265,7 +1267,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // Every load of the prologue is issued before the first dependent instruction: first-step targets, chain
   // constants, points and (single mode) the predictor table's copy into LDS share one round trip.
   for (int t = 0; t < T; ++t)
-    g.f("    double tn%d = a.targets[first_b * %d + %s], tp%d = 0.0, tq%d = 0.0;", t, prog_targets, ev.target_slot(t).c_str(), t, t);
+    g.f("    double tn%d = a.targets[first_b * %d + %s], tp%d = 0.0, tq%d = 0.0, tr%d = 0.0;", t, prog_targets, ev.target_slot(t).c_str(), t, t, t);
   g.f("    // chain-constant lane-component parameters (line points / directions, target directions)");
   g.out += ev.hoisted;
   g.out += couple_hoist;
@@ -1274,10 +1276,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     if (used[p]) g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
   for (int F = 0; F < nf; ++F) {
     if (ev.lds_constants) {  // cold per-pass state lives in LDS (register-bound kernel): plain references, same code below
-      g.f("    double& x%d = xsl[%d + lane]; double& xp%d = xsl[%d + lane];", F, 64 * (2 * F), F, 64 * (2 * F + 1));
-      g.f("    x%d = p%d; xp%d = x%d; double dx%d = 0.0;", F, ev.fp(F), F, F, F);
+      g.f("    double& x%d = xsl[%d + lane]; double& xp%d = xsl[%d + lane]; double& xq%d = xsl[%d + lane];", F, 64 * (2 * F), F,
+          64 * (2 * F + 1), F, 64 * (2 * nf + F));
+      g.f("    x%d = p%d; xp%d = x%d; xq%d = x%d; double dx%d = 0.0;", F, ev.fp(F), F, F, F, F, F);
     } else {
-      g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0;", F, ev.fp(F), F, F, F);
+      g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0; double& xq%d = xql[%d + lane]; xq%d = x%d;", F, ev.fp(F), F, F, F, F, 64 * F, F, F);
     }
   }
   g.f("    int hist = 0;");
@@ -1298,6 +1301,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      const long long nb = b + 1 < last_b ? b + 1 : last_b - 1;");
   for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
   for (int t = 0; t < T; ++t) g.f("      tn%d = a.targets[nb * %d + %s];", t, prog_targets, ev.target_slot(t).c_str());
+  g.f("      bool from_model = false;");
   // Chain heads (and the step after, which has no secant history yet) start from the polynomial model fitted
   // by okx_program_fit_predictor instead of the design state / the previous solution:
   // x(t) = sum_k coef_k prod_t T_{k_t}(u_t), Chebyshev polynomials in the targets normalised to the fitted box
@@ -1346,22 +1350,35 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("        } else {");
     evaluate("a.predictor");
     g.f("        }");
-    for (int F = 0; F < nf; ++F) g.f("        x%d = pa%d;", F, F);
+    for (int F = 0; F < nf; ++F) g.f("        xq%d = xp%d; xp%d = x%d; x%d = pa%d;", F, F, F, F, F, F);
+    g.f("        from_model = true;");
     g.f("      }");
   }
-  // secant predictor: x + alpha (x - xp), alpha from the target increments
-  g.f("      if (hist >= 2 && !(!PG && a.predictor != nullptr && a.predictor_mode == 2 && !cold)) {");
-  g.f("        double num = 0.0, den = 0.0;");
-  for (int t = 0; t < T; ++t)
-    g.f("        num = fma(%s * (tv%d - tp%d), tp%d - tq%d, num); den = fma(%s * (tp%d - tq%d), tp%d - tq%d, den);",
-        ev.target_enable(t).c_str(), t, t, t, t, ev.target_enable(t).c_str(), t, t, t, t);
-  g.f("        num = PJOIN_SUM(num); den = PJOIN_SUM(den);  // pair mode: targets of both halves");
+  // Extrapolation along the chain from the solved states x (step k-1), xp (k-2), xq (k-3):
+  // two states -> secant x + alpha (x - xp), alpha = the new target increment over the old one; three states on
+  // one line of target space with comparable spacing -> the quadratic through them (error O(h^3) instead of
+  // O(h^2): one full pass then suffices at the step sizes of the grids and ensembles).  The history shifts either way.
+  g.f("      if (!from_model && hist >= 2) {");
+  g.f("        double num = 0.0, den = 0.0, nn = 0.0, num2 = 0.0, den2 = 0.0;");
+  for (int t = 0; t < T; ++t) {
+    const std::string en = ev.target_enable(t);
+    g.f("        { const double dn = %s * (tv%d - tp%d), dold = tp%d - tq%d, dolder = tq%d - tr%d;", en.c_str(), t, t, t, t, t, t);
+    g.f("          num = fma(dn, dold, num); den = fma(%s * dold, dold, den); nn = fma(dn, tv%d - tp%d, nn);", en.c_str(), t, t);
+    g.f("          num2 = fma(%s * dold, dolder, num2); den2 = fma(%s * dolder, dolder, den2); }", en.c_str(), en.c_str());
+  }
+  g.f("        num = PJOIN_SUM(num); den = PJOIN_SUM(den); nn = PJOIN_SUM(nn); num2 = PJOIN_SUM(num2); den2 = PJOIN_SUM(den2);  // pair mode: targets of both halves");
   g.f("        double alpha = den > 0.0 ? num / den : 0.0;");
   g.f("        alpha = fmin(fmax(alpha, 0.0), 2.0);");
+  g.f("        const double beta = den2 > 0.0 ? num2 / den2 : 0.0;  // old increment over the one before");
+  g.f("        const bool line = hist >= 3 && alpha > 0.0 && beta >= 0.5 && beta <= 2.0 && num * num >= 0.98 * nn * den && num2 * num2 >= 0.98 * den * den2;");
+  g.f("        const double bq = line ? 1.0 / beta : 1.0;  // spacings in units of the old increment: new = alpha, old = 1, older = bq");
+  g.f("        const double l0 = line ? (alpha + 1.0) * (alpha + 1.0 + bq) / (1.0 + bq) : 1.0 + alpha;");
+  g.f("        const double l1 = line ? -alpha * (alpha + 1.0 + bq) / bq : -alpha;");
+  g.f("        const double l2 = line ? alpha * (alpha + 1.0) / ((1.0 + bq) * bq) : 0.0;");
   for (int F = 0; F < nf; ++F)
-    g.f("        { const double xn = fma(alpha, x%d - xp%d, x%d); xp%d = x%d; x%d = xn; }", F, F, F, F, F, F);
-  g.f("      } else {");
-  for (int F = 0; F < nf; ++F) g.f("        xp%d = x%d;", F, F);
+    g.f("        { const double xn = fma(l0, x%d, fma(l1, xp%d, l2 * xq%d)); xq%d = xp%d; xp%d = x%d; x%d = xn; }", F, F, F, F, F, F, F, F);
+  g.f("      } else if (!from_model) {");
+  for (int F = 0; F < nf; ++F) g.f("        xq%d = xp%d; xp%d = x%d;", F, F, F, F);
   g.f("      }");
   g.f("      double Fc = 0.0, lambda = 0.0, nu = 2.0, dmax = 0.0, step_len = 0.0, last_step = 0.0, mres = 0.0, pred = 0.0;");
   g.f("      int nfev = 0, iters = 0, flags = 0, nfail = 0;");
@@ -1582,12 +1599,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      a.info[bb] = inf;");
   g.f("    }");
   // chains never continue from a state that failed to converge
-  for (int t = 0; t < T; ++t) g.f("    tq%d = tp%d; tp%d = tv%d;", t, t, t, t);
+  for (int t = 0; t < T; ++t) g.f("    tr%d = tq%d; tq%d = tp%d; tp%d = tv%d;", t, t, t, t, t, t);
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
   for (int F = 0; F < nf; ++F) g.f("      x%d = ld3(gp + %s + cc, c);", F, ev.point3(ev.fp(F)).c_str());
   g.f("      hist = 0; lambda_carry = 0.0; cold = true;");
   g.f("    } else {");
-  g.f("      if (hist < 2) ++hist;");
+  g.f("      if (hist < 3) ++hist;");
   g.f("      cold = false;");
   g.f("      lambda_carry = lambda;");
   g.f("    }");
