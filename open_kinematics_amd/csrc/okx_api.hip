@@ -519,7 +519,7 @@ int32_t okx_program_has_predictor(const okx_program* p) { return p && p->predict
 int32_t okx_program_fit_predictor(okx_program* p, const double* lo, const double* hi, int32_t degree, void* stream) {
   if (!p || !lo || !hi) return fail(OKX_ERR_INVALID, "null pointer");
   if (!p->quad_fn_u) return fail(OKX_ERR_INVALID, "the predictor belongs to the quad kernel: %s", p->quad_note);
-  if (p->quad_ppw != 16) return fail(OKX_ERR_INVALID, "pair-mode kernels carry no predictor (register-bound)");
+  if (p->quad_ppw != 16 && !getenv("OKX_PAIR_MODEL")) return fail(OKX_ERR_INVALID, "pair-mode kernels carry no predictor (register-bound)");
   const okx::DevProgram& H = p->host;
   const int T = H.n_targets;
   if (T < 1) return fail(OKX_ERR_INVALID, "program has no targets");

@@ -1311,7 +1311,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // ~20 % (registers, code size) whether it runs or not.  Own-geometry launches only; a restart after a failed
   // step goes back to the design state.  Not generated in pair mode: that kernel is register-bound and the mere
   // presence of the block cost the axle 18 % on chained grids for a 3 % gain (profiles/r01/config_sweep_pred.txt).
-  if (!pv) {
+  if (!pv || getenv("OKX_PAIR_MODEL")) {
     const int TT = prog_targets;
     std::vector<int> ordinal(program.n_points, 0);  // program point -> its free ordinal
     for (int k = 0; k < program.n_free; ++k) ordinal[program.free_point[k]] = k;
@@ -1322,7 +1322,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     auto evaluate = [&](const char* base) {
       g.f("          const double* pp = %s;", base);
       for (int t = 0; t < TT; ++t) {
-        g.f("          const double pu%d = fmin(fmax((tv%d - pp[%d]) * pp[%d], -1.0), 1.0);", t, t, 3 * t, 3 * t + 1);
+        if (pv)  // the halves carry their own target lists: read the program's targets
+          g.f("          const double pu%d = fmin(fmax((a.targets[bb * %d + %d] - pp[%d]) * pp[%d], -1.0), 1.0);", t, TT, t, 3 * t, 3 * t + 1);
+        else
+          g.f("          const double pu%d = fmin(fmax((tv%d - pp[%d]) * pp[%d], -1.0), 1.0);", t, t, 3 * t, 3 * t + 1);
         g.f("          const int pD%d = (int)pp[%d];", t, 3 * t + 2);
       }
       g.f("          const int prS = (int)pp[%d];  // total-degree budget", 3 * TT);
@@ -1345,11 +1348,17 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         g.f("          } }");
       }
     };
-    g.f("        if (model_lds) {");
-    evaluate("pls");
-    g.f("        } else {");
-    evaluate("a.predictor");
-    g.f("        }");
+    if (!pv) {
+      g.f("        if (model_lds) {");
+      evaluate("pls");
+      g.f("        } else {");
+      evaluate("a.predictor");
+      g.f("        }");
+    } else {
+      g.f("        {");
+      evaluate("a.predictor");
+      g.f("        }");
+    }
     for (int F = 0; F < nf; ++F) g.f("        xq%d = xp%d; xp%d = x%d; x%d = pa%d;", F, F, F, F, F, F);
     g.f("        from_model = true;");
     g.f("      }");
