@@ -297,8 +297,12 @@ def main() -> None:
                 "lm_evaluations_mean": nfev_mean,
                 "predictor": bool(use_predictor),
                 "all_converged": ok,
-                "exchange": "RCCL all-gather of solved positions every step, overlapped with the next "
-                            "step's solve (two output slots)" if world > 1 else "none",
+                "exchange": ("RCCL all-gather of solved positions every step, overlapped with the next step's solve "
+                             "(two output slots); %d B per rank per step, i.e. every rank receives %d B per step: at the "
+                             "single-GPU solve rate that is more than xGMI can deliver, so N > 1 runs at the exchange's "
+                             "rate (DESIGN.md section 8)" % (STEPS_PER_RANK * program.n_out * 24,
+                                                         (world - 1) * STEPS_PER_RANK * program.n_out * 24))
+                            if world > 1 else "none",
             },
             "roofline": {
                 "bound": "hbm",
