@@ -177,7 +177,7 @@ def main() -> None:
     from open_kinematics_amd import _lib
     from open_kinematics_amd._abi import HostProgram
     from open_kinematics_amd.batch import DeviceProgram
-    from open_kinematics_amd.dist import GatherPipeline, shard_range
+    from open_kinematics_amd.dist import FreeGatherPipeline, shard_range
     from open_kinematics_amd.workloads import bump_sweep_problem
 
     n_total = STEPS_PER_RANK * world
@@ -187,8 +187,10 @@ def main() -> None:
     targets = torch.as_tensor(targets_all[lo:hi], device=device).contiguous()
     info = torch.empty((hi - lo, 40), dtype=torch.uint8, device=device)
     # Two output slots: with N > 1 ranks the all-gather of step k (RCCL stream) overlaps the solve
-    # of step k + 1 (launch stream), see dist.GatherPipeline.  One rank: slot 0 only, no exchange.
-    pipe = GatherPipeline(hi - lo, (program.n_out, 3), torch.float64, device)
+    # of step k + 1 (launch stream), see dist.GatherPipeline.  The exchange ships the free coordinates
+    # of each solve (144 B) and every rank rebuilds the full positions (360 B) itself
+    # (dist.FreeGatherPipeline / okx_expand_positions_batch).  One rank: slot 0 only, no exchange.
+    pipe = FreeGatherPipeline(hi - lo, program.n_out, dp.free_out_index, dp.expand, torch.float64, device)
     # pre-bound launches: per step the host only makes the C-ABI call (the kernel is ~40 us long)
     # Chain-head predictor: fitted once per program over this rank's target box (8 node solves for the
     # one varying target; setup, like the kernel compile) — every cold start of the timed launches then
@@ -297,11 +299,12 @@ def main() -> None:
                 "lm_evaluations_mean": nfev_mean,
                 "predictor": bool(use_predictor),
                 "all_converged": ok,
-                "exchange": ("RCCL all-gather of solved positions every step, overlapped with the next step's solve "
-                             "(two output slots); %d B per rank per step, i.e. every rank receives %d B per step: at the "
-                             "single-GPU solve rate that is more than xGMI can deliver, so N > 1 runs at the exchange's "
-                             "rate (DESIGN.md section 8)" % (STEPS_PER_RANK * program.n_out * 24,
-                                                         (world - 1) * STEPS_PER_RANK * program.n_out * 24))
+                "exchange": ("RCCL all-gather of the solved free coordinates every step (every rank rebuilds all positions "
+                             "from them), overlapped with the next step's solve (two output slots); %d B per rank per step "
+                             "instead of %d B of positions, i.e. every rank receives %d B per step: at the single-GPU solve "
+                             "rate that is still more than xGMI can deliver, so N > 1 runs at the exchange's rate "
+                             "(DESIGN.md section 8)" % (STEPS_PER_RANK * program.n_free * 24, STEPS_PER_RANK * program.n_out * 24,
+                                                    (world - 1) * STEPS_PER_RANK * program.n_free * 24))
                             if world > 1 else "none",
             },
             "roofline": {

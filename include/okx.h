@@ -394,6 +394,19 @@ int32_t okx_axis_rotation_batch(const okx_rotation_role* roles, int32_t n_roles,
                                 void* stream);
 
 /*
+ * Output positions from free-point coordinates: fixed points come from the program's design state (or the
+ * per-geometry table of okx_rebind_design), derived points are re-evaluated (DerivedPointsManager.update,
+ * points/derived/manager.py).  The receiving side of a multi-GPU exchange that ships the 3 n_free free
+ * coordinates of each solve instead of its 3 n_out output coordinates; also turns stored free vectors
+ * (SuspensionState.get_free_array) back into full states.
+ */
+int32_t okx_expand_positions_batch(okx_program* prog, int64_t n_problems, int64_t steps_per_geometry,
+                                   const double* d_free,      /* [B][n_free][3], free_point order */
+                                   const double* d_geom_pos,  /* [G][n_points][3] or NULL */
+                                   double* d_out_pos,         /* [B][n_out][3] */
+                                   void* stream);
+
+/*
  * Chain-head predictor.  The reference warm-starts step k from step k-1 (solver.py:774) and starts a
  * sweep at the design state; a batch that fills the chip solves every step as an independent cold
  * start instead.  okx_program_fit_predictor solves the program once at the Chebyshev

@@ -37,6 +37,7 @@ EXPORTS = (
     "okx_axle_metrics_batch",
     "okx_axis_rotation_batch",
     "okx_camber_shim_batch",
+    "okx_expand_positions_batch",
     "okx_program_fit_predictor",
     "okx_program_has_predictor",
 )
@@ -106,6 +107,8 @@ def load() -> C.CDLL:
     lib.okx_axis_rotation_batch.restype = i32
     lib.okx_camber_shim_batch.argtypes = [vp, i64, i32, vp, vp, vp, vp]
     lib.okx_camber_shim_batch.restype = i32
+    lib.okx_expand_positions_batch.argtypes = [vp, i64, i64, vp, vp, vp, vp]
+    lib.okx_expand_positions_batch.restype = i32
     lib.okx_program_fit_predictor.argtypes = [vp, vp, vp, i32, vp]
     lib.okx_program_fit_predictor.restype = i32
     lib.okx_program_has_predictor.argtypes = [vp]

@@ -322,6 +322,41 @@ class DeviceProgram:
             raise RuntimeError(f"no chain-head predictor for this program: {self._predictor_note or 'not fitted'}")
         return bool(self._predictor)
 
+    @property
+    def free_out_index(self) -> torch.Tensor:
+        """Output-list index of every free point (device int64 ``[n_free]``); raises when one is not an output."""
+        if getattr(self, "_free_out", None) is None:
+            out = [int(k) for k in self.program.out_point]
+            try:
+                idx = [out.index(int(p)) for p in self.program.free_point]
+            except ValueError:
+                raise ValueError("a free point of this program is not among its output points") from None
+            self._free_out = torch.as_tensor(idx, dtype=torch.int64, device=self.device)
+        return self._free_out
+
+    def expand(self, free: torch.Tensor, out: torch.Tensor | None = None, geom_pos: torch.Tensor | None = None,
+               steps_per_geometry: int = 0) -> torch.Tensor:
+        """
+        ``okx_expand_positions_batch``: free coordinates ``[B, n_free, 3]`` (``free_point`` order, e.g.
+        ``positions[:, dp.free_out_index]``) -> output positions ``[B, n_out, 3]``: fixed points from the design
+        state (or ``geom_pos``), derived points re-evaluated.
+        """
+        p = self.program
+        free = _as_f64(free, self.device).reshape(-1, p.n_free, 3)
+        b = free.shape[0]
+        if out is None:
+            out = torch.empty((b, p.n_out, 3), dtype=torch.float64, device=self.device)
+        elif out.shape != (b, p.n_out, 3) or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float64 [B, n_out, 3] tensor")
+        if geom_pos is not None:
+            geom_pos = _as_f64(geom_pos, self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_expand_positions_batch(self._handle, b, int(steps_per_geometry), _ptr(free), _ptr(geom_pos),
+                                                     _ptr(out), C.c_void_p(stream))
+        _lib.check(rc, "okx_expand_positions_batch")
+        return out
+
     def rebind(self, hardpoints):
         """Per-geometry design positions ``[G, P, 3]`` and row parameters ``[G, Mc, 8]``."""
         p = self.program

@@ -40,6 +40,7 @@ struct okx_program {
   hipFunction_t quad_fn_u;  // program's own geometry
   hipFunction_t quad_fn_g;  // per-geometry tables
   hipFunction_t quad_fn_eval;  // parity kernel
+  hipFunction_t quad_fn_expand;  // positions from free coordinates (single mode)
   hipFunction_t quad_fn_tan_u, quad_fn_tan_g;  // tangents (null when a free point is not an output point)
   int quad_waves_per_cu;
   int quad_ppw;             // problems per wavefront: 16 (one quad each) or 8 (pair mode: one quad per half)
@@ -173,6 +174,7 @@ void attach_quad_kernel(okx_program* p) {
   p->quad_mod = nullptr;
   p->quad_fn_u = p->quad_fn_g = nullptr;
   p->quad_fn_eval = nullptr;
+  p->quad_fn_expand = nullptr;
   p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
   p->quad_waves_per_cu = 0;
   p->quad_ppw = p->host.n_free > okx::kQuadMaxFree ? 8 : 16;
@@ -228,6 +230,7 @@ void attach_quad_kernel(okx_program* p) {
   p->quad_fn_u = fu;
   p->quad_fn_g = fg;
   if (hipModuleGetFunction(&p->quad_fn_eval, mod, "okx_quad_eval") != hipSuccess) p->quad_fn_eval = nullptr;
+  if (hipModuleGetFunction(&p->quad_fn_expand, mod, "okx_quad_expand") != hipSuccess) p->quad_fn_expand = nullptr;
   if (hipModuleGetFunction(&p->quad_fn_tan_u, mod, "okx_quad_tangent_u") != hipSuccess ||
       hipModuleGetFunction(&p->quad_fn_tan_g, mod, "okx_quad_tangent_g") != hipSuccess)
     p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
@@ -700,6 +703,45 @@ int32_t okx_rebind_design(okx_program* p, int64_t n_geometries, const double* d_
   a.n_geometries = n_geometries;
   hipLaunchKernelGGL(okx::okx_rebind_kernel, dim3(grid_for(p, n_geometries)), dim3(okx::kWave),
                      p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
+  HIP_TRY(hipGetLastError());
+  return OKX_OK;
+}
+
+int32_t okx_expand_positions_batch(okx_program* p, int64_t n_problems, int64_t steps_per_geometry, const double* d_free,
+                                   const double* d_geom_pos, double* d_out_pos, void* stream) {
+  if (!p) return fail(OKX_ERR_INVALID, "null program");
+  if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
+  if (n_problems == 0) return OKX_OK;
+  if (!d_free || !d_out_pos) return fail(OKX_ERR_INVALID, "null pointer");
+  if (steps_per_geometry < 0 || (d_geom_pos && steps_per_geometry == 0) ||
+      (steps_per_geometry > 0 && n_problems % steps_per_geometry != 0))
+    return fail(OKX_ERR_INVALID, "bad steps_per_geometry");
+  if (p->quad_fn_expand && !getenv("OKX_EXPAND_GENERIC")) {  // generated form: 16 states per wavefront, coalesced records
+    okx::QuadExpandArgs q;
+    q.free = d_free;
+    q.geom_pos = d_geom_pos;
+    q.out_pos = d_out_pos;
+    q.n_problems = n_problems;
+    q.steps_per_geometry = steps_per_geometry > 0 ? steps_per_geometry : n_problems;
+    const char* base = reinterpret_cast<const char*>(p->dev);
+    q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
+    q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
+    q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
+    const long long waves = (n_problems + 15) / 16;
+    void* kargs[] = {(void*)&q};
+    HIP_TRY(hipModuleLaunchKernel(p->quad_fn_expand, (int)(waves < 65536 ? waves : 65536), 1, 1, okx::kWave, 1, 1, 0,
+                                  (hipStream_t)stream, kargs, nullptr));
+    return OKX_OK;
+  }
+  okx::ExpandArgs a;
+  a.free = d_free;
+  a.geom_pos = d_geom_pos;
+  a.out_pos = d_out_pos;
+  a.n_problems = n_problems;
+  a.steps_per_geometry = steps_per_geometry > 0 ? steps_per_geometry : n_problems;
+  const long long blocks = (n_problems + 255) / 256;
+  hipLaunchKernelGGL(okx::okx_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const okx::DevProgram*)p->dev, a);
   HIP_TRY(hipGetLastError());
   return OKX_OK;
 }

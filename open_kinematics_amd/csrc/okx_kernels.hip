@@ -1282,6 +1282,48 @@ okx_tangent_kernel(const DevProgram* __restrict__ P, TangentArgs args) {
 // per-geometry problem emission (okx_rebind_design)
 // ------------------------------------------------------------------------------------
 
+// Full output positions from free-point coordinates: fixed points from the (per-geometry) design table, derived
+// points re-evaluated in program order.  One thread per problem — the receiving side of the multi-GPU exchange,
+// which ships the 3 n_free free coordinates of a solve instead of its 3 n_out output coordinates.
+struct ExpandArgs {
+  const double* free;      // [B][n_free][3]
+  const double* geom_pos;  // [G][P][3] or null (program's own geometry)
+  double* out_pos;         // [B][n_out][3]
+  long long n_problems, steps_per_geometry;
+};
+
+__global__ void __launch_bounds__(256) okx_expand_kernel(const DevProgram* __restrict__ P, ExpandArgs a) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.n_problems) return;
+  double pos[3 * kMaxPoints];
+  const int np = P->n_points;
+  const double* base = a.geom_pos ? a.geom_pos + (b / a.steps_per_geometry) * 3 * np : &P->design_pos[0][0];
+  for (int e = 0; e < 3 * np; ++e) pos[e] = base[e];
+  const double* x = a.free + b * 3 * P->n_free;
+  for (int k = 0; k < P->n_free; ++k) {
+    const int pt = P->free_point[k];
+    pos[3 * pt] = x[3 * k];
+    pos[3 * pt + 1] = x[3 * k + 1];
+    pos[3 * pt + 2] = x[3 * k + 2];
+  }
+  for (int e = 0; e < P->n_derived; ++e) {
+    V3 u, av;
+    double nrm, vn, ga;
+    const V3 out = dop_position(P->dop_type[e], P->dop_pts[e], P->dop_param[e], pos, &u, &nrm, &av, &vn, &ga);
+    const int pt = P->dop_out[e];
+    pos[3 * pt] = out.x;
+    pos[3 * pt + 1] = out.y;
+    pos[3 * pt + 2] = out.z;
+  }
+  double* o = a.out_pos + b * 3 * P->n_out;
+  for (int k = 0; k < P->n_out; ++k) {
+    const int pt = P->out_point[k];
+    o[3 * k] = pos[3 * pt];
+    o[3 * k + 1] = pos[3 * pt + 1];
+    o[3 * k + 2] = pos[3 * pt + 2];
+  }
+}
+
 struct RebindArgs {
   const double* hardpoints;  // [G][P][3]
   double* geom_pos;          // [G][P][3]

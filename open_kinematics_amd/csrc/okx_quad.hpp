@@ -51,6 +51,17 @@ struct QuadEvalArgs {
   const double* dop_param;
 };
 
+// Arguments of the generated `okx_quad_expand` (mirrors `struct QExpandArgs`).
+struct QuadExpandArgs {
+  const double* free;
+  const double* geom_pos;
+  double* out_pos;
+  long long n_problems, steps_per_geometry;
+  const double* design_pos;
+  const double* row_param;
+  const double* dop_param;
+};
+
 // Arguments of the generated tangent kernels `okx_quad_tangent_u/_g` (mirrors `struct QTanArgs`).
 struct QuadTanArgs {
   const double* pos;

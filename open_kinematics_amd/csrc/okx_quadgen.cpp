@@ -1563,6 +1563,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       return false;
     }
   g.out += fin.out;
+  const std::string final_src = fin.out;
   g.f("    if (mres > a.residual_tolerance) flags |= INFO_RESIDUAL_EXCEEDED;");
   // Record stores.  Independent problems (chain_len 1): the 16 problems of a wavefront are
   // consecutive, so their records form one contiguous block; it is transposed through LDS and
@@ -1623,6 +1624,41 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("}");
   g.f("");
   if (!pv) {
+  // ---- output positions from free coordinates (okx_expand_positions_batch): fixed points from the design table,
+  //      every derived point re-evaluated, records written like the solve kernel's ----
+  g.f("struct QExpandArgs { const double* free; const double* geom_pos; double* out_pos; long long n_problems, steps_per_geometry;");
+  g.f("  const double* design_pos; const double* row_param; const double* dop_param; };");
+  g.f("extern \"C\" __global__ void __launch_bounds__(64) okx_quad_expand(QExpandArgs a) {");
+  g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+  g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+  g.f("  (void)e0; (void)e1; (void)e2;");
+  if (ev.lds_constants) g.out += lds_decl;
+  g.f("  __shared__ double stage[16 * %d];", 3 * P.n_out);
+  g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_problems; wu += gridDim.x) {");
+  g.f("    long long bb = wu * 16 + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");
+  g.f("    const long long geom = a.geom_pos != nullptr ? bb / a.steps_per_geometry : 0;");
+  g.f("    const double* gp = a.geom_pos != nullptr ? a.geom_pos + geom * %d : a.design_pos;", 3 * NP);
+  g.f("    const double* gq = a.row_param; (void)gq;");
+  g.out += ev.hoisted;
+  for (int p = 0; p < NP; ++p)
+    if (used[p]) g.f("    double p%d = ld3(gp + %d + cc, c);", p, 3 * p);
+  for (int F = 0; F < nf; ++F) g.f("    p%d = ld3(a.free + bb * %d + %d + cc, c);", ev.fp(F), 3 * nf, 3 * ev.perm[F]);
+  g.out += final_src;
+  g.f("    if (c < 3) {");
+  g.f("      double* st = stage + quad * %d + c;", 3 * P.n_out);
+  for (int k = 0; k < P.n_out; ++k) g.f("      st[%d] = p%d;", 3 * k, P.out_point[k]);
+  g.f("    }");
+  g.f("    __syncthreads();");
+  g.f("    const long long rem = a.n_problems - wu * 16;");
+  g.f("    const int n_doubles = (int)(rem < 16 ? rem : 16) * %d;", 3 * P.n_out);
+  g.f("    double2* dst = reinterpret_cast<double2*>(a.out_pos + wu * 16 * %d);", 3 * P.n_out);
+  g.f("    const double2* src = reinterpret_cast<const double2*>(stage);");
+  g.f("    for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
+  g.f("    if ((n_doubles & 1) && lane == 0) a.out_pos[wu * 16 * %d + n_doubles - 1] = stage[n_doubles - 1];", 3 * P.n_out);
+  g.f("    __syncthreads();");
+  g.f("  }");
+  g.f("}");
+  g.f("");
   // ---- parity / debug kernel: r, J^T J, J^T r at given x, and the damped step for a given lambda ----
   g.f("struct QEvalArgs { const double* x; const double* targets; double* r; double* ata; double* atr; double* dx;");
   g.f("  double lambda; long long n_problems; const double* design_pos; const double* row_param; const double* dop_param; };");

@@ -98,6 +98,61 @@ class GatherPipeline:
         return self.local[self.last] if self.world == 1 else self.full[self.last]
 
 
+class FreeGatherPipeline(GatherPipeline):
+    """
+    ``GatherPipeline`` that ships the free coordinates of each solve (``3 n_free`` doubles) instead of its output
+    positions (``3 n_out``) and rebuilds the positions on the receiving side (``expand``: fixed points from the
+    design state, derived points re-evaluated) — 144 B instead of 360 B per double-wishbone solve.  The exchange is
+    what bounds N > 1, so the payload is what matters.
+
+        pipe = FreeGatherPipeline(rows_per_rank, n_out, free_out_index, expand, dtype, device)
+        out = pipe.begin(k); ... solve into out ...; pipe.submit(k); ...; full = pipe.drain()
+
+    ``free_out_index``: output-list index of every free point; ``expand(free [R, n_free, 3], out [R, n_out, 3])``
+    fills ``out`` (``DeviceProgram.expand``).  With one rank it degenerates to the local buffer.
+    """
+
+    def __init__(self, rows_per_rank: int, n_out: int, free_out_index: torch.Tensor, expand, dtype, device, group=None,
+                 depth: int = 2):
+        super().__init__(rows_per_rank, (n_out, 3), dtype, device, group, depth)
+        self.free_out_index = free_out_index
+        self.expand = expand
+        n_free = int(free_out_index.numel())
+        self.free_local = [torch.empty((rows_per_rank, n_free, 3), dtype=dtype, device=device) for _ in range(depth)]
+        self.free_full = [torch.empty((rows_per_rank * self.world, n_free, 3), dtype=dtype, device=device)
+                          if self.world > 1 else None for _ in range(depth)]
+        self.pending = [False] * depth  # gathered free coordinates not expanded yet
+
+    def _finish(self, slot: int) -> None:
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+        if self.pending[slot]:
+            self.expand(self.free_full[slot], self.full[slot])
+            self.pending[slot] = False
+
+    def begin(self, k: int) -> torch.Tensor:
+        slot = k % self.depth
+        self._finish(slot)  # the previous exchange of this slot: positions of that step are complete now
+        return self.local[slot]
+
+    def submit(self, k: int) -> None:
+        slot = k % self.depth
+        self.last = slot
+        if self.world > 1:
+            torch.index_select(self.local[slot], 1, self.free_out_index, out=self.free_local[slot])
+            self.work[slot] = dist.all_gather_into_tensor(self.free_full[slot], self.free_local[slot], group=self.group,
+                                                          async_op=True)
+            self.pending[slot] = True
+
+    def drain(self) -> torch.Tensor:
+        for slot in range(self.depth):
+            self._finish(slot)
+        if self.last < 0:
+            raise RuntimeError("nothing was submitted")
+        return self.local[self.last] if self.world == 1 else self.full[self.last]
+
+
 def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = True, group=None, **solve_kw):
     """
     Solve this rank's index block of ``targets_full [B, T]`` and (optionally) all-gather the

@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from conftest import REPO
-from open_kinematics_amd.dist import GatherPipeline, all_gather_rows, shard_range
+from open_kinematics_amd.dist import FreeGatherPipeline, GatherPipeline, all_gather_rows, shard_range
 
 
 def test_shard_range_partitions_exactly():
@@ -49,6 +49,18 @@ def _worker(rank: int, world: int, port: int, n_total: int, out_dir: str) -> Non
             out.copy_(_fake_solve(targets[lo:hi] + float(k)))
             pipe.submit(k)
         torch.save(pipe.drain().clone(), os.path.join(out_dir, f"pipe{rank}.pt"))
+        # the compact exchange: "free" points 1 and 3 travel, the receiver rebuilds the other three of five
+        index = torch.tensor([1, 3])
+
+        def expand(free, out):  # stand-in for DeviceProgram.expand: _fake_solve's points are all equal
+            out.copy_(free[:, :1, :].expand(-1, 5, -1))
+
+        compact = FreeGatherPipeline(hi - lo, 5, index, expand, torch.float64, "cpu")
+        for k in range(5):
+            out = compact.begin(k)
+            out.copy_(_fake_solve(targets[lo:hi] + float(k)))
+            compact.submit(k)
+        torch.save(compact.drain().clone(), os.path.join(out_dir, f"compact{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,6 +76,7 @@ def test_two_rank_gloo_gather_reassembles_the_sweep(tmp_path, n_total):
         if n_total % 2 == 0:
             last = _fake_solve(torch.linspace(-60.0, 80.0, n_total, dtype=torch.float64).reshape(-1, 1) + 4.0)
             assert torch.equal(torch.load(os.path.join(tmp_path, f"pipe{rank}.pt")), last)
+            assert torch.equal(torch.load(os.path.join(tmp_path, f"compact{rank}.pt")), last)
 
 
 def test_single_process_pipeline_degenerates_to_the_local_buffer():
@@ -72,6 +85,14 @@ def test_single_process_pipeline_degenerates_to_the_local_buffer():
         pipe.begin(k).fill_(float(k))
         pipe.submit(k)
     assert torch.equal(pipe.drain(), torch.full((4, 3), 2.0, dtype=torch.float64))
+
+
+def test_single_process_compact_pipeline_degenerates_to_the_local_buffer():
+    pipe = FreeGatherPipeline(4, 3, torch.tensor([0, 2]), lambda free, out: None, torch.float64, "cpu")
+    for k in range(3):
+        pipe.begin(k).fill_(float(k))
+        pipe.submit(k)
+    assert torch.equal(pipe.drain(), torch.full((4, 3, 3), 2.0, dtype=torch.float64))
 
 
 def test_single_process_gather_is_identity():

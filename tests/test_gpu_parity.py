@@ -240,3 +240,79 @@ def test_infeasible_target_is_flagged_not_fatal(golden):
     ok = [0, 1, 3]
     assert np.all((info["flags"][ok] & 7) == 1)
     assert np.all(np.isfinite(pos))
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid", "c3_axle_grid"])
+def test_positions_rebuilt_from_free_coordinates(golden, name):
+    """okx_expand_positions_batch: the free coordinates of a solve carry its whole state (multi-GPU exchange payload)."""
+    arrays, program = golden(name)
+    pinned = program.with_line_mode("pinned")
+    dp = _device_program(pinned)
+    res = dp.solve(torch.as_tensor(arrays["targets_abs"]))
+    free = res.positions[:, dp.free_out_index]
+    assert free.shape == (res.positions.shape[0], pinned.n_free, 3)
+    rebuilt = dp.expand(free)
+    torch.cuda.synchronize()
+    assert float((rebuilt - res.positions).abs().max()) <= 1e-11
+    guard = torch.full((5, pinned.n_out, 3), -3.0, dtype=torch.float64, device=rebuilt.device)
+    dp.expand(free[:4], out=guard[:4])
+    assert float((guard[:4] - res.positions[:4]).abs().max()) <= 1e-11 and float((guard[4] + 3.0).abs().max()) == 0.0
+    with pytest.raises(ValueError, match="out must be"):
+        dp.expand(free[:4], out=guard)
+
+
+def test_positions_rebuilt_with_per_geometry_tables(golden):
+    arrays, program = golden("c5_ensemble") if False else golden("c1_dw_corner")
+    pinned = program.with_line_mode("pinned")
+    dp = _device_program(pinned)
+    rng = np.random.default_rng(3)
+    table = np.repeat(pinned.design_pos[None], 3, axis=0)
+    table[1:, pinned.free_point] += rng.normal(0.0, 0.3, size=(2, pinned.n_free, 3))
+    gpos, gparam = dp.rebind(torch.as_tensor(table))
+    t = torch.as_tensor(np.tile(arrays["targets_abs"][40:60], (3, 1)))
+    res = dp.solve(t, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=20)
+    rebuilt = dp.expand(res.positions[:, dp.free_out_index], geom_pos=gpos, steps_per_geometry=20)
+    torch.cuda.synchronize()
+    assert np.all(res.accepted(res.info()))
+    assert float((rebuilt - res.positions).abs().max()) <= 1e-11
+
+
+def test_compact_exchange_pipeline_on_the_device(golden, monkeypatch):
+    """FreeGatherPipeline with a stand-in two-rank all-gather: pack, gather, rebuild on the GPU gives the full positions."""
+    import torch.distributed as dist
+
+    from open_kinematics_amd import dist as okx_dist
+
+    arrays, program = golden("c1_dw_corner")
+    pinned = program.with_line_mode("pinned")
+    dp = _device_program(pinned)
+    t = torch.as_tensor(arrays["targets_abs"], device=dp.device)
+    half = t.shape[0] // 2
+    t = t[: 2 * half]
+    ref = dp.solve(t).positions
+
+    class Done:
+        def wait(self):
+            return True
+
+    other = {}
+
+    def fake_all_gather(full, local, group=None, async_op=False):
+        # rank 0's view of a two-rank job: its own block first, the peer's (solved here too) second
+        full[:half].copy_(local)
+        full[half:].copy_(other["free"])
+        return Done()
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather)
+    pipe = okx_dist.FreeGatherPipeline(half, pinned.n_out, dp.free_out_index, dp.expand, torch.float64, dp.device)
+    assert pipe.world == 2 and pipe.free_full[0].shape == (2 * half, pinned.n_free, 3)
+    other["free"] = ref[half:, dp.free_out_index].contiguous()
+    for k in range(3):
+        out = pipe.begin(k)
+        dp.solve(t[:half], out=out)
+        pipe.submit(k)
+    full = pipe.drain()
+    torch.cuda.synchronize()
+    assert full.shape == ref.shape and float((full - ref).abs().max()) <= 1e-11
