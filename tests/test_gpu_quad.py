@@ -268,3 +268,25 @@ def test_a_damaged_cache_entry_is_rebuilt(golden, tmp_path, monkeypatch):
     assert path.stat().st_size > 10000
     res = dp.solve(arrays["targets_abs"])
     assert np.all((res.info()["flags"] & 7) == 1)
+
+
+@pytest.mark.parametrize("workload", ["mac", "axle"])
+def test_grid_chains_with_row_wraps_match_independent_solves(workload):
+    """Chains over a flattened 2-D grid: the secant / three-point extrapolation must survive the row wraps
+    (target jumps back) and give the independent solves' answers."""
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.workloads import axle_grid_problem, macpherson_grid_problem
+
+    program, targets = macpherson_grid_problem(40, 40) if workload == "mac" else axle_grid_problem(20, 20)
+    dp = DeviceProgram(program, "cuda:0")
+    t = torch.as_tensor(targets, device="cuda:0")
+    ref = dp.solve(t, chain_len=1, predictor=False)
+    assert ref.accepted(ref.info()).all()
+    for chain_len in (-1, 3, 7, 40, 100, t.shape[0]):
+        for predictor in (False, None):
+            res = dp.solve(t, chain_len=chain_len, predictor=predictor)
+            info = res.info()
+            assert res.accepted(info).all(), (chain_len, predictor)
+            assert float((res.positions - ref.positions).abs().max()) <= 1e-9, (chain_len, predictor)
+    long_chain = dp.solve(t, chain_len=t.shape[0], predictor=False).info()
+    assert long_chain["nfev"].mean() < ref.info()["nfev"].mean() - 1.0  # extrapolation pays along the rows
