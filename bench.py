@@ -153,6 +153,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-len", type=int, default=None, help="override: 1 = independent cold starts")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 rehearsal on a one-GPU box: every rank uses cuda:0 and the exchange runs over gloo "
+                         "(exercises the sharding / pipeline / rebuild logic, not RCCL; the numbers mean nothing)")
     ap.add_argument("--no-predictor", action="store_true",
                     help="chain heads start from the design state instead of the fitted polynomial model")
     args = ap.parse_args()
@@ -168,11 +171,16 @@ def main() -> None:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the solve path)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from open_kinematics_amd import _lib
     from open_kinematics_amd._abi import HostProgram
