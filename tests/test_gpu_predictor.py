@@ -105,3 +105,35 @@ def test_predictor_is_skipped_where_it_does_not_apply(golden):
     with pytest.raises(RuntimeError, match="no chain-head predictor"):
         dp.solve(t, predictor=True)
     assert not dp.fit_predictor(t, degree=13) and "degree" in dp._predictor_note
+
+
+def test_two_varying_targets_on_the_double_wishbone_against_the_oracle():
+    """Rack x bump grid on the DW corner: the 2-D model (36 terms), chains with row wraps and cold starts agree
+    with each other and with the oracle's MINPACK on a sample."""
+    from oracle.oracle import Oracle
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.workloads import bump_sweep_problem
+
+    program, base = bump_sweep_problem(2)
+    rack = np.linspace(-25.0, 25.0, 96)
+    bump = np.linspace(-70.0, 90.0, 128)
+    t0 = base[0] - np.array([0.0, -60.0])  # design targets (bump_sweep_problem starts at -60 mm)
+    grid = np.stack(np.meshgrid(rack, bump, indexing="ij"), -1).reshape(-1, 2) + t0
+    dp = DeviceProgram(program, "cuda:0")
+    t = torch.as_tensor(grid, device="cuda:0")
+    cold = dp.solve(t, chain_len=1, predictor=False)
+    assert cold.accepted(cold.info()).all()
+    assert dp.fit_predictor(t, required=True)
+    lo, hi = dp.predictor_box
+    assert hi[0] - lo[0] == pytest.approx(50.0) and hi[1] - lo[1] == pytest.approx(160.0)
+    for kw in (dict(chain_len=1, predictor=True), dict(chain_len=-1, predictor=True), dict(chain_len=128, predictor=False),
+               dict(chain_len=1000, predictor="all")):
+        res = dp.solve(t, **kw)
+        assert res.accepted(res.info()).all(), kw
+        assert float((res.positions - cold.positions).abs().max()) <= 1e-9, kw
+    model = dp.solve(t, chain_len=1, predictor=True).info()
+    assert model["nfev"].mean() <= cold.info()["nfev"].mean() - 1.5
+    pick = np.linspace(0, grid.shape[0] - 1, 40).astype(int)
+    orc = Oracle(program).sweep(grid[pick], 1e-15, 1e-15, 1e-15, warm_start=False)
+    assert orc.first_failed_step == -1
+    assert np.max(np.abs(cold.positions.cpu().numpy()[pick] - orc.positions)) <= 1e-9
