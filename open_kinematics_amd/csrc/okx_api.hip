@@ -798,7 +798,7 @@ int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_
   q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
   q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
   q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
-  const long long waves = (n_problems + 15) / 16;
+  const long long waves = (n_problems + p->quad_ppw - 1) / p->quad_ppw;
   const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
   void* kargs[] = {(void*)&q};
   HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->quad_fn_tan_g : p->quad_fn_tan_u, (int)(waves < cap ? waves : cap), 1, 1,

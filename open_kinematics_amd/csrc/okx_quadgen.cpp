@@ -1709,8 +1709,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // ---- solution-manifold tangents (reference sensitivity.py:57-143): one kernel, B solved states ----
   std::vector<int> out_index(NP, -1);
   for (int k = 0; k < P.n_out; ++k) out_index[P.out_point[k]] = k;
-  bool tangent_ok = T > 0 && !pv;  // pair mode: the interpreter's tangent kernel serves those programs
-  for (int F = 0; F < nf; ++F) tangent_ok = tangent_ok && out_index[ev.fp(F)] >= 0;
+  bool tangent_ok = T > 0;
+  for (int F = 0; F < nf; ++F) {
+    const int k = out_index[ev.fp(F)];
+    tangent_ok = tangent_ok && k >= 0 && (!pv || (pv->out[0][k] >= 0 && pv->out[1][k] >= 0));
+  }
   if (tangent_ok) {
     ev.out.clear();
     ev.uid = 200000;
@@ -1728,21 +1731,29 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("  okx_tangent_info* tinfo; long long n_problems, steps_per_geometry;");
     g.f("  const double* design_pos; const double* row_param; const double* dop_param; };");
     g.f("template <bool PG> DEV void okx_quad_tangent_body(const QTanArgs& a) {");
-    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+    if (pv)
+      g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1 = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
+    else
+      g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
     if (ev.lds_constants) g.out += lds_decl;
     g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
-    g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_problems; wu += gridDim.x) {");
-    g.f("    long long bb = wu * 16 + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");
+    g.f("  for (long long wu = blockIdx.x; wu * %d < a.n_problems; wu += gridDim.x) {", PPW);
+    g.f("    long long bb = wu * %d + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;", PPW);
     g.f("    const long long geom = a.steps_per_geometry > 0 ? bb / a.steps_per_geometry : 0;");
-    g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * NP);
-    g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * P.n_crows);
+    g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * prog_points);
+    g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * prog_crows);
     g.out += ev.hoisted;
+    g.out += couple_hoist;
     for (int p = 0; p < NP; ++p)
-      if (used[p]) g.f("    double p%d = c < 3 ? gp[%d + cc] : 0.0;", p, 3 * p);
-    for (int F = 0; F < nf; ++F)
-      g.f("    p%d = c < 3 ? a.pos[bb * %d + %d + cc] : 0.0;", ev.fp(F), 3 * P.n_out, 3 * out_index[ev.fp(F)]);
+      if (used[p]) g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
+    for (int F = 0; F < nf; ++F) {
+      const int k = out_index[ev.fp(F)];
+      const std::string off = pv ? Gen::sel(3 * pv->out[0][k], 3 * pv->out[1][k]) : std::to_string(3 * k);
+      g.f("    p%d = ld3(a.pos + bb * %d + %s + cc, c);", ev.fp(F), 3 * prog_out, off.c_str());
+    }
     for (int t = 0; t < T; ++t) g.f("    const double tv%d = 0.0;  // target values do not enter the Jacobian", t);
     g.out += eval_src;
+    g.out += couple_eval;
     g.out += rest_src;
     g.f("    const double lambda = 0.0;");
     for (int F = 0; F < nf; ++F)
@@ -1753,21 +1764,60 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
             if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
           }
         }
+    if (pv) {
+      // The joining row couples the halves: A = D + w w^T with D = blockdiag(J^T J of each half), w = (w_L, w_R).
+      // Undamped, D alone is singular (the partner's rack pickup slides freely along its line), so each half
+      // takes its own part of the rank-one term, Dt = D + blockdiag(w_L w_L^T, w_R w_R^T), and the remaining
+      // off-diagonal coupling u v^T + v u^T (u = (w_L, 0), v = (0, w_R)) goes through a 2 x 2 Woodbury system:
+      // q = y - z c,  Dt y = rhs,  Dt z = w (per half),  c = (s_partner - g_partner s_own) / (1 - g_own g_partner),
+      // g = w.z and s = w.y of each half.
+      for (int k = 0; k < 3; ++k)
+        g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
+    }
     g.out += factor_src;
+    if (pv) {
+      g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
+      g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
+      std::vector<std::string> rhs_w;
+      for (int F = 0; F < nf; ++F) rhs_w.push_back(F == FU ? "cu" : "0.0");
+      for (int F = 0; F < nf; ++F) g.f("    double nz%d;", F);
+      ev.out.clear();
+      ev.emit_substitute(rhs_w, "sz");
+      g.f("    {");
+      g.out += ev.out;
+      for (int F = 0; F < nf; ++F) g.f("    nz%d = sz%d;", F, F);
+      g.f("    }");
+      g.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g);", FU);
+      g.f("    const double sm_det = 1.0 - sm_g * sm_gp;");
+    }
+    // one solve per PROGRAM target; in pair mode a side target stands for one program target per half
+    struct Job { int t, side, prog_t; };
+    std::vector<Job> jobs;
     for (int t = 0; t < T; ++t) {
-      g.f("    {  // target %d: (J^T J) q = J^T e_t, then the velocity of every point", t);
+      if (!pv) { jobs.push_back({t, -1, t}); continue; }
+      for (int sd = 0; sd < 2; ++sd)
+        if (pv->tgt[sd][t] >= 0) jobs.push_back({t, sd, pv->tgt[sd][t]});
+    }
+    for (const Job& job : jobs) {
+      const int t = job.t;
+      g.f("    {  // program target %d: (J^T J) q = J^T e_t, then the velocity of every point", job.prog_t);
+      if (pv) g.f("    const double ms = q1 == %d ? 1.0 : 0.0;  // the half that carries this target", job.side);
       std::vector<std::string> rhs(nf, "0.0");
       auto it = ev.target_j.find(t);
       if (it != ev.target_j.end())
-        for (auto& fv : it->second) rhs[fv.first] = Gen::sx(fv.second);
+        for (auto& fv : it->second) rhs[fv.first] = pv ? "(ms * " + Gen::sx(fv.second) + ")" : Gen::sx(fv.second);
       ev.out.clear();
-      ev.emit_substitute(rhs, "q");
-      const std::string vp = "w" + std::to_string(t) + "_";
-      std::vector<bool> have_v(NP, false);
+      ev.emit_substitute(rhs, pv ? "ty" : "tq");
+      if (pv) {
+        ev.f("    const double sm_s = qsum(cu * ty%d);", FU);
+        ev.f("    const double sm_c = (xq(sm_s) - sm_gp * sm_s) / sm_det;");
+        for (int F = 0; F < nf; ++F) ev.f("    const double tq%d = fma(-nz%d, sm_c, ty%d);", F, F, F);  // (q1 is the lane's half)
+      }
+      const std::string vp = "w" + std::to_string(job.prog_t) + "_";
       for (int p = 0; p < NP; ++p) {
         if (!used[p] || ev.dop_of_point[p] >= 0) continue;
         if (ev.blk_of_point[p] >= 0)
-          ev.f("    const double %s%d = q%d;", vp.c_str(), p, ev.blk_of_point[p]);
+          ev.f("    const double %s%d = tq%d;", vp.c_str(), p, ev.blk_of_point[p]);
         else
           ev.f("    const double %s%d = 0.0;", vp.c_str(), p);
       }
@@ -1778,14 +1828,27 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         }
       g.out += ev.out;
       g.f("    if (valid && c < 3) {");
-      g.f("      double* o = a.tan + (bb * %d + %d) * %d + c;", T, t, 3 * P.n_out);
-      for (int k = 0; k < P.n_out; ++k) g.f("      o[%d] = ok ? %s%d : __builtin_nan(\"\");", 3 * k, vp.c_str(), P.out_point[k]);
+      g.f("      double* o = a.tan + (bb * %d + %d) * %d + c;", prog_targets, job.prog_t, 3 * prog_out);
+      for (int k = 0; k < P.n_out; ++k) {
+        if (!pv) {
+          g.f("      o[%d] = ok ? %s%d : __builtin_nan(\"\");", 3 * k, vp.c_str(), P.out_point[k]);
+          continue;
+        }
+        const int k0 = pv->out[0][k], k1 = pv->out[1][k];
+        if (k1 >= 0)
+          g.f("      o[%s] = ok ? %s%d : __builtin_nan(\"\");", Gen::sel(3 * k0, 3 * k1).c_str(), vp.c_str(), P.out_point[k]);
+        else
+          g.f("      if (!q1) o[%d] = ok ? %s%d : __builtin_nan(\"\");", 3 * k0, vp.c_str(), P.out_point[k]);
+      }
+      if (pv)
+        for (size_t k = 0; k < pv->shared_out.size(); ++k)
+          g.f("      if (!q1) o[%d] = ok ? 0.0 : __builtin_nan(\"\");  // chassis point of neither half", 3 * pv->shared_out[k]);
       g.f("    }");
       g.f("    }");
     }
-    g.f("    if (valid && c == 0) {");
+    g.f("    if (valid && c == 0%s) {", pv ? " && !q1" : "");
     g.f("      okx_tangent_info ti; ti.min_pivot = pmin; ti.max_pivot = pmax; ti.reserved = 0;");
-    g.f("      ti.flags = (ok ? 1 : 0) | ((!ok || pmin <= %d * 2.220446049250313e-16 * pmax) ? 2 : 0);", 3 * nf);
+    g.f("      ti.flags = (ok ? 1 : 0) | ((!ok || pmin <= %d * 2.220446049250313e-16 * pmax) ? 2 : 0);", 3 * nf * (pv ? 2 : 1));
     g.f("      a.tinfo[bb] = ti;");
     g.f("    }");
     g.f("  }");

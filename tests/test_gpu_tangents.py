@@ -105,19 +105,34 @@ def test_ensemble_tangents_use_per_geometry_tables(golden):
     assert float((wrong - tan).abs().max()) > 1e-6
 
 
-def test_axle_tangents_from_the_generic_kernel_match_the_reference(golden):
-    """Programs without a generated tangent kernel (rocker axle, n = 60, T = 3): one wavefront per state."""
+def test_axle_tangents_in_pair_mode_and_from_the_generic_kernel_match_the_reference(golden, monkeypatch):
+    """Rocker axle (n = 60, T = 3): the generated pair-mode tangent kernel (one quad per corner, the rack row through
+    Sherman-Morrison) and the interpreter's one-wavefront-per-state kernel both reproduce the reference's velocities."""
     from open_kinematics_amd.batch import DeviceProgram
 
     _, program = golden("c3_axle_grid")
     tg = _tg("c3_axle_grid")
     dp = DeviceProgram(program.with_line_mode("pinned"), "cuda:0")
-    assert dp.kernel == "quad"  # pair-mode solve kernel; its module has no tangent kernel, the interpreter's is used
+    assert dp.kernel == "quad"  # pair-mode kernels
     tan, tinfo = dp.tangents(tg["pos"])
     torch.cuda.synchronize()
     info = dp.tangent_info(tinfo)
     assert np.all(info["flags"] == 1) and np.all(info["min_pivot"] > 0)
     assert np.max(np.abs(tan.cpu().numpy() - tg["vel"])) <= 1e-9
+    monkeypatch.setenv("OKX_TANGENT_GENERIC", "1")
+    wave, winfo = dp.tangents(tg["pos"])
+    torch.cuda.synchronize()
+    assert np.all(dp.tangent_info(winfo)["flags"] == 1)
+    assert np.max(np.abs(wave.cpu().numpy() - tg["vel"])) <= 1e-9
+    assert float((tan - wave).abs().max()) <= 1e-10
+    monkeypatch.delenv("OKX_TANGENT_GENERIC")
+    # per-geometry tables; the batch is ragged anyway (fewer states than the 8 of a wavefront)
+    n = tg["pos"].shape[0]
+    assert n % 8 != 0
+    pos = torch.as_tensor(tg["pos"], device="cuda:0")
+    gpos, gparam = dp.rebind(torch.as_tensor(np.repeat(program.design_pos[None], n, axis=0)))
+    per_geom, _ = dp.tangents(pos, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=1)
+    assert float((per_geom - tan).abs().max()) <= 1e-12
 
 
 def test_generic_and_generated_tangent_kernels_agree(golden, monkeypatch):
