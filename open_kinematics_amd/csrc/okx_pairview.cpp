@@ -5,7 +5,7 @@
 //
 // Why: J^T J of such a program is blockdiag(A_left, A_right) plus the rank-one term of the joining
 // row, so the damped normal equations are solved by two independent, identical block LDL^T
-// factorisations and a Sherman-Morrison correction.  One quad per side runs the same generated
+// factorisations and a low-rank (2 x 2 Woodbury) correction.  One quad per side runs the same generated
 // instruction stream on its own half of the data; 8 problems per wavefront.
 //
 // The match is positional, which is how the reference emits such programs: free points sorted by

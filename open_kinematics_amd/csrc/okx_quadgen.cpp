@@ -1104,7 +1104,7 @@ DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* src, std::string* why) {
   // Small programs: one quad per problem.  Larger ones only when they are two identical halves
-  // joined by one distance row (composed axle): one quad per half, Sherman-Morrison for the joint.
+  // joined by one distance row (composed axle): one quad per half, a 2 x 2 Woodbury correction for the joint.
   PairView pair_store;
   const PairView* pv = nullptr;
   if (program.n_free > kQuadMaxFree) {
@@ -1168,7 +1168,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // ---- pair mode: the row joining the two halves (distance between a point and its mirror image) ----
   // Each side sees d = partner - own; residual and cost terms are bit-identical on both sides
   // (squares of opposite-signed differences, commutative sums), the Jacobian entries live in the
-  // joined point's block only and never enter the per-side J^T J: Sherman-Morrison handles them.
+  // joined point's block only; each half adds its own part of the rank-one term and a 2 x 2 Woodbury system the rest.
   std::string couple_eval, couple_light, couple_hoist;
   int FU = -1;
   if (pv) {
@@ -1496,8 +1496,14 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   if (!pv) {
     g.out += solve_src;
   } else {
-    // (D + w w^T) dx = -g with D = blockdiag of the two halves' damped J^T J and w the joining row's
-    // Jacobian: dx = y - z (w.y) / (1 + w.z), D y = -g, D z = w (Sherman-Morrison).
+    // (D + w w^T) dx = -g with D = blockdiag of the two halves' damped J^T J and w = (w_L, w_R) the joining row's
+    // Jacobian.  D alone is nearly singular once the damping has decayed (the partner's rack pickup slides along
+    // its line), so each half takes its own part of the rank-one term, Dt = D + blockdiag(w_L w_L^T, w_R w_R^T),
+    // and the off-diagonal coupling u v^T + v u^T (u = (w_L, 0), v = (0, w_R)) goes through a 2 x 2 Woodbury
+    // system: dx = y - z c, Dt y = -g, Dt z = w (per half), c = (s_partner - g_partner s_own) / (1 - g_own g_partner)
+    // with g = w.z and s = w.y of each half.  (Plain Sherman-Morrison on D cancels catastrophically there.)
+    for (int k = 0; k < 3; ++k)
+      g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
     ev.out.clear();
     ev.emit_factor();
     g.out += ev.out;
@@ -1518,7 +1524,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.out += ev.out;
     for (int F = 0; F < nf; ++F) g.f("    nz%d = sz%d;", F, F);
     g.f("    }");
-    g.f("    const double sm_k = PSUM(cu * ny%d) / (1.0 + PSUM(cu * nz%d));", FU, FU);
+    g.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g), sm_s = qsum(cu * ny%d);", FU, FU);
+    g.f("    const double sm_k = (xq(sm_s) - sm_gp * sm_s) / (1.0 - sm_g * sm_gp);");
     for (int F = 0; F < nf; ++F) g.f("    const double nx%d = fma(-nz%d, sm_k, ny%d);", F, F, F);
   }
   g.f("    double sl = 0.0, pr = 0.0;");
