@@ -1461,6 +1461,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("            // a warm-started chain step continues with the damping its predecessor ended with");
   g.f("            dmax = diag; lambda = a.lambda0 * dmax;");
   g.f("            if (lambda_carry > 0.0) lambda = fmin(lambda, lambda_carry);");
+  g.f("            // a start from the fitted model is a near-converged start: the damping only adds a linear");
+  g.f("            // contraction floor there (MacPherson grid: 3.0 -> 2.0 evaluations); it grows back if a step fails");
+  g.f("            if (from_model) lambda *= 1e-3;");
   g.f("          }");
   g.f("          else if (mode == 1 && rho > 1e-4) {");
   g.f("            // Nielsen's update; a step whose gain ratio shows the quadratic model to be accurate");
