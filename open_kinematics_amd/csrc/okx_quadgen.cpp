@@ -1283,7 +1283,23 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0; double& xq%d = xql[%d + lane]; xq%d = x%d;", F, ev.fp(F), F, F, F, F, 64 * F, F, F);
     }
   }
-  g.f("    int hist = 0;");
+  // The design state is a solved state too (of its own design targets): it seeds the chain's history, so the
+  // second step of a chain already extrapolates (secant through design and head) and the third quadratically.
+  {
+    ev.reset_caches();
+    ev.out.clear();
+    for (int i = P.n_crows; i < P.m; ++i) {
+      const int t = ev.target_of_row(i);
+      const std::string d = ev.dot(Gen::pn(P.row_pts[i][0]), ev.rpv(i, 0));
+      ev.f("    const double td%d = %s;  // target %d at the design state (zero on a half that does not carry it)", t, d.c_str(), t);
+    }
+    g.out += ev.out;
+    ev.out.clear();
+    ev.reset_caches();
+  }
+  for (int t = 0; t < T; ++t) g.f("    tp%d = td%d;", t, t);
+  g.f("    int hist = 1;        // solved states in the history (the design state counts)");
+  g.f("    int steps_done = 0;  // steps of this chain solved since its (re)start");
   g.f("    bool cold = false;  // the previous chain step failed: restart from the design state, not the predictor");
   g.f("    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)");
   // targets: the next step's values are fetched while the current step is being solved, and the two
@@ -1315,7 +1331,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     const int TT = prog_targets;
     std::vector<int> ordinal(program.n_points, 0);  // program point -> its free ordinal
     for (int k = 0; k < program.n_free; ++k) ordinal[program.free_point[k]] = k;
-    g.f("      if (!PG && a.predictor != nullptr && (hist < 2 || a.predictor_mode == 2) && !cold) {");
+    g.f("      if (!PG && a.predictor != nullptr && (steps_done < 2 || a.predictor_mode == 2) && !cold) {");
     for (int F = 0; F < nf; ++F) g.f("        double pa%d = 0.0;", F);
     auto up = [&](int t, const char* what) { return t == 0 ? std::string(what) + "S" : std::string(what) + std::to_string(t - 1); };
     // header + term loops, reading through `pp` (global memory or the LDS copy made in the prologue)
@@ -1379,7 +1395,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("        double alpha = den > 0.0 ? num / den : 0.0;");
   g.f("        alpha = fmin(fmax(alpha, 0.0), 2.0);");
   g.f("        const double beta = den2 > 0.0 ? num2 / den2 : 0.0;  // old increment over the one before");
-  g.f("        const bool line = hist >= 3 && alpha > 0.0 && beta >= 0.5 && beta <= 2.0 && num * num >= 0.98 * nn * den && num2 * num2 >= 0.98 * den * den2;");
+  g.f("        const bool line = hist >= 3 && alpha > 0.0 && beta >= 1e-3 && beta <= 2.0 && num * num >= 0.98 * nn * den && num2 * num2 >= 0.98 * den * den2;");
   g.f("        const double bq = line ? 1.0 / beta : 1.0;  // spacings in units of the old increment: new = alpha, old = 1, older = bq");
   g.f("        const double l0 = line ? (alpha + 1.0) * (alpha + 1.0 + bq) / (1.0 + bq) : 1.0 + alpha;");
   g.f("        const double l1 = line ? -alpha * (alpha + 1.0 + bq) / bq : -alpha;");
@@ -1622,9 +1638,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int t = 0; t < T; ++t) g.f("    tr%d = tq%d; tq%d = tp%d; tp%d = tv%d;", t, t, t, t, t, t);
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
   for (int F = 0; F < nf; ++F) g.f("      x%d = ld3(gp + %s + cc, c);", F, ev.point3(ev.fp(F)).c_str());
-  g.f("      hist = 0; lambda_carry = 0.0; cold = true;");
+  g.f("      hist = 1; steps_done = 0; lambda_carry = 0.0; cold = true;");
+  for (int t = 0; t < T; ++t) g.f("      tp%d = td%d;", t, t);
   g.f("    } else {");
   g.f("      if (hist < 3) ++hist;");
+  g.f("      ++steps_done;");
   g.f("      cold = false;");
   g.f("      lambda_carry = lambda;");
   g.f("    }");
