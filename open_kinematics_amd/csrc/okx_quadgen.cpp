@@ -1123,6 +1123,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   Gen g(P, pv);
   const int nf = P.n_free, NP = P.n_points, T = P.n_targets;
+  const bool lds_state = !pv && getenv("OKX_QUAD_LDS_STATE") != nullptr;  // experiment: cold per-pass state of the single-mode kernel in LDS
   const int PPW = pv ? 8 : 16;                                  // problems per wavefront
   const int prog_points = pv ? pv->n_prog_points : NP;          // strides of the caller's tables
   const int prog_crows = pv ? pv->n_prog_crows : P.n_crows;
@@ -1240,9 +1241,18 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       "  __shared__ double hql[" + std::to_string(64 * (ev.n_lane_slots + 1)) + "];  // chain-constant lane components [slot][lane]\n";
   if (ev.lds_constants) {
     g.out += lds_decl;
-    g.f("  __shared__ double xsl[%d];  // accepted point and chain history [block][lane]", 64 * 3 * nf);
+    g.f("  __shared__ double xsl[%d];  // accepted point, chain history and the step in hand [block][lane]", 64 * 4 * nf);
+    int n_fixed = 0;
+    for (int p = 0; p < NP; ++p) n_fixed += ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
+    g.f("  __shared__ double psl[%d];  // fixed points [point][lane]", 64 * (n_fixed > 0 ? n_fixed : 1));
   } else {
     g.f("  __shared__ double xql[%d];  // third chain-history point [block][lane] (registers are full)", 64 * nf);
+    if (lds_state) {
+      int n_fixed = 0;
+      for (int p = 0; p < NP; ++p) n_fixed += ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
+      g.f("  __shared__ double psl[%d];  // fixed points [point][lane]", 64 * (n_fixed > 0 ? n_fixed : 1));
+      g.f("  __shared__ double dxl[%d];  // the step in hand [block][lane]", 64 * nf);
+    }
   }
   g.f("  const long long spg = a.steps_per_geometry;");
   g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
@@ -1271,16 +1281,35 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    // chain-constant lane-component parameters (line points / directions, target directions)");
   g.out += ev.hoisted;
   g.out += couple_hoist;
-  // point registers
-  for (int p = 0; p < NP; ++p)
-    if (used[p]) g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
+  // point registers; in the register-bound pair kernel the fixed points (read once or twice per pass, never
+  // written) live in LDS instead: the compiler would otherwise park them in scratch
+  {
+    int slot = 0;
+    for (int p = 0; p < NP; ++p) {
+      if (!used[p]) continue;
+      const bool fixed = ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
+      if ((ev.lds_constants || lds_state) && fixed && getenv("OKX_PAIR_FIXED_REGS") == nullptr)
+        g.f("    double& p%d = psl[%d + lane]; p%d = ld3(gp + %s + cc, c);", p, 64 * slot++, p, ev.point3(p).c_str());
+      else
+        g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
+    }
+  }
   for (int F = 0; F < nf; ++F) {
     if (ev.lds_constants) {  // cold per-pass state lives in LDS (register-bound kernel): plain references, same code below
       g.f("    double& x%d = xsl[%d + lane]; double& xp%d = xsl[%d + lane]; double& xq%d = xsl[%d + lane];", F, 64 * (2 * F), F,
           64 * (2 * F + 1), F, 64 * (2 * nf + F));
-      g.f("    x%d = p%d; xp%d = x%d; xq%d = x%d; double dx%d = 0.0;", F, ev.fp(F), F, F, F, F, F);
+      if (getenv("OKX_PAIR_DX_REGS") == nullptr) {
+        g.f("    double& dx%d = xsl[%d + lane];", F, 64 * (3 * nf + F));
+        g.f("    x%d = p%d; xp%d = x%d; xq%d = x%d; dx%d = 0.0;", F, ev.fp(F), F, F, F, F, F);
+      } else {
+        g.f("    x%d = p%d; xp%d = x%d; xq%d = x%d; double dx%d = 0.0;", F, ev.fp(F), F, F, F, F, F);
+      }
     } else {
-      g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0; double& xq%d = xql[%d + lane]; xq%d = x%d;", F, ev.fp(F), F, F, F, F, 64 * F, F, F);
+      if (lds_state)
+        g.f("    double x%d = p%d, xp%d = x%d; double& dx%d = dxl[%d + lane]; dx%d = 0.0; double& xq%d = xql[%d + lane]; xq%d = x%d;", F,
+            ev.fp(F), F, F, F, 64 * F, F, F, 64 * F, F, F);
+      else
+        g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0; double& xq%d = xql[%d + lane]; xq%d = x%d;", F, ev.fp(F), F, F, F, F, 64 * F, F, F);
     }
   }
   // The design state is a solved state too (of its own design targets): it seeds the chain's history, so the
@@ -1349,6 +1378,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       g.f("          const double* pq = pp + %d;", 3 * TT + 2);
       for (int t = 0; t < TT; ++t) {  // one loop level per target: pc = T_i(u), pn = T_{i+1}(u)
         g.f("          { double pc%d = 1.0, pn%d = pu%d;", t, t, t);
+        if (t == TT - 1) {  // innermost level: a simple trip count, so that four terms' loads are in flight together
+          g.f("          const int pe%d = pD%d < %s ? pD%d : %s;", t, t, up(t, "pr").c_str(), t, up(t, "pr").c_str());
+          g.f("          _Pragma(\"unroll 4\")");
+          g.f("          for (int pi%d = 0; pi%d <= pe%d; ++pi%d) {", t, t, t, t);
+        } else
         g.f("          for (int pi%d = 0; pi%d <= pD%d && pi%d <= %s; ++pi%d) {", t, t, t, t, up(t, "pr").c_str(), t);
         g.f("            const double pw%d = %s * pc%d; const int pr%d = %s - pi%d;", t, up(t, "pw").c_str(), t, t, up(t, "pr").c_str(), t);
       }
