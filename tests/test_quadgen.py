@@ -31,6 +31,9 @@ def test_source_is_generated_for_corner_topologies(golden, name, mode):
     src = _source(p)
     for kernel in ("okx_quad_solve_u", "okx_quad_solve_g", "okx_quad_eval"):
         assert f"void __launch_bounds__(64, 1) {kernel}(" in src
+    assert "void __launch_bounds__(64) okx_quad_expand(" in src  # positions from free coordinates
+    if p.n_targets:
+        assert "okx_quad_tangent_u(" in src and "a.predictor" in src  # tangents; chain-head model
     # one residual per row, one J^T J accumulator per diagonal block entry
     for i in range(p.n_residuals):
         assert f"const double r{i} =" in src
@@ -66,11 +69,13 @@ def test_axle_is_generated_in_pair_mode(golden):
     _, program = golden("c3_axle_grid")
     src = _source(program.with_line_mode("pinned"))
     assert "quad = lane >> 3, q1 = (lane >> 2) & 1" in src          # 8 problems per wavefront
-    assert "__builtin_amdgcn_ds_swizzle" in src and "sm_k" in src   # cross-quad exchange, Sherman-Morrison
+    assert "__builtin_amdgcn_ds_swizzle" in src and "sm_k" in src   # cross-quad exchange, 2 x 2 Woodbury for the rack row
     for f in range(10):
         assert f"double A{f}_{f}_0" in src                           # ten free points per half
     assert "double A10_10_0" not in src
-    assert "okx_quad_eval" not in src                                # parity / tangent kernels: interpreter serves those
+    assert "okx_quad_eval" not in src and "okx_quad_expand" not in src  # parity / expand kernels: interpreter serves those
+    assert "okx_quad_tangent_u(" in src and "sm_det" in src          # tangents are generated (regularised halves)
+    assert "psl[" in src and "a.predictor[" not in src               # fixed points in LDS; no chain-head model in pair mode
 
 
 def test_precompile_fills_the_cache_without_a_device(golden, tmp_path, monkeypatch):
