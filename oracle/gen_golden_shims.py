@@ -81,9 +81,38 @@ def emit(case: str, geometry_file: str, setups: list[float]) -> None:
           {n: round(float(m), 3) for n, m in zip(names, moved) if m > 1e-9}, "residual norms", np.round(resid, 12))
 
 
+def emit_axle(case: str, geometry_file: str, setups: list[float]) -> None:
+    """Axle: the shim is authored on the left setup; the right corner gets the mirrored shim (build.py:310-318,357-375)."""
+    from kinematics.core.primitives.point_ref import PointRef
+
+    with open(os.path.join(REF_DATA, geometry_file), encoding="utf-8") as fh:
+        geometry = yaml.safe_load(fh)
+    geometry["axle_config"]["left_setup"] = {"camber_shim": {**SHIM, "setup_thickness": SHIM["design_thickness"]}}
+    design = build_suspension(copy.deepcopy(geometry)).initial_state()
+    keys = list(design.positions)
+    names = [f"{k.side.name.lower()}_{k.point.name.lower()}" if isinstance(k, PointRef) else k.name.lower() for k in keys]
+    positions = []
+    for t in setups:
+        g = copy.deepcopy(geometry)
+        g["axle_config"]["left_setup"]["camber_shim"]["setup_thickness"] = float(t)
+        st = build_suspension(g).initial_state()
+        positions.append([st.positions[k].data for k in keys])
+    authored = np.asarray([design.positions[k].data for k in keys])
+    np.savez_compressed(os.path.join(OUT, f"shims_{case}.npz"), geometry_yaml=yaml.safe_dump(geometry, sort_keys=False),
+                        names=np.array(names), authored=authored, setup=np.asarray(setups, dtype=np.float64),
+                        positions=np.asarray(positions))
+    moved = np.max(np.abs(np.asarray(positions) - authored[None]), axis=(0, 2))
+    print(f"shims_{case}: {len(setups)} thicknesses, {len(names)} points; moved:",
+          {n: round(float(m), 3) for n, m in zip(names, moved) if m > 1e-9})
+
+
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "axle":
+        emit_axle("axle_rocker", "axle_geometry_rocker.yaml", [26.0, 30.0, 38.0])
+        return
     emit("dw", "geometry.yaml", [20.0, 25.0, 29.0, 30.0, 31.0, 35.0, 40.0, 45.0])
     emit("dw_rocker", "corner_strut_rocker_geometry.yaml", [22.0, 30.0, 36.0, 40.0])
+    emit_axle("axle_rocker", "axle_geometry_rocker.yaml", [26.0, 30.0, 38.0])
 
 
 if __name__ == "__main__":

@@ -188,3 +188,26 @@ def test_bad_shim_roles_are_rejected():
         camber_shim_setup(ShimRoles(0, 1, 2, 3, 4, 5, 0), pts, shim[:, :5])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         camber_shim_setup(ShimRoles(0, 1, 2, 3, 4, 5, 0), pts.cpu(), shim.cpu())
+
+
+@pytest.mark.parametrize("setup", [26.0, 38.0])
+def test_axle_with_a_left_setup_shim_mirrors_it_to_the_right(setup):
+    """Axle geometry with `left_setup.camber_shim`: both corners' setup poses (right = mirrored shim, rocker group incl.
+    the ARB drop-link pickup) as the reference's AxleSuspension.initial_state()."""
+    from open_kinematics_amd.input import build_suspension
+    from open_kinematics_amd.results_writer import point_key_name
+
+    g = load_shim_golden("axle_rocker")
+    geometry = yaml.safe_load(str(g["geometry_yaml"]))
+    geometry["axle_config"]["left_setup"]["camber_shim"]["setup_thickness"] = float(setup)
+    axle = build_suspension(geometry)
+    state = axle.initial_state()
+    names = [point_key_name(k) for k in state.positions]
+    assert sorted(names) == sorted(g["names"])
+    k = int(np.flatnonzero(np.abs(g["setup"] - setup) < 1e-9)[0])
+    got = np.asarray([state.positions[key].data for key in state.positions])
+    want = np.asarray([g["positions"][k][g["names"].index(n)] for n in names])
+    assert np.max(np.abs(got - want)) <= 1e-9
+    moved = {n for n, a, b in zip(names, got, np.asarray([g["authored"][g["names"].index(n)] for n in names])) if np.max(np.abs(a - b)) > 1e-9}
+    assert {"left_droplink_rocker", "right_droplink_rocker", "left_pushrod_inboard", "right_upper_wishbone_outboard"} <= moved
+    assert "left_droplink_u_bar" not in moved and "left_lower_wishbone_outboard" not in moved
