@@ -54,3 +54,197 @@ def target_rows(suspension, specs, line_mode: str = "pinned") -> tuple[Constrain
                               suspension.output_points(), line_mode="softnorm").with_line_mode(line_mode)
     base = np.array([float(np.dot(program.design_pos[p], d)) for p, d in zip(program.tgt_point, program.tgt_dir)])
     return program, base
+
+
+# --------------------------------------------------------------------------------------
+# metrics of a solved sweep (reference core/sweep.py:78-173, metrics/main.py:63-185)
+# --------------------------------------------------------------------------------------
+
+
+class SweepMetricsResult:
+    """``core/sweep.py:78-87``: metric rows plus the derivative-computation status."""
+
+    def __init__(self, rows, derivative_error=None, tangent_solve_infos=None):
+        self.rows = rows
+        self.derivative_error = derivative_error
+        self.tangent_solve_infos = tangent_solve_infos
+
+
+class AxleMetricRows:
+    """``metrics/main.py:38-49``: axle-scope row plus one row per corner."""
+
+    def __init__(self, axle, corners):
+        self.axle = axle
+        self.corners = corners
+
+    def flat_row(self):
+        """``metrics/main.py:52-62``: corner keys get a ``_left`` / ``_right`` suffix, axle keys follow."""
+        from collections import OrderedDict
+
+        flat = OrderedDict()
+        for side, row in self.corners.items():
+            for key, value in row.items():
+                flat[f"{key}_{side.name.lower()}"] = value
+        flat.update(self.axle)
+        return flat
+
+
+# (response, driver) of the derivative columns every corner declares (metrics/catalog.py:160-308), in the reference's order
+_CORNER_DERIVATIVES = (
+    ("camber", "hub_z"), ("roadwheel_angle", "hub_z"), ("caster", "hub_z"), ("kpi", "hub_z"), ("half_track", "hub_z"),
+    ("wheel_center_x", "hub_z"), ("roadwheel_angle", "rack_displacement"), ("camber", "rack_displacement"),
+)
+
+
+def _none_if_nan(value: float):
+    return None if value != value else float(value)
+
+
+def _driver_ratio(response_rate, tangents, driver_idx: int, axis: int, candidates):
+    """
+    ``DerivativeMetricDefinition.select_tangent`` + ``evaluate`` (``metrics/derivatives.py:265-320``) for a whole
+    batch: along the candidate target whose tangent moves the driver coordinate most, response rate / driver rate.
+    ``response_rate [B, T]``, ``tangents [B, T, n_out, 3]`` -> ``[B]`` (NaN where no candidate drives it).
+    """
+    import torch
+
+    b = response_rate.shape[0]
+    if not candidates:
+        return torch.full((b,), float("nan"), dtype=torch.float64, device=response_rate.device)
+    cand = torch.as_tensor(candidates, device=response_rate.device)
+    rates = tangents[:, cand, driver_idx, axis]                       # [B, C]
+    pick = rates.abs().argmax(dim=1, keepdim=True)                    # strongest driver rate
+    rate = rates.gather(1, pick).squeeze(1)
+    resp = response_rate[:, cand].gather(1, pick).squeeze(1)
+    out = resp / rate
+    return torch.where(rate.abs() >= 1e-6, out, torch.full_like(out, float("nan")))
+
+
+def _corner_rows(corner, program, positions, tangents, side=None, rotation=None, actuators=()):
+    """Catalog + topology + derivative columns of one corner for every state -> list of OrderedDict."""
+    from collections import OrderedDict
+
+    from .enums import PointID, PointRef
+    from .metrics import CATALOG_ORDER, METRIC_NAMES, corner_roles, corner_state_metrics
+
+    roles = corner_roles(corner, program, side)
+    res = corner_state_metrics(roles, positions, tangents)
+    values = res.values.cpu().numpy()
+    key = (lambda p: PointRef(side, p)) if side is not None else (lambda p: p)
+    out_keys = [program.point_keys[k] for k in program.out_point]
+    columns: "OrderedDict[str, Any]" = OrderedDict((n, values[:, METRIC_NAMES.index(n)]) for n in CATALOG_ORDER)
+    rot_names, rot_values, rot_derivs = rotation if rotation is not None else ([], None, None)
+    for k, name in enumerate(rot_names):
+        columns[name] = rot_values[:, k].cpu().numpy()
+    if tangents is not None:
+        wc = out_keys.index(key(PointID.WHEEL_CENTER))
+        tgt_keys = [program.point_keys[p] for p in program.tgt_point]
+        hub = [t for t, k in enumerate(tgt_keys) if k == key(PointID.WHEEL_CENTER)]
+        rack_point = corner.rack_attachment_point()
+        rack_idx = out_keys.index(key(rack_point)) if rack_point is not None else -1
+        # a shared actuator (the axle's rack) drives both corners: its targets count for either side
+        # (metrics/main.py:103-148 _corner_tangents / _local_tangent_target)
+        rack_keys = {key(rack_point)} if rack_point is not None else set()
+        for actuator in actuators:
+            if rack_keys & set(actuator.point_keys):
+                rack_keys |= set(actuator.point_keys)
+        rack = [t for t, k in enumerate(tgt_keys) if k in rack_keys]
+        drivers = {"hub_z": (wc, 2, hub), "rack_displacement": (rack_idx, 1, rack)}
+
+        def add(response: str, driver: str, rate):
+            idx, axis, cand = drivers[driver]
+            columns[f"deriv_{response}_wrt_{driver}"] = _driver_ratio(rate, tangents, idx, axis, cand).cpu().numpy()
+
+        for response, driver in _CORNER_DERIVATIVES:
+            if driver == "rack_displacement" and rack_point is None:
+                continue  # catalog.py: rack-driven derivatives are omitted without a steering rack
+            rate = tangents[:, :, wc, 0] if response == "wheel_center_x" else res.derivatives[:, :, METRIC_NAMES.index(response)]
+            add(response, driver, rate)
+        # topology declarations (corner/double_wishbone.py, macpherson.py:224-245): actuation first, then the spring
+        for k, name in enumerate(rot_names):
+            if name == "rocker_angle":
+                add(name, "hub_z", rot_derivs[:, :, k])
+        if corner.damper_points() is not None:
+            add("damper_length", "hub_z", res.derivatives[:, :, METRIC_NAMES.index("damper_length")])
+        for k, name in enumerate(rot_names):
+            if name != "rocker_angle":
+                add(name, "hub_z", rot_derivs[:, :, k])
+    n = values.shape[0]
+    return [OrderedDict((name, _none_if_nan(col[s])) for name, col in columns.items()) for s in range(n)]
+
+
+def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> SweepMetricsResult:
+    """
+    Drop-in for ``kinematics.core.sweep.compute_sweep_metrics`` (``core/sweep.py:144-173``): every state's metric
+    row — the corner catalog, the topology's extras, the derivative columns — computed on the device from the solved
+    states (tangents -> metrics in HBM; the rows are built on the host at the end).  Corner suspensions give one
+    ``OrderedDict`` per state, axles an ``AxleMetricRows`` (axle row + one row per side, ``flat_row()``).
+    """
+    from collections import OrderedDict
+
+    import torch
+
+    from .batch import DeviceProgram
+    from .enums import Side
+    from .metrics import AXLE_METRIC_NAMES, axis_rotation_metrics, axle_roles, axle_state_metrics, topology_rotation_roles
+    from .sensitivity import _positions_array
+
+    program, _ = sweep_program(suspension, sweep_config)
+    dp = DeviceProgram(program, device)
+    derivative_error = None
+    try:
+        out_keys = [program.point_keys[k] for k in program.out_point]
+        positions = torch.as_tensor(_positions_array(states, out_keys), device=dp.device)
+        tangents = None
+        if program.n_targets > 0:
+            try:
+                tangents, _ = dp.tangents(positions)
+            except Exception as error:  # noqa: BLE001 - metrics degrade without derivatives (core/sweep.py:155-160)
+                derivative_error = f"{type(error).__name__}: {error}"
+        is_axle = hasattr(suspension, "corners")
+        names, roles = topology_rotation_roles(suspension, program)
+        rot_values = rot_derivs = None
+        if names:
+            rot_values, rot_derivs = axis_rotation_metrics(roles, positions, tangents)
+        if not is_axle:
+            rows = _corner_rows(suspension, program, positions, tangents, None, (names, rot_values, rot_derivs))
+            return SweepMetricsResult(rows, derivative_error)
+        per_side = {}
+        for side in (Side.LEFT, Side.RIGHT):
+            tag = side.name.lower()
+            mine = [k for k, n in enumerate(names) if n.endswith("_" + tag) and not n.startswith("arb_arm_angle")]
+            sub = ([names[k][: -len(tag) - 1] for k in mine],
+                   None if rot_values is None else rot_values[:, mine],
+                   None if rot_derivs is None else rot_derivs[:, :, mine])
+            per_side[side] = _corner_rows(suspension.corners[side], program, positions, tangents, side, sub,
+                                          suspension.actuator_dofs())
+        left, right = axle_roles(suspension, program)
+        axle_values = axle_state_metrics(left, right, positions).cpu().numpy()
+        arm = {side: names.index(f"arb_arm_angle_{side.name.lower()}") for side in (Side.LEFT, Side.RIGHT)} \
+            if "arb_arm_angle_left" in names else None
+        tgt_keys = [program.point_keys[p] for p in program.tgt_point]
+        rows = []
+        for s in range(len(states)):
+            axle_row = OrderedDict((n, _none_if_nan(axle_values[s, k])) for k, n in enumerate(AXLE_METRIC_NAMES))
+            rows.append(AxleMetricRows(axle_row, {side: per_side[side][s] for side in (Side.LEFT, Side.RIGHT)}))
+        if arm is not None:
+            twist = (rot_values[:, arm[Side.LEFT]] - rot_values[:, arm[Side.RIGHT]]).cpu().numpy()
+            arm_values = {side: rot_values[:, arm[side]].cpu().numpy() for side in arm}
+            d_twist = {}
+            if tangents is not None:
+                from .enums import PointID, PointRef
+
+                rate = rot_derivs[:, :, arm[Side.LEFT]] - rot_derivs[:, :, arm[Side.RIGHT]]
+                for side in (Side.LEFT, Side.RIGHT):
+                    key = PointRef(side, PointID.WHEEL_CENTER)
+                    cand = [t for t, k in enumerate(tgt_keys) if k == key]
+                    d_twist[side] = _driver_ratio(rate, tangents, out_keys.index(key), 2, cand).cpu().numpy()
+            for s, row in enumerate(rows):
+                row.axle["arb_twist"] = _none_if_nan(twist[s])
+                for side, col in d_twist.items():
+                    row.axle[f"deriv_arb_twist_wrt_hub_z_{side.name.lower()}"] = _none_if_nan(col[s])
+                for side in arm:
+                    row.corners[side]["arb_arm_angle"] = _none_if_nan(arm_values[side][s])
+        return SweepMetricsResult(rows, derivative_error)
+    finally:
+        dp.close()

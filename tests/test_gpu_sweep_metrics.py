@@ -1,0 +1,99 @@
+"""GPU: compute_sweep_metrics drop-in (core/sweep.py:144-173) — row keys, order and values against the reference."""
+
+import numpy as np
+import pytest
+import yaml
+
+from conftest import gpu_available
+from test_metrics_oracle import load_metrics_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not gpu_available():
+        pytest.skip("no GPU")
+
+
+def _states(suspension, golden_pos, out_points):
+    """SuspensionState objects holding the golden's output positions (what solve_sweep returned in the reference)."""
+    from open_kinematics_amd.state import Point3, SuspensionState
+
+    base = suspension.initial_state()
+    states = []
+    for row in golden_pos:
+        positions = {k: v.copy() for k, v in base.positions.items()}
+        for key, xyz in zip(out_points, row):
+            positions[key] = Point3(xyz)
+        states.append(SuspensionState(positions, set(base.free_points)))
+    return states
+
+
+def _close(got, ref, tol):
+    if got is None or ref != ref:
+        return got is None and ref != ref
+    return abs(got - ref) <= tol * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid"])
+def test_corner_rows_match_the_reference(golden, name):
+    from open_kinematics_amd.input import build_suspension, build_sweep
+    from open_kinematics_amd.metrics import CATALOG_ORDER, METRIC_NAMES
+    from open_kinematics_amd.sweep import compute_sweep_metrics
+
+    arrays, _ = golden(name)
+    mg = load_metrics_golden(name)
+    sus = build_suspension(yaml.safe_load(str(arrays["geometry_yaml"])))
+    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)
+    pick = range(0, mg["pos"].shape[0], max(1, mg["pos"].shape[0] // 20))
+    states = _states(sus, mg["pos"][list(pick)], sus.output_points())
+    result = compute_sweep_metrics(sus, sweep, states)  # the metrics depend on the states and target directions only
+    assert result.derivative_error is None and len(result.rows) == len(states)
+    keys = list(result.rows[0])
+    assert keys[: len(CATALOG_ORDER)] == list(CATALOG_ORDER)                          # catalog.py:71-146
+    assert [k for k in keys if k.startswith("deriv_")] == [str(n) for n in mg["deriv_names"]]  # same columns, same order
+    for row, s in zip(result.rows, pick):
+        for n in CATALOG_ORDER:
+            assert _close(row[n], mg["values"][s][METRIC_NAMES.index(n)], 1e-9), (s, n)
+        for j, col in enumerate(str(n) for n in mg["deriv_names"]):
+            assert _close(row[col], mg["deriv"][s][j], 1e-7), (s, col)
+
+
+def test_axle_rows_match_the_reference(golden):
+    from open_kinematics_amd.enums import Side
+    from open_kinematics_amd.input import build_suspension, build_sweep
+    from open_kinematics_amd.metrics import AXLE_METRIC_NAMES, CATALOG_ORDER, METRIC_NAMES
+    from open_kinematics_amd.sweep import compute_sweep_metrics
+
+    arrays, _ = golden("c3_axle_grid")
+    mg = load_metrics_golden("axle_c3")
+    axle = build_suspension(yaml.safe_load(str(arrays["geometry_yaml"])))
+    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), axle)
+    pick = list(range(0, mg["pos"].shape[0], 4))
+    states = _states(axle, mg["pos"][pick], axle.output_points())
+    result = compute_sweep_metrics(axle, sweep, states)
+    assert result.derivative_error is None
+    first = result.rows[0]
+    assert list(first.axle) == list(AXLE_METRIC_NAMES) + [str(n) for n in mg["axle_extra_names"]] + [str(n) for n in mg["axle_deriv_names"]]
+    for tag, side in (("left", Side.LEFT), ("right", Side.RIGHT)):
+        extras = [str(n) for n in mg[f"{tag}_extra_names"]]
+        derivs = [str(n) for n in mg[f"{tag}_deriv_names"]]
+        # reference order: catalog, actuation / spring values, derivative columns, then the axle hardware's arm angle
+        assert list(first.corners[side]) == list(CATALOG_ORDER) + extras[:-1] + derivs + extras[-1:]
+    for row, s in zip(result.rows, pick):
+        for k, n in enumerate(AXLE_METRIC_NAMES):
+            assert _close(row.axle[n], mg["axle_values"][s][k], 1e-9), (s, n)
+        assert _close(row.axle["arb_twist"], mg["axle_extra_values"][s][0], 1e-9)
+        for j, col in enumerate(str(n) for n in mg["axle_deriv_names"]):
+            assert _close(row.axle[col], mg["axle_deriv"][s][j], 1e-7), (s, col)
+        for tag, side in (("left", Side.LEFT), ("right", Side.RIGHT)):
+            corner = row.corners[side]
+            for n in CATALOG_ORDER:
+                assert _close(corner[n], mg[f"{tag}_values"][s][METRIC_NAMES.index(n)], 1e-9), (s, tag, n)
+            for j, n in enumerate(str(x) for x in mg[f"{tag}_extra_names"]):
+                assert _close(corner[n], mg[f"{tag}_extra_values"][s][j], 1e-9), (s, tag, n)
+            for j, n in enumerate(str(x) for x in mg[f"{tag}_deriv_names"]):
+                assert _close(corner[n], mg[f"{tag}_deriv"][s][j], 1e-7), (s, tag, n)
+    flat = first.flat_row()
+    assert "camber_left" in flat and "arb_twist" in flat and list(flat)[-1] == str(mg["axle_deriv_names"][-1])
