@@ -230,3 +230,37 @@ def frames_from_batch(program, positions, info, metrics: Mapping[str, Any] | Non
             metrics=row_metrics, metric_units=units,
         ))
     return frames
+
+
+def metric_unit(column: str) -> str | None:
+    """
+    Unit symbol of a metric column: the catalog's units, and for a derivative column
+    ``deriv_<response>_wrt_<driver>`` the quotient ``<response unit>/<driver unit>`` (``metrics/units.py:27-42``;
+    both drivers the reference declares — ``hub_z[_side]``, ``rack_displacement`` — are millimetres).
+    """
+    if column in METRIC_UNITS:
+        return METRIC_UNITS[column]
+    if column.startswith("deriv_") and "_wrt_" in column:
+        response = column[len("deriv_"):].split("_wrt_")[0]
+        unit = METRIC_UNITS.get(response, "mm" if response.endswith(("_x", "_y", "_z")) else None)
+        return None if unit is None else f"{unit}/mm"
+    for suffix in ("_left", "_right"):
+        if column.endswith(suffix):
+            return metric_unit(column[: -len(suffix)])
+    return None
+
+
+def frames_from_states(states, solver_infos, metric_rows, output_points) -> list[SolutionFrame]:
+    """
+    Frames of a solved sweep in the reference's object form (``cli`` path: ``solve_sweep`` ->
+    ``compute_sweep_metrics`` -> writer): ``states`` / ``solver_infos`` as returned by ``solve_sweep``,
+    ``metric_rows`` the rows of ``compute_sweep_metrics`` (``OrderedDict`` or ``AxleMetricRows``).
+    """
+    frames = []
+    for state, info, row in zip(states, solver_infos, metric_rows):
+        flat = row.flat_row() if hasattr(row, "flat_row") else row
+        frames.append(SolutionFrame(
+            positions=flatten_positions(state.positions, output_points), solver_info=info, metrics=dict(flat),
+            metric_units={name: unit for name in flat if (unit := metric_unit(name)) is not None},
+        ))
+    return frames
