@@ -54,6 +54,8 @@ def _as_f64(t, device) -> torch.Tensor:
 class DeviceProgram:
     """A constraint program resident on one GPU."""
 
+    AUTO_PREDICTOR_MIN_BATCH = 256  # predictor=None fits the chain-head model at the first launch of at least this size
+
     def __init__(self, program: ConstraintProgram, device: torch.device | str | None = None):
         if not torch.cuda.is_available():
             raise RuntimeError(
@@ -150,8 +152,11 @@ class DeviceProgram:
         if residual_tolerance is not None:
             opts.residual_tolerance = float(residual_tolerance)
         if predictor is not False and geom_pos is None and opts.kernel in (0, 3):
-            # fitted once, over the box of the first launch's targets (later launches clamp to it; refit with fit_predictor)
-            if self.fit_predictor(targets if self._predictor is None else None, required=bool(predictor)):
+            # Fitted once, over the target box of the first sizeable launch (later launches clamp to it; refit with
+            # fit_predictor).  Automatic mode leaves small batches alone: the fit costs more than it would save, and a
+            # box fitted to a handful of problems says nothing about the sweeps that follow.
+            fit_now = self._predictor is None and (predictor is not None or b >= self.AUTO_PREDICTOR_MIN_BATCH)
+            if self.fit_predictor(targets if fit_now else None, required=bool(predictor)):
                 opts.predictor = 2 if predictor == "all" else 1
         if geom_pos is not None:
             geom_pos = _as_f64(geom_pos, self.device)
