@@ -1230,7 +1230,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("");
   g.f("template <bool PG> DEV void okx_quad_body(const QArgs& a) {");
   if (pv)
-    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1 = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
+    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1_lane = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
   else
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
@@ -1260,6 +1260,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("  const long long chains_per_span = unit_len == 1 ? span : (span + unit_len - 1) / unit_len;");
   g.f("  const long long n_units = spg > 0 ? (a.n_problems / span) * chains_per_span : chains_per_span;");
   g.f("  for (long long wu = blockIdx.x; wu * %d < n_units; wu += gridDim.x) {", PPW);
+  if (pv) {
+    // the side bit as a value the optimiser cannot see through: every per-side table index is then computed where it
+    // is used (one v_cndmask) instead of being hoisted to the kernel's top, kept live and spilled
+    g.f("    int q1 = q1_lane; asm volatile(\"\" : \"+v\"(q1));");
+  }
   g.f("    long long unit = wu * %d + quad;", PPW);
   g.f("    const bool have = unit < n_units;");
   g.f("    if (!have) unit = n_units - 1;");
