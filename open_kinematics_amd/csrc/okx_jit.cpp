@@ -99,6 +99,21 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err, b
   (void)hiprtcVersion(&major, &minor);
   unsigned long long h = fnv1a(src);
   for (int k = 0; k < kNumOptions; ++k) h = fnv1a(kOptions[k], h);
+  // OKX_KERNEL_EXTRA_OPTS: extra compiler options (space separated) for A/B experiments; part of the cache key
+  std::vector<std::string> extra;
+  if (const char* env = getenv("OKX_KERNEL_EXTRA_OPTS")) {
+    std::string word;
+    for (const char* ch = env;; ++ch) {
+      if (*ch == ' ' || *ch == '\0') {
+        if (!word.empty()) extra.push_back(word);
+        word.clear();
+        if (*ch == '\0') break;
+      } else {
+        word += *ch;
+      }
+    }
+  }
+  for (const std::string& o : extra) h = fnv1a(o, h);
   h = fnv1a(std::to_string(major) + "." + std::to_string(minor), h);
   char name[64];
   std::snprintf(name, sizeof(name), "/okxq_%016llx", h);
@@ -116,7 +131,9 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err, b
     *err = std::string("hiprtcCreateProgram: ") + hiprtcGetErrorString(rc);
     return false;
   }
-  rc = hiprtcCompileProgram(prog, kNumOptions, kOptions);
+  std::vector<const char*> options(kOptions, kOptions + kNumOptions);
+  for (const std::string& o : extra) options.push_back(o.c_str());
+  rc = hiprtcCompileProgram(prog, (int)options.size(), options.data());
   if (rc != HIPRTC_SUCCESS) {
     size_t log_size = 0;
     (void)hiprtcGetProgramLogSize(prog, &log_size);
