@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OKX_ABI_VERSION 1
+#define OKX_ABI_VERSION 2   /* 2: okx_solve_opts.confirm_full_pass (was `reserved`); diagnostics moved to okx_debug.h */
 
 /* Hard limits of one problem (one wavefront owns one problem). */
 #define OKX_MAX_VARS 63      /* n = 3 * free points (one lane per variable)          */
@@ -149,7 +149,7 @@ typedef struct okx_solve_opts {
                              wavefront, 2 generic lane-group packed (several small problems per
                              wavefront; falls back to 1 when a problem needs more than 32
                              lanes), 3 quad kernel (OKX_ERR_INVALID when the program has none) */
-  int32_t reserved;       /* quad kernel only.  0 (default): a step predicted to land within
+  int32_t confirm_full_pass; /* quad kernel only.  0 (default): a step predicted to land within
                              step_tol of the solution (damping contraction lambda / min pivot and
                              the observed quadratic contraction, both with a 100x margin) is
                              applied and confirmed by a residual-only evaluation (cost must not

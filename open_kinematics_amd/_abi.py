@@ -8,7 +8,7 @@ import numpy as np
 
 from .program import ConstraintProgram
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -51,7 +51,7 @@ class SolveOpts(C.Structure):
         ("lambda0", C.c_double),
         ("residual_tolerance", C.c_double),
         ("kernel", C.c_int32),
-        ("reserved", C.c_int32),
+        ("confirm_full_pass", C.c_int32),
         ("predictor", C.c_int32),
         ("pad", C.c_int32),
     ]

@@ -13,7 +13,7 @@ import ctypes as C
 import os
 import subprocess
 
-from ._abi import Info, ProgramDesc, SolveOpts
+from ._abi import ABI_VERSION, Info, ProgramDesc, SolveOpts
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libokx.so")
@@ -40,6 +40,15 @@ EXPORTS = (
     "okx_expand_positions_batch",
     "okx_program_fit_predictor",
     "okx_program_has_predictor",
+)
+
+# include/okx_debug.h: test hooks and profiling aids, not part of the drop-in boundary
+DEBUG_EXPORTS = (
+    "okx_debug_normal_equations",
+    "okx_debug_quad_eval",
+    "okx_debug_quad_trace",
+    "okx_debug_phase_profile",
+    "okx_debug_plan_stats",
 )
 
 _lib = None
@@ -87,8 +96,12 @@ def load() -> C.CDLL:
     lib.okx_debug_normal_equations.restype = i32
     lib.okx_rebind_design.argtypes = [vp, i64, vp, vp, vp, vp]
     lib.okx_rebind_design.restype = i32
-    lib.okx_plan_stats.argtypes = [C.POINTER(ProgramDesc), C.POINTER(i32)]
-    lib.okx_plan_stats.restype = i32
+    lib.okx_debug_plan_stats.argtypes = [C.POINTER(ProgramDesc), C.POINTER(i32)]
+    lib.okx_debug_plan_stats.restype = i32
+    lib.okx_debug_quad_trace.argtypes = [vp, vp, i64]
+    lib.okx_debug_quad_trace.restype = i32
+    lib.okx_debug_phase_profile.argtypes = [vp, C.POINTER(SolveOpts), i64, vp, vp, vp, vp, vp]
+    lib.okx_debug_phase_profile.restype = i32
     lib.okx_program_kernel.argtypes = [vp]
     lib.okx_program_kernel.restype = C.c_char_p
     lib.okx_program_kernel_note.argtypes = [vp]
@@ -115,7 +128,7 @@ def load() -> C.CDLL:
     lib.okx_program_has_predictor.restype = i32
     lib.okx_debug_quad_eval.argtypes = [vp, i64, vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.okx_debug_quad_eval.restype = i32
-    if lib.okx_abi_version() != 1:
+    if lib.okx_abi_version() != ABI_VERSION:
         raise RuntimeError("libokx.so ABI version mismatch")
     _lib = lib
     return lib
@@ -141,4 +154,4 @@ def check(rc: int, what: str) -> None:
     raise RuntimeError(f"{what} failed ({rc}): {msg}")
 
 
-__all__ = ["load", "build", "check", "device_count", "last_error", "Info", "SolveOpts", "LIB_PATH", "EXPORTS"]
+__all__ = ["load", "build", "check", "device_count", "last_error", "Info", "SolveOpts", "LIB_PATH", "EXPORTS", "DEBUG_EXPORTS"]

@@ -118,6 +118,7 @@ class DeviceProgram:
         out: torch.Tensor | None = None,
         info_out: torch.Tensor | None = None,
         predictor: bool | str | None = None,
+        confirm_full_pass: bool | None = None,
     ) -> BatchResult:
         """
         Solve ``B`` problems; ``targets`` is ``[B, T]`` of absolute target scalars.
@@ -126,6 +127,8 @@ class DeviceProgram:
         the design state (own-geometry launches of the quad kernel).  ``None`` = use it when it can be
         fitted (once, over the target box of the first such launch), ``True`` = require it, ``False`` = plain
         cold starts, ``"all"`` = every chain step starts from the model (instead of the secant extrapolation).
+
+        ``confirm_full_pass``: always end a solve on a computed correction ``<= step_tol`` (``okx_solve_opts``).
 
         ``chain_len`` groups consecutive problems into warm-started chains walked by one
         wavefront each (``1`` independent cold starts, ``-1`` one chain per resident wavefront,
@@ -151,6 +154,8 @@ class DeviceProgram:
             opts.kernel = {"auto": 0, "single": 1, "packed": 2, "quad": 3}.get(kernel, kernel)
         if residual_tolerance is not None:
             opts.residual_tolerance = float(residual_tolerance)
+        if confirm_full_pass is not None:
+            opts.confirm_full_pass = 1 if confirm_full_pass else 0
         if predictor is not False and geom_pos is None and opts.kernel in (0, 3):
             # Fitted once, over the target box of the first sizeable launch (later launches clamp to it; refit with
             # fit_predictor).  Automatic mode leaves small batches alone: the fit costs more than it would save, and a

@@ -18,6 +18,7 @@
 #include "okx_metrics.hip"
 #include "okx_shim.hip"
 #include "okx_quad.hpp"
+#include "../../include/okx_debug.h"
 
 struct okx_program {
   okx::DevProgram host;        // host copy (dimensions, launch sizing)
@@ -47,13 +48,14 @@ struct okx_program {
   char quad_note[256];      // why the quad kernel is not in use (empty when it is)
   double* predictor_dev;    // chain-head model fitted by okx_program_fit_predictor, or null
   long long predictor_len;  // doubles in it
+  double* quad_trace;            // diagnostic hook, see okx_debug_quad_trace (null: off)
+  long long quad_trace_problem;
 };
 
 namespace {
 
 thread_local char g_err[512] = "";
-double* g_quad_trace = nullptr;          // diagnostic hook, see okx_debug_quad_trace
-long long g_quad_trace_problem = -1;
+constexpr int kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -264,7 +266,7 @@ void okx_default_opts(okx_solve_opts* o) {
   o->lambda0 = 1e-6;
   o->residual_tolerance = 1e-3;
   o->kernel = 0;
-  o->reserved = 0;
+  o->confirm_full_pass = 0;
   o->predictor = 0;
   o->pad = 0;
 }
@@ -293,8 +295,9 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   p->packed_lds_bytes = p->packed_fn ? sizeof(double) * (size_t)okx::packed_lds_doubles(p->host, p->groups) : 0;
   if (p->packed_lds_bytes > 160 * 1024) p->packed_fn = nullptr;
   if (p->lds_bytes > 160 * 1024) {
+    const size_t need = p->lds_bytes;
     delete p;
-    return fail(OKX_ERR_LIMIT, "problem needs %zu bytes of LDS (max 163840)", p->lds_bytes);
+    return fail(OKX_ERR_LIMIT, "problem needs %zu bytes of LDS (max 163840)", need);
   }
   hipError_t e = hipGetDevice(&p->device);
   if (e != hipSuccess) {
@@ -319,18 +322,21 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
     delete p;
     return fail(OKX_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(e));
   }
-  // >64 KiB of dynamic LDS needs the opt-in attribute
-  (void)hipFuncSetAttribute(p->solve_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->solve_lds_bytes);
-  (void)hipFuncSetAttribute((const void*)okx::okx_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)p->lds_bytes);
-  (void)hipFuncSetAttribute((const void*)okx::okx_rebind_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)p->lds_bytes);
-  p->blocks_per_cu = resident_blocks_per_cu(p->solve_fn, p->solve_lds_bytes);
-  p->packed_blocks_per_cu = 0;
-  if (p->packed_fn) {
-    (void)hipFuncSetAttribute(p->packed_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->packed_lds_bytes);
-    p->packed_blocks_per_cu = resident_blocks_per_cu(p->packed_fn, p->packed_lds_bytes);
+  // >64 KiB of dynamic LDS needs the opt-in attribute.  The kernels are shared by every program of the
+  // process, so the limit is raised to the hardware maximum once per kernel (a per-program size would let a
+  // later, smaller program lower it under an earlier one's feet).
+  for (const void* fn : {p->solve_fn, (const void*)okx::okx_eval_kernel, (const void*)okx::okx_rebind_kernel,
+                         p->packed_fn, p->tangent_fn}) {
+    if (!fn) continue;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+    if (e != hipSuccess) {
+      (void)hipFree(p->dev);
+      delete p;
+      return fail(OKX_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+    }
   }
+  p->blocks_per_cu = resident_blocks_per_cu(p->solve_fn, p->solve_lds_bytes);
+  p->packed_blocks_per_cu = p->packed_fn ? resident_blocks_per_cu(p->packed_fn, p->packed_lds_bytes) : 0;
   attach_quad_kernel(p);
   *out = p;
   return OKX_OK;
@@ -415,7 +421,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   // point-on-line valley: the step length says nothing about the distance there
   bool degenerate_line = false;
   for (int i = 0; i < p->host.n_crows; ++i) degenerate_line = degenerate_line || p->host.row_type[i] == OKX_ROW_POINT_ON_LINE;
-  a.confirm = (opts->reserved != 0 || degenerate_line || getenv("OKX_QUAD_CONFIRM") != nullptr) ? 1 : 0;
+  a.confirm = (opts->confirm_full_pass != 0 || degenerate_line || getenv("OKX_QUAD_CONFIRM") != nullptr) ? 1 : 0;
   // Kernel choice (profiles/r01/config_sweep_v3.txt).  The packed kernel keeps more problems in
   // flight per CU (G lane groups x resident waves): measured 1.5x on saturating batches of
   // n <= 15 systems (MacPherson grid), no gain for n = 18 (DW corner), so auto = packed only
@@ -480,8 +486,8 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
     q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
     q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
-    q.trace = g_quad_trace;
-    q.trace_problem = g_quad_trace_problem;
+    q.trace = p->quad_trace;
+    q.trace_problem = p->quad_trace_problem;
     q.predictor = (opts->predictor != 0 && !d_geom_pos) ? p->predictor_dev : nullptr;
     q.predictor_mode = opts->predictor;
     q.predictor_len = p->predictor_len;
@@ -574,7 +580,7 @@ int32_t okx_program_fit_predictor(okx_program* p, const double* lo, const double
     okx_default_opts(&o);
     o.chain_len = 1;
     o.kernel = 3;
-    o.reserved = 1;  // end on a computed correction: the fit wants every digit
+    o.confirm_full_pass = 1;  // end on a computed correction: the fit wants every digit
     hipStream_t st = (hipStream_t)stream;
     if (hipMemcpyAsync(d_t, targets.data(), targets.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
       rc = fail(OKX_ERR_DEVICE, "copy failed");
@@ -779,7 +785,6 @@ int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_
     }
     const size_t lds = p->lds_bytes + sizeof(double) * 3 * (size_t)p->host.n_points;
     if (lds > 160 * 1024) return fail(OKX_ERR_LIMIT, "tangent kernel needs %zu bytes of LDS", lds);
-    (void)hipFuncSetAttribute(p->tangent_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const okx::DevProgram* dev = p->dev;
     void* kargs[] = {(void*)&dev, (void*)&t};
     HIP_TRY(hipLaunchKernel(p->tangent_fn, dim3(grid_for(p, n_problems)), dim3(okx::kWave), kargs, lds,
@@ -942,12 +947,14 @@ int32_t okx_camber_shim_batch(const okx_shim_roles* roles, int64_t n_geometries,
   return OKX_OK;
 }
 
-/* Diagnostic: record the LM passes of ONE problem of subsequent quad-kernel solves into
-   d_trace [256][8] = (mode, trial cost, accepted cost, lambda, step, gain ratio, accepted, done);
+/* Diagnostic (okx_debug.h): record the LM passes of ONE problem of this program's subsequent quad-kernel
+   solves into d_trace [256][8] = (mode, trial cost, accepted cost, lambda, step, gain ratio, accepted, done);
    pass a null pointer to switch it off. */
-void okx_debug_quad_trace(double* d_trace, int64_t problem) {
-  g_quad_trace = d_trace;
-  g_quad_trace_problem = problem;
+int32_t okx_debug_quad_trace(okx_program* p, double* d_trace, int64_t problem) {
+  if (!p) return fail(OKX_ERR_INVALID, "null program");
+  p->quad_trace = d_trace;
+  p->quad_trace_problem = d_trace ? problem : -1;
+  return OKX_OK;
 }
 
 /* Test hook: what the quad kernel's straight-line code computes at given free vectors d_x [B][n]:
@@ -1012,22 +1019,21 @@ int32_t okx_debug_phase_profile(okx_program* p, const okx_solve_opts* opts, int6
     int width = p->group_width;
     void* kargs[] = {(void*)&dev, (void*)&a, (void*)&width};
     packed_kernel_t fn = okx::okx_solve_packed_kernel<18, 3, true>;
-    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)p->packed_lds_bytes);
+    HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
     HIP_TRY(hipLaunchKernel((const void*)fn, dim3(grid_for(p, (n_problems + 2) / 3)), dim3(okx::kWave),
                             kargs, p->packed_lds_bytes, (hipStream_t)stream));
     return OKX_OK;
   }
   void* kargs[] = {(void*)&dev, (void*)&a};
   solve_kernel_t fn = okx::okx_solve_kernel<18, true>;
-  (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
+  HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
   HIP_TRY(hipLaunchKernel((const void*)fn, dim3(grid_for(p, n_problems)), dim3(okx::kWave), kargs,
                           p->lds_bytes, (hipStream_t)stream));
   return OKX_OK;
 }
 
 /* Plan introspection for CPU-side tests: fills counts without touching a device. */
-int32_t okx_plan_stats(const okx_program_desc* desc, int32_t* out8) {
+int32_t okx_debug_plan_stats(const okx_program_desc* desc, int32_t* out8) {
   okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
   if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
   int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));

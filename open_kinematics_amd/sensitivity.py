@@ -63,6 +63,27 @@ class SweepTangents:
     solve_infos: list
 
 
+def solve_infos_from_records(info: np.ndarray, n_variables: int) -> list:
+    """
+    Device tangent records (``okx_tangent_info``: pivot range of the LDL^T of ``J^T J`` + flags) as the
+    reference's per-state ``TangentSolveInfo`` (``sensitivity.py:44-55``).  The pivots lie inside
+    ``[s_min^2, s_max^2]`` of ``J``, so their square roots stand in for the singular values; a rank-deficient
+    factorisation reports ``rank = n - 1`` (the device does not count how many pivots vanished).
+    """
+    from ._abi import TANGENT_RANK_DEFICIENT
+
+    out = []
+    for flags, lo, hi in zip(info["flags"].tolist(), info["min_pivot"].tolist(), info["max_pivot"].tolist()):
+        deficient = bool(flags & TANGENT_RANK_DEFICIENT)
+        out.append(TangentSolveInfo(
+            n_variables=n_variables,
+            rank=n_variables - 1 if deficient else n_variables,
+            smallest_singular_value=float(np.sqrt(max(lo, 0.0))),
+            condition_number=float(np.sqrt(hi / lo)) if lo > 0.0 else float("inf"),
+        ))
+    return out
+
+
 def _positions_array(states, out_keys) -> np.ndarray:
     rows = []
     for state in states:
@@ -78,24 +99,18 @@ def compute_sweep_tangents(suspension, sweep_config, states, *, device=None) -> 
     """
     import torch
 
-    from .batch import DeviceProgram
-    from .solver import convert_targets_to_absolute
+    from .solver import _device_program, convert_targets_to_absolute
     from .sweep import sweep_program
-    from ._abi import TANGENT_RANK_DEFICIENT
 
     program, _ = sweep_program(suspension, sweep_config)
-    dp = DeviceProgram(program, device)
-    try:
-        out_keys = [program.point_keys[k] for k in program.out_point]
-        pos = _positions_array(states, out_keys)
-        tan, tinfo = dp.tangents(torch.as_tensor(pos, device=dp.device))
-        tan = tan.cpu().numpy()
-        info = dp.tangent_info(tinfo)
-    finally:
-        dp.close()
+    dp = _device_program(program, device)
+    out_keys = [program.point_keys[k] for k in program.out_point]
+    pos = _positions_array(states, out_keys)
+    tan, tinfo = dp.tangents(torch.as_tensor(pos, device=dp.device))
+    tan = tan.cpu().numpy()
+    infos = solve_infos_from_records(dp.tangent_info(tinfo), program.n_vars)
     initial = suspension.initial_state()
-    per_step, infos = [], []
-    n = program.n_vars
+    per_step = []
     for s in range(len(states)):
         step_targets = convert_targets_to_absolute([sweep[s] for sweep in sweep_config.target_sweeps], initial)
         fields = []
@@ -103,14 +118,6 @@ def compute_sweep_tangents(suspension, sweep_config, states, *, device=None) -> 
             velocities = {key: tan[s, t, k].copy() for k, key in enumerate(out_keys)}
             fields.append(TangentField(target_index=t, target=target, velocities=velocities))
         per_step.append(fields)
-        deficient = bool(info["flags"][s] & TANGENT_RANK_DEFICIENT)
-        lo, hi = float(info["min_pivot"][s]), float(info["max_pivot"][s])
-        infos.append(TangentSolveInfo(
-            n_variables=n,
-            rank=n - 1 if deficient else n,
-            smallest_singular_value=float(np.sqrt(max(lo, 0.0))),
-            condition_number=float(np.sqrt(hi / lo)) if lo > 0.0 else float("inf"),
-        ))
     return SweepTangents(per_step=per_step, solve_infos=infos)
 
 
@@ -123,7 +130,6 @@ def compute_state_tangents(state, constraints, derived_manager, step_targets: Se
 
     from .batch import DeviceProgram
     from .program import flatten_problem
-    from ._abi import TANGENT_RANK_DEFICIENT
 
     if not step_targets:
         return [], TangentSolveInfo(n_variables=0, rank=0, smallest_singular_value=0.0, condition_number=1.0)
@@ -131,25 +137,21 @@ def compute_state_tangents(state, constraints, derived_manager, step_targets: Se
     out_keys = list(state.positions.keys())
     program = flatten_problem(state, constraints, derived_manager, heads, out_keys,
                               line_mode="softnorm").with_line_mode("pinned")
+    # The state being differentiated is this program's "design" state, so every call is its own program:
+    # created and released here, not through the drop-in cache (it would only evict the sweep programs).
     dp = DeviceProgram(program, device)
     try:
         keys = [program.point_keys[k] for k in program.out_point]
         pos = _positions_array([state], keys)
         tan, tinfo = dp.tangents(torch.as_tensor(pos, device=dp.device))
         tan = tan.cpu().numpy()[0]
-        info = dp.tangent_info(tinfo)[0]
+        info = solve_infos_from_records(dp.tangent_info(tinfo), program.n_vars)[0]
     finally:
         dp.close()
     fields = [TangentField(target_index=t, target=target,
                            velocities={key: tan[t, k].copy() for k, key in enumerate(keys)})
               for t, target in enumerate(step_targets)]
-    n = program.n_vars
-    lo, hi = float(info["min_pivot"]), float(info["max_pivot"])
-    deficient = bool(info["flags"] & TANGENT_RANK_DEFICIENT)
-    return fields, TangentSolveInfo(
-        n_variables=n, rank=n - 1 if deficient else n,
-        smallest_singular_value=float(np.sqrt(max(lo, 0.0))),
-        condition_number=float(np.sqrt(hi / lo)) if lo > 0.0 else float("inf"))
+    return fields, info
 
 
 def combine_tangents(fields: Sequence[TangentField], coefficients: Sequence[float]) -> dict:

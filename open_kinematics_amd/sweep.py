@@ -96,15 +96,20 @@ _CORNER_DERIVATIVES = (
 )
 
 
+EPS_GEOMETRIC = 1e-6  # primitives/constants.py:9
+
+
 def _none_if_nan(value: float):
     return None if value != value else float(value)
 
 
-def _driver_ratio(response_rate, tangents, driver_idx: int, axis: int, candidates):
+def _driver_ratio(response_rate, tangents, driver_idx: int, axis: int, candidates, column: str = ""):
     """
     ``DerivativeMetricDefinition.select_tangent`` + ``evaluate`` (``metrics/derivatives.py:265-320``) for a whole
     batch: along the candidate target whose tangent moves the driver coordinate most, response rate / driver rate.
-    ``response_rate [B, T]``, ``tangents [B, T, n_out, 3]`` -> ``[B]`` (NaN where no candidate drives it).
+    ``response_rate [B, T]``, ``tangents [B, T, n_out, 3]`` -> ``[B]`` (NaN where no candidate drives it).  Two
+    candidates of equal strength (within ``EPS_GEOMETRIC``) are the reference's "Ambiguous derivative driver"
+    ``ValueError`` (``derivatives.py:296-305``).
     """
     import torch
 
@@ -113,11 +118,18 @@ def _driver_ratio(response_rate, tangents, driver_idx: int, axis: int, candidate
         return torch.full((b,), float("nan"), dtype=torch.float64, device=response_rate.device)
     cand = torch.as_tensor(candidates, device=response_rate.device)
     rates = tangents[:, cand, driver_idx, axis]                       # [B, C]
-    pick = rates.abs().argmax(dim=1, keepdim=True)                    # strongest driver rate
+    strength = rates.abs()
+    pick = strength.argmax(dim=1, keepdim=True)                       # strongest driver rate
     rate = rates.gather(1, pick).squeeze(1)
+    if len(candidates) > 1:
+        best = strength.gather(1, pick)
+        tied = ((best - strength).abs() <= EPS_GEOMETRIC) & (strength >= EPS_GEOMETRIC)
+        if bool((tied.sum(dim=1) > 1).any()):
+            raise ValueError(f"Ambiguous derivative driver for column '{column}': "
+                             "multiple matching tangents have equal strength")
     resp = response_rate[:, cand].gather(1, pick).squeeze(1)
     out = resp / rate
-    return torch.where(rate.abs() >= 1e-6, out, torch.full_like(out, float("nan")))
+    return torch.where(rate.abs() >= EPS_GEOMETRIC, out, torch.full_like(out, float("nan")))
 
 
 def _corner_rows(corner, program, positions, tangents, side=None, rotation=None, actuators=()):
@@ -153,7 +165,8 @@ def _corner_rows(corner, program, positions, tangents, side=None, rotation=None,
 
         def add(response: str, driver: str, rate):
             idx, axis, cand = drivers[driver]
-            columns[f"deriv_{response}_wrt_{driver}"] = _driver_ratio(rate, tangents, idx, axis, cand).cpu().numpy()
+            column = f"deriv_{response}_wrt_{driver}"
+            columns[column] = _driver_ratio(rate, tangents, idx, axis, cand, column).cpu().numpy()
 
         for response, driver in _CORNER_DERIVATIVES:
             if driver == "rack_displacement" and rack_point is None:
@@ -184,67 +197,69 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
 
     import torch
 
-    from .batch import DeviceProgram
     from .enums import Side
     from .metrics import AXLE_METRIC_NAMES, axis_rotation_metrics, axle_roles, axle_state_metrics, topology_rotation_roles
-    from .sensitivity import _positions_array
+    from .sensitivity import _positions_array, solve_infos_from_records
+    from .solver import _device_program
 
+    if getattr(suspension, "config", True) is None:  # core/sweep.py:150-151
+        return SweepMetricsResult(rows=[OrderedDict() for _ in states])
     program, _ = sweep_program(suspension, sweep_config)
-    dp = DeviceProgram(program, device)
+    dp = _device_program(program, device)
     derivative_error = None
-    try:
-        out_keys = [program.point_keys[k] for k in program.out_point]
-        positions = torch.as_tensor(_positions_array(states, out_keys), device=dp.device)
-        tangents = None
-        if program.n_targets > 0:
-            try:
-                tangents, _ = dp.tangents(positions)
-            except Exception as error:  # noqa: BLE001 - metrics degrade without derivatives (core/sweep.py:155-160)
-                derivative_error = f"{type(error).__name__}: {error}"
-        is_axle = hasattr(suspension, "corners")
-        names, roles = topology_rotation_roles(suspension, program)
-        rot_values = rot_derivs = None
-        if names:
-            rot_values, rot_derivs = axis_rotation_metrics(roles, positions, tangents)
-        if not is_axle:
-            rows = _corner_rows(suspension, program, positions, tangents, None, (names, rot_values, rot_derivs))
-            return SweepMetricsResult(rows, derivative_error)
-        per_side = {}
-        for side in (Side.LEFT, Side.RIGHT):
-            tag = side.name.lower()
-            mine = [k for k, n in enumerate(names) if n.endswith("_" + tag) and not n.startswith("arb_arm_angle")]
-            sub = ([names[k][: -len(tag) - 1] for k in mine],
-                   None if rot_values is None else rot_values[:, mine],
-                   None if rot_derivs is None else rot_derivs[:, :, mine])
-            per_side[side] = _corner_rows(suspension.corners[side], program, positions, tangents, side, sub,
-                                          suspension.actuator_dofs())
-        left, right = axle_roles(suspension, program)
-        axle_values = axle_state_metrics(left, right, positions).cpu().numpy()
-        arm = {side: names.index(f"arb_arm_angle_{side.name.lower()}") for side in (Side.LEFT, Side.RIGHT)} \
-            if "arb_arm_angle_left" in names else None
-        tgt_keys = [program.point_keys[p] for p in program.tgt_point]
-        rows = []
-        for s in range(len(states)):
-            axle_row = OrderedDict((n, _none_if_nan(axle_values[s, k])) for k, n in enumerate(AXLE_METRIC_NAMES))
-            rows.append(AxleMetricRows(axle_row, {side: per_side[side][s] for side in (Side.LEFT, Side.RIGHT)}))
-        if arm is not None:
-            twist = (rot_values[:, arm[Side.LEFT]] - rot_values[:, arm[Side.RIGHT]]).cpu().numpy()
-            arm_values = {side: rot_values[:, arm[side]].cpu().numpy() for side in arm}
-            d_twist = {}
-            if tangents is not None:
-                from .enums import PointID, PointRef
+    tangent_infos = None
+    out_keys = [program.point_keys[k] for k in program.out_point]
+    positions = torch.as_tensor(_positions_array(states, out_keys), device=dp.device)
+    tangents = None
+    if program.n_targets > 0:
+        try:
+            tangents, tinfo = dp.tangents(positions)
+            tangent_infos = solve_infos_from_records(dp.tangent_info(tinfo), program.n_vars)
+        except Exception as error:  # noqa: BLE001 - metrics degrade without derivatives (core/sweep.py:155-160)
+            derivative_error = f"{type(error).__name__}: {error}"
+    is_axle = hasattr(suspension, "corners")
+    names, roles = topology_rotation_roles(suspension, program)
+    rot_values = rot_derivs = None
+    if names:
+        rot_values, rot_derivs = axis_rotation_metrics(roles, positions, tangents)
+    if not is_axle:
+        rows = _corner_rows(suspension, program, positions, tangents, None, (names, rot_values, rot_derivs))
+        return SweepMetricsResult(rows, derivative_error, tangent_infos)
+    per_side = {}
+    for side in (Side.LEFT, Side.RIGHT):
+        tag = side.name.lower()
+        mine = [k for k, n in enumerate(names) if n.endswith("_" + tag) and not n.startswith("arb_arm_angle")]
+        sub = ([names[k][: -len(tag) - 1] for k in mine],
+               None if rot_values is None else rot_values[:, mine],
+               None if rot_derivs is None else rot_derivs[:, :, mine])
+        per_side[side] = _corner_rows(suspension.corners[side], program, positions, tangents, side, sub,
+                                      suspension.actuator_dofs())
+    left, right = axle_roles(suspension, program)
+    axle_values = axle_state_metrics(left, right, positions).cpu().numpy()
+    arm = {side: names.index(f"arb_arm_angle_{side.name.lower()}") for side in (Side.LEFT, Side.RIGHT)} \
+        if "arb_arm_angle_left" in names else None
+    tgt_keys = [program.point_keys[p] for p in program.tgt_point]
+    rows = []
+    for s in range(len(states)):
+        axle_row = OrderedDict((n, _none_if_nan(axle_values[s, k])) for k, n in enumerate(AXLE_METRIC_NAMES))
+        rows.append(AxleMetricRows(axle_row, {side: per_side[side][s] for side in (Side.LEFT, Side.RIGHT)}))
+    if arm is not None:
+        twist = (rot_values[:, arm[Side.LEFT]] - rot_values[:, arm[Side.RIGHT]]).cpu().numpy()
+        arm_values = {side: rot_values[:, arm[side]].cpu().numpy() for side in arm}
+        d_twist = {}
+        if tangents is not None:
+            from .enums import PointID, PointRef
 
-                rate = rot_derivs[:, :, arm[Side.LEFT]] - rot_derivs[:, :, arm[Side.RIGHT]]
-                for side in (Side.LEFT, Side.RIGHT):
-                    key = PointRef(side, PointID.WHEEL_CENTER)
-                    cand = [t for t, k in enumerate(tgt_keys) if k == key]
-                    d_twist[side] = _driver_ratio(rate, tangents, out_keys.index(key), 2, cand).cpu().numpy()
-            for s, row in enumerate(rows):
-                row.axle["arb_twist"] = _none_if_nan(twist[s])
-                for side, col in d_twist.items():
-                    row.axle[f"deriv_arb_twist_wrt_hub_z_{side.name.lower()}"] = _none_if_nan(col[s])
-                for side in arm:
-                    row.corners[side]["arb_arm_angle"] = _none_if_nan(arm_values[side][s])
-        return SweepMetricsResult(rows, derivative_error)
-    finally:
-        dp.close()
+            rate = rot_derivs[:, :, arm[Side.LEFT]] - rot_derivs[:, :, arm[Side.RIGHT]]
+            for side in (Side.LEFT, Side.RIGHT):
+                key = PointRef(side, PointID.WHEEL_CENTER)
+                cand = [t for t, k in enumerate(tgt_keys) if k == key]
+                d_twist[side] = _driver_ratio(rate, tangents, out_keys.index(key), 2, cand,
+                                              f"deriv_arb_twist_wrt_hub_z_{side.name.lower()}").cpu().numpy()
+        for s, row in enumerate(rows):
+            row.axle["arb_twist"] = _none_if_nan(twist[s])
+            for side, col in d_twist.items():
+                row.axle[f"deriv_arb_twist_wrt_hub_z_{side.name.lower()}"] = _none_if_nan(col[s])
+            for side in arm:
+                row.corners[side]["arb_arm_angle"] = _none_if_nan(arm_values[side][s])
+    return SweepMetricsResult(rows, derivative_error, tangent_infos)

@@ -1,6 +1,7 @@
 """
 The BASELINE.json configurations as synthetic inputs.  Geometry comes from
-the YAML fixtures the reference's own tests hold (copied as data under ``tests/golden/geometry``).
+the YAML fixtures the reference's own tests hold, shipped as package data under
+``open_kinematics_amd/data`` (the same files the parity tests keep under ``tests/golden/geometry``).
 """
 
 from __future__ import annotations
@@ -14,7 +15,7 @@ from .input import build_suspension, load_geometry
 from .sweep import target_rows
 from .targeting import PointTargetAxis
 
-_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "geometry")
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 P = PointID
 Y, Z = PointTargetAxis(Axis.Y), PointTargetAxis(Axis.Z)
 
@@ -59,24 +60,39 @@ def ensemble_problem(n_geometries: int = 4096, n_steps: int = 256, sigma: float 
     C5: perturbed double-wishbone hardpoints (every authored coordinate + N(0, sigma)) x bump
     sweep.  Returns the base program, hardpoint table ``[G, P, 3]`` (authored points perturbed,
     derived entries recomputed on device by ``rebind``) and relative targets ``[S, T]``.
-    Draws that violate the loader's validators (side sign, collinear anchors) are redrawn.
+    Draws that violate the loader's validators are redrawn: the side sign
+    (``suspensions/build.py:322-343``: a left corner needs ``AXLE_OUTBOARD`` y > 0) and the track rod's rigid
+    anchors (``corner/attachments.py:77-94`` through ``corner/track_rod.py:51-53``: the first two upright
+    anchors distinct, the third off their line, both to ``EPS_GEOMETRIC``).
     """
-    import copy
-
     import yaml
+
+    from .topology import EPS_GEOMETRIC
 
     with open(geometry_path("geometry.yaml"), "r", encoding="utf-8") as fh:
         base_map = yaml.safe_load(fh)
     sus = build_suspension(base_map)
     program, _ = target_rows(sus, [(P.TRACKROD_INBOARD, Y), (P.WHEEL_CENTER, Z)], line_mode)
     authored = [program.point_index(k) for k in sus.hardpoints]
+    axle_outboard = program.point_index(P.AXLE_OUTBOARD)
+    anchors = [program.point_index(k) for k in sus.UPRIGHT_BODY[:3]]
+
+    def valid(points: np.ndarray) -> bool:
+        if points[axle_outboard, 1] <= 0.0:
+            return False
+        a, b, c = points[anchors]
+        span = float(np.linalg.norm(b - a))
+        if span <= EPS_GEOMETRIC:
+            return False
+        return float(np.linalg.norm(np.cross(c - a, (b - a) / span))) > EPS_GEOMETRIC
+
     rng = np.random.default_rng(seed)
     table = np.repeat(program.design_pos[None], n_geometries, axis=0)
     g = 0
     while g < n_geometries:
         trial = program.design_pos.copy()
         trial[authored] += rng.normal(0.0, sigma, (len(authored), 3))
-        if trial[program.point_index(P.AXLE_OUTBOARD), 1] <= 0.0:
+        if not valid(trial):
             continue
         table[g] = trial
         g += 1

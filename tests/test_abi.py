@@ -40,10 +40,28 @@ def test_library_exports_every_declared_entry_point():
     for name in declared:
         assert hasattr(lib, name), f"libokx.so does not export {name}"
     assert lib.okx_abi_version() == _abi.ABI_VERSION
+    assert set(_lib.EXPORTS) == declared, "open_kinematics_amd._lib.EXPORTS and include/okx.h disagree"
     opts = _abi.SolveOpts()
     lib.okx_default_opts(C.byref(opts))
     assert opts.max_iter == 100 and opts.step_tol == 1e-11 and opts.residual_tolerance == 1e-3
     assert C.sizeof(_abi.Info) == 40
+
+
+def test_library_exports_nothing_undeclared():
+    """Every okx_* symbol of libokx.so is declared in include/okx.h or include/okx_debug.h."""
+    import subprocess
+
+    with open(os.path.join(REPO, "include", "okx_debug.h"), "r", encoding="utf-8") as fh:
+        debug = set(re.findall(r"\b(okx_debug_[a-z_]+)\s*\(", fh.read()))
+    assert debug == set(_lib.DEBUG_EXPORTS)
+    declared = set(re.findall(r"\b(okx_[a-z_]+)\s*\(", _header_text())) | debug
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in nm.splitlines() if line.split()[-1].startswith("okx_")}
+    assert exported, "nm found no okx_* symbols"
+    assert exported <= declared, f"undeclared exports: {sorted(exported - declared)}"
+    lib = _lib.load()
+    for name in debug:
+        assert hasattr(lib, name), f"libokx.so does not export {name}"
 
 
 @pytest.mark.parametrize("name", STEERED + UNSTEERED)
@@ -54,7 +72,7 @@ def test_plan_building_on_host(golden, name):
         p = program.with_line_mode(mode)
         host = _abi.HostProgram(p)
         stats = (C.c_int32 * 8)()
-        assert lib.okx_plan_stats(host.byref(), stats) == 0
+        assert lib.okx_debug_plan_stats(host.byref(), stats) == 0
         n, m, pairs, contrib, active, js_stride, lda, lds = list(stats)
         assert (n, m) == (p.n_vars, p.n_residuals)
         assert pairs >= p.n_free and contrib >= m
@@ -75,13 +93,13 @@ def test_invalid_programs_are_rejected_with_status_codes(golden):
     # bad ABI version
     good = _abi.HostProgram(program)
     good.desc.abi_version = 99
-    assert lib.okx_plan_stats(good.byref(), stats) == -1
+    assert lib.okx_debug_plan_stats(good.byref(), stats) == -1
     assert b"ABI version" in lib.okx_last_error()
     # out-of-range point index
     broken = program.with_targets(program.tgt_point, program.tgt_dir)
     broken.row_pts = program.row_pts.copy()
     broken.row_pts[0, 0] = 1000
-    assert lib.okx_plan_stats(_abi.HostProgram(broken).byref(), stats) == -1
+    assert lib.okx_debug_plan_stats(_abi.HostProgram(broken).byref(), stats) == -1
 
 
 def test_no_gpu_means_loud_failure():

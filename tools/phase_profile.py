@@ -6,7 +6,6 @@ from open_kinematics_amd.workloads import bump_sweep_problem
 prog, t = bump_sweep_problem(16384)
 dp = DeviceProgram(prog)
 lib = _lib.load()
-lib.okx_debug_phase_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p]*5
 tg = torch.as_tensor(t, device='cuda'); out = torch.empty((16384, prog.n_out, 3), dtype=torch.float64, device='cuda')
 info = torch.empty((16384,40), dtype=torch.uint8, device='cuda'); ph = torch.zeros(12, dtype=torch.int64, device='cuda')
 opts = dp.default_opts()

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 which=${1:-dw}; waves=${2:-1}
-export OKX_KERNEL_CACHE=/tmp/q/cache_$which_$waves OKX_QUAD_WAVES=$waves
+export OKX_KERNEL_CACHE=/tmp/q/cache_${which}_${waves} OKX_QUAD_WAVES=$waves
 rm -rf $OKX_KERNEL_CACHE; mkdir -p $OKX_KERNEL_CACHE
 python - "$which" <<'PY'
 import sys

@@ -11,9 +11,7 @@ program, targets = bump_sweep_problem(101, line_mode="softnorm")
 dp = DeviceProgram(program, "cuda:0")
 t = torch.as_tensor(targets, device="cuda:0")
 tr = torch.zeros((256, 8), dtype=torch.float64, device="cuda:0")
-dp.lib.okx_debug_quad_trace.argtypes = [C.c_void_p, C.c_int64]
-dp.lib.okx_debug_quad_trace.restype = None
-dp.lib.okx_debug_quad_trace(C.c_void_p(tr.data_ptr()), int(sys.argv[1]) if len(sys.argv) > 1 else 75)
+dp.lib.okx_debug_quad_trace(dp._handle, C.c_void_p(tr.data_ptr()), int(sys.argv[1]) if len(sys.argv) > 1 else 75)
 res = dp.solve(t, chain_len=1, kernel="quad", max_iter=40, step_tol=1e-8)
 torch.cuda.synchronize()
 np.set_printoptions(linewidth=200, precision=6)
