@@ -367,6 +367,20 @@ class DeviceProgram:
         _lib.check(rc, "okx_expand_positions_batch")
         return out
 
+    def ensemble_targets(self, geom_pos: torch.Tensor, relative) -> torch.Tensor:
+        """
+        Absolute targets ``[G * S, T]`` of an ensemble from per-step RELATIVE displacements ``[S, T]``: every
+        geometry's own design coordinate along each target direction plus the displacement — the reference's
+        relative target mode applied per geometry (``convert_targets_to_absolute``, ``solver.py:584-627``).
+        ``geom_pos [G, P, 3]`` comes from ``rebind``.  Stays in HBM.
+        """
+        p = self.program
+        rel = _as_f64(relative, self.device).reshape(-1, p.n_targets)
+        dirs = torch.as_tensor(np.asarray(p.tgt_dir, dtype=np.float64), device=self.device)         # [T, 3]
+        pts = torch.as_tensor(np.asarray(p.tgt_point, dtype=np.int64), device=self.device)          # [T]
+        base = (geom_pos[:, pts, :] * dirs[None]).sum(dim=2)                                           # [G, T]
+        return (base[:, None, :] + rel[None]).reshape(-1, p.n_targets).contiguous()
+
     def rebind(self, hardpoints):
         """Per-geometry design positions ``[G, P, 3]`` and row parameters ``[G, Mc, 8]``."""
         p = self.program

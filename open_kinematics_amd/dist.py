@@ -6,6 +6,8 @@ all-gather of the solved positions (RCCL over xGMI on the GPU box; gloo in the C
 
 from __future__ import annotations
 
+from dataclasses import dataclass
+
 import torch
 import torch.distributed as dist
 
@@ -19,10 +21,11 @@ def shard_range(n_items: int, rank: int, world_size: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+def all_gather_rows(local: torch.Tensor, n_total: int, group=None, spans=None) -> torch.Tensor:
     """
-    Gather per-rank row blocks (sharded with ``shard_range``) into the full ``[n_total, ...]``
-    tensor on every rank.  Uneven shards are padded to the largest block for the collective.
+    Gather per-rank row blocks into the full ``[n_total, ...]`` tensor on every rank.  The blocks are
+    ``shard_range`` of the rows unless ``spans`` gives every rank's ``[lo, hi)`` explicitly (geometry-major
+    shards: whole geometries per rank).  Uneven blocks are padded to the largest one for the collective.
     """
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         if local.shape[0] != n_total:
@@ -30,10 +33,15 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
         return local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    lo, hi = shard_range(n_total, rank, world)
+    if spans is None:
+        spans = [shard_range(n_total, r, world) for r in range(world)]
+    if len(spans) != world or spans[0][0] != 0 or spans[-1][1] != n_total or \
+            any(a[1] != b[0] for a, b in zip(spans, spans[1:])):
+        raise ValueError("spans must tile [0, n_total) in rank order")
+    lo, hi = spans[rank]
     if local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank}: expected {hi - lo} rows, got {local.shape[0]}")
-    biggest = -(-n_total // world)
+    biggest = max(b - a for a, b in spans)
     if hi - lo < biggest:
         pad = torch.zeros((biggest - (hi - lo), *local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
@@ -42,11 +50,7 @@ def all_gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tens
     dist.all_gather_into_tensor(gathered, local, group=group)
     if n_total == world * biggest:
         return gathered
-    pieces = []
-    for r in range(world):
-        rlo, rhi = shard_range(n_total, r, world)
-        pieces.append(gathered[r * biggest : r * biggest + (rhi - rlo)])
-    return torch.cat(pieces, dim=0)
+    return torch.cat([gathered[r * biggest : r * biggest + (b - a)] for r, (a, b) in enumerate(spans)], dim=0)
 
 
 class GatherPipeline:
@@ -153,15 +157,91 @@ class FreeGatherPipeline(GatherPipeline):
         return self.local[self.last] if self.world == 1 else self.full[self.last]
 
 
-def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = True, group=None, **solve_kw):
-    """
-    Solve this rank's index block of ``targets_full [B, T]`` and (optionally) all-gather the
-    solved positions.  Returns ``(positions, local_result)``.
-    """
+@dataclass
+class EnsembleShard:
+    """What ``solve_sharded(..., hardpoints=...)`` returns next to the gathered positions."""
+
+    local: object                      # BatchResult of this rank's geometries
+    geometry_range: tuple              # [lo, hi) of the geometries this rank solved
+    free_full: torch.Tensor | None     # gathered free coordinates [G * S, n_free, 3] (exchange="free")
+    info_full: torch.Tensor | None     # gathered okx_info records [G * S, 40] uint8
+    exchange_bytes_per_rank: int       # payload this rank contributed to the all-gather(s)
+
+
+def _world(group):
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    rank = dist.get_rank(group) if world > 1 else 0
-    n_total = targets_full.shape[0]
-    lo, hi = shard_range(n_total, rank, world)
-    result = device_program.solve(targets_full[lo:hi], **solve_kw)
-    positions = all_gather_rows(result.positions, n_total, group) if gather else result.positions
-    return positions, result
+    return world, (dist.get_rank(group) if world > 1 else 0)
+
+
+def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = True, group=None, *, hardpoints=None,
+                  steps_per_geometry: int = 0, exchange: str = "free", relative_targets: bool | None = None,
+                  **solve_kw):
+    """
+    Solve this rank's index block and (optionally) all-gather the solved positions.
+
+    Without ``hardpoints``: ``targets_full [B, T]`` absolute targets of one geometry, sharded by contiguous index
+    range; returns ``(positions, local_result)``.
+
+    With ``hardpoints [G, P, 3]`` (BASELINE config 5: perturbed geometries x sweep steps): the
+    batch is **geometry-major**, a rank owns whole geometries ``shard_range(G, rank, world)``.  The rank rebinds
+    its slice of the hardpoint table on the device (per-geometry problem emission, reference
+    ``suspensions/corner/double_wishbone.py:259-308``), builds its targets, solves, and the exchange step gathers
+    ``exchange="free"`` the free coordinates (``3 n_free`` doubles per solve; every rank then rebuilds all positions
+    with ``expand`` from the replicated, rebound hardpoint table) or ``"positions"`` the output records
+    themselves, plus the 40-byte info records.  ``targets_full`` is either ``[S, T]`` RELATIVE displacements
+    applied to every geometry's own design coordinates (the reference's relative target mode) or ``[G * S, T]``
+    absolute values (``relative_targets`` says which; ``None`` infers it from the row count, absolute when both
+    fit); ``steps_per_geometry`` = S.  Returns ``(positions [G * S, n_out, 3], EnsembleShard)``;
+    uneven geometry counts are padded inside the collective and trimmed again.
+    """
+    world, rank = _world(group)
+    if hardpoints is None:
+        n_total = targets_full.shape[0]
+        lo, hi = shard_range(n_total, rank, world)
+        result = device_program.solve(targets_full[lo:hi], **solve_kw)
+        positions = all_gather_rows(result.positions, n_total, group) if gather else result.positions
+        return positions, result
+    if exchange not in ("free", "positions"):
+        raise ValueError("exchange must be 'free' or 'positions'")
+    steps = int(steps_per_geometry)
+    n_geom = int(hardpoints.shape[0])
+    if steps <= 0:
+        raise ValueError("an ensemble needs steps_per_geometry > 0")
+    program = device_program.program
+    glo, ghi = shard_range(n_geom, rank, world)
+    targets_full = torch.as_tensor(targets_full)
+    relative = relative_targets if relative_targets is not None else \
+        (targets_full.shape[0] == steps and n_geom * steps != steps)
+    if targets_full.shape[0] != (steps if relative else n_geom * steps):
+        raise ValueError("targets must be [S, T] relative displacements or [G * S, T] absolute values")
+    # Per-geometry emission.  The expand on the receiving side needs every geometry's fixed points, so with the
+    # compact exchange the (small: G x P x 24 B) hardpoint table is rebound in full on every rank — replicated
+    # inputs, as SURVEY.md section 8e allows; otherwise only this rank's slice.
+    everyone = gather and world > 1 and exchange == "free"
+    table = hardpoints if everyone else hardpoints[glo:ghi]
+    gpos, gparam = device_program.rebind(table)
+    my_pos = gpos[glo:ghi] if everyone else gpos
+    my_param = gparam[glo:ghi] if everyone else gparam
+    if relative:
+        local_targets = device_program.ensemble_targets(my_pos, targets_full)
+    else:
+        local_targets = targets_full[glo * steps : ghi * steps]
+    result = device_program.solve(local_targets, geom_pos=my_pos, geom_row_param=my_param, steps_per_geometry=steps,
+                                  **solve_kw)
+    if not gather or world == 1:
+        return result.positions, EnsembleShard(result, (glo, ghi), None, result.info_raw if gather else None, 0)
+    n_total = n_geom * steps
+    spans = [tuple(steps * g for g in shard_range(n_geom, r, world)) for r in range(world)]
+    info_full = all_gather_rows(result.info_raw, n_total, group, spans)
+    sent = result.info_raw.numel() * result.info_raw.element_size()
+    if exchange == "positions":
+        positions = all_gather_rows(result.positions, n_total, group, spans)
+        sent += result.positions.numel() * result.positions.element_size()
+        return positions, EnsembleShard(result, (glo, ghi), None, info_full, sent)
+    free_local = result.positions.index_select(1, device_program.free_out_index)
+    sent += free_local.numel() * free_local.element_size()
+    free_full = all_gather_rows(free_local, n_total, group, spans)
+    positions = device_program.expand(free_full, geom_pos=gpos, steps_per_geometry=steps)
+    # this rank's own block is bit-identical either way; keep the solver's records for it
+    positions[glo * steps : ghi * steps] = result.positions
+    return positions, EnsembleShard(result, (glo, ghi), free_full, info_full, sent)

@@ -166,6 +166,20 @@ def clear_program_cache() -> None:
         dp.close()
 
 
+def dropin_program(initial_state, constraints, sweep_config, derived_manager, solver_config=SolverConfig(),
+                   output_points=None) -> tuple[ConstraintProgram, np.ndarray]:
+    """The constraint program and absolute target table ``[S, T]`` that ``solve_suspension_sweep`` solves
+    (``__graft_entry__.build()`` precompiles the kernels of the BASELINE sweeps through this)."""
+    spec = getattr(derived_manager, "spec", derived_manager)
+    cfg = _coerce_config(solver_config)
+    heads, table = absolute_target_table(sweep_config, initial_state)
+    n_vars = 3 * len(initial_state.free_points)
+    validate_least_squares_dimensions(n_vars, len(constraints) + len(heads))
+    program = flatten_problem(initial_state, constraints, spec, heads, output_points=output_points,
+                              line_mode="softnorm").with_line_mode(cfg.line_mode)
+    return program, table
+
+
 def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_manager,
                            solver_config=SolverConfig(), *, output_points=None, device=None):
     """
@@ -179,13 +193,8 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     """
     import torch
 
-    spec = getattr(derived_manager, "spec", derived_manager)
     cfg = _coerce_config(solver_config)
-    heads, table = absolute_target_table(sweep_config, initial_state)
-    n_vars = 3 * len(initial_state.free_points)
-    validate_least_squares_dimensions(n_vars, len(constraints) + len(heads))
-    program = flatten_problem(initial_state, constraints, spec, heads, output_points=output_points,
-                              line_mode="softnorm").with_line_mode(cfg.line_mode)
+    program, table = dropin_program(initial_state, constraints, sweep_config, derived_manager, cfg, output_points)
     dp = _device_program(program, device)
     n_steps = table.shape[0]
     if n_steps == 0:

@@ -79,6 +79,120 @@ def test_two_rank_gloo_gather_reassembles_the_sweep(tmp_path, n_total):
             assert torch.equal(torch.load(os.path.join(tmp_path, f"compact{rank}.pt")), last)
 
 
+class _StandInProgram:
+    """
+    CPU stand-in for ``DeviceProgram`` with the same ensemble surface (``rebind``, ``ensemble_targets``, ``solve``
+    with geometry tables, ``free_out_index``, ``expand``): 5 output points, point 0 fixed (from the geometry),
+    points 1 and 3 "free" (a function of target and geometry), points 2 and 4 "derived" (midpoint / offset).
+    """
+
+    class program:  # noqa: N801 - attribute bag like ConstraintProgram
+        n_out, n_free, n_targets = 5, 2, 1
+
+    free_out_index = torch.tensor([1, 3])
+
+    def __init__(self):
+        self.rebound = []
+
+    def rebind(self, table):
+        table = torch.as_tensor(table, dtype=torch.float64)
+        self.rebound.append(table.shape[0])
+        return table.clone(), table[:, :1, :].expand(-1, 4, -1).reshape(table.shape[0], 4, 3).clone()
+
+    def ensemble_targets(self, gpos, relative):
+        base = gpos[:, 1, 2:3]                                               # [G, 1]
+        return (base[:, None, :] + torch.as_tensor(relative)[None]).reshape(-1, 1)
+
+    @staticmethod
+    def _assemble(free, fixed):
+        out = torch.empty((free.shape[0], 5, 3), dtype=torch.float64)
+        out[:, 0] = fixed
+        out[:, 1] = free[:, 0]
+        out[:, 3] = free[:, 1]
+        out[:, 2] = 0.5 * (free[:, 0] + free[:, 1])
+        out[:, 4] = free[:, 1] + fixed
+        return out
+
+    def solve(self, targets, *, geom_pos, geom_row_param, steps_per_geometry, **kw):
+        assert geom_pos.shape[0] * steps_per_geometry == targets.shape[0] and geom_row_param.shape[0] == geom_pos.shape[0]
+        fixed = geom_pos[:, 0].repeat_interleave(steps_per_geometry, dim=0)
+        t = targets[:, :1]
+        free = torch.stack([t * fixed, t + 2.0 * fixed], dim=1)
+
+        class _Result:
+            positions = self._assemble(free, fixed)
+            info_raw = (targets[:, :1].abs() * 7).to(torch.uint8).expand(-1, 40).contiguous()
+
+        return _Result
+
+    def expand(self, free, geom_pos=None, steps_per_geometry=0):
+        return self._assemble(free, geom_pos[:, 0].repeat_interleave(steps_per_geometry, dim=0))
+
+
+def _ensemble_inputs(n_geom: int, steps: int):
+    gen = torch.Generator().manual_seed(5)
+    table = torch.randn((n_geom, 3, 3), dtype=torch.float64, generator=gen)
+    relative = torch.linspace(-6.0, 8.0, steps, dtype=torch.float64).reshape(-1, 1)
+    return table, relative
+
+
+def _ensemble_worker(rank: int, world: int, port: int, n_geom: int, steps: int, out_dir: str) -> None:
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from open_kinematics_amd.dist import solve_sharded
+
+    table, relative = _ensemble_inputs(n_geom, steps)
+    for exchange in ("free", "positions"):
+        dp = _StandInProgram()
+        positions, shard = solve_sharded(dp, relative, hardpoints=table, steps_per_geometry=steps, exchange=exchange)
+        torch.save({"positions": positions, "info": shard.info_full, "range": shard.geometry_range,
+                    "rebound": dp.rebound, "sent": shard.exchange_bytes_per_rank},
+                   os.path.join(out_dir, f"{exchange}{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_geom", [6, 7])
+def test_two_rank_gloo_ensemble_is_geometry_major(tmp_path, n_geom):
+    """C5's multi-GPU path: geometry-major shards (uneven counts included), local rebind, solve, gather."""
+    steps = 4
+    port = 31500 + (os.getpid() + n_geom) % 2000
+    mp.spawn(_ensemble_worker, args=(2, port, n_geom, steps, str(tmp_path)), nprocs=2, join=True)
+    table, relative = _ensemble_inputs(n_geom, steps)
+    ref = _StandInProgram()
+    gpos, gparam = ref.rebind(table)
+    targets = ref.ensemble_targets(gpos, relative)
+    expect = ref.solve(targets, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=steps)
+    spans = [shard_range(n_geom, r, 2) for r in range(2)]
+    for exchange in ("free", "positions"):
+        for rank in range(2):
+            got = torch.load(os.path.join(tmp_path, f"{exchange}{rank}.pt"))
+            assert tuple(got["range"]) == spans[rank]
+            assert torch.equal(got["positions"], expect.positions)
+            assert torch.equal(got["info"], expect.info_raw)
+            rows = (spans[rank][1] - spans[rank][0]) * steps
+            payload = rows * (2 if exchange == "free" else 5) * 24 + rows * 40
+            assert got["sent"] == payload
+            # the compact exchange rebinds the replicated table in full, the positions exchange only its slice
+            assert got["rebound"] == [n_geom if exchange == "free" else spans[rank][1] - spans[rank][0]]
+
+
+def test_single_process_ensemble_needs_no_collective():
+    from open_kinematics_amd.dist import solve_sharded
+
+    table, relative = _ensemble_inputs(3, 4)
+    dp = _StandInProgram()
+    positions, shard = solve_sharded(dp, relative, hardpoints=table, steps_per_geometry=4)
+    assert shard.geometry_range == (0, 3) and shard.exchange_bytes_per_rank == 0 and positions.shape == (12, 5, 3)
+    absolute = dp.ensemble_targets(table, relative)
+    again, _ = solve_sharded(dp, absolute, hardpoints=table, steps_per_geometry=4)
+    assert torch.equal(again, positions)
+    with pytest.raises(ValueError):
+        solve_sharded(dp, relative[:3], hardpoints=table, steps_per_geometry=4)
+
+
 def test_single_process_pipeline_degenerates_to_the_local_buffer():
     pipe = GatherPipeline(4, (3,), torch.float64, "cpu")
     for k in range(3):

@@ -1,46 +1,55 @@
 #!/usr/bin/env python3
-"""Copy the artifacts of tools/profile_bench.sh from gpurun_out/ into profiles/<round>/ under a tag.
-   tools/save_profile.py r01 bench_c2_pred "note about the build" """
-import json, os, shutil, sys
-rnd, tag, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
-O, P = "gpurun_out/profile_bench", f"profiles/{rnd}"
+"""Copy the artifacts of tools/profile_run.sh from gpurun_out/profile_<tag>/ into profiles/<round>/ under that tag and write
+   the per-launch traffic / SQ summary next to them.
+   tools/save_profile.py r02 bench_c2_cold <units per launch> <algorithmic bytes per unit> "note about the build" """
+import json, os, shutil, sys, glob
+rnd, tag, units, bytes_per = sys.argv[1], sys.argv[2], int(sys.argv[3]), float(sys.argv[4])
+note = sys.argv[5] if len(sys.argv) > 5 else ""
+O, P = f"gpurun_out/profile_{tag}", f"profiles/{rnd}"
 os.makedirs(P, exist_ok=True)
 s = json.load(open(f"{O}/summary.json"))
 last = lambda path: json.loads(open(path).read().strip().splitlines()[-1])
-bench, under = last(f"{O}/bench.json"), last(f"{O}/bench_under_rocprof.json")
-shutil.copy(f"{O}/bench.json", f"{P}/{tag}.json")
-shutil.copy(f"{O}/bench_under_rocprof.json", f"{P}/{tag}_under_rocprof.json")
-shutil.copy(f"{O}/trace/t_kernel_stats.csv", f"{P}/{tag}_kernel_stats.csv")
-with open(f"{O}/trace/t_kernel_trace.csv") as f, open(f"{P}/{tag}_kernel_trace_head.csv", "w") as g:
+run, under = last(f"{O}/run.json"), last(f"{O}/run_under_rocprof.json")
+find = lambda d, suffix: (glob.glob(f"{O}/{d}/**/*{suffix}", recursive=True) or [None])[0]
+shutil.copy(f"{O}/run.json", f"{P}/{tag}.json")
+shutil.copy(f"{O}/run_under_rocprof.json", f"{P}/{tag}_under_rocprof.json")
+shutil.copy(find("trace", "kernel_stats.csv"), f"{P}/{tag}_kernel_stats.csv")
+with open(find("trace", "kernel_trace.csv")) as f, open(f"{P}/{tag}_kernel_trace_head.csv", "w") as g:
     g.writelines(line for i, line in enumerate(f) if i < 40)
-for src, name in (("fetch/f", "FETCH_SIZE"), ("write/w", "WRITE_SIZE"), ("sq/sq", "SQ")):
-    shutil.copy(f"{O}/{src}_counter_collection.csv", f"{P}/{tag}_pmc_{name}.csv")
+for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", "SQ"), ("sq2", "SQ2")):
+    src = find(d, "counter_collection.csv")
+    if src:
+        shutil.copy(src, f"{P}/{tag}_pmc_{name}.csv")
 fetch = s["FETCH_SIZE"]["per_dispatch_kib_median"] * 1024
 write = s["WRITE_SIZE"]["per_dispatch_kib_median"] * 1024
 sq, w = s["SQ"], s["SQ"]["SQ_WAVES"]
+kms = lambda r: r.get("roofline", {}).get("kernel_ms") or next((r[m]["kernel_ms"] for m in ("cold", "chained") if m in r), None)
 out = {
-    "kernel": "okx_quad_solve_u (runtime-specialised quad kernel of the DW corner program)" + (": " + note if note else ""),
-    "workload": "bench.py C2 16384-step sweep, one launch = 16384 problems = 1024 wavefronts (1 per SIMD)",
-    "command": "tools/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* (separate passes) --output-format csv "
-               "-- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline; per-dispatch MEDIANS (the predictor's 8-problem node solve is "
-               "one more, tiny dispatch of the same kernel)",
+    "kernel": s.get("dispatch", {}).get("Kernel_Name", "") + (": " + note if note else ""),
+    "dispatch": s.get("dispatch"),
+    "workload": run.get("config", {}).get("workload") or run.get("workload"),
+    "units_per_launch": units,
+    "command": "tools/profile_run.sh: rocprofv3 --kernel-trace --stats; then --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in "
+               "SEPARATE passes, --output-format csv; per-dispatch MEDIANS over the dispatches of the solve kernel",
     "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
     "corrections": "counter unit = KiB (x1024). The gfx950 x2 FETCH_SIZE correction of MI355X_MICROARCH.md applies to wide (16 B/lane) "
-                   "coalesced streaming reads; this kernel reads 8-byte targets and L2-resident parameter / coefficient tables, so FETCH_SIZE "
-                   "is reported uncorrected (uncalibrated width per the guide; doubling it would add 0.4 MB). WRITE_SIZE is exact: 6400 KiB = "
-                   "16384 x (360 B positions + 40 B info).",
-    "algorithmic_bytes_per_launch": 392 * 16384,
+                   "coalesced streaming reads; these kernels read 8-byte targets and L2-resident parameter tables (and, for ensembles, "
+                   "8-byte per-lane geometry entries), so FETCH_SIZE is reported uncorrected (uncalibrated width per the guide). "
+                   "WRITE_SIZE is exact for the 16-byte-per-lane record stores.",
+    "algorithmic_bytes_per_launch": bytes_per * units,
+    "traffic_over_algorithmic": (fetch + write) / (bytes_per * units),
     "sq_counters_per_wavefront": {
+        "waves": w,
         "wave_cycles": sq["SQ_WAVE_CYCLES"] * 4 / w, "valu_instructions": sq["SQ_INSTS_VALU"] / w, "salu_instructions": sq["SQ_INSTS_SALU"] / w,
         "valu_active_cycles": sq["SQ_ACTIVE_INST_VALU"] * 4 / w, "wait_any_cycles": sq["SQ_WAIT_ANY"] * 4 / w,
-        "wait_inst_any_cycles": sq["SQ_WAIT_INST_ANY"] * 4 / w,
-        "note": "SQ cycle counters are in quad-cycles (x4 applied); 1024 wavefronts per launch"},
+        "wait_inst_any_cycles": sq["SQ_WAIT_INST_ANY"] * 4 / w, "active_inst_any_cycles": sq["SQ_ACTIVE_INST_ANY"] * 4 / w,
+        "wait_any_share": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
+        "note": "SQ cycle counters are in quad-cycles (x4 applied)"},
+    "sq2_per_wavefront": {k: v / w for k, v in s.get("SQ2", {}).items()},
     "kernel_stats": s["kernel_stats"],
-    "bench_value": bench["value"], "bench_kernel_ms": bench["roofline"]["kernel_ms"],
-    "under_rocprof_kernel_ms": under["roofline"]["kernel_ms"],
-    "raw": {k: s[k] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ")},
+    "kernel_ms_events": kms(run), "kernel_ms_events_under_rocprof": kms(under),
+    "raw": {k: s[k] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2") if k in s},
 }
 json.dump(out, open(f"{P}/{tag}_pmc_traffic.json", "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("traffic_bytes_per_launch", "sq_counters_per_wavefront", "kernel_stats", "bench_value",
-                                      "bench_kernel_ms", "under_rocprof_kernel_ms")}, indent=1))
-print(json.dumps({k: bench[k] for k in ("value", "ms_per_step", "roofline", "compute", "cpu_baseline")}, indent=1))
+print(json.dumps({k: out[k] for k in ("dispatch", "traffic_bytes_per_launch", "traffic_over_algorithmic", "sq_counters_per_wavefront",
+                                      "sq2_per_wavefront", "kernel_stats", "kernel_ms_events", "kernel_ms_events_under_rocprof")}, indent=1))
