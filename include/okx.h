@@ -158,7 +158,15 @@ typedef struct okx_solve_opts {
   int32_t predictor;      /* quad kernel, own-geometry launches.  non-zero: chain heads (cold starts) begin at
                              the polynomial model of okx_program_fit_predictor instead of the design state
                              (ignored until a predictor has been fitted).  Same solutions, fewer passes. */
-  int32_t pad;
+  int32_t shared_first_step; /* quad kernel (single mode).  non-zero (default 1): a chain head starts at its geometry's
+                             design state, where the constraint residuals vanish and the Jacobian, J^T J and its damped
+                             factorisation are identical for every problem of that geometry; that first Levenberg-
+                             Marquardt pass is evaluated ONCE PER GEOMETRY (a small launch ahead of the solve; own
+                             geometry: once per program and lambda0) and every head takes its first step
+                             dx = -sum_t r_t (J^T J + lambda I)^-1 J^T e_t from that table.  Same iteration, same
+                             iterates up to rounding; info.nfev counts the evaluations a problem ran itself.
+                             0: every chain head runs its own first pass.  With geometry tables the scratch table lives
+                             in the program: such launches of one program must be stream-ordered.                      */
 } okx_solve_opts;
 
 /* Per-problem result, the device analogue of SolverInfo (solver.py:83-96). */
@@ -169,13 +177,21 @@ typedef struct okx_info {
   int32_t iterations;     /* LM iterations used                                            */
   int32_t nfev;           /* residual evaluations (SolverInfo.nfev analogue)               */
   int32_t flags;          /* bit0 converged, bit1 max_residual > residual_tolerance,
-                             bit2 damping failure / non-finite                             */
+                             bit2 damping failure / non-finite, bit3 ill-conditioned: in the last
+                             factorisation (smallest pivot - damping) / largest pivot fell below
+                             OKX_ILL_CONDITIONED_PIVOT_RATIO, i.e. cond(J) above ~1e6: a singular
+                             configuration, typically a compromise point just beyond kinematic
+                             lock-out whose residual is still inside residual_tolerance.  The
+                             minimiser is only defined to ~cond(J) * eps * |x| there: advisory.
+                             (quad kernel and the one-problem-per-wavefront interpreter)   */
   int32_t reserved;
 } okx_info;
 
 #define OKX_INFO_CONVERGED 1
 #define OKX_INFO_RESIDUAL_EXCEEDED 2
 #define OKX_INFO_FAILED 4
+#define OKX_INFO_ILL_CONDITIONED 8
+#define OKX_ILL_CONDITIONED_PIVOT_RATIO 1e-12 /* (min pivot - lambda) / max pivot of the LDL^T of J^T J + lambda I */
 
 int32_t okx_abi_version(void);
 const char* okx_last_error(void);

@@ -53,7 +53,7 @@ class SolveOpts(C.Structure):
         ("kernel", C.c_int32),
         ("confirm_full_pass", C.c_int32),
         ("predictor", C.c_int32),
-        ("pad", C.c_int32),
+        ("shared_first_step", C.c_int32),
     ]
 
 
@@ -90,6 +90,7 @@ TANGENT_RANK_DEFICIENT = 2
 INFO_CONVERGED = 1
 INFO_RESIDUAL_EXCEEDED = 2
 INFO_FAILED = 4
+INFO_ILL_CONDITIONED = 8  # advisory: pivot ratio of the last factorisation below 1e-12 (cond(J) above ~1e6)
 
 
 class HostProgram:

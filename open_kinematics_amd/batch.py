@@ -119,6 +119,7 @@ class DeviceProgram:
         info_out: torch.Tensor | None = None,
         predictor: bool | str | None = None,
         confirm_full_pass: bool | None = None,
+        shared_first_step: bool | None = None,
     ) -> BatchResult:
         """
         Solve ``B`` problems; ``targets`` is ``[B, T]`` of absolute target scalars.
@@ -127,6 +128,9 @@ class DeviceProgram:
         the design state (own-geometry launches of the quad kernel).  ``None`` = use it when it can be
         fitted (once, over the target box of the first such launch), ``True`` = require it, ``False`` = plain
         cold starts, ``"all"`` = every chain step starts from the model (instead of the secant extrapolation).
+
+        ``shared_first_step`` (default on): chain heads take their first LM step from the per-geometry table of the
+        design state instead of running that (batch-invariant) pass themselves (``okx_solve_opts``).
 
         ``confirm_full_pass``: always end a solve on a computed correction ``<= step_tol`` (``okx_solve_opts``).
 
@@ -156,6 +160,8 @@ class DeviceProgram:
             opts.residual_tolerance = float(residual_tolerance)
         if confirm_full_pass is not None:
             opts.confirm_full_pass = 1 if confirm_full_pass else 0
+        if shared_first_step is not None:
+            opts.shared_first_step = 1 if shared_first_step else 0
         if predictor is not False and geom_pos is None and opts.kernel in (0, 3):
             # Fitted once, over the target box of the first sizeable launch (later launches clamp to it; refit with
             # fit_predictor).  Automatic mode leaves small batches alone: the fit costs more than it would save, and a

@@ -48,6 +48,12 @@ struct okx_program {
   char quad_note[256];      // why the quad kernel is not in use (empty when it is)
   double* predictor_dev;    // chain-head model fitted by okx_program_fit_predictor, or null
   long long predictor_len;  // doubles in it
+  // shared first step of the chain heads (okx_quad_head_u/_g; null functions: not generated for this program)
+  hipFunction_t quad_fn_head_u, quad_fn_head_g;
+  double* head_dev;         // own geometry's table (quad_head_stride doubles), filled on first use per lambda0
+  double head_lambda0;      // the lambda0 it was computed for (NaN: not yet)
+  double* head_geom_dev;    // scratch table of the latest launch with geometry tables (grow-only)
+  long long head_geom_cap;  // geometries it holds
   double* quad_trace;            // diagnostic hook, see okx_debug_quad_trace (null: off)
   long long quad_trace_problem;
 };
@@ -236,6 +242,15 @@ void attach_quad_kernel(okx_program* p) {
   if (hipModuleGetFunction(&p->quad_fn_tan_u, mod, "okx_quad_tangent_u") != hipSuccess ||
       hipModuleGetFunction(&p->quad_fn_tan_g, mod, "okx_quad_tangent_g") != hipSuccess)
     p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
+  p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
+  p->head_dev = nullptr;
+  p->head_lambda0 = std::nan("");
+  if (p->quad_ppw == 16 && hipModuleGetFunction(&p->quad_fn_head_u, mod, "okx_quad_head_u") == hipSuccess &&
+      hipModuleGetFunction(&p->quad_fn_head_g, mod, "okx_quad_head_g") == hipSuccess) {
+    const size_t bytes = sizeof(double) * (size_t)okx::quad_head_stride(p->host.n_free, p->host.n_targets);
+    if (hipMalloc((void**)&p->head_dev, bytes) != hipSuccess) p->head_dev = nullptr;
+  }
+  if (!p->head_dev) p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
   (void)hipGetLastError();  // optional kernels absent from a module must not leave a sticky error behind
   p->quad_waves_per_cu = 4 * per_simd;
 }
@@ -268,7 +283,7 @@ void okx_default_opts(okx_solve_opts* o) {
   o->kernel = 0;
   o->confirm_full_pass = 0;
   o->predictor = 0;
-  o->pad = 0;
+  o->shared_first_step = 1;
 }
 
 int32_t okx_device_count(void) {
@@ -346,6 +361,8 @@ void okx_program_destroy(okx_program* p) {
   if (!p) return;
   if (p->quad_mod) (void)hipModuleUnload(p->quad_mod);
   if (p->predictor_dev) (void)hipFree(p->predictor_dev);
+  if (p->head_dev) (void)hipFree(p->head_dev);
+  if (p->head_geom_dev) (void)hipFree(p->head_geom_dev);
   if (p->dev) (void)hipFree(p->dev);
   delete p;
 }
@@ -491,6 +508,49 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     q.predictor = (opts->predictor != 0 && !d_geom_pos) ? p->predictor_dev : nullptr;
     q.predictor_mode = opts->predictor;
     q.predictor_len = p->predictor_len;
+    q.head = nullptr;
+    if (p->quad_fn_head_u && opts->shared_first_step != 0 && opts->grad_tol <= 0.0 && p->host.n_targets > 0) {
+      // Shared first step: the design state's Jacobian, J^T J and damped factorisation are common to every problem
+      // of a geometry, so they are evaluated once per geometry (one quad each) instead of once per chain head.
+      okx::QuadHeadArgs h;
+      h.geom_pos = d_geom_pos;
+      h.geom_row_param = d_geom_row_param;
+      h.lambda0 = opts->lambda0;
+      h.design_pos = q.design_pos;
+      h.row_param = q.row_param;
+      h.dop_param = q.dop_param;
+      void* hargs[] = {(void*)&h};
+      if (!d_geom_pos) {
+        if (!(p->head_lambda0 == opts->lambda0)) {  // own geometry: once per lambda0, then cached
+          h.head = p->head_dev;
+          h.n_geometries = 1;
+          HIP_TRY(hipModuleLaunchKernel(p->quad_fn_head_u, 1, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, hargs, nullptr));
+          p->head_lambda0 = opts->lambda0;
+        }
+        q.head = p->head_dev;
+      } else {
+        const long long n_geom = n_problems / spg;
+        if (n_geom > p->head_geom_cap) {
+          // grow-only scratch; earlier launches may still read the old table
+          if (p->head_geom_dev) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(p->head_geom_dev);
+            p->head_geom_dev = nullptr;
+            p->head_geom_cap = 0;
+          }
+          const size_t bytes = sizeof(double) * (size_t)n_geom * (size_t)okx::quad_head_stride(p->host.n_free, p->host.n_targets);
+          HIP_TRY(hipMalloc((void**)&p->head_geom_dev, bytes));
+          p->head_geom_cap = n_geom;
+        }
+        h.head = p->head_geom_dev;
+        h.n_geometries = n_geom;
+        const long long head_waves = (n_geom + 15) / 16;
+        const long long head_cap = (long long)p->n_cu * p->quad_waves_per_cu;
+        HIP_TRY(hipModuleLaunchKernel(p->quad_fn_head_g, (int)(head_waves < head_cap ? head_waves : head_cap), 1, 1, okx::kWave, 1, 1,
+                                      0, (hipStream_t)stream, hargs, nullptr));
+        q.head = p->head_geom_dev;
+      }
+    }
     const long long wave_units = (units + p->quad_ppw - 1) / p->quad_ppw;
     const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
     const int grid = (int)(wave_units < cap ? (wave_units < 1 ? 1 : wave_units) : cap);

@@ -942,6 +942,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
       int nfev = 0, iters = 0, flags = 0;
       double F = 0.0, g = 0.0, dx = 0.0, lambda = 0.0, dmax = 0.0, nu = 2.0;
       double last_step = 0.0, step_len = 0.0, prev_step = 0.0;
+      double piv_lo = 0.0, piv_hi = 0.0;  // pivot range of the last successful factorisation
       double xt = x;
       bool first = true;
       for (;;) {
@@ -1027,6 +1028,8 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
           flags |= OKX_INFO_FAILED;
           break;
         }
+        piv_lo = pmin - lambda;  // what the damping did not put there
+        piv_hi = pmax;
         OKX_STAMP(7)
         step_len = wave_max(lane < n ? fabs(dx) : 0.0);
         if (step_len <= args.step_tol) {
@@ -1071,6 +1074,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
       for (int i = lane; i < m; i += kWave) ra = fmax(ra, reference_abs_residual(P, S, i, cur));
       const double max_res = wave_max(ra);
       if (max_res > args.residual_tolerance) flags |= OKX_INFO_RESIDUAL_EXCEEDED;
+      if (piv_hi > 0.0 && piv_lo <= OKX_ILL_CONDITIONED_PIVOT_RATIO * piv_hi) flags |= OKX_INFO_ILL_CONDITIONED;
       double* out = args.out_pos + b * 3 * P->n_out;
       for (int e = lane; e < 3 * P->n_out; e += kWave) out[e] = S.pos[3 * P->out_point[e / 3] + e % 3];
       if (lane == 0) {

@@ -34,7 +34,27 @@ struct QuadArgs {
   const double* predictor;  // chain-head polynomial model (okx_program_fit_predictor) or null
   long long predictor_mode; // 2: every chain step starts from the model
   long long predictor_len;  // doubles in the table
+  const double* head;       // per-geometry first-step table (okx_quad_head_u/_g) or null
 };
+
+// Arguments of the generated `okx_quad_head_u/_g` (mirrors `struct QHeadArgs`): one quad per geometry evaluates the
+// design state once and tabulates the first Levenberg-Marquardt step of every chain head of that geometry.
+struct QuadHeadArgs {
+  const double* geom_pos;
+  const double* geom_row_param;
+  double* head;
+  long long n_geometries;
+  double lambda0;
+  const double* design_pos;
+  const double* row_param;
+  const double* dop_param;
+};
+// doubles per geometry in that table: Q[k][F][4], M[j][k], N[j][k] for k = constraint gradient + one per target, 8 scalars
+// (okx_quadgen.cpp)
+inline int quad_head_stride(int n_free, int n_targets) {
+  const int k = n_targets + 1;
+  return 4 * n_free * k + 2 * k * k + 8;
+}
 
 // Arguments of the generated parity kernel `okx_quad_eval` (mirrors `struct QEvalArgs`).
 struct QuadEvalArgs {

@@ -1020,6 +1020,7 @@ struct QArgs {
   const double* predictor;  // polynomial model of the solution over the fitted target range for chain heads (null: off)
   long long predictor_mode; // 2: every chain step starts from the model, not only the heads
   long long predictor_len;  // doubles in the table
+  const double* head;       // per-geometry first-step table of okx_quad_head_u/_g (null: every chain head takes its own first pass)
 };
 #define EPS_SQ 1e-12
 #define EPS 1e-6
@@ -1030,6 +1031,8 @@ DEV double ld3(const double* p, int c) { const double v = *p; return c < 3 ? v :
 #define INFO_CONVERGED 1
 #define INFO_RESIDUAL_EXCEEDED 2
 #define INFO_FAILED 4
+#define INFO_ILL_CONDITIONED 8
+#define ILL_CONDITIONED_PIVOT_RATIO 1e-12
 
 // DPP quad_perm of a double (2 x v_mov_b32_dpp): lane l of every quad reads lane sel[l].
 // (mov_dpp, not update_dpp: every lane of a quad_perm has a valid source, so there is no "old"
@@ -1165,6 +1168,17 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     if (!lt.hoisted.empty()) light_ok = false;  // would need loads the main body did not hoist
     light_src = lt.out;
   }
+
+  // Shared first step of the chain heads (single mode): layout of one geometry's table, in doubles:
+  // Q[k][F][4] (lane components, 0 in slot 3), M[j][k] = Q_j . G_k, N[j][k] = Q_j . Q_k, then
+  // dmax, min pivot, sum of squared constraint residuals, max |constraint residual|, ok, max pivot, 0, 0.
+  // Column k = 0 is the constraint rows' own gradient G_0 = Jc^T rc at the design state (the reference's distance
+  // rows carry softnorm's -1e-6 offset there, constraints.py:125-134, so it is small but not zero) with weight 1;
+  // column k = t + 1 belongs to target t: G_k = J^T e_t, weight = that target's residual.  Q_k = (J^T J + lambda I)^-1 G_k.
+  const bool head_ok = !pv && T >= 1 && getenv("OKX_QUAD_NO_HEAD") == nullptr;
+  const int HK = T + 1;
+  const int head_off = 4 * nf * HK + 2 * HK * HK;
+  const int head_stride = head_off + 8;
 
   // ---- pair mode: the row joining the two halves (distance between a point and its mirror image) ----
   // Each side sees d = partner - own; residual and cost terms are bit-identical on both sides
@@ -1448,8 +1462,48 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      int nfev = 0, iters = 0, flags = 0, nfail = 0;");
   g.f("      int mode = 0;  // 0 first evaluation, 1 trial point, 2 re-evaluation of the accepted point");
   g.f("      bool done = !valid, want_light = false;");
-  g.f("      double prev_sl = 0.0;");
+  g.f("      double prev_sl = 0.0, piv_lo = 0.0, piv_hi = 0.0;  // pivot range of the last successful factorisation");
   for (int F = 0; F < nf; ++F) g.f("      dx%d = 0.0;", F);
+  if (head_ok) {
+    // Shared first step.  A chain head starts at its geometry's design state, where the constraint
+    // residuals vanish and the Jacobian, J^T J and its damped factorisation are the same for EVERY problem of that
+    // geometry: only the target residuals differ.  The first LM step is therefore dx = -sum_t r_t Q_t with
+    // Q_t = (J^T J + lambda I)^-1 J^T e_t tabulated once per geometry (okx_quad_head_*), and the problem enters the
+    // loop below exactly where its own first pass would have left it: trial point x + dx in hand (mode 1), cost and
+    // damping of the design state, predicted reduction 0.5 (lambda |dx|^2 - dx . g) from the table's Gram matrices.
+    g.f("      if (a.head != nullptr && a.grad_tol <= 0.0) {");
+    g.f("        const bool at_design = valid && hist == 1 && !from_model;  // x is this geometry's design state");
+    g.f("        if (wave_any(at_design)) {");
+    g.f("          const double* hp = a.head + (PG ? geom * %d : 0);", head_stride);
+    g.f("          const double hr0 = 1.0;  // weight of the constraint rows' own gradient");
+    for (int t = 0; t < T; ++t) g.f("          const double hr%d = td%d - tv%d;  // target residual at the design state", t + 1, t, t);
+    for (int F = 0; F < nf; ++F) {
+      std::string e;
+      for (int k = 0; k < HK; ++k) e += (k ? " + hr" : "hr") + std::to_string(k) + " * hp[" + std::to_string(4 * (k * nf + F)) + " + c]";
+      g.f("          const double hx%d = -(%s);", F, e.c_str());
+    }
+    g.f("          double hsl = 0.0, hN = 0.0, hM = 0.0, hss = hp[%d], hmr = hp[%d];", head_off + 2, head_off + 3);
+    for (int F = 0; F < nf; ++F) g.f("          hsl = fmax(hsl, fabs(hx%d));", F);
+    g.f("          hsl = PMAX(hsl);");
+    for (int j = 0; j < HK; ++j)
+      for (int k = 0; k < HK; ++k)
+        g.f("          hM = fma(hr%d * hr%d, hp[%d], hM); hN = fma(hr%d * hr%d, hp[%d], hN);", j, k, 4 * nf * HK + j * HK + k, j, k,
+            4 * nf * HK + HK * HK + j * HK + k);
+    for (int t = 1; t < HK; ++t) g.f("          hss = fma(hr%d, hr%d, hss); hmr = fmax(hmr, fabs(hr%d));", t, t, t);
+    g.f("          if (at_design && hp[%d] > 0.5) {", head_off + 4);
+    for (int F = 0; F < nf; ++F) g.f("            dx%d = hx%d;", F, F);
+    g.f("            Fc = 0.5 * hss; mres = hmr; dmax = hp[%d]; lambda = a.lambda0 * dmax;", head_off);
+    g.f("            step_len = hsl; pred = 0.5 * fma(lambda, hN, hM); iters = 1; mode = 1;");
+    g.f("            piv_lo = hp[%d] - lambda; piv_hi = hp[%d];", head_off + 1, head_off + 5);
+    g.f("            if (hsl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = hsl; done = true; }");
+    g.f("            else {");
+    g.f("              want_light = hsl <= 1e-3 && (100.0 * lambda / hp[%d] + hsl) * hsl <= a.step_tol;", head_off + 1);
+    g.f("              prev_sl = hsl;");
+    g.f("            }");
+    g.f("          }");
+    g.f("        }");
+    g.f("      }");
+  }
   g.f("      while (wave_any(!done)) {");
   if (light_ok) {
     // Confirming pass: every active problem of this wavefront has a step in hand that is
@@ -1594,6 +1648,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    if (solve_now) {");
   g.f("      ++iters;");
   g.f("      if (ok) {");
+  g.f("        piv_lo = pmin - lambda; piv_hi = pmax;  // what the damping did not put there");
   for (int F = 0; F < nf; ++F) g.f("        dx%d = nx%d;", F, F);
   g.f("        step_len = sl; pred = pr;");
   g.f("        if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
@@ -1630,6 +1685,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.out += fin.out;
   const std::string final_src = fin.out;
   g.f("    if (mres > a.residual_tolerance) flags |= INFO_RESIDUAL_EXCEEDED;");
+  g.f("    if (piv_hi > 0.0 && piv_lo <= ILL_CONDITIONED_PIVOT_RATIO * piv_hi) flags |= INFO_ILL_CONDITIONED;");
   // Record stores.  Independent problems (chain_len 1): the 16 problems of a wavefront are
   // consecutive, so their records form one contiguous block; it is transposed through LDS and
   // written with full-width 16-byte-per-lane stores.  Chains: a quad's problems are far apart in
@@ -1924,6 +1980,101 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         waves_per_simd);
     g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_tangent_g(QTanArgs a) { okx_quad_tangent_body<true>(a); }",
         waves_per_simd);
+    g.f("");
+  }
+  if (head_ok) {
+    // ---- first-step table: one quad per geometry evaluates the design state once (rows, J^T J, damped LDL^T) and
+    //      one substitution per target; what every chain head of that geometry starts from (see the solve kernel) ----
+    ev.out.clear();
+    ev.uid = 400000;
+    ev.reset_caches();
+    ev.emit_factor();
+    const std::string factor_src = ev.out;
+    g.f("struct QHeadArgs { const double* geom_pos; const double* geom_row_param; double* head; long long n_geometries; double lambda0;");
+    g.f("  const double* design_pos; const double* row_param; const double* dop_param; };");
+    g.f("template <bool PG> DEV void okx_quad_head_body(const QHeadArgs& a) {");
+    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+    g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+    if (ev.lds_constants) g.out += lds_decl;
+    g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_geometries; wu += gridDim.x) {");
+    g.f("    long long geom = wu * 16 + quad; const bool valid = geom < a.n_geometries; if (!valid) geom = a.n_geometries - 1;");
+    g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * prog_points);
+    g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * prog_crows);
+    g.out += ev.hoisted;
+    for (int p = 0; p < NP; ++p)
+      if (used[p]) g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
+    // targets at their design values: the target rows vanish, ss / mres_new are the constraint rows' alone
+    {
+      ev.reset_caches();
+      ev.out.clear();
+      // active derived points are evaluated by eval_src itself; the design table already holds every point
+      for (int i = P.n_crows; i < P.m; ++i) {
+        const int t = ev.target_of_row(i);
+        const std::string d = ev.dot(Gen::pn(P.row_pts[i][0]), ev.rpv(i, 0));
+        ev.f("    const double tv%d = %s;", t, d.c_str());
+      }
+      g.out += ev.out;
+      ev.out.clear();
+      ev.reset_caches();
+    }
+    g.out += eval_src;
+    g.f("    double diag = 0.0;");
+    for (int F = 0; F < nf; ++F)
+      g.f("    diag = fmax(diag, c == 0 ? %s : (c == 1 ? %s : (c == 2 ? %s : 0.0)));", Gen::A(F, F, 0).c_str(),
+          Gen::A(F, F, 1).c_str(), Gen::A(F, F, 2).c_str());
+    g.f("    diag = PMAX(diag);");
+    g.f("    const double lambda = a.lambda0 * diag;");
+    for (int F = 0; F < nf; ++F)
+      for (int G = 0; G <= F; ++G)
+        if (ev.fillf[F][G]) {
+          for (int k = 0; k < 3; ++k) {
+            if (!(F == G && k == 2)) g.f("    double %s;", Gen::Ln(F, G, k).c_str());
+            if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
+          }
+        }
+    g.out += factor_src;
+    g.f("    double* ho = a.head + geom * %d;", head_stride);
+    std::vector<std::vector<std::string>> rhs_of(HK, std::vector<std::string>(nf, "0.0"));
+    for (int F = 0; F < nf; ++F) rhs_of[0][F] = "gn" + std::to_string(F);  // constraint rows' gradient (target rows vanish here)
+    for (int k = 0; k < HK; ++k) {
+      if (k > 0) {
+        auto it = ev.target_j.find(k - 1);
+        if (it != ev.target_j.end())
+          for (auto& fv : it->second) rhs_of[k][fv.first] = Gen::sx(fv.second);
+      }
+      ev.out.clear();
+      const std::string outn = "hq" + std::to_string(k) + "_";
+      ev.emit_substitute(rhs_of[k], outn.c_str());
+      g.f("    // column %d: Q_k = (J^T J + lambda I)^-1 G_k", k);
+      // emit_substitute declares y{F} afresh: one scope per column, results copied out
+      for (int F = 0; F < nf; ++F) g.f("    double hQ%d_%d;", k, F);
+      g.f("    {");
+      g.out += ev.out;
+      for (int F = 0; F < nf; ++F) g.f("    hQ%d_%d = %s%d;", k, F, outn.c_str(), F);
+      g.f("    }");
+      g.f("    if (valid) {");
+      for (int F = 0; F < nf; ++F) g.f("      ho[%d + c] = c < 3 ? hQ%d_%d : 0.0;", 4 * (k * nf + F), k, F);
+      g.f("    }");
+    }
+    for (int j = 0; j < HK; ++j)
+      for (int k = 0; k < HK; ++k) {
+        std::string em, en;
+        for (int F = 0; F < nf; ++F) {
+          if (rhs_of[k][F] != "0.0") em += (em.empty() ? "" : " + ") + ("hQ" + std::to_string(j) + "_" + std::to_string(F)) + " * (" + rhs_of[k][F] + ")";
+          en += (en.empty() ? "" : " + ") + ("hQ" + std::to_string(j) + "_" + std::to_string(F)) + " * hQ" + std::to_string(k) + "_" + std::to_string(F);
+        }
+        if (em.empty()) em = "0.0";
+        g.f("    { const double vm = PSUM(%s), vn = PSUM(%s);", em.c_str(), en.c_str());
+        g.f("      if (valid && c == 0) { ho[%d] = vm; ho[%d] = vn; } }", 4 * nf * HK + j * HK + k, 4 * nf * HK + HK * HK + j * HK + k);
+      }
+    g.f("    if (valid && c == 0) {");
+    g.f("      ho[%d] = diag; ho[%d] = pmin; ho[%d] = ss; ho[%d] = mres_new; ho[%d] = ok ? 1.0 : 0.0; ho[%d] = pmax; ho[%d] = 0.0; ho[%d] = 0.0;",
+        head_off, head_off + 1, head_off + 2, head_off + 3, head_off + 4, head_off + 5, head_off + 6, head_off + 7);
+    g.f("    }");
+    g.f("  }");
+    g.f("}");
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_head_u(QHeadArgs a) { okx_quad_head_body<false>(a); }", waves_per_simd);
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_head_g(QHeadArgs a) { okx_quad_head_body<true>(a); }", waves_per_simd);
     g.f("");
   }
   g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_solve_u(QArgs a) { okx_quad_body<false>(a); }",

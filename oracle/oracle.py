@@ -17,7 +17,7 @@ from open_kinematics_amd._abi import HostProgram, ProgramDesc
 from open_kinematics_amd.program import ConstraintProgram
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libokx_oracle.so")
+_LIB_PATH = os.environ.get("OKX_ORACLE_LIB") or os.path.join(_HERE, "libokx_oracle.so")  # override: sanitizer build (tests)
 _f64p = C.POINTER(C.c_double)
 
 
@@ -63,7 +63,8 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
+        if "OKX_ORACLE_LIB" not in os.environ:
+            build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.okx_oracle_eval.restype = C.c_int32
         _lib.okx_oracle_eval.argtypes = [C.POINTER(ProgramDesc), C.c_int64, _f64p, _f64p, _f64p, _f64p]
