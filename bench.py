@@ -554,8 +554,14 @@ def run_c2(args, world: int, rank: int, device) -> dict:
             "start": ("fitted chain-head model (--start model; NOT the section 8d rule)" if use_model else
                       "every one of the 16384 solves per GPU is an independent cold start from the design state "
                       "(SURVEY.md section 8d; reference solver.py:710): chain_len=-1 resolves to chains of length 1 because the "
-                      "16384 steps fit the chip's 16384 resident problem slots"),
+                      "16384 steps fit the chip's 16384 resident problem slots.  The Levenberg-Marquardt pass AT the design "
+                      "state (Jacobian, J^T J, damped factorisation) is identical for every problem of a geometry, so it is "
+                      "evaluated once per geometry (okx_quad_head_u: one wavefront at program set-up, cached per lambda0) "
+                      "and each problem takes its first step from that table, then iterates on its own "
+                      "(okx_solve_opts.shared_first_step, default on; the same launch with every problem running its own "
+                      "first pass is reported under own_first_pass)"),
             "lm_evaluations_mean": nfev_mean,
+            "lm_evaluations_note": "evaluations each problem ran itself; the shared design-state pass is not counted",
             "predictor": bool(use_model),
             "all_converged": ok,
             "exchange": ("RCCL all-gather of the solved free coordinates every step (every rank rebuilds all positions from "
@@ -599,6 +605,12 @@ def run_c2(args, world: int, rank: int, device) -> dict:
                             "collective": "all_gather_into_tensor (RCCL)" if not args.rehearse_on_one_gpu else "gloo (rehearsal)"}
     if world == 1 and not args.no_extras:
         extra_steps = max(5, min(args.steps, 50))
+        own = dp.plan(targets, out=pipe.local[0], info_out=info, chain_len=args.chain_len, predictor=False, shared_first_step=False)
+        own_wall, own_ms = time_launches(own, args.steps, args.warmup, device)
+        own_nfev, own_ok = info_summary(info)
+        line["own_first_pass"] = {"value": (hi - lo) / own_wall, "kernel_ms": own_ms, "lm_evaluations_mean": own_nfev,
+                                  "all_converged": own_ok,
+                                  "note": "shared_first_step=0: every problem evaluates the design state itself (round-1 behaviour)"}
         line["with_model"] = measure_with_model(program, targets, device, args.steps, args.warmup)
         line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, extra_steps, dict(chain_len=args.chain_len, predictor=False))
         dp.close()

@@ -886,7 +886,7 @@ class Gen {
         f("    const double piv = QB%d(%s);", k, A(G, G, k).c_str());
         f("    ok = ok && piv > 0.0;  // a failed factor is never used: no need to sanitise the pivot");
         f("    pmin = fmin(pmin, piv); pmax = fmax(pmax, piv);");
-        f("    const double rinv = fast_rcp(piv);");
+        f("    const double rinv = pivot_rcp(piv);");
         f("    dinv%d = fma(e%d, rinv, dinv%d);", G, k, G);
         // factor entries of this column (rows below the pivot)
         if (k < 2) f("    %s = c > %d ? %s * rinv : 0.0;", Ln(G, G, k).c_str(), k, A(G, G, k).c_str());
@@ -1037,6 +1037,9 @@ DEV double ld3(const double* p, int c) { const double v = *p; return c < 3 ? v :
 // DPP quad_perm of a double (2 x v_mov_b32_dpp): lane l of every quad reads lane sel[l].
 // (mov_dpp, not update_dpp: every lane of a quad_perm has a valid source, so there is no "old"
 // value to preserve and no v_mov to initialise it.)
+// (The same permutations through the LDS crossbar - ds_swizzle_b32 in quad-permute mode, which issues on the LDS pipe
+// instead of the vector ALU - were measured: only the J^T J accumulation's broadcasts 28.9 vs 28.5 us on C2, all of
+// them 39.9 us.  One wavefront per SIMD cannot hide the crossbar's latency.)
 template <int CTRL> DEV double qperm(double v) {
   int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
   int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
@@ -1066,13 +1069,19 @@ DEV double fast_rcp(double x) {
   e = fma(-x, r, 1.0);
   return fma(e, r, r);
 }
+// v_rcp_f64 / v_rsq_f64 deliver 2^-24.3 (measured on MI355X over 2^20 arguments, profiles/r02/README.md).
+// Reciprocal of a pivot: ONE Newton step (2^-48.6).  The factor only steers the Levenberg-Marquardt step (and the
+// tangents to 1e-9): a 2e-15 relative error in L is far inside what the damping already does to it.
+DEV double pivot_rcp(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+// sqrt(x) to the last bit or so and 1 / sqrt(x) to 4e-15: one Goldschmidt step (both to ~1.5 * 2^-48.4), then the
+// residual correction of the root (x - g^2 is exact in the fma), which squares its error.
 DEV void fast_sqrt_rsqrt(double x, double* root, double* inv) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
+  const double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   h = fma(h, r, h);
   const double d = fma(-g, g, x);
