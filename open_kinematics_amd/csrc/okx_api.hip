@@ -625,35 +625,35 @@ int32_t okx_program_fit_predictor(okx_program* p, const double* lo, const double
     for (int t = 0; t < T; ++t) targets[(size_t)k * T + t] = mid[t];
     for (int j = 0; j < d; ++j) targets[(size_t)k * T + vary[j]] = mid[vary[j]] + half[vary[j]] * node[digit(k, j)];
   }
-  double *d_t = nullptr, *d_out = nullptr;
-  okx_info* d_info = nullptr;
+  // one scratch allocation for the node solve: targets | positions | info records
   const size_t out_doubles = (size_t)S * H.n_out * 3;
-  HIP_TRY(hipMalloc(&d_t, targets.size() * sizeof(double)));
-  hipError_t e1 = hipMalloc(&d_out, out_doubles * sizeof(double));
-  hipError_t e2 = hipMalloc(&d_info, (size_t)S * sizeof(okx_info));
+  const size_t bytes_t = targets.size() * sizeof(double), bytes_out = out_doubles * sizeof(double);
+  const size_t bytes_info = (size_t)S * sizeof(okx_info);
+  char* d_scratch = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_scratch, bytes_t + bytes_out + bytes_info));
+  double* d_t = reinterpret_cast<double*>(d_scratch);
+  double* d_out = reinterpret_cast<double*>(d_scratch + bytes_t);
+  okx_info* d_info = reinterpret_cast<okx_info*>(d_scratch + bytes_t + bytes_out);
   std::vector<double> out(out_doubles);
   std::vector<okx_info> info((size_t)S);
   int32_t rc = OKX_OK;
-  if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(OKX_ERR_DEVICE, "hipMalloc failed");
-  if (rc == OKX_OK) {
+  {
     okx_solve_opts o;
     okx_default_opts(&o);
     o.chain_len = 1;
     o.kernel = 3;
     o.confirm_full_pass = 1;  // end on a computed correction: the fit wants every digit
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemcpyAsync(d_t, targets.data(), targets.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+    if (hipMemcpyAsync(d_t, targets.data(), bytes_t, hipMemcpyHostToDevice, st) != hipSuccess)
       rc = fail(OKX_ERR_DEVICE, "copy failed");
     if (rc == OKX_OK) rc = okx_solve_batch(p, &o, S, d_t, nullptr, nullptr, d_out, d_info, stream);
     if (rc == OKX_OK &&
-        (hipMemcpyAsync(out.data(), d_out, out_doubles * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
-         hipMemcpyAsync(info.data(), d_info, (size_t)S * sizeof(okx_info), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        (hipMemcpyAsync(out.data(), d_out, bytes_out, hipMemcpyDeviceToHost, st) != hipSuccess ||
+         hipMemcpyAsync(info.data(), d_info, bytes_info, hipMemcpyDeviceToHost, st) != hipSuccess ||
          hipStreamSynchronize(st) != hipSuccess))
       rc = fail(OKX_ERR_DEVICE, "node solve failed: %s", hipGetErrorString(hipGetLastError()));
   }
-  (void)hipFree(d_t);
-  (void)hipFree(d_out);
-  (void)hipFree(d_info);
+  (void)hipFree(d_scratch);
   if (rc != OKX_OK) return rc;
   for (long long k = 0; k < S; ++k)
     if (!(info[k].flags & OKX_INFO_CONVERGED) || (info[k].flags & (OKX_INFO_FAILED | OKX_INFO_RESIDUAL_EXCEEDED)))

@@ -183,6 +183,9 @@ class Gen {
   }
 
   // ---- quad data movement ----
+  int row_fence = 0;  // > 0: a scheduling barrier after every row_fence rows of the evaluation
+  bool fence_after_row = false;
+  int col_fence = 0;  // > 0: a scheduling barrier after every col_fence columns of the factorisation
   std::string bcast(const std::string& n, int r) {
     std::vector<std::string>& slot = bc_[n];
     if (slot.empty()) slot.resize(3);
@@ -578,7 +581,7 @@ class Gen {
         std::string g1 = tmp("g"), g2 = tmp("g");
         f("    const double %s = %s * %s - %s * %s;", g1.c_str(), ka.c_str(), w1.c_str(), kb.c_str(), v2.c_str());
         f("    const double %s = %s * %s - %s * %s;", g2.c_str(), ka.c_str(), w2.c_str(), kb.c_str(), v1.c_str());
-        f("    const double %s = lean_atan2_pos(%s - EPS, %s) - %s;", r.c_str(), s.c_str(), dt.c_str(),
+        f("    const double %s = lean_atan2_pos<%s>(%s - EPS, %s, %s) - %s;", r.c_str(), pv ? "true" : "false", s.c_str(), dt.c_str(), pv ? "atl" : "nullptr",
           rp(i, 0).c_str());
         if (type == OKX_ROW_ANGLE) {
           ro->partial.push_back({pts[0], {g1, -1}});
@@ -831,6 +834,7 @@ class Gen {
         }
       }
       if (P.row_type[i] == kRowTarget) target_j[(int)P.row_param[i][3]] = jv;
+      if (row_fence > 0 && (i + 1) % row_fence == 0) fence_after_row = true;
       // J^T r and J^T J (lower block triangle: F >= G)
       for (auto& fv : jv) f("    gn%d = fma(%s, %s, gn%d);", fv.first, sx(fv.second).c_str(), ro.r.c_str(), fv.first);
       for (size_t ia = 0; ia < jv.size(); ++ia)
@@ -851,6 +855,11 @@ class Gen {
             }
           }
         }
+      if (fence_after_row) {
+        // keep the scheduler from interleaving many rows' temporaries (the kernel is register-bound)
+        f("    __builtin_amdgcn_sched_barrier(0);");
+        fence_after_row = false;
+      }
     }
     // diagonal blocks that no row touched still exist (as zeros)
     for (int F = 0; F < nf; ++F)
@@ -907,6 +916,7 @@ class Gen {
           }
         }
         f("    }");
+        if (col_fence > 0 && (3 * G + k + 1) % col_fence == 0) f("    __builtin_amdgcn_sched_barrier(0);");
       }
     for (int F = 0; F < nf; ++F)
       for (int G = 0; G < nf; ++G) fillf[F][G] = fill[F][G];
@@ -1090,7 +1100,17 @@ DEV void fast_sqrt_rsqrt(double x, double* root, double* inv) {
   *inv = h + h;
 }
 // atan2(y, x), y >= 0, result in [0, pi]: fdlibm-style reduction + odd polynomial (see okx_kernels.hip).
-DEV double lean_atan2_pos(double y, double x) {
+// In the register-bound pair kernels (TAB) the eleven polynomial coefficients are READ WHERE THEY ARE USED, from a table in LDS (`tab`, filled once per
+// workgroup from kAtanCoef; every lane reads the same address: a broadcast), through an index the optimiser cannot see
+// through.  As literals they are loop invariants: the compiler materialises them ahead of the Levenberg-Marquardt loop,
+// runs out of scalar registers, parks them in vector registers and - in the register-bound pair kernel - spills them
+// to scratch, from where every angle row then re-reads them one dependent load at a time (profiles/r02/c3_*).
+__constant__ double kAtanCoef[12] = {
+    3.33333333333329318027e-01, 1.42857142725034663711e-01, 9.09088713343650656196e-02, 6.66107313738753120669e-02,
+    4.97687799461593236017e-02, 1.62858201153657823623e-02,
+    -1.99999999998764832476e-01, -1.11111104054623557880e-01, -7.69187620504482999495e-02, -5.83357013379057348645e-02,
+    -3.65315727442169155270e-02, 0.0};
+template <bool TAB> DEV double lean_atan2_pos(double y, double x, const double* tab) {
   const double ax = fabs(x);
   if (!(y > 0.0)) return x >= 0.0 ? 0.0 : 3.14159265358979311600e+00;
   if (ax == 0.0) return 1.57079632679489655800e+00;
@@ -1102,10 +1122,18 @@ DEV double lean_atan2_pos(double y, double x) {
   else if (t < 2.4375) { hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; t = (t - 1.5) * fast_rcp(1.0 + 1.5 * t); }
   else { hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; t = -fast_rcp(t); }
   const double z = t * t, w = z * z;
-  const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
-                    w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
-  const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
-                    w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+  double s1, s2;
+  if (TAB) {
+    int k0 = 0; asm volatile("" : "+v"(k0));
+    const double* ct = tab + k0;
+    s1 = z * (ct[0] + w * (ct[1] + w * (ct[2] + w * (ct[3] + w * (ct[4] + w * ct[5])))));
+    s2 = w * (ct[6] + w * (ct[7] + w * (ct[8] + w * (ct[9] + w * ct[10]))));
+  } else {  // kernels with registers to spare keep the coefficients as literals
+    s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+         w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+         w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+  }
   const double at = hi - ((t * (s1 + s2) - lo) - t);
   return x > 0.0 ? at : 3.14159265358979311600e+00 - (at - 1.2246467991473531772e-16);
 }
@@ -1145,6 +1173,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // ---- evaluation body (rows + normal equations), generated first to learn the sparsity ----
   Gen ev(P, pv);
   ev.lds_constants = pv != nullptr || getenv("OKX_QUAD_LDS") != nullptr;
+  if (const char* env = getenv(pv ? "OKX_PAIR_ROW_FENCE" : "OKX_QUAD_ROW_FENCE")) ev.row_fence = atoi(env);
+  if (const char* env = getenv(pv ? "OKX_PAIR_COL_FENCE" : "OKX_QUAD_COL_FENCE")) ev.col_fence = atoi(env);
   for (int e = 0; e < P.n_derived; ++e) ev.dp(e);  // every derived-op parameter is chain-constant
   ev.f("    // ---- active derived points with chain-rule blocks ----");
   for (int idx = 0; idx < P.n_active; ++idx)
@@ -1164,7 +1194,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // confirming evaluation (residuals only).  Not offered for programs with the reference's
   // zero-gradient point-on-line row: along that row's valley the step length says nothing about
   // the distance to the minimiser, so those always take full passes.
-  bool light_ok = true;
+  bool light_ok = getenv("OKX_QUAD_NO_LIGHT") == nullptr;  // (experiment switch: no residual-only confirming pass)
   for (int i = 0; i < P.n_crows; ++i) light_ok = light_ok && P.row_type[i] != OKX_ROW_POINT_ON_LINE;
   std::string light_src;
   if (light_ok) {
@@ -1185,6 +1215,23 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // rows carry softnorm's -1e-6 offset there, constraints.py:125-134, so it is small but not zero) with weight 1;
   // column k = t + 1 belongs to target t: G_k = J^T e_t, weight = that target's residual.  Q_k = (J^T J + lambda I)^-1 G_k.
   const bool head_ok = !pv && T >= 1 && getenv("OKX_QUAD_NO_HEAD") == nullptr;
+  bool has_atan = false;
+  for (int i = 0; i < P.n_crows; ++i)
+    has_atan = has_atan || P.row_type[i] == OKX_ROW_ANGLE || P.row_type[i] == OKX_ROW_THREE_POINT_ANGLE;
+  const std::string atan_decl = !(has_atan && pv) ? std::string() :
+      "  __shared__ double atl[12];  // atan2's polynomial coefficients, read at their use (lean_atan2_pos)\n"
+      "  if (threadIdx.x < 12) atl[threadIdx.x] = kAtanCoef[threadIdx.x];\n"
+      "  __syncthreads();\n";
+  // Pair mode: the quad-uniform Levenberg-Marquardt scalars and the chain's target history live in LDS, one slot per
+  // quad side like the chain constants (all lanes of a quad write the same value).  Left in registers the compiler
+  // spills them to scratch, and the pass re-reads ~60 of them from there at memory latency (profiles/r02/c3_*).
+  const bool pair_state_lds = pv && getenv("OKX_PAIR_STATE_REGS") == nullptr;
+  int n_state_slots = 0;
+  auto state_ref = [&](const std::string& name, const std::string& init) {
+    // declaration of one per-quad scalar: a register, or a reference into lms[slot][quad side]
+    if (!pair_state_lds) return "double " + name + " = " + init + ";";
+    return "double& " + name + " = lms[" + std::to_string(16 * n_state_slots++) + " + qs]; " + name + " = " + init + ";";
+  };
   const int HK = T + 1;
   const int head_off = 4 * nf * HK + 2 * HK * HK;
   const int head_stride = head_off + 8;
@@ -1256,6 +1303,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1_lane = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
   else
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+  g.out += atan_decl;
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
   if (!pv) g.f("  __shared__ double pls[%d];  // LDS copy of the chain-head predictor's table", kPredictorLdsDoubles);
   const std::string lds_decl =
@@ -1297,15 +1345,30 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      if (unit_len == 1) { span_idx = unit / spg; chain_in_span = unit - span_idx * spg; }");
   g.f("      else { span_idx = unit / chains_per_span; chain_in_span = unit - span_idx * chains_per_span; }");
   g.f("    }");
+  if (pair_state_lds) {
+    // the chain's index bookkeeping and the table pointers (quad-uniform too) in LDS as well: [slot][quad side]
+    g.f("    __shared__ long long lmi[%d];", 16 * 5);
+    g.f("    long long& first_b = lmi[0 + qs]; first_b = span_idx * span + chain_in_span * unit_len;");
+    g.f("    long long& last_b = lmi[16 + qs]; last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
+    g.f("    long long& geom = lmi[32 + qs]; geom = span_idx;");
+    g.f("#define gp (PG ? a.geom_pos + geom * %d : a.design_pos)", 3 * prog_points);
+    g.f("#define gq (PG ? a.geom_row_param + geom * %d : a.row_param)", 8 * prog_crows);
+  } else {
   g.f("    const long long first_b = span_idx * span + chain_in_span * unit_len;");
   g.f("    const long long last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
   g.f("    const long long geom = span_idx;");
   g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * prog_points);
   g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * prog_crows);
+  }
   // Every load of the prologue is issued before the first dependent instruction: first-step targets, chain
   // constants, points and (single mode) the predictor table's copy into LDS share one round trip.
-  for (int t = 0; t < T; ++t)
-    g.f("    double tn%d = a.targets[first_b * %d + %s], tp%d = 0.0, tq%d = 0.0, tr%d = 0.0;", t, prog_targets, ev.target_slot(t).c_str(), t, t, t);
+  if (pair_state_lds) g.f("    __shared__ double lms[%d];  // per-quad scalars [slot][quad side]", 16 * (5 * T + 12));
+  for (int t = 0; t < T; ++t) {
+    char init[160];
+    std::snprintf(init, sizeof(init), "a.targets[first_b * %d + %s]", prog_targets, ev.target_slot(t).c_str());
+    g.f("    %s %s %s %s", state_ref("tn" + std::to_string(t), init).c_str(), state_ref("tp" + std::to_string(t), "0.0").c_str(),
+        state_ref("tq" + std::to_string(t), "0.0").c_str(), state_ref("tr" + std::to_string(t), "0.0").c_str());
+  }
   g.f("    // chain-constant lane-component parameters (line points / directions, target directions)");
   g.out += ev.hoisted;
   g.out += couple_hoist;
@@ -1348,6 +1411,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     for (int i = P.n_crows; i < P.m; ++i) {
       const int t = ev.target_of_row(i);
       const std::string d = ev.dot(Gen::pn(P.row_pts[i][0]), ev.rpv(i, 0));
+      if (pair_state_lds)
+        ev.f("    %s  // target %d at the design state (zero on a half that does not carry it)", state_ref("td" + std::to_string(t), d).c_str(), t);
+      else
       ev.f("    const double td%d = %s;  // target %d at the design state (zero on a half that does not carry it)", t, d.c_str(), t);
     }
     g.out += ev.out;
@@ -1355,10 +1421,16 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     ev.reset_caches();
   }
   for (int t = 0; t < T; ++t) g.f("    tp%d = td%d;", t, t);
+  if (pair_state_lds) {
+    g.f("    __shared__ int lmk[%d];  // per-quad counters [slot][quad side]", 16 * 6);
+    g.f("    int& hist = lmk[0 + qs]; hist = 1;                // solved states in the history (the design state counts)");
+    g.f("    int& steps_done = lmk[16 + qs]; steps_done = 0;   // steps of this chain solved since its (re)start");
+  } else {
   g.f("    int hist = 1;        // solved states in the history (the design state counts)");
   g.f("    int steps_done = 0;  // steps of this chain solved since its (re)start");
+  }
   g.f("    bool cold = false;  // the previous chain step failed: restart from the design state, not the predictor");
-  g.f("    double lambda_carry = 0.0;  // damping a converged chain step ended with (0: none)");
+  g.f("    %s  // damping a converged chain step ended with (0: none)", state_ref("lambda_carry", "0.0").c_str());
   // targets: the next step's values are fetched while the current step is being solved, and the two
   // previous steps' values (secant predictor) stay in registers
   if (!pv) {
@@ -1467,11 +1539,24 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      } else if (!from_model) {");
   for (int F = 0; F < nf; ++F) g.f("        xq%d = xp%d; xp%d = x%d;", F, F, F, F);
   g.f("      }");
+  if (pair_state_lds) {
+    // (declared once per chain step: the slots are the same every time)
+    const int first_slot = n_state_slots;
+    g.f("      double lambda = 0.0;");
+    for (const char* name : {"Fc", "dmax", "step_len", "last_step", "mres", "pred", "prev_sl", "piv_lo", "piv_hi"})
+      g.f("      %s", state_ref(name, "0.0").c_str());
+    g.f("      %s", state_ref("nu", "2.0").c_str());
+    n_state_slots = first_slot + 10;
+  } else
   g.f("      double Fc = 0.0, lambda = 0.0, nu = 2.0, dmax = 0.0, step_len = 0.0, last_step = 0.0, mres = 0.0, pred = 0.0;");
+  if (pair_state_lds) {
+    g.f("      int& nfev = lmk[32 + qs]; nfev = 0; int& iters = lmk[48 + qs]; iters = 0; int& nfail = lmk[64 + qs]; nfail = 0;");
+    g.f("      int flags = 0;");
+  } else
   g.f("      int nfev = 0, iters = 0, flags = 0, nfail = 0;");
   g.f("      int mode = 0;  // 0 first evaluation, 1 trial point, 2 re-evaluation of the accepted point");
   g.f("      bool done = !valid, want_light = false;");
-  g.f("      double prev_sl = 0.0, piv_lo = 0.0, piv_hi = 0.0;  // pivot range of the last successful factorisation");
+  if (!pair_state_lds) g.f("      double prev_sl = 0.0, piv_lo = 0.0, piv_hi = 0.0;  // pivot range of the last successful factorisation");
   for (int F = 0; F < nf; ++F) g.f("      dx%d = 0.0;", F);
   if (head_ok) {
     // Shared first step.  A chain head starts at its geometry's design state, where the constraint
@@ -1491,9 +1576,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       for (int k = 0; k < HK; ++k) e += (k ? " + hr" : "hr") + std::to_string(k) + " * hp[" + std::to_string(4 * (k * nf + F)) + " + c]";
       g.f("          const double hx%d = -(%s);", F, e.c_str());
     }
-    g.f("          double hsl = 0.0, hN = 0.0, hM = 0.0, hss = hp[%d], hmr = hp[%d];", head_off + 2, head_off + 3);
-    for (int F = 0; F < nf; ++F) g.f("          hsl = fmax(hsl, fabs(hx%d));", F);
-    g.f("          hsl = PMAX(hsl);");
+    g.f("          double hstep = 0.0, hN = 0.0, hM = 0.0, hss = hp[%d], hmr = hp[%d];", head_off + 2, head_off + 3);
+    for (int F = 0; F < nf; ++F) g.f("          hstep = fmax(hstep, fabs(hx%d));", F);
+    g.f("          hstep = PMAX(hstep);");
     for (int j = 0; j < HK; ++j)
       for (int k = 0; k < HK; ++k)
         g.f("          hM = fma(hr%d * hr%d, hp[%d], hM); hN = fma(hr%d * hr%d, hp[%d], hN);", j, k, 4 * nf * HK + j * HK + k, j, k,
@@ -1502,12 +1587,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("          if (at_design && hp[%d] > 0.5) {", head_off + 4);
     for (int F = 0; F < nf; ++F) g.f("            dx%d = hx%d;", F, F);
     g.f("            Fc = 0.5 * hss; mres = hmr; dmax = hp[%d]; lambda = a.lambda0 * dmax;", head_off);
-    g.f("            step_len = hsl; pred = 0.5 * fma(lambda, hN, hM); iters = 1; mode = 1;");
+    g.f("            step_len = hstep; pred = 0.5 * fma(lambda, hN, hM); iters = 1; mode = 1;");
     g.f("            piv_lo = hp[%d] - lambda; piv_hi = hp[%d];", head_off + 1, head_off + 5);
-    g.f("            if (hsl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = hsl; done = true; }");
+    g.f("            if (hstep <= a.step_tol) { flags |= INFO_CONVERGED; last_step = hstep; done = true; }");
     g.f("            else {");
-    g.f("              want_light = hsl <= 1e-3 && (100.0 * lambda / hp[%d] + hsl) * hsl <= a.step_tol;", head_off + 1);
-    g.f("              prev_sl = hsl;");
+    g.f("              want_light = hstep <= 1e-3 && (100.0 * lambda / hp[%d] + hstep) * hstep <= a.step_tol;", head_off + 1);
+    g.f("              prev_sl = hstep;");
     g.f("            }");
     g.f("          }");
     g.f("        }");
@@ -1701,16 +1786,36 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // memory, each lane stores its own 8-byte components.
   if (pv) {
     g.f("    if (valid && c < 3) {");
-    g.f("      double* o = a.out_pos + bb * %d + c;", 3 * prog_out);
+    // (the record's address is rebuilt from an opaque copy of the problem index: as an induction variable the compiler
+    //  keeps one strength-reduced 64-bit address per output point alive across the chain loop and spills all of them)
+    g.f("      long long bo = bb; asm volatile(\"\" : \"+v\"(bo));");
+    // The two halves' records usually sit a constant distance apart in the output list (left block, right block):
+    // one select on the side bit then serves every store.  Otherwise each store selects its own index, on a fresh
+    // opaque copy of the side bit so that the selects are made here instead of being kept (and spilled) as invariants.
+    long long delta = 0;
+    bool uniform_delta = true, first = true;
     for (int k = 0; k < P.n_out; ++k) {
       const int k0 = pv->out[0][k], k1 = pv->out[1][k];
-      if (k1 >= 0)
-        g.f("      o[%s] = p%d;", Gen::sel(3 * k0, 3 * k1).c_str(), P.out_point[k]);
+      if (k1 < 0) continue;
+      if (first) delta = 3LL * (k1 - k0), first = false;
+      else uniform_delta = uniform_delta && delta == 3LL * (k1 - k0);
+    }
+    g.f("      int q1s = q1; asm volatile(\"\" : \"+v\"(q1s));");
+    if (uniform_delta)
+      g.f("      double* o = a.out_pos + bo * %d + c + (q1s ? %lld : 0);", 3 * prog_out, delta);
+    else
+      g.f("      double* o = a.out_pos + bo * %d + c;", 3 * prog_out);
+    for (int k = 0; k < P.n_out; ++k) {
+      const int k0 = pv->out[0][k], k1 = pv->out[1][k];
+      if (k1 >= 0 && uniform_delta)
+        g.f("      o[%d] = p%d;", 3 * k0, P.out_point[k]);
+      else if (k1 >= 0)
+        g.f("      o[q1s ? %d : %d] = p%d;", 3 * k1, 3 * k0, P.out_point[k]);
       else
-        g.f("      if (!q1) o[%d] = p%d;", 3 * k0, P.out_point[k]);
+        g.f("      if (!q1s) o[%d] = p%d;", 3 * k0, P.out_point[k]);
     }
     for (size_t k = 0; k < pv->shared_out.size(); ++k)
-      g.f("      if (!q1) o[%d] = gp[%d + c];", 3 * pv->shared_out[k], 3 * pv->shared_pt[k]);
+      g.f("      if (!q1s) o[%d] = gp[%d + c];", 3 * pv->shared_out[k], 3 * pv->shared_pt[k]);
     g.f("    }");
     g.f("    if (false) {");
   } else {
@@ -1741,7 +1846,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // chains never continue from a state that failed to converge
   for (int t = 0; t < T; ++t) g.f("    tr%d = tq%d; tq%d = tp%d; tp%d = tv%d;", t, t, t, t, t, t);
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
+  if (pv) {  // restart addresses are built here, from a fresh opaque copy of the side bit, not carried through the kernel
+    g.f("      int q1r = q1; asm volatile(\"\" : \"+v\"(q1r));");
+    g.f("      { const int q1 = q1r; (void)q1;");
+  }
   for (int F = 0; F < nf; ++F) g.f("      x%d = ld3(gp + %s + cc, c);", F, ev.point3(ev.fp(F)).c_str());
+  if (pv) g.f("      }");
   g.f("      hist = 1; steps_done = 0; lambda_carry = 0.0; cold = true;");
   for (int t = 0; t < T; ++t) g.f("      tp%d = td%d;", t, t);
   g.f("    } else {");
@@ -1754,6 +1864,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    }  // chain steps");
   g.f("  }  // wave units");
   g.f("}");
+  if (pair_state_lds) g.f("#undef gp\n#undef gq");
   g.f("");
   if (!pv) {
   // ---- output positions from free coordinates (okx_expand_positions_batch): fixed points from the design table,
@@ -1796,6 +1907,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("  double lambda; long long n_problems; const double* design_pos; const double* row_param; const double* dop_param; };");
   g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_eval(QEvalArgs a) {", waves_per_simd);
   g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+  g.out += atan_decl;
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
   if (ev.lds_constants) g.out += lds_decl;
   g.f("  const double* gp = a.design_pos; const double* gq = a.row_param;");
@@ -1867,6 +1979,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1 = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
     else
       g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+    g.out += atan_decl;
     if (ev.lds_constants) g.out += lds_decl;
     g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
     g.f("  for (long long wu = blockIdx.x; wu * %d < a.n_problems; wu += gridDim.x) {", PPW);
@@ -2003,6 +2116,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("  const double* design_pos; const double* row_param; const double* dop_param; };");
     g.f("template <bool PG> DEV void okx_quad_head_body(const QHeadArgs& a) {");
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+  g.out += atan_decl;
     g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
     if (ev.lds_constants) g.out += lds_decl;
     g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_geometries; wu += gridDim.x) {");

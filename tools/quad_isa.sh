@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instruction mix of the generated quad kernel for a BASELINE program (no GPU needed).
-#   tools/quad_isa.sh dw|mac [waves]
+#   tools/quad_isa.sh dw|mac|axle [waves]
 set -e
 cd "$(dirname "$0")/.."
 which=${1:-dw}; waves=${2:-1}
@@ -10,9 +10,9 @@ python - "$which" <<'PY'
 import sys
 from open_kinematics_amd import _lib
 from open_kinematics_amd._abi import HostProgram
-from open_kinematics_amd.workloads import bump_sweep_problem, macpherson_grid_problem
+from open_kinematics_amd.workloads import axle_grid_problem, bump_sweep_problem, macpherson_grid_problem
 lib = _lib.load()
-program, _ = bump_sweep_problem(5) if sys.argv[1] == "dw" else macpherson_grid_problem(4, 4)
+program, _ = {"dw": lambda: bump_sweep_problem(5), "mac": lambda: macpherson_grid_problem(4, 4), "axle": lambda: axle_grid_problem(4, 4)}[sys.argv[1]]()
 rc = lib.okx_precompile(HostProgram(program).byref())
 print("precompile", rc, _lib.last_error() if rc else "")
 PY
