@@ -227,6 +227,9 @@ def measure_with_model(program, targets, device, steps: int, warmup: int) -> dic
     n = targets.shape[0]
     out = torch.empty((n, program.n_out, 3), dtype=torch.float64, device=device)
     info = torch.empty((n, 40), dtype=torch.uint8, device=device)
+    # one cold sweep first: the fresh program's code object is loaded lazily at its first launch (tens of ms, paid by any
+    # first launch, model or not); what is timed below is what the fit adds on top
+    dp.plan(targets, out=out, info_out=info, chain_len=-1, predictor=False)()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     fitted = dp.fit_predictor(targets)
@@ -320,12 +323,14 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
         program, table, rel = made
         dp = DeviceProgram(program, device)
         spg = rel.shape[0]
-        torch.cuda.synchronize(device)
-        r0 = time.perf_counter()
-        gpos, gparam = dp.rebind(torch.as_tensor(table, device=device))
-        targets = dp.ensemble_targets(gpos, rel)
-        torch.cuda.synchronize(device)
-        rebind_ms = (time.perf_counter() - r0) * 1e3
+        table_dev = torch.as_tensor(table, device=device)
+        for _ in range(2):  # the second round is the one reported: the first pays the lazy load of every kernel involved
+            torch.cuda.synchronize(device)
+            r0 = time.perf_counter()
+            gpos, gparam = dp.rebind(table_dev)
+            targets = dp.ensemble_targets(gpos, rel)
+            torch.cuda.synchronize(device)
+            rebind_ms = (time.perf_counter() - r0) * 1e3
         kw = dict(geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=spg)
     else:
         program, targets_host = made
@@ -640,13 +645,14 @@ def run_c5(args, world: int, rank: int, device) -> dict:
     glo, ghi = shard_range(n_geom, rank, world)
     spans = [tuple(spg * g for g in shard_range(n_geom, r, world)) for r in range(world)]
     table_dev = torch.as_tensor(table, device=device)
-    torch.cuda.synchronize(device)
-    r0 = time.perf_counter()
-    gpos_all, gparam_all = dp.rebind(table_dev)   # replicated inputs (1.5 MB): the receiving side's expand needs every geometry
-    gpos, gparam = gpos_all[glo:ghi].contiguous(), gparam_all[glo:ghi].contiguous()
-    targets = dp.ensemble_targets(gpos, rel)
-    torch.cuda.synchronize(device)
-    rebind_ms = (time.perf_counter() - r0) * 1e3
+    for _ in range(2):  # the second round is the one reported: the first pays the lazy load of every kernel involved
+        torch.cuda.synchronize(device)
+        r0 = time.perf_counter()
+        gpos_all, gparam_all = dp.rebind(table_dev)   # replicated inputs (1.5 MB): the receiving side's expand needs every geometry
+        gpos, gparam = gpos_all[glo:ghi].contiguous(), gparam_all[glo:ghi].contiguous()
+        targets = dp.ensemble_targets(gpos, rel)
+        torch.cuda.synchronize(device)
+        rebind_ms = (time.perf_counter() - r0) * 1e3
     n_local, n_total = (ghi - glo) * spg, n_geom * spg
     out = torch.empty((n_local, program.n_out, 3), dtype=torch.float64, device=device)
     info = torch.empty((n_local, 40), dtype=torch.uint8, device=device)
