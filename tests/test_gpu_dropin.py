@@ -103,3 +103,44 @@ def test_toy_two_link_sweep():
         assert abs(p[2] - z) < 1e-9 and abs(p[1] - 100.0) < 1e-6
         assert abs(np.linalg.norm(p) - length) < 1e-5
     assert all(i.converged for i in infos)
+
+
+def test_repeated_calls_reuse_the_device_program():
+    """solver._PROGRAM_CACHE: the reference's benchmark calls solve_sweep over and over on one suspension."""
+    import time
+
+    from open_kinematics_amd import solver
+    from open_kinematics_amd.input import load_geometry, load_sweep
+    from open_kinematics_amd.sweep import compute_sweep_metrics, solve_sweep
+
+    solver.clear_program_cache()
+    axle = load_geometry(os.path.join(GEOM, "axle_geometry_rocker.yaml"))
+    sweep = load_sweep(os.path.join(GEOM, "axle_rocker_sweep.yaml"), axle)
+    t0 = time.perf_counter()
+    states, infos = solve_sweep(axle, sweep)
+    first = time.perf_counter() - t0
+    assert len(solver._PROGRAM_CACHE) == 1
+    cached = next(iter(solver._PROGRAM_CACHE.values()))
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        again, _ = solve_sweep(axle, sweep)
+        times.append(time.perf_counter() - t0)
+    assert len(solver._PROGRAM_CACHE) == 1 and next(iter(solver._PROGRAM_CACHE.values())) is cached
+    for a, b in zip(states, again):
+        for key in a.positions:
+            assert np.array_equal(a.positions[key].data, b.positions[key].data)
+    assert again[0].positions is not states[0].positions
+    assert min(times) < first  # no upload / generation / code-object load on the way
+    # the metrics entry point shares the cache (its program lists Suspension.output_points(): a second entry)
+    result = compute_sweep_metrics(axle, sweep, states)
+    assert len(result.rows) == len(states) and len(solver._PROGRAM_CACHE) == 2
+    assert result.tangent_solve_infos is not None and len(result.tangent_solve_infos) == len(states)
+    assert all(not info.rank_deficient and info.n_variables == 60 for info in result.tangent_solve_infos)
+    # a different geometry value is a different program
+    other = load_geometry(os.path.join(GEOM, "geometry.yaml"))
+    from open_kinematics_amd.input import load_sweep as load
+    solve_sweep(other, load(os.path.join(GEOM, "bump_sweep.yaml"), other))
+    assert len(solver._PROGRAM_CACHE) == 3
+    solver.clear_program_cache()
+    assert not solver._PROGRAM_CACHE and cached._handle is None
