@@ -50,7 +50,8 @@ struct okx_program {
   long long predictor_len;  // doubles in it
   // shared first step of the chain heads (okx_quad_head_u/_g; null functions: not generated for this program)
   hipFunction_t quad_fn_head_u, quad_fn_head_g;
-  double* head_dev;         // own geometry's table (quad_head_stride doubles), filled on first use per lambda0
+  int head_stride;          // doubles per geometry in the table (okx::quad_head_stride)
+  double* head_dev;         // own geometry's table, filled on first use per lambda0
   double head_lambda0;      // the lambda0 it was computed for (NaN: not yet)
   double* head_geom_dev;    // scratch table of the latest launch with geometry tables (grow-only)
   long long head_geom_cap;  // geometries it holds
@@ -245,10 +246,10 @@ void attach_quad_kernel(okx_program* p) {
   p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
   p->head_dev = nullptr;
   p->head_lambda0 = std::nan("");
-  if (p->quad_ppw == 16 && hipModuleGetFunction(&p->quad_fn_head_u, mod, "okx_quad_head_u") == hipSuccess &&
+  p->head_stride = okx::quad_head_stride(p->host);
+  if (p->head_stride > 0 && hipModuleGetFunction(&p->quad_fn_head_u, mod, "okx_quad_head_u") == hipSuccess &&
       hipModuleGetFunction(&p->quad_fn_head_g, mod, "okx_quad_head_g") == hipSuccess) {
-    const size_t bytes = sizeof(double) * (size_t)okx::quad_head_stride(p->host.n_free, p->host.n_targets);
-    if (hipMalloc((void**)&p->head_dev, bytes) != hipSuccess) p->head_dev = nullptr;
+    if (hipMalloc((void**)&p->head_dev, sizeof(double) * (size_t)p->head_stride) != hipSuccess) p->head_dev = nullptr;
   }
   if (!p->head_dev) p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
   (void)hipGetLastError();  // optional kernels absent from a module must not leave a sticky error behind
@@ -538,13 +539,13 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
             p->head_geom_dev = nullptr;
             p->head_geom_cap = 0;
           }
-          const size_t bytes = sizeof(double) * (size_t)n_geom * (size_t)okx::quad_head_stride(p->host.n_free, p->host.n_targets);
+          const size_t bytes = sizeof(double) * (size_t)n_geom * (size_t)p->head_stride;
           HIP_TRY(hipMalloc((void**)&p->head_geom_dev, bytes));
           p->head_geom_cap = n_geom;
         }
         h.head = p->head_geom_dev;
         h.n_geometries = n_geom;
-        const long long head_waves = (n_geom + 15) / 16;
+        const long long head_waves = (n_geom + p->quad_ppw - 1) / p->quad_ppw;
         const long long head_cap = (long long)p->n_cu * p->quad_waves_per_cu;
         HIP_TRY(hipModuleLaunchKernel(p->quad_fn_head_g, (int)(head_waves < head_cap ? head_waves : head_cap), 1, 1, okx::kWave, 1, 1,
                                       0, (hipStream_t)stream, hargs, nullptr));

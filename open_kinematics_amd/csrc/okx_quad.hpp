@@ -49,12 +49,9 @@ struct QuadHeadArgs {
   const double* row_param;
   const double* dop_param;
 };
-// doubles per geometry in that table: Q[k][F][4], M[j][k], N[j][k] for k = constraint gradient + one per target, 8 scalars
-// (okx_quadgen.cpp)
-inline int quad_head_stride(int n_free, int n_targets) {
-  const int k = n_targets + 1;
-  return 4 * n_free * k + 2 * k * k + 8;
-}
+// doubles per geometry in that table (0: the program has no quad kernel): Q[k][F][4] per half, M[j][k], N[j][k] for
+// k = constraint gradient + one column per program target, 8 scalars (okx_quadgen.cpp)
+int quad_head_stride(const DevProgram& program);
 
 // Arguments of the generated parity kernel `okx_quad_eval` (mirrors `struct QEvalArgs`).
 struct QuadEvalArgs {

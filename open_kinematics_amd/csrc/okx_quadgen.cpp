@@ -1142,6 +1142,19 @@ DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 }  // namespace
 
+int quad_head_stride(const DevProgram& program) {
+  // mirrors the layout quad_generate() gives the first-step table (head_cols / head_off / head_stride there)
+  if (program.n_free <= kQuadMaxFree) {
+    const int k = program.n_targets + 1;
+    return 4 * program.n_free * k + 2 * k * k + 8;
+  }
+  PairView pv;
+  std::string why;
+  if (!build_pair_view(program, &pv, &why)) return 0;
+  const int k = pv.n_prog_targets + 1;
+  return 2 * 4 * pv.side.n_free * k + 2 * k * k + 8;
+}
+
 bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* src, std::string* why) {
   // Small programs: one quad per problem.  Larger ones only when they are two identical halves
   // joined by one distance row (composed axle): one quad per half, a 2 x 2 Woodbury correction for the joint.
@@ -1214,7 +1227,25 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // Column k = 0 is the constraint rows' own gradient G_0 = Jc^T rc at the design state (the reference's distance
   // rows carry softnorm's -1e-6 offset there, constraints.py:125-134, so it is small but not zero) with weight 1;
   // column k = t + 1 belongs to target t: G_k = J^T e_t, weight = that target's residual.  Q_k = (J^T J + lambda I)^-1 G_k.
-  const bool head_ok = !pv && T >= 1 && getenv("OKX_QUAD_NO_HEAD") == nullptr;
+  // Pair mode: generated on request only (OKX_PAIR_HEAD=1).  Measured on the axle grid: cold starts 5.65 -> 4.85
+  // evaluations but only -2 % time, and +3 % on chained grids, where the block's mere presence costs more registers
+  // than one head in eight steps gives back.
+  const bool head_ok = T >= 1 && getenv("OKX_QUAD_NO_HEAD") == nullptr && (!pv || getenv("OKX_PAIR_HEAD") != nullptr);
+  // columns of the table: the constraint gradient, then one per PROGRAM target (pair mode: a side target stands for one
+  // program target per half that carries it; the column's weight is that half's residual, its Q spans both halves)
+  struct HeadCol { int t, side, prog_t; };
+  std::vector<HeadCol> head_cols;
+  head_cols.push_back({-1, -1, -1});
+  for (int pt = 0; pt < prog_targets; ++pt)
+    for (int t = 0; t < T; ++t) {
+      if (!pv) { if (t == pt) head_cols.push_back({t, -1, pt}); continue; }
+      for (int sd = 0; sd < 2; ++sd)
+        if (pv->tgt[sd][t] == pt) head_cols.push_back({t, sd, pt});
+    }
+  const int HK = (int)head_cols.size();
+  const int head_side = 4 * nf * HK;                       // doubles of one half's Q block
+  const int head_off = (pv ? 2 : 1) * head_side + 2 * HK * HK;
+  const int head_stride = head_off + 8;
   bool has_atan = false;
   for (int i = 0; i < P.n_crows; ++i)
     has_atan = has_atan || P.row_type[i] == OKX_ROW_ANGLE || P.row_type[i] == OKX_ROW_THREE_POINT_ANGLE;
@@ -1232,9 +1263,6 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     if (!pair_state_lds) return "double " + name + " = " + init + ";";
     return "double& " + name + " = lms[" + std::to_string(16 * n_state_slots++) + " + qs]; " + name + " = " + init + ";";
   };
-  const int HK = T + 1;
-  const int head_off = 4 * nf * HK + 2 * HK * HK;
-  const int head_stride = head_off + 8;
 
   // ---- pair mode: the row joining the two halves (distance between a point and its mirror image) ----
   // Each side sees d = partner - own; residual and cost terms are bit-identical on both sides
@@ -1570,10 +1598,18 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("        if (wave_any(at_design)) {");
     g.f("          const double* hp = a.head + (PG ? geom * %d : 0);", head_stride);
     g.f("          const double hr0 = 1.0;  // weight of the constraint rows' own gradient");
-    for (int t = 0; t < T; ++t) g.f("          const double hr%d = td%d - tv%d;  // target residual at the design state", t + 1, t, t);
+    for (int k = 1; k < HK; ++k) {
+      const HeadCol& col = head_cols[k];
+      if (!pv)
+        g.f("          const double hr%d = td%d - tv%d;  // target residual at the design state", k, col.t, col.t);
+      else  // the residual of the half that carries this program target, known to both halves
+        g.f("          const double hr%d = q1 == %d ? td%d - tv%d : xq(td%d - tv%d);", k, col.side, col.t, col.t, col.t, col.t);
+    }
+    if (pv) g.f("          const double* hq = hp + (q1 ? %d : 0);  // this half's block of the table", head_side);
     for (int F = 0; F < nf; ++F) {
       std::string e;
-      for (int k = 0; k < HK; ++k) e += (k ? " + hr" : "hr") + std::to_string(k) + " * hp[" + std::to_string(4 * (k * nf + F)) + " + c]";
+      for (int k = 0; k < HK; ++k)
+        e += (k ? " + hr" : "hr") + std::to_string(k) + " * " + (pv ? "hq[" : "hp[") + std::to_string(4 * (k * nf + F)) + " + c]";
       g.f("          const double hx%d = -(%s);", F, e.c_str());
     }
     g.f("          double hstep = 0.0, hN = 0.0, hM = 0.0, hss = hp[%d], hmr = hp[%d];", head_off + 2, head_off + 3);
@@ -1581,8 +1617,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("          hstep = PMAX(hstep);");
     for (int j = 0; j < HK; ++j)
       for (int k = 0; k < HK; ++k)
-        g.f("          hM = fma(hr%d * hr%d, hp[%d], hM); hN = fma(hr%d * hr%d, hp[%d], hN);", j, k, 4 * nf * HK + j * HK + k, j, k,
-            4 * nf * HK + HK * HK + j * HK + k);
+        g.f("          hM = fma(hr%d * hr%d, hp[%d], hM); hN = fma(hr%d * hr%d, hp[%d], hN);", j, k, head_off - 2 * HK * HK + j * HK + k, j, k,
+            head_off - HK * HK + j * HK + k);
     for (int t = 1; t < HK; ++t) g.f("          hss = fma(hr%d, hr%d, hss); hmr = fmax(hmr, fabs(hr%d));", t, t, t);
     g.f("          if (at_design && hp[%d] > 0.5) {", head_off + 4);
     for (int F = 0; F < nf; ++F) g.f("            dx%d = hx%d;", F, F);
@@ -2105,8 +2141,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("");
   }
   if (head_ok) {
-    // ---- first-step table: one quad per geometry evaluates the design state once (rows, J^T J, damped LDL^T) and
-    //      one substitution per target; what every chain head of that geometry starts from (see the solve kernel) ----
+    // ---- first-step table: one quad (pair mode: one quad pair) per geometry evaluates the design state once (rows,
+    //      J^T J, damped LDL^T) and substitutes once per column; what every chain head of that geometry starts from ----
     ev.out.clear();
     ev.uid = 400000;
     ev.reset_caches();
@@ -2115,22 +2151,25 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("struct QHeadArgs { const double* geom_pos; const double* geom_row_param; double* head; long long n_geometries; double lambda0;");
     g.f("  const double* design_pos; const double* row_param; const double* dop_param; };");
     g.f("template <bool PG> DEV void okx_quad_head_body(const QHeadArgs& a) {");
-    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
-  g.out += atan_decl;
+    if (pv)
+      g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1 = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
+    else
+      g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+    g.out += atan_decl;
     g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
     if (ev.lds_constants) g.out += lds_decl;
-    g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_geometries; wu += gridDim.x) {");
-    g.f("    long long geom = wu * 16 + quad; const bool valid = geom < a.n_geometries; if (!valid) geom = a.n_geometries - 1;");
+    g.f("  for (long long wu = blockIdx.x; wu * %d < a.n_geometries; wu += gridDim.x) {", PPW);
+    g.f("    long long geom = wu * %d + quad; const bool valid = geom < a.n_geometries; if (!valid) geom = a.n_geometries - 1;", PPW);
     g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * prog_points);
     g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * prog_crows);
     g.out += ev.hoisted;
+    g.out += couple_hoist;
     for (int p = 0; p < NP; ++p)
       if (used[p]) g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
     // targets at their design values: the target rows vanish, ss / mres_new are the constraint rows' alone
     {
       ev.reset_caches();
       ev.out.clear();
-      // active derived points are evaluated by eval_src itself; the design table already holds every point
       for (int i = P.n_crows; i < P.m; ++i) {
         const int t = ev.target_of_row(i);
         const std::string d = ev.dot(Gen::pn(P.row_pts[i][0]), ev.rpv(i, 0));
@@ -2141,6 +2180,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       ev.reset_caches();
     }
     g.out += eval_src;
+    g.out += couple_eval;
     g.f("    double diag = 0.0;");
     for (int F = 0; F < nf; ++F)
       g.f("    diag = fmax(diag, c == 0 ? %s : (c == 1 ? %s : (c == 2 ? %s : 0.0)));", Gen::A(F, F, 0).c_str(),
@@ -2155,15 +2195,36 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
             if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
           }
         }
+    if (pv)  // each half takes its own part of the joining row's rank-one term (see the solve kernel)
+      for (int k = 0; k < 3; ++k)
+        g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
     g.out += factor_src;
-    g.f("    double* ho = a.head + geom * %d;", head_stride);
+    if (pv) {
+      g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
+      g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
+      std::vector<std::string> rhs_w;
+      for (int F = 0; F < nf; ++F) rhs_w.push_back(F == FU ? "cu" : "0.0");
+      for (int F = 0; F < nf; ++F) g.f("    double nz%d;", F);
+      ev.out.clear();
+      ev.emit_substitute(rhs_w, "sz");
+      g.f("    {");
+      g.out += ev.out;
+      for (int F = 0; F < nf; ++F) g.f("    nz%d = sz%d;", F, F);
+      g.f("    }");
+      g.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g);", FU);
+      g.f("    const double sm_det = 1.0 - sm_g * sm_gp;");
+    }
+    g.f("    double* ho = a.head + geom * %d%s;", head_stride, pv ? (" + (q1 ? " + std::to_string(head_side) + " : 0)").c_str() : "");
+    g.f("    double* hs = a.head + geom * %d;  // Gram matrices and scalars (written once per geometry)", head_stride);
     std::vector<std::vector<std::string>> rhs_of(HK, std::vector<std::string>(nf, "0.0"));
     for (int F = 0; F < nf; ++F) rhs_of[0][F] = "gn" + std::to_string(F);  // constraint rows' gradient (target rows vanish here)
     for (int k = 0; k < HK; ++k) {
+      const HeadCol& col = head_cols[k];
       if (k > 0) {
-        auto it = ev.target_j.find(k - 1);
+        auto it = ev.target_j.find(col.t);
         if (it != ev.target_j.end())
-          for (auto& fv : it->second) rhs_of[k][fv.first] = Gen::sx(fv.second);
+          for (auto& fv : it->second) rhs_of[k][fv.first] = pv ? "(hm" + std::to_string(k) + " * " + Gen::sx(fv.second) + ")" : Gen::sx(fv.second);
+        if (pv) g.f("    const double hm%d = q1 == %d ? 1.0 : 0.0;  // the half that carries program target %d", k, col.side, col.prog_t);
       }
       ev.out.clear();
       const std::string outn = "hq" + std::to_string(k) + "_";
@@ -2173,7 +2234,13 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       for (int F = 0; F < nf; ++F) g.f("    double hQ%d_%d;", k, F);
       g.f("    {");
       g.out += ev.out;
-      for (int F = 0; F < nf; ++F) g.f("    hQ%d_%d = %s%d;", k, F, outn.c_str(), F);
+      if (pv) {  // the coupling between the halves: 2 x 2 Woodbury, as in the solve kernel
+        g.f("    const double sm_s = qsum(cu * %s%d);", outn.c_str(), FU);
+        g.f("    const double sm_c = (xq(sm_s) - sm_gp * sm_s) / sm_det;");
+        for (int F = 0; F < nf; ++F) g.f("    hQ%d_%d = fma(-nz%d, sm_c, %s%d);", k, F, F, outn.c_str(), F);
+      } else {
+        for (int F = 0; F < nf; ++F) g.f("    hQ%d_%d = %s%d;", k, F, outn.c_str(), F);
+      }
       g.f("    }");
       g.f("    if (valid) {");
       for (int F = 0; F < nf; ++F) g.f("      ho[%d + c] = c < 3 ? hQ%d_%d : 0.0;", 4 * (k * nf + F), k, F);
@@ -2188,10 +2255,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         }
         if (em.empty()) em = "0.0";
         g.f("    { const double vm = PSUM(%s), vn = PSUM(%s);", em.c_str(), en.c_str());
-        g.f("      if (valid && c == 0) { ho[%d] = vm; ho[%d] = vn; } }", 4 * nf * HK + j * HK + k, 4 * nf * HK + HK * HK + j * HK + k);
+        g.f("      if (valid && c == 0%s) { hs[%d] = vm; hs[%d] = vn; } }", pv ? " && !q1" : "", head_off - 2 * HK * HK + j * HK + k,
+            head_off - HK * HK + j * HK + k);
       }
-    g.f("    if (valid && c == 0) {");
-    g.f("      ho[%d] = diag; ho[%d] = pmin; ho[%d] = ss; ho[%d] = mres_new; ho[%d] = ok ? 1.0 : 0.0; ho[%d] = pmax; ho[%d] = 0.0; ho[%d] = 0.0;",
+    g.f("    if (valid && c == 0%s) {", pv ? " && !q1" : "");
+    g.f("      hs[%d] = diag; hs[%d] = pmin; hs[%d] = ss; hs[%d] = mres_new; hs[%d] = ok ? 1.0 : 0.0; hs[%d] = pmax; hs[%d] = 0.0; hs[%d] = 0.0;",
         head_off, head_off + 1, head_off + 2, head_off + 3, head_off + 4, head_off + 5, head_off + 6, head_off + 7);
     g.f("    }");
     g.f("  }");

@@ -21,14 +21,19 @@ def _both(dp, targets, **kw):
     return own, shared
 
 
-@pytest.mark.parametrize("workload", ["dw", "mac"])
+@pytest.mark.parametrize("workload", ["dw", "mac", "axle"])
 @pytest.mark.parametrize("line_mode", ["pinned", "softnorm"])
-def test_cold_starts_take_the_same_path_with_one_evaluation_less(workload, line_mode):
+def test_cold_starts_take_the_same_path_with_one_evaluation_less(workload, line_mode, monkeypatch, tmp_path):
     from open_kinematics_amd.batch import DeviceProgram
+
+    if workload == "axle":  # pair-mode kernels carry the table on request only (no net gain there)
+        monkeypatch.setenv("OKX_PAIR_HEAD", "1")
+        monkeypatch.setenv("OKX_KERNEL_CACHE", str(tmp_path))  # compiled in place: not one of the precompiled kernels
     from open_kinematics_amd import workloads as W
     from oracle.oracle import Oracle
 
-    program, targets = (W.bump_sweep_problem(1024, line_mode) if workload == "dw" else W.macpherson_grid_problem(32, 32, line_mode))
+    program, targets = {"dw": lambda: W.bump_sweep_problem(1024, line_mode), "mac": lambda: W.macpherson_grid_problem(32, 32, line_mode),
+                        "axle": lambda: W.axle_grid_problem(24, 24, line_mode)}[workload]()  # axle: pair-mode kernel, 3 program targets
     dp = DeviceProgram(program, "cuda:0")
     assert dp.kernel == "quad"
     t = torch.as_tensor(targets, device="cuda:0")
@@ -42,9 +47,11 @@ def test_cold_starts_take_the_same_path_with_one_evaluation_less(workload, line_
     assert float((own.positions - shared.positions).abs().max()) <= tol
     # exactly the own path minus its first evaluation, except where a rejected first step changes the bookkeeping
     saved = io["nfev"].astype(int) - ish["nfev"].astype(int)
-    if line_mode == "pinned":
+    if line_mode == "pinned" and workload != "axle":
         assert np.median(saved) == 1 and saved.min() >= 0 and np.mean(saved == 1) >= 0.95
         assert np.mean(io["iterations"] == ish["iterations"]) >= 0.95
+    elif line_mode == "pinned":  # the coupled halves take marginal accept / reject decisions differently now and then
+        assert float(np.mean(saved)) >= 0.5 and saved.min() >= -2
     else:  # dozens of linearly converging passes along the valley: rounding decides the exact count
         assert abs(float(np.mean(saved)) - 1.0) <= 1.0
     if line_mode == "pinned":
