@@ -489,6 +489,7 @@ class Gen {
   // components in hql[slot][lane]; a lane only ever reads what it (or a lane of its own quad, with
   // the same value) wrote, in program order, so no barrier is involved.
   bool lds_constants = false;
+
   int n_scalar_slots = 0, n_lane_slots = 0;
   std::string scalar_home(const char* name) {
     if (!lds_constants) return name;
@@ -1449,6 +1450,41 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     ev.reset_caches();
   }
   for (int t = 0; t < T; ++t) g.f("    tp%d = td%d;", t, t);
+  if (head_ok && !pv) {
+    // Shared first step of the unit's FIRST problem, taken here, in the unit prologue, so that the
+    // table loads travel with the prologue's other loads (inside the chain loop the compiler serialises them - two
+    // loads, wait, fma, next load: a dozen dependent L2 round trips, ~3 us per unit) and nothing of the table stays
+    // live across the chain loop: the step and its seven scalars go to LDS and are picked up by the first chain step.
+    g.f("    __shared__ double hxl[%d];  // first step of the unit's head problem [block][lane]", 64 * nf);
+    g.f("    __shared__ double hsc[%d];  // its scalars [slot][quad]: step length, dx.g, |dx|^2, cost x 2, max |r|, dmax, min / max pivot, ok", 16 * 9);
+    g.f("    bool head_ready = false;");
+    g.f("    if (a.head != nullptr && a.grad_tol <= 0.0 && (PG || a.predictor == nullptr)) {");
+    g.f("      const double* hp = a.head + (PG ? geom * %d : 0);", head_stride);
+    for (int k = 0; k < HK; ++k)
+      for (int F = 0; F < nf; ++F) g.f("      const double hq%d_%d = hp[%d + c];", k, F, 4 * (k * nf + F));
+    for (int j = 0; j < HK; ++j)
+      for (int k = j; k < HK; ++k) g.f("      const double hm%d_%d = hp[%d];", j, k, head_off - 2 * HK * HK + j * HK + k);
+    for (int i = 0; i < 6; ++i) g.f("      const double hs%d = hp[%d];", i, head_off + i);
+    g.f("      const double hr0 = 1.0;  // weight of the constraint rows' own gradient");
+    for (int k = 1; k < HK; ++k)
+      g.f("      const double hr%d = td%d - tn%d;  // target residual of the first problem at the design state", k, head_cols[k].t, head_cols[k].t);
+    g.f("      double hstep = 0.0, hN = 0.0, hM = 0.0, hss = hs2, hmr = hs3;");
+    for (int F = 0; F < nf; ++F) {
+      std::string e;
+      for (int k = 0; k < HK; ++k) e += (k ? " + hr" : "hr") + std::to_string(k) + " * hq" + std::to_string(k) + "_" + std::to_string(F);
+      g.f("      { const double hx = -(%s); hxl[%d + lane] = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", e.c_str(), 64 * F);
+    }
+    g.f("      hstep = PMAX(hstep); hN = PSUM(hN);");
+    for (int j = 0; j < HK; ++j)
+      for (int k = j; k < HK; ++k)
+        g.f("      hM = fma(%shr%d * hr%d, hm%d_%d, hM);", j == k ? "" : "2.0 * ", j, k, j, k);  // M is symmetric: Q_j . G_k = G_j^T (A + lambda I)^-1 G_k
+    for (int k = 1; k < HK; ++k) g.f("      hss = fma(hr%d, hr%d, hss); hmr = fmax(hmr, fabs(hr%d));", k, k, k);
+    g.f("      const int hq_ = lane >> 2;");
+    g.f("      hsc[0 + hq_] = hstep; hsc[16 + hq_] = hM; hsc[32 + hq_] = hN; hsc[48 + hq_] = hss; hsc[64 + hq_] = hmr;");
+    g.f("      hsc[80 + hq_] = hs0; hsc[96 + hq_] = hs1; hsc[112 + hq_] = hs5; hsc[128 + hq_] = hs4;");
+    g.f("      head_ready = true;");
+    g.f("    }");
+  }
   if (pair_state_lds) {
     g.f("    __shared__ int lmk[%d];  // per-quad counters [slot][quad side]", 16 * 6);
     g.f("    int& hist = lmk[0 + qs]; hist = 1;                // solved states in the history (the design state counts)");
@@ -1593,6 +1629,24 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     // Q_t = (J^T J + lambda I)^-1 J^T e_t tabulated once per geometry (okx_quad_head_*), and the problem enters the
     // loop below exactly where its own first pass would have left it: trial point x + dx in hand (mode 1), cost and
     // damping of the design state, predicted reduction 0.5 (lambda |dx|^2 - dx . g) from the table's Gram matrices.
+    if (!pv) {
+    g.f("      if (head_ready && b == first_b) {  // wave-uniform: every quad of the wavefront is at its unit's first problem");
+    g.f("        const int hq_ = lane >> 2;");
+    g.f("        const bool at_design = valid && hist == 1 && !from_model && hsc[128 + hq_] > 0.5;  // x is the design state, the table is good");
+    g.f("        if (at_design) {");
+    for (int F = 0; F < nf; ++F) g.f("          dx%d = hxl[%d + lane];", F, 64 * F);
+    g.f("          const double hstep = hsc[0 + hq_];");
+    g.f("          Fc = 0.5 * hsc[48 + hq_]; mres = hsc[64 + hq_]; dmax = hsc[80 + hq_]; lambda = a.lambda0 * dmax;");
+    g.f("          step_len = hstep; pred = 0.5 * fma(lambda, hsc[32 + hq_], hsc[16 + hq_]); iters = 1; mode = 1;");
+    g.f("          piv_lo = hsc[96 + hq_] - lambda; piv_hi = hsc[112 + hq_];");
+    g.f("          if (hstep <= a.step_tol) { flags |= INFO_CONVERGED; last_step = hstep; done = true; }");
+    g.f("          else {");
+    g.f("            want_light = hstep <= 1e-3 && (100.0 * lambda / hsc[96 + hq_] + hstep) * hstep <= a.step_tol;");
+    g.f("            prev_sl = hstep;");
+    g.f("          }");
+    g.f("        }");
+    g.f("      }");
+    } else {
     g.f("      if (a.head != nullptr && a.grad_tol <= 0.0) {");
     g.f("        const bool at_design = valid && hist == 1 && !from_model;  // x is this geometry's design state");
     g.f("        if (wave_any(at_design)) {");
@@ -1633,6 +1687,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("          }");
     g.f("        }");
     g.f("      }");
+    }
   }
   g.f("      while (wave_any(!done)) {");
   if (light_ok) {

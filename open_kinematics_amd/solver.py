@@ -98,7 +98,9 @@ def absolute_target_table(sweep_config, initial_state) -> tuple[list, np.ndarray
         first = dim[0]
         unit0 = resolve_direction(first.direction)
         for t in dim:
-            if t.point_id != first.point_id or not np.array_equal(resolve_direction(t.direction), unit0):
+            # (a dimension built by build_sweep shares ONE direction object: the identity test settles nearly every step)
+            if t.point_id != first.point_id or (t.direction is not first.direction and
+                                                not np.array_equal(resolve_direction(t.direction), unit0)):
                 raise NotImplementedError(
                     "a sweep dimension must keep one point and direction for all steps "
                     "(the batched solver shares target rows across the sweep)"

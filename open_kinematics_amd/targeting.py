@@ -76,8 +76,16 @@ class ActuatorDOF:
 def validate_sweep_controls(sweep_config, actuator_dofs) -> None:
     """Exactly one target per physical actuator coordinate and step (``targeting.py:168-186``)."""
     for actuator in actuator_dofs:
+        memo: dict = {}  # (point, direction object) -> matches: a dimension repeats both for every step
         for step in range(sweep_config.n_steps):
-            hits = sum(1 for dim in sweep_config.target_sweeps if _matches(actuator, dim[step]))
+            hits = 0
+            for dim in sweep_config.target_sweeps:
+                target = dim[step]
+                key = (target.point_id, id(target.direction))
+                hit = memo.get(key)
+                if hit is None:
+                    hit = memo[key] = _matches(actuator, target)
+                hits += hit
             if hits != 1:
                 raise ValueError(
                     f"Sweep requires exactly one target for actuator '{actuator.name}' along "
