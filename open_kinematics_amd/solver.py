@@ -41,6 +41,7 @@ class SolverConfig(NamedTuple):
     warm_start: bool = True     # reference semantics: step k starts from step k-1 (solver.py:774)
     step_tol: float = 1e-11     # mm
     max_iter: int = 100
+    parallel_chains: bool = True  # long warm-started sweeps: several chains at once, verified against the sequential path
 
 
 @dataclass
@@ -201,17 +202,69 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     n_steps = table.shape[0]
     if n_steps == 0:
         return [], []
-    result = dp.solve(torch.as_tensor(table), chain=bool(cfg.warm_start), max_iter=cfg.max_iter,
-                      step_tol=cfg.step_tol, residual_tolerance=cfg.residual_tolerance,
-                      predictor=False)  # one sweep = one chain (or explicit cold starts): nothing for a fitted model to save
-    # one D2H copy each; .cpu() synchronises with the launch stream
-    positions = result.positions.cpu().numpy()
-    info = result.info()
+    solve_kw = dict(max_iter=cfg.max_iter, step_tol=cfg.step_tol, residual_tolerance=cfg.residual_tolerance,
+                    predictor=False)  # one sweep = a few chains (or explicit cold starts): nothing for a fitted model to save
+    targets = torch.as_tensor(table)
+    positions = info = None
+    segment = _segment_length(n_steps) if cfg.warm_start and cfg.parallel_chains else 0
+    if segment:
+        # One chain is one quad walking the sweep step by step: 1/16384 of the chip and ~12 us per step.  A long sweep
+        # is therefore cut into a few chains that run side by side (chain heads start at the design state) and the
+        # result is kept only if it is what the sequential warm start would have produced: every step accepted and
+        # every chain head where the extrapolation of the chain before it says it should be.
+        result = dp.solve(targets, chain_len=segment, **solve_kw)
+        positions = result.positions.cpu().numpy()
+        info = result.info()
+        if not _chains_are_continuous(program, table, positions, info, segment):
+            positions = info = None
+    if positions is None:
+        result = dp.solve(targets, chain=bool(cfg.warm_start), **solve_kw)
+        # one D2H copy each; .cpu() synchronises with the launch stream
+        positions = result.positions.cpu().numpy()
+        info = result.info()
     _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg)
     states = _states_from_positions(initial_state, program, positions)
     infos = [SolverInfo(c, n, r) for c, n, r in zip(((info["flags"] & 1) != 0).tolist(), info["nfev"].tolist(),
                                                     info["max_residual"].tolist())]
     return states, infos
+
+
+def _segment_length(n_steps: int) -> int:
+    """Chain length for a warm-started sweep solved as several chains at once (0: keep it one chain)."""
+    if n_steps < 32:
+        return 0
+    return max(8, int(np.ceil(np.sqrt(n_steps))))
+
+
+def _chains_are_continuous(program: ConstraintProgram, table: np.ndarray, positions: np.ndarray, info: np.ndarray,
+                           segment: int) -> bool:
+    """
+    Whether a sweep solved as chains of `segment` steps is the path the sequential warm start (reference
+    ``solver.py:716,774``) follows: every step accepted, and at every chain boundary the head's free coordinates within
+    half a step of the secant extrapolation of the previous chain's last two states (a head that fell onto another
+    assembly branch is many steps away from it).
+    """
+    flags = info["flags"]
+    if np.any((flags & 1) == 0) or np.any((flags & 6) != 0):
+        return False
+    out = [int(k) for k in program.out_point]
+    try:
+        free = positions[:, [out.index(int(p)) for p in program.free_point], :].reshape(positions.shape[0], -1)
+    except ValueError:  # a free point is not among the outputs: nothing to check against
+        return False
+    for k in range(segment, positions.shape[0], segment):
+        if k < 2:
+            return False
+        d_prev = table[k - 1] - table[k - 2]
+        d_new = table[k] - table[k - 1]
+        den = float(d_prev @ d_prev)
+        alpha = float(d_new @ d_prev) / den if den > 0.0 else 0.0
+        step = free[k - 1] - free[k - 2]
+        predicted = free[k - 1] + alpha * step
+        scale = float(np.abs(step).max()) * max(abs(alpha), 1.0)
+        if float(np.abs(free[k] - predicted).max()) > 0.5 * scale + 1e-6:
+            return False
+    return True
 
 
 def _coerce_config(config) -> SolverConfig:

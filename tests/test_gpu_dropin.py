@@ -144,3 +144,64 @@ def test_repeated_calls_reuse_the_device_program():
     assert len(solver._PROGRAM_CACHE) == 3
     solver.clear_program_cache()
     assert not solver._PROGRAM_CACHE and cached._handle is None
+
+
+def test_parallel_chains_give_the_sequential_answer_or_fall_back(golden):
+    """Long warm-started sweeps run as several chains at once; the result is kept only when it is the sequential path."""
+    import yaml
+
+    from open_kinematics_amd import solver
+    from open_kinematics_amd.input import build_sweep
+    from open_kinematics_amd.solver import SolverConfig
+    from open_kinematics_amd.sweep import solve_sweep
+
+    arrays, _ = golden("c1_dw_corner")
+    sus = _dw()
+    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)  # 101 steps: chains of 11
+    assert solver._segment_length(101) == 11 and solver._segment_length(31) == 0
+    fast, fast_info = solve_sweep(sus, sweep)
+    slow, slow_info = solve_sweep(sus, sweep, SolverConfig(parallel_chains=False))
+    for a, b in zip(fast, slow):
+        for key in a.positions:
+            assert np.max(np.abs(a.positions[key].data - b.positions[key].data)) <= 1e-9
+    # ten chain heads started cold: a few evaluations more than one chain, far fewer than 101 cold starts
+    cold = solve_sweep(sus, sweep, SolverConfig(warm_start=False))[1]
+    assert sum(i.nfev for i in slow_info) <= sum(i.nfev for i in fast_info) < sum(i.nfev for i in cold)
+
+    # the continuity test itself: a chain head on another branch, a rejected step and a kinked target path all fail it
+    program, table = solver.dropin_program(sus.initial_state(), sus.constraints(), sweep, sus.derived_spec())
+    pos = np.array([[s.positions[k].data for k in program.point_keys] for s in fast])
+    info = np.zeros(101, dtype=[("flags", "<i4")])
+    info["flags"] = 1
+    assert solver._chains_are_continuous(program, table, pos, info, 11)
+    jumped = pos.copy()
+    jumped[22:33, program.free_point[0]] += 5.0
+    assert not solver._chains_are_continuous(program, table, jumped, info, 11)
+    bad = info.copy()
+    bad["flags"][40] = 3
+    assert not solver._chains_are_continuous(program, table, pos, bad, 11)
+    kinked = table.copy()
+    kinked[33:] = kinked[33:][::-1]
+    assert not solver._chains_are_continuous(program, kinked, pos, info, 11)
+
+
+def test_infeasible_long_sweep_raises_at_the_sequential_step():
+    """The parallel attempt is discarded and the reference's first-failure semantics come from the sequential chain."""
+    from open_kinematics_amd.enums import Axis, PointID
+    from open_kinematics_amd.solver import SolverConfig
+    from open_kinematics_amd.sweep import solve_sweep
+    from open_kinematics_amd.targeting import PointTarget, PointTargetAxis, SweepConfig
+    from open_kinematics_amd.enums import TargetPositionMode
+
+    sus = _dw()
+    z = PointTargetAxis(Axis.Z)
+    y = PointTargetAxis(Axis.Y)
+    bump = np.linspace(0.0, 600.0, 64)  # runs past lock-out (bump reach ~ 451 mm)
+    sweep = SweepConfig([[PointTarget(PointID.WHEEL_CENTER, z, float(v), TargetPositionMode.RELATIVE) for v in bump],
+                         [PointTarget(PointID.TRACKROD_INBOARD, y, 0.0, TargetPositionMode.RELATIVE) for _ in bump]])
+    messages = []
+    for config in (SolverConfig(), SolverConfig(parallel_chains=False)):
+        with pytest.raises(RuntimeError) as err:
+            solve_sweep(sus, sweep, config)
+        messages.append(str(err.value))
+    assert messages[0] == messages[1] and "did not reach an acceptable residual" in messages[0]
