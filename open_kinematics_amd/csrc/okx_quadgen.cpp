@@ -727,7 +727,7 @@ class Gen {
         std::string g1 = c23, g2 = c31, g3 = c12;
         if (type == OKX_ROW_SCALAR_TRIPLE) {
           std::string isc = tmp("is");
-          f("    const double %s = 1.0 / %s;", isc.c_str(), rp(i, 1).c_str());
+          f("    const double %s = fast_rcp(%s);", isc.c_str(), rp(i, 1).c_str());
           g1 = tmp("g"), g2 = tmp("g"), g3 = tmp("g");
           f("    const double %s = %s * %s, %s = %s * %s, %s = %s * %s;", g1.c_str(), c23.c_str(), isc.c_str(),
             g2.c_str(), c31.c_str(), isc.c_str(), g3.c_str(), c12.c_str(), isc.c_str());
@@ -1590,14 +1590,15 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("          num2 = fma(%s * dold, dolder, num2); den2 = fma(%s * dolder, dolder, den2); }", en.c_str(), en.c_str());
   }
   g.f("        num = PJOIN_SUM(num); den = PJOIN_SUM(den); nn = PJOIN_SUM(nn); num2 = PJOIN_SUM(num2); den2 = PJOIN_SUM(den2);  // pair mode: targets of both halves");
-  g.f("        double alpha = den > 0.0 ? num / den : 0.0;");
+  g.f("        double alpha = den > 0.0 ? num * fast_rcp(den) : 0.0;  // (Newton-refined reciprocals here and below: an IEEE fp64 division is ~25 instructions)");
   g.f("        alpha = fmin(fmax(alpha, 0.0), 2.0);");
-  g.f("        const double beta = den2 > 0.0 ? num2 / den2 : 0.0;  // old increment over the one before");
+  g.f("        const double beta = den2 > 0.0 ? num2 * fast_rcp(den2) : 0.0;  // old increment over the one before");
   g.f("        const bool line = hist >= 3 && alpha > 0.0 && beta >= 1e-3 && beta <= 2.0 && num * num >= 0.98 * nn * den && num2 * num2 >= 0.98 * den * den2;");
-  g.f("        const double bq = line ? 1.0 / beta : 1.0;  // spacings in units of the old increment: new = alpha, old = 1, older = bq");
-  g.f("        const double l0 = line ? (alpha + 1.0) * (alpha + 1.0 + bq) / (1.0 + bq) : 1.0 + alpha;");
-  g.f("        const double l1 = line ? -alpha * (alpha + 1.0 + bq) / bq : -alpha;");
-  g.f("        const double l2 = line ? alpha * (alpha + 1.0) / ((1.0 + bq) * bq) : 0.0;");
+  g.f("        const double bq = line ? fast_rcp(beta) : 1.0;  // spacings in units of the old increment: new = alpha, old = 1, older = bq (1 / bq = beta)");
+  g.f("        const double r1q = fast_rcp(1.0 + bq);");
+  g.f("        const double l0 = line ? (alpha + 1.0) * (alpha + 1.0 + bq) * r1q : 1.0 + alpha;");
+  g.f("        const double l1 = line ? -alpha * (alpha + 1.0 + bq) * beta : -alpha;");
+  g.f("        const double l2 = line ? alpha * (alpha + 1.0) * r1q * beta : 0.0;");
   for (int F = 0; F < nf; ++F)
     g.f("        { const double xn = fma(l0, x%d, fma(l1, xp%d, l2 * xq%d)); xq%d = xp%d; xp%d = x%d; x%d = xn; }", F, F, F, F, F, F, F, F);
   g.f("      } else if (!from_model) {");
@@ -1641,7 +1642,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("          piv_lo = hsc[96 + hq_] - lambda; piv_hi = hsc[112 + hq_];");
     g.f("          if (hstep <= a.step_tol) { flags |= INFO_CONVERGED; last_step = hstep; done = true; }");
     g.f("          else {");
-    g.f("            want_light = hstep <= 1e-3 && (100.0 * lambda / hsc[96 + hq_] + hstep) * hstep <= a.step_tol;");
+    g.f("            want_light = hstep <= 1e-3 && (100.0 * lambda * fast_rcp(hsc[96 + hq_]) + hstep) * hstep <= a.step_tol;");
     g.f("            prev_sl = hstep;");
     g.f("          }");
     g.f("        }");
@@ -1681,7 +1682,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("            piv_lo = hp[%d] - lambda; piv_hi = hp[%d];", head_off + 1, head_off + 5);
     g.f("            if (hstep <= a.step_tol) { flags |= INFO_CONVERGED; last_step = hstep; done = true; }");
     g.f("            else {");
-    g.f("              want_light = hstep <= 1e-3 && (100.0 * lambda / hp[%d] + hstep) * hstep <= a.step_tol;", head_off + 1);
+    g.f("              want_light = hstep <= 1e-3 && (100.0 * lambda * fast_rcp(hp[%d]) + hstep) * hstep <= a.step_tol;", head_off + 1);
     g.f("              prev_sl = hstep;");
     g.f("            }");
     g.f("          }");
@@ -1724,7 +1725,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    if (mode == 1) {");
   g.f("      const bool finite = Ft == Ft && step_len == step_len && Ft < 1e300;");
   g.f("      const bool small = finite && step_len <= 1e-8 && Ft <= Fc * (1.0 + 1e-6) + 1e-28;");
-  g.f("      rho = (finite && pred > 0.0) ? (Fc - Ft) / pred : -1.0;");
+  g.f("      rho = (finite && pred > 0.0) ? (Fc - Ft) * fast_rcp(pred) : -1.0;");
   g.f("      accept = rho > 1e-4 || small;");
   g.f("      if (finite && step_len <= a.step_tol) { accept = small; stop = true; }");
   g.f("      else if (accept && finite && Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) stop = true;");
@@ -1822,7 +1823,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     for (int F = 0; F < nf; ++F) g.f("    nz%d = sz%d;", F, F);
     g.f("    }");
     g.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g), sm_s = qsum(cu * ny%d);", FU, FU);
-    g.f("    const double sm_k = (xq(sm_s) - sm_gp * sm_s) / (1.0 - sm_g * sm_gp);");
+    g.f("    const double sm_k = (xq(sm_s) - sm_gp * sm_s) * fast_rcp(1.0 - sm_g * sm_gp);");
     for (int F = 0; F < nf; ++F) g.f("    const double nx%d = fma(-nz%d, sm_k, ny%d);", F, F, F);
   }
   g.f("    double sl = 0.0, pr = 0.0;");
@@ -1842,8 +1843,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("          // rho = lambda / sigma_min(J^T J), bounded with the smallest pivot (x 100), plus the");
   g.f("          // Gauss-Newton curvature term with C = 100 x the observed |dx| / |dx-|^2, or 1 / mm on a");
   g.f("          // problem's first step (two orders above a linkage's curvature / stiffness ratio).");
-  g.f("          const double cq = prev_sl > 0.0 ? fmax(100.0 * sl / (prev_sl * prev_sl), 1e-3) : 1.0;");
-  g.f("          const double rho_lin = 100.0 * lambda / pmin;");
+  g.f("          const double cq = prev_sl > 0.0 ? fmax(100.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
+  g.f("          const double rho_lin = 100.0 * lambda * fast_rcp(pmin);");
   g.f("          want_light = sl <= 1e-3 && (rho_lin + cq * sl) * sl <= a.step_tol;");
   g.f("          prev_sl = sl;");
   g.f("        }");
