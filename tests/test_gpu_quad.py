@@ -290,3 +290,44 @@ def test_grid_chains_with_row_wraps_match_independent_solves(workload):
             assert float((res.positions - ref.positions).abs().max()) <= 1e-9, (chain_len, predictor)
     long_chain = dp.solve(t, chain_len=t.shape[0], predictor=False).info()
     assert long_chain["nfev"].mean() < ref.info()["nfev"].mean() - 1.0  # extrapolation pays along the rows
+
+
+def test_empty_batches_and_invalid_launches(golden):
+    """The C-ABI's edge contract on the device: nothing to do is not an error, malformed launches are OKX_ERR_INVALID."""
+    import ctypes as C
+
+    from open_kinematics_amd import _lib
+
+    arrays, program = golden("c1_dw_corner")
+    pinned = program.with_line_mode("pinned")
+    dp = _dp(pinned)
+    empty = dp.solve(torch.empty((0, pinned.n_targets), dtype=torch.float64, device="cuda:0"))
+    assert empty.positions.shape == (0, pinned.n_out, 3) and empty.info().shape == (0,)
+    tan, tinfo = dp.tangents(empty.positions)
+    assert tan.shape == (0, pinned.n_targets, pinned.n_out, 3)
+    assert dp.expand(torch.empty((0, pinned.n_free, 3), dtype=torch.float64, device="cuda:0")).shape == (0, pinned.n_out, 3)
+    lib = dp.lib
+    opts = dp.default_opts()
+    t = torch.as_tensor(arrays["targets_abs"][:4], device="cuda:0")
+    out = torch.empty((4, pinned.n_out, 3), dtype=torch.float64, device="cuda:0")
+    info = torch.empty((4, 40), dtype=torch.uint8, device="cuda:0")
+    ptr = lambda x: C.c_void_p(x.data_ptr())
+    null = C.c_void_p(0)
+    call = lambda n, tp, gp, gq, op, ip: lib.okx_solve_batch(dp._handle, C.byref(opts), n, tp, gp, gq, op, ip, null)
+    assert call(-1, ptr(t), null, null, ptr(out), ptr(info)) == -1 and "negative" in _lib.last_error()
+    assert call(4, ptr(t), null, null, null, ptr(info)) == -1
+    assert call(4, null, null, null, ptr(out), ptr(info)) == -1 and "targets" in _lib.last_error()
+    assert call(4, ptr(t), ptr(out), null, ptr(out), ptr(info)) == -1  # geometry positions without row parameters
+    opts.steps_per_geometry = 3  # 4 problems are not whole geometries of 3 steps
+    assert call(4, ptr(t), null, null, ptr(out), ptr(info)) == -1
+    opts.steps_per_geometry = 0
+    opts.max_iter = 0
+    assert call(4, ptr(t), null, null, ptr(out), ptr(info)) == -1
+    opts.max_iter = 100
+    assert call(4, ptr(t), null, null, ptr(out), ptr(info)) == 0  # and the same launch, well formed, runs
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="geometry table has the wrong shape"):
+        dp.solve(t, geom_pos=torch.zeros((2, 3, 3)), geom_row_param=torch.zeros((2, pinned.n_rows, 8)), steps_per_geometry=2)
+    with pytest.raises(ValueError, match="B must equal"):
+        gpos, gparam = dp.rebind(torch.as_tensor(pinned.design_pos[None]))
+        dp.solve(t, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=3)
