@@ -17,6 +17,7 @@ The same JSON line also carries, each measured in this run:
   cpu_baseline   the CPU oracle (reference-shaped MINPACK sweeps) on this box's host cores: one core timed,
                  then every core the process may run on
   other_configs  BASELINE configs 3, 4, 5 at full size: cold independent solves and the product's chained mode
+  downstream     tangents and the metric catalog on the solved states
   dropin         wall-clock of the drop-in `solve_sweep` on the reference's own benchmark workloads
 
 With N > 1 ranks the global sweep (N x 16384 steps) is sharded by index and the solved free coordinates are
@@ -394,6 +395,36 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
     return res
 
 
+def measure_downstream(dp, suspension_yaml: str, positions, device, reps: int = 20) -> dict:
+    """The callers after the solve on the same 16384 solved states, each one launch: solution-manifold
+    tangents (okx_tangent_batch) and the corner metric catalog with its derivative columns (okx_corner_metrics_batch)."""
+    from open_kinematics_amd.input import load_geometry
+    from open_kinematics_amd.metrics import corner_roles, corner_state_metrics
+
+    program = dp.program
+    roles = corner_roles(load_geometry(suspension_yaml), program)
+    n = positions.shape[0]
+
+    def timed(fn):
+        for _ in range(3):
+            out = fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / reps, out
+
+    t_tan, (tangents, _) = timed(lambda: dp.tangents(positions))
+    t_met, _ = timed(lambda: corner_state_metrics(roles, positions, tangents))
+    return {"states": n,
+            "tangents": {"value": n / t_tan, "unit": "states/s", "ms": t_tan * 1e3,
+                         "bytes_per_state": 24 * program.n_out * (1 + program.n_targets) + 24},
+            "corner_metrics_with_derivatives": {"value": n / t_met, "unit": "states/s", "ms": t_met * 1e3,
+                                                "bytes_per_state": 24 * program.n_out * (1 + program.n_targets) + 152 * (1 + program.n_targets)},
+            "note": "wall time per call incl. the host side of the C-ABI call and output allocation; inputs and outputs in HBM"}
+
+
 def measure_dropin(device) -> dict:
     """The reference's own entry point on its own benchmark workloads (tests/benchmarks/test_bench_sweep.py:29-40
     times `solve_sweep` on the rocker axle; BASELINE config 1 is the 101-step bump sweep): wall-clock per call."""
@@ -648,6 +679,8 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["pipelined"] = measure_pipelined(dp, targets, device, max(args.steps, 60))
         line["with_model"] = measure_with_model(program, targets, device, args.steps, args.warmup)
         line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, extra_steps, dict(chain_len=args.chain_len, predictor=False))
+        from open_kinematics_amd.workloads import geometry_path
+        line["downstream"] = measure_downstream(dp, geometry_path("geometry.yaml"), pipe.local[0], device)
         dp.close()
         line["other_configs"] = [
             measure_config("C3 rocker + U-bar axle, 256x256 heave x roll grid (n = 60, pair mode)",
