@@ -84,6 +84,17 @@ def plan_stats(program) -> dict:
     return dict(zip(["n", "m", "pairs", "contrib", "active", "js_stride", "lda", "lds_bytes"], list(raw)))
 
 
+def committed_fp64(tag: str):
+    """fp64 instruction counts of the solve kernel from the committed PMC pass of this same command (SQ_INSTS_VALU_ADD/MUL/
+    FMA_F64, wave-level, per-dispatch medians): the counter-based companion of the analytic flop model."""
+    path = os.path.join(REPO, "profiles", PROFILE_ROUND, f"{tag}_pmc_traffic.json")
+    try:
+        with open(path, "r", encoding="utf-8") as fh:
+            return json.load(fh).get("fp64_instructions_per_launch"), os.path.relpath(path, REPO)
+    except (OSError, ValueError):
+        return None, None
+
+
 def committed_traffic(tag: str) -> tuple:
     """
     HBM bytes per launch of the solve kernel from the COMMITTED rocprofv3 PMC passes of this same command
@@ -659,6 +670,14 @@ def run_c2(args, world: int, rank: int, device) -> dict:
             "source": "analytic flop model x measured LM evaluations (not a counter reading)",
         },
     }
+    counted, counted_src = committed_fp64("bench_c2_cold" if not use_model else "bench_c2_model") if default_run else (None, None)
+    if counted:
+        hw = counted["flops_64_lanes"] / (kernel_ms * 1e-3) / 1e12
+        line["compute"]["counters"] = {
+            "fp64_flops_per_launch_64_lanes": counted["flops_64_lanes"], "achieved": hw, "frac": hw / FP64_VECTOR_PEAK_TFLOPS,
+            "useful_frac": 0.75 * hw / FP64_VECTOR_PEAK_TFLOPS, "source": counted_src, "measured_in_this_run": False,
+            "note": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 of the committed PMC pass x 64 lanes over this run's kernel time; one lane in "
+                    "four carries zeros in the quad layout (useful_frac = 3/4)"}
     if world > 1:
         line["solve_only"] = {
             "value": n_total / (kernel_ms * 1e-3),

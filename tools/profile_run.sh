@@ -16,6 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o t -- pytho
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/fetch" -o f -- python3 "$SCRIPT" "$@" > /dev/null 2> "$O/pmc_fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/write" -o w -- python3 "$SCRIPT" "$@" > /dev/null 2> "$O/pmc_write.err"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$O/sq" -o sq -- python3 "$SCRIPT" "$@" > /dev/null 2> "$O/pmc_sq.err"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d "$O/sq3" -o sq3 -- python3 "$SCRIPT" "$@" > /dev/null 2> "$O/pmc_sq3.err" || true
 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS --output-format csv -d "$O/sq2" -o sq2 -- python3 "$SCRIPT" "$@" > /dev/null 2> "$O/pmc_sq2.err" || true
 python3 - "$O" "$KPREFIX" <<'PY'
 import csv, glob, json, statistics as st, sys
@@ -33,8 +34,9 @@ for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     # median over dispatches: setup launches of the same kernel (predictor node solves, warm-up of another mode) are outliers
     out[name] = {"per_dispatch_kib_median": st.median(v), "per_dispatch_kib_mean": st.mean(v), "min": min(v), "max": max(v), "dispatches": len(v)} if v else None
 for grp, names in (("SQ", ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY")),
-                   ("SQ2", ("SQ_INSTS_LDS", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_INSTS_FLAT", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS"))):
-    path = find("sq" if grp == "SQ" else "sq2", "counter_collection.csv")
+                   ("SQ2", ("SQ_INSTS_LDS", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM", "SQ_INSTS_FLAT", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS")),
+                   ("SQ3", ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))):
+    path = find({"SQ": "sq", "SQ2": "sq2", "SQ3": "sq3"}[grp], "counter_collection.csv")
     rec = {}
     for name in names:
         v = vals(path, name)

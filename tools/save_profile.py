@@ -16,7 +16,7 @@ shutil.copy(f"{O}/run_under_rocprof.json", f"{P}/{tag}_under_rocprof.json")
 shutil.copy(find("trace", "kernel_stats.csv"), f"{P}/{tag}_kernel_stats.csv")
 with open(find("trace", "kernel_trace.csv")) as f, open(f"{P}/{tag}_kernel_trace_head.csv", "w") as g:
     g.writelines(line for i, line in enumerate(f) if i < 40)
-for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", "SQ"), ("sq2", "SQ2")):
+for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", "SQ"), ("sq2", "SQ2"), ("sq3", "SQ3")):
     src = find(d, "counter_collection.csv")
     if src:
         shutil.copy(src, f"{P}/{tag}_pmc_{name}.csv")
@@ -46,9 +46,15 @@ out = {
         "wait_any_share": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
         "note": "SQ cycle counters are in quad-cycles (x4 applied)"},
     "sq2_per_wavefront": {k: v / w for k, v in s.get("SQ2", {}).items()},
+    "fp64_instructions_per_launch": (lambda q: None if not q or "SQ_INSTS_VALU_FMA_F64" not in q else {
+        "add": q.get("SQ_INSTS_VALU_ADD_F64", 0.0), "mul": q.get("SQ_INSTS_VALU_MUL_F64", 0.0), "fma": q["SQ_INSTS_VALU_FMA_F64"],
+        "trans": q.get("SQ_INSTS_VALU_TRANS_F64", 0.0), "valu_total": q.get("SQ_INSTS_VALU"),
+        "flops_64_lanes": 64.0 * (q.get("SQ_INSTS_VALU_ADD_F64", 0.0) + q.get("SQ_INSTS_VALU_MUL_F64", 0.0) + 2.0 * q["SQ_INSTS_VALU_FMA_F64"]),
+        "note": "wave-level instruction counts (per-dispatch medians) x 64 lanes; v_max / v_min / compares and the 32-bit moves are not "
+                "in them; one lane in four carries zeros in the quad layout, so the useful share is 3/4 of flops_64_lanes"})(s.get("SQ3")),
     "kernel_stats": s["kernel_stats"],
     "kernel_ms_events": kms(run), "kernel_ms_events_under_rocprof": kms(under),
-    "raw": {k: s[k] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2") if k in s},
+    "raw": {k: s[k] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2", "SQ3") if k in s},
 }
 json.dump(out, open(f"{P}/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: out[k] for k in ("dispatch", "traffic_bytes_per_launch", "traffic_over_algorithmic", "sq_counters_per_wavefront",
