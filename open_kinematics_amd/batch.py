@@ -54,8 +54,6 @@ def _as_f64(t, device) -> torch.Tensor:
 class DeviceProgram:
     """A constraint program resident on one GPU."""
 
-    AUTO_PREDICTOR_MIN_BATCH = 256  # predictor=None fits the chain-head model at the first launch of at least this size
-
     def __init__(self, program: ConstraintProgram, device: torch.device | str | None = None):
         if not torch.cuda.is_available():
             raise RuntimeError(
@@ -70,7 +68,7 @@ class DeviceProgram:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.okx_program_create(self.host.byref(), C.byref(handle)), "okx_program_create")
         self._handle = handle
-        self._predictor: bool | None = None  # fitted lazily (fit_predictor)
+        self._predictor: bool | None = None  # None: no fit attempted yet (fit_predictor)
         self.predictor_box = None
         self._predictor_note = ""
 
@@ -125,9 +123,10 @@ class DeviceProgram:
         Solve ``B`` problems; ``targets`` is ``[B, T]`` of absolute target scalars.
 
         ``predictor``: chain heads start from the polynomial model of ``okx_program_fit_predictor`` instead of
-        the design state (own-geometry launches of the quad kernel).  ``None`` = use it when it can be
-        fitted (once, over the target box of the first such launch), ``True`` = require it, ``False`` = plain
-        cold starts, ``"all"`` = every chain step starts from the model (instead of the secant extrapolation).
+        the design state (own-geometry launches of the quad kernel).  ``None`` (default) = use a model that
+        ``fit_predictor`` has fitted, never fit one implicitly; ``True`` = require it (fitted over this launch's target
+        box if there is none yet); ``False`` = cold starts; ``"all"`` = every chain step starts from the model (instead
+        of the secant extrapolation).
 
         ``shared_first_step`` (default on): chain heads take their first LM step from the per-geometry table of the
         design state instead of running that (batch-invariant) pass themselves (``okx_solve_opts``).
@@ -163,10 +162,10 @@ class DeviceProgram:
         if shared_first_step is not None:
             opts.shared_first_step = 1 if shared_first_step else 0
         if predictor is not False and geom_pos is None and opts.kernel in (0, 3):
-            # Fitted once, over the target box of the first sizeable launch (later launches clamp to it; refit with
-            # fit_predictor).  Automatic mode leaves small batches alone: the fit costs more than it would save, and a
-            # box fitted to a handful of problems says nothing about the sweeps that follow.
-            fit_now = self._predictor is None and (predictor is not None or b >= self.AUTO_PREDICTOR_MIN_BATCH)
+            # The model is never fitted behind the caller's back (the fit is a synchronous ~8 ms step: node solves, D2H,
+            # host fit): predictor=None uses a model that fit_predictor() has put there, True / "all" fit one over this
+            # launch's target box if there is none yet (later launches clamp to that box; refit with fit_predictor).
+            fit_now = self._predictor is None and predictor is not None
             if self.fit_predictor(targets if fit_now else None, required=bool(predictor)):
                 opts.predictor = 2 if predictor == "all" else 1
         if geom_pos is not None:

@@ -90,14 +90,18 @@ def test_predictor_is_skipped_where_it_does_not_apply(golden):
     # generic interpreter kernel: no predictor, plain solve
     a = dp.solve(t, kernel="single")
     assert dp._predictor is None
-    # automatic mode leaves small batches alone (64 < AUTO_PREDICTOR_MIN_BATCH) ...
+    # a plain solve never fits a model behind the caller's back (the fit is a synchronous step), whatever the batch size ...
     small = dp.solve(t)
     assert dp._predictor is None and float((small.positions - a.positions).abs().max()) <= 1e-9
-    # ... and fits at the first sizeable launch
-    big_program, big_targets = bump_sweep_problem(dp.AUTO_PREDICTOR_MIN_BATCH)
+    big_program, big_targets = bump_sweep_problem(4096)
     big = DeviceProgram(big_program, "cuda:0")
-    big.solve(torch.as_tensor(big_targets, device="cuda:0"))
-    assert big._predictor is True and big.predictor_box is not None
+    plain = big.solve(torch.as_tensor(big_targets, device="cuda:0"))
+    assert big._predictor is None and big.predictor_box is None
+    # ... but uses one that was fitted explicitly
+    assert big.fit_predictor(torch.as_tensor(big_targets, device="cuda:0"))
+    modelled = big.solve(torch.as_tensor(big_targets, device="cuda:0"))
+    assert big._predictor is True and modelled.info()["nfev"].mean() < plain.info()["nfev"].mean()
+    assert float((modelled.positions - plain.positions).abs().max()) <= 1e-9
     # per-geometry launches never use it
     gpos, gparam = dp.rebind(torch.as_tensor(program.design_pos[None]))
     dp.fit_predictor(t, required=True)
