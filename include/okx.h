@@ -159,14 +159,15 @@ typedef struct okx_solve_opts {
                              the polynomial model of okx_program_fit_predictor instead of the design state
                              (ignored until a predictor has been fitted).  Same solutions, fewer passes. */
   int32_t shared_first_step; /* quad kernel (single mode).  non-zero (default 1): a chain head starts at its geometry's
-                             design state, where the constraint residuals vanish and the Jacobian, J^T J and its damped
-                             factorisation are identical for every problem of that geometry; that first Levenberg-
-                             Marquardt pass is evaluated ONCE PER GEOMETRY (a small launch ahead of the solve; own
-                             geometry: once per program and lambda0) and every head takes its first step
-                             dx = -sum_t r_t (J^T J + lambda I)^-1 J^T e_t from that table.  Same iteration, same
-                             iterates up to rounding; info.nfev counts the evaluations a problem ran itself.
-                             0: every chain head runs its own first pass.  With geometry tables the scratch table lives
-                             in the program: such launches of one program must be stream-ordered.                      */
+                             design state, where only the target residuals depend on the problem: the constraint
+                             residuals, the Jacobian, J^T J and its damped factorisation are identical for every problem
+                             of that geometry.  That first Levenberg-Marquardt pass is evaluated ONCE PER GEOMETRY (own
+                             geometry: once per program and lambda0; geometry tables: a small launch ahead of the solve,
+                             when there are at least four steps per geometry) and every head takes its first step
+                             dx = -(Q_0 + sum_t r_t Q_t), Q_k = (J^T J + lambda I)^-1 G_k, from that table.  Same
+                             iteration, same iterates up to rounding; info.nfev counts the evaluations a problem ran
+                             itself.  0: every chain head runs its own first pass.  With geometry tables the scratch
+                             table lives in the program: such launches of one program must be stream-ordered.        */
 } okx_solve_opts;
 
 /* Per-problem result, the device analogue of SolverInfo (solver.py:83-96). */

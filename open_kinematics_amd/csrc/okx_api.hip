@@ -529,7 +529,9 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
           p->head_lambda0 = opts->lambda0;
         }
         q.head = p->head_dev;
-      } else {
+      } else if (spg >= 4 && (n_problems / spg) * (long long)p->head_stride * 8 <= (256LL << 20)) {
+        // (one table row costs about 1.3 passes of one quad: with fewer than four steps per geometry, or a table beyond
+        //  256 MiB, the heads run their own first pass)
         const long long n_geom = n_problems / spg;
         if (n_geom > p->head_geom_cap) {
           // grow-only scratch; earlier launches may still read the old table
