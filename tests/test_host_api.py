@@ -162,3 +162,44 @@ def test_reference_objects_pass_through_the_drop_in_front_end(golden):
         assert np.array_equal(table, arrays["targets_abs"])
         # the reference's own ActuatorDOF objects drive the control validation
         validate_sweep_controls(sweep, sus.actuator_dofs())
+
+
+def test_parallel_chain_policy_and_continuity_check():
+    """solver._segment_length / _chains_are_continuous on synthetic paths (the device part is tests/test_gpu_dropin.py)."""
+    from types import SimpleNamespace
+
+    from open_kinematics_amd import solver
+
+    assert [solver._segment_length(n) for n in (1, 31, 32, 36, 101, 1000)] == [0, 0, 8, 8, 11, 32]
+    program = SimpleNamespace(out_point=np.arange(4), free_point=np.array([1, 3]))
+    steps = 40
+    table = np.stack([np.linspace(0.0, 39.0, steps), np.zeros(steps)], axis=1)
+    s = table[:, 0]
+    pos = np.zeros((steps, 4, 3))
+    pos[:, 1, 0] = 2.0 * s + 0.01 * s * s   # smooth path of the first free point
+    pos[:, 3, 2] = -s
+    info = np.zeros(steps, dtype=[("flags", "<i4")])
+    info["flags"] = 1
+    assert solver._chains_are_continuous(program, table, pos, info, 8)
+    other_branch = pos.copy()
+    other_branch[16:24, 3, 2] += 3.0            # one chain landed three steps away from the path
+    assert not solver._chains_are_continuous(program, table, other_branch, info, 8)
+    flagged = info.copy()
+    flagged["flags"][5] = 0
+    assert not solver._chains_are_continuous(program, table, pos, flagged, 8)
+    missing = SimpleNamespace(out_point=np.arange(3), free_point=np.array([1, 3]))  # a free point that is not an output
+    assert not solver._chains_are_continuous(missing, table, pos[:, :3], info, 8)
+
+
+def test_bench_helpers():
+    import bench
+    from types import SimpleNamespace
+
+    cores, how = bench.host_cores()
+    assert cores >= 1 and ("affinity" in how or "quota" in how)
+    dw = SimpleNamespace(n_targets=2, n_out=15)
+    assert bench.algorithmic_bytes_per_solve(dw) == 392.0                     # SURVEY.md section 8d, C2
+    assert abs(bench.algorithmic_bytes_per_solve(dw, 256) - 393.46875) < 1e-9   # C5: + (10 x 24 + 17 x 8) / 256
+    assert bench.algorithmic_bytes_per_solve(SimpleNamespace(n_targets=3, n_out=38)) == 952.0
+    assert bench.algorithmic_bytes_per_solve(SimpleNamespace(n_targets=2, n_out=14)) == 368.0
+    assert bench.committed_traffic("no_such_tag") == (None, None)

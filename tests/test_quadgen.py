@@ -99,3 +99,25 @@ def test_header_documents_the_kernel_choice():
     text = open(os.path.join(REPO, "include", "okx.h"), encoding="utf-8").read()
     for name in ("okx_program_kernel", "okx_quad_source", "okx_precompile"):
         assert name in text
+
+
+def test_first_step_table_kernels_are_generated_where_they_pay(golden, monkeypatch):
+    """okx_quad_head_u/_g: single-mode programs with targets carry them and take the unit's head step
+    in the prologue; pair-mode kernels only on request; OKX_QUAD_NO_HEAD removes them."""
+    _, dw = golden("c1_dw_corner")
+    src = _source(dw.with_line_mode("pinned"))
+    assert "okx_quad_head_u(QHeadArgs a)" in src and "okx_quad_head_g(QHeadArgs a)" in src
+    assert "__shared__ double hxl[" in src and "if (head_ready && b == first_b)" in src
+    # table stride = 4 n_free (T + 1) + 2 (T + 1)^2 + 8 doubles: the head kernel's last scalar slot
+    k = dw.n_targets + 1
+    stride = 4 * dw.n_free * k + 2 * k * k + 8
+    assert f"double* ho = a.head + geom * {stride};" in src
+    assert "v_div" not in src and " / pred" not in src  # control code divides through refined reciprocals
+    _, axle = golden("c3_axle_grid")
+    pair = _source(axle.with_line_mode("pinned"))
+    assert "okx_quad_head_u(QHeadArgs" not in pair and "lms[" in pair and "lean_atan2_pos<true>" in pair  # pair mode: LDS state, no table
+    monkeypatch.setenv("OKX_PAIR_HEAD", "1")
+    assert "okx_quad_head_u(QHeadArgs a)" in _source(axle.with_line_mode("pinned"))
+    monkeypatch.delenv("OKX_PAIR_HEAD")
+    monkeypatch.setenv("OKX_QUAD_NO_HEAD", "1")
+    assert "okx_quad_head_u(QHeadArgs" not in _source(dw.with_line_mode("pinned"))
