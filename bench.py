@@ -551,7 +551,7 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize(device)
+        torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.sum([s.elapsed_time(e) for s, e in zip(starts, ends)])) / steps
     if world > 1:
