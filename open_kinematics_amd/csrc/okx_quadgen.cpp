@@ -778,6 +778,17 @@ class Gen {
     return true;
   }
 
+  // pin_ata / pin_atr: every row's J^T J and J^T r contributions are made where the row is (an opaque use after the
+  // row).  Left alone the optimiser sinks all of them into the branch that factors, and keeps every row's gradient and
+  // its broadcasts alive until then - in AGPRs, at a v_accvgpr move per use (measured: DW corner -4 %, MacPherson -7 %,
+  // axle -6 % per sweep; tools/quad_sections.py shows where a pass's instructions are).
+  bool pin_ata = false, pin_atr = false;
+  // OKX_QUAD_MARK=1: `s_nop 11..17` between the sections of a pass (tools/quad_sections.py counts the instructions
+  // in between; scheduling barriers keep the sections apart, so the marked kernel is for counting, not for timing)
+  bool marks = false;
+  void mark(int n) {
+    if (marks) f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + n);
+  }
   bool emit_rows() {
     const int nf = P.n_free;
     for (int F = 0; F < nf; ++F) {
@@ -788,9 +799,11 @@ class Gen {
     std::set<std::string> declared;
     for (int i = 0; i < P.m; ++i) {
       RowOut ro;
+      mark(1);
       if (!row(i, &ro)) return false;
       f("    ss = fma(%s, %s, ss);", ro.r.c_str(), ro.r.c_str());
       if (!ro.absres.empty()) f("    mres_new = fmax(mres_new, %s);", ro.absres.c_str());
+      mark(2);
       // point partials -> free blocks
       std::map<int, std::vector<LV>> terms;
       for (auto& pp : ro.partial) {
@@ -838,6 +851,10 @@ class Gen {
       if (row_fence > 0 && (i + 1) % row_fence == 0) fence_after_row = true;
       // J^T r and J^T J (lower block triangle: F >= G)
       for (auto& fv : jv) f("    gn%d = fma(%s, %s, gn%d);", fv.first, sx(fv.second).c_str(), ro.r.c_str(), fv.first);
+      if (pin_atr)
+        for (auto& fv : jv) f("    asm volatile(\"\" : \"+v\"(gn%d));", fv.first);
+      mark(3);
+      std::vector<std::string> touched;
       for (size_t ia = 0; ia < jv.size(); ++ia)
         for (size_t ib = 0; ib <= ia; ++ib) {
           const int F = jv[ia].first, G = jv[ib].first;
@@ -854,8 +871,12 @@ class Gen {
             } else {
               f("    %s = fma(%s%s, %s, %s);", an.c_str(), sg < 0 ? "-" : "", jF.n.c_str(), b.c_str(), an.c_str());
             }
+            touched.push_back(an);
           }
         }
+      if (pin_ata)
+        for (auto& an : touched) f("    asm volatile(\"\" : \"+v\"(%s));", an.c_str());
+      mark(4);
       if (fence_after_row) {
         // keep the scheduler from interleaving many rows' temporaries (the kernel is register-bound)
         f("    __builtin_amdgcn_sched_barrier(0);");
@@ -871,11 +892,14 @@ class Gen {
 
   // LDL^T of (J^T J + lambda I), forward / diagonal / backward substitution -> dx{F}.
   void emit_solve() {
+    mark(5);
     emit_factor();
+    mark(6);
     // right-hand side -g, result nx{F}
     std::vector<std::string> rhs;
     for (int F = 0; F < P.n_free; ++F) rhs.push_back("-gn" + std::to_string(F));
     emit_substitute(rhs, "nx");
+    mark(7);
   }
 
   // LDL^T of (J^T J + lambda I) in registers; leaves L{F}_{G}_{k}, dinv{F}, ok, pmin, pmax.
@@ -1189,6 +1213,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   ev.lds_constants = pv != nullptr || getenv("OKX_QUAD_LDS") != nullptr;
   if (const char* env = getenv(pv ? "OKX_PAIR_ROW_FENCE" : "OKX_QUAD_ROW_FENCE")) ev.row_fence = atoi(env);
   if (const char* env = getenv(pv ? "OKX_PAIR_COL_FENCE" : "OKX_QUAD_COL_FENCE")) ev.col_fence = atoi(env);
+  ev.pin_ata = ev.pin_atr = getenv("OKX_QUAD_NO_PIN") == nullptr;  // (experiment switch)
+  ev.marks = getenv("OKX_QUAD_MARK") != nullptr;
   for (int e = 0; e < P.n_derived; ++e) ev.dp(e);  // every derived-op parameter is chain-constant
   ev.f("    // ---- active derived points with chain-rule blocks ----");
   for (int idx = 0; idx < P.n_active; ++idx)
