@@ -47,6 +47,10 @@ int32_t okx_debug_phase_profile(okx_program* prog, const okx_solve_opts* opts, i
  * derived ops, Jacobian row stride, lda, LDS bytes of the generic kernel). */
 int32_t okx_debug_plan_stats(const okx_program_desc* desc, int32_t* out8);
 
+/* Scratch (private segment) bytes of the runtime-specialised solve kernels this program would use, read from the code
+ * object's metadata (no device needed; compiles into the kernel cache like okx_precompile): 0 = nothing spilt. */
+int32_t okx_debug_kernel_scratch(const okx_program_desc* desc, int32_t* scratch_bytes);
+
 #ifdef __cplusplus
 }
 #endif

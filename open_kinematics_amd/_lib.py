@@ -49,6 +49,7 @@ DEBUG_EXPORTS = (
     "okx_debug_quad_trace",
     "okx_debug_phase_profile",
     "okx_debug_plan_stats",
+    "okx_debug_kernel_scratch",
 )
 
 _lib = None
@@ -98,6 +99,8 @@ def load() -> C.CDLL:
     lib.okx_rebind_design.restype = i32
     lib.okx_debug_plan_stats.argtypes = [C.POINTER(ProgramDesc), C.POINTER(i32)]
     lib.okx_debug_plan_stats.restype = i32
+    lib.okx_debug_kernel_scratch.argtypes = [C.POINTER(ProgramDesc), C.POINTER(i32)]
+    lib.okx_debug_kernel_scratch.restype = i32
     lib.okx_debug_quad_trace.argtypes = [vp, vp, i64]
     lib.okx_debug_quad_trace.restype = i32
     lib.okx_debug_phase_profile.argtypes = [vp, C.POINTER(SolveOpts), i64, vp, vp, vp, vp, vp]

@@ -194,14 +194,10 @@ void attach_quad_kernel(okx_program* p) {
       return;
     }
   }
-  std::string src, why, code, err;
-  if (!okx::quad_generate(p->host, quad_waves_per_simd(), &src, &why)) {
-    std::snprintf(p->quad_note, sizeof(p->quad_note), "not generated: %s", why.c_str());
-    return;
-  }
-  if (!okx::quad_compile(src, &code, &err)) {
-    std::snprintf(p->quad_note, sizeof(p->quad_note), "compile failed: %.200s", err.c_str());
-    if (getenv("OKX_VERBOSE")) std::fprintf(stderr, "okx: quad kernel: %s\n", err.c_str());
+  std::string src, why, code;
+  if (!okx::quad_build(p->host, quad_waves_per_simd(), &src, &code, &why)) {
+    std::snprintf(p->quad_note, sizeof(p->quad_note), "not generated: %.200s", why.c_str());
+    if (getenv("OKX_VERBOSE")) std::fprintf(stderr, "okx: quad kernel: %s\n", why.c_str());
     return;
   }
   hipModule_t mod = nullptr;
@@ -209,7 +205,7 @@ void attach_quad_kernel(okx_program* p) {
   if (e != hipSuccess) {
     // a damaged cache entry (truncated file, other toolchain): rebuild it once
     (void)hipGetLastError();
-    if (okx::quad_compile(src, &code, &err, true)) e = hipModuleLoadData(&mod, code.data());
+    if (okx::quad_build(p->host, quad_waves_per_simd(), &src, &code, &why, true)) e = hipModuleLoadData(&mod, code.data());
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -400,12 +396,26 @@ int32_t okx_precompile(const okx_program_desc* desc) {
   okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
   if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
   int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
-  std::string src, why, code, err;
-  if (rc == OKX_OK && !okx::quad_generate(*tmp, quad_waves_per_simd(), &src, &why))
+  std::string src, why, code;
+  if (rc == OKX_OK && !okx::quad_build(*tmp, quad_waves_per_simd(), &src, &code, &why))
+    rc = fail(why.compare(0, 14, "compile failed") == 0 ? OKX_ERR_DEVICE : OKX_ERR_LIMIT, "no quad kernel for this program: %s", why.c_str());
+  delete tmp;
+  return rc;
+}
+
+/* Scratch (private segment) bytes of the solve kernels okx_precompile / okx_program_create would use for this program:
+   0 means the register allocation holds everything (what every BASELINE program is expected to report). */
+int32_t okx_debug_kernel_scratch(const okx_program_desc* desc, int32_t* scratch_bytes) {
+  if (!scratch_bytes) return fail(OKX_ERR_INVALID, "null output pointer");
+  okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
+  if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
+  int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
+  std::string src, why, code;
+  if (rc == OKX_OK && !okx::quad_build(*tmp, quad_waves_per_simd(), &src, &code, &why))
     rc = fail(OKX_ERR_LIMIT, "no quad kernel for this program: %s", why.c_str());
   delete tmp;
   if (rc != OKX_OK) return rc;
-  if (!okx::quad_compile(src, &code, &err)) return fail(OKX_ERR_DEVICE, "%s", err.c_str());
+  *scratch_bytes = okx::quad_code_scratch_bytes(code, "okx_quad_solve");
   return OKX_OK;
 }
 

@@ -166,4 +166,55 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err, b
   return true;
 }
 
+// Minimal reader for the two msgpack fields needed from the AMDGPU metadata note: kernel-level maps list their keys in
+// alphabetical order, so the ".name" string nearest before a ".private_segment_fixed_size" key is that kernel's name
+// (argument names sit under ".args", earlier in the map).
+int quad_code_scratch_bytes(const std::string& code, const char* prefix) {
+  static const char kKey[] = ".private_segment_fixed_size";
+  static const char kName[] = ".name";
+  const size_t klen = sizeof(kKey) - 1, nlen = sizeof(kName) - 1, plen = std::strlen(prefix);
+  int best = -1;
+  for (size_t at = code.find(kKey); at != std::string::npos; at = code.find(kKey, at + klen)) {
+    const unsigned char* v = reinterpret_cast<const unsigned char*>(code.data()) + at + klen;
+    const size_t left = code.size() - (at + klen);
+    long long value = -1;
+    if (left >= 1 && v[0] <= 0x7f) value = v[0];
+    else if (left >= 2 && v[0] == 0xcc) value = v[1];
+    else if (left >= 3 && v[0] == 0xcd) value = (v[1] << 8) | v[2];
+    else if (left >= 5 && v[0] == 0xce) value = ((long long)v[1] << 24) | (v[2] << 16) | (v[3] << 8) | v[4];
+    if (value < 0) continue;
+    const size_t nm = code.rfind(kName, at);
+    if (nm == std::string::npos) continue;
+    const unsigned char* s = reinterpret_cast<const unsigned char*>(code.data()) + nm + nlen;
+    size_t len = 0, skip = 0;
+    if ((s[0] & 0xe0) == 0xa0) len = s[0] & 0x1f, skip = 1;
+    else if (s[0] == 0xd9) len = s[1], skip = 2;
+    else if (s[0] == 0xda) len = (s[1] << 8) | s[2], skip = 3;
+    else continue;
+    if (nm + nlen + skip + len > at || len < plen) continue;
+    if (std::memcmp(s + skip, prefix, plen) != 0) continue;
+    if (value > best) best = (int)value;
+  }
+  return best;
+}
+
+bool quad_build(const DevProgram& P, int waves_per_simd, std::string* src, std::string* code, std::string* why,
+                bool ignore_cached) {
+  std::string err;
+  if (!quad_generate(P, waves_per_simd, src, why, false)) return false;
+  if (!quad_compile(*src, code, &err, ignore_cached)) {
+    *why = "compile failed: " + err;
+    return false;
+  }
+  if (P.n_free <= kQuadMaxFree || quad_code_scratch_bytes(*code, "okx_quad_solve") <= 0) return true;
+  // pair mode and the register-resident variant spills: constants and fixed points back to LDS
+  std::string src2, code2, why2;
+  if (!quad_generate(P, waves_per_simd, &src2, &why2, true) || !quad_compile(src2, &code2, &err, ignore_cached)) return true;
+  if (quad_code_scratch_bytes(code2, "okx_quad_solve") < quad_code_scratch_bytes(*code, "okx_quad_solve")) {
+    *src = src2;
+    *code = code2;
+  }
+  return true;
+}
+
 }  // namespace okx

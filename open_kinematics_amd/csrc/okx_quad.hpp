@@ -112,12 +112,24 @@ bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why);
 // Emits the HIP source of the kernel specialised to `P`.  Returns false (and says why) when the
 // program uses a feature the generator has no code path for; the caller then keeps the generic
 // interpreter kernels of okx_kernels.hip.
-bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why);
+// `lds_homes` (pair mode only): the chain constants and the fixed points live in LDS instead of registers - the
+// fallback for a half program whose register-resident variant spills (see quad_build).
+bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why, bool lds_homes = false);
 
 // Compiles `src` for gfx950 with hiprtc (no device needed) or fetches it from the on-disk cache
 // (<dir of libokx.so>/_kcache/<hash>.okxc, override with OKX_KERNEL_CACHE).  Returns the code
 // object in `code`; false + message on failure.
 // `ignore_cached` recompiles and overwrites the cache entry (used once when a cached object fails to load).
 bool quad_compile(const std::string& src, std::string* code, std::string* err, bool ignore_cached = false);
+
+// Largest private-segment (scratch) size among the kernels of a code object whose name starts with `prefix`, read from
+// the code object's metadata note; -1 when no such kernel is found.
+int quad_code_scratch_bytes(const std::string& code, const char* prefix);
+
+// quad_generate + quad_compile.  A pair-mode program is first generated with its chain constants in registers; if the
+// compiler then spills in the solve kernels (a larger half program than the BASELINE axle), the variant with LDS homes
+// is generated and compiled instead.  `src` receives the source of the variant that was kept.
+bool quad_build(const DevProgram& P, int waves_per_simd, std::string* src, std::string* code, std::string* why,
+                bool ignore_cached = false);
 
 }  // namespace okx

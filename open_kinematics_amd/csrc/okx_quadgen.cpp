@@ -453,7 +453,7 @@ class Gen {
     char name[48], line[200];
     std::snprintf(name, sizeof(name), "hd%d", e);
     const std::string home = scalar_home(name);
-    std::snprintf(line, sizeof(line), "      %s%s = a.dop_param[%s];\n", decl(), home.c_str(), dop_slot(e).c_str());
+    std::snprintf(line, sizeof(line), "      %s%s = a.dop_param[%s];\n", sdecl(), home.c_str(), dop_slot(e).c_str());
     hoisted += line;
     hoisted_names[key] = home;
     return home;
@@ -472,9 +472,9 @@ class Gen {
     std::snprintf(name, sizeof(name), "hs%d_%d", i, k);
     const std::string home = scalar_home(name);
     if (i < P.n_crows)
-      std::snprintf(line, sizeof(line), "      %s%s = gq[%s];\n", decl(), home.c_str(), crow8(i, k).c_str());
+      std::snprintf(line, sizeof(line), "      %s%s = gq[%s];\n", sdecl(), home.c_str(), crow8(i, k).c_str());
     else
-      std::snprintf(line, sizeof(line), "      %s%s = a.row_param[%s];\n", decl(), home.c_str(), trow8(i, k).c_str());
+      std::snprintf(line, sizeof(line), "      %s%s = a.row_param[%s];\n", sdecl(), home.c_str(), trow8(i, k).c_str());
     hoisted += line;
     hoisted_names[key] = home;
     return home;
@@ -491,15 +491,18 @@ class Gen {
   bool lds_constants = false;
 
   int n_scalar_slots = 0, n_lane_slots = 0;
+  // (the scalars and the lane components can be sent back to registers separately: experiment switches)
+  bool scalars_in_regs = false, lanes_in_regs = false;
   std::string scalar_home(const char* name) {
-    if (!lds_constants) return name;
+    if (!lds_constants || scalars_in_regs) return name;
     return "hsl[" + std::to_string(16 * n_scalar_slots++) + " + qs]";
   }
   std::string lane_home(const char* name) {
-    if (!lds_constants) return name;
+    if (!lds_constants || lanes_in_regs) return name;
     return "hql[" + std::to_string(64 * n_lane_slots++) + " + lane]";
   }
-  const char* decl() const { return lds_constants ? "" : "const double "; }
+  const char* sdecl() const { return lds_constants && !scalars_in_regs ? "" : "const double "; }
+  const char* ldecl() const { return lds_constants && !lanes_in_regs ? "" : "const double "; }
   std::string rpv(int i, int k0) {
     i = pin_leader(i);
     auto key = std::make_pair(i, k0);
@@ -509,9 +512,9 @@ class Gen {
     std::snprintf(name, sizeof(name), "hq%d_%d", i, k0);
     const std::string home = lane_home(name);
     if (i < P.n_crows)
-      std::snprintf(line, sizeof(line), "      %s%s = ld3(gq + %s + cc, c);\n", decl(), home.c_str(), crow8(i, k0).c_str());
+      std::snprintf(line, sizeof(line), "      %s%s = ld3(gq + %s + cc, c);\n", ldecl(), home.c_str(), crow8(i, k0).c_str());
     else  // target direction; zero on a side that does not carry this target (pair mode)
-      std::snprintf(line, sizeof(line), "      %s%s = ld3(a.row_param + %s + cc, c) * %s;\n", decl(), home.c_str(),
+      std::snprintf(line, sizeof(line), "      %s%s = ld3(a.row_param + %s + cc, c) * %s;\n", ldecl(), home.c_str(),
                     trow8(i, k0).c_str(), target_enable(target_of_row(i)).c_str());
     hoisted += line;
     hoisted_names[key] = home;
@@ -1180,7 +1183,7 @@ int quad_head_stride(const DevProgram& program) {
   return 2 * 4 * pv.side.n_free * k + 2 * k * k + 8;
 }
 
-bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* src, std::string* why) {
+bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* src, std::string* why, bool lds_homes) {
   // Small programs: one quad per problem.  Larger ones only when they are two identical halves
   // joined by one distance row (composed axle): one quad per half, a 2 x 2 Woodbury correction for the joint.
   PairView pair_store;
@@ -1210,7 +1213,14 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
 
   // ---- evaluation body (rows + normal equations), generated first to learn the sparsity ----
   Gen ev(P, pv);
+  // Pair mode: the accepted point, the chain history and the step in hand live in LDS (`lds_constants` switches that
+  // layout on); the chain constants and the fixed points stay in registers unless the caller asks for LDS homes (the
+  // fallback of quad_build for half programs that would spill) - measured on the axle grid: -8.5 % chained, -10 % cold
+  // against everything in LDS (130 -> 60 LDS round trips per pass, which a lone wavefront cannot hide).
+  if (getenv("OKX_PAIR_LDS_HOMES")) lds_homes = true;  // (experiment switch)
   ev.lds_constants = pv != nullptr || getenv("OKX_QUAD_LDS") != nullptr;
+  ev.scalars_in_regs = ev.lanes_in_regs = pv != nullptr && !lds_homes;
+  const bool fixed_in_regs = pv != nullptr && !lds_homes;
   if (const char* env = getenv(pv ? "OKX_PAIR_ROW_FENCE" : "OKX_QUAD_ROW_FENCE")) ev.row_fence = atoi(env);
   if (const char* env = getenv(pv ? "OKX_PAIR_COL_FENCE" : "OKX_QUAD_COL_FENCE")) ev.col_fence = atoi(env);
   ev.pin_ata = ev.pin_atr = getenv("OKX_QUAD_NO_PIN") == nullptr;  // (experiment switch)
@@ -1301,9 +1311,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     FU = ev.blk_of_point[pv->couple_point];
     char buf[1024];
     const std::string hcl_home = ev.scalar_home("hcL");
-    std::snprintf(buf, sizeof(buf), "      %s = gq[%d];  // length of the joining row\n", hcl_home.c_str(), 8 * pv->couple_row);
+    std::snprintf(buf, sizeof(buf), "      %s%s = gq[%d];  // length of the joining row\n", ev.sdecl(), hcl_home.c_str(), 8 * pv->couple_row);
     couple_hoist = buf;
-    couple_hoist += "#define hcL " + hcl_home + "\n";
+    if (hcl_home != "hcL") couple_hoist += "#define hcL " + hcl_home + "\n";
     std::snprintf(buf, sizeof(buf),
                   "    const double cd = xq(p%d) - p%d;\n"
                   "    const double cs = qsum(cd * cd);\n"
@@ -1339,11 +1349,21 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("// Two quads own one problem: `xq` reads the other quad's lane with the same component");
     g.f("// (ds_swizzle, lane ^ 4: data path only, no LDS memory); PSUM / PMAX reduce over both quads and");
     g.f("// are bit-identical in all eight lanes (commutative combination of the two quad results).");
+    if (getenv("OKX_PAIR_XQ_DPP")) {
+      // lane ^ 4 as two masked row shifts on the vector ALU: quads 1 and 3 of a row read four lanes down, quads 0 and 2
+      // four lanes up (bank masks 0xA / 0x5)
+      g.f("DEV int xq32(int v) {");
+      g.f("  int t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xA, false);");
+      g.f("  return __builtin_amdgcn_update_dpp(t, v, 0x104, 0xf, 0x5, false);");
+      g.f("}");
+      g.f("DEV double xq(double v) { return __hiloint2double(xq32(__double2hiint(v)), xq32(__double2loint(v))); }");
+    } else {
     g.f("DEV double xq(double v) {");
     g.f("  int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x101F);");
     g.f("  int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x101F);");
     g.f("  return __hiloint2double(hi, lo);");
     g.f("}");
+    }
     g.f("DEV double PSUM(double v) { const double s = qsum(v); return s + xq(s); }");
     g.f("DEV double PMAX(double v) { const double s = qmax(v); return fmax(s, xq(s)); }");
     g.f("#define PJOIN_SUM(v) ((v) + xq(v))");
@@ -1370,8 +1390,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("  __shared__ double xsl[%d];  // accepted point, chain history and the step in hand [block][lane]", 64 * 4 * nf);
     int n_fixed = 0;
     for (int p = 0; p < NP; ++p) n_fixed += ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
-    g.f("  __shared__ double psl[%d];  // fixed points [point][lane]", 64 * (n_fixed > 0 ? n_fixed : 1));
+    if (!fixed_in_regs) g.f("  __shared__ double psl[%d];  // fixed points [point][lane]", 64 * (n_fixed > 0 ? n_fixed : 1));
   } else {
+    if (pair_state_lds) g.f("  const int qs = lane >> 2;  // quad(-side) slot of this lane inside the wavefront");
     g.f("  __shared__ double xql[%d];  // third chain-history point [block][lane] (registers are full)", 64 * nf);
     if (lds_state) {
       int n_fixed = 0;
@@ -1434,7 +1455,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     for (int p = 0; p < NP; ++p) {
       if (!used[p]) continue;
       const bool fixed = ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
-      if ((ev.lds_constants || lds_state) && fixed && getenv("OKX_PAIR_FIXED_REGS") == nullptr)
+      if ((ev.lds_constants || lds_state) && fixed && !fixed_in_regs)
         g.f("    double& p%d = psl[%d + lane]; p%d = ld3(gp + %s + cc, c);", p, 64 * slot++, p, ev.point3(p).c_str());
       else
         g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());

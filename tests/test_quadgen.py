@@ -75,7 +75,30 @@ def test_axle_is_generated_in_pair_mode(golden):
     assert "double A10_10_0" not in src
     assert "okx_quad_eval" not in src and "okx_quad_expand" not in src  # parity / expand kernels: interpreter serves those
     assert "okx_quad_tangent_u(" in src and "sm_det" in src          # tangents are generated (regularised halves)
-    assert "psl[" in src and "a.predictor[" not in src               # fixed points in LDS; no chain-head model in pair mode
+    assert "xsl[" in src and "a.predictor[" not in src               # chain state in LDS; no chain-head model in pair mode
+
+
+def test_pair_mode_constants_live_in_registers_unless_lds_homes_are_asked_for(golden, monkeypatch):
+    """Chain constants and fixed points: registers by default (quad_build falls back to LDS homes when that variant
+    spills), LDS with the experiment switch."""
+    _, program = golden("c3_axle_grid")
+    pinned = program.with_line_mode("pinned")
+    src = _source(pinned)
+    assert "psl[" not in src and " = hsl[" not in src and "const double hcL = gq[" in src
+    monkeypatch.setenv("OKX_PAIR_LDS_HOMES", "1")
+    src = _source(pinned)
+    assert "psl[" in src and " = hsl[" in src and "#define hcL hsl[" in src
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid", "c3_axle_grid"])
+def test_solve_kernels_of_the_baseline_programs_do_not_spill(golden, name):
+    """Private segment size of okx_quad_solve_u/_g from the code object's metadata (in-tree cache after build())."""
+    _, program = golden(name)
+    lib = _lib.load()
+    host = _abi.HostProgram(program.with_line_mode("pinned"))
+    scratch = C.c_int32(-7)
+    assert lib.okx_debug_kernel_scratch(host.byref(), C.byref(scratch)) == 0, _lib.last_error()
+    assert scratch.value == 0
 
 
 def test_precompile_fills_the_cache_without_a_device(golden, tmp_path, monkeypatch):
