@@ -189,6 +189,26 @@ def test_axle_runs_in_pair_mode_one_quad_per_half(golden, name):
         assert float((res.positions + 7.0).abs().min()) > 0.0  # no slot left unwritten
 
 
+def test_pair_mode_fallback_variant_with_lds_homes_gives_the_same_answers(golden, tmp_path, monkeypatch):
+    """quad_build keeps the chain constants and fixed points in registers and falls back to LDS homes for a half
+    program that would spill; the fallback variant (forced here) must solve the axle identically, chains included."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden("c3_axle_grid")
+    pinned = program.with_line_mode("pinned")
+    t = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
+    ref = DeviceProgram(pinned, "cuda:0").solve(t, kernel="quad", predictor=False)
+    monkeypatch.setenv("OKX_PAIR_LDS_HOMES", "1")
+    monkeypatch.setenv("OKX_KERNEL_CACHE", str(tmp_path))
+    dp = DeviceProgram(pinned, "cuda:0")
+    assert dp.kernel == "quad", dp.kernel_note
+    for cl in (1, 16):
+        res = dp.solve(t, kernel="quad", predictor=False, chain_len=cl)
+        torch.cuda.synchronize()
+        assert np.all((res.info()["flags"] & 7) == 1)
+        assert float((res.positions - ref.positions).abs().max()) <= 1e-9
+
+
 def test_quad_rows_on_the_contact_patch(golden):
     """A target on the contact-patch centre: its chain blocks T = R Nw Wa Na come from the generator."""
     from oracle.oracle import Oracle
