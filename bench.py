@@ -533,13 +533,17 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
     for k in range(warmup):
         step(k, None, None)
     drain()
+    n_pairs = steps if per_launch_events else 1
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
+    # torch creates the HIP event at its first record(), and the process's first timing event initialises the runtime's
+    # timestamp machinery (~45 us, measured): both happen here, with the warm-up, not inside the K timed steps
+    for ev in starts + ends:
+        ev.record()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
-    n_pairs = steps if per_launch_events else 1
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
     t0 = time.perf_counter()
     if not per_launch_events:
         starts[0].record()
