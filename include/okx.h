@@ -148,7 +148,9 @@ typedef struct okx_solve_opts {
                              else 1 or 2 by size), 1 generic interpreter, one problem per
                              wavefront, 2 generic lane-group packed (several small problems per
                              wavefront; falls back to 1 when a problem needs more than 32
-                             lanes), 3 quad kernel (OKX_ERR_INVALID when the program has none) */
+                             lanes), 3 quad kernel (OKX_ERR_INVALID when the program has none),
+                             4 lane kernel (one lane per problem, 64 per wavefront; auto picks it for
+                             batches of at least okx_program_lane_threshold() problems)          */
   int32_t confirm_full_pass; /* quad kernel only.  0 (default): a step predicted to land within
                              step_tol of the solution (damping contraction lambda / min pivot and
                              the observed quadratic contraction, both with a 100x margin) is
@@ -502,9 +504,22 @@ const char* okx_program_kernel_note(const okx_program* prog);
  * needs, or a negative okx_status (OKX_ERR_LIMIT: no quad kernel for this program). */
 int64_t okx_quad_source(const okx_program_desc* desc, char* buf, int64_t buflen);
 
-/* Generate + compile a program's quad kernel into the on-disk cache (no device needed), so
- * that a later okx_program_create only loads it. */
+/* Generate + compile a program's quad kernel (and its lane kernel, when it has one) into the on-disk
+ * cache (no device needed), so that a later okx_program_create only loads them. */
 int32_t okx_precompile(const okx_program_desc* desc);
+
+/*
+ * The second generated kernel family: ONE LANE PER PROBLEM, 64 problems per wavefront, no cross-lane
+ * operand at all (the quad kernel moves every dot product, J^T J column and pivot through DPP and idles
+ * one lane in four).  About a quarter of the quad kernel's instructions per problem, but one wavefront
+ * holds 64 problems: it pays from the batch size at which the chip is full, one wavefront per SIMD
+ * (okx_program_lane_threshold(), 65536 problems on an MI355X).  Programs with at most 6 free points
+ * (n <= 18) whose quad kernel is loaded have one; okx_program_lane_note() says why another has not.
+ * Same algorithm, same evaluation points, same first-step tables; okx_solve_opts.kernel = 4 forces it.
+ */
+const char* okx_program_lane_note(const okx_program* prog);
+int64_t okx_program_lane_threshold(const okx_program* prog);   /* -1: no lane kernel */
+int64_t okx_lane_source(const okx_program_desc* desc, char* buf, int64_t buflen);
 
 #ifdef __cplusplus
 }

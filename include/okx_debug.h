@@ -30,6 +30,11 @@ int32_t okx_debug_quad_eval(okx_program* prog, int64_t n_problems, const double*
                             double lambda, double* d_r, double* d_ata, double* d_atr, double* d_dx,
                             void* stream);
 
+/* The same quantities as the LANE kernel's straight-line code computes them (okx.h: lane kernel). */
+int32_t okx_debug_lane_eval(okx_program* prog, int64_t n_problems, const double* d_x, const double* d_targets,
+                            double lambda, double* d_r, double* d_ata, double* d_atr, double* d_dx,
+                            void* stream);
+
 /* Record the LM passes of ONE problem of this program's subsequent quad-kernel solves into
  * d_trace [256][8] = (mode, trial cost, accepted cost, lambda, step, gain ratio, accepted, done);
  * a null pointer switches it off.  Per program (no process-global state). */

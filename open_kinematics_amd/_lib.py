@@ -40,12 +40,16 @@ EXPORTS = (
     "okx_expand_positions_batch",
     "okx_program_fit_predictor",
     "okx_program_has_predictor",
+    "okx_program_lane_note",
+    "okx_program_lane_threshold",
+    "okx_lane_source",
 )
 
 # include/okx_debug.h: test hooks and profiling aids, not part of the drop-in boundary
 DEBUG_EXPORTS = (
     "okx_debug_normal_equations",
     "okx_debug_quad_eval",
+    "okx_debug_lane_eval",
     "okx_debug_quad_trace",
     "okx_debug_phase_profile",
     "okx_debug_plan_stats",
@@ -131,6 +135,14 @@ def load() -> C.CDLL:
     lib.okx_program_has_predictor.restype = i32
     lib.okx_debug_quad_eval.argtypes = [vp, i64, vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.okx_debug_quad_eval.restype = i32
+    lib.okx_debug_lane_eval.argtypes = [vp, i64, vp, vp, C.c_double, vp, vp, vp, vp, vp]
+    lib.okx_debug_lane_eval.restype = i32
+    lib.okx_program_lane_note.argtypes = [vp]
+    lib.okx_program_lane_note.restype = C.c_char_p
+    lib.okx_program_lane_threshold.argtypes = [vp]
+    lib.okx_program_lane_threshold.restype = i64
+    lib.okx_lane_source.argtypes = [C.POINTER(ProgramDesc), C.c_char_p, i64]
+    lib.okx_lane_source.restype = i64
     if lib.okx_abi_version() != ABI_VERSION:
         raise RuntimeError("libokx.so ABI version mismatch")
     _lib = lib

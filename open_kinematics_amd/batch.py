@@ -82,6 +82,16 @@ class DeviceProgram:
         """Why the quad kernel is not in use (empty when it is)."""
         return self.lib.okx_program_kernel_note(self._handle).decode()
 
+    @property
+    def lane_threshold(self) -> int:
+        """Batch size from which auto selection uses the lane kernel (one lane per problem); -1: the program has none."""
+        return int(self.lib.okx_program_lane_threshold(self._handle))
+
+    @property
+    def lane_note(self) -> str:
+        """Why the program has no lane kernel (empty when it has one)."""
+        return self.lib.okx_program_lane_note(self._handle).decode()
+
     def close(self) -> None:
         if getattr(self, "_handle", None):
             self.lib.okx_program_destroy(self._handle)
@@ -154,7 +164,7 @@ class DeviceProgram:
         if ftol is not None:
             opts.ftol = float(ftol)
         if kernel is not None:
-            opts.kernel = {"auto": 0, "single": 1, "packed": 2, "quad": 3}.get(kernel, kernel)
+            opts.kernel = {"auto": 0, "single": 1, "packed": 2, "quad": 3, "lane": 4}.get(kernel, kernel)
         if residual_tolerance is not None:
             opts.residual_tolerance = float(residual_tolerance)
         if confirm_full_pass is not None:
@@ -281,11 +291,12 @@ class DeviceProgram:
     def tangent_info(tinfo: torch.Tensor) -> np.ndarray:
         return tinfo.cpu().numpy().view(TANGENT_INFO_DTYPE).reshape(-1)
 
-    def quad_eval(self, x, targets, lam: float = 0.0):
+    def quad_eval(self, x, targets, lam: float = 0.0, lane: bool = False):
         """
-        Test hook for the runtime-specialised kernel: residuals ``[B, m]``, ``J^T J [B, n, n]``
+        Test hook for the runtime-specialised kernels: residuals ``[B, m]``, ``J^T J [B, n, n]``
         (symmetrised from the lane-owned lower rows), ``J^T r [B, n]`` and the damped step
         ``dx = -(J^T J + lam I)^-1 J^T r`` from its in-register LDL^T, at free vectors ``x [B, n]``.
+        ``lane=True``: the same from the lane kernel's code (one lane per problem).
         """
         p = self.program
         x = _as_f64(x, self.device).reshape(-1, p.n_vars)
@@ -300,7 +311,7 @@ class DeviceProgram:
         dx = torch.empty((b, n), dtype=torch.float64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with torch.cuda.device(self.device):
-            rc = self.lib.okx_debug_quad_eval(
+            rc = (self.lib.okx_debug_lane_eval if lane else self.lib.okx_debug_quad_eval)(
                 self._handle, b, _ptr(x), _ptr(targets), float(lam), _ptr(r), _ptr(ata), _ptr(atr), _ptr(dx),
                 C.c_void_p(stream),
             )

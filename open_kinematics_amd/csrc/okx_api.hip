@@ -57,6 +57,13 @@ struct okx_program {
   long long head_geom_cap;  // geometries it holds
   double* quad_trace;            // diagnostic hook, see okx_debug_quad_trace (null: off)
   long long quad_trace_problem;
+  // lane kernel (okx_lanegen.cpp): one lane per problem, for batches of at least lane_min_problems; null when the
+  // program does not fit one lane's registers (or the quad kernel, whose first-step tables it shares, is absent)
+  hipModule_t lane_mod;
+  hipFunction_t lane_fn_u, lane_fn_g, lane_fn_eval;  // independent solves (chain_len 1), parity kernel
+  hipFunction_t lane_chain_u, lane_chain_g;          // chains
+  long long lane_min_problems;
+  char lane_note[256];
 };
 
 namespace {
@@ -252,6 +259,65 @@ void attach_quad_kernel(okx_program* p) {
   p->quad_waves_per_cu = 4 * per_simd;
 }
 
+// The lane kernel of a program that has a quad kernel (same policy: failure only means the quad kernel serves every
+// batch size; okx_program_lane_note() says why).
+void attach_lane_kernel(okx_program* p) {
+  p->lane_mod = nullptr;
+  p->lane_fn_u = p->lane_fn_g = p->lane_fn_eval = nullptr;
+  p->lane_chain_u = p->lane_chain_g = nullptr;
+  p->lane_note[0] = 0;
+  // one wavefront of 64 problems per SIMD fills the chip; below that the quad kernel (16 problems per wavefront) does
+  p->lane_min_problems = (long long)p->n_cu * 4 * 64;
+  if (const char* env = getenv("OKX_LANE_MIN")) p->lane_min_problems = atoll(env);
+  if (!p->quad_fn_u || p->quad_ppw != 16) {
+    std::snprintf(p->lane_note, sizeof(p->lane_note), "no single-mode quad kernel to share first-step tables with");
+    return;
+  }
+  if (const char* env = getenv("OKX_LANE")) {
+    if (env[0] == '0') {
+      std::snprintf(p->lane_note, sizeof(p->lane_note), "disabled by OKX_LANE=0");
+      return;
+    }
+  }
+  std::string src, why, code, err;
+  if (!okx::lane_generate(p->host, &src, &why)) {
+    std::snprintf(p->lane_note, sizeof(p->lane_note), "not generated: %.200s", why.c_str());
+    return;
+  }
+  if (!okx::quad_compile(src, &code, &err)) {
+    std::snprintf(p->lane_note, sizeof(p->lane_note), "compile failed: %.200s", err.c_str());
+    return;
+  }
+  if (okx::quad_code_scratch_bytes(code, "okx_lane_solve") > 0 && !getenv("OKX_LANE_ALLOW_SCRATCH")) {
+    std::snprintf(p->lane_note, sizeof(p->lane_note), "the lane kernel of this program spills to scratch: not used");
+    return;
+  }
+  hipModule_t mod = nullptr;
+  hipError_t e = hipModuleLoadData(&mod, code.data());
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (okx::quad_compile(src, &code, &err, true)) e = hipModuleLoadData(&mod, code.data());
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    std::snprintf(p->lane_note, sizeof(p->lane_note), "hipModuleLoadData: %s", hipGetErrorString(e));
+    return;
+  }
+  if (hipModuleGetFunction(&p->lane_fn_u, mod, "okx_lane_solve_u") != hipSuccess ||
+      hipModuleGetFunction(&p->lane_fn_g, mod, "okx_lane_solve_g") != hipSuccess ||
+      hipModuleGetFunction(&p->lane_chain_u, mod, "okx_lane_chain_u") != hipSuccess ||
+      hipModuleGetFunction(&p->lane_chain_g, mod, "okx_lane_chain_g") != hipSuccess ||
+      hipModuleGetFunction(&p->lane_fn_eval, mod, "okx_lane_eval") != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipModuleUnload(mod);
+    p->lane_fn_u = p->lane_fn_g = p->lane_fn_eval = nullptr;
+    p->lane_chain_u = p->lane_chain_g = nullptr;
+    std::snprintf(p->lane_note, sizeof(p->lane_note), "kernel symbols missing in the code object");
+    return;
+  }
+  p->lane_mod = mod;
+}
+
 int grid_for(const okx_program* p, long long units) {
   long long cap = (long long)p->n_cu * p->blocks_per_cu;
   if (cap < 1) cap = 1;
@@ -350,6 +416,7 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   p->blocks_per_cu = resident_blocks_per_cu(p->solve_fn, p->solve_lds_bytes);
   p->packed_blocks_per_cu = p->packed_fn ? resident_blocks_per_cu(p->packed_fn, p->packed_lds_bytes) : 0;
   attach_quad_kernel(p);
+  attach_lane_kernel(p);
   *out = p;
   return OKX_OK;
 }
@@ -357,6 +424,7 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
 void okx_program_destroy(okx_program* p) {
   if (!p) return;
   if (p->quad_mod) (void)hipModuleUnload(p->quad_mod);
+  if (p->lane_mod) (void)hipModuleUnload(p->lane_mod);
   if (p->predictor_dev) (void)hipFree(p->predictor_dev);
   if (p->head_dev) (void)hipFree(p->head_dev);
   if (p->head_geom_dev) (void)hipFree(p->head_geom_dev);
@@ -370,6 +438,28 @@ const char* okx_program_kernel(const okx_program* p) {
 }
 
 const char* okx_program_kernel_note(const okx_program* p) { return p ? p->quad_note : ""; }
+
+/* Why the program has no lane kernel (empty string: it has one), and the batch size from which auto selection uses it. */
+const char* okx_program_lane_note(const okx_program* p) { return p ? p->lane_note : ""; }
+int64_t okx_program_lane_threshold(const okx_program* p) { return p && p->lane_fn_u ? p->lane_min_problems : -1; }
+
+/* Generated source of the lane kernel for a program (no device needed); same contract as okx_quad_source. */
+int64_t okx_lane_source(const okx_program_desc* desc, char* buf, int64_t buflen) {
+  okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
+  if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
+  int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
+  std::string src, why;
+  if (rc == OKX_OK && !okx::lane_generate(*tmp, &src, &why))
+    rc = fail(OKX_ERR_LIMIT, "no lane kernel for this program: %s", why.c_str());
+  delete tmp;
+  if (rc != OKX_OK) return rc;
+  if (buf && buflen > 0) {
+    const size_t ncopy = src.size() < (size_t)buflen - 1 ? src.size() : (size_t)buflen - 1;
+    std::memcpy(buf, src.data(), ncopy);
+    buf[ncopy] = 0;
+  }
+  return (int64_t)src.size() + 1;
+}
 
 /* Generated source of the quad kernel for a program (no device needed).  Returns the number of
    bytes the full text needs (including the terminator) or a negative okx_status. */
@@ -399,6 +489,12 @@ int32_t okx_precompile(const okx_program_desc* desc) {
   std::string src, why, code;
   if (rc == OKX_OK && !okx::quad_build(*tmp, quad_waves_per_simd(), &src, &code, &why))
     rc = fail(why.compare(0, 14, "compile failed") == 0 ? OKX_ERR_DEVICE : OKX_ERR_LIMIT, "no quad kernel for this program: %s", why.c_str());
+  if (rc == OKX_OK && tmp->n_free <= okx::kQuadMaxFree) {
+    // the lane kernel of the same program (programs it does not fit simply have none)
+    std::string lsrc, lwhy, lcode, lerr;
+    if (okx::lane_generate(*tmp, &lsrc, &lwhy) && !okx::quad_compile(lsrc, &lcode, &lerr))
+      rc = fail(OKX_ERR_DEVICE, "lane kernel: compile failed: %s", lerr.c_str());
+  }
   delete tmp;
   return rc;
 }
@@ -456,10 +552,16 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   // for n <= 15 and batches of at least 8 problems per resident slot.
   const long long single_slots = (long long)p->n_cu * p->blocks_per_cu;
   const long long packed_slots = (long long)p->n_cu * p->packed_blocks_per_cu * p->groups;
-  bool use_quad = p->quad_fn_u != nullptr && (opts->kernel == 0 || opts->kernel == 3);
+  bool use_quad = p->quad_fn_u != nullptr && (opts->kernel == 0 || opts->kernel == 3 || opts->kernel == 4);
   if (opts->kernel == 3 && !use_quad)
     return fail(OKX_ERR_INVALID, "quad kernel requested but not available: %s", p->quad_note);
   const long long quad_slots = (long long)p->n_cu * p->quad_waves_per_cu * p->quad_ppw;
+  // Lane kernel (one lane per problem, 64 per wavefront): auto selection from lane_min_problems on, when nothing the
+  // quad kernel alone offers is asked for (fitted model, trace); kernel == 4 forces it.
+  bool use_lane = p->lane_fn_u != nullptr && use_quad && opts->predictor == 0 && p->quad_trace == nullptr &&
+                  (opts->kernel == 4 || (opts->kernel == 0 && n_problems >= p->lane_min_problems));
+  if (opts->kernel == 4 && !use_lane)
+    return fail(OKX_ERR_INVALID, "lane kernel requested but not available: %s", p->lane_note[0] ? p->lane_note : "predictor / trace in use");
   bool use_packed = false;
   if (p->packed_fn && !use_quad) {
     if (opts->kernel == 2) use_packed = true;
@@ -471,12 +573,16 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     long long len = opts->chain_len;
     if (len == 0) len = opts->chain ? span : 1;
     if (len < 0) {  // auto: about one chain per resident problem slot, balanced inside a geometry
-      const long long slots = use_quad ? quad_slots : (use_packed ? packed_slots : single_slots);
+      const long long lane_slots = (long long)p->n_cu * 4 * 64;
+      const long long slots = use_lane ? lane_slots : use_quad ? quad_slots : (use_packed ? packed_slots : single_slots);
       const long long ideal = (n_problems + slots - 1) / slots;
       if (ideal >= span) {
         len = span;
       } else {
-        const long long per_span = (span + ideal - 1) / ideal;
+        long long per_span = (span + ideal - 1) / ideal;
+        // lane kernel: a wave unit is 64 chains of ONE span, so the chains of a span come in multiples of 64
+        if (use_lane) per_span = (per_span + 63) / 64 * 64;
+        if (per_span > span) per_span = span;
         len = (span + per_span - 1) / per_span;
       }
     }
@@ -564,10 +670,19 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
         q.head = p->head_geom_dev;
       }
     }
+    void* kargs[] = {(void*)&q};
+    if (use_lane) {
+      const long long chains_per_span = (span_ + a.chain_len - 1) / a.chain_len;
+      const long long lane_units = (n_problems / span_) * ((chains_per_span + 63) / 64);
+      const long long lane_cap = (long long)p->n_cu * 4;  // one wavefront per SIMD (512 registers, ~37 KB LDS)
+      const int lane_grid = (int)(lane_units < lane_cap ? (lane_units < 1 ? 1 : lane_units) : lane_cap);
+      hipFunction_t fn = a.chain_len == 1 ? (d_geom_pos ? p->lane_fn_g : p->lane_fn_u) : (d_geom_pos ? p->lane_chain_g : p->lane_chain_u);
+      HIP_TRY(hipModuleLaunchKernel(fn, lane_grid, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
+      return OKX_OK;
+    }
     const long long wave_units = (units + p->quad_ppw - 1) / p->quad_ppw;
     const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
     const int grid = (int)(wave_units < cap ? (wave_units < 1 ? 1 : wave_units) : cap);
-    void* kargs[] = {(void*)&q};
     HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->quad_fn_g : p->quad_fn_u, grid, 1, 1, okx::kWave, 1, 1, 0,
                                   (hipStream_t)stream, kargs, nullptr));
     return OKX_OK;
@@ -1057,6 +1172,33 @@ int32_t okx_debug_quad_eval(okx_program* p, int64_t n_problems, const double* d_
   const long long waves = (n_problems + 15) / 16;
   void* kargs[] = {(void*)&q};
   HIP_TRY(hipModuleLaunchKernel(p->quad_fn_eval, (int)(waves < 4096 ? waves : 4096), 1, 1, okx::kWave, 1, 1, 0,
+                                (hipStream_t)stream, kargs, nullptr));
+  return OKX_OK;
+}
+
+/* Test hook: okx_debug_quad_eval's quantities as the LANE kernel's straight-line code computes them. */
+int32_t okx_debug_lane_eval(okx_program* p, int64_t n_problems, const double* d_x, const double* d_targets,
+                            double lambda, double* d_r, double* d_ata, double* d_atr, double* d_dx,
+                            void* stream) {
+  if (!p || !d_x || !d_r || !d_ata || !d_atr || !d_dx) return fail(OKX_ERR_INVALID, "null pointer");
+  if (!p->lane_fn_eval) return fail(OKX_ERR_INVALID, "no lane kernel: %s", p->lane_note);
+  if (n_problems <= 0) return OKX_OK;
+  okx::QuadEvalArgs q;
+  q.x = d_x;
+  q.targets = d_targets;
+  q.r = d_r;
+  q.ata = d_ata;
+  q.atr = d_atr;
+  q.dx = d_dx;
+  q.lambda = lambda;
+  q.n_problems = n_problems;
+  const char* base = reinterpret_cast<const char*>(p->dev);
+  q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
+  q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
+  q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
+  const long long waves = (n_problems + 63) / 64;
+  void* kargs[] = {(void*)&q};
+  HIP_TRY(hipModuleLaunchKernel(p->lane_fn_eval, (int)(waves < 1024 ? waves : 1024), 1, 1, okx::kWave, 1, 1, 0,
                                 (hipStream_t)stream, kargs, nullptr));
   return OKX_OK;
 }

@@ -1,0 +1,1478 @@
+// okx_lanegen.cpp — source generator of the "lane" solve kernel: ONE LANE OWNS ONE PROBLEM.
+//
+// Second member of the runtime-specialised kernel family (the first is the quad kernel of okx_quadgen.cpp).
+// Same objective, same residual / Jacobian definitions (reference core/constraints.py, core/jacobians.py,
+// core/solver.py:226-275, :502-581), same Levenberg-Marquardt policy and the same evaluation points as the quad
+// kernel; only the parallel decomposition differs:
+//
+//   * quad kernel: four lanes own one problem, lane c holds Cartesian component c.  Every dot product, cross
+//     product, J^T J column and pivot crosses lanes through DPP (two v_mov_b32_dpp per double), one lane in four
+//     idles, and the three working lanes repeat all scalar arithmetic.  16 problems per wavefront: the right
+//     shape when a batch only just fills the chip (16384 problems = one wavefront per SIMD).
+//   * lane kernel (this file): a problem lives entirely in the registers (and a little LDS) of ONE lane, 64
+//     problems per wavefront.  No cross-lane operand exists: the instruction stream of a pass is fp64 arithmetic
+//     on statically named registers, about a quarter of the quad kernel's instructions per problem.  The price
+//     is the register file: the lower triangle of J^T J alone is 135 doubles for the double wishbone, so the
+//     kernel runs one wavefront per SIMD with the cold part of the state (accepted point, step in hand, chain
+//     history) in LDS, [slot][lane] so that every access is conflict-free.  It is the right shape for batches of
+//     at least 64 problems per SIMD (grids, ensembles: BASELINE configs 4 and 5).
+//
+// Geometry data (fixed points, row parameters, the first-step table) is WAVE-UNIFORM here: a wavefront's 64
+// problems always belong to one geometry (work units never straddle a span), so those values are read once per
+// wave unit and live in scalar registers; fp64 VALU instructions take them as scalar operands.
+//
+// The first-step tables are the quad module's (okx_quad_head_u/_g); this generator uses the same block
+// elimination order, so the table layout is shared.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "okx_plan.hpp"
+#include "okx_quad.hpp"
+
+namespace okx {
+namespace {
+
+// Three scalar expressions (names of doubles); an empty string is a structural zero.  `sg` folds a sign into uses.
+struct S3 {
+  std::string c[3];
+  int sg = 1;
+};
+
+// d(derived point) / d(free block): s * I, or a full 3 x 3 block m[r][k] = d out_r / d free_k.
+struct LBlk {
+  bool scaled = true;
+  std::string s;
+  std::string m[3][3];
+};
+
+struct LBlkTerm {
+  LBlk b;
+  int sg;
+};
+
+class LGen {
+ public:
+  explicit LGen(const DevProgram& prog) : P(prog) {
+    blk_of_point.assign(P.n_points, -1);
+    dop_of_point.assign(P.n_points, -1);
+    perm = lane_elimination_order(P);
+    for (int F = 0; F < P.n_free; ++F) blk_of_point[fp(F)] = F;
+    for (int e = 0; e < P.n_derived; ++e) dop_of_point[P.dop_out[e]] = e;
+  }
+
+  // Same greedy minimum-degree order as the quad generator (okx_quadgen.cpp, Gen::elimination_order): the
+  // first-step table of okx_quad_head_* is laid out in that block order.
+  static std::vector<int> lane_elimination_order(const DevProgram& P) {
+    const int nf = P.n_free;
+    std::vector<std::set<int>> adj(nf);
+    for (int i = 0; i < P.m; ++i)
+      for (int a = 0; a < P.row_nblk[i]; ++a)
+        for (int b = 0; b < P.row_nblk[i]; ++b)
+          if (a != b) adj[P.row_blk[i][a]].insert(P.row_blk[i][b]);
+    std::vector<bool> gone(nf, false);
+    std::vector<int> perm;
+    for (int step = 0; step < nf; ++step) {
+      int best = -1;
+      for (int k = 0; k < nf; ++k)
+        if (!gone[k] && (best < 0 || adj[k].size() < adj[best].size())) best = k;
+      perm.push_back(best);
+      gone[best] = true;
+      for (int u : adj[best]) {
+        adj[u].erase(best);
+        for (int w : adj[best])
+          if (w != u) adj[u].insert(w);
+      }
+      adj[best].clear();
+    }
+    return perm;
+  }
+
+  const DevProgram& P;
+  std::vector<int> perm;
+  int fp(int F) const { return P.free_point[perm[F]]; }
+  std::string out, why;
+  std::vector<int> blk_of_point, dop_of_point;
+  int uid = 0;
+  std::map<int, std::map<int, LBlk>> dblk;  // active derived op -> free block -> chain block
+  bool nz[kMaxVars][kMaxVars] = {};         // scalar-level structure of the lower triangle (block-dense)
+  bool fill[kMaxVars][kMaxVars] = {};       // ... after symbolic factorisation
+
+  void f(const char* fmt, ...) {
+    char buf[2048];
+    va_list ap, again;
+    va_start(ap, fmt);
+    va_copy(again, ap);
+    const int need = std::vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (need >= (int)sizeof(buf)) {
+      std::string big((size_t)need + 1, '\0');
+      std::vsnprintf(&big[0], big.size(), fmt, again);
+      big.resize((size_t)need);
+      out += big;
+    } else if (need > 0) {
+      out += buf;
+    }
+    va_end(again);
+    out += '\n';
+  }
+  std::string tmp(const char* base) { return "_" + std::string(base) + std::to_string(uid++); }
+
+  // ---- scalar vector algebra on named doubles ----
+  static S3 pt(int p) {
+    S3 v;
+    for (int k = 0; k < 3; ++k) v.c[k] = "p" + std::to_string(p) + "_" + std::to_string(k);
+    return v;
+  }
+  static std::string sgn(const S3& a, int k) { return a.sg < 0 ? "(-" + a.c[k] + ")" : a.c[k]; }
+  static S3 neg(S3 a) {
+    a.sg = -a.sg;
+    return a;
+  }
+  // sum of products as one nested fma expression; skips structural zeros; "" when everything is zero
+  static std::string sum_expr(const std::vector<std::pair<std::string, std::string>>& prods, const std::string& init = "") {
+    std::string e = init;
+    for (auto it = prods.rbegin(); it != prods.rend(); ++it) {
+      if (it->first.empty() || it->second.empty()) continue;
+      if (e.empty()) e = it->first + " * " + it->second;
+      else e = "fma(" + it->first + ", " + it->second + ", " + e + ")";
+    }
+    return e;
+  }
+  std::string emit(const char* base, const std::string& expr) {
+    if (expr.empty()) return "";
+    std::string t = tmp(base);
+    f("    const double %s = %s;", t.c_str(), expr.c_str());
+    return t;
+  }
+  S3 sub(const S3& a, const S3& b) {
+    S3 r;
+    for (int k = 0; k < 3; ++k) {
+      if (a.c[k].empty() && b.c[k].empty()) continue;
+      if (b.c[k].empty()) r.c[k] = emit("v", sgn(a, k));
+      else if (a.c[k].empty()) r.c[k] = emit("v", "-" + sgn(b, k));
+      else r.c[k] = emit("v", sgn(a, k) + " - " + sgn(b, k));
+    }
+    return r;
+  }
+  std::string dot(const S3& a, const S3& b, const std::string& init = "") {
+    std::vector<std::pair<std::string, std::string>> pr;
+    const int sg = a.sg * b.sg;
+    for (int k = 0; k < 3; ++k)
+      if (!a.c[k].empty() && !b.c[k].empty()) pr.push_back({sg < 0 ? "(-" + a.c[k] + ")" : a.c[k], b.c[k]});
+    const std::string e = sum_expr(pr, init);
+    if (e.empty()) return "0.0";
+    return emit("d", e);
+  }
+  // (a x b)_k = a_{k+1} b_{k+2} - a_{k+2} b_{k+1}
+  S3 cross(const S3& a, const S3& b) {
+    S3 r;
+    r.sg = a.sg * b.sg;
+    for (int k = 0; k < 3; ++k) {
+      const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+      const bool t1 = !a.c[k1].empty() && !b.c[k2].empty(), t2 = !a.c[k2].empty() && !b.c[k1].empty();
+      if (t1 && t2) r.c[k] = emit("cx", "fma(" + a.c[k1] + ", " + b.c[k2] + ", -(" + a.c[k2] + " * " + b.c[k1] + "))");
+      else if (t1) r.c[k] = emit("cx", a.c[k1] + " * " + b.c[k2]);
+      else if (t2) r.c[k] = emit("cx", "-(" + a.c[k2] + " * " + b.c[k1] + ")");
+    }
+    return r;
+  }
+  S3 scale(const std::string& k, const S3& a) {
+    S3 r;
+    r.sg = a.sg;
+    for (int i = 0; i < 3; ++i)
+      if (!a.c[i].empty()) r.c[i] = emit("s", k + " * " + a.c[i]);
+    return r;
+  }
+  static S3 unit(int axis) {
+    S3 r;
+    r.c[axis] = "1.0";
+    return r;
+  }
+
+  // ---- chain constants: wave-uniform values (row parameters, derived-op parameters, fixed points) ----
+  // They live in a small LDS table `cl`, filled once per wave unit, and are READ WHERE THEY ARE USED (one ds_read_b64
+  // each, every lane the same address: a broadcast) through an index the optimiser cannot see through (`kz`, an opaque
+  // zero refreshed at the top of every pass).  As named values loaded ahead of the loops (the first version) they are
+  // ~50 loop invariants: the compiler runs out of scalar registers, parks them in vector registers and then spills.
+  // A constant's name is a macro: `#define hs3_0 cl[7 + kz]`.
+  std::string hoisted;   // fill code: cl[k] = source;
+  std::string defines;   // #define name cl[k + kz]
+  std::string undefs;
+  int n_consts = 0;
+  std::map<std::pair<int, int>, std::string> hoisted_names;
+  void add_const(const char* name, const char* source) {
+    char line[256];
+    std::snprintf(line, sizeof(line), "    cl[%d] = %s;\n", n_consts, source);
+    hoisted += line;
+    std::snprintf(line, sizeof(line), "#define %s cl[%d + kz]\n", name, n_consts);
+    defines += line;
+    std::snprintf(line, sizeof(line), "#undef %s\n", name);
+    undefs += line;
+    ++n_consts;
+  }
+  std::string dp(int e) {
+    auto key = std::make_pair(-1 - e, 0);
+    auto it = hoisted_names.find(key);
+    if (it != hoisted_names.end()) return it->second;
+    char name[48], line[200];
+    std::snprintf(name, sizeof(name), "hd%d", e);
+    std::snprintf(line, sizeof(line), "a.dop_param[%d]", e);
+    add_const(name, line);
+    hoisted_names[key] = name;
+    return name;
+  }
+  int pin_leader(int i) const {
+    if (i >= P.n_crows || P.row_type[i] != OKX_ROW_LINE_PIN) return i;
+    for (int j = 0; j < i; ++j) {
+      if (P.row_type[j] != OKX_ROW_LINE_PIN || P.row_pts[j][0] != P.row_pts[i][0]) continue;
+      bool same = true;
+      for (int k = 0; k < 6; ++k) same = same && P.row_param[j][k] == P.row_param[i][k];
+      if (same) return j;
+    }
+    return i;
+  }
+  std::string rp(int i, int k) {
+    i = pin_leader(i);
+    auto key = std::make_pair(i, k);
+    auto it = hoisted_names.find(key);
+    if (it != hoisted_names.end()) return it->second;
+    char name[48], line[200];
+    std::snprintf(name, sizeof(name), "hs%d_%d", i, k);
+    if (i < P.n_crows)
+      std::snprintf(line, sizeof(line), "gq[%d]", 8 * i + k);
+    else
+      std::snprintf(line, sizeof(line), "a.row_param[%d]", 8 * i + k);
+    add_const(name, line);
+    hoisted_names[key] = name;
+    return name;
+  }
+  S3 rpv(int i, int k0) {
+    S3 v;
+    for (int k = 0; k < 3; ++k) v.c[k] = rp(i, k0 + k);
+    return v;
+  }
+  int target_of_row(int i) const { return (int)P.row_param[i][3]; }
+  std::map<int, S3> pin_cross_;
+
+  // ---- derived points ----
+  std::map<int, LBlk> blocks_of_point(int p) {
+    std::map<int, LBlk> r;
+    if (blk_of_point[p] >= 0) {
+      LBlk b;
+      b.scaled = true;
+      b.s = "1.0";
+      r[blk_of_point[p]] = b;
+    } else if (dop_of_point[p] >= 0) {
+      auto it = dblk.find(dop_of_point[p]);
+      if (it != dblk.end()) r = it->second;
+    }
+    return r;
+  }
+  std::map<int, LBlk> combine(std::map<int, std::vector<LBlkTerm>>& acc) {
+    std::map<int, LBlk> res;
+    for (auto& kv : acc) {
+      std::string ssum;
+      std::vector<LBlkTerm*> gen;
+      for (auto& t : kv.second) {
+        if (t.b.scaled) {
+          if (!ssum.empty()) ssum += t.sg < 0 ? " - " : " + ";
+          else if (t.sg < 0) ssum += "-";
+          ssum += "(" + t.b.s + ")";
+        } else {
+          gen.push_back(&t);
+        }
+      }
+      LBlk b;
+      if (gen.empty()) {
+        b.scaled = true;
+        b.s = emit("ks", ssum);
+      } else {
+        b.scaled = false;
+        for (int r = 0; r < 3; ++r)
+          for (int k = 0; k < 3; ++k) {
+            std::string e;
+            for (auto* t : gen) {
+              if (t->b.m[r][k].empty()) continue;
+              if (!e.empty()) e += t->sg < 0 ? " - " : " + ";
+              else if (t->sg < 0) e += "-";
+              e += t->b.m[r][k];
+            }
+            if (!ssum.empty() && r == k) e += (e.empty() ? "(" : " + (") + ssum + ")";
+            b.m[r][k] = emit("B", e);
+          }
+      }
+      res[kv.first] = b;
+    }
+    return res;
+  }
+
+  bool derived_op(int e, bool with_blocks) {
+    const int type = P.dop_type[e];
+    const int* pts = P.dop_pts[e];
+    const S3 o = pt(P.dop_out[e]);
+    f("    // derived op %d (type %d) -> point %d", e, type, P.dop_out[e]);
+    if (type == OKX_DOP_MIDPOINT) {  // definitions.py:76-89
+      const S3 a = pt(pts[0]), b = pt(pts[1]);
+      for (int k = 0; k < 3; ++k) f("    %s = fma(%s - %s, 0.5, %s);", o.c[k].c_str(), b.c[k].c_str(), a.c[k].c_str(), a.c[k].c_str());
+      if (with_blocks) {
+        std::map<int, std::vector<LBlkTerm>> acc;
+        for (int s = 0; s < 2; ++s)
+          for (auto& kv : blocks_of_point(pts[s])) {
+            LBlk b2 = kv.second;
+            if (b2.scaled) {
+              b2.s = "0.5 * (" + b2.s + ")";
+            } else {
+              for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < 3; ++k)
+                  if (!b2.m[r][k].empty()) b2.m[r][k] = emit("B", "0.5 * " + b2.m[r][k]);
+            }
+            acc[kv.first].push_back({b2, 1});
+          }
+        dblk[e] = combine(acc);
+      }
+      return true;
+    }
+    if (type == OKX_DOP_ALONG) {  // definitions.py:24-33, :92-155: out = base + normalize(a - b) * c
+      const S3 v = sub(pt(pts[1]), pt(pts[2]));
+      const std::string s2 = dot(v, v);
+      const std::string nrm = tmp("nr"), inrm = tmp("in");
+      f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", nrm.c_str(), inrm.c_str(), s2.c_str(), nrm.c_str(), inrm.c_str());
+      const S3 u = scale(inrm, v);
+      const S3 base = pt(pts[0]);
+      for (int k = 0; k < 3; ++k) f("    %s = fma(%s, %s, %s);", o.c[k].c_str(), u.c[k].c_str(), dp(e).c_str(), base.c[k].c_str());
+      if (with_blocks) {
+        std::map<int, std::vector<LBlkTerm>> acc;
+        for (auto& kv : blocks_of_point(pts[0])) acc[kv.first].push_back({kv.second, 1});
+        const std::string k = emit("k", dp(e) + " * " + inrm);
+        for (int s = 1; s <= 2; ++s) {
+          const int sg = s == 1 ? 1 : -1;
+          for (auto& kv : blocks_of_point(pts[s])) {
+            LBlk nb;
+            nb.scaled = false;
+            const LBlk& b = kv.second;
+            if (b.scaled) {  // k s (I - u u^T): symmetric
+              const std::string ks = emit("ks", k + " * (" + b.s + ")");
+              for (int r = 0; r < 3; ++r)
+                for (int c = 0; c <= r; ++c) {
+                  const std::string uu = u.c[r] + " * " + u.c[c];
+                  nb.m[r][c] = emit("B", r == c ? ks + " * (1.0 - " + uu + ")" : "-(" + ks + " * (" + uu + "))");
+                  nb.m[c][r] = nb.m[r][c];
+                }
+            } else {  // k (B - u (u^T B))
+              for (int c = 0; c < 3; ++c) {
+                const std::string ub = emit("ub", sum_expr({{u.c[0], b.m[0][c]}, {u.c[1], b.m[1][c]}, {u.c[2], b.m[2][c]}}));
+                for (int r = 0; r < 3; ++r) {
+                  std::string e2;
+                  if (!b.m[r][c].empty() && !ub.empty()) e2 = k + " * fma(-" + u.c[r] + ", " + ub + ", " + b.m[r][c] + ")";
+                  else if (!b.m[r][c].empty()) e2 = k + " * " + b.m[r][c];
+                  else if (!ub.empty()) e2 = "-(" + k + " * " + u.c[r] + " * " + ub + ")";
+                  nb.m[r][c] = emit("B", e2);
+                }
+              }
+            }
+            acc[kv.first].push_back({nb, sg});
+          }
+        }
+        dblk[e] = combine(acc);
+      }
+      return true;
+    }
+    if (type == OKX_DOP_CONTACT_PATCH) {  // definitions.py:36-73, :158-180
+      const S3 v = sub(pt(pts[2]), pt(pts[1]));
+      const std::string vv = dot(v, v);
+      const std::string vn = tmp("vn"), ivn = tmp("iv");
+      f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", vn.c_str(), ivn.c_str(), vv.c_str(), vn.c_str(), ivn.c_str());
+      const S3 ax = scale(ivn, v);
+      const std::string az = ax.c[2];
+      S3 wd;  // -ga a - e_z with ga = -a_z
+      wd.c[0] = emit("wd", az + " * " + ax.c[0]);
+      wd.c[1] = emit("wd", az + " * " + ax.c[1]);
+      wd.c[2] = emit("wd", "fma(" + az + ", " + ax.c[2] + ", -1.0)");
+      const std::string ww = dot(wd, wd);
+      const std::string wn = tmp("wn"), iwn = tmp("iw");
+      f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", wn.c_str(), iwn.c_str(), ww.c_str(), wn.c_str(), iwn.c_str());
+      const S3 wc = pt(pts[0]);
+      const std::string rk = emit("rk", iwn + " * " + dp(e));
+      for (int k = 0; k < 3; ++k) f("    %s = fma(%s, %s, %s);", o.c[k].c_str(), wd.c[k].c_str(), rk.c_str(), wc.c[k].c_str());
+      if (with_blocks) {
+        // d out / d axo = T = R Nw Wa Na (axi: -T, wheel centre: I), Na = (I - a a^T)/|v|, Wa = a_z I + a e_z^T,
+        // Nw = (I - wu wu^T)/|wd|; applied column by column to the input's own block.
+        const S3 wu = scale(iwn, wd);
+        auto apply_t = [&](const std::string b[3], std::string t[3]) {
+          const std::string adb = emit("ad", sum_expr({{ax.c[0], b[0]}, {ax.c[1], b[1]}, {ax.c[2], b[2]}}));
+          std::string nn[3], w[3];
+          for (int r = 0; r < 3; ++r) {
+            std::string e2;
+            if (!b[r].empty() && !adb.empty()) e2 = ivn + " * fma(-" + ax.c[r] + ", " + adb + ", " + b[r] + ")";
+            else if (!b[r].empty()) e2 = ivn + " * " + b[r];
+            else if (!adb.empty()) e2 = "-(" + ivn + " * " + ax.c[r] + " * " + adb + ")";
+            nn[r] = emit("n", e2);
+          }
+          for (int r = 0; r < 3; ++r) w[r] = emit("w", sum_expr({{az, nn[r]}, {ax.c[r], nn[2]}}));
+          const std::string wdw = emit("ww", sum_expr({{wu.c[0], w[0]}, {wu.c[1], w[1]}, {wu.c[2], w[2]}}));
+          for (int r = 0; r < 3; ++r) {
+            std::string e2;
+            if (!w[r].empty() && !wdw.empty()) e2 = rk + " * fma(-" + wu.c[r] + ", " + wdw + ", " + w[r] + ")";
+            else if (!w[r].empty()) e2 = rk + " * " + w[r];
+            else if (!wdw.empty()) e2 = "-(" + rk + " * " + wu.c[r] + " * " + wdw + ")";
+            t[r] = emit("B", e2);
+          }
+        };
+        std::map<int, std::vector<LBlkTerm>> acc;
+        for (auto& kv : blocks_of_point(pts[0])) acc[kv.first].push_back({kv.second, 1});
+        for (int sidx = 1; sidx <= 2; ++sidx) {
+          const int sg = sidx == 2 ? 1 : -1;
+          for (auto& kv : blocks_of_point(pts[sidx])) {
+            const LBlk& b = kv.second;
+            LBlk nb;
+            nb.scaled = false;
+            for (int c = 0; c < 3; ++c) {
+              std::string col[3], t[3];
+              for (int r = 0; r < 3; ++r) col[r] = b.scaled ? (r == c ? "(" + b.s + ")" : std::string()) : b.m[r][c];
+              apply_t(col, t);
+              for (int r = 0; r < 3; ++r) nb.m[r][c] = t[r];
+            }
+            acc[kv.first].push_back({nb, sg});
+          }
+        }
+        dblk[e] = combine(acc);
+      }
+      return true;
+    }
+    why = "unknown derived op";
+    return false;
+  }
+
+  // ---- rows ----
+  struct RowOut {
+    std::string r;
+    std::vector<std::pair<int, S3>> partial;  // point -> d r / d point
+    std::string absres;
+  };
+
+  void sqrt_rsqrt(const std::string& x, std::string* root, std::string* inv) {
+    *root = tmp("rt");
+    *inv = tmp("iv");
+    f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", root->c_str(), inv->c_str(), x.c_str(), root->c_str(), inv->c_str());
+  }
+
+  bool row(int i, RowOut* ro) {
+    const int type = P.row_type[i];
+    const int* pts = P.row_pts[i];
+    f("    // row %d (type %d)", i, type);
+    const std::string r = "r" + std::to_string(i);
+    ro->r = r;
+    ro->absres = "fabs(" + r + ")";
+    switch (type) {
+      case OKX_ROW_DISTANCE:
+      case OKX_ROW_SPHERICAL: {  // constraints.py:125-134,162-170; jacobians.py:35-51
+        const S3 d = sub(pt(pts[1]), pt(pts[0]));
+        const std::string s = dot(d, d, "EPS_SQ");
+        std::string root, inv;
+        sqrt_rsqrt(s, &root, &inv);
+        const S3 g = scale(inv, d);
+        if (type == OKX_ROW_DISTANCE)
+          f("    const double %s = (%s - EPS) - %s;", r.c_str(), root.c_str(), rp(i, 0).c_str());
+        else
+          f("    const double %s = %s - EPS;", r.c_str(), root.c_str());
+        ro->partial.push_back({pts[0], neg(g)});
+        ro->partial.push_back({pts[1], g});
+        return true;
+      }
+      case OKX_ROW_ANGLE:
+      case OKX_ROW_THREE_POINT_ANGLE: {  // constraints.py:223-243,287-308; jacobians.py:55-188
+        S3 v1, v2;
+        if (type == OKX_ROW_ANGLE) {
+          v1 = sub(pt(pts[1]), pt(pts[0]));
+          v2 = sub(pt(pts[3]), pt(pts[2]));
+        } else {
+          v1 = sub(pt(pts[0]), pt(pts[1]));
+          v2 = sub(pt(pts[2]), pt(pts[1]));
+        }
+        const S3 cv = cross(v1, v2);
+        const std::string t15 = dot(cv, cv, "EPS_SQ");
+        const std::string dt = dot(v1, v2);
+        std::string s, is;
+        sqrt_rsqrt(t15, &s, &is);
+        const std::string inv = emit("iv", "fast_rcp(fma(" + dt + ", " + dt + ", " + t15 + "))");
+        const std::string ka = emit("ka", dt + " * " + inv + " * " + is), kb = emit("kb", s + " * " + inv);
+        const S3 w1 = cross(v2, cv), w2 = cross(cv, v1);
+        S3 g1, g2;
+        for (int k = 0; k < 3; ++k) {
+          g1.c[k] = emit("g", "fma(" + ka + ", " + w1.c[k] + ", -(" + kb + " * " + v2.c[k] + "))");
+          g2.c[k] = emit("g", "fma(" + ka + ", " + w2.c[k] + ", -(" + kb + " * " + v1.c[k] + "))");
+        }
+        f("    const double %s = lean_atan2_pos(%s - EPS, %s) - %s;", r.c_str(), s.c_str(), dt.c_str(), rp(i, 0).c_str());
+        if (type == OKX_ROW_ANGLE) {
+          ro->partial.push_back({pts[0], neg(g1)});
+          ro->partial.push_back({pts[1], g1});
+          ro->partial.push_back({pts[2], neg(g2)});
+          ro->partial.push_back({pts[3], g2});
+        } else {
+          S3 gm;
+          for (int k = 0; k < 3; ++k) gm.c[k] = emit("g", "-" + g1.c[k] + " - " + g2.c[k]);
+          ro->partial.push_back({pts[0], g1});
+          ro->partial.push_back({pts[1], gm});
+          ro->partial.push_back({pts[2], g2});
+        }
+        return true;
+      }
+      case OKX_ROW_VECTORS_PARALLEL:
+      case OKX_ROW_VECTORS_PERPENDICULAR: {  // constraints.py:351-371,414-429; jacobians.py:192-318
+        const S3 v1 = sub(pt(pts[1]), pt(pts[0])), v2 = sub(pt(pts[3]), pt(pts[2]));
+        const std::string n1 = dot(v1, v1, "EPS_SQ"), n2 = dot(v2, v2, "EPS_SQ");
+        const std::string s1 = emit("s", "sqrt(" + n1 + ")"), s2 = emit("s", "sqrt(" + n2 + ")");
+        S3 g1, g2;
+        if (type == OKX_ROW_VECTORS_PARALLEL) {
+          const S3 cv = cross(v1, v2);
+          const std::string c2 = dot(cv, cv, "EPS_SQ");
+          const std::string sc = emit("s", "sqrt(" + c2 + ")");
+          const S3 w1 = cross(v2, cv), w2 = cross(cv, v1);
+          const std::string k26 = emit("k", "1.0 / (" + s1 + " * " + s2 + " * " + sc + ")");
+          const std::string k19 = emit("k", sc + " / (" + s2 + " * " + s1 + " * " + s1 + " * " + s1 + ")");
+          const std::string k31 = emit("k", sc + " / (" + s1 + " * " + s2 + " * " + s2 + " * " + s2 + ")");
+          for (int k = 0; k < 3; ++k) {
+            g1.c[k] = emit("g", k26 + " * " + w1.c[k] + " - " + k19 + " * " + v1.c[k]);
+            g2.c[k] = emit("g", k26 + " * " + w2.c[k] + " - " + k31 + " * " + v2.c[k]);
+          }
+          f("    const double %s = (%s - EPS) / ((%s - EPS) * (%s - EPS));", r.c_str(), sc.c_str(), s1.c_str(), s2.c_str());
+        } else {
+          const std::string dt = dot(v1, v2);
+          const std::string k16 = emit("k", "1.0 / (" + s1 + " * " + s2 + ")");
+          const std::string k18 = emit("k", dt + " / (" + s2 + " * " + s1 + " * " + s1 + " * " + s1 + ")");
+          const std::string k19 = emit("k", dt + " / (" + s1 + " * " + s2 + " * " + s2 + " * " + s2 + ")");
+          for (int k = 0; k < 3; ++k) {
+            g1.c[k] = emit("g", k16 + " * " + v2.c[k] + " - " + k18 + " * " + v1.c[k]);
+            g2.c[k] = emit("g", k16 + " * " + v1.c[k] + " - " + k19 + " * " + v2.c[k]);
+          }
+          f("    const double %s = %s / ((%s - EPS) * (%s - EPS));", r.c_str(), dt.c_str(), s1.c_str(), s2.c_str());
+        }
+        ro->partial.push_back({pts[0], neg(g1)});
+        ro->partial.push_back({pts[1], g1});
+        ro->partial.push_back({pts[2], neg(g2)});
+        ro->partial.push_back({pts[3], g2});
+        return true;
+      }
+      case OKX_ROW_EQUAL_DISTANCE: {  // constraints.py:466-477; jacobians.py:322-367
+        const S3 d1 = sub(pt(pts[1]), pt(pts[0])), d2 = sub(pt(pts[3]), pt(pts[2]));
+        const std::string s1 = dot(d1, d1, "EPS_SQ"), s2 = dot(d2, d2, "EPS_SQ");
+        std::string r1, i1, r2, i2;
+        sqrt_rsqrt(s1, &r1, &i1);
+        sqrt_rsqrt(s2, &r2, &i2);
+        const S3 g1 = scale(i1, d1), g2 = scale(i2, d2);
+        f("    const double %s = (%s - EPS) - (%s - EPS);", r.c_str(), r1.c_str(), r2.c_str());
+        ro->partial.push_back({pts[0], neg(g1)});
+        ro->partial.push_back({pts[1], g1});
+        ro->partial.push_back({pts[2], g2});
+        ro->partial.push_back({pts[3], neg(g2)});
+        return true;
+      }
+      case OKX_ROW_FIXED_AXIS: {  // constraints.py:508-516; solver.py:407-416
+        const int ax = (int)P.row_param[i][0];
+        f("    const double %s = %s - %s;", r.c_str(), pt(pts[0]).c[ax].c_str(), rp(i, 1).c_str());
+        ro->partial.push_back({pts[0], unit(ax)});
+        return true;
+      }
+      case OKX_ROW_POINT_ON_LINE:
+      case OKX_ROW_LINE_PIN: {  // constraints.py:560-576; jacobians.py:372-403; okx.h (pin)
+        const S3 lp = rpv(i, 0), ld = rpv(i, 3);
+        S3 cv;
+        const int leader = pin_leader(i);
+        if (type == OKX_ROW_LINE_PIN && pin_cross_.count(leader)) {
+          cv = pin_cross_[leader];
+        } else {
+          const S3 w = sub(pt(pts[0]), lp);
+          cv = cross(w, ld);
+          if (type == OKX_ROW_LINE_PIN) pin_cross_[leader] = cv;
+        }
+        if (type == OKX_ROW_POINT_ON_LINE) {
+          const std::string c2 = dot(cv, cv, "EPS_SQ");
+          std::string root, inv;
+          sqrt_rsqrt(c2, &root, &inv);
+          const S3 gx = cross(ld, cv);
+          const S3 g = scale(inv, gx);
+          f("    const double %s = %s - EPS;", r.c_str(), root.c_str());
+          ro->partial.push_back({pts[0], g});
+          return true;
+        }
+        const int comp = (int)P.row_param[i][6];
+        // r = e_comp . (w x ld) = w . (ld x e_comp)
+        const S3 g = cross(ld, unit(comp));
+        f("    const double %s = %s;", r.c_str(), cv.c[comp].c_str());
+        ro->partial.push_back({pts[0], g});
+        if (comp == 0) {
+          const std::string c2 = dot(cv, cv, "EPS_SQ");
+          ro->absres = "fabs(sqrt(" + c2 + ") - EPS)";
+        } else {
+          ro->absres.clear();
+        }
+        return true;
+      }
+      case OKX_ROW_POINT_ON_PLANE: {  // constraints.py:616-627; solver.py:429-437
+        const S3 pp = rpv(i, 0), nn = rpv(i, 3);
+        const S3 w = sub(pt(pts[0]), pp);
+        const std::string d = dot(w, nn);
+        f("    const double %s = %s;", r.c_str(), d.c_str());
+        ro->partial.push_back({pts[0], nn});
+        return true;
+      }
+      case OKX_ROW_MIDPOINT_ON_PLANE: {  // constraints.py:657-666; solver.py:439-448
+        const S3 pp = rpv(i, 0), nn = rpv(i, 3);
+        const S3 a = pt(pts[0]), b = pt(pts[1]);
+        S3 mid;
+        for (int k = 0; k < 3; ++k) mid.c[k] = emit("m", "fma(" + b.c[k] + " - " + a.c[k] + ", 0.5, " + a.c[k] + ")");
+        const S3 w = sub(mid, pp);
+        const std::string d = dot(w, nn);
+        const S3 h = scale("0.5", nn);
+        f("    const double %s = %s;", r.c_str(), d.c_str());
+        ro->partial.push_back({pts[0], h});
+        ro->partial.push_back({pts[1], h});
+        return true;
+      }
+      case OKX_ROW_COPLANAR:
+      case OKX_ROW_SCALAR_TRIPLE: {  // constraints.py:698-709,731-733; jacobians.py:426-483
+        const S3 v1 = sub(pt(pts[1]), pt(pts[0])), v2 = sub(pt(pts[2]), pt(pts[0])), v3 = sub(pt(pts[3]), pt(pts[0]));
+        const S3 c23 = cross(v2, v3), c31 = cross(v3, v1), c12 = cross(v1, v2);
+        const std::string vol = dot(v1, c23);
+        S3 g1 = c23, g2 = c31, g3 = c12;
+        if (type == OKX_ROW_SCALAR_TRIPLE) {
+          const std::string isc = emit("is", "fast_rcp(" + rp(i, 1) + ")");
+          g1 = scale(isc, c23), g2 = scale(isc, c31), g3 = scale(isc, c12);
+          f("    const double %s = (%s - %s) * %s;", r.c_str(), vol.c_str(), rp(i, 0).c_str(), isc.c_str());
+        } else {
+          f("    const double %s = %s;", r.c_str(), vol.c_str());
+        }
+        S3 g0;
+        for (int k = 0; k < 3; ++k) g0.c[k] = emit("g", "-(" + g1.c[k] + " + " + g2.c[k] + " + " + g3.c[k] + ")");
+        ro->partial.push_back({pts[0], g0});
+        ro->partial.push_back({pts[1], g1});
+        ro->partial.push_back({pts[2], g2});
+        ro->partial.push_back({pts[3], g3});
+        return true;
+      }
+      case kRowTarget: {  // solver.py:264-270, :560-579
+        const S3 dir = rpv(i, 0);
+        const std::string d = dot(pt(pts[0]), dir);
+        f("    const double %s = %s - tv%d;", r.c_str(), d.c_str(), target_of_row(i));
+        ro->partial.push_back({pts[0], dir});
+        return true;
+      }
+      default:
+        why = "row type " + std::to_string(type) + " has no lane code path yet";
+        return false;
+    }
+  }
+
+  static std::string A(int i, int j) { return "A" + std::to_string(i) + "_" + std::to_string(j); }
+  static std::string L(int i, int j) { return "L" + std::to_string(i) + "_" + std::to_string(j); }
+  static std::string gn(int i) { return "gn" + std::to_string(i); }
+
+  bool emit_rows_residual_only() {
+    f("    double ss = 0.0, mres_new = 0.0;");
+    for (int i = 0; i < P.m; ++i) {
+      RowOut ro;
+      if (!row(i, &ro)) return false;
+      f("    ss = fma(%s, %s, ss);", ro.r.c_str(), ro.r.c_str());
+      if (!ro.absres.empty()) f("    mres_new = fmax(mres_new, %s);", ro.absres.c_str());
+    }
+    return true;
+  }
+
+  std::map<int, std::vector<std::pair<int, S3>>> target_j;  // target index -> (free block, d r / d block)
+  // J^T J is NOT accumulated where the rows are: the lower triangle (135 doubles for the double wishbone) plus the
+  // state would need ~540 registers.  Every row keeps its gradient (3 doubles for a distance row) and the products
+  // of entry (i, j) are recorded here; emit_factor assembles column j just before it eliminates it, so that what is
+  // live is the finished factor columns + the Schur complement in progress + the gradients still to be consumed.
+  // Only the diagonal is accumulated at the rows (the first damping of a solve is scaled by its largest entry).
+  bool pin_acc = true;  // opaque use of the touched accumulators after each row (keeps the contributions at the row)
+  struct Prod { std::string a, b; int sg; };
+  std::map<std::pair<int, int>, std::vector<Prod>> ata_terms;  // (i, j), i > j
+  bool early_ata = false;  // parity kernel: additionally accumulate the whole lower triangle as E{i}_{j} at the rows
+  std::set<std::string> early_declared;
+  static std::string E(int i, int j) { return "E" + std::to_string(i) + "_" + std::to_string(j); }
+
+  // Rows: r_i, cost, max |r|, gradient gn{i} = (J^T r)_i, diagonal A{i}_{i} of J^T J (elimination order).
+  bool emit_rows() {
+    const int n = 3 * P.n_free;
+    for (int i = 0; i < n; ++i) {
+      f("    double %s = 0.0, %s = 0.0;", gn(i).c_str(), A(i, i).c_str());
+      nz[i][i] = true;
+    }
+    f("    double ss = 0.0, mres_new = 0.0;");
+    for (int i = 0; i < P.m; ++i) {
+      RowOut ro;
+      if (!row(i, &ro)) return false;
+      f("    ss = fma(%s, %s, ss);", ro.r.c_str(), ro.r.c_str());
+      if (!ro.absres.empty()) f("    mres_new = fmax(mres_new, %s);", ro.absres.c_str());
+      // point partials -> free blocks (chain rule through derived points: point_partial @ block, solver.py:554-558)
+      std::map<int, std::vector<S3>> terms;
+      for (auto& pp : ro.partial) {
+        const int p = pp.first;
+        const S3& g = pp.second;
+        if (blk_of_point[p] >= 0) {
+          terms[blk_of_point[p]].push_back(g);
+        } else if (dop_of_point[p] >= 0) {
+          auto it = dblk.find(dop_of_point[p]);
+          if (it == dblk.end()) {
+            why = "row reads a derived point without chain blocks";
+            return false;
+          }
+          for (auto& kv : it->second) {
+            const LBlk& b = kv.second;
+            S3 t;
+            t.sg = g.sg;
+            for (int k = 0; k < 3; ++k) {
+              if (b.scaled) {
+                if (!g.c[k].empty()) t.c[k] = emit("j", "(" + b.s + ") * " + g.c[k]);
+              } else {
+                t.c[k] = emit("j", sum_expr({{g.c[0], b.m[0][k]}, {g.c[1], b.m[1][k]}, {g.c[2], b.m[2][k]}}));
+              }
+            }
+            terms[kv.first].push_back(t);
+          }
+        }
+      }
+      std::vector<std::pair<int, S3>> jv;
+      for (auto& kv : terms) {
+        if (kv.second.size() == 1) {
+          jv.push_back({kv.first, kv.second[0]});
+        } else {
+          S3 t;
+          for (int k = 0; k < 3; ++k) {
+            std::string e;
+            for (auto& s : kv.second) {
+              if (s.c[k].empty()) continue;
+              if (!e.empty()) e += s.sg < 0 ? " - " : " + ";
+              else if (s.sg < 0) e += "-";
+              e += s.c[k];
+            }
+            t.c[k] = emit("j", e);
+          }
+          jv.push_back({kv.first, t});
+        }
+      }
+      if (P.row_type[i] == kRowTarget) target_j[target_of_row(i)] = jv;
+      std::vector<std::string> touched;
+      for (auto& fv : jv)
+        for (int a = 0; a < 3; ++a) {
+          if (fv.second.c[a].empty()) continue;
+          const int ia = 3 * fv.first + a;
+          f("    %s = fma(%s, %s, %s);", gn(ia).c_str(), sgn(fv.second, a).c_str(), ro.r.c_str(), gn(ia).c_str());
+          f("    %s = fma(%s, %s, %s);", A(ia, ia).c_str(), fv.second.c[a].c_str(), fv.second.c[a].c_str(), A(ia, ia).c_str());
+          touched.push_back(gn(ia));
+          touched.push_back(A(ia, ia));
+        }
+      for (size_t ia = 0; ia < jv.size(); ++ia)
+        for (size_t ib = 0; ib <= ia; ++ib) {
+          const int F = jv[ia].first, G = jv[ib].first;
+          const S3& jF = jv[ia].second;
+          const S3& jG = jv[ib].second;
+          const int sg = jF.sg * jG.sg;
+          for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < (F == G ? a : 3); ++b) {
+              if (jF.c[a].empty() || jG.c[b].empty()) continue;
+              const int i2 = 3 * F + a, j2 = 3 * G + b;
+              nz[i2][j2] = true;
+              ata_terms[{i2, j2}].push_back({jF.c[a], jG.c[b], sg});
+              if (early_ata) {
+                const std::string en = E(i2, j2);
+                if (!early_declared.count(en)) {
+                  early_declared.insert(en);
+                  f("    double %s = %s%s * %s;", en.c_str(), sg < 0 ? "-" : "", jF.c[a].c_str(), jG.c[b].c_str());
+                } else {
+                  f("    %s = fma(%s%s, %s, %s);", en.c_str(), sg < 0 ? "-" : "", jF.c[a].c_str(), jG.c[b].c_str(), en.c_str());
+                }
+              }
+            }
+        }
+      if (pin_acc)
+        for (auto& an : touched) f("    asm volatile(\"\" : \"+v\"(%s));", an.c_str());
+    }
+    return true;
+  }
+
+  // Structure of the factor at scalar granularity (symbolic right-looking elimination).
+  void symbolic() {
+    const int n = 3 * P.n_free;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) fill[i][j] = j <= i && nz[i][j];
+    for (int j = 0; j < n; ++j) {
+      std::vector<int> rows;
+      for (int i = j + 1; i < n; ++i)
+        if (fill[i][j]) rows.push_back(i);
+      for (size_t a = 0; a < rows.size(); ++a)
+        for (size_t b = 0; b <= a; ++b) fill[rows[a]][rows[b]] = true;
+    }
+  }
+
+  // LDL^T of (J^T J + lambda I) with the forward substitution of ONE right-hand side fused in, LEFT-LOOKING, column by
+  // column.  Column j: scale row j (L_jk = C_jk / d_k, k < j), y_j = rhs_j - sum_k L_jk y_k, then every entry of the
+  // column at once: C_ij = (J^T J)_ij [assembled here from the rows' gradients] - sum_k C_ik L_jk.  Nothing of the
+  // trailing matrix exists before its column's turn: what is live is the window of unscaled entries C_ik with row > j
+  // >= column, the gradients still to be consumed, y and the pivots.  A finished ROW j is cold until the backward
+  // substitution reads it once (last row first): all but the last rows are parked in accumulation registers by hand
+  // (v_accvgpr_write / _read through "a"-class operands).  Left to the compiler the register allocator shuffles the
+  // whole factor through the AGPRs (measured: 912 moves for 1407 fp64 instructions in this block) and spills.
+  // Leaves L{i}_{j} (parked or resident), dinv{j}, y{i}, ok, pmin, pmax.
+  int col_fence = 3;     // scheduling barrier after every col_fence columns (keeps the late assembly late)
+  int resident_rows = 3; // the last rows of the factor stay in vector registers
+  std::set<std::pair<int, int>> parked;
+  void emit_factor(const std::vector<std::string>& rhs) {
+    const int n = 3 * P.n_free;
+    symbolic();
+    parked.clear();
+    f("    // ---- damped normal equations: LDL^T + forward substitution, left-looking ----");
+    f("    bool ok = true;");
+    f("    double pmin = 1e300, pmax = 0.0;");
+    for (int j = 0; j < n; ++j) {
+      f("    // column %d", j);
+      std::vector<int> cols;  // k < j with L_jk structurally non-zero
+      for (int k = 0; k < j; ++k)
+        if (fill[j][k]) cols.push_back(k);
+      for (int k : cols) f("    const double %s = C%d_%d * dinv%d;", L(j, k).c_str(), j, k, k);
+      {
+        std::vector<std::pair<std::string, std::string>> pr;
+        for (int k : cols) pr.push_back({"(-" + L(j, k) + ")", "y" + std::to_string(k)});
+        const std::string e = sum_expr(pr, rhs[j] == "0.0" ? "" : rhs[j]);
+        f("    const double y%d = %s;", j, e.empty() ? "0.0" : e.c_str());
+      }
+      for (int i = j; i < n; ++i) {
+        if (!fill[i][j]) continue;
+        // (J^T J)_ij from the gradients, then the earlier columns
+        std::vector<std::pair<std::string, std::string>> pr;
+        for (int k : cols)
+          if (fill[i][k]) pr.push_back({"(-C" + std::to_string(i) + "_" + std::to_string(k) + ")", L(j, k)});
+        std::string init;
+        if (i == j) {
+          init = A(j, j) + " + lambda";
+        } else {
+          auto it = ata_terms.find({i, j});
+          if (it != ata_terms.end()) {
+            std::vector<std::pair<std::string, std::string>> ap;
+            for (const Prod& t : it->second) ap.push_back({t.sg < 0 ? "(-" + t.a + ")" : t.a, t.b});
+            init = sum_expr(ap);
+          }
+        }
+        const std::string e = sum_expr(pr, init);
+        f("    const double C%d_%d = %s;", i, j, e.empty() ? "0.0" : e.c_str());
+      }
+      f("    ok = ok && C%d_%d > 0.0;", j, j);
+      f("    pmin = fmin(pmin, C%d_%d); pmax = fmax(pmax, C%d_%d);", j, j, j, j);
+      f("    const double dinv%d = pivot_rcp(C%d_%d);", j, j, j);
+      if (j < n - resident_rows)
+        for (int k : cols) {
+          f("    int %s_lo, %s_hi; park(%s, %s_lo, %s_hi);", L(j, k).c_str(), L(j, k).c_str(), L(j, k).c_str(), L(j, k).c_str(), L(j, k).c_str());
+          parked.insert({j, k});
+        }
+      if (col_fence > 0 && (j + 1) % col_fence == 0 && j + 1 < n) f("    __builtin_amdgcn_sched_barrier(0);");
+    }
+  }
+
+  // D z = y, L^T x = z, row-oriented: x_j is final once every later row has been scattered; row j of L is read once.
+  void emit_backward(const char* outn) {
+    const int n = 3 * P.n_free;
+    f("    // ---- D z = y, L^T x = z (row by row, last row first) ----");
+    for (int i = 0; i < n; ++i) f("    double %s%d = y%d * dinv%d;", outn, i, i, i);
+    for (int j = n - 1; j >= 0; --j) {
+      for (int k = 0; k < j; ++k) {
+        if (!fill[j][k]) continue;
+        if (parked.count({j, k}))
+          f("    %s%d = fma(-unpark(%s_lo, %s_hi), %s%d, %s%d);", outn, k, L(j, k).c_str(), L(j, k).c_str(), outn, j, outn, k);
+        else
+          f("    %s%d = fma(-%s, %s%d, %s%d);", outn, k, L(j, k).c_str(), outn, j, outn, k);
+      }
+    }
+  }
+};
+
+const char* kLanePreamble = R"SRC(
+// Generated by okx_lanegen.cpp for one constraint program — do not edit.
+typedef struct { double max_residual, cost, last_step; int iterations, nfev, flags, reserved; } okx_info;
+struct QArgs {
+  const double* targets; const double* geom_pos; const double* geom_row_param;
+  double* out_pos; okx_info* info;
+  long long n_problems, steps_per_geometry, chain_len;
+  int max_iter, confirm;
+  double step_tol, grad_tol, ftol, lambda0, residual_tolerance;
+  const double* design_pos; const double* row_param; const double* dop_param;
+  double* trace; long long trace_problem;
+  const double* predictor; long long predictor_mode; long long predictor_len;
+  const double* head;
+};
+#define EPS_SQ 1e-12
+#define EPS 1e-6
+#define DEV __device__ __forceinline__
+#define INFO_CONVERGED 1
+#define INFO_RESIDUAL_EXCEEDED 2
+#define INFO_FAILED 4
+#define INFO_ILL_CONDITIONED 8
+#define ILL_CONDITIONED_PIVOT_RATIO 1e-12
+// A wave-uniform double as a scalar-register value (every lane loaded the same address).
+DEV double uni(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+DEV double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(e, r, r);
+  e = fma(-x, r, 1.0);
+  return fma(e, r, r);
+}
+// v_rcp_f64 / v_rsq_f64 deliver 2^-24.3 (measured on MI355X, profiles/r02/README.md): one Newton step for a pivot.
+DEV double pivot_rcp(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+// sqrt(x) to the last bit or so and 1 / sqrt(x) to 4e-15: one Goldschmidt step, then the residual correction.
+DEV void fast_sqrt_rsqrt(double x, double* root, double* inv) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  *root = g;
+  *inv = h + h;
+}
+// atan2(y, x), y >= 0, result in [0, pi]: fdlibm-style reduction + odd polynomial (see okx_kernels.hip).
+DEV double lean_atan2_pos(double y, double x) {
+  const double ax = fabs(x);
+  if (!(y > 0.0)) return x >= 0.0 ? 0.0 : 3.14159265358979311600e+00;
+  if (ax == 0.0) return 1.57079632679489655800e+00;
+  double t = y * fast_rcp(ax);
+  double hi, lo;
+  if (t < 0.4375) { hi = 0.0; lo = 0.0; }
+  else if (t < 0.6875) { hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; t = (2.0 * t - 1.0) * fast_rcp(2.0 + t); }
+  else if (t < 1.1875) { hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; t = (t - 1.0) * fast_rcp(t + 1.0); }
+  else if (t < 2.4375) { hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; t = (t - 1.5) * fast_rcp(1.0 + 1.5 * t); }
+  else { hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; t = -fast_rcp(t); }
+  const double z = t * t, w = z * z;
+  const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+       w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+  const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+       w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+  const double at = hi - ((t * (s1 + s2) - lo) - t);
+  return x > 0.0 ? at : 3.14159265358979311600e+00 - (at - 1.2246467991473531772e-16);
+}
+DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// A double parked in two accumulation registers by hand (the factor's finished rows): never a candidate for the
+// register allocator's own spilling, one write and one read per half.
+DEV void park(double v, int& lo, int& hi) {
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(v)));
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(v)));
+}
+DEV double unpark(int lo, int hi) {
+  int l, h;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi));
+  return __hiloint2double(h, l);
+}
+)SRC";
+
+}  // namespace
+
+bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
+  if (P.n_free > kLaneMaxFree) {
+    *why = "more than " + std::to_string(kLaneMaxFree) + " free points: the lower triangle of J^T J does not fit one lane's registers";
+    return false;
+  }
+  if (P.n_targets > kMaxTargets || P.n_targets < 1) {
+    *why = "needs 1.." + std::to_string(kMaxTargets) + " targets";
+    return false;
+  }
+  const int nf = P.n_free, n = 3 * nf, NP = P.n_points, T = P.n_targets;
+  LGen ev(P);
+  ev.pin_acc = getenv("OKX_LANE_NO_PIN") == nullptr;  // (experiment switch)
+  for (int e = 0; e < P.n_derived; ++e) ev.dp(e);
+  ev.f("    // ---- active derived points with chain-rule blocks ----");
+  for (int idx = 0; idx < P.n_active; ++idx)
+    if (!ev.derived_op(P.active_op[idx], true)) {
+      *why = ev.why;
+      return false;
+    }
+  if (!ev.emit_rows()) {
+    *why = ev.why;
+    return false;
+  }
+  const std::string eval_src = ev.out;
+  ev.out.clear();
+  if (const char* env = getenv("OKX_LANE_COL_FENCE")) ev.col_fence = atoi(env);
+  if (const char* env = getenv("OKX_LANE_RESIDENT_ROWS")) ev.resident_rows = atoi(env);
+  {
+    std::vector<std::string> rhs;
+    for (int i = 0; i < n; ++i) rhs.push_back("-" + LGen::gn(i));
+    ev.emit_factor(rhs);
+  }
+  const std::string factor_src = ev.out;
+  ev.out.clear();
+  ev.emit_backward("nx");
+  const std::string subst_src = ev.out;
+  ev.out.clear();
+
+  // confirming evaluation (residuals only); not for programs with the reference's zero-gradient point-on-line row
+  bool light_ok = true;
+  for (int i = 0; i < P.n_crows; ++i) light_ok = light_ok && P.row_type[i] != OKX_ROW_POINT_ON_LINE;
+  std::string light_src;
+  if (light_ok) {
+    LGen lt(P);
+    lt.uid = 300000;
+    lt.hoisted_names = ev.hoisted_names;
+    for (int idx = 0; idx < P.n_active; ++idx)
+      if (!lt.derived_op(P.active_op[idx], false)) light_ok = false;
+    if (light_ok && !lt.emit_rows_residual_only()) light_ok = false;
+    if (!lt.hoisted.empty()) light_ok = false;
+    light_src = lt.out;
+  }
+  // final state: every derived point
+  LGen fin(P);
+  fin.uid = 100000;
+  fin.hoisted_names = ev.hoisted_names;
+  for (int e = 0; e < P.n_derived; ++e)
+    if (!fin.derived_op(e, false)) {
+      *why = fin.why;
+      return false;
+    }
+  if (!fin.hoisted.empty()) {
+    *why = "final derived points need constants the pass did not load";
+    return false;
+  }
+  const std::string final_src = fin.out;
+
+  std::vector<bool> used(NP, false);
+  for (int k = 0; k < P.n_out; ++k) used[P.out_point[k]] = true;
+  for (int i = 0; i < P.m; ++i)
+    for (int s = 0; s < 4; ++s)
+      if (P.row_pts[i][s] >= 0) used[P.row_pts[i][s]] = true;
+  for (int e = 0; e < P.n_derived; ++e) {
+    used[P.dop_out[e]] = true;
+    for (int s = 0; s < 4; ++s)
+      if (P.dop_pts[e][s] >= 0) used[P.dop_pts[e][s]] = true;
+  }
+  for (int k = 0; k < nf; ++k) used[P.free_point[k]] = true;
+  auto is_fixed = [&](int p) { return ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0; };
+
+  // first-step table layout (shared with okx_quadgen.cpp: quad_head_stride)
+  const int HK = T + 1;
+  const int head_off = 4 * nf * HK + 2 * HK * HK;
+  const int head_stride = head_off + 8;
+
+  // the fixed points are chain constants too (macros p{k}_{c} -> cl[...])
+  for (int p = 0; p < NP; ++p)
+    if (used[p] && is_fixed(p))
+      for (int c = 0; c < 3; ++c) {
+        char name[32], source[48];
+        std::snprintf(name, sizeof(name), "p%d_%d", p, c);
+        std::snprintf(source, sizeof(source), "gp[%d]", 3 * p + c);
+        ev.add_const(name, source);
+      }
+  const int n_consts = ev.n_consts > 0 ? ev.n_consts : 1;
+  const bool marks = getenv("OKX_LANE_MARK") != nullptr;  // `s_nop 11..16` between the sections of a pass (tools/lane_isa.sh)
+
+  LGen g(P);
+  g.out += kLanePreamble;
+  g.f("");
+  g.out += ev.defines;
+  auto PF = [&](int i) { return "p" + std::to_string(ev.fp(i / 3)) + "_" + std::to_string(i % 3); };
+  const char* refresh_kz = "asm volatile(\"\" : \"+v\"(kz));";
+
+  // One body per start mode.  COLD: every problem is an independent solve from the design state (chain_len 1): no
+  // chain loop, no history, 36 LDS slots.  CHAIN: consecutive problems of a lane form a chain with secant / quadratic
+  // extrapolation: the history xp / xq takes another 36 slots.
+  std::string lds_why;
+  auto body = [&](bool ch) -> bool {
+    int n_slots = 0;
+    auto slot_ref = [&](const std::string& name) { return "double& " + name + " = lds[" + std::to_string(64 * n_slots++) + " + lane];"; };
+    std::string state_decl;
+    for (int i = 0; i < n; ++i) {
+      state_decl += "    " + slot_ref("x" + std::to_string(i)) + " " + slot_ref("dx" + std::to_string(i));
+      if (ch) state_decl += " " + slot_ref("xp" + std::to_string(i)) + " " + slot_ref("xq" + std::to_string(i));
+      state_decl += "\n";
+    }
+    const int state_doubles = 64 * n_slots;
+    const int stage_doubles = ch ? 0 : 64 * 3 * P.n_out;
+    const int lds_doubles = state_doubles > stage_doubles ? state_doubles : stage_doubles;
+    if ((lds_doubles + n_consts) * 8 > 40 * 1024) {
+      lds_why = "per-wavefront LDS state exceeds 40 KiB";
+      return false;
+    }
+    auto mark = [&](int k) {
+      if (marks && !ch) g.f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + k);
+    };
+    g.f("template <bool PG> DEV void okx_lane_body_%s(const QArgs& a) {", ch ? "chain" : "cold");
+    g.f("  const int lane = threadIdx.x;");
+    g.f("  __shared__ double lds[%d];", lds_doubles);
+    g.f("  __shared__ double cl[%d];  // chain constants of the wave unit's geometry", n_consts);
+    g.f("  int kz = 0;");
+    g.f("  const long long spg = a.steps_per_geometry;");
+    g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
+    g.f("  const long long n_spans = spg > 0 ? a.n_problems / span : 1;");
+    if (ch) {
+      g.f("  const long long unit_len = a.chain_len;");
+      g.f("  const long long chains_per_span = (span + unit_len - 1) / unit_len;");
+    } else {
+      g.f("  const long long unit_len = 1;");
+      g.f("  const long long chains_per_span = span;");
+    }
+    g.f("  const long long waves_per_span = (chains_per_span + 63) / 64;");
+    g.f("  const long long n_wave_units = n_spans * waves_per_span;");
+    g.f("  for (long long wu = blockIdx.x; wu < n_wave_units; wu += gridDim.x) {");
+    g.f("    const long long span_idx = n_spans > 1 ? wu / waves_per_span : 0;  // wave-uniform: one geometry per wave unit");
+    g.f("    const long long wave_in_span = wu - span_idx * waves_per_span;");
+    g.f("    long long chain_in_span = wave_in_span * 64 + lane;");
+    g.f("    const bool have = chain_in_span < chains_per_span;");
+    g.f("    if (!have) chain_in_span = chains_per_span - 1;");
+    g.f("    const long long first_b = span_idx * span + chain_in_span * unit_len;");
+    if (ch) g.f("    const long long last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
+    g.f("    const double* gp = PG ? a.geom_pos + span_idx * %d : a.design_pos;", 3 * NP);
+    g.f("    const double* gq = PG ? a.geom_row_param + span_idx * %d : a.row_param;", 8 * P.n_crows);
+    g.f("    (void)gq;");
+    if (ch)
+      for (int t = 0; t < T; ++t) g.f("    double tn%d = a.targets[first_b * %d + %d], tp%d = 0.0, tq%d = 0.0, tr%d = 0.0;", t, T, t, t, t, t);
+    else
+      for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[first_b * %d + %d];", t, T, t);
+    g.f("    // chain constants of this wave unit (every lane writes the same values: no barrier involved)");
+    g.out += ev.hoisted;
+    g.f("    %s", refresh_kz);
+    for (int p = 0; p < NP; ++p) {
+      if (!used[p] || is_fixed(p)) continue;
+      for (int c = 0; c < 3; ++c) g.f("    double p%d_%d = gp[%d];", p, c, 3 * p + c);
+    }
+    g.out += state_decl;
+    for (int i = 0; i < n; ++i) {
+      g.f("    x%d = %s; dx%d = 0.0;", i, PF(i).c_str(), i);
+      if (ch) g.f("    xp%d = %s; xq%d = %s;", i, PF(i).c_str(), i, PF(i).c_str());
+    }
+    // the design state is a solved state of its own design targets: it seeds the chain's history
+    for (int i = P.n_crows; i < P.m; ++i) {
+      const int t = ev.target_of_row(i);
+      const S3 dir = ev.rpv(i, 0);
+      const S3 q = LGen::pt(P.row_pts[i][0]);
+      g.f("    const double td%d = fma(%s, %s, fma(%s, %s, %s * %s));", t, q.c[0].c_str(), dir.c[0].c_str(), q.c[1].c_str(),
+          dir.c[1].c_str(), q.c[2].c_str(), dir.c[2].c_str());
+    }
+    if (ch)
+      for (int t = 0; t < T; ++t) g.f("    tp%d = td%d;", t, t);
+    // shared first step of the unit's first problem, table of okx_quad_head_u/_g
+    g.f("    bool head_ready = false;");
+    g.f("    double hstep = 0.0, hN = 0.0, hM = 0.0, hss = 0.0, hmr = 0.0, hs0 = 0.0, hs1 = 0.0, hs4 = 0.0, hs5 = 0.0;");
+    g.f("    if (a.head != nullptr && a.grad_tol <= 0.0) {");
+    g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
+    g.f("      const double hr0 = 1.0;");
+    for (int k = 1; k < HK; ++k) g.f("      const double hr%d = td%d - tn%d;", k, k - 1, k - 1);
+    for (int i = 0; i < n; ++i) {
+      std::string e;
+      for (int k = 0; k < HK; ++k)
+        e += (k ? " + hr" : "hr") + std::to_string(k) + " * hp[" + std::to_string(4 * (k * nf + i / 3) + i % 3) + "]";
+      g.f("      { const double hx = -(%s); dx%d = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", e.c_str(), i);
+    }
+    for (int j = 0; j < HK; ++j)
+      for (int k = j; k < HK; ++k)
+        g.f("      hM = fma(%shr%d * hr%d, hp[%d], hM);", j == k ? "" : "2.0 * ", j, k, head_off - 2 * HK * HK + j * HK + k);
+    g.f("      hss = hp[%d]; hmr = hp[%d];", head_off + 2, head_off + 3);
+    for (int k = 1; k < HK; ++k) g.f("      hss = fma(hr%d, hr%d, hss); hmr = fmax(hmr, fabs(hr%d));", k, k, k);
+    g.f("      hs0 = hp[%d]; hs1 = hp[%d]; hs4 = hp[%d]; hs5 = hp[%d];", head_off, head_off + 1, head_off + 4, head_off + 5);
+    g.f("      head_ready = true;");
+    g.f("    }");
+    if (ch) {
+      g.f("    int hist = 1;");
+      g.f("    double lambda_carry = 0.0;");
+      g.f("    for (long long b = first_b; wave_any(have && b < last_b); ++b) {");
+      g.f("      const bool valid = have && b < last_b;");
+      g.f("      const long long bb = valid ? b : last_b - 1;");
+      g.f("      const long long nb = b + 1 < last_b ? b + 1 : last_b - 1;");
+      for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
+      for (int t = 0; t < T; ++t) g.f("      tn%d = a.targets[nb * %d + %d];", t, T, t);
+      // extrapolation along the chain: secant / quadratic through the last solved states
+      g.f("      if (hist >= 2) {");
+      g.f("        double num = 0.0, den = 0.0, nn = 0.0, num2 = 0.0, den2 = 0.0;");
+      for (int t = 0; t < T; ++t) {
+        g.f("        { const double dn = tv%d - tp%d, dold = tp%d - tq%d, dolder = tq%d - tr%d;", t, t, t, t, t, t);
+        g.f("          num = fma(dn, dold, num); den = fma(dold, dold, den); nn = fma(dn, dn, nn);");
+        g.f("          num2 = fma(dold, dolder, num2); den2 = fma(dolder, dolder, den2); }");
+      }
+      g.f("        double alpha = den > 0.0 ? num * fast_rcp(den) : 0.0;");
+      g.f("        alpha = fmin(fmax(alpha, 0.0), 2.0);");
+      g.f("        const double beta = den2 > 0.0 ? num2 * fast_rcp(den2) : 0.0;");
+      g.f("        const bool line = hist >= 3 && alpha > 0.0 && beta >= 1e-3 && beta <= 2.0 && num * num >= 0.98 * nn * den && num2 * num2 >= 0.98 * den * den2;");
+      g.f("        const double bq = line ? fast_rcp(beta) : 1.0;");
+      g.f("        const double r1q = fast_rcp(1.0 + bq);");
+      g.f("        const double l0 = line ? (alpha + 1.0) * (alpha + 1.0 + bq) * r1q : 1.0 + alpha;");
+      g.f("        const double l1 = line ? -alpha * (alpha + 1.0 + bq) * beta : -alpha;");
+      g.f("        const double l2 = line ? alpha * (alpha + 1.0) * r1q * beta : 0.0;");
+      for (int i = 0; i < n; ++i)
+        g.f("        { const double xo = x%d, xpo = xp%d; const double xn = fma(l0, xo, fma(l1, xpo, l2 * xq%d)); xq%d = xpo; xp%d = xo; x%d = xn; }", i, i, i, i, i, i);
+      g.f("      } else {");
+      for (int i = 0; i < n; ++i) g.f("        { const double xo = x%d; xq%d = xp%d; xp%d = xo; }", i, i, i, i);
+      g.f("      }");
+    } else {
+      g.f("    {");
+      g.f("      const bool valid = have;");
+      g.f("      const long long bb = first_b;");
+      for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
+    }
+    g.f("      double Fc = 0.0, lambda = 0.0, nu = 2.0, dmax = 0.0, step_len = 0.0, last_step = 0.0, mres = 0.0, pred = 0.0;");
+    g.f("      int nfev = 0, iters = 0, flags = 0, nfail = 0;");
+    g.f("      int mode = 0;  // 0 first evaluation, 1 trial point, 2 re-evaluation of the accepted point");
+    g.f("      bool done = !valid, want_light = false;");
+    g.f("      double prev_sl = 0.0, piv_lo = 0.0, piv_hi = 0.0;");
+    g.f("      if (head_ready%s) {", ch ? " && b == first_b" : "");
+    g.f("        const bool at_design = valid%s && hs4 > 0.5;", ch ? " && hist == 1" : "");
+    g.f("        if (at_design) {");
+    g.f("          Fc = 0.5 * hss; mres = hmr; dmax = hs0; lambda = a.lambda0 * dmax;");
+    g.f("          step_len = hstep; pred = 0.5 * fma(lambda, hN, hM); iters = 1; mode = 1;");
+    g.f("          piv_lo = hs1 - lambda; piv_hi = hs5;");
+    g.f("          if (hstep <= a.step_tol) { flags |= INFO_CONVERGED; last_step = hstep; done = true; }");
+    g.f("          else {");
+    g.f("            want_light = hstep <= 1e-3 && (100.0 * lambda * fast_rcp(hs1) + hstep) * hstep <= a.step_tol;");
+    g.f("            prev_sl = hstep;");
+    g.f("          }");
+    g.f("        } else {");
+    for (int i = 0; i < n; ++i) g.f("          dx%d = 0.0;", i);
+    g.f("        }");
+    g.f("      }%s", ch ? " else {" : "");
+    if (ch) {
+      for (int i = 0; i < n; ++i) g.f("        dx%d = 0.0;", i);
+      g.f("      }");
+    }
+    g.f("      while (wave_any(!done)) {");
+    g.f("    %s", refresh_kz);
+    if (light_ok) {
+      g.f("    if (a.confirm == 0 && !wave_any(!done && !want_light)) {");
+      for (int i = 0; i < n; ++i) g.f("      %s = x%d + dx%d;", PF(i).c_str(), i, i);
+      g.out += light_src;
+      g.f("      const double Fl = 0.5 * ss;");
+      g.f("      if (!done) {");
+      g.f("        ++nfev;");
+      g.f("        if (Fl == Fl && Fl <= Fc * (1.0 + 1e-6) + 1e-28) {");
+      for (int i = 0; i < n; ++i) g.f("          x%d = %s;", i, PF(i).c_str());
+      g.f("          Fc = Fl; mres = mres_new; last_step = step_len; flags |= INFO_CONVERGED; done = true;");
+      g.f("        } else {");
+      g.f("          want_light = false;");
+      g.f("        }");
+      g.f("      }");
+      g.f("      continue;");
+      g.f("    }");
+      g.f("    want_light = false;");
+    }
+    mark(1);
+    for (int i = 0; i < n; ++i) g.f("    %s = mode == 2 ? x%d : x%d + dx%d;", PF(i).c_str(), i, i, i);
+    g.out += eval_src;
+    mark(2);
+    g.f("    const double Ft = 0.5 * ss;");
+    g.f("    bool accept = true, stop = false;");
+    g.f("    double rho = 1.0;");
+    g.f("    if (mode == 1) {");
+    g.f("      const bool finite = Ft == Ft && step_len == step_len && Ft < 1e300;");
+    g.f("      const bool small = finite && step_len <= 1e-8 && Ft <= Fc * (1.0 + 1e-6) + 1e-28;");
+    g.f("      rho = (finite && pred > 0.0) ? (Fc - Ft) * fast_rcp(pred) : -1.0;");
+    g.f("      accept = rho > 1e-4 || small;");
+    g.f("      if (finite && step_len <= a.step_tol) { accept = small; stop = true; }");
+    g.f("      else if (accept && finite && Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) stop = true;");
+    g.f("    }");
+    g.f("    double diag = 0.0, gm = 0.0;");
+    g.f("    if (wave_any(mode == 0)) {");
+    for (int i = 0; i < n; ++i) g.f("      diag = fmax(diag, %s);", LGen::A(i, i).c_str());
+    g.f("    }");
+    g.f("    if (a.grad_tol > 0.0) {");
+    for (int i = 0; i < n; ++i) g.f("      gm = fmax(gm, fabs(%s));", LGen::gn(i).c_str());
+    g.f("    }");
+    g.f("    if (!done) {");
+    g.f("      ++nfev;");
+    g.f("      if (stop) flags |= INFO_CONVERGED;");
+    g.f("      if (accept) {");
+    g.f("        if (mode != 2) {");
+    for (int i = 0; i < n; ++i) g.f("          x%d = %s;", i, PF(i).c_str());
+    g.f("          if (mode == 1) last_step = step_len;");
+    g.f("          nu = 2.0;");
+    g.f("        }");
+    g.f("        Fc = Ft; mres = mres_new;");
+    g.f("        if (!stop) {");
+    g.f("          if (mode == 0) {");
+    g.f("            dmax = diag; lambda = a.lambda0 * dmax;");
+    if (ch) g.f("            if (lambda_carry > 0.0) lambda = fmin(lambda, lambda_carry);");
+    g.f("          }");
+    g.f("          else if (mode == 1 && rho > 1e-4) {");
+    g.f("            const double t = 2.0 * rho - 1.0;");
+    g.f("            lambda *= rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t);");
+    g.f("          }");
+    g.f("          if (a.grad_tol > 0.0 && gm <= a.grad_tol) { flags |= INFO_CONVERGED; stop = true; }");
+    g.f("        }");
+    g.f("      } else if (!stop) {");
+    g.f("        lambda *= nu; nu *= 2.0;");
+    g.f("      }");
+    g.f("      if (stop || iters >= a.max_iter) done = true;");
+    g.f("    }");
+    g.f("    const bool solve_now = !done && accept;");
+    g.f("    if (!done && !accept) mode = 2;");
+    g.f("    if (wave_any(solve_now)) {");
+    mark(3);
+    g.out += factor_src;
+    mark(4);
+    g.out += subst_src;
+    mark(5);
+    g.f("    double sl = 0.0, pr = 0.0;");
+    for (int i = 0; i < n; ++i) g.f("    sl = fmax(sl, fabs(nx%d));", i);
+    for (int i = 0; i < n; ++i) g.f("    pr = fma(nx%d, fma(lambda, nx%d, -%s), pr);", i, i, LGen::gn(i).c_str());
+    g.f("    pr = 0.5 * pr;");
+    g.f("    if (solve_now) {");
+    g.f("      ++iters;");
+    g.f("      if (ok) {");
+    g.f("        piv_lo = pmin - lambda; piv_hi = pmax;");
+    for (int i = 0; i < n; ++i) g.f("        dx%d = nx%d;", i, i);
+    g.f("        step_len = sl; pred = pr;");
+    g.f("        if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
+    g.f("        else {");
+    g.f("          const double cq = prev_sl > 0.0 ? fmax(100.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
+    g.f("          const double rho_lin = 100.0 * lambda * fast_rcp(pmin);");
+    g.f("          want_light = sl <= 1e-3 && (rho_lin + cq * sl) * sl <= a.step_tol;");
+    g.f("          prev_sl = sl;");
+    g.f("        }");
+    g.f("        mode = 1;");
+    g.f("      } else {");
+    g.f("        lambda = fmax(lambda * 10.0, 1e-12 * dmax);");
+    g.f("        if (++nfail > 60 || !(lambda < 1e30)) { flags |= INFO_FAILED; done = true; }");
+    g.f("        mode = 2;");
+    g.f("      }");
+    g.f("    }");
+    mark(6);
+    g.f("    }  // any lane solves");
+    g.f("      }  // LM passes");
+    // final state and output
+    g.f("      {");
+    g.f("    %s", refresh_kz);
+    for (int i = 0; i < n; ++i) g.f("    %s = x%d;", PF(i).c_str(), i);
+    g.out += final_src;
+    g.f("    if (mres > a.residual_tolerance) flags |= INFO_RESIDUAL_EXCEEDED;");
+    g.f("    if (piv_hi > 0.0 && piv_lo <= ILL_CONDITIONED_PIVOT_RATIO * piv_hi) flags |= INFO_ILL_CONDITIONED;");
+    if (ch) {
+      // chain bookkeeping
+      for (int t = 0; t < T; ++t) g.f("    tr%d = tq%d; tq%d = tp%d; tp%d = tv%d;", t, t, t, t, t, t);
+      g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
+      for (int i = 0; i < n; ++i) g.f("      x%d = gp[%d];", i, 3 * ev.fp(i / 3) + i % 3);
+      g.f("      hist = 1; lambda_carry = 0.0;");
+      for (int t = 0; t < T; ++t) g.f("      tp%d = td%d;", t, t);
+      g.f("    } else {");
+      g.f("      if (hist < 3) ++hist;");
+      g.f("      lambda_carry = lambda;");
+      g.f("    }");
+    }
+    g.f("    if (valid) {");
+    g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
+    g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
+    g.f("      a.info[bb] = inf;");
+    g.f("    }");
+    if (!ch) {
+      // Records of independent solves: the 64 problems of a wave unit are consecutive, their records one contiguous
+      // block: transposed through LDS (which the state no longer needs) and written as full 16-byte-per-lane rows.
+      g.f("      __syncthreads();");
+      g.f("      double* st = lds + lane * %d;", 3 * P.n_out);
+      for (int k = 0; k < P.n_out; ++k)
+        for (int c = 0; c < 3; ++c) g.f("      st[%d] = p%d_%d;", 3 * k + c, P.out_point[k], c);
+      g.f("      __syncthreads();");
+      g.f("      const long long base_b = span_idx * span + wave_in_span * 64;");
+      g.f("      const long long rem = (span_idx + 1) * span - base_b;");
+      g.f("      const int n_doubles = (int)(rem < 64 ? rem : 64) * %d;", 3 * P.n_out);
+      g.f("      double* dst = a.out_pos + base_b * %d;", 3 * P.n_out);
+      g.f("      double2* dst2 = reinterpret_cast<double2*>(dst);");
+      g.f("      const double2* src2 = reinterpret_cast<const double2*>(lds);");
+      g.f("      if ((reinterpret_cast<unsigned long long>(dst) & 15ull) == 0ull) {");
+      g.f("        for (int i = lane; i < n_doubles / 2; i += 64) dst2[i] = src2[i];");
+      g.f("        if ((n_doubles & 1) && lane == 0) dst[n_doubles - 1] = lds[n_doubles - 1];");
+      g.f("      } else {");
+      g.f("        for (int i = lane; i < n_doubles; i += 64) dst[i] = lds[i];");
+      g.f("      }");
+      g.f("      __syncthreads();");
+    } else {
+      // chains: a lane's problems are far apart in memory, every lane stores its own record
+      g.f("    if (valid) {");
+      g.f("      double* o = a.out_pos + bb * %d;", 3 * P.n_out);
+      for (int k = 0; k < P.n_out; ++k)
+        for (int c = 0; c < 3; ++c) g.f("      o[%d] = p%d_%d;", 3 * k + c, P.out_point[k], c);
+      g.f("    }");
+    }
+    g.f("      }");
+    g.f("    }  // chain steps");
+    g.f("  }  // wave units");
+    g.f("}");
+    g.f("");
+    return true;
+  };
+  if (!body(false) || !body(true)) {
+    *why = lds_why;
+    return false;
+  }
+  // ---- parity / debug kernel: r, J^T J, J^T r at given x, and the damped step for a given lambda ----
+  g.f("struct QEvalArgs { const double* x; const double* targets; double* r; double* ata; double* atr; double* dx;");
+  g.f("  double lambda; long long n_problems; const double* design_pos; const double* row_param; const double* dop_param; };");
+  g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_eval(QEvalArgs a) {");
+  g.f("  const double* gp = a.design_pos; const double* gq = a.row_param; (void)gq;");
+  g.f("  __shared__ double cl[%d];", n_consts);
+  g.f("  int kz = 0;");
+  g.out += ev.hoisted;
+  g.f("  %s", refresh_kz);
+  g.f("  for (long long wu = blockIdx.x; wu * 64 < a.n_problems; wu += gridDim.x) {");
+  g.f("    long long bb = wu * 64 + threadIdx.x; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");
+  for (int p = 0; p < NP; ++p)
+    if (used[p] && !is_fixed(p))
+      for (int c = 0; c < 3; ++c) g.f("    double p%d_%d = gp[%d];", p, c, 3 * p + c);
+  for (int i = 0; i < n; ++i) g.f("    %s = a.x[bb * %d + %d];", PF(i).c_str(), n, 3 * ev.perm[i / 3] + i % 3);
+  for (int t = 0; t < T; ++t) g.f("    const double tv%d = a.targets[bb * %d + %d];", t, T, t);
+  {
+    // the parity kernel additionally accumulates the whole lower triangle of J^T J where the rows are (E{i}_{j}): the
+    // solve kernels never hold it in that form
+    LGen ee(P);
+    ee.uid = 500000;
+    ee.early_ata = getenv("OKX_LANE_EVAL_NO_E") == nullptr;
+    ee.pin_acc = false;
+    ee.hoisted_names = ev.hoisted_names;
+    for (int idx = 0; idx < P.n_active; ++idx) (void)ee.derived_op(P.active_op[idx], true);
+    (void)ee.emit_rows();
+    g.out += ee.out;
+    ee.out.clear();
+    g.f("    if (valid) {");
+    for (int i = 0; i < P.m; ++i) g.f("      a.r[bb * %d + %d] = r%d;", P.m, i, i);
+    for (int i = 0; i < n; ++i) {
+      const int pi = 3 * ev.perm[i / 3] + i % 3;
+      g.f("      a.atr[bb * %d + %d] = %s;", n, pi, LGen::gn(i).c_str());
+      g.f("      a.ata[(bb * %d + %d) * %d + %d] = %s;", n, pi, n, pi, LGen::A(i, i).c_str());
+      for (int j = 0; j < i; ++j)
+        if (ee.nz[i][j] && ee.early_ata) {
+          const int pj = 3 * ev.perm[j / 3] + j % 3;
+          g.f("      a.ata[(bb * %d + %d) * %d + %d] = %s;", n, pi, n, pj, LGen::E(i, j).c_str());
+          if (i / 3 == j / 3) g.f("      a.ata[(bb * %d + %d) * %d + %d] = %s;", n, pj, n, pi, LGen::E(i, j).c_str());
+        }
+    }
+    g.f("    }");
+    g.f("    const double lambda = a.lambda;");
+    std::vector<std::string> rhs;
+    for (int i = 0; i < n; ++i) rhs.push_back("-" + LGen::gn(i));
+    ee.col_fence = ev.col_fence;
+    ee.resident_rows = ev.resident_rows;
+    ee.emit_factor(rhs);
+    ee.emit_backward("nx");
+    g.out += ee.out;
+  }
+  g.f("    if (valid) {");
+  for (int i = 0; i < n; ++i) g.f("      a.dx[bb * %d + %d] = ok ? nx%d : __builtin_nan(\"\");", n, 3 * ev.perm[i / 3] + i % 3, i);
+  g.f("    }");
+  g.f("  }");
+  g.f("}");
+  g.f("");
+  g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_solve_u(QArgs a) { okx_lane_body_cold<false>(a); }");
+  g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_solve_g(QArgs a) { okx_lane_body_cold<true>(a); }");
+  g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_chain_u(QArgs a) { okx_lane_body_chain<false>(a); }");
+  g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_chain_g(QArgs a) { okx_lane_body_chain<true>(a); }");
+  g.out += ev.undefs;
+  *src = g.out;
+  return true;
+}
+
+}  // namespace okx

@@ -15,6 +15,7 @@ constexpr int kPredictorMaxDegree = 12;
 constexpr int kPredictorLdsDoubles = 1024;  // single mode: tables up to this size are staged through LDS (8 KB per wavefront)
 constexpr int kQuadMaxFree = 8;          // n <= 24 unknowns: the lane-owned rows of J^T J stay in registers
 constexpr int kQuadMaxFreePerSide = 10;  // pair mode (two identical halves, one quad each): free points per half
+constexpr int kLaneMaxFree = 6;          // lane kernel (one lane per problem): n <= 18 unknowns, lower triangle of J^T J <= 171 doubles
 
 // Kernel arguments of the generated kernels (mirrors `struct QArgs` in the generated source).
 struct QuadArgs {
@@ -115,6 +116,11 @@ bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why);
 // `lds_homes` (pair mode only): the chain constants and the fixed points live in LDS instead of registers - the
 // fallback for a half program whose register-resident variant spills (see quad_build).
 bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why, bool lds_homes = false);
+
+// Emits the HIP source of the LANE kernel specialised to `P` (okx_lanegen.cpp): one lane per problem, 64 problems per
+// wavefront, for batches that fill the chip several times over.  Kernels okx_lane_solve_u/_g (arguments: QuadArgs) and
+// okx_lane_eval (QuadEvalArgs).  Returns false (and says why) when the program does not fit one lane's registers.
+bool lane_generate(const DevProgram& P, std::string* src, std::string* why);
 
 // Compiles `src` for gfx950 with hiprtc (no device needed) or fetches it from the on-disk cache
 // (<dir of libokx.so>/_kcache/<hash>.okxc, override with OKX_KERNEL_CACHE).  Returns the code
