@@ -519,6 +519,9 @@ int32_t okx_precompile(const okx_program_desc* desc);
  */
 const char* okx_program_lane_note(const okx_program* prog);
 int64_t okx_program_lane_threshold(const okx_program* prog);   /* -1: no lane kernel */
+/* Which bodies auto selection uses: bit0 independent solves (chain_len 1), bit1 chains.  A body whose register
+ * allocation spills more than a little stays with the quad kernel (okx_solve_opts.kernel = 4 still runs it). */
+int32_t okx_program_lane_bodies(const okx_program* prog);
 int64_t okx_lane_source(const okx_program_desc* desc, char* buf, int64_t buflen);
 
 #ifdef __cplusplus

@@ -42,6 +42,7 @@ EXPORTS = (
     "okx_program_has_predictor",
     "okx_program_lane_note",
     "okx_program_lane_threshold",
+    "okx_program_lane_bodies",
     "okx_lane_source",
 )
 
@@ -141,6 +142,8 @@ def load() -> C.CDLL:
     lib.okx_program_lane_note.restype = C.c_char_p
     lib.okx_program_lane_threshold.argtypes = [vp]
     lib.okx_program_lane_threshold.restype = i64
+    lib.okx_program_lane_bodies.argtypes = [vp]
+    lib.okx_program_lane_bodies.restype = i32
     lib.okx_lane_source.argtypes = [C.POINTER(ProgramDesc), C.c_char_p, i64]
     lib.okx_lane_source.restype = i64
     if lib.okx_abi_version() != ABI_VERSION:

@@ -88,6 +88,11 @@ class DeviceProgram:
         return int(self.lib.okx_program_lane_threshold(self._handle))
 
     @property
+    def lane_bodies(self) -> int:
+        """Bodies of the lane kernel auto selection uses: bit0 independent solves, bit1 chains (0: none)."""
+        return int(self.lib.okx_program_lane_bodies(self._handle))
+
+    @property
     def lane_note(self) -> str:
         """Why the program has no lane kernel (empty when it has one)."""
         return self.lib.okx_program_lane_note(self._handle).decode()

@@ -63,6 +63,8 @@ struct okx_program {
   hipFunction_t lane_fn_u, lane_fn_g, lane_fn_eval;  // independent solves (chain_len 1), parity kernel
   hipFunction_t lane_chain_u, lane_chain_g;          // chains
   long long lane_min_problems;
+  int lane_cold_scratch, lane_chain_scratch;  // private-segment bytes of the two bodies (code object metadata)
+  bool lane_cold_ok, lane_chain_ok;           // bodies that auto selection may use
   char lane_note[256];
 };
 
@@ -288,8 +290,17 @@ void attach_lane_kernel(okx_program* p) {
     std::snprintf(p->lane_note, sizeof(p->lane_note), "compile failed: %.200s", err.c_str());
     return;
   }
-  if (okx::quad_code_scratch_bytes(code, "okx_lane_solve") > 0 && !getenv("OKX_LANE_ALLOW_SCRATCH")) {
-    std::snprintf(p->lane_note, sizeof(p->lane_note), "the lane kernel of this program spills to scratch: not used");
+  // A body that spills is only worth having while the spill is small.  Measured on MI355X: the double wishbone's
+  // independent-solve body (104 - 192 B of scratch) is still 1.8x the quad kernel on 4096 geometries x 256 steps, its chain
+  // body (668 B) is 8 % slower than the quad kernel's chains; MacPherson (0 B) wins both ways.
+  p->lane_cold_scratch = okx::quad_code_scratch_bytes(code, "okx_lane_solve");
+  p->lane_chain_scratch = okx::quad_code_scratch_bytes(code, "okx_lane_chain");
+  const bool any = getenv("OKX_LANE_ALLOW_SCRATCH") != nullptr;
+  p->lane_cold_ok = p->lane_cold_scratch >= 0 && (any || p->lane_cold_scratch <= 256);
+  p->lane_chain_ok = p->lane_chain_scratch >= 0 && (any || p->lane_chain_scratch == 0);
+  if (!p->lane_cold_ok && !p->lane_chain_ok) {
+    std::snprintf(p->lane_note, sizeof(p->lane_note), "the lane kernel of this program spills (%d / %d B of scratch): not used",
+                  p->lane_cold_scratch, p->lane_chain_scratch);
     return;
   }
   hipModule_t mod = nullptr;
@@ -442,6 +453,10 @@ const char* okx_program_kernel_note(const okx_program* p) { return p ? p->quad_n
 /* Why the program has no lane kernel (empty string: it has one), and the batch size from which auto selection uses it. */
 const char* okx_program_lane_note(const okx_program* p) { return p ? p->lane_note : ""; }
 int64_t okx_program_lane_threshold(const okx_program* p) { return p && p->lane_fn_u ? p->lane_min_problems : -1; }
+/* bit0: auto selection uses the lane kernel's independent-solve body, bit1: its chain body (0: neither / no lane kernel) */
+int32_t okx_program_lane_bodies(const okx_program* p) {
+  return p && p->lane_fn_u ? (p->lane_cold_ok ? 1 : 0) | (p->lane_chain_ok ? 2 : 0) : 0;
+}
 
 /* Generated source of the lane kernel for a program (no device needed); same contract as okx_quad_source. */
 int64_t okx_lane_source(const okx_program_desc* desc, char* buf, int64_t buflen) {
@@ -558,8 +573,17 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   const long long quad_slots = (long long)p->n_cu * p->quad_waves_per_cu * p->quad_ppw;
   // Lane kernel (one lane per problem, 64 per wavefront): auto selection from lane_min_problems on, when nothing the
   // quad kernel alone offers is asked for (fitted model, trace); kernel == 4 forces it.
+  // (which body a launch needs is known once the chain length is: a body auto selection may not use sends the launch
+  //  back to the quad kernel below)
   bool use_lane = p->lane_fn_u != nullptr && use_quad && opts->predictor == 0 && p->quad_trace == nullptr &&
                   (opts->kernel == 4 || (opts->kernel == 0 && n_problems >= p->lane_min_problems));
+  if (use_lane && opts->kernel == 0) {
+    const long long span0 = spg > 0 ? spg : n_problems;
+    long long len0 = opts->chain_len;
+    if (len0 == 0) len0 = opts->chain ? span0 : 1;
+    const bool cold_launch = len0 == 1 || span0 == 1;
+    if (cold_launch ? !p->lane_cold_ok : !p->lane_chain_ok) use_lane = false;
+  }
   if (opts->kernel == 4 && !use_lane)
     return fail(OKX_ERR_INVALID, "lane kernel requested but not available: %s", p->lane_note[0] ? p->lane_note : "predictor / trace in use");
   bool use_packed = false;

@@ -146,7 +146,7 @@ class LGen {
   std::string emit(const char* base, const std::string& expr) {
     if (expr.empty()) return "";
     std::string t = tmp(base);
-    f("    const double %s = %s;", t.c_str(), expr.c_str());
+    f("    double %s = %s;", t.c_str(), expr.c_str());
     return t;
   }
   S3 sub(const S3& a, const S3& b) {
@@ -690,6 +690,22 @@ class LGen {
   // live is the finished factor columns + the Schur complement in progress + the gradients still to be consumed.
   // Only the diagonal is accumulated at the rows (the first damping of a solve is scaled by its largest entry).
   bool pin_acc = true;  // opaque use of the touched accumulators after each row (keeps the contributions at the row)
+  // Homes of the rows' gradients between the rows and the factorisation.  A gradient component is written once where its
+  // row is and read back once per block column that multiplies it: up to j_lds_slots of them in LDS slots
+  // [j_lds_base + k][lane] (the independent-solve body has 40-odd slots to spare), the rest stay in registers.
+  int j_lds_base = 0, j_lds_slots = 0;
+  std::map<std::string, int> j_home;  // gradient component name -> LDS slot
+  void home_gradients(const std::vector<std::pair<int, S3>>& jv) {
+    for (auto& fv : jv)
+      for (int a = 0; a < 3; ++a) {
+        const std::string& nm = fv.second.c[a];
+        if (nm.empty() || nm == "1.0" || j_home.count(nm) || nm.compare(0, 2, "hs") == 0) continue;  // (constants have a home already)
+        if ((int)j_home.size() >= j_lds_slots) return;
+        const int slot = j_lds_base + (int)j_home.size();
+        j_home[nm] = slot;
+        f("    lds[%d + lane] = %s;", 64 * slot, nm.c_str());
+      }
+  }
   struct Prod { std::string a, b; int sg; };
   std::map<std::pair<int, int>, std::vector<Prod>> ata_terms;  // (i, j), i > j
   bool early_ata = false;  // parity kernel: additionally accumulate the whole lower triangle as E{i}_{j} at the rows
@@ -792,6 +808,7 @@ class LGen {
         }
       if (pin_acc)
         for (auto& an : touched) f("    asm volatile(\"\" : \"+v\"(%s));", an.c_str());
+      home_gradients(jv);
     }
     return true;
   }
@@ -820,17 +837,64 @@ class LGen {
   // whole factor through the AGPRs (measured: 912 moves for 1407 fp64 instructions in this block) and spills.
   // Leaves L{i}_{j} (parked or resident), dinv{j}, y{i}, ok, pmin, pmax.
   int col_fence = 3;     // scheduling barrier after every col_fence columns (keeps the late assembly late)
-  int resident_rows = 3; // the last rows of the factor stay in vector registers
+  // A HARD fence: an opaque, never-taken branch with a side effect ends the basic block, so neither instruction
+  // selection nor the machine scheduler (both work per block) can pull the next section's independent multiplications
+  // up into this one.  Measured on the double wishbone: rows alone 288 registers, factorisation alone 312, both in one
+  // block 590 (spilling) - the compiler starts assembling J^T J while the rows are still being evaluated.
+  bool hard_fence = false;
+  bool launder = true;
+  void fence() {
+    if (hard_fence) f("    { int fz = 0; asm volatile(\"\" : \"+s\"(fz)); if (fz) __builtin_trap(); }");
+    else f("    __builtin_amdgcn_sched_barrier(0);");
+  }
+  int resident_rows = 1 << 20; // rows of the factor (counted from the last) that are NOT parked in accumulation registers by hand: all of them
   std::set<std::pair<int, int>> parked;
+  // ... or in LDS, where the body has slots to spare: [l_lds_base + k][lane], first rows first (they wait longest)
+  int l_lds_base = 0, l_lds_slots = 0;
+  std::map<std::pair<int, int>, int> l_home;
   void emit_factor(const std::vector<std::string>& rhs) {
     const int n = 3 * P.n_free;
     symbolic();
     parked.clear();
+    l_home.clear();
     f("    // ---- damped normal equations: LDL^T + forward substitution, left-looking ----");
+    fence();
+    if (launder) {
+      // every value the factorisation takes over from the rows is redefined here (an empty asm, no instruction): nothing
+      // of the factorisation can be computed ahead of this point
+      std::set<std::string> seen;
+      for (auto& kv : ata_terms)
+        for (const Prod& t : kv.second)
+          for (const std::string* nm : {&t.a, &t.b})
+            if (!j_home.count(*nm) && nm->compare(0, 1, "_") == 0 && seen.insert(*nm).second)
+              f("    asm volatile(\"\" : \"+v\"(%s));", nm->c_str());
+      for (int i = 0; i < n; ++i) f("    asm volatile(\"\" : \"+v\"(%s), \"+v\"(%s));", gn(i).c_str(), A(i, i).c_str());
+    }
     f("    bool ok = true;");
     f("    double pmin = 1e300, pmax = 0.0;");
+    std::map<std::string, std::string> alias;  // gradient component -> its reloaded copy of the current block column
+    auto ref = [&](const std::string& nm) {
+      auto it = alias.find(nm);
+      return it == alias.end() ? nm : it->second;
+    };
     for (int j = 0; j < n; ++j) {
       f("    // column %d", j);
+      if (j % 3 == 0 && !j_home.empty()) {  // gradients of this block column's products come back from LDS
+        alias.clear();
+        for (int jj = j; jj < j + 3 && jj < n; ++jj)
+          for (int i = jj + 1; i < n; ++i) {
+            auto it = ata_terms.find({i, jj});
+            if (it == ata_terms.end()) continue;
+            for (const Prod& t : it->second)
+              for (const std::string* nm : {&t.a, &t.b}) {
+                auto h = j_home.find(*nm);
+                if (h == j_home.end() || alias.count(*nm)) continue;
+                const std::string cp = *nm + "_c" + std::to_string(j / 3);
+                f("    const double %s = lds[%d + lane + kz];", cp.c_str(), 64 * h->second);  // (opaque index: no store-to-load forwarding)
+                alias[*nm] = cp;
+              }
+          }
+      }
       std::vector<int> cols;  // k < j with L_jk structurally non-zero
       for (int k = 0; k < j; ++k)
         if (fill[j][k]) cols.push_back(k);
@@ -854,7 +918,7 @@ class LGen {
           auto it = ata_terms.find({i, j});
           if (it != ata_terms.end()) {
             std::vector<std::pair<std::string, std::string>> ap;
-            for (const Prod& t : it->second) ap.push_back({t.sg < 0 ? "(-" + t.a + ")" : t.a, t.b});
+            for (const Prod& t : it->second) ap.push_back({t.sg < 0 ? "(-" + ref(t.a) + ")" : ref(t.a), ref(t.b)});
             init = sum_expr(ap);
           }
         }
@@ -864,13 +928,21 @@ class LGen {
       f("    ok = ok && C%d_%d > 0.0;", j, j);
       f("    pmin = fmin(pmin, C%d_%d); pmax = fmax(pmax, C%d_%d);", j, j, j, j);
       f("    const double dinv%d = pivot_rcp(C%d_%d);", j, j, j);
+      for (int k : cols) {
+        if ((int)l_home.size() >= l_lds_slots) break;
+        const int slot = l_lds_base + (int)l_home.size();
+        l_home[{j, k}] = slot;
+        f("    lds[%d + lane] = %s;", 64 * slot, L(j, k).c_str());
+      }
       if (j < n - resident_rows)
         for (int k : cols) {
+          if (l_home.count({j, k})) continue;
           f("    int %s_lo, %s_hi; park(%s, %s_lo, %s_hi);", L(j, k).c_str(), L(j, k).c_str(), L(j, k).c_str(), L(j, k).c_str(), L(j, k).c_str());
           parked.insert({j, k});
         }
-      if (col_fence > 0 && (j + 1) % col_fence == 0 && j + 1 < n) f("    __builtin_amdgcn_sched_barrier(0);");
+      if (col_fence > 0 && (j + 1) % col_fence == 0 && j + 1 < n) fence();
     }
+    fence();
   }
 
   // D z = y, L^T x = z, row-oriented: x_j is final once every later row has been scattered; row j of L is read once.
@@ -881,7 +953,9 @@ class LGen {
     for (int j = n - 1; j >= 0; --j) {
       for (int k = 0; k < j; ++k) {
         if (!fill[j][k]) continue;
-        if (parked.count({j, k}))
+        if (l_home.count({j, k}))
+          f("    %s%d = fma(-lds[%d + lane + kz], %s%d, %s%d);", outn, k, 64 * l_home[{j, k}], outn, j, outn, k);
+        else if (parked.count({j, k}))
           f("    %s%d = fma(-unpark(%s_lo, %s_hi), %s%d, %s%d);", outn, k, L(j, k).c_str(), L(j, k).c_str(), outn, j, outn, k);
         else
           f("    %s%d = fma(-%s, %s%d, %s%d);", outn, k, L(j, k).c_str(), outn, j, outn, k);
@@ -989,33 +1063,60 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     return false;
   }
   const int nf = P.n_free, n = 3 * nf, NP = P.n_points, T = P.n_targets;
+  // The pass (rows, factorisation, backward substitution) is generated once per body: the independent-solve body has
+  // LDS slots to spare for the rows' gradients, the chain body has not.  `ev` is the chain body's generator (no LDS
+  // homes) and the owner of the chain constants; `evc` the independent-solve body's.
+  const int kColdStateSlots = 2 * n;                               // x, dx
+  int cold_j_slots = (40 * 1024 - 1024) / 512 - kColdStateSlots;   // what is left of 40 KiB per wavefront, less the constants' table
+  if (cold_j_slots < 0) cold_j_slots = 0;
+  if (const char* env = getenv("OKX_LANE_J_SLOTS")) cold_j_slots = atoi(env);
+  struct PassSrc { std::string eval, factor, subst; };
+  auto make_pass = [&](LGen& gen, PassSrc* out) -> bool {
+    gen.pin_acc = getenv("OKX_LANE_NO_PIN") == nullptr;  // (experiment switch)
+    gen.hard_fence = getenv("OKX_LANE_HARD_FENCE") != nullptr;
+    gen.launder = getenv("OKX_LANE_NO_LAUNDER") == nullptr;
+    if (const char* env = getenv("OKX_LANE_COL_FENCE")) gen.col_fence = atoi(env);
+    if (const char* env = getenv("OKX_LANE_RESIDENT_ROWS")) gen.resident_rows = atoi(env);
+    for (int e = 0; e < P.n_derived; ++e) gen.dp(e);
+    gen.f("    // ---- active derived points with chain-rule blocks ----");
+    for (int idx = 0; idx < P.n_active; ++idx)
+      if (!gen.derived_op(P.active_op[idx], true)) return false;
+    if (!gen.emit_rows()) return false;
+    out->eval = gen.out;
+    gen.out.clear();
+    std::vector<std::string> rhs;
+    for (int i = 0; i < n; ++i) rhs.push_back("-" + LGen::gn(i));
+    gen.emit_factor(rhs);
+    out->factor = gen.out;
+    gen.out.clear();
+    gen.emit_backward("nx");
+    out->subst = gen.out;
+    gen.out.clear();
+    return true;
+  };
   LGen ev(P);
-  ev.pin_acc = getenv("OKX_LANE_NO_PIN") == nullptr;  // (experiment switch)
-  for (int e = 0; e < P.n_derived; ++e) ev.dp(e);
-  ev.f("    // ---- active derived points with chain-rule blocks ----");
-  for (int idx = 0; idx < P.n_active; ++idx)
-    if (!ev.derived_op(P.active_op[idx], true)) {
-      *why = ev.why;
-      return false;
-    }
-  if (!ev.emit_rows()) {
+  PassSrc pass_chain, pass_cold;
+  if (!make_pass(ev, &pass_chain)) {
     *why = ev.why;
     return false;
   }
-  const std::string eval_src = ev.out;
-  ev.out.clear();
-  if (const char* env = getenv("OKX_LANE_COL_FENCE")) ev.col_fence = atoi(env);
-  if (const char* env = getenv("OKX_LANE_RESIDENT_ROWS")) ev.resident_rows = atoi(env);
-  {
-    std::vector<std::string> rhs;
-    for (int i = 0; i < n; ++i) rhs.push_back("-" + LGen::gn(i));
-    ev.emit_factor(rhs);
+  LGen evc(P);
+  evc.hoisted_names = ev.hoisted_names;
+  // Measured on the double wishbone (scratch bytes of okx_lane_solve_u): the spare slots given to the factor's rows
+  // 104 B, to the rows' gradients 432 B, hand-parked AGPR rows on top of either 250 - 1000 B (the allocator needs the
+  // accumulation registers for its own spilling).  So: the factor's first rows in LDS, nothing parked by hand.
+  int cold_l_slots = cold_j_slots;
+  if (const char* env = getenv("OKX_LANE_L_SLOTS")) cold_l_slots = atoi(env);
+  if (cold_l_slots > cold_j_slots) cold_l_slots = cold_j_slots;
+  cold_j_slots -= cold_l_slots;
+  evc.j_lds_base = kColdStateSlots;
+  evc.j_lds_slots = cold_j_slots;
+  evc.l_lds_base = kColdStateSlots + cold_j_slots;
+  evc.l_lds_slots = cold_l_slots;
+  if (!make_pass(evc, &pass_cold) || !evc.hoisted.empty()) {
+    *why = evc.why.empty() ? "pass generation is not reproducible" : evc.why;
+    return false;
   }
-  const std::string factor_src = ev.out;
-  ev.out.clear();
-  ev.emit_backward("nx");
-  const std::string subst_src = ev.out;
-  ev.out.clear();
 
   // confirming evaluation (residuals only); not for programs with the reference's zero-gradient point-on-line row
   bool light_ok = true;
@@ -1096,6 +1197,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
       if (ch) state_decl += " " + slot_ref("xp" + std::to_string(i)) + " " + slot_ref("xq" + std::to_string(i));
       state_decl += "\n";
     }
+    if (!ch) n_slots = evc.l_lds_base + evc.l_lds_slots > n_slots + (int)evc.j_home.size() ? evc.l_lds_base + evc.l_lds_slots : n_slots + (int)evc.j_home.size();  // + the rows' gradients / the factor's first rows
     const int state_doubles = 64 * n_slots;
     const int stage_doubles = ch ? 0 : 64 * 3 * P.n_out;
     const int lds_doubles = state_doubles > stage_doubles ? state_doubles : stage_doubles;
@@ -1264,7 +1366,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     }
     mark(1);
     for (int i = 0; i < n; ++i) g.f("    %s = mode == 2 ? x%d : x%d + dx%d;", PF(i).c_str(), i, i, i);
-    g.out += eval_src;
+    g.out += (ch ? pass_chain : pass_cold).eval;
     mark(2);
     g.f("    const double Ft = 0.5 * ss;");
     g.f("    bool accept = true, stop = false;");
@@ -1314,9 +1416,9 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     g.f("    if (!done && !accept) mode = 2;");
     g.f("    if (wave_any(solve_now)) {");
     mark(3);
-    g.out += factor_src;
+    g.out += (ch ? pass_chain : pass_cold).factor;
     mark(4);
-    g.out += subst_src;
+    g.out += (ch ? pass_chain : pass_cold).subst;
     mark(5);
     g.f("    double sl = 0.0, pr = 0.0;");
     for (int i = 0; i < n; ++i) g.f("    sl = fmax(sl, fabs(nx%d));", i);

@@ -1,0 +1,71 @@
+"""
+The lane kernel (one lane per problem, okx_lanegen.cpp), CPU side: source generation from a constraint program and the
+decisions about which programs get one.  (Compilation into the cache is part of __graft_entry__.build().)
+"""
+
+import ctypes as C
+
+import pytest
+
+from open_kinematics_amd import _abi, _lib
+
+
+def _lane_source(program) -> str:
+    lib = _lib.load()
+    host = _abi.HostProgram(program)
+    size = lib.okx_lane_source(host.byref(), None, 0)
+    if size < 0:
+        raise ValueError(_lib.last_error())
+    buf = C.create_string_buffer(size)
+    assert lib.okx_lane_source(host.byref(), buf, size) == size
+    return buf.value.decode()
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid", "u_dw_corner", "u_macpherson", "rows_all_classes"])
+@pytest.mark.parametrize("mode", ["pinned", "softnorm"])
+def test_lane_source_is_generated_for_corner_topologies(golden, name, mode):
+    _, program = golden(name)
+    p = program.with_line_mode(mode)
+    src = _lane_source(p)
+    for kernel in ("okx_lane_solve_u", "okx_lane_solve_g", "okx_lane_chain_u", "okx_lane_chain_g", "okx_lane_eval"):
+        assert f"void __launch_bounds__(64, 1) {kernel}(" in src
+    n = p.n_vars
+    # one residual per row; the diagonal of J^T J is accumulated at the rows, every other entry is assembled when its
+    # column is eliminated (left-looking LDL^T); one pivot per unknown
+    for i in range(p.n_residuals):
+        assert f"const double r{i} =" in src
+    for i in range(n):
+        assert f"A{i}_{i} = 0.0" in src and f"const double dinv{i} = pivot_rcp(C{i}_{i});" in src
+    assert "__builtin_amdgcn_mov_dpp" not in src and "ds_swizzle" not in src  # no cross-lane operand anywhere
+    # chain constants are read from the LDS table where they are used
+    assert "#define hs0_0 cl[" in src and "+ kz]" in src
+    # structure only: no geometry value is baked into the text
+    assert "471.69" not in src and "559.01" not in src and "410.0" not in src
+
+
+def test_lane_kernel_shares_the_quad_kernels_elimination_order(golden):
+    """The first-step tables come from okx_quad_head_*: both generators must number the free blocks alike."""
+    import re
+
+    _, program = golden("c1_dw_corner")
+    p = program.with_line_mode("pinned")
+    lane = _lane_source(p)
+    lib = _lib.load()
+    host = _abi.HostProgram(p)
+    size = lib.okx_quad_source(host.byref(), None, 0)
+    buf = C.create_string_buffer(size)
+    lib.okx_quad_source(host.byref(), buf, size)
+    quad = buf.value.decode()
+    # quad: `double x{F} = p{point}` per block; lane: `x{3F} = p{point}_0`
+    quad_order = [int(m) for m in re.findall(r"double x\d+ = p(\d+), xp\d+", quad)]
+    lane_order = [int(m) for m in re.findall(r"\bx\d+ = p(\d+)_0; dx\d+ = 0\.0;", lane)]
+    assert quad_order and quad_order == lane_order[: len(quad_order)]
+
+
+def test_programs_beyond_six_free_points_have_no_lane_kernel(golden):
+    _, program = golden("c3_axle_grid")  # 20 free points (pair mode in the quad kernel)
+    lib = _lib.load()
+    host = _abi.HostProgram(program.with_line_mode("pinned"))
+    assert lib.okx_lane_source(host.byref(), None, 0) == -2  # OKX_ERR_LIMIT
+    assert "free points" in _lib.last_error()
+    assert lib.okx_precompile(host.byref()) == 0  # the quad kernel alone is precompiled then

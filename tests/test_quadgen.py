@@ -107,13 +107,14 @@ def test_precompile_fills_the_cache_without_a_device(golden, tmp_path, monkeypat
     lib = _lib.load()
     host = _abi.HostProgram(program.with_line_mode("pinned"))
     assert lib.okx_precompile(host.byref()) == 0, _lib.last_error()
-    files = [f for f in os.listdir(tmp_path) if f.endswith(".okxc")]
-    assert len(files) == 1
-    blob = (tmp_path / files[0]).read_bytes()
-    assert blob[:6] == b"OKXCK1" and blob[24:28] == b"\x7fELF" and b"okx_quad_solve_u" in blob
-    stamp = os.path.getmtime(tmp_path / files[0])
+    files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".okxc"))
+    assert len(files) == 2  # the quad kernel's code object and the lane kernel's
+    blobs = [(tmp_path / f).read_bytes() for f in files]
+    assert all(b[:6] == b"OKXCK1" and b[24:28] == b"\x7fELF" for b in blobs)
+    assert sum(b"okx_quad_solve_u" in b for b in blobs) == 1 and sum(b"okx_lane_solve_u" in b for b in blobs) == 1
+    stamps = [os.path.getmtime(tmp_path / f) for f in files]
     assert lib.okx_precompile(host.byref()) == 0  # second call is a cache hit
-    assert os.path.getmtime(tmp_path / files[0]) == stamp
+    assert [os.path.getmtime(tmp_path / f) for f in files] == stamps
 
 
 def test_header_documents_the_kernel_choice():
