@@ -49,7 +49,7 @@ import torch.distributed as dist
 STEPS_PER_RANK = 16384
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor fp64 vector peak, secondary ceiling
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 INFO_FIELDS = np.dtype([("max_residual", "<f8"), ("cost", "<f8"), ("last_step", "<f8"), ("iterations", "<i4"),
                         ("nfev", "<i4"), ("flags", "<i4"), ("reserved", "<i4")])
 
@@ -273,6 +273,49 @@ def measure_with_model(program, targets, device, steps: int, warmup: int) -> dic
     }
 
 
+def measure_one_shot(program, targets, device, steady_kernel_ms: float) -> dict:
+    """What a caller who makes ONE call observes on a fresh program, and what the shared first step costs.  The table of
+    the program's own geometry for the default damping is part of okx_program_create (one wavefront, synchronous), so the
+    first launch is a plain solve; a launch with another lambda0 fills a new table on its stream first (head_ms)."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    n = targets.shape[0]
+    out = torch.empty((n, program.n_out, 3), dtype=torch.float64, device=device)
+    info = torch.empty((n, 40), dtype=torch.uint8, device=device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    dp = DeviceProgram(program, device)   # code objects come from the in-tree cache; includes the own-geometry table
+    torch.cuda.synchronize(device)
+    create_ms = (time.perf_counter() - t0) * 1e3
+
+    def timed_once(**kw):
+        launch = dp.plan(targets, out=out, info_out=info, chain_len=-1, predictor=False, **kw)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for e in ev:   # first record() of an event creates it: not inside the measurement
+            e.record()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        ev[0].record()
+        launch()
+        ev[1].record()
+        torch.cuda.synchronize(device)
+        return ev[0].elapsed_time(ev[1]), (time.perf_counter() - t1) * 1e3
+
+    first_gpu_ms, first_wall_ms = timed_once()                      # the fresh program's first launch (lazy code-object load included)
+    second_gpu_ms, _ = timed_once()                                 # ... and its second
+    other_gpu_ms, _ = timed_once(lambda0=1.0000001e-6)              # a damping without a table yet: head kernel + solve
+    nfev, ok = info_summary(info)
+    dp.close()
+    return {"program_create_ms": create_ms, "first_launch_gpu_ms": first_gpu_ms, "first_launch_wall_ms": first_wall_ms,
+            "second_launch_gpu_ms": second_gpu_ms, "head_ms": max(0.0, other_gpu_ms - second_gpu_ms),
+            "launch_with_new_lambda0_gpu_ms": other_gpu_ms, "value_first_launch": n / (first_gpu_ms * 1e-3),
+            "all_converged": ok,
+            "note": "fresh DeviceProgram (kernels from the in-tree cache): create (upload, module load, own-geometry first-step "
+                    "table for the default lambda0: synchronous, part of set-up), then single launches timed with one HIP-event "
+                    "pair each; head_ms = what a launch pays when its lambda0 has no table yet (okx_quad_head_u on the launch "
+                    "stream) over the steady launch; the headline's kernel_ms is %.4f" % steady_kernel_ms}
+
+
 def measure_pipelined(dp, targets, device, steps: int, n_streams: int = 3) -> dict:
     """The same cold sweeps issued round-robin over a few streams (own output buffers): a launch no longer waits for its
     predecessor to drain, so the ~3.5 us dispatch gap and the prologue's memory round trip hide behind the previous
@@ -383,6 +426,16 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
     out = torch.empty((n, program.n_out, 3), dtype=torch.float64, device=device)
     info = torch.empty((n, 40), dtype=torch.uint8, device=device)
     bytes_per = algorithmic_bytes_per_solve(program, spg)
+    lane_from = dp.lane_threshold
+    lane_bodies = dp.lane_bodies if lane_from > 0 else 0
+
+    def kernel_of(cold: bool) -> str:
+        if dp.kernel != "quad":
+            return f"{dp.kernel} ({dp.kernel_note})"
+        if lane_from > 0 and n >= lane_from and (lane_bodies & (1 if cold else 2)):
+            return "lane (one lane per problem, 64 per wavefront)"
+        return "quad (four lanes per problem)" + (f"; lane kernel: {dp.lane_note}" if dp.lane_note else "")
+
     res = {"workload": name, "problems": n, "n_vars": program.n_vars, "n_residual_rows": program.n_residuals,
            "kernel": dp.kernel + ("" if dp.kernel == "quad" else f" ({dp.kernel_note})"),
            "algorithmic_bytes_per_solve": bytes_per, "setup_ms": setup_ms}
@@ -396,7 +449,12 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
         nfev, ok = info_summary(info)
         gbs = bytes_per * n / (kernel_ms * 1e-3) / 1e9
         res[tag] = {"value": n / wall, "kernel_ms": kernel_ms, "lm_evaluations_mean": nfev, "all_converged": ok,
-                    "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+                    "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "kernel": kernel_of(chain_len == 1)}
+        if dp.kernel == "quad" and "lane" in res[tag]["kernel"]:
+            # the quad kernel on the same launch, for the record (what round 2 measured)
+            q_launch = dp.plan(targets, out=out, info_out=info, chain_len=chain_len, predictor=False, kernel="quad", **kw)
+            q_wall, q_ms = time_launches(q_launch, steps, warmup, device)
+            res[tag]["quad_kernel"] = {"value": n / q_wall, "kernel_ms": q_ms, "lm_evaluations_mean": info_summary(info)[0]}
     if "cold" in res:
         res["cold"]["start"] = "every problem an independent cold start from its geometry's design state (SURVEY.md section 8d)"
     if "chained" in res:
@@ -494,24 +552,50 @@ def main() -> None:
                     help="design: cold starts from the design state (section 8d, the headline); model: the fitted chain-head model "
                          "(profiling runs of the predictor path; never the default)")
     ap.add_argument("--chain-len", type=int, default=-1, help="-1 auto (16384 steps fit the chip: independent solves), 1 = independent")
+    ap.add_argument("--rccl-world-one", action="store_true",
+                    help="one rank, but with an RCCL process group and the all-gather in the step: what a one-GPU box can "
+                         "rehearse of the N > 1 path (communicator, stream ordering of the pipeline, expand of the gathered block)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher plumbing only: start the ranks, have rank 0 print a line, touch no GPU (CPU test)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 rehearsal on a one-GPU box: every rank uses cuda:0 and the exchange runs over gloo "
                          "(exercises the sharding / pipeline / rebuild logic, not RCCL; the numbers mean nothing)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as children, BEFORE anything here
+        # has touched the GPU (a process that has initialised HIP must never exec / re-exec), hand their output
+        # through (rank 0 prints the JSON line) and leave with the launcher's return code.
+        sys.exit(self_launch(args.gpus, sys.argv[1:], dry=args.dry_launch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.dry_launch:
+        # launcher plumbing only (a CPU test drives this): no GPU, no process group
+        if rank == 0:
+            print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": world,
+                              "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the solve path)")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.rccl_world_one:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                free_port = sock.getsockname()[1]
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -522,9 +606,26 @@ def main() -> None:
         line = run_c2(args, world, rank, device)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.rccl_world_one:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n_ranks: int, argv: list, dry: bool = False) -> int:
+    """Run this script under `python -m torch.distributed.run` with one rank per GPU of this node (rendezvous on
+    127.0.0.1, a free port) and return the launcher's exit code.  The ranks inherit stdout / stderr."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if dry:
+        env["HIP_VISIBLE_DEVICES"] = ""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_launch_events: bool):
@@ -580,7 +681,8 @@ def run_c2(args, world: int, rank: int, device) -> dict:
     # Two output slots: with N > 1 ranks the all-gather of step k (RCCL stream) overlaps the solve of step k + 1
     # (launch stream), dist.GatherPipeline.  The exchange ships the free coordinates of each solve (144 B) and every
     # rank rebuilds the full positions (360 B) itself (dist.FreeGatherPipeline / okx_expand_positions_batch).
-    pipe = FreeGatherPipeline(hi - lo, program.n_out, dp.free_out_index, dp.expand, torch.float64, device)
+    pipe = FreeGatherPipeline(hi - lo, program.n_out, dp.free_out_index, dp.expand, torch.float64, device,
+                              collective_at_world_one=args.rccl_world_one)
     use_model = args.start == "model" and bool(dp.fit_predictor(targets))
     cold_kw = dict(chain_len=args.chain_len, predictor=use_model)
     # pre-bound launches: per step the host only makes the C-ABI call
@@ -598,14 +700,20 @@ def run_c2(args, world: int, rank: int, device) -> dict:
     # One rank: a single event pair brackets the K back-to-back launches (average = elapsed / K, launch gaps included;
     # per-launch pairs would add two stream markers per ~30 us kernel).  Several ranks: per-launch pairs, so the
     # exchange between launches is excluded from the kernel time.
-    elapsed, kernel_ms = timed_region(step, pipe.drain, args.steps, args.warmup, world, device, per_launch_events=world > 1)
+    exchanging = world > 1 or args.rccl_world_one
+    elapsed, kernel_ms = timed_region(step, pipe.drain, args.steps, args.warmup, world, device, per_launch_events=exchanging)
+    if args.rccl_world_one:
+        # the gathered + expanded block of the last step must be the locally solved one, bit for bit
+        gathered = pipe.drain()
+        if not torch.equal(gathered, pipe.local[pipe.last]):
+            raise SystemExit("rccl-world-one: the gathered and re-expanded positions differ from the solved ones")
     nfev_mean, ok = info_summary(info)
     if rank != 0:
         return {}
 
     stats = plan_stats(program)
     bytes_per_solve = algorithmic_bytes_per_solve(program)
-    default_run = world == 1 and args.chain_len == -1 and dp.kernel == "quad"
+    default_run = world == 1 and args.chain_len == -1 and dp.kernel == "quad" and not args.rccl_world_one
     traffic, traffic_src = committed_traffic("bench_c2_cold" if not use_model else "bench_c2_model") if default_run else (None, None)
     achieved_gbs = bytes_per_solve * (hi - lo) / (kernel_ms * 1e-3) / 1e9
     flops = estimated_flops_per_evaluation(program, stats) * nfev_mean * (hi - lo)
@@ -648,7 +756,7 @@ def run_c2(args, world: int, rank: int, device) -> dict:
                          "them), overlapped with the next step's solve (two output slots); %d B per rank per step instead of "
                          "%d B of positions; every rank receives %d B per step (DESIGN.md section 8)"
                          % (free_bytes, STEPS_PER_RANK * program.n_out * 24, (world - 1) * free_bytes))
-                        if world > 1 else "none",
+                        if exchanging else "none",
         },
         "roofline": {
             "bound": "hbm",
@@ -682,7 +790,7 @@ def run_c2(args, world: int, rank: int, device) -> dict:
             "useful_frac": 0.75 * hw / FP64_VECTOR_PEAK_TFLOPS, "source": counted_src, "measured_in_this_run": False,
             "note": "SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 of the committed PMC pass x 64 lanes over this run's kernel time; one lane in "
                     "four carries zeros in the quad layout (useful_frac = 3/4)"}
-    if world > 1:
+    if exchanging:
         line["solve_only"] = {
             "value": n_total / (kernel_ms * 1e-3),
             "kernel_ms_max_over_ranks": kernel_ms,
@@ -691,7 +799,13 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         }
         line["exchange"] = {"bytes_sent_per_rank_per_step": free_bytes, "bytes_received_per_rank_per_step": (world - 1) * free_bytes,
                             "collective": "all_gather_into_tensor (RCCL)" if not args.rehearse_on_one_gpu else "gloo (rehearsal)"}
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.rccl_world_one:
+        # Sustained figure: a few thousand back-to-back launches (the 20-step driver run times 0.6 ms of GPU work).
+        sus_wall, sus_ms = time_launches(launches[0], 2000, 10, device)
+        line["sustained"] = {"value": (hi - lo) / sus_wall, "kernel_ms": sus_ms, "launches": 2000,
+                             "note": "the same launch 2000 times back to back on one stream, one HIP-event pair around them"}
+        line["one_shot"] = measure_one_shot(program, targets, device, kernel_ms)
+    if world == 1 and not args.no_extras and not args.rccl_world_one:
         extra_steps = max(5, min(args.steps, 50))
         own = dp.plan(targets, out=pipe.local[0], info_out=info, chain_len=args.chain_len, predictor=False, shared_first_step=False)
         own_wall, own_ms = time_launches(own, args.steps, args.warmup, device)

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,8 +52,12 @@ struct okx_program {
   // shared first step of the chain heads (okx_quad_head_u/_g; null functions: not generated for this program)
   hipFunction_t quad_fn_head_u, quad_fn_head_g;
   int head_stride;          // doubles per geometry in the table (okx::quad_head_stride)
-  double* head_dev;         // own geometry's table, filled on first use per lambda0
-  double head_lambda0;      // the lambda0 it was computed for (NaN: not yet)
+  // own geometry's tables, one per lambda0 ever asked for (never overwritten: launches on other streams may still be
+  // reading an older one); the default lambda0's is filled synchronously at okx_program_create, any other on first use on
+  // the caller's stream, with an event that launches on other streams wait for
+  struct HeadTable { double lambda0; double* dev; hipEvent_t ready; hipStream_t filled_on; };
+  std::vector<HeadTable>* head_tables;
+  std::mutex* head_mutex;
   double* head_geom_dev;    // scratch table of the latest launch with geometry tables (grow-only)
   long long head_geom_cap;  // geometries it holds
   double* quad_trace;            // diagnostic hook, see okx_debug_quad_trace (null: off)
@@ -185,6 +190,48 @@ int quad_waves_per_simd() {
   return 1;
 }
 
+// The first-step table of the program's own geometry for `lambda0`: found, or filled by one wavefront of okx_quad_head_u
+// on `stream` (a new buffer per lambda0: an older table may still be read by launches in flight).  A launch on another
+// stream than the one that filled the table waits for the fill's event.
+int own_head_table(okx_program* p, double lambda0, hipStream_t stream, double** table) {
+  std::lock_guard<std::mutex> lock(*p->head_mutex);
+  for (okx_program::HeadTable& t : *p->head_tables)
+    if (t.lambda0 == lambda0) {
+      if (t.filled_on != stream) HIP_TRY(hipStreamWaitEvent(stream, t.ready, 0));
+      *table = t.dev;
+      return OKX_OK;
+    }
+  okx_program::HeadTable t;
+  t.lambda0 = lambda0;
+  t.filled_on = stream;
+  HIP_TRY(hipMalloc((void**)&t.dev, sizeof(double) * (size_t)p->head_stride));
+  if (hipEventCreateWithFlags(&t.ready, hipEventDisableTiming) != hipSuccess) {
+    (void)hipFree(t.dev);
+    return fail(OKX_ERR_DEVICE, "hipEventCreate failed");
+  }
+  okx::QuadHeadArgs h;
+  h.geom_pos = nullptr;
+  h.geom_row_param = nullptr;
+  h.head = t.dev;
+  h.n_geometries = 1;
+  h.lambda0 = lambda0;
+  const char* base = reinterpret_cast<const char*>(p->dev);
+  h.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
+  h.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
+  h.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
+  void* hargs[] = {(void*)&h};
+  hipError_t e = hipModuleLaunchKernel(p->quad_fn_head_u, 1, 1, 1, okx::kWave, 1, 1, 0, stream, hargs, nullptr);
+  if (e == hipSuccess) e = hipEventRecord(t.ready, stream);
+  if (e != hipSuccess) {
+    (void)hipEventDestroy(t.ready);
+    (void)hipFree(t.dev);
+    return fail(OKX_ERR_DEVICE, "first-step table: %s", hipGetErrorString(e));
+  }
+  p->head_tables->push_back(t);
+  *table = t.dev;
+  return OKX_OK;
+}
+
 // Generate, compile (or fetch from the cache) and load the kernel specialised to this program.
 // Failure is not an error of okx_program_create: the generic kernels stay in charge and
 // okx_program_kernel_note() says why.
@@ -249,16 +296,24 @@ void attach_quad_kernel(okx_program* p) {
       hipModuleGetFunction(&p->quad_fn_tan_g, mod, "okx_quad_tangent_g") != hipSuccess)
     p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
   p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
-  p->head_dev = nullptr;
-  p->head_lambda0 = std::nan("");
   p->head_stride = okx::quad_head_stride(p->host);
-  if (p->head_stride > 0 && hipModuleGetFunction(&p->quad_fn_head_u, mod, "okx_quad_head_u") == hipSuccess &&
-      hipModuleGetFunction(&p->quad_fn_head_g, mod, "okx_quad_head_g") == hipSuccess) {
-    if (hipMalloc((void**)&p->head_dev, sizeof(double) * (size_t)p->head_stride) != hipSuccess) p->head_dev = nullptr;
-  }
-  if (!p->head_dev) p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
+  if (!(p->head_stride > 0 && hipModuleGetFunction(&p->quad_fn_head_u, mod, "okx_quad_head_u") == hipSuccess &&
+        hipModuleGetFunction(&p->quad_fn_head_g, mod, "okx_quad_head_g") == hipSuccess))
+    p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
   (void)hipGetLastError();  // optional kernels absent from a module must not leave a sticky error behind
   p->quad_waves_per_cu = 4 * per_simd;
+  // The first-step table of the program's own geometry for the default damping belongs to the program's set-up, like the
+  // kernel itself: filled here, synchronously (one wavefront, ~10 us), so that no solve launch ever pays for it or has to
+  // order itself against it.
+  if (p->quad_fn_head_u) {
+    okx_solve_opts o;
+    okx_default_opts(&o);
+    double* unused = nullptr;
+    if (own_head_table(p, o.lambda0, nullptr, &unused) != OKX_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+      (void)hipGetLastError();
+      p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
+    }
+  }
 }
 
 // The lane kernel of a program that has a quad kernel (same policy: failure only means the quad kernel serves every
@@ -329,6 +384,20 @@ void attach_lane_kernel(okx_program* p) {
   p->lane_mod = mod;
 }
 
+// frees the first-step tables and the host-side containers (every exit path of okx_program_create / _destroy)
+void release_host_side(okx_program* p) {
+  if (p->head_tables) {
+    for (okx_program::HeadTable& t : *p->head_tables) {
+      (void)hipEventDestroy(t.ready);
+      (void)hipFree(t.dev);
+    }
+    delete p->head_tables;
+    p->head_tables = nullptr;
+  }
+  delete p->head_mutex;
+  p->head_mutex = nullptr;
+}
+
 int grid_for(const okx_program* p, long long units) {
   long long cap = (long long)p->n_cu * p->blocks_per_cu;
   if (cap < 1) cap = 1;
@@ -372,8 +441,17 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   okx_program* p = new (std::nothrow) okx_program;
   if (!p) return fail(OKX_ERR_ALLOC, "out of host memory");
   std::memset(p, 0, sizeof(*p));
+  p->head_tables = new (std::nothrow) std::vector<okx_program::HeadTable>();
+  p->head_mutex = new (std::nothrow) std::mutex();
+  if (!p->head_tables || !p->head_mutex) {
+    delete p->head_tables;
+    delete p->head_mutex;
+    delete p;
+    return fail(OKX_ERR_ALLOC, "out of host memory");
+  }
   int rc = okx::build_dev_program(desc, &p->host, g_err, (int)sizeof(g_err));
   if (rc != OKX_OK) {
+    release_host_side(p);
     delete p;
     return rc;
   }
@@ -385,29 +463,34 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   if (p->packed_lds_bytes > 160 * 1024) p->packed_fn = nullptr;
   if (p->lds_bytes > 160 * 1024) {
     const size_t need = p->lds_bytes;
+    release_host_side(p);
     delete p;
     return fail(OKX_ERR_LIMIT, "problem needs %zu bytes of LDS (max 163840)", need);
   }
   hipError_t e = hipGetDevice(&p->device);
   if (e != hipSuccess) {
+    release_host_side(p);
     delete p;
     return fail(OKX_ERR_DEVICE, "hipGetDevice failed: %s (no GPU?)", hipGetErrorString(e));
   }
   hipDeviceProp_t prop;
   e = hipGetDeviceProperties(&prop, p->device);
   if (e != hipSuccess) {
+    release_host_side(p);
     delete p;
     return fail(OKX_ERR_DEVICE, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
   }
   p->n_cu = prop.multiProcessorCount;
   e = hipMalloc((void**)&p->dev, sizeof(okx::DevProgram));
   if (e != hipSuccess) {
+    release_host_side(p);
     delete p;
     return fail(OKX_ERR_DEVICE, "hipMalloc failed: %s", hipGetErrorString(e));
   }
   e = hipMemcpy(p->dev, &p->host, sizeof(okx::DevProgram), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     (void)hipFree(p->dev);
+    release_host_side(p);
     delete p;
     return fail(OKX_ERR_DEVICE, "hipMemcpy failed: %s", hipGetErrorString(e));
   }
@@ -420,7 +503,9 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
     if (e != hipSuccess) {
       (void)hipFree(p->dev);
-      delete p;
+      release_host_side(p);
+      release_host_side(p);
+    delete p;
       return fail(OKX_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
     }
   }
@@ -437,7 +522,7 @@ void okx_program_destroy(okx_program* p) {
   if (p->quad_mod) (void)hipModuleUnload(p->quad_mod);
   if (p->lane_mod) (void)hipModuleUnload(p->lane_mod);
   if (p->predictor_dev) (void)hipFree(p->predictor_dev);
-  if (p->head_dev) (void)hipFree(p->head_dev);
+  release_host_side(p);
   if (p->head_geom_dev) (void)hipFree(p->head_geom_dev);
   if (p->dev) (void)hipFree(p->dev);
   delete p;
@@ -662,27 +747,24 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
       h.dop_param = q.dop_param;
       void* hargs[] = {(void*)&h};
       if (!d_geom_pos) {
-        if (!(p->head_lambda0 == opts->lambda0)) {  // own geometry: once per lambda0, then cached
-          h.head = p->head_dev;
-          h.n_geometries = 1;
-          HIP_TRY(hipModuleLaunchKernel(p->quad_fn_head_u, 1, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, hargs, nullptr));
-          p->head_lambda0 = opts->lambda0;
-        }
-        q.head = p->head_dev;
+        double* table = nullptr;  // own geometry: once per lambda0 (the default's at program creation), then cached
+        const int rc = own_head_table(p, opts->lambda0, (hipStream_t)stream, &table);
+        if (rc != OKX_OK) return rc;
+        q.head = table;
       } else if (spg >= 4 && (n_problems / spg) * (long long)p->head_stride * 8 <= (256LL << 20)) {
         // (one table row costs about 1.3 passes of one quad: with fewer than four steps per geometry, or a table beyond
         //  256 MiB, the heads run their own first pass)
         const long long n_geom = n_problems / spg;
         if (n_geom > p->head_geom_cap) {
-          // grow-only scratch; earlier launches may still read the old table
+          // grow-only scratch, replaced in stream order: launches of this program with geometry tables are stream-ordered
+          // (okx.h), so the old table's readers are ahead of the free on this stream - no device-wide synchronisation
           if (p->head_geom_dev) {
-            HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(p->head_geom_dev);
+            HIP_TRY(hipFreeAsync(p->head_geom_dev, (hipStream_t)stream));
             p->head_geom_dev = nullptr;
             p->head_geom_cap = 0;
           }
           const size_t bytes = sizeof(double) * (size_t)n_geom * (size_t)p->head_stride;
-          HIP_TRY(hipMalloc((void**)&p->head_geom_dev, bytes));
+          HIP_TRY(hipMallocAsync((void**)&p->head_geom_dev, bytes, (hipStream_t)stream));
           p->head_geom_cap = n_geom;
         }
         h.head = p->head_geom_dev;

@@ -68,13 +68,17 @@ class GatherPipeline:
         full = pipe.drain()            # gathered positions of the last step, all exchanges complete
     """
 
-    def __init__(self, rows_per_rank: int, tail_shape, dtype, device, group=None, depth: int = 2):
+    def __init__(self, rows_per_rank: int, tail_shape, dtype, device, group=None, depth: int = 2,
+                 collective_at_world_one: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # one rank with an initialised process group can still run the collective (a one-GPU box rehearsing the RCCL
+        # path: communicator set-up, stream ordering of the pipeline, the expand on the gathered buffer)
+        self.exchange = self.world > 1 or (collective_at_world_one and dist.is_available() and dist.is_initialized())
         self.depth = depth
         self.local = [torch.empty((rows_per_rank, *tail_shape), dtype=dtype, device=device) for _ in range(depth)]
         self.full = [torch.empty((rows_per_rank * self.world, *tail_shape), dtype=dtype, device=device)
-                     if self.world > 1 else None for _ in range(depth)]
+                     if self.exchange else None for _ in range(depth)]
         self.work = [None] * depth
         self.last = -1
 
@@ -88,7 +92,7 @@ class GatherPipeline:
     def submit(self, k: int) -> None:
         slot = k % self.depth
         self.last = slot
-        if self.world > 1:
+        if self.exchange:
             self.work[slot] = dist.all_gather_into_tensor(self.full[slot], self.local[slot], group=self.group,
                                                           async_op=True)
 
@@ -99,7 +103,7 @@ class GatherPipeline:
                 self.work[slot] = None
         if self.last < 0:
             raise RuntimeError("nothing was submitted")
-        return self.local[self.last] if self.world == 1 else self.full[self.last]
+        return self.full[self.last] if self.exchange else self.local[self.last]
 
 
 class FreeGatherPipeline(GatherPipeline):
@@ -117,14 +121,14 @@ class FreeGatherPipeline(GatherPipeline):
     """
 
     def __init__(self, rows_per_rank: int, n_out: int, free_out_index: torch.Tensor, expand, dtype, device, group=None,
-                 depth: int = 2):
-        super().__init__(rows_per_rank, (n_out, 3), dtype, device, group, depth)
+                 depth: int = 2, collective_at_world_one: bool = False):
+        super().__init__(rows_per_rank, (n_out, 3), dtype, device, group, depth, collective_at_world_one)
         self.free_out_index = free_out_index
         self.expand = expand
         n_free = int(free_out_index.numel())
         self.free_local = [torch.empty((rows_per_rank, n_free, 3), dtype=dtype, device=device) for _ in range(depth)]
         self.free_full = [torch.empty((rows_per_rank * self.world, n_free, 3), dtype=dtype, device=device)
-                          if self.world > 1 else None for _ in range(depth)]
+                          if self.exchange else None for _ in range(depth)]
         self.pending = [False] * depth  # gathered free coordinates not expanded yet
 
     def _finish(self, slot: int) -> None:
@@ -143,7 +147,7 @@ class FreeGatherPipeline(GatherPipeline):
     def submit(self, k: int) -> None:
         slot = k % self.depth
         self.last = slot
-        if self.world > 1:
+        if self.exchange:
             torch.index_select(self.local[slot], 1, self.free_out_index, out=self.free_local[slot])
             self.work[slot] = dist.all_gather_into_tensor(self.free_full[slot], self.free_local[slot], group=self.group,
                                                           async_op=True)
@@ -154,7 +158,7 @@ class FreeGatherPipeline(GatherPipeline):
             self._finish(slot)
         if self.last < 0:
             raise RuntimeError("nothing was submitted")
-        return self.local[self.last] if self.world == 1 else self.full[self.last]
+        return self.full[self.last] if self.exchange else self.local[self.last]
 
 
 @dataclass

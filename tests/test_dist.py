@@ -214,3 +214,26 @@ def test_single_process_gather_is_identity():
     assert all_gather_rows(x, 4) is x
     with pytest.raises(ValueError):
         all_gather_rows(x, 5)
+
+
+def test_bench_launches_its_own_ranks_for_gpus_n():
+    """`python bench.py --gpus 2` without a launcher starts the ranks itself (torch.distributed.run as a child, before
+    anything touches a GPU) and leaves with the launcher's code; --dry-launch keeps the GPUs out of it."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"],
+                          capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [json.loads(l) for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout  # rank 0 alone prints
+    assert lines[0] == {"dry_launch": True, "n_gpus": 2, "ranks_seen": 2, "master": lines[0]["master"]}
+    assert lines[0]["master"].startswith("127.0.0.1:")
+    # a launcher that starts another number of ranks than --gpus says is an error, not a silent mismatch
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "started 3 rank" in (bad.stderr + bad.stdout)
