@@ -450,7 +450,7 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
         gbs = bytes_per * n / (kernel_ms * 1e-3) / 1e9
         res[tag] = {"value": n / wall, "kernel_ms": kernel_ms, "lm_evaluations_mean": nfev, "all_converged": ok,
                     "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "kernel": kernel_of(chain_len == 1)}
-        if dp.kernel == "quad" and "lane" in res[tag]["kernel"]:
+        if res[tag]["kernel"].startswith("lane") and not os.environ.get("OKX_BENCH_NO_QUAD_COMPARE"):
             # the quad kernel on the same launch, for the record (what round 2 measured)
             q_launch = dp.plan(targets, out=out, info_out=info, chain_len=chain_len, predictor=False, kernel="quad", **kw)
             q_wall, q_ms = time_launches(q_launch, steps, warmup, device)

@@ -280,12 +280,14 @@ def test_a_damaged_cache_entry_is_rebuilt(golden, tmp_path, monkeypatch):
     assert dp.kernel == "quad"
     dp.close()
     files = [f for f in os.listdir(tmp_path) if f.endswith(".okxc")]
-    assert len(files) == 1
-    path = tmp_path / files[0]
-    path.write_bytes(path.read_bytes()[:1000])  # truncated: the header's size / checksum no longer match
+    assert len(files) == 2  # the quad kernel's code object and the lane kernel's
+    for name in files:      # both truncated: the headers' size / checksum no longer match
+        path = tmp_path / name
+        path.write_bytes(path.read_bytes()[:1000])
     dp = DeviceProgram(program, "cuda:0")
     assert dp.kernel == "quad", dp.kernel_note
-    assert path.stat().st_size > 10000
+    assert dp.lane_threshold > 0, dp.lane_note
+    assert all((tmp_path / name).stat().st_size > 10000 for name in files)
     res = dp.solve(arrays["targets_abs"])
     assert np.all((res.info()["flags"] & 7) == 1)
 
