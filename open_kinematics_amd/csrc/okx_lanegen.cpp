@@ -26,6 +26,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -708,6 +709,11 @@ class LGen {
   }
   struct Prod { std::string a, b; int sg; };
   std::map<std::pair<int, int>, std::vector<Prod>> ata_terms;  // (i, j), i > j
+  // late_diag: the diagonal is assembled at its column too (18 doubles less between the rows and the factorisation); the
+  // largest diagonal entry, which scales the damping of a solve that starts without a first-step table, is then formed
+  // from the same products in the (rare) branch that needs it.
+  bool late_diag = false;
+  std::map<int, std::vector<std::string>> diag_terms;  // i -> gradient components whose squares make (J^T J)_ii
   bool early_ata = false;  // parity kernel: additionally accumulate the whole lower triangle as E{i}_{j} at the rows
   std::set<std::string> early_declared;
   static std::string E(int i, int j) { return "E" + std::to_string(i) + "_" + std::to_string(j); }
@@ -716,7 +722,8 @@ class LGen {
   bool emit_rows() {
     const int n = 3 * P.n_free;
     for (int i = 0; i < n; ++i) {
-      f("    double %s = 0.0, %s = 0.0;", gn(i).c_str(), A(i, i).c_str());
+      if (late_diag) f("    double %s = 0.0;", gn(i).c_str());
+      else f("    double %s = 0.0, %s = 0.0;", gn(i).c_str(), A(i, i).c_str());
       nz[i][i] = true;
     }
     f("    double ss = 0.0, mres_new = 0.0;");
@@ -779,9 +786,13 @@ class LGen {
           if (fv.second.c[a].empty()) continue;
           const int ia = 3 * fv.first + a;
           f("    %s = fma(%s, %s, %s);", gn(ia).c_str(), sgn(fv.second, a).c_str(), ro.r.c_str(), gn(ia).c_str());
-          f("    %s = fma(%s, %s, %s);", A(ia, ia).c_str(), fv.second.c[a].c_str(), fv.second.c[a].c_str(), A(ia, ia).c_str());
           touched.push_back(gn(ia));
-          touched.push_back(A(ia, ia));
+          if (late_diag) {
+            diag_terms[ia].push_back(fv.second.c[a]);
+          } else {
+            f("    %s = fma(%s, %s, %s);", A(ia, ia).c_str(), fv.second.c[a].c_str(), fv.second.c[a].c_str(), A(ia, ia).c_str());
+            touched.push_back(A(ia, ia));
+          }
         }
       for (size_t ia = 0; ia < jv.size(); ++ia)
         for (size_t ib = 0; ib <= ia; ++ib) {
@@ -811,6 +822,14 @@ class LGen {
       home_gradients(jv);
     }
     return true;
+  }
+
+  // (J^T J)_ii as one expression of the rows' gradient components (late_diag)
+  std::string diag_expr(int i, const std::function<std::string(const std::string&)>& ref) {
+    std::vector<std::pair<std::string, std::string>> pr;
+    for (const std::string& nm : diag_terms[i]) pr.push_back({ref(nm), ref(nm)});
+    const std::string e = sum_expr(pr);
+    return e.empty() ? "0.0" : e;
   }
 
   // Structure of the factor at scalar granularity (symbolic right-looking elimination).
@@ -868,7 +887,10 @@ class LGen {
           for (const std::string* nm : {&t.a, &t.b})
             if (!j_home.count(*nm) && nm->compare(0, 1, "_") == 0 && seen.insert(*nm).second)
               f("    asm volatile(\"\" : \"+v\"(%s));", nm->c_str());
-      for (int i = 0; i < n; ++i) f("    asm volatile(\"\" : \"+v\"(%s), \"+v\"(%s));", gn(i).c_str(), A(i, i).c_str());
+      for (int i = 0; i < n; ++i) {
+        if (late_diag) f("    asm volatile(\"\" : \"+v\"(%s));", gn(i).c_str());
+        else f("    asm volatile(\"\" : \"+v\"(%s), \"+v\"(%s));", gn(i).c_str(), A(i, i).c_str());
+      }
     }
     f("    bool ok = true;");
     f("    double pmin = 1e300, pmax = 0.0;");
@@ -881,6 +903,14 @@ class LGen {
       f("    // column %d", j);
       if (j % 3 == 0 && !j_home.empty()) {  // gradients of this block column's products come back from LDS
         alias.clear();
+        for (int jj = j; jj < j + 3 && jj < n && late_diag; ++jj)
+          for (const std::string& nm : diag_terms[jj]) {
+            auto h = j_home.find(nm);
+            if (h == j_home.end() || alias.count(nm)) continue;
+            const std::string cp = nm + "_c" + std::to_string(j / 3);
+            f("    const double %s = lds[%d + lane + kz];", cp.c_str(), 64 * h->second);
+            alias[nm] = cp;
+          }
         for (int jj = j; jj < j + 3 && jj < n; ++jj)
           for (int i = jj + 1; i < n; ++i) {
             auto it = ata_terms.find({i, jj});
@@ -913,7 +943,13 @@ class LGen {
           if (fill[i][k]) pr.push_back({"(-C" + std::to_string(i) + "_" + std::to_string(k) + ")", L(j, k)});
         std::string init;
         if (i == j) {
-          init = A(j, j) + " + lambda";
+          if (late_diag) {
+            std::vector<std::pair<std::string, std::string>> ap;
+            for (const std::string& nm : diag_terms[j]) ap.push_back({ref(nm), ref(nm)});
+            init = sum_expr(ap, "lambda");
+          } else {
+            init = A(j, j) + " + lambda";
+          }
         } else {
           auto it = ata_terms.find({i, j});
           if (it != ata_terms.end()) {
@@ -991,6 +1027,11 @@ DEV double uni(double v) {
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
   const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
   return __hiloint2double(hi, lo);
+}
+DEV long long uni64(long long v) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned int)lo;
 }
 DEV double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -1072,9 +1113,12 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
   if (const char* env = getenv("OKX_LANE_J_SLOTS")) cold_j_slots = atoi(env);
   struct PassSrc { std::string eval, factor, subst; };
   auto make_pass = [&](LGen& gen, PassSrc* out) -> bool {
-    gen.pin_acc = getenv("OKX_LANE_NO_PIN") == nullptr;  // (experiment switch)
+    // (experiment switches.  Measured on the double wishbone, scratch bytes of the independent-solve bodies _u / _g:
+    //  pins + launder 0 / 188, pins only 160 / -, launder only 96 / 96, neither 0 / 0.  The register allocator's result
+    //  is not monotonic in anything; tools/lane_isa.sh + tools/lane_meta.py show it in ten seconds.)
+    gen.pin_acc = getenv("OKX_LANE_PIN") != nullptr;
     gen.hard_fence = getenv("OKX_LANE_HARD_FENCE") != nullptr;
-    gen.launder = getenv("OKX_LANE_NO_LAUNDER") == nullptr;
+    gen.launder = getenv("OKX_LANE_LAUNDER") != nullptr;
     if (const char* env = getenv("OKX_LANE_COL_FENCE")) gen.col_fence = atoi(env);
     if (const char* env = getenv("OKX_LANE_RESIDENT_ROWS")) gen.resident_rows = atoi(env);
     for (int e = 0; e < P.n_derived; ++e) gen.dp(e);
@@ -1113,6 +1157,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
   evc.j_lds_slots = cold_j_slots;
   evc.l_lds_base = kColdStateSlots + cold_j_slots;
   evc.l_lds_slots = cold_l_slots;
+  evc.late_diag = getenv("OKX_LANE_LATE_DIAG") != nullptr;  // (measured: 200 / 264 B of scratch against 104 / 192 B: not kept)
   if (!make_pass(evc, &pass_cold) || !evc.hoisted.empty()) {
     *why = evc.why.empty() ? "pass generation is not reproducible" : evc.why;
     return false;
@@ -1226,8 +1271,10 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     g.f("  const long long waves_per_span = (chains_per_span + 63) / 64;");
     g.f("  const long long n_wave_units = n_spans * waves_per_span;");
     g.f("  for (long long wu = blockIdx.x; wu < n_wave_units; wu += gridDim.x) {");
-    g.f("    const long long span_idx = n_spans > 1 ? wu / waves_per_span : 0;  // wave-uniform: one geometry per wave unit");
-    g.f("    const long long wave_in_span = wu - span_idx * waves_per_span;");
+    // (the 64-bit division runs on the vector ALU; its result goes to scalar registers so that every table address
+    //  derived from it is scalar arithmetic, not a pair of vector registers kept alive through the solve)
+    g.f("    const long long span_idx = uni64(n_spans > 1 ? wu / waves_per_span : 0);  // wave-uniform: one geometry per wave unit");
+    g.f("    const long long wave_in_span = uni64(wu - span_idx * waves_per_span);");
     g.f("    long long chain_in_span = wave_in_span * 64 + lane;");
     g.f("    const bool have = chain_in_span < chains_per_span;");
     g.f("    if (!have) chain_in_span = chains_per_span - 1;");
@@ -1344,6 +1391,31 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
       for (int i = 0; i < n; ++i) g.f("        dx%d = 0.0;", i);
       g.f("      }");
     }
+    // Two nested loops: the inner one runs full passes while any lane needs one; when every active lane only has a step to
+    // confirm, the outer loop takes the residual-only pass and comes back (a lane whose step is not confirmed goes on with
+    // full passes).  Same order of evaluations as one loop with the confirming pass as a branch at its top.
+    const bool nested = light_ok && getenv("OKX_LANE_FLAT_LOOP") == nullptr;
+    if (nested) {
+      g.f("      while (wave_any(!done)) {");
+      g.f("    %s", refresh_kz);
+      g.f("    if (a.confirm == 0 && !wave_any(!done && !want_light)) {");
+      for (int i = 0; i < n; ++i) g.f("      %s = x%d + dx%d;", PF(i).c_str(), i, i);
+      g.out += light_src;
+      g.f("      const double Fl = 0.5 * ss;");
+      g.f("      if (!done) {");
+      g.f("        ++nfev;");
+      g.f("        if (Fl == Fl && Fl <= Fc * (1.0 + 1e-6) + 1e-28) {");
+      for (int i = 0; i < n; ++i) g.f("          x%d = %s;", i, PF(i).c_str());
+      g.f("          Fc = Fl; mres = mres_new; last_step = step_len; flags |= INFO_CONVERGED; done = true;");
+      g.f("        } else {");
+      g.f("          want_light = false;");
+      g.f("        }");
+      g.f("      }");
+      g.f("    }");
+      g.f("    while (wave_any(!done) && (a.confirm != 0 || wave_any(!done && !want_light))) {");
+      g.f("    %s", refresh_kz);
+      g.f("    want_light = false;");
+    } else {
     g.f("      while (wave_any(!done)) {");
     g.f("    %s", refresh_kz);
     if (light_ok) {
@@ -1364,6 +1436,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
       g.f("    }");
       g.f("    want_light = false;");
     }
+    }
     mark(1);
     for (int i = 0; i < n; ++i) g.f("    %s = mode == 2 ? x%d : x%d + dx%d;", PF(i).c_str(), i, i, i);
     g.out += (ch ? pass_chain : pass_cold).eval;
@@ -1381,7 +1454,12 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     g.f("    }");
     g.f("    double diag = 0.0, gm = 0.0;");
     g.f("    if (wave_any(mode == 0)) {");
-    for (int i = 0; i < n; ++i) g.f("      diag = fmax(diag, %s);", LGen::A(i, i).c_str());
+    if (!ch && evc.late_diag) {
+      auto same = [](const std::string& nm) { return nm; };
+      for (int i = 0; i < n; ++i) g.f("      diag = fmax(diag, %s);", evc.diag_expr(i, same).c_str());
+    } else {
+      for (int i = 0; i < n; ++i) g.f("      diag = fmax(diag, %s);", LGen::A(i, i).c_str());
+    }
     g.f("    }");
     g.f("    if (a.grad_tol > 0.0) {");
     for (int i = 0; i < n; ++i) g.f("      gm = fmax(gm, fabs(%s));", LGen::gn(i).c_str());
@@ -1446,6 +1524,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     g.f("    }");
     mark(6);
     g.f("    }  // any lane solves");
+    if (nested) g.f("    }  // full passes");
     g.f("      }  // LM passes");
     // final state and output
     g.f("      {");
