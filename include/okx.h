@@ -498,6 +498,10 @@ int32_t okx_camber_shim_batch(const okx_shim_roles* roles, int64_t n_geometries,
  * owned by the program). */
 const char* okx_program_kernel(const okx_program* prog);
 const char* okx_program_kernel_note(const okx_program* prog);
+/* 1 when chain heads of the program's own geometry take their first Levenberg-Marquardt step from the shared first-step
+ * table (okx_solve_opts.shared_first_step): okx_info.nfev of such a head does not count the design-state evaluation,
+ * which was made once for all of them (the drop-in's SolverInfo.nfev adds it back, solver.py:766-771). */
+int32_t okx_program_shares_first_step(const okx_program* prog);
 
 /* Generated source of a program's quad kernel (no device needed).  Copies at most buflen - 1
  * bytes plus a terminator into buf (buf may be NULL) and returns the size the full text

@@ -30,6 +30,7 @@ EXPORTS = (
     "okx_rebind_design",
     "okx_program_kernel",
     "okx_program_kernel_note",
+    "okx_program_shares_first_step",
     "okx_quad_source",
     "okx_precompile",
     "okx_tangent_batch",
@@ -114,6 +115,8 @@ def load() -> C.CDLL:
     lib.okx_program_kernel.restype = C.c_char_p
     lib.okx_program_kernel_note.argtypes = [vp]
     lib.okx_program_kernel_note.restype = C.c_char_p
+    lib.okx_program_shares_first_step.argtypes = [vp]
+    lib.okx_program_shares_first_step.restype = i32
     lib.okx_quad_source.argtypes = [C.POINTER(ProgramDesc), C.c_char_p, i64]
     lib.okx_quad_source.restype = i64
     lib.okx_precompile.argtypes = [C.POINTER(ProgramDesc)]

@@ -83,6 +83,11 @@ class DeviceProgram:
         return self.lib.okx_program_kernel_note(self._handle).decode()
 
     @property
+    def shares_first_step(self) -> bool:
+        """Chain heads of the own geometry take their first step from the shared first-step table (their ``nfev`` omits it)."""
+        return bool(self.lib.okx_program_shares_first_step(self._handle))
+
+    @property
     def lane_threshold(self) -> int:
         """Batch size from which auto selection uses the lane kernel (one lane per problem); -1: the program has none."""
         return int(self.lib.okx_program_lane_threshold(self._handle))

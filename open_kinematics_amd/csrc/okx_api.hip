@@ -535,6 +535,10 @@ const char* okx_program_kernel(const okx_program* p) {
 
 const char* okx_program_kernel_note(const okx_program* p) { return p ? p->quad_note : ""; }
 
+/* 1 when chain heads of this program's own geometry take their first step from the shared first-step table
+   (okx_solve_opts.shared_first_step with a generated head kernel): their okx_info.nfev then omits that evaluation. */
+int32_t okx_program_shares_first_step(const okx_program* p) { return p && p->quad_fn_head_u ? 1 : 0; }
+
 /* Why the program has no lane kernel (empty string: it has one), and the batch size from which auto selection uses it. */
 const char* okx_program_lane_note(const okx_program* p) { return p ? p->lane_note : ""; }
 int64_t okx_program_lane_threshold(const okx_program* p) { return p && p->lane_fn_u ? p->lane_min_problems : -1; }

@@ -8,6 +8,7 @@ this package's; the returned states are built with the same classes as the input
 from __future__ import annotations
 
 import hashlib
+import threading
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Any, NamedTuple
@@ -91,26 +92,53 @@ def _absolute_like(mode):
         return TargetPositionMode.ABSOLUTE
 
 
-def absolute_target_table(sweep_config, initial_state) -> tuple[list, np.ndarray]:
-    """``([(point, direction)] per dimension, values [S, T])`` with the reference's arithmetic."""
+def target_segments(sweep_config) -> list:
+    """
+    ``[(first step, last step + 1)]``: maximal runs of steps over which every sweep dimension keeps its target point and
+    direction.  The reference pairs arbitrary ``PointTarget``s by index (``targeting.py:67-75``), so a dimension may
+    change the point or the direction it drives from one step to the next; the batched solver shares its target ROWS
+    across the steps of one launch, so such a sweep is solved run by run.
+    """
     dims = sweep_config.target_sweeps
+    n_steps = sweep_config.n_steps
+    cuts = set()
+    for dim in dims:
+        prev, prev_unit = dim[0], None
+        for k in range(1, n_steps):
+            t = dim[k]
+            # (a dimension built by build_sweep shares ONE direction object: the identity test settles nearly every step)
+            same = t.point_id == prev.point_id and t.direction is prev.direction
+            if not same and t.point_id == prev.point_id:
+                if prev_unit is None:
+                    prev_unit = resolve_direction(prev.direction)
+                same = bool(np.array_equal(resolve_direction(t.direction), prev_unit))
+            if not same:
+                cuts.add(k)
+                prev_unit = None
+            prev = t
+    bounds = [0] + sorted(cuts) + [n_steps]
+    return [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1) if bounds[i + 1] > bounds[i]]
+
+
+def absolute_target_table(sweep_config, initial_state, steps: tuple | None = None) -> tuple[list, np.ndarray]:
+    """``([(point, direction)] per dimension, values [S, T])`` with the reference's arithmetic, for the steps
+    ``[steps[0], steps[1])`` (default: the whole sweep, which must then keep one point and direction per dimension)."""
+    dims = sweep_config.target_sweeps
+    lo, hi = steps if steps is not None else (0, sweep_config.n_steps)
+    if steps is None and len(target_segments(sweep_config)) > 1:
+        raise NotImplementedError(
+            "a sweep dimension changes its target point or direction between steps: one launch shares its target rows "
+            "across its steps (solve_suspension_sweep solves such a sweep run by run, see target_segments)"
+        )
     heads, columns = [], []
     for dim in dims:
-        first = dim[0]
+        first = dim[lo] if hi > lo else dim[0]
         unit0 = resolve_direction(first.direction)
-        for t in dim:
-            # (a dimension built by build_sweep shares ONE direction object: the identity test settles nearly every step)
-            if t.point_id != first.point_id or (t.direction is not first.direction and
-                                                not np.array_equal(resolve_direction(t.direction), unit0)):
-                raise NotImplementedError(
-                    "a sweep dimension must keep one point and direction for all steps "
-                    "(the batched solver shares target rows across the sweep)"
-                )
         position = initial_state.positions[first.point_id]
         base = float(np.dot(np.asarray(getattr(position, "data", position)), unit0))
-        columns.append([t.value if _is_absolute(t.mode) else base + t.value for t in dim])
+        columns.append([t.value if _is_absolute(t.mode) else base + t.value for t in dim[lo:hi]])
         heads.append((first.point_id, first.direction))
-    table = np.asarray(columns, dtype=np.float64).T.reshape(sweep_config.n_steps, len(dims))
+    table = np.asarray(columns, dtype=np.float64).T.reshape(hi - lo, len(dims))
     return heads, np.ascontiguousarray(table)
 
 
@@ -127,6 +155,7 @@ def describe_worst_residual(program: ConstraintProgram, residuals: np.ndarray) -
 # then skips the upload, the kernel generation and the code-object load; the key covers the structure AND the
 # geometry values of the flattened program, the line mode and the device, so a hit is the same program.
 _PROGRAM_CACHE: "OrderedDict[tuple, Any]" = OrderedDict()
+_PROGRAM_CACHE_LOCK = threading.Lock()
 PROGRAM_CACHE_SIZE = 8
 
 
@@ -147,26 +176,30 @@ def _device_program(program: ConstraintProgram, device=None):
 
     from .batch import DeviceProgram
 
-    device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}") \
-        if torch.cuda.is_available() else device
+    if torch.cuda.is_available():
+        device = torch.device(device if device is not None else "cuda")
+        if device.type == "cuda" and device.index is None:  # 'cuda' and 'cuda:0' are the same cache entry
+            device = torch.device("cuda", torch.cuda.current_device())
     key = _program_key(program, device)
-    dp = _PROGRAM_CACHE.get(key)
-    if dp is not None:
-        _PROGRAM_CACHE.move_to_end(key)
-        return dp
+    with _PROGRAM_CACHE_LOCK:
+        dp = _PROGRAM_CACHE.get(key)
+        if dp is not None:
+            _PROGRAM_CACHE.move_to_end(key)
+            return dp
     dp = DeviceProgram(program, device)
-    _PROGRAM_CACHE[key] = dp
-    while len(_PROGRAM_CACHE) > PROGRAM_CACHE_SIZE:
-        _, old = _PROGRAM_CACHE.popitem(last=False)
-        old.close()
+    with _PROGRAM_CACHE_LOCK:
+        _PROGRAM_CACHE[key] = dp
+        # an evicted program is only DROPPED: another caller (another thread, a BatchResult's owner) may still hold it,
+        # and its device memory goes when the last reference does (DeviceProgram.__del__)
+        while len(_PROGRAM_CACHE) > PROGRAM_CACHE_SIZE:
+            _PROGRAM_CACHE.popitem(last=False)
     return dp
 
 
 def clear_program_cache() -> None:
-    """Release every cached device program (their HBM copies and loaded code objects)."""
-    while _PROGRAM_CACHE:
-        _, dp = _PROGRAM_CACHE.popitem()
-        dp.close()
+    """Forget every cached device program (each is released when its last holder lets go of it)."""
+    with _PROGRAM_CACHE_LOCK:
+        _PROGRAM_CACHE.clear()
 
 
 def dropin_program(initial_state, constraints, sweep_config, derived_manager, solver_config=SolverConfig(),
@@ -197,15 +230,20 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     import torch
 
     cfg = _coerce_config(solver_config)
+    if sweep_config.n_steps == 0:
+        return [], []
+    segments = target_segments(sweep_config)
+    if len(segments) > 1:
+        return _solve_sweep_in_runs(initial_state, constraints, sweep_config, derived_manager, cfg, segments,
+                                    output_points, device)
     program, table = dropin_program(initial_state, constraints, sweep_config, derived_manager, cfg, output_points)
     dp = _device_program(program, device)
     n_steps = table.shape[0]
-    if n_steps == 0:
-        return [], []
     solve_kw = dict(max_iter=cfg.max_iter, step_tol=cfg.step_tol, residual_tolerance=cfg.residual_tolerance,
                     predictor=False)  # one sweep = a few chains (or explicit cold starts): nothing for a fitted model to save
     targets = torch.as_tensor(table)
     positions = info = None
+    positions_from_segments = False
     segment = _segment_length(n_steps) if cfg.warm_start and cfg.parallel_chains else 0
     if segment:
         # One chain is one quad walking the sweep step by step: 1/16384 of the chip and ~12 us per step.  A long sweep
@@ -215,17 +253,66 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
         result = dp.solve(targets, chain_len=segment, **solve_kw)
         positions = result.positions.cpu().numpy()
         info = result.info()
+        positions_from_segments = True
         if not _chains_are_continuous(program, table, positions, info, segment):
             positions = info = None
+            positions_from_segments = False
     if positions is None:
         result = dp.solve(targets, chain=bool(cfg.warm_start), **solve_kw)
         # one D2H copy each; .cpu() synchronises with the launch stream
         positions = result.positions.cpu().numpy()
         info = result.info()
+        if not cfg.warm_start:
+            positions_from_segments, segment = True, 1  # every step is a chain head
     _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg)
     states = _states_from_positions(initial_state, program, positions)
-    infos = [SolverInfo(c, n, r) for c, n, r in zip(((info["flags"] & 1) != 0).tolist(), info["nfev"].tolist(),
-                                                    info["max_residual"].tolist())]
+    return states, _solver_infos(info, dp, segment if positions_from_segments else n_steps)
+
+
+def _solver_infos(info: np.ndarray, dp, chain_len: int) -> list:
+    """``SolverInfo`` per step.  A chain head that took its first step from the program's shared first-step table
+    (``okx_solve_opts.shared_first_step``) did not run the design-state evaluation itself - the device's ``nfev`` counts
+    what a problem ran - but the evaluation was made on its behalf: it is counted here, like the reference counts it."""
+    nfev = info["nfev"].astype(np.int64)
+    if getattr(dp, "shares_first_step", False) and chain_len > 0:
+        nfev[::chain_len] += 1
+    return [SolverInfo(c, n, r) for c, n, r in zip(((info["flags"] & 1) != 0).tolist(), nfev.tolist(),
+                                                   info["max_residual"].tolist())]
+
+
+def _solve_sweep_in_runs(initial_state, constraints, sweep_config, derived_manager, cfg, segments, output_points, device):
+    """
+    A sweep whose target rows change between steps (``targeting.py:67-75`` pairs arbitrary targets by index): every
+    maximal run of steps with one set of target rows is one warm-started chain on its own program, and the run after it
+    starts where this one ended, exactly like the reference's sequential warm start (``solver.py:716,774``) - the next
+    program is flattened at the last solved state (its constraint rows keep their authored parameters; only the start
+    point moves).  Relative targets stay relative to the ORIGINAL initial state (``solver.py:584-627``).
+    """
+    import torch
+
+    spec = getattr(derived_manager, "spec", derived_manager)
+    n_vars = 3 * len(initial_state.free_points)
+    states, infos = [], []
+    start_state = initial_state
+    keep = None if output_points is None else set(output_points)
+    for lo, hi in segments:
+        heads, table = absolute_target_table(sweep_config, initial_state, (lo, hi))
+        validate_least_squares_dimensions(n_vars, len(constraints) + len(heads))
+        program = flatten_problem(start_state, constraints, spec, heads, output_points=None,
+                                  line_mode="softnorm").with_line_mode(cfg.line_mode)
+        dp = _device_program(program, device)
+        result = dp.solve(torch.as_tensor(table), chain=bool(cfg.warm_start), max_iter=cfg.max_iter, step_tol=cfg.step_tol,
+                          residual_tolerance=cfg.residual_tolerance, predictor=False)
+        positions = result.positions.cpu().numpy()
+        info = result.info()
+        _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg, first_step=lo)
+        run_states = _states_from_positions(initial_state, program, positions)
+        start_state = run_states[-1]
+        infos.extend(_solver_infos(info, dp, hi - lo if cfg.warm_start else 1))
+        states.extend(run_states)
+    if keep is not None:
+        states = [type(s)(positions={k: v for k, v in s.positions.items() if k in keep},
+                          free_points=set(s.free_points) & keep) for s in states]
     return states, infos
 
 
@@ -274,7 +361,7 @@ def _coerce_config(config) -> SolverConfig:
     return SolverConfig(**fields)
 
 
-def _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg) -> None:
+def _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg, first_step: int = 0) -> None:
     import torch
 
     flags = info["flags"]
@@ -282,7 +369,7 @@ def _raise_on_first_failure(program, dp, table, positions, info, sweep_config, i
     if bad.size == 0:
         return
     step = int(bad[0])
-    step_targets = convert_targets_to_absolute([dim[step] for dim in sweep_config.target_sweeps], initial_state)
+    step_targets = convert_targets_to_absolute([dim[first_step + step] for dim in sweep_config.target_sweeps], initial_state)
     # A step that stalls far from feasibility is the reference's "converged to a compromise"
     # case (MINPACK stops on ftol=1e-5 there): report it through the residual check.
     exceeded = (flags[step] & 2) != 0 and (flags[step] & 4) == 0
@@ -291,10 +378,20 @@ def _raise_on_first_failure(program, dp, table, positions, info, sweep_config, i
             f"Solver failed to converge for targets: {step_targets}."
             f"\nMessage: device Levenberg-Marquardt stopped after {int(info['iterations'][step])} iterations"
         )
-    x = positions[step][program.free_point].reshape(1, -1)
-    r, _ = dp.eval(torch.as_tensor(x), torch.as_tensor(table[step : step + 1]), jac=False)
-    worst = describe_worst_residual(program, r.cpu().numpy()[0])
+    # the record holds the OUTPUT points in output order: map the free points through it (a restricted output list may
+    # not hold all of them; the worst row is then named from a re-solve of this one step with every point written)
+    out = [int(k) for k in program.out_point]
+    try:
+        x = positions[step][[out.index(int(p)) for p in program.free_point]].reshape(1, -1)
+    except ValueError:
+        x = None
+    if x is not None:
+        r, _ = dp.eval(torch.as_tensor(x), torch.as_tensor(table[step : step + 1]), jac=False)
+        worst = describe_worst_residual(program, r.cpu().numpy()[0])
+    else:
+        worst = "unavailable (the requested output_points do not include every free point)"
     value = float(info["max_residual"][step])
+    step = first_step + step
     raise RuntimeError(
         f"Solve at sweep step {step} did not reach an acceptable residual: worst residual "
         f"{value:.6g} exceeds the acceptance tolerance {cfg.residual_tolerance:.6g}. "

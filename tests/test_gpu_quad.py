@@ -353,3 +353,35 @@ def test_empty_batches_and_invalid_launches(golden):
     with pytest.raises(ValueError, match="B must equal"):
         gpos, gparam = dp.rebind(torch.as_tensor(pinned.design_pos[None]))
         dp.solve(t, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=3)
+
+
+def test_first_step_tables_are_ordered_across_streams_and_kept_per_lambda0(golden):
+    """the own-geometry first-step table was mutable per-program state without cross-stream ordering.
+    Now: one table per lambda0 (never overwritten), the default's filled at program creation, any other on the stream of
+    the first launch that needs it, with an event that launches on other streams wait for."""
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.workloads import bump_sweep_problem
+
+    program, targets = bump_sweep_problem(16384)
+    t = torch.as_tensor(targets, device="cuda:0")
+    ref_dp = DeviceProgram(program, "cuda:0")
+    refs = {lam: ref_dp.solve(t, chain_len=1, predictor=False, lambda0=lam, shared_first_step=False).positions.clone()
+            for lam in (1e-6, 3e-6, 1e-5)}
+    torch.cuda.synchronize()
+    dp = DeviceProgram(program, "cuda:0")   # fresh: only the default lambda0 has a table
+    s1, s2 = torch.cuda.Stream("cuda:0"), torch.cuda.Stream("cuda:0")
+    outs = []
+    # keep stream 1 busy so that its table fills are still queued when stream 2 asks for the same tables
+    with torch.cuda.stream(s1):
+        busy = torch.zeros(1 << 26, device="cuda:0")
+        for _ in range(20):
+            busy.add_(1.0)
+        for lam in (3e-6, 1e-5):
+            outs.append((lam, dp.solve(t, chain_len=1, predictor=False, lambda0=lam)))
+    with torch.cuda.stream(s2):
+        for lam in (1e-5, 3e-6, 1e-6):
+            outs.append((lam, dp.solve(t, chain_len=1, predictor=False, lambda0=lam)))
+    torch.cuda.synchronize()
+    for lam, res in outs:
+        assert np.all((res.info()["flags"] & 7) == 1)
+        assert float((res.positions - refs[lam]).abs().max()) <= 1e-9, lam
