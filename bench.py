@@ -396,6 +396,51 @@ def measure_e2e(dp, targets_host: np.ndarray, device, steps: int, cold_kw: dict)
     }
 
 
+def measure_e2e_compact(dp, targets_host: np.ndarray, device, steps: int, cold_kw: dict) -> dict:
+    """Host buffers in, host buffers out, with the boundary's compact output (okx_solve_opts.output = free coordinates:
+    144 B + the 40-byte info record per double-wishbone solve instead of 360 + 40 B) and two sets of buffers on two
+    streams, so that the D2H of sweep k overlaps the H2D and the solve of sweep k + 1.  The host gets the free points;
+    `expand` (device) or a host-side re-evaluation of the derived points rebuilds full records where they are wanted."""
+    p = dp.program
+    n = targets_host.shape[0]
+    h_t = torch.as_tensor(targets_host).pin_memory()
+    slots = []
+    for _ in range(2):
+        stream = torch.cuda.Stream(device)
+        with torch.cuda.stream(stream):
+            d_t = torch.empty_like(h_t, device=device)
+            d_free = torch.empty((n, p.n_free, 3), dtype=torch.float64, device=device)
+            d_info = torch.empty((n, 40), dtype=torch.uint8, device=device)
+            launch = dp.plan(d_t, out=d_free, info_out=d_info, output="free", **cold_kw)
+        slots.append(dict(stream=stream, d_t=d_t, d_free=d_free, d_info=d_info, launch=launch,
+                          h_free=torch.empty((n, p.n_free, 3), dtype=torch.float64).pin_memory(),
+                          h_info=torch.empty((n, 40), dtype=torch.uint8).pin_memory(), done=torch.cuda.Event()))
+
+    def issue(slot):
+        with torch.cuda.stream(slot["stream"]):
+            slot["d_t"].copy_(h_t, non_blocking=True)
+            slot["launch"]()
+            slot["h_free"].copy_(slot["d_free"], non_blocking=True)
+            slot["h_info"].copy_(slot["d_info"], non_blocking=True)
+            slot["done"].record()
+
+    for k in range(4):
+        issue(slots[k % 2])
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        slot = slots[k % 2]
+        slot["done"].synchronize()   # the host owns this slot's buffers again (the sweep before last)
+        issue(slot)
+    torch.cuda.synchronize(device)
+    wall = (time.perf_counter() - t0) / steps
+    ok = bool(np.all((slots[0]["h_info"].numpy().view(INFO_FIELDS).reshape(-1)["flags"] & 7) == 1))
+    return {"value": n / wall, "ms_per_sweep": wall * 1e3, "bytes_h2d": int(h_t.numel() * 8),
+            "bytes_d2h": int(n * (p.n_free * 24 + 40)), "all_converged": ok,
+            "note": "output = free coordinates, two buffer sets on two streams (D2H of one sweep under the next one's H2D + solve), "
+                    "pinned host buffers; never reported as `value`"}
+
+
 def measure_config(name: str, make, device, steps: int, warmup: int, modes=("cold", "chained")) -> dict:
     """One BASELINE configuration at full size: cold independent solves (section 8d's rule) and the product's chained mode."""
     from open_kinematics_amd.batch import DeviceProgram
@@ -450,6 +495,11 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
         gbs = bytes_per * n / (kernel_ms * 1e-3) / 1e9
         res[tag] = {"value": n / wall, "kernel_ms": kernel_ms, "lm_evaluations_mean": nfev, "all_converged": ok,
                     "algorithmic_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "kernel": kernel_of(chain_len == 1)}
+        if not os.environ.get("OKX_BENCH_NO_QUAD_COMPARE") and dp.kernel == "quad":
+            # the same launch without its position stores (okx_solve_opts.output = none): what the records cost
+            n_launch = dp.plan(targets, info_out=info, chain_len=chain_len, predictor=False, output="none", **kw)
+            n_wall, n_ms = time_launches(n_launch, steps, warmup, device)
+            res[tag]["output_none"] = {"value": n / n_wall, "kernel_ms": n_ms}
         if res[tag]["kernel"].startswith("lane") and not os.environ.get("OKX_BENCH_NO_QUAD_COMPARE"):
             # the quad kernel on the same launch, for the record (what round 2 measured)
             q_launch = dp.plan(targets, out=out, info_out=info, chain_len=chain_len, predictor=False, kernel="quad", **kw)
@@ -816,6 +866,8 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["pipelined"] = measure_pipelined(dp, targets, device, max(args.steps, 60))
         line["with_model"] = measure_with_model(program, targets, device, args.steps, args.warmup)
         line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, extra_steps, dict(chain_len=args.chain_len, predictor=False))
+        line["e2e"]["compact"] = measure_e2e_compact(dp, targets_all[lo:hi], device, max(extra_steps, 200),
+                                                     dict(chain_len=args.chain_len, predictor=False))
         from open_kinematics_amd.workloads import geometry_path
         line["downstream"] = measure_downstream(dp, geometry_path("geometry.yaml"), pipe.local[0], device)
         dp.close()

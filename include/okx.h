@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OKX_ABI_VERSION 2   /* 2: okx_solve_opts.confirm_full_pass (was `reserved`); diagnostics moved to okx_debug.h */
+#define OKX_ABI_VERSION 3   /* 3: okx_solve_opts.output (+ reserved); lane kernel entry points.  2: confirm_full_pass; diagnostics moved to okx_debug.h */
 
 /* Hard limits of one problem (one wavefront owns one problem). */
 #define OKX_MAX_VARS 63      /* n = 3 * free points (one lane per variable)          */
@@ -169,8 +169,21 @@ typedef struct okx_solve_opts {
                              dx = -(Q_0 + sum_t r_t Q_t), Q_k = (J^T J + lambda I)^-1 G_k, from that table.  Same
                              iteration, same iterates up to rounding; info.nfev counts the evaluations a problem ran
                              itself.  0: every chain head runs its own first pass.  With geometry tables the scratch
-                             table lives in the program: such launches of one program must be stream-ordered.        */
+                             table lives in the program: such launches of one program must be stream-ordered.  Own
+                             geometry: one table per lambda0, the default's filled at okx_program_create, any other by
+                             the first launch that asks for it (on its stream; launches on other streams wait for it). */
+  int32_t output;         /* what okx_solve_batch writes to d_out_pos (generated kernels; the interpreter kernels only
+                             know OKX_OUTPUT_RECORDS):
+                             OKX_OUTPUT_RECORDS (0, default) [B][n_out][3]: every output point, the reference's state copy
+                               (solver.py:763);
+                             OKX_OUTPUT_FREE [B][n_free][3]: the solved free points only, in the program's free_point order
+                               (144 B instead of 360 B per double-wishbone solve: what a PCIe link or an xGMI all-gather
+                               wants to carry; okx_expand_positions_batch rebuilds the records, bit-identical);
+                             OKX_OUTPUT_NONE: nothing (d_out_pos may be NULL) - only d_info, for feasibility scans.      */
+  int32_t reserved;
 } okx_solve_opts;
+
+enum { OKX_OUTPUT_RECORDS = 0, OKX_OUTPUT_FREE = 1, OKX_OUTPUT_NONE = 2 };
 
 /* Per-problem result, the device analogue of SolverInfo (solver.py:83-96). */
 typedef struct okx_info {

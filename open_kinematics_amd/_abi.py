@@ -8,7 +8,7 @@ import numpy as np
 
 from .program import ConstraintProgram
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -54,6 +54,8 @@ class SolveOpts(C.Structure):
         ("confirm_full_pass", C.c_int32),
         ("predictor", C.c_int32),
         ("shared_first_step", C.c_int32),
+        ("output", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -23,8 +23,9 @@ from .program import ConstraintProgram
 
 @dataclass
 class BatchResult:
-    positions: torch.Tensor  # [B, n_out, 3] float64, device
+    positions: torch.Tensor | None  # [B, n_out, 3] float64, device (``output="records"``, the default)
     info_raw: torch.Tensor  # [B, 40] uint8, device (okx_info records)
+    free: torch.Tensor | None = None  # [B, n_free, 3] float64, device (``output="free"``): the solved free points alone
 
     def info(self) -> np.ndarray:
         """Host copy of the per-problem records as a structured array (``_abi.INFO_DTYPE``)."""
@@ -138,6 +139,7 @@ class DeviceProgram:
         predictor: bool | str | None = None,
         confirm_full_pass: bool | None = None,
         shared_first_step: bool | None = None,
+        output: str = "records",
     ) -> BatchResult:
         """
         Solve ``B`` problems; ``targets`` is ``[B, T]`` of absolute target scalars.
@@ -152,6 +154,11 @@ class DeviceProgram:
         design state instead of running that (batch-invariant) pass themselves (``okx_solve_opts``).
 
         ``confirm_full_pass``: always end a solve on a computed correction ``<= step_tol`` (``okx_solve_opts``).
+
+        ``output`` (``okx_solve_opts.output``): ``"records"`` (default) writes every output point ``[B, n_out, 3]``;
+        ``"free"`` the solved free points alone ``[B, n_free, 3]`` in ``free_point`` order (``BatchResult.free``;
+        ``expand`` rebuilds the records, bit-identical) - what a PCIe link or an all-gather wants to carry; ``"none"``
+        only the info records.  ``out`` is the buffer of whichever is written.
 
         ``chain_len`` groups consecutive problems into warm-started chains walked by one
         wavefront each (``1`` independent cold starts, ``-1`` one chain per resident wavefront,
@@ -196,15 +203,21 @@ class DeviceProgram:
                 raise ValueError("geometry table has the wrong shape")
             if steps_per_geometry <= 0 or g * steps_per_geometry != b:
                 raise ValueError("B must equal n_geometries * steps_per_geometry")
-        if out is None:
-            out = torch.empty((b, p.n_out, 3), dtype=torch.float64, device=self.device)
+        mode = {"records": 0, "free": 1, "none": 2}[output]
+        opts.output = mode
+        if mode == 2:
+            out = None
+        elif out is None:
+            out = torch.empty((b, p.n_out if mode == 0 else p.n_free, 3), dtype=torch.float64, device=self.device)
+        elif out.shape != (b, p.n_out if mode == 0 else p.n_free, 3) or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float64 [B, n_out, 3] ([B, n_free, 3] with output='free') tensor")
         if info_out is None:
             info_out = torch.empty((b, INFO_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         args = (self._handle, C.byref(opts), b, _ptr(targets), _ptr(geom_pos), _ptr(geom_row_param),
                 _ptr(out), _ptr(info_out), C.c_void_p(stream))
         keep = (opts, targets, geom_pos, geom_row_param)  # tensors / structs the raw pointers refer to
-        return args, keep, BatchResult(out, info_out)
+        return args, keep, BatchResult(out if mode == 0 else None, info_out, out if mode == 1 else None)
 
     def solve(self, targets, **kw) -> BatchResult:
         """See ``_prepare`` for the arguments: validates, then launches ``okx_solve_batch`` once."""

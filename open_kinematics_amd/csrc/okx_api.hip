@@ -67,6 +67,7 @@ struct okx_program {
   hipModule_t lane_mod;
   hipFunction_t lane_fn_u, lane_fn_g, lane_fn_eval;  // independent solves (chain_len 1), parity kernel
   hipFunction_t lane_chain_u, lane_chain_g;          // chains
+  hipFunction_t lane_compact[4];                     // the same four with compact outputs (solve_u, solve_g, chain_u, chain_g)
   long long lane_min_problems;
   int lane_cold_scratch, lane_chain_scratch;  // private-segment bytes of the two bodies (code object metadata)
   bool lane_cold_ok, lane_chain_ok;           // bodies that auto selection may use
@@ -373,6 +374,10 @@ void attach_lane_kernel(okx_program* p) {
       hipModuleGetFunction(&p->lane_fn_g, mod, "okx_lane_solve_g") != hipSuccess ||
       hipModuleGetFunction(&p->lane_chain_u, mod, "okx_lane_chain_u") != hipSuccess ||
       hipModuleGetFunction(&p->lane_chain_g, mod, "okx_lane_chain_g") != hipSuccess ||
+      hipModuleGetFunction(&p->lane_compact[0], mod, "okx_lane_solve_u_c") != hipSuccess ||
+      hipModuleGetFunction(&p->lane_compact[1], mod, "okx_lane_solve_g_c") != hipSuccess ||
+      hipModuleGetFunction(&p->lane_compact[2], mod, "okx_lane_chain_u_c") != hipSuccess ||
+      hipModuleGetFunction(&p->lane_compact[3], mod, "okx_lane_chain_g_c") != hipSuccess ||
       hipModuleGetFunction(&p->lane_fn_eval, mod, "okx_lane_eval") != hipSuccess) {
     (void)hipGetLastError();
     (void)hipModuleUnload(mod);
@@ -427,6 +432,8 @@ void okx_default_opts(okx_solve_opts* o) {
   o->confirm_full_pass = 0;
   o->predictor = 0;
   o->shared_first_step = 1;
+  o->output = OKX_OUTPUT_RECORDS;
+  o->reserved = 0;
 }
 
 int32_t okx_device_count(void) {
@@ -626,7 +633,8 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   if (!p || !opts) return fail(OKX_ERR_INVALID, "null program or options");
   if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
   if (n_problems == 0) return OKX_OK;
-  if (!d_out_pos || !d_info) return fail(OKX_ERR_INVALID, "null output pointer");
+  if (opts->output < OKX_OUTPUT_RECORDS || opts->output > OKX_OUTPUT_NONE) return fail(OKX_ERR_INVALID, "unknown output mode");
+  if ((!d_out_pos && opts->output != OKX_OUTPUT_NONE) || !d_info) return fail(OKX_ERR_INVALID, "null output pointer");
   if (p->host.n_targets > 0 && !d_targets) return fail(OKX_ERR_INVALID, "null targets");
   if ((d_geom_pos == nullptr) != (d_geom_row_param == nullptr))
     return fail(OKX_ERR_INVALID, "geometry positions and row parameters must be given together");
@@ -739,6 +747,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     q.predictor_mode = opts->predictor;
     q.predictor_len = p->predictor_len;
     q.head = nullptr;
+    q.out_mode = opts->output;
     if (p->quad_fn_head_u && opts->shared_first_step != 0 && opts->grad_tol <= 0.0 && p->host.n_targets > 0) {
       // Shared first step: the design state's Jacobian, J^T J and damped factorisation are common to every problem
       // of a geometry, so they are evaluated once per geometry (one quad each) instead of once per chain head.
@@ -787,6 +796,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
       const long long lane_cap = (long long)p->n_cu * 4;  // one wavefront per SIMD (512 registers, ~37 KB LDS)
       const int lane_grid = (int)(lane_units < lane_cap ? (lane_units < 1 ? 1 : lane_units) : lane_cap);
       hipFunction_t fn = a.chain_len == 1 ? (d_geom_pos ? p->lane_fn_g : p->lane_fn_u) : (d_geom_pos ? p->lane_chain_g : p->lane_chain_u);
+      if (opts->output != OKX_OUTPUT_RECORDS) fn = p->lane_compact[(a.chain_len == 1 ? 0 : 2) + (d_geom_pos ? 1 : 0)];
       HIP_TRY(hipModuleLaunchKernel(fn, lane_grid, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
       return OKX_OK;
     }
@@ -797,6 +807,9 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
                                   (hipStream_t)stream, kargs, nullptr));
     return OKX_OK;
   }
+  if (opts->output != OKX_OUTPUT_RECORDS)
+    return fail(OKX_ERR_INVALID, "output mode %d needs a generated kernel (this launch runs the interpreter: %s)", opts->output,
+                p->quad_note[0] ? p->quad_note : "kernel option");
   if (use_packed) {
     int width = p->group_width;
     long long cap = (long long)p->n_cu * p->packed_blocks_per_cu;

@@ -1013,6 +1013,7 @@ struct QArgs {
   double* trace; long long trace_problem;
   const double* predictor; long long predictor_mode; long long predictor_len;
   const double* head;
+  long long out_mode;   // okx_solve_opts.output: 0 records of every output point, 1 the free points only, 2 nothing
 };
 #define EPS_SQ 1e-12
 #define EPS 1e-6
@@ -1253,7 +1254,10 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     auto mark = [&](int k) {
       if (marks && !ch) g.f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + k);
     };
-    g.f("template <bool PG> DEV void okx_lane_body_%s(const QArgs& a) {", ch ? "chain" : "cold");
+    // FULL: the kernel that writes full records (okx_solve_opts.output = 0) is compiled on its own, exactly as it was
+    // before the compact outputs existed: the register allocator's result for the double wishbone is that fragile
+    // (the same body with the output mode as a run-time switch: 0 -> 248 B of scratch).
+    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a) {", ch ? "chain" : "cold");
     g.f("  const int lane = threadIdx.x;");
     g.f("  __shared__ double lds[%d];", lds_doubles);
     g.f("  __shared__ double cl[%d];  // chain constants of the wave unit's geometry", n_consts);
@@ -1530,7 +1534,9 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     g.f("      {");
     g.f("    %s", refresh_kz);
     for (int i = 0; i < n; ++i) g.f("    %s = x%d;", PF(i).c_str(), i);
+    g.f("    if (FULL) {  // the derived points only matter to the full records");
     g.out += final_src;
+    g.f("    }");
     g.f("    if (mres > a.residual_tolerance) flags |= INFO_RESIDUAL_EXCEEDED;");
     g.f("    if (piv_hi > 0.0 && piv_lo <= ILL_CONDITIONED_PIVOT_RATIO * piv_hi) flags |= INFO_ILL_CONDITIONED;");
     if (ch) {
@@ -1553,15 +1559,23 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     if (!ch) {
       // Records of independent solves: the 64 problems of a wave unit are consecutive, their records one contiguous
       // block: transposed through LDS (which the state no longer needs) and written as full 16-byte-per-lane rows.
+      // (okx_solve_opts.output: the full record, the free points alone in the program's free_point order, or nothing)
+      g.f("      if (FULL || a.out_mode == 1) {");
+      g.f("      const int rec = FULL ? %d : %d;", 3 * P.n_out, n);
       g.f("      __syncthreads();");
+      g.f("      if (FULL) {");
       g.f("      double* st = lds + lane * %d;", 3 * P.n_out);
       for (int k = 0; k < P.n_out; ++k)
         for (int c = 0; c < 3; ++c) g.f("      st[%d] = p%d_%d;", 3 * k + c, P.out_point[k], c);
+      g.f("      } else {");
+      g.f("      double* st = lds + lane * %d;", n);
+      for (int i = 0; i < n; ++i) g.f("      st[%d] = %s;", 3 * ev.perm[i / 3] + i % 3, PF(i).c_str());
+      g.f("      }");
       g.f("      __syncthreads();");
       g.f("      const long long base_b = span_idx * span + wave_in_span * 64;");
       g.f("      const long long rem = (span_idx + 1) * span - base_b;");
-      g.f("      const int n_doubles = (int)(rem < 64 ? rem : 64) * %d;", 3 * P.n_out);
-      g.f("      double* dst = a.out_pos + base_b * %d;", 3 * P.n_out);
+      g.f("      const int n_doubles = (int)(rem < 64 ? rem : 64) * rec;");
+      g.f("      double* dst = a.out_pos + base_b * rec;");
       g.f("      double2* dst2 = reinterpret_cast<double2*>(dst);");
       g.f("      const double2* src2 = reinterpret_cast<const double2*>(lds);");
       g.f("      if ((reinterpret_cast<unsigned long long>(dst) & 15ull) == 0ull) {");
@@ -1571,12 +1585,16 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
       g.f("        for (int i = lane; i < n_doubles; i += 64) dst[i] = lds[i];");
       g.f("      }");
       g.f("      __syncthreads();");
+      g.f("      }");
     } else {
       // chains: a lane's problems are far apart in memory, every lane stores its own record
-      g.f("    if (valid) {");
+      g.f("    if (valid && FULL) {");
       g.f("      double* o = a.out_pos + bb * %d;", 3 * P.n_out);
       for (int k = 0; k < P.n_out; ++k)
         for (int c = 0; c < 3; ++c) g.f("      o[%d] = p%d_%d;", 3 * k + c, P.out_point[k], c);
+      g.f("    } else if (valid && !FULL && a.out_mode == 1) {");
+      g.f("      double* o = a.out_pos + bb * %d;", n);
+      for (int i = 0; i < n; ++i) g.f("      o[%d] = %s;", 3 * ev.perm[i / 3] + i % 3, PF(i).c_str());
       g.f("    }");
     }
     g.f("      }");
@@ -1647,10 +1665,11 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
   g.f("  }");
   g.f("}");
   g.f("");
-  g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_solve_u(QArgs a) { okx_lane_body_cold<false>(a); }");
-  g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_solve_g(QArgs a) { okx_lane_body_cold<true>(a); }");
-  g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_chain_u(QArgs a) { okx_lane_body_chain<false>(a); }");
-  g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_chain_g(QArgs a) { okx_lane_body_chain<true>(a); }");
+  for (const char* body : {"solve", "chain"})
+    for (const char* geo : {"u", "g"})
+      for (const char* out : {"", "_c"})   // _c: compact outputs (free coordinates or nothing)
+        g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_%s_%s%s(QArgs a) { okx_lane_body_%s<%s, %s>(a); }", body, geo,
+            out, body[0] == 's' ? "cold" : "chain", geo[0] == 'g' ? "true" : "false", out[0] ? "false" : "true");
   g.out += ev.undefs;
   *src = g.out;
   return true;

@@ -36,6 +36,7 @@ struct QuadArgs {
   long long predictor_mode; // 2: every chain step starts from the model
   long long predictor_len;  // doubles in the table
   const double* head;       // per-geometry first-step table (okx_quad_head_u/_g) or null
+  long long out_mode;       // okx_solve_opts.output: 0 records, 1 free coordinates, 2 nothing
 };
 
 // Arguments of the generated `okx_quad_head_u/_g` (mirrors `struct QHeadArgs`): one quad per geometry evaluates the

@@ -1059,6 +1059,7 @@ struct QArgs {
   long long predictor_mode; // 2: every chain step starts from the model, not only the heads
   long long predictor_len;  // doubles in the table
   const double* head;       // per-geometry first-step table of okx_quad_head_u/_g (null: every chain head takes its own first pass)
+  long long out_mode;       // okx_solve_opts.output: 0 records of every output point, 1 the free points only, 2 nothing
 };
 #define EPS_SQ 1e-12
 #define EPS 1e-6
@@ -1915,7 +1916,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       *why = fin.why;
       return false;
     }
+  g.f("    if (a.out_mode == 0) {  // the derived points only matter to the full records");
   g.out += fin.out;
+  g.f("    }");
   const std::string final_src = fin.out;
   g.f("    if (mres > a.residual_tolerance) flags |= INFO_RESIDUAL_EXCEEDED;");
   g.f("    if (piv_hi > 0.0 && piv_lo <= ILL_CONDITIONED_PIVOT_RATIO * piv_hi) flags |= INFO_ILL_CONDITIONED;");
@@ -1923,8 +1926,22 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // consecutive, so their records form one contiguous block; it is transposed through LDS and
   // written with full-width 16-byte-per-lane stores.  Chains: a quad's problems are far apart in
   // memory, each lane stores its own 8-byte components.
+  {
+    // okx_solve_opts.output = OKX_OUTPUT_FREE: the solved free points alone, [n_free][3] in the program's free_point order
+    std::vector<int> ordinal(program.n_points, 0);
+    for (int k = 0; k < program.n_free; ++k) ordinal[program.free_point[k]] = k;
+    g.f("    if (a.out_mode == 1 && valid && c < 3) {");
+    g.f("      long long bf = bb; asm volatile(\"\" : \"+v\"(bf));");
+    g.f("      double* o = a.out_pos + bf * %d + c;", 3 * program.n_free);
+    for (int F = 0; F < nf; ++F) {
+      const int pt = ev.fp(F);
+      const std::string off = pv ? Gen::sel(3 * ordinal[pv->pt[0][pt]], 3 * ordinal[pv->pt[1][pt]]) : std::to_string(3 * ordinal[pt]);
+      g.f("      o[%s] = x%d;", off.c_str(), F);
+    }
+    g.f("    }");
+  }
   if (pv) {
-    g.f("    if (valid && c < 3) {");
+    g.f("    if (a.out_mode == 0 && valid && c < 3) {");
     // (the record's address is rebuilt from an opaque copy of the problem index: as an induction variable the compiler
     //  keeps one strength-reduced 64-bit address per output point alive across the chain loop and spills all of them)
     g.f("      long long bo = bb; asm volatile(\"\" : \"+v\"(bo));");
@@ -1958,7 +1975,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("    }");
     g.f("    if (false) {");
   } else {
-  g.f("    if (unit_len == 1) {");
+  g.f("    if (a.out_mode != 0) {");
+  g.f("    } else if (unit_len == 1) {");
   g.f("      __shared__ double stage[16 * %d];", 3 * P.n_out);
   g.f("      if (c < 3) {");
   g.f("        double* st = stage + quad * %d + c;", 3 * P.n_out);

@@ -23,7 +23,7 @@ open("/tmp/q/lane.hip", "wb").write(buf.value)
 print("source bytes", need)
 PY
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -include hip/hip_runtime.h -S -o /tmp/q/lane.s /tmp/q/lane.hip "$@" 2>&1 | grep -v warning | head -20
-for k in okx_lane_solve_u okx_lane_chain_u okx_lane_chain_g okx_lane_eval; do
+for k in okx_lane_solve_u okx_lane_solve_u_c okx_lane_chain_u okx_lane_eval; do
   awk -v k="$k" '$0 ~ "^"k":"{f=1} f&&/s_endpgm/{print; f=0} f' /tmp/q/lane.s > /tmp/q/lane_$k.s
   echo "== $k: $(grep -c '^\s*[a-z]' /tmp/q/lane_$k.s) instructions"
   for pat in v_fma_f64 v_mul_f64 v_add_f64 v_fmac_f64 v_accvgpr_read v_accvgpr_write v_cndmask v_mov_b32 v_readlane v_writelane scratch_ ds_read ds_write s_waitcnt global_load v_rcp_f64 v_rsq_f64 v_max_f64 v_readfirstlane; do echo "   $pat: $(grep -c "$pat" /tmp/q/lane_$k.s)"; done | paste - - - - - -
