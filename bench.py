@@ -398,46 +398,75 @@ def measure_e2e(dp, targets_host: np.ndarray, device, steps: int, cold_kw: dict)
 
 def measure_e2e_compact(dp, targets_host: np.ndarray, device, steps: int, cold_kw: dict) -> dict:
     """Host buffers in, host buffers out, with the boundary's compact output (okx_solve_opts.output = free coordinates:
-    144 B + the 40-byte info record per double-wishbone solve instead of 360 + 40 B) and two sets of buffers on two
+    144 B + the 40-byte info record per double-wishbone solve instead of 360 + 40 B) and three sets of buffers on three
     streams, so that the D2H of sweep k overlaps the H2D and the solve of sweep k + 1.  The host gets the free points;
     `expand` (device) or a host-side re-evaluation of the derived points rebuilds full records where they are wanted."""
     p = dp.program
     n = targets_host.shape[0]
     h_t = torch.as_tensor(targets_host).pin_memory()
     slots = []
-    for _ in range(2):
+    n_slots = 3
+    for _ in range(n_slots):
         stream = torch.cuda.Stream(device)
         with torch.cuda.stream(stream):
             d_t = torch.empty_like(h_t, device=device)
-            d_free = torch.empty((n, p.n_free, 3), dtype=torch.float64, device=device)
-            d_info = torch.empty((n, 40), dtype=torch.uint8, device=device)
+            # free coordinates and info records side by side in ONE device buffer and one pinned host buffer: one D2H copy
+            free_bytes = n * p.n_free * 24
+            d_blob = torch.empty(free_bytes + n * 40, dtype=torch.uint8, device=device)
+            d_free = d_blob[:free_bytes].view(torch.float64).view(n, p.n_free, 3)
+            d_info = d_blob[free_bytes:].view(n, 40)
             launch = dp.plan(d_t, out=d_free, info_out=d_info, output="free", **cold_kw)
-        slots.append(dict(stream=stream, d_t=d_t, d_free=d_free, d_info=d_info, launch=launch,
-                          h_free=torch.empty((n, p.n_free, 3), dtype=torch.float64).pin_memory(),
-                          h_info=torch.empty((n, 40), dtype=torch.uint8).pin_memory(), done=torch.cuda.Event()))
+        h_blob = torch.empty(free_bytes + n * 40, dtype=torch.uint8).pin_memory()
+        slots.append(dict(stream=stream, d_t=d_t, d_blob=d_blob, launch=launch, h_blob=h_blob,
+                          h_free=h_blob[:free_bytes].view(torch.float64).view(n, p.n_free, 3), h_info=h_blob[free_bytes:].view(n, 40),
+                          done=torch.cuda.Event()))
+
+    def body(slot):
+        slot["d_t"].copy_(h_t, non_blocking=True)
+        slot["launch"]()
+        slot["h_blob"].copy_(slot["d_blob"], non_blocking=True)
+
+    # One HIP graph per buffer set (H2D, the solve launch through the C-ABI, two D2H copies): replaying it costs the host
+    # one call instead of four stream operations, which is what bounds a ~70 us sweep from Python.  Falls back to plain
+    # stream operations when the capture is refused.
+    how = "hip graph replay per sweep"
+    try:
+        for slot in slots:
+            with torch.cuda.stream(slot["stream"]):
+                body(slot)   # warm: nothing of the first launch (lazy loads) inside the capture
+            slot["stream"].synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=slot["stream"]):
+                body(slot)
+            slot["graph"] = graph
+    except Exception as exc:  # pragma: no cover - depends on the runtime
+        how = f"stream operations (graph capture refused: {type(exc).__name__})"
+        for slot in slots:
+            slot.pop("graph", None)
 
     def issue(slot):
-        with torch.cuda.stream(slot["stream"]):
-            slot["d_t"].copy_(h_t, non_blocking=True)
-            slot["launch"]()
-            slot["h_free"].copy_(slot["d_free"], non_blocking=True)
-            slot["h_info"].copy_(slot["d_info"], non_blocking=True)
-            slot["done"].record()
+        if "graph" in slot:
+            slot["graph"].replay()
+            slot["done"].record(slot["stream"])
+        else:
+            with torch.cuda.stream(slot["stream"]):
+                body(slot)
+                slot["done"].record()
 
-    for k in range(4):
-        issue(slots[k % 2])
+    for k in range(2 * n_slots):
+        issue(slots[k % n_slots])
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for k in range(steps):
-        slot = slots[k % 2]
-        slot["done"].synchronize()   # the host owns this slot's buffers again (the sweep before last)
+        slot = slots[k % n_slots]
+        slot["done"].synchronize()   # the host owns this slot's buffers again (n_slots sweeps ago)
         issue(slot)
     torch.cuda.synchronize(device)
     wall = (time.perf_counter() - t0) / steps
     ok = bool(np.all((slots[0]["h_info"].numpy().view(INFO_FIELDS).reshape(-1)["flags"] & 7) == 1))
     return {"value": n / wall, "ms_per_sweep": wall * 1e3, "bytes_h2d": int(h_t.numel() * 8),
-            "bytes_d2h": int(n * (p.n_free * 24 + 40)), "all_converged": ok,
-            "note": "output = free coordinates, two buffer sets on two streams (D2H of one sweep under the next one's H2D + solve), "
+            "bytes_d2h": int(n * (p.n_free * 24 + 40)), "all_converged": ok, "host_side": how,
+            "note": "output = free coordinates, three buffer sets on three streams (D2H of one sweep under the next ones' H2D + solve), "
                     "pinned host buffers; never reported as `value`"}
 
 
