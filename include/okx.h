@@ -199,7 +199,14 @@ typedef struct okx_info {
                              configuration, typically a compromise point just beyond kinematic
                              lock-out whose residual is still inside residual_tolerance.  The
                              minimiser is only defined to ~cond(J) * eps * |x| there: advisory.
-                             (quad kernel and the one-problem-per-wavefront interpreter)   */
+                             (quad kernel and the one-problem-per-wavefront interpreter).  Pair-mode kernels
+                             test the halves' pivots and the stiffness of the mode their joining row ties
+                             together.  The generated kernels test, beside the pivots (lower bounds of the
+                             smallest eigenvalue), the Rayleigh quotient of the last step in J^T J + lambda I less
+                             lambda (an upper bound, close where J is singular): a singular direction spread
+                             over several pivots leaves every one of them well above the damping.  A solve that
+                             ends on the ftol test while missing its rows by more than 1 % of
+                             residual_tolerance (a compromise point) sets it as well.                       */
   int32_t reserved;
 } okx_info;
 

@@ -1446,7 +1446,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     g.out += (ch ? pass_chain : pass_cold).eval;
     mark(2);
     g.f("    const double Ft = 0.5 * ss;");
-    g.f("    bool accept = true, stop = false;");
+    g.f("    bool accept = true, stop = false, compromise = false;");
     g.f("    double rho = 1.0;");
     g.f("    if (mode == 1) {");
     g.f("      const bool finite = Ft == Ft && step_len == step_len && Ft < 1e300;");
@@ -1454,7 +1454,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     g.f("      rho = (finite && pred > 0.0) ? (Fc - Ft) * fast_rcp(pred) : -1.0;");
     g.f("      accept = rho > 1e-4 || small;");
     g.f("      if (finite && step_len <= a.step_tol) { accept = small; stop = true; }");
-    g.f("      else if (accept && finite && Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) stop = true;");
+    g.f("      else if (accept && finite && Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) { stop = true; compromise = true; }");
     g.f("    }");
     g.f("    double diag = 0.0, gm = 0.0;");
     g.f("    if (wave_any(mode == 0)) {");
@@ -1471,6 +1471,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     g.f("    if (!done) {");
     g.f("      ++nfev;");
     g.f("      if (stop) flags |= INFO_CONVERGED;");
+    // a solve that ends on the cost test without meeting its rows sits at a compromise point (okx_quadgen.cpp): advisory bit
+    g.f("      if (compromise && mres_new > 0.01 * a.residual_tolerance) flags |= INFO_ILL_CONDITIONED;");
     g.f("      if (accept) {");
     g.f("        if (mode != 2) {");
     for (int i = 0; i < n; ++i) g.f("          x%d = %s;", i, PF(i).c_str());
@@ -1502,14 +1504,17 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     mark(4);
     g.out += (ch ? pass_chain : pass_cold).subst;
     mark(5);
-    g.f("    double sl = 0.0, pr = 0.0;");
+    g.f("    double sl = 0.0, pr = 0.0, dd = 0.0;");
     for (int i = 0; i < n; ++i) g.f("    sl = fmax(sl, fabs(nx%d));", i);
-    for (int i = 0; i < n; ++i) g.f("    pr = fma(nx%d, fma(lambda, nx%d, -%s), pr);", i, i, LGen::gn(i).c_str());
+    for (int i = 0; i < n; ++i) g.f("    pr = fma(nx%d, fma(lambda, nx%d, -%s), pr); dd = fma(nx%d, nx%d, dd);", i, i, LGen::gn(i).c_str(), i, i);
     g.f("    pr = 0.5 * pr;");
+    // Rayleigh quotient of the step in J^T J + lambda I, less lambda: an upper bound of what the damping did not put on the
+    // weakest direction (okx_quadgen.cpp); joins the pivots in the conditioning test
+    g.f("    const double rq = dd > 0.0 ? (2.0 * pr - lambda * dd) * fast_rcp(dd) - lambda : 1e300;");
     g.f("    if (solve_now) {");
     g.f("      ++iters;");
     g.f("      if (ok) {");
-    g.f("        piv_lo = pmin - lambda; piv_hi = pmax;");
+    g.f("        piv_lo = fmin(pmin - lambda, rq); piv_hi = pmax;");
     for (int i = 0; i < n; ++i) g.f("        dx%d = nx%d;", i, i);
     g.f("        step_len = sl; pred = pr;");
     g.f("        if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");

@@ -1768,7 +1768,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.out += couple_eval;
   g.f("    const double Ft = 0.5 * ss;");
   // LM decision (mirrors okx_solve_kernel)
-  g.f("    bool accept = true, stop = false;");
+  g.f("    bool accept = true, stop = false, compromise = false;");
   g.f("    double rho = 1.0;");
   g.f("    if (mode == 1) {");
   g.f("      const bool finite = Ft == Ft && step_len == step_len && Ft < 1e300;");
@@ -1776,7 +1776,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      rho = (finite && pred > 0.0) ? (Fc - Ft) * fast_rcp(pred) : -1.0;");
   g.f("      accept = rho > 1e-4 || small;");
   g.f("      if (finite && step_len <= a.step_tol) { accept = small; stop = true; }");
-  g.f("      else if (accept && finite && Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) stop = true;");
+  g.f("      else if (accept && finite && Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) { stop = true; compromise = true; }");
   g.f("    }");
   g.f("    double diag = 0.0, gm = 0.0;");
   g.f("    if (wave_any(mode == 0)) {  // largest diagonal entry scales the first damping");
@@ -1792,6 +1792,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    if (!done) {");
   g.f("      ++nfev;");
   g.f("      if (stop) flags |= INFO_CONVERGED;");
+  // A solve that ends on the cost test (no further reduction, actual or predicted) WITHOUT meeting its rows to a hundredth
+  // of the acceptance tolerance sits at a compromise point: a local minimum with a residual, i.e. beyond kinematic
+  // lock-out, where J is singular.  The pivot / Rayleigh tests cannot certify that while the damping is above the weak
+  // direction's curvature (rocker axle in rebound just beyond lock-out: cond(J) 9.6e8, smallest pivot 1.9 lambda), so the
+  // ending itself raises the advisory bit.
+  g.f("      if (compromise && mres_new > 0.01 * a.residual_tolerance) flags |= INFO_ILL_CONDITIONED;");
   g.f("      if (accept) {");
   g.f("        if (mode != 2) {");
   for (int F = 0; F < nf; ++F) g.f("          x%d = p%d;", F, ev.fp(F));
@@ -1873,16 +1879,36 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g), sm_s = qsum(cu * ny%d);", FU, FU);
     g.f("    const double sm_k = (xq(sm_s) - sm_gp * sm_s) * fast_rcp(1.0 - sm_g * sm_gp);");
     for (int F = 0; F < nf; ++F) g.f("    const double nx%d = fma(-nz%d, sm_k, ny%d);", F, F, F);
+    // Conditioning of the COUPLED system.  Each half was regularised with its own part of the joining row (Dt = D + w w^T,
+    // |w| = 1), so the halves' pivots say nothing about the one mode the joining row ties together: both joined points
+    // moving along w.  With s = w^T D^-1 w of a half (the compliance of that half along w), g = w^T Dt^-1 w = s / (1 + s),
+    // so 1 / s = (1 - g) / g, and the stiffness of the tied mode is the two halves' in parallel: (1 - g_L) / g_L +
+    // (1 - g_R) / g_R.  It joins the pivots in the ill-conditioned test (and in the predicted-convergence bound).
+    // With damping each half's share is at least lambda (s <= 1 / lambda), so what the damping did not put there is
+    // kc - 2 lambda; `pcoup` carries it to the conditioning test, kc itself bounds the predicted convergence with the pivots.
+    g.f("    const double kc = (1.0 - sm_g) * fast_rcp(sm_g) + (1.0 - sm_gp) * fast_rcp(sm_gp);");
+    g.f("    const double pcoup = fmax(kc - 2.0 * lambda, 0.0);");
+    g.f("    pmin = fmin(pmin, fmax(kc, 0.0));");
   }
-  g.f("    double sl = 0.0, pr = 0.0;");
+  g.f("    double sl = 0.0, pr = 0.0, dd = 0.0;");
   for (int F = 0; F < nf; ++F) g.f("    sl = fmax(sl, fabs(nx%d));", F);
   g.f("    sl = PMAX(sl);");
-  for (int F = 0; F < nf; ++F) g.f("    pr = fma(nx%d, fma(lambda, nx%d, -gn%d), pr);", F, F, F);
+  for (int F = 0; F < nf; ++F) g.f("    pr = fma(nx%d, fma(lambda, nx%d, -gn%d), pr); dd = fma(nx%d, nx%d, dd);", F, F, F, F, F);
   g.f("    pr = 0.5 * PSUM(pr);  // predicted cost reduction of this step (gain-ratio denominator)");
+  // Rayleigh quotient of the step in the damped matrix M = J^T J + lambda I: dx^T M dx / dx^T dx = -dx.g / |dx|^2, an UPPER
+  // bound of M's smallest eigenvalue - and, since dx = -M^-1 g amplifies the weakest direction most, a close one where J
+  // is (nearly) singular.  The pivots bound that eigenvalue from below only (every pivot >= lambda_min(M)): a singular
+  // direction spread over several pivots leaves all of them well above the damping (rocker axle in rebound just beyond
+  // lock-out: cond(J) 8.6e8, smallest pivot 8.7e-6 above lambda).  rq = quotient - lambda joins the conditioning test.
+  g.f("    dd = PSUM(dd);");
+  g.f("    const double rq = dd > 0.0 ? (2.0 * pr - lambda * dd) * fast_rcp(dd) - lambda : 1e300;");
   g.f("    if (solve_now) {");
   g.f("      ++iters;");
   g.f("      if (ok) {");
-  g.f("        piv_lo = pmin - lambda; piv_hi = pmax;  // what the damping did not put there");
+  if (pv) {
+    g.f("        piv_lo = fmin(fmin(pmin - lambda, pcoup), rq); piv_hi = pmax;  // what the damping did not put there (halves' pivots, tied mode, Rayleigh bound)");
+  }
+  else g.f("        piv_lo = fmin(pmin - lambda, rq); piv_hi = pmax;  // what the damping did not put there (pivots, Rayleigh bound)");
   for (int F = 0; F < nf; ++F) g.f("        dx%d = nx%d;", F, F);
   g.f("        step_len = sl; pred = pr;");
   g.f("        if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
@@ -1997,6 +2023,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    }");
   g.f("    if (valid && c == 0%s) {", pv ? " && !q1" : "");
   g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
+  if (getenv("OKX_PAIR_DEBUG_PIV")) g.f("      inf.cost = piv_hi; inf.last_step = piv_lo;  // (diagnostic build)");
   g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
   g.f("      a.info[bb] = inf;");
   g.f("    }");
