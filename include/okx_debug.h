@@ -56,6 +56,10 @@ int32_t okx_debug_plan_stats(const okx_program_desc* desc, int32_t* out8);
  * object's metadata (no device needed; compiles into the kernel cache like okx_precompile): 0 = nothing spilt. */
 int32_t okx_debug_kernel_scratch(const okx_program_desc* desc, int32_t* scratch_bytes);
 
+/* The same for the lane kernel: out3 = (scratch bytes of the independent-solve bodies, of the chain bodies, emission
+ * variant kept by the build). */
+int32_t okx_debug_lane_scratch(const okx_program_desc* desc, int32_t* out3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,6 +56,7 @@ DEBUG_EXPORTS = (
     "okx_debug_phase_profile",
     "okx_debug_plan_stats",
     "okx_debug_kernel_scratch",
+    "okx_debug_lane_scratch",
 )
 
 _lib = None
@@ -107,6 +108,8 @@ def load() -> C.CDLL:
     lib.okx_debug_plan_stats.restype = i32
     lib.okx_debug_kernel_scratch.argtypes = [C.POINTER(ProgramDesc), C.POINTER(i32)]
     lib.okx_debug_kernel_scratch.restype = i32
+    lib.okx_debug_lane_scratch.argtypes = [C.POINTER(ProgramDesc), C.POINTER(i32)]
+    lib.okx_debug_lane_scratch.restype = i32
     lib.okx_debug_quad_trace.argtypes = [vp, vp, i64]
     lib.okx_debug_quad_trace.restype = i32
     lib.okx_debug_phase_profile.argtypes = [vp, C.POINTER(SolveOpts), i64, vp, vp, vp, vp, vp]

@@ -337,13 +337,9 @@ void attach_lane_kernel(okx_program* p) {
       return;
     }
   }
-  std::string src, why, code, err;
-  if (!okx::lane_generate(p->host, &src, &why)) {
+  std::string src, why, code;
+  if (!okx::lane_build(p->host, &src, &code, &why)) {
     std::snprintf(p->lane_note, sizeof(p->lane_note), "not generated: %.200s", why.c_str());
-    return;
-  }
-  if (!okx::quad_compile(src, &code, &err)) {
-    std::snprintf(p->lane_note, sizeof(p->lane_note), "compile failed: %.200s", err.c_str());
     return;
   }
   // A body that spills is only worth having while the spill is small.  Measured on MI355X: the double wishbone's
@@ -363,7 +359,7 @@ void attach_lane_kernel(okx_program* p) {
   hipError_t e = hipModuleLoadData(&mod, code.data());
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    if (okx::quad_compile(src, &code, &err, true)) e = hipModuleLoadData(&mod, code.data());
+    if (okx::lane_build(p->host, &src, &code, &why, true)) e = hipModuleLoadData(&mod, code.data());
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -602,9 +598,9 @@ int32_t okx_precompile(const okx_program_desc* desc) {
     rc = fail(why.compare(0, 14, "compile failed") == 0 ? OKX_ERR_DEVICE : OKX_ERR_LIMIT, "no quad kernel for this program: %s", why.c_str());
   if (rc == OKX_OK && tmp->n_free <= okx::kQuadMaxFree) {
     // the lane kernel of the same program (programs it does not fit simply have none)
-    std::string lsrc, lwhy, lcode, lerr;
-    if (okx::lane_generate(*tmp, &lsrc, &lwhy) && !okx::quad_compile(lsrc, &lcode, &lerr))
-      rc = fail(OKX_ERR_DEVICE, "lane kernel: compile failed: %s", lerr.c_str());
+    std::string lsrc, lwhy, lcode;
+    if (okx::lane_generate(*tmp, &lsrc, &lwhy, 0) && !okx::lane_build(*tmp, &lsrc, &lcode, &lwhy))
+      rc = fail(OKX_ERR_DEVICE, "lane kernel: %s", lwhy.c_str());
   }
   delete tmp;
   return rc;
@@ -623,6 +619,25 @@ int32_t okx_debug_kernel_scratch(const okx_program_desc* desc, int32_t* scratch_
   delete tmp;
   if (rc != OKX_OK) return rc;
   *scratch_bytes = okx::quad_code_scratch_bytes(code, "okx_quad_solve");
+  return OKX_OK;
+}
+
+/* The lane kernel of a program as okx_precompile / okx_program_create would build it: scratch bytes of its independent-solve
+   and chain bodies and the emission variant lane_build kept (out3; no device needed). */
+int32_t okx_debug_lane_scratch(const okx_program_desc* desc, int32_t* out3) {
+  if (!out3) return fail(OKX_ERR_INVALID, "null output pointer");
+  okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
+  if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
+  int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
+  std::string src, why, code;
+  int variant = -1;
+  if (rc == OKX_OK && !okx::lane_build(*tmp, &src, &code, &why, false, &variant))
+    rc = fail(OKX_ERR_LIMIT, "no lane kernel for this program: %s", why.c_str());
+  delete tmp;
+  if (rc != OKX_OK) return rc;
+  out3[0] = okx::quad_code_scratch_bytes(code, "okx_lane_solve");
+  out3[1] = okx::quad_code_scratch_bytes(code, "okx_lane_chain");
+  out3[2] = variant;
   return OKX_OK;
 }
 

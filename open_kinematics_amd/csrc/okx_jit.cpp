@@ -198,6 +198,52 @@ int quad_code_scratch_bytes(const std::string& code, const char* prefix) {
   return best;
 }
 
+bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::string* why, bool ignore_cached, int* variant_out) {
+  std::string src0, err;
+  if (!lane_generate(P, &src0, why, 0)) return false;
+  char name[64];
+  std::snprintf(name, sizeof(name), "/okxl_%016llx.lanevar", fnv1a(src0));
+  const std::string memo = cache_dir() + name;
+  const bool no_cache = getenv("OKX_KERNEL_NOCACHE") != nullptr;
+  int first = 0, last = lane_variant_count() - 1;
+  if (const char* env = getenv("OKX_LANE_VARIANT")) first = last = atoi(env);  // (experiment switch: one variant only)
+  else if (!no_cache) {
+    std::string text;
+    if (read_file(memo, &text)) {
+      const int v = atoi(text.c_str());
+      if (v >= 0 && v < lane_variant_count()) first = last = v;
+    }
+  }
+  int best = -1, best_scratch = 1 << 30;
+  std::string best_src, best_code;
+  for (int v = first; v <= last; ++v) {
+    std::string s1, c1, w1;
+    if (v == 0) s1 = src0;
+    else if (!lane_generate(P, &s1, &w1, v)) continue;
+    if (!quad_compile(s1, &c1, &err, ignore_cached)) {
+      if (best < 0) *why = "compile failed: " + err;
+      continue;
+    }
+    const int scratch = quad_code_scratch_bytes(c1, "okx_lane_solve");
+    if (scratch >= 0 && scratch < best_scratch) {
+      best = v;
+      best_scratch = scratch;
+      best_src.swap(s1);
+      best_code.swap(c1);
+    }
+    if (best_scratch == 0) break;
+  }
+  if (best < 0) return false;
+  if (first != last && !no_cache) {
+    (void)mkdir(cache_dir().c_str(), 0777);
+    write_file_atomic(memo, std::to_string(best) + "\n");
+  }
+  *src = best_src;
+  *code = best_code;
+  if (variant_out) *variant_out = best;
+  return true;
+}
+
 bool quad_build(const DevProgram& P, int waves_per_simd, std::string* src, std::string* code, std::string* why,
                 bool ignore_cached) {
   std::string err;

@@ -1095,7 +1095,19 @@ DEV double unpark(int lo, int hi) {
 
 }  // namespace
 
-bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
+int lane_variant_count() { return 8; }
+
+bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant) {
+  // Emission variants: the same arithmetic in the same order, differing only in hints to the compiler (opaque uses after
+  // each row, a redefinition of the factorisation's inputs at its top, where the scheduling barriers of the factorisation
+  // sit, whether the diagonal is assembled late).  The register allocator's result for an 18-unknown program sits at the
+  // edge of the 512-register file and is not monotonic in any of them (0 ... 250 B of scratch across these for the double
+  // wishbone), so lane_build (okx_jit.cpp) compiles them in this order and keeps the first one that does not spill.
+  static const struct { bool pin, launder, late_diag; int col_fence; } kVariants[8] = {
+      {false, false, false, 3}, {true, true, false, 3}, {false, true, false, 3}, {true, false, false, 3},
+      {false, false, false, 1}, {false, false, false, 6}, {false, false, true, 3}, {false, false, false, 0}};
+  if (variant < 0 || variant >= lane_variant_count()) variant = 0;
+  const auto& V = kVariants[variant];
   if (P.n_free > kLaneMaxFree) {
     *why = "more than " + std::to_string(kLaneMaxFree) + " free points: the lower triangle of J^T J does not fit one lane's registers";
     return false;
@@ -1117,9 +1129,10 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
     // (experiment switches.  Measured on the double wishbone, scratch bytes of the independent-solve bodies _u / _g:
     //  pins + launder 0 / 188, pins only 160 / -, launder only 96 / 96, neither 0 / 0.  The register allocator's result
     //  is not monotonic in anything; tools/lane_isa.sh + tools/lane_meta.py show it in ten seconds.)
-    gen.pin_acc = getenv("OKX_LANE_PIN") != nullptr;
+    gen.pin_acc = V.pin || getenv("OKX_LANE_PIN") != nullptr;
     gen.hard_fence = getenv("OKX_LANE_HARD_FENCE") != nullptr;
-    gen.launder = getenv("OKX_LANE_LAUNDER") != nullptr;
+    gen.launder = V.launder || getenv("OKX_LANE_LAUNDER") != nullptr;
+    gen.col_fence = V.col_fence;
     if (const char* env = getenv("OKX_LANE_COL_FENCE")) gen.col_fence = atoi(env);
     if (const char* env = getenv("OKX_LANE_RESIDENT_ROWS")) gen.resident_rows = atoi(env);
     for (int e = 0; e < P.n_derived; ++e) gen.dp(e);
@@ -1158,7 +1171,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why) {
   evc.j_lds_slots = cold_j_slots;
   evc.l_lds_base = kColdStateSlots + cold_j_slots;
   evc.l_lds_slots = cold_l_slots;
-  evc.late_diag = getenv("OKX_LANE_LATE_DIAG") != nullptr;  // (measured: 200 / 264 B of scratch against 104 / 192 B: not kept)
+  evc.late_diag = V.late_diag || getenv("OKX_LANE_LATE_DIAG") != nullptr;
   if (!make_pass(evc, &pass_cold) || !evc.hoisted.empty()) {
     *why = evc.why.empty() ? "pass generation is not reproducible" : evc.why;
     return false;

@@ -121,7 +121,15 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
 // Emits the HIP source of the LANE kernel specialised to `P` (okx_lanegen.cpp): one lane per problem, 64 problems per
 // wavefront, for batches that fill the chip several times over.  Kernels okx_lane_solve_u/_g (arguments: QuadArgs) and
 // okx_lane_eval (QuadEvalArgs).  Returns false (and says why) when the program does not fit one lane's registers.
-bool lane_generate(const DevProgram& P, std::string* src, std::string* why);
+// `variant` in [0, lane_variant_count()): the same arithmetic with other hints to the compiler (see lane_build).
+bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant = 0);
+int lane_variant_count();
+// lane_generate + quad_compile over the emission variants: keeps the first variant whose independent-solve bodies
+// (okx_lane_solve_*) do not spill, else the one that spills least.  The choice is remembered next to the code objects
+// (<hash of variant 0's source>.lanevar in the kernel cache), so a later call compiles nothing.  `variant_out` (may be
+// null) receives the variant kept.
+bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::string* why, bool ignore_cached = false,
+                int* variant_out = nullptr);
 
 // Compiles `src` for gfx950 with hiprtc (no device needed) or fetches it from the on-disk cache
 // (<dir of libokx.so>/_kcache/<hash>.okxc, override with OKX_KERNEL_CACHE).  Returns the code

@@ -69,3 +69,18 @@ def test_programs_beyond_six_free_points_have_no_lane_kernel(golden):
     assert lib.okx_lane_source(host.byref(), None, 0) == -2  # OKX_ERR_LIMIT
     assert "free points" in _lib.last_error()
     assert lib.okx_precompile(host.byref()) == 0  # the quad kernel alone is precompiled then
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid", "c5_ensemble"])
+def test_independent_solve_bodies_of_the_baseline_programs_do_not_spill(golden, name):
+    """The lane kernel sits at the edge of the 512-register file: lane_build compiles its emission variants until one keeps
+    the independent-solve bodies out of scratch (in-tree cache after build()).  The chain bodies of the 18-unknown double
+    wishbone still spill (auto selection keeps the quad kernel's chains for it)."""
+    _, program = golden(name)
+    lib = _lib.load()
+    host = _abi.HostProgram(program.with_line_mode("pinned"))
+    out = (C.c_int32 * 3)()
+    assert lib.okx_debug_lane_scratch(host.byref(), out) == 0, _lib.last_error()
+    assert out[0] == 0, f"independent-solve bodies spill {out[0]} B (variant {out[2]})"
+    if name == "c4_macpherson_grid":
+        assert out[1] == 0
