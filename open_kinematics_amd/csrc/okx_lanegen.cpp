@@ -1222,7 +1222,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // first-step table layout (shared with okx_quadgen.cpp: quad_head_stride)
   const int HK = T + 1;
   const int head_off = 4 * nf * HK + 2 * HK * HK;
-  const int head_stride = head_off + 8;
+  const int head_s_off = head_off + 8;                                   // second-order vectors S_st, [pair][F][4]
+  const int head_stride = head_s_off + 4 * nf * (HK - 1) * HK / 2;
 
   // the fixed points are chain constants too (macros p{k}_{c} -> cl[...])
   for (int p = 0; p < NP; ++p)
@@ -1333,12 +1334,24 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
     g.f("      const double hr0 = 1.0;");
     for (int k = 1; k < HK; ++k) g.f("      const double hr%d = td%d - tn%d;", k, k - 1, k - 1);
+    // first-order step d1 and, when the table carries them (scalar 6), the second-order correction
+    // d2 = -1/2 sum_st w_s w_t S_st (okx_quadgen.cpp, okx_quad_head_*), taken while 2 |d2| <= 0.75 |d1|
+    g.f("      double hst1 = 0.0, hst2 = 0.0;");
     for (int i = 0; i < n; ++i) {
-      std::string e;
+      std::string e, e2;
       for (int k = 0; k < HK; ++k)
         e += (k ? " + hr" : "hr") + std::to_string(k) + " * hp[" + std::to_string(4 * (k * nf + i / 3) + i % 3) + "]";
-      g.f("      { const double hx = -(%s); dx%d = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", e.c_str(), i);
+      int pi = 0;
+      for (int s2 = 1; s2 < HK; ++s2)
+        for (int t2 = s2; t2 < HK; ++t2, ++pi)
+          e2 += (pi ? " + " : "") + std::string(s2 == t2 ? "0.5" : "1.0") + " * hr" + std::to_string(s2) + " * hr" + std::to_string(t2) + " * hp[" +
+                std::to_string(head_s_off + 4 * (pi * nf + i / 3) + i % 3) + "]";
+      g.f("      const double hxa%d = -(%s), hxb%d = -(%s);", i, e.c_str(), i, e2.c_str());
+      g.f("      hst1 = fmax(hst1, fabs(hxa%d)); hst2 = fmax(hst2, fabs(hxb%d));", i, i);
     }
+    g.f("      const double hw2 = (hp[%d] > 0.5 && hst2 <= 0.375 * hst1) ? 1.0 : 0.0;", head_off + 6);
+    for (int i = 0; i < n; ++i)
+      g.f("      { const double hx = fma(hw2, hxb%d, hxa%d); dx%d = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", i, i, i);
     for (int j = 0; j < HK; ++j)
       for (int k = j; k < HK; ++k)
         g.f("      hM = fma(%shr%d * hr%d, hp[%d], hM);", j == k ? "" : "2.0 * ", j, k, head_off - 2 * HK * HK + j * HK + k);
@@ -1500,7 +1513,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("          }");
     g.f("          else if (mode == 1 && rho > 1e-4) {");
     g.f("            const double t = 2.0 * rho - 1.0;");
-    g.f("            lambda *= rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t);");
+    g.f("            lambda *= (rho > 0.99 && (step_len <= 1.0 || Ft <= 1e-2)) ? 1e-3 : (rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t));");
     g.f("          }");
     g.f("          if (a.grad_tol > 0.0 && gm <= a.grad_tol) { flags |= INFO_CONVERGED; stop = true; }");
     g.f("        }");
@@ -1532,7 +1545,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("        step_len = sl; pred = pr;");
     g.f("        if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
     g.f("        else {");
-    g.f("          const double cq = prev_sl > 0.0 ? fmax(100.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
+    g.f("          const double cq = prev_sl > 0.0 ? fmax(3.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
     g.f("          const double rho_lin = 100.0 * lambda * fast_rcp(pmin);");
     g.f("          want_light = sl <= 1e-3 && (rho_lin + cq * sl) * sl <= a.step_tol;");
     g.f("          prev_sl = sl;");

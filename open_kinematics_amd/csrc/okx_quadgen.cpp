@@ -27,6 +27,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <set>
 #include <string>
@@ -792,20 +793,29 @@ class Gen {
   void mark(int n) {
     if (marks) f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + n);
   }
+  // jtv_rhs non-empty: only J^T v is formed, for every listed right-hand side q (v_i = the variable {q}{i}, result
+  // {q}g{F}): the second Jacobian pass of the first-step table's second-order terms (okx_quad_head_*).
+  std::vector<std::string> jtv_rhs;
+  std::function<std::string(int, int)> jtv_value;  // (rhs index, row) -> expression of v_i, read where the row is
+  bool jtv_only = true;                            // false: the normal evaluation AND the extra J^T v accumulations
   bool emit_rows() {
     const int nf = P.n_free;
+    const bool jtv = !jtv_rhs.empty() && jtv_only;
     for (int F = 0; F < nf; ++F) {
-      f("    double gn%d = 0.0;", F);
+      for (const std::string& q : jtv_rhs) f("    double %sg%d = 0.0;", q.c_str(), F);
+      if (!jtv) f("    double gn%d = 0.0;", F);
       nz[F][F] = true;
     }
-    f("    double ss = 0.0, mres_new = 0.0;");
+    if (!jtv) f("    double ss = 0.0, mres_new = 0.0;");
     std::set<std::string> declared;
     for (int i = 0; i < P.m; ++i) {
       RowOut ro;
       mark(1);
       if (!row(i, &ro)) return false;
+      if (!jtv) {
       f("    ss = fma(%s, %s, ss);", ro.r.c_str(), ro.r.c_str());
       if (!ro.absres.empty()) f("    mres_new = fmax(mres_new, %s);", ro.absres.c_str());
+      }
       mark(2);
       // point partials -> free blocks
       std::map<int, std::vector<LV>> terms;
@@ -850,6 +860,12 @@ class Gen {
           jv.push_back({kv.first, {t, 1}});
         }
       }
+      for (size_t qi = 0; qi < jtv_rhs.size(); ++qi) {
+        const std::string& q = jtv_rhs[qi];
+        if (jtv_value) f("    const double %s%d = %s;", q.c_str(), i, jtv_value((int)qi, i).c_str());
+        for (auto& fv : jv) f("    %sg%d = fma(%s, %s%d, %sg%d);", q.c_str(), fv.first, sx(fv.second).c_str(), q.c_str(), i, q.c_str(), fv.first);
+      }
+      if (jtv) continue;
       if (P.row_type[i] == kRowTarget) target_j[(int)P.row_param[i][3]] = jv;
       if (row_fence > 0 && (i + 1) % row_fence == 0) fence_after_row = true;
       // J^T r and J^T J (lower block triangle: F >= G)
@@ -887,7 +903,7 @@ class Gen {
       }
     }
     // diagonal blocks that no row touched still exist (as zeros)
-    for (int F = 0; F < nf; ++F)
+    for (int F = 0; F < nf && !jtv; ++F)
       for (int k = 0; k < 3; ++k)
         if (!declared.count(A(F, F, k))) f("    double %s = 0.0;", A(F, F, k).c_str());
     return true;
@@ -1174,8 +1190,8 @@ DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 int quad_head_stride(const DevProgram& program) {
   // mirrors the layout quad_generate() gives the first-step table (head_cols / head_off / head_stride there)
   if (program.n_free <= kQuadMaxFree) {
-    const int k = program.n_targets + 1;
-    return 4 * program.n_free * k + 2 * k * k + 8;
+    const int k = program.n_targets + 1, pairs = program.n_targets * (program.n_targets + 1) / 2;
+    return 4 * program.n_free * k + 2 * k * k + 8 + 4 * program.n_free * pairs;  // Q, Gram matrices, scalars, second-order S
   }
   PairView pv;
   std::string why;
@@ -1283,7 +1299,15 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   const int HK = (int)head_cols.size();
   const int head_side = 4 * nf * HK;                       // doubles of one half's Q block
   const int head_off = (pv ? 2 : 1) * head_side + 2 * HK * HK;
-  const int head_stride = head_off + 8;
+  // Second-order terms of the shared first step (single mode): S_st = (J^T J + lambda I)^-1 J^T r''(Q_s, Q_t) for the target
+  // columns s <= t, [pair][F][4] after the scalars; scalar 6 says how many pairs the table carries.
+  std::vector<std::pair<int, int>> head_pairs;
+  if (!pv && getenv("OKX_QUAD_FIRST_ORDER_HEAD") == nullptr)
+    for (int s2 = 1; s2 < HK; ++s2)
+      for (int t2 = s2; t2 < HK; ++t2) head_pairs.push_back({s2, t2});
+  const int NPAIR = (int)head_pairs.size();
+  const int head_s_off = head_off + 8;
+  const int head_stride = head_off + 8 + (pv ? 0 : 4 * nf * (HK - 1) * HK / 2);
   bool has_atan = false;
   for (int i = 0; i < P.n_crows; ++i)
     has_atan = has_atan || P.row_type[i] == OKX_ROW_ANGLE || P.row_type[i] == OKX_ROW_THREE_POINT_ANGLE;
@@ -1517,10 +1541,32 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     for (int k = 1; k < HK; ++k)
       g.f("      const double hr%d = td%d - tn%d;  // target residual of the first problem at the design state", k, head_cols[k].t, head_cols[k].t);
     g.f("      double hstep = 0.0, hN = 0.0, hM = 0.0, hss = hs2, hmr = hs3;");
+    if (NPAIR > 0) {
+      // first-order step d1 and the second-order correction d2 = -1/2 sum_st w_s w_t S_st (see okx_quad_head_*); d2 is
+      // taken while it is a correction, 2 |d2| <= 0.75 |d1| (Transtrum & Sethna's acceptance rule)
+      g.f("      const double hs6 = hp[%d];", head_off + 6);
+      g.f("      double hst1 = 0.0, hst2 = 0.0;");
+      for (int F = 0; F < nf; ++F) {
+        std::string e, e2;
+        for (int k = 0; k < HK; ++k) e += (k ? " + hr" : "hr") + std::to_string(k) + " * hq" + std::to_string(k) + "_" + std::to_string(F);
+        for (int pi = 0; pi < NPAIR; ++pi) {
+          const int s2 = head_pairs[pi].first, t2 = head_pairs[pi].second;
+          e2 += (pi ? " + " : "") + std::string(s2 == t2 ? "0.5" : "1.0") + " * hr" + std::to_string(s2) + " * hr" + std::to_string(t2) + " * hp[" +
+                std::to_string(head_s_off + 4 * (pi * nf + F)) + " + c]";
+        }
+        g.f("      const double hxa%d = -(%s), hxb%d = -(%s);", F, e.c_str(), F, e2.c_str());
+        g.f("      hst1 = fmax(hst1, fabs(hxa%d)); hst2 = fmax(hst2, fabs(hxb%d));", F, F);
+      }
+      g.f("      hst1 = PMAX(hst1); hst2 = PMAX(hst2);");
+      g.f("      const double hw2 = (hs6 > 0.5 && hst2 <= 0.375 * hst1) ? 1.0 : 0.0;");
+      for (int F = 0; F < nf; ++F)
+        g.f("      { const double hx = fma(hw2, hxb%d, hxa%d); hxl[%d + lane] = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", F, F, 64 * F);
+    } else {
     for (int F = 0; F < nf; ++F) {
       std::string e;
       for (int k = 0; k < HK; ++k) e += (k ? " + hr" : "hr") + std::to_string(k) + " * hq" + std::to_string(k) + "_" + std::to_string(F);
       g.f("      { const double hx = -(%s); hxl[%d + lane] = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", e.c_str(), 64 * F);
+    }
     }
     g.f("      hstep = PMAX(hstep); hN = PSUM(hN);");
     for (int j = 0; j < HK; ++j)
@@ -1816,10 +1862,14 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("          }");
   g.f("          else if (mode == 1 && rho > 1e-4) {");
   g.f("            // Nielsen's update; a step whose gain ratio shows the quadratic model to be accurate");
-  g.f("            // (rho > 0.9) drops the damping by 10 (Marquardt) so that the final steps are");
-  g.f("            // Gauss-Newton steps without a linear contraction floor, like MINPACK's par = 0");
+  g.f("            // (rho > 0.9) drops the damping by 10 (Marquardt), one that matches it to 1 % NEAR the solution - a step");
+  g.f("            // of at most 1 mm, or rows met to ~0.1 mm (cost <= 1e-2) - by 1000 (far from the solution the collapse");
+  g.f("            // costs dozens of rejected steps: MacPherson cold starts at 99 % of the rack's reach), so that the");
+  g.f("            // final steps are Gauss-Newton steps without a linear contraction floor, like MINPACK's par = 0");
+  g.f("            // (after the second-order shared first step two such steps finish a cold start: the damping must");
+  g.f("            //  be out of the way by the second)");
   g.f("            const double t = 2.0 * rho - 1.0;");
-  g.f("            lambda *= rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t);");
+  g.f("            lambda *= (rho > 0.99 && (step_len <= 1.0 || Ft <= 1e-2)) ? 1e-3 : (rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t));");
   g.f("          }");
   g.f("          if (a.grad_tol > 0.0 && gm <= a.grad_tol) { flags |= INFO_CONVERGED; stop = true; }");
   g.f("        }");
@@ -1915,9 +1965,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("        else {");
   g.f("          // Next correction predicted as rho |dx| + C |dx|^2: the damping's linear contraction");
   g.f("          // rho = lambda / sigma_min(J^T J), bounded with the smallest pivot (x 100), plus the");
-  g.f("          // Gauss-Newton curvature term with C = 100 x the observed |dx| / |dx-|^2, or 1 / mm on a");
+  g.f("          // Gauss-Newton curvature term with C = 3 x the observed |dx| / |dx-|^2, or 1 / mm on a");
   g.f("          // problem's first step (two orders above a linkage's curvature / stiffness ratio).");
-  g.f("          const double cq = prev_sl > 0.0 ? fmax(100.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
+  g.f("          const double cq = prev_sl > 0.0 ? fmax(3.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
   g.f("          const double rho_lin = 100.0 * lambda * fast_rcp(pmin);");
   g.f("          want_light = sl <= 1e-3 && (rho_lin + cq * sl) * sl <= a.step_tol;");
   g.f("          prev_sl = sl;");
@@ -2329,6 +2379,15 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     }
     g.out += eval_src;
     g.out += couple_eval;
+    const int n_fd_dirs = NPAIR > 0 ? (HK - 1) + (HK - 1) * (HK - 2) / 2 : 0;
+    if (NPAIR > 0) {
+      // second differences of the rows per direction, [direction][row][quad] in LDS (63 quad-uniform doubles would
+      // otherwise sit in registers beside the factor); every one starts at -2 r(design state), while the r_i are at hand
+      g.f("    __shared__ double hDl[%d];", n_fd_dirs * P.m * 16);
+      g.f("    const int hdq = lane >> 2;");
+      for (int d = 0; d < n_fd_dirs; ++d)
+        for (int i = 0; i < P.m; ++i) g.f("    hDl[%d + hdq] = -2.0 * r%d;", (d * P.m + i) * 16, i);
+    }
     g.f("    double diag = 0.0;");
     for (int F = 0; F < nf; ++F)
       g.f("    diag = fmax(diag, c == 0 ? %s : (c == 1 ? %s : (c == 2 ? %s : 0.0)));", Gen::A(F, F, 0).c_str(),
@@ -2406,9 +2465,113 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         g.f("      if (valid && c == 0%s) { hs[%d] = vm; hs[%d] = vn; } }", pv ? " && !q1" : "", head_off - 2 * HK * HK + j * HK + k,
             head_off - HK * HK + j * HK + k);
       }
+    if (NPAIR > 0) {
+      // ---- second-order terms of the first step (geodesic acceleration, Transtrum & Sethna 2012): the first step
+      // d1 = -sum_k w_k Q_k is the Gauss-Newton step of the LINEARISED rows; the rows' curvature along it,
+      // r''(d1, d1) = sum_st w_s w_t r''(Q_s, Q_t), gives the correction d2 = -1/2 (J^T J + lambda I)^-1 J^T r''(d1, d1),
+      // which is a quadratic form in the weights with per-geometry coefficient vectors S_st = M^-1 J^T r''(Q_s, Q_t).
+      // r'' by central second differences of the residual vector along Q_s, Q_t and Q_s + Q_t (the constraint column's
+      // Q_0 is ~1e-6 mm: its second-order share is far below the solve's tolerance and is left out); then one more pass
+      // over the rows' gradients at the design state for J^T r'' and one substitution per pair.
+      const double kFdStep = 0.25;  // displacement of the finite differences in units of Q (mm per mm of target residual)
+      for (int F = 0; F < nf; ++F) g.f("    const double hx0_%d = p%d;", F, ev.fp(F));
+      // directions: 0 .. T-1 the target columns, then the sums of two
+      struct Dir { int s, t; };
+      std::vector<Dir> dirs;
+      for (int s2 = 1; s2 < HK; ++s2) dirs.push_back({s2, -1});
+      for (int s2 = 1; s2 < HK; ++s2)
+        for (int t2 = s2 + 1; t2 < HK; ++t2) dirs.push_back({s2, t2});
+      int uid_base = 600000;
+      for (size_t d = 0; d < dirs.size(); ++d) {
+        for (int sign = 0; sign < 2; ++sign) {
+          Gen fd(P, pv);
+          fd.uid = uid_base;
+          uid_base += 20000;
+          fd.hoisted_names = ev.hoisted_names;
+          fd.lds_constants = ev.lds_constants;
+          fd.scalars_in_regs = ev.scalars_in_regs;
+          fd.lanes_in_regs = ev.lanes_in_regs;
+          for (int idx = 0; idx < P.n_active; ++idx) (void)fd.derived_op(P.active_op[idx], false);
+          (void)fd.emit_rows_residual_only();
+          g.f("    {");
+          for (int F = 0; F < nf; ++F) {
+            if (dirs[d].t < 0)
+              g.f("    p%d = fma(%s, hQ%d_%d, hx0_%d);", ev.fp(F), sign ? "-0.25" : "0.25", dirs[d].s, F, F);
+            else
+              g.f("    p%d = fma(%s, hQ%d_%d + hQ%d_%d, hx0_%d);", ev.fp(F), sign ? "-0.25" : "0.25", dirs[d].s, F, dirs[d].t, F, F);
+          }
+          g.out += fd.out;
+          for (int i = 0; i < P.m; ++i) g.f("    hDl[%d + hdq] += r%d;", (int)(d * P.m + i) * 16, i);
+          g.f("    }");
+        }
+      }
+      (void)kFdStep;
+      // r''(Q_s, Q_t) per pair = the right-hand sides hR{pair}_{row}, formed from the LDS accumulators where the row is
+      auto dir_of = [&](int s2, int t2) {
+        for (size_t d = 0; d < dirs.size(); ++d)
+          if (dirs[d].s == s2 && dirs[d].t == t2) return (int)d;
+        return -1;
+      };
+      auto hd = [&](int d, int i) { return "hDl[" + std::to_string((d * P.m + i) * 16) + " + hdq]"; };
+      auto pair_value = [&](int pi, int i) {
+        const int s2 = head_pairs[pi].first, t2 = head_pairs[pi].second;
+        char buf[256];
+        if (s2 == t2)
+          std::snprintf(buf, sizeof(buf), "%s * %.17g", hd(dir_of(s2, -1), i).c_str(), 1.0 / (0.25 * 0.25));
+        else
+          std::snprintf(buf, sizeof(buf), "(%s - %s - %s) * %.17g", hd(dir_of(s2, t2), i).c_str(), hd(dir_of(s2, -1), i).c_str(),
+                        hd(dir_of(t2, -1), i).c_str(), 0.5 / (0.25 * 0.25));
+        return std::string(buf);
+      };
+      // J^T r'' at the design state needs the rows' gradients once more - and the substitutions the factor.  Keeping the
+      // factor alive across the six residual evaluations above costs more registers than the file has (564 B of scratch);
+      // instead the design state is evaluated and factored a second time here (one pass of ~2 k instructions, once per
+      // geometry), in a scope of its own, with J^T r'' accumulated beside J^T r.
+      g.f("    {");
+      for (int F = 0; F < nf; ++F) g.f("    p%d = hx0_%d;", ev.fp(F), F);
+      {
+        Gen jt(P, pv);
+        jt.uid = uid_base;
+        jt.hoisted_names = ev.hoisted_names;
+        jt.lds_constants = ev.lds_constants;
+        jt.scalars_in_regs = ev.scalars_in_regs;
+        jt.lanes_in_regs = ev.lanes_in_regs;
+        jt.pin_ata = ev.pin_ata;
+        jt.pin_atr = ev.pin_atr;
+        for (int pi = 0; pi < NPAIR; ++pi) jt.jtv_rhs.push_back("hR" + std::to_string(pi) + "_");
+        jt.jtv_value = pair_value;
+        jt.jtv_only = false;
+        for (int idx = 0; idx < P.n_active; ++idx) (void)jt.derived_op(P.active_op[idx], true);
+        (void)jt.emit_rows();
+        g.out += jt.out;
+        for (int F = 0; F < nf; ++F)
+          for (int G = 0; G <= F; ++G)
+            if (ev.fillf[F][G]) {
+              for (int k = 0; k < 3; ++k) {
+                if (!(F == G && k == 2)) g.f("    double %s;", Gen::Ln(F, G, k).c_str());
+                if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
+              }
+            }
+        g.out += factor_src;
+        for (int pi = 0; pi < NPAIR; ++pi) {
+          std::vector<std::string> rhs;
+          for (int F = 0; F < nf; ++F) rhs.push_back("hR" + std::to_string(pi) + "_g" + std::to_string(F));
+          ev.out.clear();
+          const std::string outn = "hS" + std::to_string(pi) + "_";
+          ev.emit_substitute(rhs, outn.c_str());
+          g.f("    {");
+          g.out += ev.out;
+          g.f("    if (valid) {");
+          for (int F = 0; F < nf; ++F) g.f("      ho[%d + c] = c < 3 ? %s%d : 0.0;", head_s_off + 4 * (pi * nf + F), outn.c_str(), F);
+          g.f("    }");
+          g.f("    }");
+        }
+      }
+      g.f("    }");
+    }
     g.f("    if (valid && c == 0%s) {", pv ? " && !q1" : "");
-    g.f("      hs[%d] = diag; hs[%d] = pmin; hs[%d] = ss; hs[%d] = mres_new; hs[%d] = ok ? 1.0 : 0.0; hs[%d] = pmax; hs[%d] = 0.0; hs[%d] = 0.0;",
-        head_off, head_off + 1, head_off + 2, head_off + 3, head_off + 4, head_off + 5, head_off + 6, head_off + 7);
+    g.f("      hs[%d] = diag; hs[%d] = pmin; hs[%d] = ss; hs[%d] = mres_new; hs[%d] = ok ? 1.0 : 0.0; hs[%d] = pmax; hs[%d] = %d.0; hs[%d] = 0.0;",
+        head_off, head_off + 1, head_off + 2, head_off + 3, head_off + 4, head_off + 5, head_off + 6, NPAIR, head_off + 7);
     g.f("    }");
     g.f("  }");
     g.f("}");

@@ -45,11 +45,12 @@ def test_cold_starts_take_the_same_path_with_one_evaluation_less(workload, line_
     assert own.accepted(io).all() and shared.accepted(ish).all()
     tol = 1e-9 if line_mode == "pinned" else 6e-8
     assert float((own.positions - shared.positions).abs().max()) <= tol
-    # exactly the own path minus its first evaluation, except where a rejected first step changes the bookkeeping
+    # the own path minus its first evaluation - and, since the table carries the second-order terms of the step
+    # (round 3), usually one more: the trial point is second-order accurate in the target displacement
     saved = io["nfev"].astype(int) - ish["nfev"].astype(int)
     if line_mode == "pinned" and workload != "axle":
-        assert np.median(saved) == 1 and saved.min() >= 0 and np.mean(saved == 1) >= 0.95
-        assert np.mean(io["iterations"] == ish["iterations"]) >= 0.95
+        assert np.median(saved) >= 1 and saved.min() >= 0 and np.mean(saved >= 1) >= 0.95
+        assert np.mean(ish["iterations"] <= io["iterations"]) >= 0.95
     elif line_mode == "pinned":  # the coupled halves take marginal accept / reject decisions differently now and then
         assert float(np.mean(saved)) >= 0.5 and saved.min() >= -2
     else:  # dozens of linearly converging passes along the valley: rounding decides the exact count
@@ -92,7 +93,7 @@ def test_chains_and_geometry_tables():
         assert float((own.positions - shared.positions).abs().max()) <= 1e-9
         heads = 48 * 64 if chain_len == 1 else 48 * (64 // 8 if chain_len == 8 else 1)
         saved = int(own.info()["nfev"].sum()) - int(shared.info()["nfev"].sum())
-        assert 0.9 * heads <= saved <= 1.1 * heads or chain_len == -1  # one evaluation per chain head
+        assert 0.9 * heads <= saved <= 2.2 * heads or chain_len == -1  # one or two evaluations per chain head
         ref = shared.positions if ref is None else ref
         assert float((ref - shared.positions).abs().max()) <= 1e-9
     # a second, larger ensemble through the same program: the scratch table grows, the results stay right

@@ -37,7 +37,8 @@ def test_predictor_gives_the_same_states_in_fewer_evaluations(workload):
     ci, pi = cold.info(), pred.info()
     assert cold.accepted(ci).all() and pred.accepted(pi).all()
     assert float((cold.positions - pred.positions).abs().max()) <= 1e-9  # north-star tolerance
-    assert pi["nfev"].mean() <= ci["nfev"].mean() - 1.0
+    # (a cold start with the second-order shared first step is itself down to ~3 evaluations: the model's margin is one)
+    assert pi["nfev"].mean() <= ci["nfev"].mean() - 0.5
     assert pi["nfev"].max() <= ci["nfev"].max()
     # a chained launch: heads (and their successors) start from the model, later steps from the secant
     chained = dp.solve(t, chain_len=8, predictor=True)
@@ -144,7 +145,7 @@ def test_two_varying_targets_on_the_double_wishbone_against_the_oracle():
         assert res.accepted(res.info()).all(), kw
         assert float((res.positions - cold.positions).abs().max()) <= 1e-9, kw
     model = dp.solve(t, chain_len=1, predictor=True).info()
-    assert model["nfev"].mean() <= cold.info()["nfev"].mean() - 1.5
+    assert model["nfev"].mean() <= cold.info()["nfev"].mean() - 0.9
     pick = np.linspace(0, grid.shape[0] - 1, 40).astype(int)
     orc = Oracle(program).sweep(grid[pick], 1e-15, 1e-15, 1e-15, warm_start=False)
     assert orc.first_failed_step == -1

@@ -72,7 +72,11 @@ def test_quad_solve_matches_oracle_wave_kernel_and_reference(golden, name):
     pos = quad.positions.cpu().numpy()
     # same LM policy, other summation order: the two device kernels agree far below the tolerance
     assert np.max(np.abs(pos - wave.positions.cpu().numpy())) <= 1e-10
-    assert np.max(np.abs(info["nfev"] - wave.info()["nfev"])) <= 1  # same policy up to the damping decay near convergence
+    # the interpreter takes its own first pass and keeps Marquardt's factor-10 decay; the generated kernels start from the
+    # second-order shared first step and drop the damping faster near the solution: never more evaluations, usually two less
+    assert np.all(info["nfev"] <= wave.info()["nfev"]) and np.median(wave.info()["nfev"] - info["nfev"]) >= 1
+    own = dp.solve(t, kernel="quad", predictor=False, shared_first_step=False)
+    assert np.max(np.abs(own.info()["nfev"].astype(int) - wave.info()["nfev"])) <= 2 and float((own.positions - quad.positions).abs().max()) <= 1e-10
     sub = slice(None, None, max(1, t.shape[0] // 64))
     orc = Oracle(pinned).sweep(arrays["targets_abs"][sub], 1e-15, 1e-15, 1e-15, warm_start=False)
     assert np.max(np.abs(pos[sub] - orc.positions)) <= 1e-9  # north-star tolerance (mm)
@@ -311,7 +315,7 @@ def test_grid_chains_with_row_wraps_match_independent_solves(workload):
             assert res.accepted(info).all(), (chain_len, predictor)
             assert float((res.positions - ref.positions).abs().max()) <= 1e-9, (chain_len, predictor)
     long_chain = dp.solve(t, chain_len=t.shape[0], predictor=False).info()
-    assert long_chain["nfev"].mean() < ref.info()["nfev"].mean() - 1.0  # extrapolation pays along the rows
+    assert long_chain["nfev"].mean() < ref.info()["nfev"].mean() - 0.3  # extrapolation pays along the rows (cold starts: ~3.6 since the second-order first step)
 
 
 def test_empty_batches_and_invalid_launches(golden):
