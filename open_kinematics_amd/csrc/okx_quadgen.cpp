@@ -1862,9 +1862,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("          }");
   g.f("          else if (mode == 1 && rho > 1e-4) {");
   g.f("            // Nielsen's update; a step whose gain ratio shows the quadratic model to be accurate");
-  g.f("            // (rho > 0.9) drops the damping by 10 (Marquardt), one that matches it to 1 % NEAR the solution - a step");
+  g.f("            // (rho > 0.9) drops the damping by 10 (Marquardt), one that matches it to a percent NEAR the solution - a step");
   g.f("            // of at most 1 mm, or rows met to ~0.1 mm (cost <= 1e-2) - by 1000 (far from the solution the collapse");
-  g.f("            // costs dozens of rejected steps: MacPherson cold starts at 99 % of the rack's reach), so that the");
+  g.f("            // costs dozens of rejected steps: MacPherson cold starts at 0.99 of the rack's reach), so that the");
   g.f("            // final steps are Gauss-Newton steps without a linear contraction floor, like MINPACK's par = 0");
   g.f("            // (after the second-order shared first step two such steps finish a cold start: the damping must");
   g.f("            //  be out of the way by the second)");
