@@ -148,3 +148,32 @@ def test_first_step_table_kernels_are_generated_where_they_pay(golden, monkeypat
     monkeypatch.delenv("OKX_PAIR_HEAD")
     monkeypatch.setenv("OKX_QUAD_NO_HEAD", "1")
     assert "okx_quad_head_u(QHeadArgs" not in _source(dw.with_line_mode("pinned"))
+
+
+def test_generated_sources_are_the_same_in_every_process(tmp_path):
+    """The kernel cache is keyed by the source text: a stray printf conversion in a generated comment once made the quad
+    source differ from process to process, and every program creation compiled its kernels afresh (2.7 s)."""
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    code = (
+        "import sys, hashlib, ctypes as C\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        "from open_kinematics_amd import _lib\n"
+        "from open_kinematics_amd._abi import HostProgram\n"
+        "from open_kinematics_amd.workloads import bump_sweep_problem, macpherson_grid_problem, axle_grid_problem\n"
+        "lib = _lib.load()\n"
+        "for make in (bump_sweep_problem, lambda n: macpherson_grid_problem(n, n), lambda n: axle_grid_problem(n, n)):\n"
+        "    hp = HostProgram(make(4)[0])\n"
+        "    for fn in (lib.okx_quad_source, lib.okx_lane_source):\n"
+        "        n = fn(hp.byref(), None, 0)\n"
+        "        if n < 0:\n"
+        "            print('none'); continue\n"
+        "        buf = C.create_string_buffer(n); fn(hp.byref(), buf, n)\n"
+        "        print(hashlib.sha256(buf.value).hexdigest())\n"
+    )
+    runs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300) for _ in range(2)]
+    assert all(r.returncode == 0 for r in runs), runs[0].stderr[-1000:]
+    assert runs[0].stdout == runs[1].stdout and len(runs[0].stdout.split()) == 6
