@@ -62,6 +62,7 @@ class LGen {
     blk_of_point.assign(P.n_points, -1);
     dop_of_point.assign(P.n_points, -1);
     perm = lane_elimination_order(P);
+    layout_tables();
     for (int F = 0; F < P.n_free; ++F) blk_of_point[fp(F)] = F;
     for (int e = 0; e < P.n_derived; ++e) dop_of_point[P.dop_out[e]] = e;
   }
@@ -196,34 +197,38 @@ class LGen {
   }
 
   // ---- chain constants: wave-uniform values (row parameters, derived-op parameters, fixed points) ----
-  // They live in a small LDS table `cl`, filled once per wave unit, and are READ WHERE THEY ARE USED (one ds_read_b64
-  // each, every lane the same address: a broadcast) through an index the optimiser cannot see through (`kz`, an opaque
-  // zero refreshed at the top of every pass).  As named values loaded ahead of the loops (the first version) they are
-  // ~50 loop invariants: the compiler runs out of scalar registers, parks them in vector registers and then spills.
-  // A constant's name is a macro: `#define hs3_0 cl[7 + kz]`.
-  std::string hoisted;   // fill code: cl[k] = source;
-  std::string defines;   // #define name cl[k + kz]
-  std::string undefs;
-  int n_consts = 0;
+  // The geometry's tables (positions, constraint-row parameters; the program's target-row and derived-op parameters) are
+  // STAGED into LDS once per wave unit with coalesced loads (lane k fetches entry k) and read where they are used: one
+  // ds_read_b64 each, every lane the same address (a broadcast), through an index the optimiser cannot see through
+  // (`kz`, an opaque zero refreshed at the top of every pass).  As named values loaded ahead of the loops (the first
+  // version) they are ~50 loop invariants that the compiler parks in vector registers and spills; as ~200 same-address
+  // global loads per wave unit (the second) the ensemble kernel spent 43 % of its cycles waiting (profiles/r03).
+  // A constant's name is a macro: `#define hs3_0 gl[GQ0 + 24 + kz]`.
+  std::set<std::string> defines;   // #define name gl[offset + kz]
+  std::set<std::string> undefs;
+  int gl_gp0 = 0, gl_gq0 = 0, gl_tq0 = 0, gl_dp0 = 0, gl_size = 0;
+  void layout_tables() {
+    gl_gp0 = 0;
+    gl_gq0 = gl_gp0 + 3 * P.n_points;
+    gl_tq0 = gl_gq0 + 8 * P.n_crows;
+    gl_dp0 = gl_tq0 + 8 * P.n_targets;
+    gl_size = gl_dp0 + (P.n_derived > 0 ? P.n_derived : 1);
+  }
   std::map<std::pair<int, int>, std::string> hoisted_names;
-  void add_const(const char* name, const char* source) {
+  void add_const(const char* name, int offset) {
     char line[256];
-    std::snprintf(line, sizeof(line), "    cl[%d] = %s;\n", n_consts, source);
-    hoisted += line;
-    std::snprintf(line, sizeof(line), "#define %s cl[%d + kz]\n", name, n_consts);
-    defines += line;
+    std::snprintf(line, sizeof(line), "#define %s gl[%d + kz]\n", name, offset);
+    defines.insert(line);
     std::snprintf(line, sizeof(line), "#undef %s\n", name);
-    undefs += line;
-    ++n_consts;
+    undefs.insert(line);
   }
   std::string dp(int e) {
     auto key = std::make_pair(-1 - e, 0);
     auto it = hoisted_names.find(key);
     if (it != hoisted_names.end()) return it->second;
-    char name[48], line[200];
+    char name[48];
     std::snprintf(name, sizeof(name), "hd%d", e);
-    std::snprintf(line, sizeof(line), "a.dop_param[%d]", e);
-    add_const(name, line);
+    add_const(name, gl_dp0 + e);
     hoisted_names[key] = name;
     return name;
   }
@@ -242,13 +247,9 @@ class LGen {
     auto key = std::make_pair(i, k);
     auto it = hoisted_names.find(key);
     if (it != hoisted_names.end()) return it->second;
-    char name[48], line[200];
+    char name[48];
     std::snprintf(name, sizeof(name), "hs%d_%d", i, k);
-    if (i < P.n_crows)
-      std::snprintf(line, sizeof(line), "gq[%d]", 8 * i + k);
-    else
-      std::snprintf(line, sizeof(line), "a.row_param[%d]", 8 * i + k);
-    add_const(name, line);
+    add_const(name, i < P.n_crows ? gl_gq0 + 8 * i + k : gl_tq0 + 8 * (i - P.n_crows) + k);
     hoisted_names[key] = name;
     return name;
   }
@@ -1121,7 +1122,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // LDS slots to spare for the rows' gradients, the chain body has not.  `ev` is the chain body's generator (no LDS
   // homes) and the owner of the chain constants; `evc` the independent-solve body's.
   const int kColdStateSlots = 2 * n;                               // x, dx
-  int cold_j_slots = (40 * 1024 - 1024) / 512 - kColdStateSlots;   // what is left of 40 KiB per wavefront, less the constants' table
+  // what is left of 40 KiB per wavefront once the geometry tables (gl) have their share
+  int cold_j_slots = (40 * 1024 - 8 * (3 * P.n_points + 8 * (P.n_crows + P.n_targets) + (P.n_derived > 0 ? P.n_derived : 1)) - 256) / 512 - kColdStateSlots;
   if (cold_j_slots < 0) cold_j_slots = 0;
   if (const char* env = getenv("OKX_LANE_J_SLOTS")) cold_j_slots = atoi(env);
   struct PassSrc { std::string eval, factor, subst; };
@@ -1172,8 +1174,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   evc.l_lds_base = kColdStateSlots + cold_j_slots;
   evc.l_lds_slots = cold_l_slots;
   evc.late_diag = V.late_diag || getenv("OKX_LANE_LATE_DIAG") != nullptr;
-  if (!make_pass(evc, &pass_cold) || !evc.hoisted.empty()) {
-    *why = evc.why.empty() ? "pass generation is not reproducible" : evc.why;
+  if (!make_pass(evc, &pass_cold)) {
+    *why = evc.why;
     return false;
   }
 
@@ -1188,7 +1190,6 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     for (int idx = 0; idx < P.n_active; ++idx)
       if (!lt.derived_op(P.active_op[idx], false)) light_ok = false;
     if (light_ok && !lt.emit_rows_residual_only()) light_ok = false;
-    if (!lt.hoisted.empty()) light_ok = false;
     light_src = lt.out;
   }
   // final state: every derived point
@@ -1200,10 +1201,6 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       *why = fin.why;
       return false;
     }
-  if (!fin.hoisted.empty()) {
-    *why = "final derived points need constants the pass did not load";
-    return false;
-  }
   const std::string final_src = fin.out;
 
   std::vector<bool> used(NP, false);
@@ -1229,18 +1226,40 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   for (int p = 0; p < NP; ++p)
     if (used[p] && is_fixed(p))
       for (int c = 0; c < 3; ++c) {
-        char name[32], source[48];
+        char name[32];
         std::snprintf(name, sizeof(name), "p%d_%d", p, c);
-        std::snprintf(source, sizeof(source), "gp[%d]", 3 * p + c);
-        ev.add_const(name, source);
+        ev.add_const(name, ev.gl_gp0 + 3 * p + c);
       }
-  const int n_consts = ev.n_consts > 0 ? ev.n_consts : 1;
+  const int gl_size = ev.gl_size;
+  // coalesced staging of the geometry's tables (and, in the solve bodies, of its first-step table) into LDS
+  auto stage_tables = [&](LGen& gg, const char* indent) {
+    gg.f("%sfor (int k = lane; k < %d; k += 64) gl[%d + k] = gp[k];", indent, 3 * NP, ev.gl_gp0);
+    gg.f("%sfor (int k = lane; k < %d; k += 64) gl[%d + k] = gq[k];", indent, 8 * P.n_crows, ev.gl_gq0);
+    gg.f("%sif (lane < %d) gl[%d + lane] = a.row_param[%d + lane];", indent, 8 * T, ev.gl_tq0, 8 * P.n_crows);
+    gg.f("%sif (lane < %d) gl[%d + lane] = a.dop_param[lane];", indent, P.n_derived, ev.gl_dp0);
+  };
   const bool marks = getenv("OKX_LANE_MARK") != nullptr;  // `s_nop 11..16` between the sections of a pass (tools/lane_isa.sh)
 
   LGen g(P);
   g.out += kLanePreamble;
   g.f("");
-  g.out += ev.defines;
+  {
+    // every table entry a constant's name can stand for (unused macros cost nothing)
+    std::set<std::string> defs;
+    for (LGen* gen : {&ev, &evc}) defs.insert(gen->defines.begin(), gen->defines.end());
+    char line[96];
+    for (int i = 0; i < P.m; ++i)
+      for (int k = 0; k < 8; ++k) {
+        std::snprintf(line, sizeof(line), "#define hs%d_%d gl[%d + kz]\n", i, k,
+                      i < P.n_crows ? ev.gl_gq0 + 8 * i + k : ev.gl_tq0 + 8 * (i - P.n_crows) + k);
+        defs.insert(line);
+      }
+    for (int e = 0; e < P.n_derived; ++e) {
+      std::snprintf(line, sizeof(line), "#define hd%d gl[%d + kz]\n", e, ev.gl_dp0 + e);
+      defs.insert(line);
+    }
+    for (const std::string& d : defs) g.out += d;
+  }
   auto PF = [&](int i) { return "p" + std::to_string(ev.fp(i / 3)) + "_" + std::to_string(i % 3); };
   const char* refresh_kz = "asm volatile(\"\" : \"+v\"(kz));";
 
@@ -1257,11 +1276,16 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       if (ch) state_decl += " " + slot_ref("xp" + std::to_string(i)) + " " + slot_ref("xq" + std::to_string(i));
       state_decl += "\n";
     }
+    const int state_doubles_before_l = 64 * n_slots;  // x, dx (and the chain history): live from the prologue on
     if (!ch) n_slots = evc.l_lds_base + evc.l_lds_slots > n_slots + (int)evc.j_home.size() ? evc.l_lds_base + evc.l_lds_slots : n_slots + (int)evc.j_home.size();  // + the rows' gradients / the factor's first rows
     const int state_doubles = 64 * n_slots;
     const int stage_doubles = ch ? 0 : 64 * 3 * P.n_out;
-    const int lds_doubles = state_doubles > stage_doubles ? state_doubles : stage_doubles;
-    if ((lds_doubles + n_consts) * 8 > 40 * 1024) {
+    int lds_doubles = state_doubles > stage_doubles ? state_doubles : stage_doubles;
+    // the first-step table of the wave unit's geometry is staged behind the state (the area the factor's rows are parked
+    // in later): the prologue's 100-odd table reads are LDS broadcasts instead of same-address global loads
+    const int head_l0 = state_doubles_before_l;
+    if (lds_doubles < head_l0 + head_stride) lds_doubles = head_l0 + head_stride;
+    if ((lds_doubles + gl_size) * 8 > 40 * 1024) {
       lds_why = "per-wavefront LDS state exceeds 40 KiB";
       return false;
     }
@@ -1274,7 +1298,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a) {", ch ? "chain" : "cold");
     g.f("  const int lane = threadIdx.x;");
     g.f("  __shared__ double lds[%d];", lds_doubles);
-    g.f("  __shared__ double cl[%d];  // chain constants of the wave unit's geometry", n_consts);
+    g.f("  __shared__ double gl[%d];  // the wave unit's geometry tables: positions, row parameters, derived-op parameters", gl_size);
     g.f("  int kz = 0;");
     g.f("  const long long spg = a.steps_per_geometry;");
     g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
@@ -1305,8 +1329,15 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       for (int t = 0; t < T; ++t) g.f("    double tn%d = a.targets[first_b * %d + %d], tp%d = 0.0, tq%d = 0.0, tr%d = 0.0;", t, T, t, t, t, t);
     else
       for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[first_b * %d + %d];", t, T, t);
-    g.f("    // chain constants of this wave unit (every lane writes the same values: no barrier involved)");
-    g.out += ev.hoisted;
+    g.f("    // the geometry's tables (and its first-step table) into LDS, lane k fetching entry k");
+    g.f("    __syncthreads();  // (the previous wave unit's last reads of these areas are done)");
+    stage_tables(g, "    ");
+    g.f("    const bool with_head = a.head != nullptr && a.grad_tol <= 0.0;");
+    g.f("    if (with_head) {");
+    g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
+    g.f("      for (int k = lane; k < %d; k += 64) lds[%d + k] = hp[k];", head_stride, head_l0);
+    g.f("    }");
+    g.f("    __syncthreads();");
     g.f("    %s", refresh_kz);
     for (int p = 0; p < NP; ++p) {
       if (!used[p] || is_fixed(p)) continue;
@@ -1330,8 +1361,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     // shared first step of the unit's first problem, table of okx_quad_head_u/_g
     g.f("    bool head_ready = false;");
     g.f("    double hstep = 0.0, hN = 0.0, hM = 0.0, hss = 0.0, hmr = 0.0, hs0 = 0.0, hs1 = 0.0, hs4 = 0.0, hs5 = 0.0;");
-    g.f("    if (a.head != nullptr && a.grad_tol <= 0.0) {");
-    g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
+    g.f("    if (with_head) {");
+    g.f("      const double* hp = lds + %d + kz;  // the staged table", head_l0);
     g.f("      const double hr0 = 1.0;");
     for (int k = 1; k < HK; ++k) g.f("      const double hr%d = td%d - tn%d;", k, k - 1, k - 1);
     // first-order step d1 and, when the table carries them (scalar 6), the second-order correction
@@ -1644,9 +1675,11 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   g.f("  double lambda; long long n_problems; const double* design_pos; const double* row_param; const double* dop_param; };");
   g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_eval(QEvalArgs a) {");
   g.f("  const double* gp = a.design_pos; const double* gq = a.row_param; (void)gq;");
-  g.f("  __shared__ double cl[%d];", n_consts);
+  g.f("  __shared__ double gl[%d];", gl_size);
+  g.f("  const int lane = threadIdx.x;");
   g.f("  int kz = 0;");
-  g.out += ev.hoisted;
+  stage_tables(g, "  ");
+  g.f("  __syncthreads();");
   g.f("  %s", refresh_kz);
   g.f("  for (long long wu = blockIdx.x; wu * 64 < a.n_problems; wu += gridDim.x) {");
   g.f("    long long bb = wu * 64 + threadIdx.x; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");
@@ -1701,7 +1734,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       for (const char* out : {"", "_c"})   // _c: compact outputs (free coordinates or nothing)
         g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_%s_%s%s(QArgs a) { okx_lane_body_%s<%s, %s>(a); }", body, geo,
             out, body[0] == 's' ? "cold" : "chain", geo[0] == 'g' ? "true" : "false", out[0] ? "false" : "true");
-  g.out += ev.undefs;
+  (void)ev.undefs;  // (the macros live to the end of the translation unit: one program per module)
   *src = g.out;
   return true;
 }

@@ -37,8 +37,8 @@ def test_lane_source_is_generated_for_corner_topologies(golden, name, mode):
     for i in range(n):
         assert f"A{i}_{i} = 0.0" in src and f"const double dinv{i} = pivot_rcp(C{i}_{i});" in src
     assert "__builtin_amdgcn_mov_dpp" not in src and "ds_swizzle" not in src  # no cross-lane operand anywhere
-    # chain constants are read from the LDS table where they are used
-    assert "#define hs0_0 cl[" in src and "+ kz]" in src
+    # the geometry's tables are staged into LDS with coalesced loads and read where they are used
+    assert "#define hs0_0 gl[" in src and "+ kz]" in src and "gl[0 + k] = gp[k]" in src
     # structure only: no geometry value is baked into the text
     assert "471.69" not in src and "559.01" not in src and "410.0" not in src
 
