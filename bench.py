@@ -508,6 +508,8 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
             return f"{dp.kernel} ({dp.kernel_note})"
         if lane_from > 0 and n >= lane_from and (lane_bodies & (1 if cold else 2)):
             return "lane (one lane per problem, 64 per wavefront)"
+        if lane_from > 0 and n >= lane_from and not cold and (lane_bodies & 1):
+            return "lane, independent solves (chain_len -1 resolves to cold starts: this program's chain body spills)"
         return "quad (four lanes per problem)" + (f"; lane kernel: {dp.lane_note}" if dp.lane_note else "")
 
     res = {"workload": name, "problems": n, "n_vars": program.n_vars, "n_residual_rows": program.n_residuals,
