@@ -32,7 +32,7 @@ extern "C" {
 #define OKX_ABI_VERSION 3   /* 3: okx_solve_opts.output (+ reserved); lane kernel entry points.  2: confirm_full_pass; diagnostics moved to okx_debug.h */
 
 /* Hard limits of one problem (one wavefront owns one problem). */
-#define OKX_MAX_VARS 63      /* n = 3 * free points (one lane per variable)          */
+#define OKX_MAX_VARS 126     /* n = 3 * free points (one thread per variable: one wavefront up to 63, two beyond) */
 #define OKX_MAX_ROWS 128     /* m = constraint rows + target rows                    */
 #define OKX_MAX_POINTS 96    /* fixed + free + derived                               */
 #define OKX_MAX_TARGETS 8

@@ -30,7 +30,9 @@ struct okx_program {
   size_t solve_lds_bytes;  // selected solve kernel
   int blocks_per_cu;
   int nreg;                // padded row length of the register-resident factorisation
-  const void* solve_fn;    // okx_solve_kernel<NREG> (one problem per wavefront)
+  const void* solve_fn;    // okx_solve_kernel<NREG> (one problem per wavefront; two wavefronts for n > 63)
+  const void* eval_fn;     // okx_eval_kernel<threads>
+  int threads;             // threads per problem of the generic kernels: 64, or 128 for n > 63
   const void* tangent_fn;  // okx_tangent_kernel<NREG> (generic tangents)
   int groups;              // problems per wavefront of the packed kernel (1 = not available)
   int group_width;         // lanes per problem in the packed kernel
@@ -126,12 +128,18 @@ void select_solve_kernels(okx_program* p) {
     fn = okx::okx_solve_kernel<48, false>;
     p->tangent_fn = (const void*)okx::okx_tangent_kernel<48>;
     p->nreg = 48;
-  } else {
+  } else if (n <= 63) {
     fn = okx::okx_solve_kernel<63, false>;
     p->tangent_fn = (const void*)okx::okx_tangent_kernel<63>;
     p->nreg = 63;
+  } else {  // 64 ... 126 variables: two wavefronts per problem, LDL^T rows in LDS (okx_kernels.hip ldlt_solve_wide)
+    fn = okx::okx_solve_kernel<126, false>;
+    p->tangent_fn = (const void*)okx::okx_tangent_kernel<126>;
+    p->nreg = 126;
   }
   p->solve_fn = (const void*)fn;
+  p->threads = okx::GroupWidth<126>::value * (n > 63) + okx::kWave * (n <= 63);
+  p->eval_fn = n > 63 ? (const void*)okx::okx_eval_kernel<2 * okx::kWave> : (const void*)okx::okx_eval_kernel<okx::kWave>;
 
   p->groups = 1;
   p->group_width = 64;
@@ -163,7 +171,7 @@ void select_solve_kernels(okx_program* p) {
 // Resident single-wave workgroups per CU.  The occupancy API assumes 64 KiB of LDS per CU on
 // this stack, so the limit is derived here: 512 VGPRs per SIMD lane (8-register granules),
 // 160 KiB LDS per CU, 8 waves per SIMD.
-int resident_blocks_per_cu(const void* fn, size_t lds_bytes) {
+int resident_blocks_per_cu(const void* fn, size_t lds_bytes, int threads = okx::kWave) {
   int occ = 32;
   hipFuncAttributes fa;
   if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.numRegs > 0) {
@@ -173,6 +181,7 @@ int resident_blocks_per_cu(const void* fn, size_t lds_bytes) {
     if (per_simd < 1) per_simd = 1;
     occ = 4 * per_simd;
   }
+  occ /= threads > okx::kWave ? threads / okx::kWave : 1;  // workgroups of two wavefronts (n > 63)
   const int by_lds = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
   if (by_lds < occ) occ = by_lds;
   if (occ < 1) occ = 1;
@@ -500,7 +509,7 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   // >64 KiB of dynamic LDS needs the opt-in attribute.  The kernels are shared by every program of the
   // process, so the limit is raised to the hardware maximum once per kernel (a per-program size would let a
   // later, smaller program lower it under an earlier one's feet).
-  for (const void* fn : {p->solve_fn, (const void*)okx::okx_eval_kernel, (const void*)okx::okx_rebind_kernel,
+  for (const void* fn : {p->solve_fn, p->eval_fn, (const void*)okx::okx_rebind_kernel,
                          p->packed_fn, p->tangent_fn}) {
     if (!fn) continue;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
@@ -512,7 +521,7 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
       return fail(OKX_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
     }
   }
-  p->blocks_per_cu = resident_blocks_per_cu(p->solve_fn, p->solve_lds_bytes);
+  p->blocks_per_cu = resident_blocks_per_cu(p->solve_fn, p->solve_lds_bytes, p->threads);
   p->packed_blocks_per_cu = p->packed_fn ? resident_blocks_per_cu(p->packed_fn, p->packed_lds_bytes) : 0;
   attach_quad_kernel(p);
   attach_lane_kernel(p);
@@ -846,7 +855,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   }
   const int grid = grid_for(p, units);
   void* kargs[] = {(void*)&dev, (void*)&a};
-  HIP_TRY(hipLaunchKernel(p->solve_fn, dim3(grid), dim3(okx::kWave), kargs, p->lds_bytes,
+  HIP_TRY(hipLaunchKernel(p->solve_fn, dim3(grid), dim3(p->threads), kargs, p->lds_bytes,
                           (hipStream_t)stream));
   return OKX_OK;
 }
@@ -1006,9 +1015,10 @@ int32_t okx_eval_batch(okx_program* p, int64_t n_problems, const double* d_x,
   a.ata = nullptr;
   a.atr = nullptr;
   a.n_problems = n_problems;
-  hipLaunchKernelGGL(okx::okx_eval_kernel, dim3(grid_for(p, n_problems)), dim3(okx::kWave),
-                     p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
-  HIP_TRY(hipGetLastError());
+  const okx::DevProgram* dev = p->dev;
+  void* kargs[] = {(void*)&dev, (void*)&a};
+  HIP_TRY(hipLaunchKernel(p->eval_fn, dim3(grid_for(p, n_problems)), dim3(p->threads), kargs, p->lds_bytes,
+                          (hipStream_t)stream));
   return OKX_OK;
 }
 
@@ -1026,9 +1036,10 @@ int32_t okx_debug_normal_equations(okx_program* p, int64_t n_problems, const dou
   a.ata = d_ata;
   a.atr = d_atr;
   a.n_problems = n_problems;
-  hipLaunchKernelGGL(okx::okx_eval_kernel, dim3(grid_for(p, n_problems)), dim3(okx::kWave),
-                     p->lds_bytes, (hipStream_t)stream, (const okx::DevProgram*)p->dev, a);
-  HIP_TRY(hipGetLastError());
+  const okx::DevProgram* dev = p->dev;
+  void* kargs[] = {(void*)&dev, (void*)&a};
+  HIP_TRY(hipLaunchKernel(p->eval_fn, dim3(grid_for(p, n_problems)), dim3(p->threads), kargs, p->lds_bytes,
+                          (hipStream_t)stream));
   return OKX_OK;
 }
 
@@ -1122,7 +1133,7 @@ int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_
     if (lds > 160 * 1024) return fail(OKX_ERR_LIMIT, "tangent kernel needs %zu bytes of LDS", lds);
     const okx::DevProgram* dev = p->dev;
     void* kargs[] = {(void*)&dev, (void*)&t};
-    HIP_TRY(hipLaunchKernel(p->tangent_fn, dim3(grid_for(p, n_problems)), dim3(okx::kWave), kargs, lds,
+    HIP_TRY(hipLaunchKernel(p->tangent_fn, dim3(grid_for(p, n_problems)), dim3(p->threads), kargs, lds,
                             (hipStream_t)stream));
     return OKX_OK;
   }

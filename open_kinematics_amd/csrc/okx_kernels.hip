@@ -89,6 +89,33 @@ __device__ __forceinline__ double wave_max(double v) {
 
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
+// Reductions over the W threads that share one problem: one wavefront (W = 64: the DPP network alone) or, for programs of
+// more than 63 variables, a workgroup of two wavefronts whose partial results meet in two LDS slots (`red`).  Every
+// thread of the group gets the same bits, so the control flow built on them stays uniform.
+template <int W>
+__device__ __forceinline__ double grp_sum(double* red, double v) {
+  v = wave_sum(v);
+  if constexpr (W > kWave) {
+    __syncthreads();  // the readers of the previous reduction are done with red[]
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = v;
+    __syncthreads();
+    v = red[0] + red[1];
+  }
+  return v;
+}
+
+template <int W>
+__device__ __forceinline__ double grp_max(double* red, double v) {
+  v = wave_max(v);
+  if constexpr (W > kWave) {
+    __syncthreads();
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = v;
+    __syncthreads();
+    v = fmax(red[0], red[1]);
+  }
+  return v;
+}
+
 // Diagnostic phase timer (only alive in the PROFILE instantiation; a null pointer folds away).
 struct Prof {
   unsigned long long phase[12];
@@ -219,6 +246,7 @@ struct Lds {
   double* tv;     // [T]       targets of the current problem
   double* col;    // [kColBuf] pivot column being broadcast by the factorisation
   double* zbuf;   // [kColBuf] right-hand side in / z out
+  double* red;    // [4]       two-wavefront groups: partial reductions [0..1], pivot / broadcast slots [2..3]
   // program tables staged once per workgroup (static for the whole launch)
   int* rowmeta;              // [m][kRowMetaStride]
   int* item_dst;             // [n_work]
@@ -230,7 +258,12 @@ struct Lds {
 // residual buffer = m residuals + a zero.
 __host__ __device__ inline int js_buf_doubles(const DevProgram& P) { return P.zero_off + 1; }
 __host__ __device__ inline int rb_buf_doubles(const DevProgram& P) { return P.m + 1; }
-__host__ __device__ inline int tri_doubles(const DevProgram& P) { return P.n * (P.n - 1) / 2 + 1; }
+// programs of more than 63 variables (two wavefronts per problem, LDL^T in LDS) carry the right-hand side as row n
+__host__ __device__ inline bool wide_program(const DevProgram& P) { return P.n > kWave - 1; }
+__host__ __device__ inline int tri_doubles(const DevProgram& P) {
+  const int rows = wide_program(P) ? P.n + 1 : P.n;
+  return rows * (rows - 1) / 2 + 1;
+}
 __host__ __device__ inline int tri(int i, int j) { return i * (i - 1) / 2 + j; }  // j < i
 
 __host__ __device__ inline int lds_table_doubles(const DevProgram& P) {
@@ -248,7 +281,7 @@ __host__ __device__ inline int lds_doubles(const DevProgram& P) {
   s += tri_doubles(P);
   s += P.n;
   s += kMaxTargets;
-  s += 2 * kColBuf;
+  s += 2 * kColBuf + 4;
   s = (s + 1) & ~1;
   s += lds_table_doubles(P);
   return (s + 1) & ~1;
@@ -286,14 +319,16 @@ __device__ __forceinline__ Lds carve(double* base, const DevProgram* P) {
   p += kColBuf;
   S.zbuf = p;
   p += kColBuf;
+  S.red = p;
+  p += 4;
   p = base + (((p - base) + 1) & ~1);
   carve_tables(reinterpret_cast<int*>(p), P, &S);
   return S;
 }
 
 // Copy the static program tables into LDS (once per persistent workgroup).
-__device__ __forceinline__ void stage_program(const DevProgram* P, const Lds& S, int lane) {
-  for (int i = lane; i < P->m; i += kWave) {
+__device__ __forceinline__ void stage_program(const DevProgram* P, const Lds& S, int lane, int W = kWave) {
+  for (int i = lane; i < P->m; i += W) {
     int* r = S.rowmeta + i * kRowMetaStride;
     r[0] = P->row_type[i];
 #pragma unroll
@@ -306,7 +341,7 @@ __device__ __forceinline__ void stage_program(const DevProgram* P, const Lds& S,
     }
     r[14] = (int)P->row_first[i];
   }
-  for (int w = lane; w < P->n_work; w += kWave) S.item_dst[w] = P->item_dst[w];
+  for (int w = lane; w < P->n_work; w += W) S.item_dst[w] = P->item_dst[w];
   __syncthreads();
 }
 
@@ -686,11 +721,11 @@ __device__ __forceinline__ double eval_rows(const DevProgram* P, const Lds& S, i
   return ss;
 }
 
-// One problem per wavefront: returns 0.5 * sum r^2 (uniform).
-template <bool WITH_J>
+// One problem per group of W threads (a wavefront, or two for a wide program): returns 0.5 * sum r^2 (uniform).
+template <bool WITH_J, int W = kWave>
 __device__ __forceinline__ double evaluate(const DevProgram* P, const Lds& S, int lane, double x,
                                            int xaddr, int buf, Prof* prof = nullptr) {
-  return 0.5 * wave_sum(eval_rows<WITH_J>(P, S, lane, kWave, x, xaddr, buf, prof));
+  return 0.5 * grp_sum<W>(S.red, eval_rows<WITH_J>(P, S, lane, W, x, xaddr, buf, prof));
 }
 
 // ------------------------------------------------------------------------------------
@@ -811,6 +846,78 @@ __device__ __forceinline__ bool ldlt_solve_reg(const DevProgram* P, const Lds& S
   return true;
 }
 
+// The same solve for programs of 64 ... 126 variables: W = 128 threads, thread i owns row i of the packed triangle in
+// LDS (its diagonal entry in a register) and thread n the right-hand side, carried as row n of the matrix so that the
+// forward substitution and the division by D happen inside the factorisation (row n ends as z = D^-1 L^-1 (-g)).
+// Right-looking, two barriers per column: (a) the pivot is published, every row below scales its own column entry;
+// (b) every row subtracts its multiple of the scaled column from the rest of itself.  The backward substitution
+// publishes one finished unknown per barrier (two slots, alternating).  This is the capacity path - a T-bar axle
+// with a heave link has 66 variables - not a tuned one: ~3 n barriers per step.
+template <int W>
+__device__ __forceinline__ bool ldlt_solve_wide(const DevProgram* P, const Lds& S, int tid, double lambda,
+                                                double g, double* dx, double* pivot_min = nullptr,
+                                                double* pivot_max = nullptr) {
+  const int n = P->n;
+  double diag = tid < n ? S.dA[tid] + lambda : 0.0;
+  if (tid < n) S.A[tri(n, tid)] = -g;
+  if (tid == 0) S.red[2] = diag;
+  bool ok = true;
+  for (int k = 0; k < n; ++k) {
+    __syncthreads();  // (a) pivot k and every update of column k are visible
+    const double pivot = S.red[2 + (k & 1)];
+    if (!(pivot > 0.0)) {
+      ok = false;
+      break;
+    }
+    if (pivot_min) {
+      *pivot_min = fmin(*pivot_min, pivot);
+      *pivot_max = fmax(*pivot_max, pivot);
+    }
+    const double rinv = 1.0 / pivot;
+    const bool below = tid > k && tid <= n;
+    double c = 0.0;
+    if (below) {
+      c = S.A[tri(tid, k)];
+      S.A[tri(tid, k)] = c * rinv;  // L[tid][k]
+    }
+    __syncthreads();  // (b) the scaled column is visible
+    if (below) {
+      double* row = S.A + tri(tid, 0);
+      for (int j = k + 1; j < tid; ++j) row[j] -= c * S.A[tri(j, k)];
+      diag -= c * c * rinv;
+      if (tid == k + 1) S.red[2 + ((k + 1) & 1)] = diag;
+    }
+  }
+  __syncthreads();
+  if (!ok) return false;
+  double b = tid < n ? S.A[tri(n, tid)] : 0.0;  // z
+  for (int k = n - 1; k >= 1; --k) {  // L^T dx = z, row k of L is contiguous: L[k][tid], tid < k
+    if (tid == k) S.red[2 + (k & 1)] = b;
+    __syncthreads();
+    if (tid < k) b -= S.A[tri(k, tid)] * S.red[2 + (k & 1)];
+  }
+  __syncthreads();
+  *dx = b;
+  return true;
+}
+
+// The factorisation a kernel instantiation uses: register rows for one wavefront, LDS rows for two.
+template <int NREG, int W>
+__device__ __forceinline__ bool ldlt_solve(const DevProgram* P, const Lds& S, int lane, double lambda, double g,
+                                           double* dx, double* pivot_min = nullptr, double* pivot_max = nullptr) {
+  if constexpr (W > kWave) {
+    return ldlt_solve_wide<W>(P, S, lane, lambda, g, dx, pivot_min, pivot_max);
+  } else {
+    return ldlt_solve_reg<NREG>(P, S, lane, lambda, g, dx, pivot_min, pivot_max);
+  }
+}
+
+// Threads per problem of the instantiation for rows of NREG entries.
+template <int NREG>
+struct GroupWidth {
+  static constexpr int value = NREG > kWave - 1 ? 2 * kWave : kWave;
+};
+
 // ------------------------------------------------------------------------------------
 // problem setup helpers
 // ------------------------------------------------------------------------------------
@@ -861,8 +968,9 @@ __device__ __forceinline__ double reference_abs_residual(const DevProgram* P, co
 // Register budget: rows of up to 24 entries fit 3 waves/SIMD (168 VGPRs); longer rows need the
 // 256-register budget of 2 waves/SIMD (the LDS slice of such problems allows <= 5 waves/CU anyway).
 template <int NREG, bool PROFILE>
-__global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG <= 48 ? 2 : 1)) okx_solve_kernel(const DevProgram* __restrict__ P,
+__global__ void __launch_bounds__(GroupWidth<NREG>::value, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG <= 48 ? 2 : 1)) okx_solve_kernel(const DevProgram* __restrict__ P,
                                                           SolveArgs args) {
+  constexpr int W = GroupWidth<NREG>::value;  // threads per problem: one wavefront, two for NREG > 63
   Prof prof_store;
   Prof* prof = nullptr;
   if constexpr (PROFILE) {
@@ -875,8 +983,8 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
   const Lds S = carve(lds_base, P);
   const int n = P->n, m = P->m, T = P->n_targets;
   const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
-  stage_program(P, S, lane);
-  init_slice(P, S, lane, kWave);
+  stage_program(P, S, lane, W);
+  init_slice(P, S, lane, W);
   OKX_STAMP(0)
 
   const long long spg = args.steps_per_geometry;
@@ -898,7 +1006,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
       const long long step = b - first;
       const long long geom = spg > 0 ? b / spg : 0;
       if (geom != loaded_geom) {
-        load_geometry(P, S, lane, kWave,
+        load_geometry(P, S, lane, W,
                       args.geom_pos ? args.geom_pos + geom * 3 * P->n_points : nullptr,
                       args.geom_row_param ? args.geom_row_param + geom * 8 * P->n_crows : nullptr);
         loaded_geom = geom;
@@ -923,8 +1031,8 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
         S.tv[lane] = t_new;
       }
       if (hist >= 2) {
-        const double num = wave_sum((t_new - t_old) * (t_old - t_old2));
-        const double den = wave_sum((t_old - t_old2) * (t_old - t_old2));
+        const double num = grp_sum<W>(S.red, (t_new - t_old) * (t_old - t_old2));
+        const double den = grp_sum<W>(S.red, (t_old - t_old2) * (t_old - t_old2));
         double alpha = den > 0.0 ? num / den : 0.0;
         alpha = fmin(fmax(alpha, 0.0), 2.0);
         const double xp = x + alpha * (x - x_prev);
@@ -946,7 +1054,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
       double xt = x;
       bool first = true;
       for (;;) {
-        const double Ft = evaluate<true>(P, S, lane, xt, xaddr, cur ^ 1, prof);
+        const double Ft = evaluate<true, W>(P, S, lane, xt, xaddr, cur ^ 1, prof);
         ++nfev;
         bool accept;
         bool stop = false;
@@ -954,7 +1062,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
         if (first) {
           accept = true;
         } else {
-          const double pred = 0.5 * wave_sum(lane < n ? dx * (lambda * dx - g) : 0.0);
+          const double pred = 0.5 * grp_sum<W>(S.red, lane < n ? dx * (lambda * dx - g) : 0.0);
           const bool finite = Ft == Ft && step_len == step_len && Ft < 1e300;
           const bool small = finite && step_len <= 1e-8 && Ft <= F * (1.0 + 1e-6) + 1e-28;
           rho = (finite && pred > 0.0) ? (F - Ft) / pred : -1.0;
@@ -977,10 +1085,10 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
           if (!first) last_step = step_len;
           if (!stop) {
             OKX_STAMP(4)
-            g = build_normal(P, S, lane, kWave, cur, lane < n);
+            g = build_normal(P, S, lane, W, cur, lane < n);
             OKX_STAMP(5)
             if (first) {
-              dmax = wave_max(lane < n ? S.dA[lane] : 0.0);
+              dmax = grp_max<W>(S.red, lane < n ? S.dA[lane] : 0.0);
               lambda = args.lambda0 * dmax;
               // a warm-started chain step continues with the damping its predecessor ended with
               if (lambda_carry > 0.0) lambda = fmin(lambda, lambda_carry);
@@ -991,7 +1099,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
               lambda *= rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t);
             }
             nu = 2.0;
-            if (args.grad_tol > 0.0 && wave_max(lane < n ? fabs(g) : 0.0) <= args.grad_tol) {
+            if (args.grad_tol > 0.0 && grp_max<W>(S.red, lane < n ? fabs(g) : 0.0) <= args.grad_tol) {
               flags |= OKX_INFO_CONVERGED;
               stop = true;
             }
@@ -1006,9 +1114,9 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
         if (!accept) {
           // Rejected trial (rare): the single Jacobian buffer now holds J(xt) and the packed
           // triangle holds the factor, so the accepted point's J and J^T J are rebuilt.
-          evaluate<true>(P, S, lane, x, xaddr, cur, prof);
+          evaluate<true, W>(P, S, lane, x, xaddr, cur, prof);
           ++nfev;
-          g = build_normal(P, S, lane, kWave, cur, lane < n);
+          g = build_normal(P, S, lane, W, cur, lane < n);
         }
         ++iters;
         OKX_STAMP(4)
@@ -1018,11 +1126,11 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
         for (int tries = 0; tries < 60; ++tries) {
           if (!(lambda < 1e30)) break;
           pmin = 1e300;
-          ok = ldlt_solve_reg<NREG>(P, S, lane, lambda, g, &dx, &pmin, &pmax);
+          ok = ldlt_solve<NREG, W>(P, S, lane, lambda, g, &dx, &pmin, &pmax);
           stamp(prof, 6);
           if (ok) break;
           lambda = fmax(lambda * 10.0, 1e-12 * dmax);
-          build_normal(P, S, lane, kWave, cur, lane < n);  // the failed factor overwrote J^T J
+          build_normal(P, S, lane, W, cur, lane < n);  // the failed factor overwrote J^T J
         }
         if (!ok) {
           flags |= OKX_INFO_FAILED;
@@ -1031,7 +1139,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
         piv_lo = pmin - lambda;  // what the damping did not put there
         piv_hi = pmax;
         OKX_STAMP(7)
-        step_len = wave_max(lane < n ? fabs(dx) : 0.0);
+        step_len = grp_max<W>(S.red, lane < n ? fabs(dx) : 0.0);
         if (step_len <= args.step_tol) {
           // the Newton-type correction is already below tolerance: x is the answer and the
           // residuals in hand belong to it (no confirming evaluation of x + dx)
@@ -1048,7 +1156,7 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
           const double cq = prev_step > 0.0 ? fmax(100.0 * step_len / (prev_step * prev_step), 1e-3) : 1.0;
           const double rho_lin = 100.0 * lambda / pmin;
           if (step_len <= 1e-3 && (rho_lin + cq * step_len) * step_len <= args.step_tol) {
-            const double Fl = evaluate<false>(P, S, lane, xt, xaddr, cur ^ 1, prof);
+            const double Fl = evaluate<false, W>(P, S, lane, xt, xaddr, cur ^ 1, prof);
             ++nfev;
             if (Fl == Fl && Fl <= F * (1.0 + 1e-6) + 1e-28) {
               x = xt;
@@ -1069,14 +1177,14 @@ __global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG
       wave_sync();
       if (lane < n) S.pos[xaddr] = x;
       wave_sync();
-      derived_update<false>(P, S, lane, kWave, false);
+      derived_update<false>(P, S, lane, W, false);
       double ra = 0.0;
-      for (int i = lane; i < m; i += kWave) ra = fmax(ra, reference_abs_residual(P, S, i, cur));
-      const double max_res = wave_max(ra);
+      for (int i = lane; i < m; i += W) ra = fmax(ra, reference_abs_residual(P, S, i, cur));
+      const double max_res = grp_max<W>(S.red, ra);
       if (max_res > args.residual_tolerance) flags |= OKX_INFO_RESIDUAL_EXCEEDED;
       if (piv_hi > 0.0 && piv_lo <= OKX_ILL_CONDITIONED_PIVOT_RATIO * piv_hi) flags |= OKX_INFO_ILL_CONDITIONED;
       double* out = args.out_pos + b * 3 * P->n_out;
-      for (int e = lane; e < 3 * P->n_out; e += kWave) out[e] = S.pos[3 * P->out_point[e / 3] + e % 3];
+      for (int e = lane; e < 3 * P->n_out; e += W) out[e] = S.pos[3 * P->out_point[e / 3] + e % 3];
       if (lane == 0) {
         okx_info inf;
         inf.max_residual = max_res;
@@ -1122,38 +1230,38 @@ struct EvalArgs {
   long long n_problems;
 };
 
-__global__ void __launch_bounds__(kWave) okx_eval_kernel(const DevProgram* __restrict__ P,
-                                                         EvalArgs args) {
+template <int W>
+__global__ void __launch_bounds__(W) okx_eval_kernel(const DevProgram* __restrict__ P, EvalArgs args) {
   extern __shared__ double lds_base[];
   const int lane = threadIdx.x;
   const Lds S = carve(lds_base, P);
   const int n = P->n, m = P->m, T = P->n_targets;
   const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
-  stage_program(P, S, lane);
-  init_slice(P, S, lane, kWave);
-  load_geometry(P, S, lane, kWave, nullptr, nullptr);
+  stage_program(P, S, lane, W);
+  init_slice(P, S, lane, W);
+  load_geometry(P, S, lane, W, nullptr, nullptr);
   for (long long b = blockIdx.x; b < args.n_problems; b += gridDim.x) {
     wave_sync();
     if (lane < T) S.tv[lane] = args.targets[b * T + lane];
     const double x = lane < n ? args.x[b * n + lane] : 0.0;
-    evaluate<true>(P, S, lane, x, xaddr, 0);
-    for (int i = lane; i < m; i += kWave) args.r[b * m + i] = S.rb[i];
+    evaluate<true, W>(P, S, lane, x, xaddr, 0);
+    for (int i = lane; i < m; i += W) args.r[b * m + i] = S.rb[i];
     if (args.jac) {
       double* J = args.jac + b * (long long)m * n;
-      for (int e = lane; e < m * n; e += kWave) J[e] = 0.0;
+      for (int e = lane; e < m * n; e += W) J[e] = 0.0;
       wave_sync();
-      for (int i = lane; i < m; i += kWave) {
+      for (int i = lane; i < m; i += W) {
         const double* jr = S.js + (size_t)i * P->js_stride;
         for (int s = 0; s < P->row_nblk[i]; ++s)
           for (int k = 0; k < 3; ++k) J[(long long)i * n + 3 * P->row_blk[i][s] + k] = jr[3 * s + k];
       }
     }
     if (args.ata || args.atr) {
-      const double g = build_normal(P, S, lane, kWave, 0, lane < n);
+      const double g = build_normal(P, S, lane, W, 0, lane < n);
       if (args.atr && lane < n) args.atr[b * n + lane] = g;
       if (args.ata) {
         double* M = args.ata + b * (long long)n * n;
-        for (int e = lane; e < n * n; e += kWave) {
+        for (int e = lane; e < n * n; e += W) {
           const int i = e / n, j = e % n;
           M[e] = i == j ? S.dA[i] : (i < j ? S.A[tri(j, i)] : S.A[tri(i, j)]);
         }
@@ -1217,33 +1325,34 @@ __device__ __forceinline__ V3 dop_velocity(int type, const int* pts, double c, c
 // with right-hand side J^T e_t (the target row's own Jacobian entries), derived-point velocities.
 // Dynamic LDS = the solve kernel's slice + a [P][3] velocity table.
 template <int NREG>
-__global__ void __launch_bounds__(kWave, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG <= 48 ? 2 : 1))
+__global__ void __launch_bounds__(GroupWidth<NREG>::value, NREG <= 24 ? OKX_WAVES_PER_SIMD : (NREG <= 48 ? 2 : 1))
 okx_tangent_kernel(const DevProgram* __restrict__ P, TangentArgs args) {
+  constexpr int W = GroupWidth<NREG>::value;
   extern __shared__ double lds_base[];
   const int lane = threadIdx.x;
   const Lds S = carve(lds_base, P);
   double* vel = lds_base + P->lds_doubles;
   const int n = P->n, T = P->n_targets;
   const int xaddr = lane < n ? 3 * P->free_point[lane / 3] + lane % 3 : 0;
-  stage_program(P, S, lane);
-  init_slice(P, S, lane, kWave);
+  stage_program(P, S, lane, W);
+  init_slice(P, S, lane, W);
   long long loaded_geom = -1;
   for (long long b = blockIdx.x; b < args.n_problems; b += gridDim.x) {
     const long long geom = args.steps_per_geometry > 0 ? b / args.steps_per_geometry : 0;
     if (geom != loaded_geom) {
-      load_geometry(P, S, lane, kWave, args.geom_pos ? args.geom_pos + geom * 3 * P->n_points : nullptr,
+      load_geometry(P, S, lane, W, args.geom_pos ? args.geom_pos + geom * 3 * P->n_points : nullptr,
                     args.geom_row_param ? args.geom_row_param + geom * 8 * P->n_crows : nullptr);
       loaded_geom = geom;
     }
     wave_sync();
     if (lane < T) S.tv[lane] = 0.0;  // target values do not enter the Jacobian
     const double x = lane < n ? args.pos[(b * P->n_out + args.free_out[lane / 3]) * 3 + lane % 3] : 0.0;
-    evaluate<true>(P, S, lane, x, xaddr, 0);
-    derived_update<false>(P, S, lane, kWave, false);  // every derived point (inputs of the velocity pass)
+    evaluate<true, W>(P, S, lane, x, xaddr, 0);
+    derived_update<false>(P, S, lane, W, false);  // every derived point (inputs of the velocity pass)
     double pmin = 1e300, pmax = 0.0;
     bool all_ok = true;
     for (int t = 0; t < T; ++t) {
-      build_normal(P, S, lane, kWave, 0, lane < n);  // the previous factorisation overwrote J^T J
+      build_normal(P, S, lane, W, 0, lane < n);  // the previous factorisation overwrote J^T J
       // (J^T e_t)_j = J[target row t][j]
       const int row = P->n_crows + t;
       double rhs = 0.0;
@@ -1253,10 +1362,10 @@ okx_tangent_kernel(const DevProgram* __restrict__ P, TangentArgs args) {
           if (P->row_blk[row][s] == blk) rhs = S.js[(size_t)row * P->js_stride + 3 * s + lane % 3];
       }
       double q = 0.0;
-      const bool ok = ldlt_solve_reg<NREG>(P, S, lane, 0.0, -rhs, &q, &pmin, &pmax);
+      const bool ok = ldlt_solve<NREG, W>(P, S, lane, 0.0, -rhs, &q, &pmin, &pmax);
       all_ok = all_ok && ok;
       wave_sync();
-      for (int e = lane; e < 3 * P->n_points; e += kWave) vel[e] = 0.0;
+      for (int e = lane; e < 3 * P->n_points; e += W) vel[e] = 0.0;
       wave_sync();
       if (lane < n) vel[xaddr] = q;
       wave_sync();
@@ -1267,7 +1376,7 @@ okx_tangent_kernel(const DevProgram* __restrict__ P, TangentArgs args) {
         wave_sync();
       }
       double* out = args.tan + ((b * T + t) * P->n_out) * 3;
-      for (int e = lane; e < 3 * P->n_out; e += kWave)
+      for (int e = lane; e < 3 * P->n_out; e += W)
         out[e] = ok ? vel[3 * P->out_point[e / 3] + e % 3] : __builtin_nan("");
     }
     if (lane == 0) {

@@ -23,8 +23,8 @@ namespace okx {
 
 constexpr int kWave = 64;
 constexpr int kMaxPoints = OKX_MAX_POINTS;   // 96
-constexpr int kMaxVars = OKX_MAX_VARS;       // 63: one lane per variable
-constexpr int kMaxFree = OKX_MAX_VARS / 3;   // 21
+constexpr int kMaxVars = OKX_MAX_VARS;       // 126: one thread per variable (one wavefront up to 63, two beyond)
+constexpr int kMaxFree = OKX_MAX_VARS / 3;   // 42
 constexpr int kMaxDerived = 32;
 constexpr int kMaxRows = OKX_MAX_ROWS;       // 128 (constraint rows + target rows)
 constexpr int kMaxTargets = OKX_MAX_TARGETS;

@@ -181,22 +181,29 @@ def build_suspension(data: Mapping[str, Any]) -> Suspension:
     center = _hardpoints(hp.get("center") or {})
     arb = str(axle_config.get("anti_roll", {}).get("type", "none")).lower()
     heave = str(axle_config.get("heave_link", {}).get("type", "none")).lower()
-    if arb not in ("none", "u_bar"):
-        raise NotImplementedError(f"anti-roll type '{arb}' is outside the accelerated path")
-    if heave != "none":
-        raise NotImplementedError(f"heave link '{heave}' is outside the accelerated path")
+    if arb not in ("none", "u_bar", "t_bar"):
+        raise ValueError(f"Unsupported anti-roll type: {arb}")
+    if heave not in ("none", "rocker_to_rocker"):
+        raise ValueError(f"Unsupported heave-link type: {heave}")
+    has_rocker = kind == "double_wishbone" and str(axle_config.get("actuation", {}).get("type", "")).lower() == "pushrod_rocker"
+    strut = ", which a MacPherson corner does not provide" if kind == "macpherson" else ""
+    if arb != "none" and not has_rocker:  # schema/geometry.py:128-137,196-208
+        raise ValueError("The implemented anti-roll mechanism requires pushrod-rocker actuation" + strut)
+    if heave != "none" and not has_rocker:
+        raise ValueError("A rocker-to-rocker heave link requires pushrod-rocker actuation" + strut)
     external: tuple = ()
     droplinks: dict = {}
-    if arb == "u_bar":
-        if kind != "double_wishbone" or str(axle_config.get("actuation", {}).get("type", "")).lower() != "pushrod_rocker":
-            raise ValueError("The implemented anti-roll mechanism requires pushrod-rocker actuation")
+    if arb != "none":  # build.py:147-179: the droplink's rocker pickup belongs to the corner, its bar end to the axle
         external = (PointID.DROPLINK_ROCKER,)
+        arm = PointID.DROPLINK_U_BAR if arb == "u_bar" else PointID.DROPLINK_T_BAR
         for side, points in ((Side.LEFT, left), (Side.RIGHT, right)):
-            if PointID.DROPLINK_U_BAR not in points:
-                raise ValueError(f"{side.name} u-bar requires DROPLINK_U_BAR")
-            droplinks[side] = points.pop(PointID.DROPLINK_U_BAR)
+            if arm not in points:
+                raise ValueError(f"{side.name} {arb.replace('_', '-')} requires {arm.name}")
+            droplinks[side] = points.pop(arm)
     elif center:
         raise ValueError("Axle without anti-roll hardware does not accept center points")
+    if heave != "none":
+        external = (*external, PointID.HEAVE_LINK_ROCKER)
     name = str(data.get("name", "unnamed"))
     corners = {}
     for side, points in ((Side.LEFT, left), (Side.RIGHT, right)):
@@ -204,7 +211,8 @@ def build_suspension(data: Mapping[str, Any]) -> Suspension:
                                       axle_config.get("actuation"), axle_config.get("spring"), external,
                                       vehicle=_vehicle(data["vehicle_config"] or {}, axle_config.get("axle_position")),
                                       camber_shim=shims[side])
-    return AxleSuspension(name=name, corners=corners, arb_center_points=center, arb_droplink_points=droplinks)
+    return AxleSuspension(name=name, corners=corners, arb_center_points=center, arb_droplink_points=droplinks,
+                          arb_kind=arb if arb != "none" else "", heave_link=heave != "none")
 
 
 def build_sweep(data: Mapping[str, Any], suspension: Suspension | None = None) -> SweepConfig:

@@ -159,7 +159,7 @@ def topology_rotation_roles(suspension, program, side=None) -> tuple[list[str], 
             n, r = topology_rotation_roles(suspension.corners[s], program, s)
             names += [f"{k}_{s.name.lower()}" for k in n]
             roles += r
-        if suspension.has_arb:
+        if suspension.arb_kind == "u_bar":
             a, b = (suspension.arb_center_points[k].data for k in (PointID.ARB_U_BAR_AXIS_A, PointID.ARB_U_BAR_AXIS_B))
             for s in (Side.LEFT, Side.RIGHT):
                 names.append(f"arb_arm_angle_{s.name.lower()}")
@@ -224,6 +224,82 @@ def axle_topology_metrics(axle, program, positions: torch.Tensor, tangents: torc
         out["arb_twist"] = out["arb_arm_angle_left"] - out["arb_arm_angle_right"]
         if deriv is not None:
             out["d_arb_twist"] = out["d_arb_arm_angle_left"] - out["d_arb_arm_angle_right"]
+    return out
+
+
+def _response_with_rates(fn, positions: torch.Tensor, tangents: torch.Tensor | None):
+    """``fn(positions [B, n_out, 3]) -> [B]`` and, with tangents ``[B, T, n_out, 3]``, its rate along every target's
+    tangent ``[B, T]`` (the reference pushes dual numbers through the same closed forms: ``metrics/derivatives.py``);
+    every state's value depends on its own positions only, so one reverse pass of the batch sum gives all gradients."""
+    if tangents is None:
+        return fn(positions), None
+    with torch.enable_grad():
+        pos = positions.detach().clone().requires_grad_(True)
+        value = fn(pos)
+        (grad,) = torch.autograd.grad(value.sum(), pos)
+    return value.detach(), torch.einsum("bpc,btpc->bt", grad, tangents)
+
+
+def axle_hardware_metrics(axle, program, positions: torch.Tensor, tangents: torch.Tensor | None = None) -> dict:
+    """
+    State metrics of the axle's shared hardware that are not rotations about a fixed axis, on the device tensors the
+    solve returned: a rigid T-bar's ``t_bar_heave_angle`` (crossbar midpoint about the pivot's lateral axis, design ->
+    current) and ``arb_twist`` (crossbar rotation about the moving stem, minus its design value), and a
+    rocker-to-rocker heave link's ``heave_link_length`` (``axle/mechanisms.py:763-815,934-944``).  With tangents also
+    ``d_t_bar_center_x``, ``d_arb_twist`` and ``d_heave_link_length``: rates ``[B, T]`` along every target's tangent
+    (``mechanisms.py:718-761,903-928``).  Values in deg / mm like the reference's rows.
+    """
+    if not positions.is_cuda:
+        raise RuntimeError("axle_hardware_metrics needs device tensors (there is no CPU fallback)")
+    out_keys = [program.point_keys[k] for k in program.out_point]
+    pos = positions.to(torch.float64)
+    out: dict = {}
+    design = axle.initial_state().positions
+    dev = pos.device
+    vec = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float64), device=dev)  # noqa: E731
+    if getattr(axle, "arb_kind", "") == "t_bar":
+        il = out_keys.index(PointRef(Side.LEFT, PointID.DROPLINK_T_BAR))
+        ir = out_keys.index(PointRef(Side.RIGHT, PointID.DROPLINK_T_BAR))
+        pivot = vec(axle.arb_center_points[PointID.ARB_T_BAR_PIVOT].data)
+        lateral = vec([0.0, 1.0, 0.0])
+        d_left = design[PointRef(Side.LEFT, PointID.DROPLINK_T_BAR)].data
+        d_right = design[PointRef(Side.RIGHT, PointID.DROPLINK_T_BAR)].data
+
+        def center(p, a=il, b=ir):
+            return p[:, a] + (p[:, b] - p[:, a]) / 2.0
+
+        def shaft_twist(p, a=il, b=ir):  # mechanisms.py:800-815
+            stem = center(p, a, b) - pivot
+            stem = stem / stem.norm(dim=1, keepdim=True)
+            crossbar = p[:, a] - p[:, b]
+            crossbar = crossbar - stem * (crossbar * stem).sum(1, keepdim=True)
+            sine = (stem * torch.linalg.cross(lateral.expand_as(crossbar), crossbar)).sum(1)
+            return torch.atan2(sine, crossbar[:, 1])
+
+        design_pair = vec(np.stack([d_left, d_right]))[None]  # [1, 2, 3]: (left end, right end) of the design state
+        design_center, design_twist = center(design_pair, 0, 1)[0], shaft_twist(design_pair, 0, 1)[0]
+        radius0 = design_center - pivot
+        perp0 = radius0 - lateral * radius0[1]
+
+        def heave_angle(p):  # signed_angle_about_axis, vector_utils/geometric.py:31-52
+            radius = center(p) - pivot
+            perp = radius - lateral * radius[:, 1:2]
+            sine = (lateral * torch.linalg.cross(radius0.expand_as(radius), radius)).sum(1)
+            return torch.rad2deg(torch.atan2(sine, (perp * perp0).sum(1)))
+
+        out["t_bar_heave_angle"] = heave_angle(pos)
+        twist, d_twist = _response_with_rates(lambda p: torch.rad2deg(shaft_twist(p)), pos, tangents)
+        out["arb_twist"] = twist - torch.rad2deg(design_twist)
+        if tangents is not None:
+            out["d_arb_twist"] = d_twist
+            out["d_t_bar_center_x"] = (tangents[:, :, il, 0] + (tangents[:, :, ir, 0] - tangents[:, :, il, 0]) / 2.0).to(torch.float64)
+    if getattr(axle, "heave_link", False):
+        hl = out_keys.index(PointRef(Side.LEFT, PointID.HEAVE_LINK_ROCKER))
+        hr = out_keys.index(PointRef(Side.RIGHT, PointID.HEAVE_LINK_ROCKER))
+        length, d_length = _response_with_rates(lambda p: (p[:, hl] - p[:, hr]).norm(dim=1), pos, tangents)
+        out["heave_link_length"] = length
+        if tangents is not None:
+            out["d_heave_link_length"] = d_length
     return out
 
 

@@ -45,7 +45,7 @@ DOP_CONTACT_PATCH = 2
 
 ROW_PARAMS = 8
 ROW_POINTS = 4
-MAX_VARS = 63
+MAX_VARS = 126
 MAX_ROWS = 128
 MAX_POINTS = 96
 MAX_TARGETS = 8
@@ -233,7 +233,8 @@ class ConstraintProgram:
         """Static checks shared by the oracle and the device library."""
         if self.n_points > MAX_POINTS or self.n_vars > MAX_VARS:
             raise ValueError(
-                f"problem too large for one wavefront: points={self.n_points}, vars={self.n_vars}"
+                f"problem too large: points={self.n_points} (limit {MAX_POINTS}), vars={self.n_vars} (limit {MAX_VARS}: "
+                f"one thread per variable, two wavefronts per problem)"
             )
         if self.n_residuals > MAX_ROWS or self.n_targets > MAX_TARGETS:
             raise ValueError(

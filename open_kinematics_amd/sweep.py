@@ -243,23 +243,44 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
     for s in range(len(states)):
         axle_row = OrderedDict((n, _none_if_nan(axle_values[s, k])) for k, n in enumerate(AXLE_METRIC_NAMES))
         rows.append(AxleMetricRows(axle_row, {side: per_side[side][s] for side in (Side.LEFT, Side.RIGHT)}))
-    if arm is not None:
-        twist = (rot_values[:, arm[Side.LEFT]] - rot_values[:, arm[Side.RIGHT]]).cpu().numpy()
-        arm_values = {side: rot_values[:, arm[side]].cpu().numpy() for side in arm}
-        d_twist = {}
-        if tangents is not None:
-            from .enums import PointID, PointRef
+    from .enums import PointID, PointRef
+    from .metrics import axle_hardware_metrics
 
-            rate = rot_derivs[:, :, arm[Side.LEFT]] - rot_derivs[:, :, arm[Side.RIGHT]]
-            for side in (Side.LEFT, Side.RIGHT):
-                key = PointRef(side, PointID.WHEEL_CENTER)
-                cand = [t for t, k in enumerate(tgt_keys) if k == key]
-                d_twist[side] = _driver_ratio(rate, tangents, out_keys.index(key), 2, cand,
-                                              f"deriv_arb_twist_wrt_hub_z_{side.name.lower()}").cpu().numpy()
-        for s, row in enumerate(rows):
-            row.axle["arb_twist"] = _none_if_nan(twist[s])
-            for side, col in d_twist.items():
-                row.axle[f"deriv_arb_twist_wrt_hub_z_{side.name.lower()}"] = _none_if_nan(col[s])
-            for side in arm:
-                row.corners[side]["arb_arm_angle"] = _none_if_nan(arm_values[side][s])
+    def hub_z_columns(response: str, rate) -> dict:
+        """``deriv_<response>_wrt_hub_z_<side>`` per side from the response's rate along every target's tangent."""
+        columns = OrderedDict()
+        for side in (Side.LEFT, Side.RIGHT):
+            key = PointRef(side, PointID.WHEEL_CENTER)
+            cand = [t for t, k in enumerate(tgt_keys) if k == key]
+            column = f"deriv_{response}_wrt_hub_z_{side.name.lower()}"
+            columns[column] = _driver_ratio(rate, tangents, out_keys.index(key), 2, cand, column).cpu().numpy()
+        return columns
+
+    # the shared hardware's state metrics, then its derivative columns: anti-roll bar first, heave link second
+    # (axle/suspension.py:213-238)
+    state_columns: OrderedDict = OrderedDict()
+    deriv_columns: OrderedDict = OrderedDict()
+    hardware = axle_hardware_metrics(suspension, program, positions, tangents)
+    if arm is not None:  # U-bar: arm angles about the bar's axis; the twist is their difference
+        state_columns["arb_twist"] = (rot_values[:, arm[Side.LEFT]] - rot_values[:, arm[Side.RIGHT]]).cpu().numpy()
+        if tangents is not None:
+            deriv_columns.update(hub_z_columns("arb_twist", rot_derivs[:, :, arm[Side.LEFT]] - rot_derivs[:, :, arm[Side.RIGHT]]))
+    if "t_bar_heave_angle" in hardware:  # rigid T-bar (axle/mechanisms.py:718-797)
+        state_columns["t_bar_heave_angle"] = hardware["t_bar_heave_angle"].cpu().numpy()
+        state_columns["arb_twist"] = hardware["arb_twist"].cpu().numpy()
+        if tangents is not None:
+            center, twist = hub_z_columns("t_bar_center_x", hardware["d_t_bar_center_x"]), hub_z_columns("arb_twist", hardware["d_arb_twist"])
+            for side in ("left", "right"):  # per driver: centre travel, then twist
+                for columns in (center, twist):
+                    deriv_columns.update({k: v for k, v in columns.items() if k.endswith("_" + side)})
+    if "heave_link_length" in hardware:  # mechanisms.py:903-944
+        state_columns["heave_link_length"] = hardware["heave_link_length"].cpu().numpy()
+        if tangents is not None:
+            deriv_columns.update(hub_z_columns("heave_link_length", hardware["d_heave_link_length"]))
+    arm_values = {side: rot_values[:, arm[side]].cpu().numpy() for side in arm} if arm is not None else {}
+    for s, row in enumerate(rows):
+        for name, col in (*state_columns.items(), *deriv_columns.items()):
+            row.axle[name] = _none_if_nan(col[s])
+        for side, col in arm_values.items():
+            row.corners[side]["arb_arm_angle"] = _none_if_nan(col[s])
     return SweepMetricsResult(rows, derivative_error, tangent_infos)

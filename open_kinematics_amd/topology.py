@@ -11,8 +11,7 @@ Reference (``core/suspensions/``): ``corner/double_wishbone.py:233-308``,
 Scope: double-wishbone corner (direct or pushrod-rocker actuation; no spring, coil-over or
 torsion bar; rack or fixed toe link), MacPherson corner, and the composed axle with rack
 coupling and a U-bar anti-roll bar; a double wishbone's camber-shim setup solve runs on the device
-(``shims.py``).  T-bar ARBs and heave links are outside the hot path and raise
-``NotImplementedError``.
+(``shims.py``); the axle's shared hardware: U-bar or rigid T-bar anti-roll bar, rocker-to-rocker heave link.
 """
 
 from __future__ import annotations
@@ -27,6 +26,7 @@ from .constraints import (
     AngleConstraint,
     Constraint,
     DistanceConstraint,
+    MidpointOnPlaneConstraint,
     PointOnLineConstraint,
     ScalarTripleProductConstraint,
 )
@@ -607,19 +607,24 @@ def _wrap_side(function, side: Side):
 
 @dataclass
 class AxleSuspension(Suspension):
-    """Two corners + rack coupling + U-bar ARB (``axle/suspension.py``, ``axle/mechanisms.py:228-342``)."""
+    """Two corners + rack coupling + the shared hardware: a U-bar or a rigid T-bar anti-roll bar and a
+    rocker-to-rocker heave link (``axle/suspension.py``, ``axle/mechanisms.py:228-342,600-720,880-960``)."""
 
     name: str
     corners: dict
-    arb_center_points: dict = field(default_factory=dict)      # PointID -> Point3 (U-bar axis)
+    arb_center_points: dict = field(default_factory=dict)      # PointID -> Point3 (U-bar axis / T-bar pivot)
     arb_droplink_points: dict = field(default_factory=dict)    # Side -> Point3
+    arb_kind: str = ""                                         # "", "u_bar", "t_bar" ("" = from the points given)
+    heave_link: bool = False                                   # variable-length link between the rockers
     _state: SuspensionState | None = field(default=None, init=False, repr=False)
 
     def __post_init__(self) -> None:
         if set(self.corners) != {Side.LEFT, Side.RIGHT}:
             raise ValueError("Axle requires exactly LEFT and RIGHT corner models.")
         self.rack_attachment_points()
-        if self.has_arb:
+        if not self.arb_kind and self.has_arb:
+            self.arb_kind = "t_bar" if P.ARB_T_BAR_PIVOT in self.arb_center_points else "u_bar"
+        if self.arb_kind == "u_bar":
             if set(self.arb_center_points) != {P.ARB_U_BAR_AXIS_A, P.ARB_U_BAR_AXIS_B}:
                 raise ValueError("U-bar requires center ARB_U_BAR_AXIS_A and ARB_U_BAR_AXIS_B")
             if set(self.arb_droplink_points) != {Side.LEFT, Side.RIGHT}:
@@ -627,10 +632,50 @@ class AxleSuspension(Suspension):
             for side, corner in self.corners.items():
                 if P.DROPLINK_ROCKER not in corner.free_points():
                     raise ValueError(f"{side.name} U-bar corner does not expose DROPLINK_ROCKER as a moving pickup")
+        elif self.arb_kind == "t_bar":
+            self._validate_t_bar()
+        if self.heave_link:  # mechanisms.py:884-899
+            for side, corner in self.corners.items():
+                if P.HEAVE_LINK_ROCKER not in corner.free_points():
+                    raise ValueError(f"{side.name} corner does not expose HEAVE_LINK_ROCKER as a moving pickup")
+            left = self.corners[Side.LEFT].initial_state().positions[P.HEAVE_LINK_ROCKER].data
+            right = self.corners[Side.RIGHT].initial_state().positions[P.HEAVE_LINK_ROCKER].data
+            if float(np.linalg.norm(left - right)) <= EPS_GEOMETRIC:
+                raise ValueError("Rocker-to-rocker heave-link pickups must be separated in the design state")
+
+    def _validate_t_bar(self) -> None:
+        """``ArbTBar.validate`` (``axle/mechanisms.py:610-646``): pivot and crossbar midpoint on the centre line,
+        a proper triangle."""
+        for side, corner in self.corners.items():
+            if P.DROPLINK_ROCKER not in corner.free_points():
+                raise ValueError(f"{side.name} T-bar corner does not expose DROPLINK_ROCKER as a moving pickup")
+        if set(self.arb_center_points) != {P.ARB_T_BAR_PIVOT}:
+            raise ValueError("T-bar requires center ARB_T_BAR_PIVOT")
+        if set(self.arb_droplink_points) != {Side.LEFT, Side.RIGHT}:
+            raise ValueError("T-bar requires DROPLINK_T_BAR on both sides")
+        pivot = self.arb_center_points[P.ARB_T_BAR_PIVOT].data
+        if abs(float(pivot[1])) > EPS_GEOMETRIC:
+            raise ValueError("ARB_T_BAR_PIVOT must lie on the vehicle centerline Y = 0")
+        left, right = self.arb_droplink_points[Side.LEFT].data, self.arb_droplink_points[Side.RIGHT].data
+        middle = left + (right - left) / 2.0
+        if abs(float(middle[1])) > EPS_GEOMETRIC:
+            raise ValueError("The T-bar crossbar midpoint must lie on the vehicle centerline Y = 0")
+        crossbar, stem = right - left, middle - pivot
+        if float(np.linalg.norm(crossbar)) <= EPS_GEOMETRIC:
+            raise ValueError("T-bar crossbar points must be distinct")
+        if float(np.linalg.norm(stem)) <= EPS_GEOMETRIC:
+            raise ValueError("T-bar pivot and crossbar midpoint must be distinct")
+        if float(np.linalg.norm(np.cross(crossbar, stem))) <= EPS_GEOMETRIC:
+            raise ValueError("T-bar points must define a non-degenerate triangle")
 
     @property
     def has_arb(self) -> bool:
         return bool(self.arb_center_points) or bool(self.arb_droplink_points)
+
+    @property
+    def arb_arm_point(self):
+        """The moving ARB pickup a droplink ends on, per side: ``DROPLINK_U_BAR`` / ``DROPLINK_T_BAR`` / None."""
+        return {"u_bar": P.DROPLINK_U_BAR, "t_bar": P.DROPLINK_T_BAR}.get(self.arb_kind)
 
     def rack_attachment_points(self):
         left = self.corners[Side.LEFT].rack_attachment_point()
@@ -651,9 +696,10 @@ class AxleSuspension(Suspension):
         return PointRef(side, point)
 
     def _arb_free(self) -> tuple:
-        if not self.has_arb:
+        arm = self.arb_arm_point
+        if arm is None:
             return ()
-        return (PointRef(Side.LEFT, P.DROPLINK_U_BAR), PointRef(Side.RIGHT, P.DROPLINK_U_BAR))
+        return (PointRef(Side.LEFT, arm), PointRef(Side.RIGHT, arm))
 
     def initial_state(self) -> SuspensionState:
         if self._state is None:
@@ -666,7 +712,7 @@ class AxleSuspension(Suspension):
             for point, position in self.arb_center_points.items():
                 positions[PointRef(Side.CENTER, point)] = position.copy()
             for side, position in self.arb_droplink_points.items():
-                key = PointRef(side, P.DROPLINK_U_BAR)
+                key = PointRef(side, self.arb_arm_point)
                 positions[key] = position.copy()
                 free.add(key)
             self._state = SuspensionState(positions, free)
@@ -689,19 +735,35 @@ class AxleSuspension(Suspension):
             right = self.corners[Side.RIGHT].initial_state().positions[rack[1]].data
             rows.append(DistanceConstraint(PointRef(Side.LEFT, rack[0]), PointRef(Side.RIGHT, rack[1]),
                                            float(np.linalg.norm(right - left))))
-        if self.has_arb:  # mechanisms.py:307-342
+        rocker = {side: self.corners[side].initial_state().positions.get(P.DROPLINK_ROCKER) for side in self.corners}
+        if self.arb_kind == "u_bar":  # mechanisms.py:307-342
             axis_a = self.arb_center_points[P.ARB_U_BAR_AXIS_A].data
             axis_b = self.arb_center_points[P.ARB_U_BAR_AXIS_B].data
             key_a, key_b = PointRef(Side.CENTER, P.ARB_U_BAR_AXIS_A), PointRef(Side.CENTER, P.ARB_U_BAR_AXIS_B)
             for side in (Side.LEFT, Side.RIGHT):
                 drop = self.arb_droplink_points[side].data
                 arm = PointRef(side, P.DROPLINK_U_BAR)
-                rocker = self.corners[side].initial_state().positions[P.DROPLINK_ROCKER].data
                 rows += [
                     DistanceConstraint(arm, key_a, float(np.linalg.norm(axis_a - drop))),
                     DistanceConstraint(arm, key_b, float(np.linalg.norm(axis_b - drop))),
-                    DistanceConstraint(PointRef(side, P.DROPLINK_ROCKER), arm, float(np.linalg.norm(drop - rocker))),
+                    DistanceConstraint(PointRef(side, P.DROPLINK_ROCKER), arm, float(np.linalg.norm(drop - rocker[side].data))),
                 ]
+        elif self.arb_kind == "t_bar":
+            # rigid triangle (two crossbar ends + chassis pivot), crossbar midpoint on the vehicle XZ plane, one
+            # droplink per side (mechanisms.py:670-716); the heave link adds no row - its length is free
+            pivot_key = PointRef(Side.CENTER, P.ARB_T_BAR_PIVOT)
+            pivot = self.arb_center_points[P.ARB_T_BAR_PIVOT].data
+            ends = {side: self.arb_droplink_points[side].data for side in (Side.LEFT, Side.RIGHT)}
+            arm = {side: PointRef(side, P.DROPLINK_T_BAR) for side in (Side.LEFT, Side.RIGHT)}
+            rows += [
+                DistanceConstraint(arm[Side.LEFT], arm[Side.RIGHT], float(np.linalg.norm(ends[Side.LEFT] - ends[Side.RIGHT]))),
+                DistanceConstraint(arm[Side.LEFT], pivot_key, float(np.linalg.norm(ends[Side.LEFT] - pivot))),
+                DistanceConstraint(arm[Side.RIGHT], pivot_key, float(np.linalg.norm(ends[Side.RIGHT] - pivot))),
+                MidpointOnPlaneConstraint(arm[Side.LEFT], arm[Side.RIGHT], np.zeros(3), WORLD_Y),
+            ]
+            for side in (Side.LEFT, Side.RIGHT):
+                rows.append(DistanceConstraint(PointRef(side, P.DROPLINK_ROCKER), arm[side],
+                                               float(np.linalg.norm(rocker[side].data - ends[side]))))
         return rows
 
     def derived_spec(self) -> DerivedPointsSpec:

@@ -125,6 +125,8 @@ def emit_axle(name: str, out_name: str, stride: int) -> None:
     arrays["axle_deriv_names"] = np.array(dnames)
     arrays["axle_deriv"] = np.asarray([[_num(r.axle[k]) for k in dnames] for r in rows])
     np.savez_compressed(os.path.join(OUT, f"metrics_{out_name}.npz"), **arrays)
+    arrays["axle_key_order"] = np.array(list(rows[0].axle))
+    arrays["left_key_order"] = np.array(list(rows[0].corners[Side.LEFT]))
     print(f"   extras: axle {extra} + {dnames}; left {list(arrays['left_extra_names'])} + {list(arrays['left_deriv_names'])}")
     print(f"metrics_{out_name}: {len(rows)} states; axle row {dict(zip(AXLE_NAMES, arrays['axle_values'][len(rows) // 3]))}")
 
@@ -132,6 +134,11 @@ def emit_axle(name: str, out_name: str, stride: int) -> None:
 def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "axle":
         emit_axle("c3_axle_grid", "axle_c3", stride=5)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "hardware":  # T-bar anti-roll bar, rocker-to-rocker heave link
+        emit_axle("t_axle_t_bar_roll", "axle_t_bar_roll", stride=3)
+        emit_axle("t_axle_t_bar_bump", "axle_t_bar_bump", stride=5)
+        emit_axle("t_axle_heave_link", "axle_heave_link", stride=1)
         return
     emit("c1_dw_corner")
     emit("c4_macpherson_grid")

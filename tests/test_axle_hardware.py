@@ -1,0 +1,129 @@
+"""
+Host side of the axle's shared hardware (CPU): the rigid T-bar anti-roll bar and the rocker-to-rocker heave link as the
+loader builds them - points, rows, validation messages - after the reference's tests/test_t_bar_arb.py and
+tests/test_axle_rocker.py (axle/mechanisms.py:600-720,880-960; schema/geometry.py:120-137,190-208).
+"""
+
+import copy
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from conftest import GOLDEN
+from open_kinematics_amd import input as okin
+from open_kinematics_amd.constraints import DistanceConstraint, MidpointOnPlaneConstraint
+from open_kinematics_amd.enums import PointID, PointRef, Side
+from open_kinematics_amd.program import MAX_VARS, flatten_problem
+from open_kinematics_amd.solver import absolute_target_table
+
+GEOM = os.path.join(GOLDEN, "geometry")
+
+
+def _load(name):
+    with open(os.path.join(GEOM, name), encoding="utf-8") as fh:
+        return yaml.safe_load(fh)
+
+
+def _heave_axle_data(pickup_y_mm: float = 300.0) -> dict:
+    """The reference's own construction (tests/test_axle_rocker.py:40-60)."""
+    data = copy.deepcopy(_load("axle_geometry_rocker.yaml"))
+    data["axle_config"]["heave_link"] = {"type": "rocker_to_rocker"}
+    data["hardpoints"]["left"]["heave_link_rocker"] = {"x": 0, "y": pickup_y_mm, "z": 400}
+    return data
+
+
+def test_t_bar_assembly_has_only_pivot_and_crossbar_endpoints():
+    axle = okin.build_suspension(_load("axle_geometry_t_bar.yaml"))
+    assert axle.arb_kind == "t_bar" and not axle.heave_link
+    state = axle.initial_state()
+    pivot = PointRef(Side.CENTER, PointID.ARB_T_BAR_PIVOT)
+    assert pivot in state.positions and pivot not in state.free_points
+    for side in (Side.LEFT, Side.RIGHT):
+        assert PointRef(side, PointID.DROPLINK_T_BAR) in state.free_points
+        assert PointRef(side, PointID.DROPLINK_T_BAR) in axle.output_points()
+    assert not any(k.point is PointID.DROPLINK_T_BAR for k in axle.derived_spec().functions)
+    rows = axle.constraints()
+    assert len(state.positions) == 43 and len(axle.free_points()) == 20 and len(rows) == 65
+    plane = [c for c in rows if isinstance(c, MidpointOnPlaneConstraint)]
+    assert len(plane) == 1 and np.array_equal(plane[0].plane_normal, [0.0, 1.0, 0.0])
+    # rigid triangle: both crossbar ends to each other and to the pivot, at their design lengths
+    ends = {side: PointRef(side, PointID.DROPLINK_T_BAR) for side in (Side.LEFT, Side.RIGHT)}
+    pairs = [{ends[Side.LEFT], ends[Side.RIGHT]}, {ends[Side.LEFT], pivot}, {ends[Side.RIGHT], pivot}]
+    for pair in pairs:
+        row = [c for c in rows if isinstance(c, DistanceConstraint) and {c.p1, c.p2} == pair]
+        assert len(row) == 1
+        a, b = (state.positions[k].data for k in pair)
+        assert row[0].target_distance == float(np.linalg.norm(a - b))
+
+
+def test_t_bar_validation_messages():
+    base = _load("axle_geometry_t_bar.yaml")
+    off = copy.deepcopy(base)
+    off["hardpoints"]["center"]["arb_t_bar_pivot"]["y"] = 1.0
+    with pytest.raises(ValueError, match="ARB_T_BAR_PIVOT must lie on the vehicle centerline"):
+        okin.build_suspension(off)
+    missing = copy.deepcopy(base)
+    del missing["hardpoints"]["left"]["droplink_t_bar"]
+    with pytest.raises(ValueError, match="LEFT t-bar requires DROPLINK_T_BAR"):
+        okin.build_suspension(missing)
+    no_pivot = copy.deepcopy(base)
+    no_pivot["hardpoints"]["center"] = {}
+    with pytest.raises(ValueError, match="T-bar requires center ARB_T_BAR_PIVOT"):
+        okin.build_suspension(no_pivot)
+    flat = copy.deepcopy(base)  # pivot on the crossbar: no triangle
+    left = flat["hardpoints"]["left"]["droplink_t_bar"]
+    flat["hardpoints"]["center"]["arb_t_bar_pivot"] = {"x": left["x"], "y": 0.0, "z": left["z"]}
+    with pytest.raises(ValueError, match="T-bar pivot and crossbar midpoint must be distinct|non-degenerate triangle"):
+        okin.build_suspension(flat)
+    direct = copy.deepcopy(_load("axle_geometry.yaml"))
+    direct["axle_config"]["anti_roll"] = {"type": "t_bar"}
+    with pytest.raises(ValueError, match="requires pushrod-rocker actuation"):
+        okin.build_suspension(direct)
+    strut = copy.deepcopy(_load("macpherson_axle_geometry.yaml"))
+    strut["axle_config"]["heave_link"] = {"type": "rocker_to_rocker"}
+    with pytest.raises(ValueError, match="heave link requires pushrod-rocker actuation, which a MacPherson corner does not provide"):
+        okin.build_suspension(strut)
+    bogus = copy.deepcopy(base)
+    bogus["axle_config"]["anti_roll"] = {"type": "z_bar"}
+    with pytest.raises(ValueError, match="Unsupported anti-roll type"):
+        okin.build_suspension(bogus)
+
+
+@pytest.mark.parametrize("pickup_y_mm", [0.0, 1e-6 / 4.0])
+def test_heave_link_rejects_undefined_design_distance(pickup_y_mm):
+    with pytest.raises(ValueError, match="heave-link pickups must be separated in the design state"):
+        okin.build_suspension(_heave_axle_data(pickup_y_mm))
+
+
+def test_heave_link_composes_with_u_bar_without_rigid_length_constraint():
+    axle = okin.build_suspension(_heave_axle_data())
+    assert axle.arb_kind == "u_bar" and axle.heave_link
+    ends = {PointRef(Side.LEFT, PointID.HEAVE_LINK_ROCKER), PointRef(Side.RIGHT, PointID.HEAVE_LINK_ROCKER)}
+    state = axle.initial_state()
+    assert ends <= state.positions.keys() and ends <= state.free_points and ends <= set(axle.output_points())
+    right = state.positions[PointRef(Side.RIGHT, PointID.HEAVE_LINK_ROCKER)].data
+    assert np.array_equal(right, [0.0, -300.0, 400.0])  # mirrored pickup
+    assert not any(isinstance(c, DistanceConstraint) and {c.p1, c.p2} == ends for c in axle.constraints())
+    # 22 free points: beyond one wavefront's 63 variables, within the two-wavefront kernels' 126
+    sweep = okin.build_sweep(_load("axle_rocker_sweep.yaml"), axle)
+    heads, _ = absolute_target_table(sweep, state)
+    program = flatten_problem(state, axle.constraints(), axle.derived_spec(), heads, axle.output_points())
+    assert 63 < program.n_vars == 66 <= MAX_VARS
+
+
+def test_programs_beyond_the_variable_limit_are_refused_with_the_limit_named():
+    """43 free points = 129 variables: the loader builds it, the flattened program refuses it."""
+    from open_kinematics_amd.state import Point3, SuspensionState
+
+    n_free = MAX_VARS // 3 + 1
+    positions = {PointRef(Side.LEFT, PointID(k)) if k < 34 else PointRef(Side.RIGHT, PointID(k - 34)): Point3([float(k), 1.0, 2.0])
+                 for k in range(n_free + 1)}
+    keys = list(positions)
+    state = SuspensionState(positions, set(keys[:n_free]))
+    rows = [DistanceConstraint(a, keys[-1], 1.0) for a in keys[:n_free]]
+    from open_kinematics_amd.derived import DerivedPointsSpec
+
+    with pytest.raises((ValueError, NotImplementedError), match=str(MAX_VARS)):
+        flatten_problem(state, rows, DerivedPointsSpec({}, {}), [], tuple(keys[:n_free])).validate()

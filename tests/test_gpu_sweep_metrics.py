@@ -60,17 +60,23 @@ def test_corner_rows_match_the_reference(golden, name):
             assert _close(row[col], mg["deriv"][s][j], 1e-7), (s, col)
 
 
-def test_axle_rows_match_the_reference(golden):
+@pytest.mark.parametrize("name,metrics_name,stride", [
+    ("c3_axle_grid", "axle_c3", 4),                    # U-bar: arm angles + twist
+    ("t_axle_t_bar_roll", "axle_t_bar_roll", 1),       # rigid T-bar, wheels opposed: twist
+    ("t_axle_t_bar_bump", "axle_t_bar_bump", 1),       # rigid T-bar, wheels in phase: stem heave angle
+    ("t_axle_heave_link", "axle_heave_link", 1),       # U-bar + rocker-to-rocker heave link (66 variables)
+])
+def test_axle_rows_match_the_reference(golden, name, metrics_name, stride):
     from open_kinematics_amd.enums import Side
     from open_kinematics_amd.input import build_suspension, build_sweep
     from open_kinematics_amd.metrics import AXLE_METRIC_NAMES, CATALOG_ORDER, METRIC_NAMES
     from open_kinematics_amd.sweep import compute_sweep_metrics
 
-    arrays, _ = golden("c3_axle_grid")
-    mg = load_metrics_golden("axle_c3")
+    arrays, _ = golden(name)
+    mg = load_metrics_golden(metrics_name)
     axle = build_suspension(yaml.safe_load(str(arrays["geometry_yaml"])))
     sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), axle)
-    pick = list(range(0, mg["pos"].shape[0], 4))
+    pick = list(range(0, mg["pos"].shape[0], stride))
     states = _states(axle, mg["pos"][pick], axle.output_points())
     result = compute_sweep_metrics(axle, sweep, states)
     assert result.derivative_error is None
@@ -79,12 +85,17 @@ def test_axle_rows_match_the_reference(golden):
     for tag, side in (("left", Side.LEFT), ("right", Side.RIGHT)):
         extras = [str(n) for n in mg[f"{tag}_extra_names"]]
         derivs = [str(n) for n in mg[f"{tag}_deriv_names"]]
-        # reference order: catalog, actuation / spring values, derivative columns, then the axle hardware's arm angle
-        assert list(first.corners[side]) == list(CATALOG_ORDER) + extras[:-1] + derivs + extras[-1:]
+        # reference order: catalog, actuation / spring values, derivative columns, then a U-bar's arm angle
+        tail = [n for n in extras if n == "arb_arm_angle"]
+        assert list(first.corners[side]) == list(CATALOG_ORDER) + [n for n in extras if n not in tail] + derivs + tail
+    if "axle_key_order" in mg:
+        assert list(first.axle) == [str(n) for n in mg["axle_key_order"]]
+        assert list(first.corners[Side.LEFT]) == [str(n) for n in mg["left_key_order"]]
     for row, s in zip(result.rows, pick):
         for k, n in enumerate(AXLE_METRIC_NAMES):
             assert _close(row.axle[n], mg["axle_values"][s][k], 1e-9), (s, n)
-        assert _close(row.axle["arb_twist"], mg["axle_extra_values"][s][0], 1e-9)
+        for j, n in enumerate(str(x) for x in mg["axle_extra_names"]):  # arb_twist, t_bar_heave_angle, heave_link_length
+            assert _close(row.axle[n], mg["axle_extra_values"][s][j], 1e-9), (s, n)
         for j, col in enumerate(str(n) for n in mg["axle_deriv_names"]):
             assert _close(row.axle[col], mg["axle_deriv"][s][j], 1e-7), (s, col)
         for tag, side in (("left", Side.LEFT), ("right", Side.RIGHT)):
