@@ -470,6 +470,51 @@ def measure_e2e_compact(dp, targets_host: np.ndarray, device, steps: int, cold_k
                     "pinned host buffers; never reported as `value`"}
 
 
+def measure_e2e_zero_copy(dp, targets_host: np.ndarray, device, steps: int, cold_kw: dict, n_slots: int = 3) -> dict:
+    """Host buffers in, host buffers out with NO copy commands: the boundary takes plain pointers, and pinned host memory
+    is device-accessible, so the solve kernel reads its targets from and stores its compact output (free coordinates +
+    info records) straight into the caller's pinned buffers - the bytes cross PCIe as the kernel issues them, three
+    sweeps in flight on three streams.  What bounds it is the link (3.0 MB out per 16384-step sweep), not the copy
+    engine's per-command latency that bounds the copy-based pipeline above."""
+    p = dp.program
+    n = targets_host.shape[0]
+    h_t = torch.as_tensor(targets_host).pin_memory()
+    slots = []
+    for _ in range(n_slots):
+        stream = torch.cuda.Stream(device)
+        h_free = torch.empty((n, p.n_free, 3), dtype=torch.float64).pin_memory()
+        h_info = torch.empty((n, 40), dtype=torch.uint8).pin_memory()
+        with torch.cuda.stream(stream):
+            launch = dp.plan(h_t, out=h_free, info_out=h_info, output="free", **cold_kw)
+        slots.append(dict(stream=stream, launch=launch, h_free=h_free, h_info=h_info, done=torch.cuda.Event()))
+
+    def issue(slot):
+        with torch.cuda.stream(slot["stream"]):
+            slot["launch"]()
+            slot["done"].record()
+
+    for k in range(2 * n_slots):
+        issue(slots[k % n_slots])
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        slot = slots[k % n_slots]
+        slot["done"].synchronize()   # the host owns this slot's buffers again (n_slots sweeps ago)
+        issue(slot)
+    torch.cuda.synchronize(device)
+    wall = (time.perf_counter() - t0) / steps
+    ok = bool(np.all((slots[0]["h_info"].numpy().view(INFO_FIELDS).reshape(-1)["flags"] & 7) == 1))
+    # the same sweep through device buffers: the host copy must hold the same bits
+    ref = dp.solve(torch.as_tensor(targets_host, device=device), output="free", **cold_kw)
+    torch.cuda.synchronize(device)
+    same = bool(np.array_equal(slots[0]["h_free"].numpy(), ref.free.cpu().numpy()))
+    bytes_out = int(n * (p.n_free * 24 + 40))
+    return {"value": n / wall, "ms_per_sweep": wall * 1e3, "bytes_in_over_pcie": int(h_t.numel() * 8), "bytes_out_over_pcie": bytes_out,
+            "pcie_out_gbs": bytes_out / wall / 1e9, "all_converged": ok, "same_bits_as_device_buffers": same, "streams": n_slots,
+            "note": "d_targets / d_out_pos / d_info of okx_solve_batch are the caller's pinned host buffers (device-accessible): "
+                    "no H2D / D2H commands at all; never reported as `value`"}
+
+
 def measure_config(name: str, make, device, steps: int, warmup: int, modes=("cold", "chained")) -> dict:
     """One BASELINE configuration at full size: cold independent solves (section 8d's rule) and the product's chained mode."""
     from open_kinematics_amd.batch import DeviceProgram
@@ -521,6 +566,10 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
         if tag not in modes:
             continue
         launch = dp.plan(targets, out=out, info_out=info, chain_len=chain_len, predictor=False, **kw)
+        warm_until = time.perf_counter() + 0.05  # >= 50 ms of the same launch first: the clocks ramp over tens of ms
+        while time.perf_counter() < warm_until:
+            launch()
+            torch.cuda.synchronize(device)
         wall, kernel_ms = time_launches(launch, steps, warmup, device)
         nfev, ok = info_summary(info)
         gbs = bytes_per * n / (kernel_ms * 1e-3) / 1e9
@@ -899,6 +948,8 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, extra_steps, dict(chain_len=args.chain_len, predictor=False))
         line["e2e"]["compact"] = measure_e2e_compact(dp, targets_all[lo:hi], device, max(extra_steps, 200),
                                                      dict(chain_len=args.chain_len, predictor=False))
+        line["e2e"]["zero_copy"] = measure_e2e_zero_copy(dp, targets_all[lo:hi], device, max(extra_steps, 200),
+                                                         dict(chain_len=args.chain_len, predictor=False))
         from open_kinematics_amd.workloads import geometry_path
         line["downstream"] = measure_downstream(dp, geometry_path("geometry.yaml"), pipe.local[0], device)
         dp.close()

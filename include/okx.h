@@ -9,7 +9,11 @@
  *
  * Conventions
  *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t passed as void*.
- *   - every pointer named d_* is a DEVICE pointer (HBM); everything else is host memory
+ *   - every pointer named d_* is a DEVICE-ACCESSIBLE pointer: normally HBM; pinned host
+ *     memory (hipHostMalloc / hipHostRegister, mapped) is accepted as well - okx_solve_batch's
+ *     d_targets, d_out_pos and d_info then cross PCIe as the kernel reads / stores them, with
+ *     no copy command on either side (bench.py `e2e.zero_copy`; the host may read the outputs
+ *     once an event recorded after the call has completed).  Everything else is host memory
  *     that is only read during the call.
  *   - all entry points return OKX_OK (0) or a negative okx_status; they never throw.
  *     okx_last_error() returns a thread-local message for the last failure.

@@ -49,6 +49,8 @@ def _ptr(t: torch.Tensor | None) -> C.c_void_p:
 def _as_f64(t, device) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         t = torch.as_tensor(np.asarray(t, dtype=np.float64))
+    if not t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.is_pinned():
+        return t  # pinned host memory is device-accessible: the kernel reads it over PCIe, no copy (okx.h: d_* pointers)
     return t.to(device=device, dtype=torch.float64).contiguous()
 
 

@@ -1281,10 +1281,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // Column k = 0 is the constraint rows' own gradient G_0 = Jc^T rc at the design state (the reference's distance
   // rows carry softnorm's -1e-6 offset there, constraints.py:125-134, so it is small but not zero) with weight 1;
   // column k = t + 1 belongs to target t: G_k = J^T e_t, weight = that target's residual.  Q_k = (J^T J + lambda I)^-1 G_k.
-  // Pair mode: generated on request only (OKX_PAIR_HEAD=1).  Measured on the axle grid: cold starts 5.65 -> 4.85
-  // evaluations but only -2 % time, and +3 % on chained grids, where the block's mere presence costs more registers
-  // than one head in eight steps gives back.
-  const bool head_ok = T >= 1 && getenv("OKX_QUAD_NO_HEAD") == nullptr && (!pv || getenv("OKX_PAIR_HEAD") != nullptr);
+  // Pair mode carries the first-order table (OKX_PAIR_NO_HEAD=1 leaves it out).  Measured on the axle grid, round 3:
+  // cold starts 5.57 -> 4.72 evaluations, 0.483 -> 0.455 ms; chained grids unchanged (0.211 vs 0.212 ms) - in round 2
+  // the block's registers still cost the chained grid 3 %, before the LM scalars and constants had homes in LDS.
+  const bool head_ok = T >= 1 && getenv("OKX_QUAD_NO_HEAD") == nullptr && (!pv || getenv("OKX_PAIR_NO_HEAD") == nullptr);
   // columns of the table: the constraint gradient, then one per PROGRAM target (pair mode: a side target stands for one
   // program target per half that carries it; the column's weight is that half's residual, its Q spans both halves)
   struct HeadCol { int t, side, prog_t; };

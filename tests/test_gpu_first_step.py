@@ -26,9 +26,6 @@ def _both(dp, targets, **kw):
 def test_cold_starts_take_the_same_path_with_one_evaluation_less(workload, line_mode, monkeypatch, tmp_path):
     from open_kinematics_amd.batch import DeviceProgram
 
-    if workload == "axle":  # pair-mode kernels carry the table on request only (no net gain there)
-        monkeypatch.setenv("OKX_PAIR_HEAD", "1")
-        monkeypatch.setenv("OKX_KERNEL_CACHE", str(tmp_path))  # compiled in place: not one of the precompiled kernels
     from open_kinematics_amd import workloads as W
     from oracle.oracle import Oracle
 

@@ -96,3 +96,24 @@ def test_the_interpreter_kernels_only_write_records(golden):
     with pytest.raises(ValueError, match="needs a generated kernel"):
         dp.solve(arrays["targets_abs"], kernel="single", output="free")
     assert dp.solve(arrays["targets_abs"], kernel="single").positions is not None
+
+
+def test_pinned_host_buffers_are_accepted_as_device_accessible_pointers(golden):
+    """okx.h: d_* pointers may be pinned host memory.  Targets read from and compact outputs stored straight into the
+    caller's pinned buffers hold the same bits as a launch on HBM buffers (bench.py e2e.zero_copy)."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden("c2_dw_subset")
+    dp = DeviceProgram(program.with_line_mode("pinned"), "cuda:0")
+    n = arrays["targets_abs"].shape[0]
+    h_t = torch.as_tensor(arrays["targets_abs"]).pin_memory()
+    for mode, shape in (("free", (n, program.n_free, 3)), ("records", (n, program.n_out, 3))):
+        h_out = torch.full(shape, -7.0, dtype=torch.float64).pin_memory()
+        h_info = torch.zeros((n, 40), dtype=torch.uint8).pin_memory()
+        dp.solve(h_t, out=h_out, info_out=h_info, output=mode, chain_len=-1)
+        torch.cuda.synchronize()
+        ref = dp.solve(torch.as_tensor(arrays["targets_abs"], device="cuda:0"), output=mode, chain_len=-1)
+        torch.cuda.synchronize()
+        want = ref.free if mode == "free" else ref.positions
+        assert np.array_equal(h_out.numpy(), want.cpu().numpy())
+        assert np.array_equal(h_info.numpy(), ref.info_raw.cpu().numpy())

@@ -176,7 +176,12 @@ def test_axle_runs_in_pair_mode_one_quad_per_half(golden, name):
     assert np.all((info["flags"] & 7) == 1)
     pos = quad.positions.cpu().numpy()
     assert np.max(np.abs(pos - wave.positions.cpu().numpy())) <= 1e-10
-    assert np.max(np.abs(info["nfev"] - wave.info()["nfev"])) <= 1
+    # the same passes as the interpreter when every problem takes its own first pass; with the shared first step
+    # (default) the design-state evaluation is not the problem's own (okx.h: shared_first_step)
+    own = dp.solve(t, kernel="quad", predictor=False, shared_first_step=False).info()
+    assert np.max(np.abs(own["nfev"] - wave.info()["nfev"])) <= 1
+    saved = own["nfev"].astype(int) - info["nfev"].astype(int)
+    assert saved.min() >= -1 and saved.max() <= 2 and saved.mean() >= 0.5
     assert np.max(np.abs(info["max_residual"] - arrays["ref_tight_maxres"])) <= 1e-8
     sub = slice(None, None, max(1, t.shape[0] // 32))
     orc = Oracle(pinned).sweep(arrays["targets_abs"][sub], 1e-15, 1e-15, 1e-15, warm_start=False)

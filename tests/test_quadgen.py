@@ -142,10 +142,11 @@ def test_first_step_table_kernels_are_generated_where_they_pay(golden, monkeypat
     assert "v_div" not in src and " / pred" not in src  # control code divides through refined reciprocals
     _, axle = golden("c3_axle_grid")
     pair = _source(axle.with_line_mode("pinned"))
-    assert "okx_quad_head_u(QHeadArgs" not in pair and "lms[" in pair and "lean_atan2_pos<true>" in pair  # pair mode: LDS state, no table
-    monkeypatch.setenv("OKX_PAIR_HEAD", "1")
-    assert "okx_quad_head_u(QHeadArgs a)" in _source(axle.with_line_mode("pinned"))
-    monkeypatch.delenv("OKX_PAIR_HEAD")
+    # pair mode: LDS state, first-order table (no second-order vectors)
+    assert "okx_quad_head_u(QHeadArgs a)" in pair and "hS0_" not in pair and "lms[" in pair and "lean_atan2_pos<true>" in pair
+    monkeypatch.setenv("OKX_PAIR_NO_HEAD", "1")
+    assert "okx_quad_head_u(QHeadArgs" not in _source(axle.with_line_mode("pinned"))
+    monkeypatch.delenv("OKX_PAIR_NO_HEAD")
     monkeypatch.setenv("OKX_QUAD_NO_HEAD", "1")
     assert "okx_quad_head_u(QHeadArgs" not in _source(dw.with_line_mode("pinned"))
 
