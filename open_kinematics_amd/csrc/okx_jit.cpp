@@ -169,12 +169,11 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err, b
 // Minimal reader for the two msgpack fields needed from the AMDGPU metadata note: kernel-level maps list their keys in
 // alphabetical order, so the ".name" string nearest before a ".private_segment_fixed_size" key is that kernel's name
 // (argument names sit under ".args", earlier in the map).
-int quad_code_scratch_bytes(const std::string& code, const char* prefix) {
-  static const char kKey[] = ".private_segment_fixed_size";
+static int code_kernel_field(const std::string& code, const char* prefix, const char* key, bool name_follows) {
   static const char kName[] = ".name";
-  const size_t klen = sizeof(kKey) - 1, nlen = sizeof(kName) - 1, plen = std::strlen(prefix);
+  const size_t klen = std::strlen(key), nlen = sizeof(kName) - 1, plen = std::strlen(prefix);
   int best = -1;
-  for (size_t at = code.find(kKey); at != std::string::npos; at = code.find(kKey, at + klen)) {
+  for (size_t at = code.find(key); at != std::string::npos; at = code.find(key, at + klen)) {
     const unsigned char* v = reinterpret_cast<const unsigned char*>(code.data()) + at + klen;
     const size_t left = code.size() - (at + klen);
     long long value = -1;
@@ -183,19 +182,30 @@ int quad_code_scratch_bytes(const std::string& code, const char* prefix) {
     else if (left >= 3 && v[0] == 0xcd) value = (v[1] << 8) | v[2];
     else if (left >= 5 && v[0] == 0xce) value = ((long long)v[1] << 24) | (v[2] << 16) | (v[3] << 8) | v[4];
     if (value < 0) continue;
-    const size_t nm = code.rfind(kName, at);
+    const size_t nm = name_follows ? code.find(kName, at) : code.rfind(kName, at);
     if (nm == std::string::npos) continue;
+    if (name_follows && nm - at > 512) continue;  // the same kernel's map: a few short keys further on
     const unsigned char* s = reinterpret_cast<const unsigned char*>(code.data()) + nm + nlen;
     size_t len = 0, skip = 0;
     if ((s[0] & 0xe0) == 0xa0) len = s[0] & 0x1f, skip = 1;
     else if (s[0] == 0xd9) len = s[1], skip = 2;
     else if (s[0] == 0xda) len = (s[1] << 8) | s[2], skip = 3;
     else continue;
-    if (nm + nlen + skip + len > at || len < plen) continue;
+    if ((!name_follows && nm + nlen + skip + len > at) || len < plen) continue;
     if (std::memcmp(s + skip, prefix, plen) != 0) continue;
     if (value > best) best = (int)value;
   }
   return best;
+}
+
+int quad_code_scratch_bytes(const std::string& code, const char* prefix) {
+  return code_kernel_field(code, prefix, ".private_segment_fixed_size", false);
+}
+
+// Static LDS bytes (largest over the kernels whose name starts with `prefix`): ".group_segment_fixed_size" sorts before
+// ".name" in the kernel's metadata map.
+int quad_code_lds_bytes(const std::string& code, const char* prefix) {
+  return code_kernel_field(code, prefix, ".group_segment_fixed_size", true);
 }
 
 bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::string* why, bool ignore_cached, int* variant_out) {
@@ -244,18 +254,27 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
   return true;
 }
 
+constexpr int kPairScratchOk = 256;
+
 bool quad_build(const DevProgram& P, int waves_per_simd, std::string* src, std::string* code, std::string* why,
                 bool ignore_cached) {
   std::string err;
-  if (!quad_generate(P, waves_per_simd, src, why, false)) return false;
+  const char* layout = getenv("OKX_PAIR_LAYOUT");  // "regs" / "lds": force one of the two pair-mode layouts (measurement)
+  const bool force_lds = layout && std::string(layout) == "lds" && P.n_free > kQuadMaxFree;
+  if (!quad_generate(P, waves_per_simd, src, why, force_lds)) return false;
   if (!quad_compile(*src, code, &err, ignore_cached)) {
     *why = "compile failed: " + err;
     return false;
   }
-  if (P.n_free <= kQuadMaxFree || quad_code_scratch_bytes(*code, "okx_quad_solve") <= 0) return true;
-  // pair mode and the register-resident variant spills: constants and fixed points back to LDS
+  if (layout) return true;
+  // Pair mode: up to kPairScratchOk bytes of scratch the register-resident layout stays - measured on the axle grid with
+  // the second-order first step (164 B, almost all of it prologue temporaries): 0.403 ms per cold grid against 0.796 ms
+  // for the LDS-homes layout, whose 42 KB of LDS leave three wavefronts per CU instead of four.
+  if (P.n_free <= kQuadMaxFree || quad_code_scratch_bytes(*code, "okx_quad_solve") <= kPairScratchOk) return true;
+  // beyond that (round 1's 636 B, re-read in every pass): constants and fixed points back to LDS, if that fits
   std::string src2, code2, why2;
   if (!quad_generate(P, waves_per_simd, &src2, &why2, true) || !quad_compile(src2, &code2, &err, ignore_cached)) return true;
+  if (quad_code_lds_bytes(code2, "okx_quad_solve") > 40 * 1024) return true;  // four wavefronts per CU need <= 40 KB each
   if (quad_code_scratch_bytes(code2, "okx_quad_solve") < quad_code_scratch_bytes(*code, "okx_quad_solve")) {
     *src = src2;
     *code = code2;

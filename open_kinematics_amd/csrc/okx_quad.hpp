@@ -140,6 +140,7 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err, b
 // Largest private-segment (scratch) size among the kernels of a code object whose name starts with `prefix`, read from
 // the code object's metadata note; -1 when no such kernel is found.
 int quad_code_scratch_bytes(const std::string& code, const char* prefix);
+int quad_code_lds_bytes(const std::string& code, const char* prefix);  // static LDS of those kernels
 
 // quad_generate + quad_compile.  A pair-mode program is first generated with its chain constants in registers; if the
 // compiler then spills in the solve kernels (a larger half program than the BASELINE axle), the variant with LDS homes

@@ -1196,8 +1196,8 @@ int quad_head_stride(const DevProgram& program) {
   PairView pv;
   std::string why;
   if (!build_pair_view(program, &pv, &why)) return 0;
-  const int k = pv.n_prog_targets + 1;
-  return 2 * 4 * pv.side.n_free * k + 2 * k * k + 8;
+  const int k = pv.n_prog_targets + 1, pairs = pv.n_prog_targets * (pv.n_prog_targets + 1) / 2;
+  return 2 * 4 * pv.side.n_free * k + 2 * k * k + 8 + 2 * 4 * pv.side.n_free * pairs;  // both halves' Q and S blocks
 }
 
 bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* src, std::string* why, bool lds_homes) {
@@ -1299,15 +1299,17 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   const int HK = (int)head_cols.size();
   const int head_side = 4 * nf * HK;                       // doubles of one half's Q block
   const int head_off = (pv ? 2 : 1) * head_side + 2 * HK * HK;
-  // Second-order terms of the shared first step (single mode): S_st = (J^T J + lambda I)^-1 J^T r''(Q_s, Q_t) for the target
-  // columns s <= t, [pair][F][4] after the scalars; scalar 6 says how many pairs the table carries.
+  // Second-order terms of the shared first step: S_st = (J^T J + lambda I)^-1 J^T r''(Q_s, Q_t) for the target
+  // columns s <= t, [pair][F][4] after the scalars (pair mode: one such block per half, the left half's first);
+  // scalar 6 says how many pairs the table carries.
   std::vector<std::pair<int, int>> head_pairs;
-  if (!pv && getenv("OKX_QUAD_FIRST_ORDER_HEAD") == nullptr)
+  if (getenv("OKX_QUAD_FIRST_ORDER_HEAD") == nullptr && !(pv && getenv("OKX_PAIR_FIRST_ORDER_HEAD") != nullptr))
     for (int s2 = 1; s2 < HK; ++s2)
       for (int t2 = s2; t2 < HK; ++t2) head_pairs.push_back({s2, t2});
   const int NPAIR = (int)head_pairs.size();
   const int head_s_off = head_off + 8;
-  const int head_stride = head_off + 8 + (pv ? 0 : 4 * nf * (HK - 1) * HK / 2);
+  const int head_s_side = 4 * nf * (HK - 1) * HK / 2;      // doubles of one half's S block
+  const int head_stride = head_off + 8 + (pv ? 2 : 1) * head_s_side;
   bool has_atan = false;
   for (int i = 0; i < P.n_crows; ++i)
     has_atan = has_atan || P.row_type[i] == OKX_ROW_ANGLE || P.row_type[i] == OKX_ROW_THREE_POINT_ANGLE;
@@ -1522,7 +1524,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     ev.reset_caches();
   }
   for (int t = 0; t < T; ++t) g.f("    tp%d = td%d;", t, t);
-  if (head_ok && !pv) {
+  if (head_ok) {
     // Shared first step of the unit's FIRST problem, taken here, in the unit prologue, so that the
     // table loads travel with the prologue's other loads (inside the chain loop the compiler serialises them - two
     // loads, wait, fma, next load: a dozen dependent L2 round trips, ~3 us per unit) and nothing of the table stays
@@ -1532,39 +1534,65 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("    bool head_ready = false;");
     g.f("    if (a.head != nullptr && a.grad_tol <= 0.0 && (PG || a.predictor == nullptr)) {");
     g.f("      const double* hp = a.head + (PG ? geom * %d : 0);", head_stride);
-    for (int k = 0; k < HK; ++k)
-      for (int F = 0; F < nf; ++F) g.f("      const double hq%d_%d = hp[%d + c];", k, F, 4 * (k * nf + F));
+    // pair mode: each half reads its own Q and S blocks; the Gram matrices and scalars belong to the whole problem
+    g.f("      const double* hqb = hp%s;", pv ? (" + (q1 ? " + std::to_string(head_side) + " : 0)").c_str() : "");
+    g.f("      const double* hsb = hp%s;", pv ? (" + (q1 ? " + std::to_string(head_s_side) + " : 0)").c_str() : "");
+    // single mode: every table load issued at once (they travel with the prologue's other loads).  Pair mode: 2 x 100
+    // values at once do not fit beside the chain's invariants (152 B of scratch); there the entries are read where they
+    // are used, two blocks between scheduling barriers.
+    if (!pv)
+      for (int k = 0; k < HK; ++k)
+        for (int F = 0; F < nf; ++F) g.f("      const double hq%d_%d = hqb[%d + c];", k, F, 4 * (k * nf + F));
     for (int j = 0; j < HK; ++j)
       for (int k = j; k < HK; ++k) g.f("      const double hm%d_%d = hp[%d];", j, k, head_off - 2 * HK * HK + j * HK + k);
     for (int i = 0; i < 6; ++i) g.f("      const double hs%d = hp[%d];", i, head_off + i);
     g.f("      const double hr0 = 1.0;  // weight of the constraint rows' own gradient");
-    for (int k = 1; k < HK; ++k)
-      g.f("      const double hr%d = td%d - tn%d;  // target residual of the first problem at the design state", k, head_cols[k].t, head_cols[k].t);
+    for (int k = 1; k < HK; ++k) {
+      const HeadCol& col = head_cols[k];
+      if (!pv)
+        g.f("      const double hr%d = td%d - tn%d;  // target residual of the first problem at the design state", k, col.t, col.t);
+      else  // the residual of the half that carries this program target, known to both halves
+        g.f("      const double hr%d = q1 == %d ? td%d - tn%d : xq(td%d - tn%d);", k, col.side, col.t, col.t, col.t, col.t);
+    }
     g.f("      double hstep = 0.0, hN = 0.0, hM = 0.0, hss = hs2, hmr = hs3;");
     if (NPAIR > 0) {
       // first-order step d1 and the second-order correction d2 = -1/2 sum_st w_s w_t S_st (see okx_quad_head_*); d2 is
       // taken while it is a correction, 2 |d2| <= 0.75 |d1| (Transtrum & Sethna's acceptance rule)
       g.f("      const double hs6 = hp[%d];", head_off + 6);
       g.f("      double hst1 = 0.0, hst2 = 0.0;");
+      if (pv)
+        for (int pi = 0; pi < NPAIR; ++pi)
+          g.f("      const double hv%d = %s * hr%d * hr%d;", pi, head_pairs[pi].first == head_pairs[pi].second ? "0.5" : "1.0",
+              head_pairs[pi].first, head_pairs[pi].second);
       for (int F = 0; F < nf; ++F) {
         std::string e, e2;
-        for (int k = 0; k < HK; ++k) e += (k ? " + hr" : "hr") + std::to_string(k) + " * hq" + std::to_string(k) + "_" + std::to_string(F);
+        for (int k = 0; k < HK; ++k)
+          e += (k ? " + hr" : "hr") + std::to_string(k) + " * " +
+               (pv ? "hqb[" + std::to_string(4 * (k * nf + F)) + " + c]" : "hq" + std::to_string(k) + "_" + std::to_string(F));
         for (int pi = 0; pi < NPAIR; ++pi) {
           const int s2 = head_pairs[pi].first, t2 = head_pairs[pi].second;
-          e2 += (pi ? " + " : "") + std::string(s2 == t2 ? "0.5" : "1.0") + " * hr" + std::to_string(s2) + " * hr" + std::to_string(t2) + " * hp[" +
-                std::to_string(head_s_off + 4 * (pi * nf + F)) + " + c]";
+          const std::string w = pv ? "hv" + std::to_string(pi)
+                                   : std::string(s2 == t2 ? "0.5" : "1.0") + " * hr" + std::to_string(s2) + " * hr" + std::to_string(t2);
+          e2 += (pi ? " + " : "") + w + " * hsb[" + std::to_string(head_s_off + 4 * (pi * nf + F)) + " + c]";
         }
         g.f("      const double hxa%d = -(%s), hxb%d = -(%s);", F, e.c_str(), F, e2.c_str());
         g.f("      hst1 = fmax(hst1, fabs(hxa%d)); hst2 = fmax(hst2, fabs(hxb%d));", F, F);
+        if (pv) {  // the first-order part waits in LDS, where the finished step goes anyway
+          g.f("      hxl[%d + lane] = hxa%d;", 64 * F, F);
+          if (F % 2 == 1) g.f("      __builtin_amdgcn_sched_barrier(0);");
+        }
       }
       g.f("      hst1 = PMAX(hst1); hst2 = PMAX(hst2);");
       g.f("      const double hw2 = (hs6 > 0.5 && hst2 <= 0.375 * hst1) ? 1.0 : 0.0;");
       for (int F = 0; F < nf; ++F)
-        g.f("      { const double hx = fma(hw2, hxb%d, hxa%d); hxl[%d + lane] = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", F, F, 64 * F);
+        g.f("      { const double hx = fma(hw2, hxb%d, %s); hxl[%d + lane] = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", F,
+            pv ? ("hxl[" + std::to_string(64 * F) + " + lane]").c_str() : ("hxa" + std::to_string(F)).c_str(), 64 * F);
     } else {
     for (int F = 0; F < nf; ++F) {
       std::string e;
-      for (int k = 0; k < HK; ++k) e += (k ? " + hr" : "hr") + std::to_string(k) + " * hq" + std::to_string(k) + "_" + std::to_string(F);
+      for (int k = 0; k < HK; ++k)
+        e += (k ? " + hr" : "hr") + std::to_string(k) + " * " +
+             (pv ? "hqb[" + std::to_string(4 * (k * nf + F)) + " + c]" : "hq" + std::to_string(k) + "_" + std::to_string(F));
       g.f("      { const double hx = -(%s); hxl[%d + lane] = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", e.c_str(), 64 * F);
     }
     }
@@ -1724,7 +1752,6 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     // Q_t = (J^T J + lambda I)^-1 J^T e_t tabulated once per geometry (okx_quad_head_*), and the problem enters the
     // loop below exactly where its own first pass would have left it: trial point x + dx in hand (mode 1), cost and
     // damping of the design state, predicted reduction 0.5 (lambda |dx|^2 - dx . g) from the table's Gram matrices.
-    if (!pv) {
     g.f("      if (head_ready && b == first_b) {  // wave-uniform: every quad of the wavefront is at its unit's first problem");
     g.f("        const int hq_ = lane >> 2;");
     g.f("        const bool at_design = valid && hist == 1 && !from_model && hsc[128 + hq_] > 0.5;  // x is the design state, the table is good");
@@ -1741,48 +1768,6 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("          }");
     g.f("        }");
     g.f("      }");
-    } else {
-    g.f("      if (a.head != nullptr && a.grad_tol <= 0.0) {");
-    g.f("        const bool at_design = valid && hist == 1 && !from_model;  // x is this geometry's design state");
-    g.f("        if (wave_any(at_design)) {");
-    g.f("          const double* hp = a.head + (PG ? geom * %d : 0);", head_stride);
-    g.f("          const double hr0 = 1.0;  // weight of the constraint rows' own gradient");
-    for (int k = 1; k < HK; ++k) {
-      const HeadCol& col = head_cols[k];
-      if (!pv)
-        g.f("          const double hr%d = td%d - tv%d;  // target residual at the design state", k, col.t, col.t);
-      else  // the residual of the half that carries this program target, known to both halves
-        g.f("          const double hr%d = q1 == %d ? td%d - tv%d : xq(td%d - tv%d);", k, col.side, col.t, col.t, col.t, col.t);
-    }
-    if (pv) g.f("          const double* hq = hp + (q1 ? %d : 0);  // this half's block of the table", head_side);
-    for (int F = 0; F < nf; ++F) {
-      std::string e;
-      for (int k = 0; k < HK; ++k)
-        e += (k ? " + hr" : "hr") + std::to_string(k) + " * " + (pv ? "hq[" : "hp[") + std::to_string(4 * (k * nf + F)) + " + c]";
-      g.f("          const double hx%d = -(%s);", F, e.c_str());
-    }
-    g.f("          double hstep = 0.0, hN = 0.0, hM = 0.0, hss = hp[%d], hmr = hp[%d];", head_off + 2, head_off + 3);
-    for (int F = 0; F < nf; ++F) g.f("          hstep = fmax(hstep, fabs(hx%d));", F);
-    g.f("          hstep = PMAX(hstep);");
-    for (int j = 0; j < HK; ++j)
-      for (int k = 0; k < HK; ++k)
-        g.f("          hM = fma(hr%d * hr%d, hp[%d], hM); hN = fma(hr%d * hr%d, hp[%d], hN);", j, k, head_off - 2 * HK * HK + j * HK + k, j, k,
-            head_off - HK * HK + j * HK + k);
-    for (int t = 1; t < HK; ++t) g.f("          hss = fma(hr%d, hr%d, hss); hmr = fmax(hmr, fabs(hr%d));", t, t, t);
-    g.f("          if (at_design && hp[%d] > 0.5) {", head_off + 4);
-    for (int F = 0; F < nf; ++F) g.f("            dx%d = hx%d;", F, F);
-    g.f("            Fc = 0.5 * hss; mres = hmr; dmax = hp[%d]; lambda = a.lambda0 * dmax;", head_off);
-    g.f("            step_len = hstep; pred = 0.5 * fma(lambda, hN, hM); iters = 1; mode = 1;");
-    g.f("            piv_lo = hp[%d] - lambda; piv_hi = hp[%d];", head_off + 1, head_off + 5);
-    g.f("            if (hstep <= a.step_tol) { flags |= INFO_CONVERGED; last_step = hstep; done = true; }");
-    g.f("            else {");
-    g.f("              want_light = hstep <= 1e-3 && (100.0 * lambda * fast_rcp(hp[%d]) + hstep) * hstep <= a.step_tol;", head_off + 1);
-    g.f("              prev_sl = hstep;");
-    g.f("            }");
-    g.f("          }");
-    g.f("        }");
-    g.f("      }");
-    }
   }
   g.f("      while (wave_any(!done)) {");
   if (light_ok) {
@@ -2380,13 +2365,17 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.out += eval_src;
     g.out += couple_eval;
     const int n_fd_dirs = NPAIR > 0 ? (HK - 1) + (HK - 1) * (HK - 2) / 2 : 0;
+    const int fd_rows = P.m + (pv ? 1 : 0);
     if (NPAIR > 0) {
       // second differences of the rows per direction, [direction][row][quad] in LDS (63 quad-uniform doubles would
       // otherwise sit in registers beside the factor); every one starts at -2 r(design state), while the r_i are at hand
-      g.f("    __shared__ double hDl[%d];", n_fd_dirs * P.m * 16);
+      // (pair mode: the joining row is row P.m of each half's list - both halves hold the same value)
+      g.f("    __shared__ double hDl[%d];", n_fd_dirs * fd_rows * 16);
       g.f("    const int hdq = lane >> 2;");
-      for (int d = 0; d < n_fd_dirs; ++d)
-        for (int i = 0; i < P.m; ++i) g.f("    hDl[%d + hdq] = -2.0 * r%d;", (d * P.m + i) * 16, i);
+      for (int d = 0; d < n_fd_dirs; ++d) {
+        for (int i = 0; i < P.m; ++i) g.f("    hDl[%d + hdq] = -2.0 * r%d;", (d * fd_rows + i) * 16, i);
+        if (pv) g.f("    hDl[%d + hdq] = -2.0 * rc;", (d * fd_rows + P.m) * 16);
+      }
     }
     g.f("    double diag = 0.0;");
     for (int F = 0; F < nf; ++F)
@@ -2501,7 +2490,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
               g.f("    p%d = fma(%s, hQ%d_%d + hQ%d_%d, hx0_%d);", ev.fp(F), sign ? "-0.25" : "0.25", dirs[d].s, F, dirs[d].t, F, F);
           }
           g.out += fd.out;
-          for (int i = 0; i < P.m; ++i) g.f("    hDl[%d + hdq] += r%d;", (int)(d * P.m + i) * 16, i);
+          for (int i = 0; i < P.m; ++i) g.f("    hDl[%d + hdq] += r%d;", (int)(d * fd_rows + i) * 16, i);
+          if (pv) {  // the joining row at the displaced halves (each half moved its own joined point)
+            g.out += couple_light;
+            g.f("    hDl[%d + hdq] += rc;", (int)(d * fd_rows + P.m) * 16);
+          }
           g.f("    }");
         }
       }
@@ -2512,7 +2505,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
           if (dirs[d].s == s2 && dirs[d].t == t2) return (int)d;
         return -1;
       };
-      auto hd = [&](int d, int i) { return "hDl[" + std::to_string((d * P.m + i) * 16) + " + hdq]"; };
+      auto hd = [&](int d, int i) { return "hDl[" + std::to_string((d * fd_rows + i) * 16) + " + hdq]"; };
       auto pair_value = [&](int pi, int i) {
         const int s2 = head_pairs[pi].first, t2 = head_pairs[pi].second;
         char buf[256];
@@ -2544,6 +2537,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         for (int idx = 0; idx < P.n_active; ++idx) (void)jt.derived_op(P.active_op[idx], true);
         (void)jt.emit_rows();
         g.out += jt.out;
+        if (pv) {  // the joining row: its gradient lives in the joined point's block, its curvature term with it
+          g.out += couple_eval;
+          for (int pi = 0; pi < NPAIR; ++pi)
+            g.f("    hR%d_g%d = fma(cu, %s, hR%d_g%d);", pi, FU, pair_value(pi, P.m).c_str(), pi, FU);
+        }
         for (int F = 0; F < nf; ++F)
           for (int G = 0; G <= F; ++G)
             if (ev.fillf[F][G]) {
@@ -2552,7 +2550,23 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
                 if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
               }
             }
+        if (pv)
+          for (int k = 0; k < 3; ++k)
+            g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
         g.out += factor_src;
+        if (pv) {  // D~ z = w once more (the first scope's z is not kept alive across the residual passes above)
+          std::vector<std::string> rhs_w;
+          for (int F = 0; F < nf; ++F) rhs_w.push_back(F == FU ? "cu" : "0.0");
+          for (int F = 0; F < nf; ++F) g.f("    double nz%d;", F);
+          ev.out.clear();
+          ev.emit_substitute(rhs_w, "sz");
+          g.f("    {");
+          g.out += ev.out;
+          for (int F = 0; F < nf; ++F) g.f("    nz%d = sz%d;", F, F);
+          g.f("    }");
+          g.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g);", FU);
+          g.f("    const double sm_det = 1.0 - sm_g * sm_gp;");
+        }
         for (int pi = 0; pi < NPAIR; ++pi) {
           std::vector<std::string> rhs;
           for (int F = 0; F < nf; ++F) rhs.push_back("hR" + std::to_string(pi) + "_g" + std::to_string(F));
@@ -2561,9 +2575,19 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
           ev.emit_substitute(rhs, outn.c_str());
           g.f("    {");
           g.out += ev.out;
+          if (pv) {  // the coupling between the halves, as for the columns
+            g.f("    const double sm_s = qsum(cu * %s%d);", outn.c_str(), FU);
+            g.f("    const double sm_c = (xq(sm_s) - sm_gp * sm_s) / sm_det;");
+            g.f("    double* hso = hs + (q1 ? %d : 0);  // this half's S block", head_s_side);
+            g.f("    if (valid) {");
+            for (int F = 0; F < nf; ++F)
+              g.f("      hso[%d + c] = c < 3 ? fma(-nz%d, sm_c, %s%d) : 0.0;", head_s_off + 4 * (pi * nf + F), F, outn.c_str(), F);
+            g.f("    }");
+          } else {
           g.f("    if (valid) {");
           for (int F = 0; F < nf; ++F) g.f("      ho[%d + c] = c < 3 ? %s%d : 0.0;", head_s_off + 4 * (pi * nf + F), outn.c_str(), F);
           g.f("    }");
+          }
           g.f("    }");
         }
       }
