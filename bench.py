@@ -670,8 +670,9 @@ def measure_dropin(device) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults: ~11 ms of warm-up launches (the clocks ramp over milliseconds) and ~45 ms of timed ones per rank
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--config", choices=("c2", "c5"), default="c2",
                     help="c2: BASELINE config 2, weak scaling (default, the headline); c5: BASELINE config 5, 4096 perturbed "
                          "geometries x 256 steps, geometry-major shards (strong scaling)")
@@ -946,19 +947,22 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["pipelined"] = measure_pipelined(dp, targets, device, max(args.steps, 60))
         line["with_model"] = measure_with_model(program, targets, device, args.steps, args.warmup)
         line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, extra_steps, dict(chain_len=args.chain_len, predictor=False))
+        # zero-copy before the graph-replay pipeline: measured after it (same process) the kernel's PCIe stores run at a
+        # fifth of their rate (tools/zc_order.py: 62 us per sweep alone or after the other legs, 315 us after `compact`)
+        zero_copy = measure_e2e_zero_copy(dp, targets_all[lo:hi], device, max(extra_steps, 200),
+                                          dict(chain_len=args.chain_len, predictor=False))
         line["e2e"]["compact"] = measure_e2e_compact(dp, targets_all[lo:hi], device, max(extra_steps, 200),
                                                      dict(chain_len=args.chain_len, predictor=False))
-        line["e2e"]["zero_copy"] = measure_e2e_zero_copy(dp, targets_all[lo:hi], device, max(extra_steps, 200),
-                                                         dict(chain_len=args.chain_len, predictor=False))
+        line["e2e"]["zero_copy"] = zero_copy
         from open_kinematics_amd.workloads import geometry_path
         line["downstream"] = measure_downstream(dp, geometry_path("geometry.yaml"), pipe.local[0], device)
         dp.close()
         line["other_configs"] = [
             measure_config("C3 rocker + U-bar axle, 256x256 heave x roll grid (n = 60, pair mode)",
-                           lambda: axle_grid_problem(256, 256), device, 5, 2),
-            measure_config("C4 MacPherson corner, 512x512 bump x rack grid", lambda: macpherson_grid_problem(512, 512), device, 5, 2),
+                           lambda: axle_grid_problem(256, 256), device, 20, 3),
+            measure_config("C4 MacPherson corner, 512x512 bump x rack grid", lambda: macpherson_grid_problem(512, 512), device, 20, 3),
             measure_config("C5 4096 perturbed double-wishbone geometries x 256-step bump sweep (one GPU)",
-                           lambda: ensemble_problem(4096, 256), device, 5, 2),
+                           lambda: ensemble_problem(4096, 256), device, 20, 3),
         ]
         line["dropin"] = measure_dropin(device)
     if world == 1 and not args.no_cpu_baseline:
