@@ -1149,7 +1149,7 @@ __global__ void __launch_bounds__(GroupWidth<NREG>::value, NREG <= 24 ? OKX_WAVE
         }
         xt = x + dx;
         // Predicted next correction (rho |dx| + C |dx|^2: damping contraction lambda / min pivot and
-        // the observed quadratic contraction, both x 100; DESIGN.md §5.1 "Ending a solve"): when it is
+        // the observed quadratic contraction, both x 100; profiles/r02/DESIGN_r02.md §5.1 "Ending a solve"): when it is
         // within step_tol the step is applied and confirmed by a residual-only evaluation instead of
         // a full Jacobian / factorisation pass.
         if (!args.confirm) {

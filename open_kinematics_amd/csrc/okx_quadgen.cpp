@@ -1746,7 +1746,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   if (!pair_state_lds) g.f("      double prev_sl = 0.0, piv_lo = 0.0, piv_hi = 0.0;  // pivot range of the last successful factorisation");
   for (int F = 0; F < nf; ++F) g.f("      dx%d = 0.0;", F);
   if (head_ok) {
-    // Shared first step (DESIGN.md section 5.1).  A chain head starts at its geometry's design state, where the constraint
+    // Shared first step (DESIGN.md section 4).  A chain head starts at its geometry's design state, where the constraint
     // residuals vanish and the Jacobian, J^T J and its damped factorisation are the same for EVERY problem of that
     // geometry: only the target residuals differ.  The first LM step is therefore dx = -sum_t r_t Q_t with
     // Q_t = (J^T J + lambda I)^-1 J^T e_t tabulated once per geometry (okx_quad_head_*), and the problem enters the
