@@ -513,7 +513,7 @@ int32_t okx_camber_shim_batch(const okx_shim_roles* roles, int64_t n_geometries,
  * offline for its Jacobian rows (tools/generate_jacobians.py -> core/jacobians.py) and
  * interprets the rest per call (solver.py:226-275, :502-581).  Code objects are cached under
  * <directory of libokx.so>/_kcache (override: OKX_KERNEL_CACHE), keyed by the generated source.
- * Programs the generator has no code path for (more than 8 free points, unsupported row or
+ * Programs the generator has no code path for (more than 9 free points and no pair structure, unsupported row or
  * derived-point types) keep the generic interpreter kernels; nothing else changes for them.
  */
 

@@ -13,8 +13,9 @@ namespace okx {
 constexpr int kPredictorDegree = 7;
 constexpr int kPredictorMaxDegree = 12;
 constexpr int kPredictorLdsDoubles = 1024;  // single mode: tables up to this size are staged through LDS (8 KB per wavefront)
-constexpr int kQuadMaxFree = 8;          // n <= 24 unknowns: the lane-owned rows of J^T J stay in registers
-constexpr int kQuadMaxFreePerSide = 10;  // pair mode (two identical halves, one quad each): free points per half
+constexpr int kQuadMaxFree = 9;          // n <= 27 unknowns (a corner with pushrod, rocker and coil-over): up to 8 free points the lane-owned
+                                         // rows of J^T J stay in registers, the ninth costs ~400 B of scratch (3.2e8 solves/s against 1.5e7 on the interpreter)
+constexpr int kQuadMaxFreePerSide = 11;  // pair mode (two identical halves, one quad each): free points per half (rocker corner + droplink + heave pickup)
 constexpr int kLaneMaxFree = 6;          // lane kernel (one lane per problem): n <= 18 unknowns, lower triangle of J^T J <= 171 doubles
 
 // Kernel arguments of the generated kernels (mirrors `struct QArgs` in the generated source).

@@ -39,10 +39,10 @@ def golden():
 BASELINE_STEERED = ["c1_dw_corner", "c2_dw_subset", "c3_axle_grid", "c4_macpherson_grid", "e2e_sweep"]
 # every other reference geometry the loader accepts (oracle/gen_golden_topologies.py): plain and explicit double-wishbone
 # axles, the MacPherson axle, corners with pushrod + rocker + torsion bar / coil-over, the rigid T-bar anti-roll bar
-# (in phase / opposed wheel travel), a rocker-to-rocker heave link on the U-bar axle (66 variables: two wavefronts
-# per problem)
+# (in phase / opposed wheel travel), a rocker-to-rocker heave link on the U-bar axle (66 variables, pair mode with 11
+# free points per half) and on the T-bar axle (66 variables, three joining rows: two wavefronts per problem)
 TOPOLOGIES = ["t_axle_dw", "t_axle_dw_explicit", "t_axle_macpherson", "t_corner_rocker", "t_corner_strut",
-              "t_corner_strut_rocker", "t_axle_t_bar_bump", "t_axle_t_bar_roll", "t_axle_heave_link"]
+              "t_corner_strut_rocker", "t_axle_t_bar_bump", "t_axle_t_bar_roll", "t_axle_heave_link", "t_axle_t_bar_heave"]
 STEERED = BASELINE_STEERED + TOPOLOGIES
 UNSTEERED = ["u_dw_corner", "u_macpherson", "u_axle"]
 ALL_ROW_CLASSES = ["rows_all_classes"]  # synthetic: one row of each of the reference's 13 constraint classes

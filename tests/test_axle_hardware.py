@@ -106,7 +106,7 @@ def test_heave_link_composes_with_u_bar_without_rigid_length_constraint():
     right = state.positions[PointRef(Side.RIGHT, PointID.HEAVE_LINK_ROCKER)].data
     assert np.array_equal(right, [0.0, -300.0, 400.0])  # mirrored pickup
     assert not any(isinstance(c, DistanceConstraint) and {c.p1, c.p2} == ends for c in axle.constraints())
-    # 22 free points: beyond one wavefront's 63 variables, within the two-wavefront kernels' 126
+    # 22 free points: beyond one wavefront's 63 variables (pair mode: 11 per half; the interpreter: two wavefronts)
     sweep = okin.build_sweep(_load("axle_rocker_sweep.yaml"), axle)
     heads, _ = absolute_target_table(sweep, state)
     program = flatten_problem(state, axle.constraints(), axle.derived_spec(), heads, axle.output_points())

@@ -1,7 +1,8 @@
 """
-GPU: the axle's shared hardware through the drop-in - rigid T-bar anti-roll bar (60 variables, one wavefront per
-problem) and a rocker-to-rocker heave link on the U-bar axle (66 variables: two wavefronts per problem, LDL^T rows in
-LDS).  After the reference's tests/test_t_bar_arb.py:96-196 and tests/test_axle_rocker.py:143-175, plus the parity of the
+GPU: the axle's shared hardware through the drop-in - rigid T-bar anti-roll bar (60 variables, three joining rows: the
+interpreter, one wavefront per problem), a rocker-to-rocker heave link on the U-bar axle (66 variables: pair-mode quad
+kernel, 11 free points per half) and on the T-bar axle (66 variables, no pair structure: the interpreter on two
+wavefronts per problem, LDL^T rows in LDS).  After the reference's tests/test_t_bar_arb.py:96-196 and tests/test_axle_rocker.py:143-175, plus the parity of the
 two-wavefront kernels against the oracle and against the one-wavefront kernels on a program both can run.
 """
 
@@ -119,7 +120,7 @@ def test_heave_link_length_follows_the_rockers(golden):
     assert max(lengths) - min(lengths) > 1e-3
 
 
-@pytest.mark.parametrize("name", ["t_axle_heave_link"])
+@pytest.mark.parametrize("name", ["t_axle_t_bar_heave", "t_axle_heave_link"])
 def test_two_wavefront_kernels_match_the_oracle(golden, name):
     """R1 / R1b / solve for a program of more than 63 variables: residuals, Jacobian, J^T J, J^T r at seeded points and
     the solved sweep, cold and chained, against the oracle; tangents against a central difference of solves."""
@@ -130,7 +131,10 @@ def test_two_wavefront_kernels_match_the_oracle(golden, name):
     pinned = program.with_line_mode("pinned")
     assert pinned.n_vars > 63
     dp = DeviceProgram(pinned, "cuda:0")
-    assert dp.kernel == "wave"
+    # the T-bar variant has no generated kernel (three joining rows); the U-bar variant does (pair mode), and its
+    # interpreter instantiation is forced here
+    assert dp.kernel == ("wave" if name == "t_axle_t_bar_heave" else "quad"), dp.kernel_note
+    force = {} if dp.kernel == "wave" else {"kernel": "single"}
     x, t = arrays["eval_x"], arrays["eval_targets"]
     r_o, jac_o = Oracle(pinned).eval(x, t)
     r, jac = dp.eval(x, t)
@@ -143,14 +147,19 @@ def test_two_wavefront_kernels_match_the_oracle(golden, name):
     targets = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
     orc = Oracle(pinned).sweep(arrays["targets_abs"], 1e-15, 1e-15, 1e-15, warm_start=False)
     for kw in (dict(chain_len=1), dict(chain=True)):
-        res = dp.solve(targets, **kw)
+        res = dp.solve(targets, **kw, **force)
         torch.cuda.synchronize()
         info = res.info()
         assert np.all((info["flags"] & 7) == 1), info["flags"]
         pos = res.positions.cpu().numpy()
         assert np.max(np.abs(pos - orc.positions)) <= 1e-9                # north-star tolerance (mm)
         assert np.max(np.abs(pos - arrays["ref_tight_pos"])) <= 6e-8     # the reference's own floor
-    # tangents: d positions / d target against central differences of tight solves
+    if force:  # the generated pair-mode kernel against the interpreter on the same program
+        quad = dp.solve(targets, chain_len=1)
+        assert dp.solve(targets, chain_len=1).info()["flags"].tolist() == [1] * len(targets)
+        assert float((quad.positions - dp.solve(targets, chain_len=1, **force).positions).abs().max()) <= 1e-10
+    # tangents (interpreter kernel for the T-bar variant, generated kernel for the U-bar one): d positions / d target
+    # against central differences of tight solves
     res = dp.solve(targets, chain_len=1)
     tan, tinfo = dp.tangents(res.positions)
     torch.cuda.synchronize()
@@ -168,9 +177,10 @@ def test_two_wavefront_factorisation_gives_the_damped_step(golden):
     damped step of the 66-variable program against numpy on the kernel's own J^T J."""
     from open_kinematics_amd.batch import DeviceProgram
 
-    arrays, program = golden("t_axle_heave_link")
+    arrays, program = golden("t_axle_t_bar_heave")
     pinned = program.with_line_mode("pinned")
     dp = DeviceProgram(pinned, "cuda:0")
+    assert dp.kernel == "wave" and pinned.n_vars == 66
     targets = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
     # one LM step from the design state with max_iter = 1 is x0 - (J^T J + lambda I)^-1 J^T r
     res = dp.solve(targets, chain_len=1, max_iter=1, shared_first_step=False)
