@@ -93,8 +93,8 @@ bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why) {
       return false;
     }
   }
-  if (r0.size() != r1.size() || cross.size() != 1) {
-    *why = "need equal halves joined by exactly one row";
+  if (r0.size() != r1.size() || cross.empty() || cross.size() > (size_t)kQuadMaxJoins) {
+    *why = "need equal halves joined by one to " + std::to_string(kQuadMaxJoins) + " rows";
     return false;
   }
   for (size_t j = 0; j < r0.size(); ++j) {
@@ -108,16 +108,26 @@ bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why) {
       return false;
     }
   }
-  const int ci = cross[0];
-  {
+  pv->joins.clear();
+  for (int ci : cross) {
     const int a = P.row_pts[ci][0], b = P.row_pts[ci][1];
-    if (P.row_type[ci] != OKX_ROW_DISTANCE || a < 0 || b < 0 || mirror[a] != b || !is_free[a]) {
-      *why = "the joining row is not a distance between mirrored free points";
+    const int type = P.row_type[ci];
+    if ((type != OKX_ROW_DISTANCE && type != OKX_ROW_MIDPOINT_ON_PLANE) || a < 0 || b < 0 || mirror[a] != b || !is_free[a]) {
+      *why = "a joining row is not a distance between mirrored free points (or their midpoint on a plane)";
       return false;
     }
-    pv->couple_row = ci;
-    pv->couple_point = side[a] == 0 ? a : b;  // program index for now
+    if (type == OKX_ROW_MIDPOINT_ON_PLANE && side[a] != 0) {
+      *why = "a joining midpoint row lists the second half's point first";
+      return false;
+    }
+    pv->joins.push_back({ci, side[a] == 0 ? a : b, type});  // program point index for now
   }
+  if (pv->joins[0].type != OKX_ROW_DISTANCE) {
+    *why = "the first joining row is not a distance";
+    return false;
+  }
+  pv->couple_row = pv->joins[0].row;
+  pv->couple_point = pv->joins[0].point;
   // side-0 point set -> V numbering (ascending program index)
   std::set<int> vset;
   for (int p = 0; p < NP; ++p)
@@ -234,6 +244,7 @@ bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why) {
     return false;
   }
   pv->couple_point = vidx[pv->couple_point];
+  for (auto& join : pv->joins) join.point = vidx[join.point];
   pv->n_prog_points = NP, pv->n_prog_crows = Mc, pv->n_prog_targets = T, pv->n_prog_out = P.n_out;
   return true;
 }

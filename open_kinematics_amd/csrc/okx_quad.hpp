@@ -15,6 +15,7 @@ constexpr int kPredictorMaxDegree = 12;
 constexpr int kPredictorLdsDoubles = 1024;  // single mode: tables up to this size are staged through LDS (8 KB per wavefront)
 constexpr int kQuadMaxFree = 9;          // n <= 27 unknowns (a corner with pushrod, rocker and coil-over): up to 8 free points the lane-owned
                                          // rows of J^T J stay in registers, the ninth costs ~400 B of scratch (3.2e8 solves/s against 1.5e7 on the interpreter)
+constexpr int kQuadMaxJoins = 3;          // pair mode: rows joining the two halves (rack; T-bar crossbar length and centre plane)
 constexpr int kQuadMaxFreePerSide = 11;  // pair mode (two identical halves, one quad each): free points per half (rocker corner + droplink + heave pickup)
 constexpr int kLaneMaxFree = 6;          // lane kernel (one lane per problem): n <= 18 unknowns, lower triangle of J^T J <= 171 doubles
 
@@ -106,8 +107,13 @@ struct PairView {
   std::vector<int> out[2];     // side output k -> index in the program's output list, -1: not written by that side
   std::vector<int> shared_out; // output-list indices of fixed points neither half owns (written once)
   std::vector<int> shared_pt;  // their program point indices
-  int couple_point;            // side point (free) joined to its mirror image by the coupling row
+  int couple_point;            // side point (free) joined to its mirror image by the (first) coupling row
   int couple_row;              // program constraint row of that distance
+  // Every row joining the halves, in program row order (joins[0] = couple_point / couple_row): a distance between a
+  // free point and its mirror image (the rack, a T-bar's crossbar) or the midpoint of such a pair on a plane (the
+  // T-bar's centre line).  One joining row: a 2 x 2 Woodbury system; k rows: 2k x 2k (okx_quadgen.cpp).
+  struct Join { int row, point, type; };
+  std::vector<Join> joins;
   int n_prog_points, n_prog_crows, n_prog_targets, n_prog_out;
 };
 bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why);

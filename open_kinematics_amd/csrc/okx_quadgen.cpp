@@ -1334,7 +1334,60 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // joined point's block only; each half adds its own part of the rank-one term and a 2 x 2 Woodbury system the rest.
   std::string couple_eval, couple_light, couple_hoist;
   int FU = -1;
-  if (pv) {
+  const int NK = pv ? (int)pv->joins.size() : 0;  // rows joining the halves
+  std::vector<int> FUj;                            // their joined point's block
+  for (int j = 0; j < NK; ++j) FUj.push_back(ev.blk_of_point[pv->joins[j].point]);
+  if (pv && NK > 1) {
+    // k joining rows (T-bar axle: rack length, crossbar length, crossbar midpoint on the centre plane): residual rc{j},
+    // gradient in the joined point's block cu{j} (lane component), both bit-identical on the two halves.
+    FU = FUj[0];
+    char buf[1024];
+    std::string resid, grads;
+    for (int j = 0; j < NK; ++j) {
+      const PairView::Join& join = pv->joins[j];
+      if (join.type == OKX_ROW_DISTANCE) {
+        const std::string nm = "hcL" + std::to_string(j);
+        const std::string home = ev.scalar_home(nm.c_str());
+        std::snprintf(buf, sizeof(buf), "      %s%s = gq[%d];  // length of joining row %d\n", ev.sdecl(), home.c_str(), 8 * join.row, j);
+        couple_hoist += buf;
+        if (home != nm) couple_hoist += "#define " + nm + " " + home + "\n";
+        std::snprintf(buf, sizeof(buf),
+                      "    const double cd%d = xq(p%d) - p%d;\n"
+                      "    const double cs%d = qsum(cd%d * cd%d);\n"
+                      "    double crt%d, cinv%d; fast_sqrt_rsqrt(cs%d + EPS_SQ, &crt%d, &cinv%d);\n"
+                      "    const double rc%d = (crt%d - EPS) - %s;\n",
+                      j, join.point, join.point, j, j, j, j, j, j, j, j, j, j, nm.c_str());
+        resid += buf;
+        std::snprintf(buf, sizeof(buf), "    const double cu%d = -cd%d * cinv%d;  // d rc%d / d (own joined point), lane component\n", j, j, j, j);
+        grads += buf;
+      } else {  // midpoint of the pair on a plane: r = n . (a + (b - a) / 2 - p0), a = the first half's point (constraints.py:657-666)
+        std::snprintf(buf, sizeof(buf), "      const double hcN%d = ld3(gq + %d + cc, c), hcP%d = ld3(gq + %d + cc, c);  // plane normal / point of joining row %d\n",
+                      j, 8 * join.row + 3, j, 8 * join.row, j);
+        couple_hoist += buf;
+        std::snprintf(buf, sizeof(buf),
+                      "    const double cpx%d = xq(p%d);  // (exchanged by every lane: never inside a select on the side bit)\n"
+                      "    const double cpa%d = q1 ? cpx%d : p%d, cpb%d = q1 ? p%d : cpx%d;\n"
+                      "    const double rc%d = qsum(hcN%d * ((cpa%d + (cpb%d - cpa%d) * 0.5) - hcP%d));\n",
+                      j, join.point, j, j, join.point, j, join.point, j, j, j, j, j, j, j);
+        resid += buf;
+        std::snprintf(buf, sizeof(buf), "    const double cu%d = 0.5 * hcN%d;  // d rc%d / d (own joined point), lane component\n", j, j, j);
+        grads += buf;
+      }
+    }
+    std::string sumsq = "(ss + xq(ss))", maxr = "fmax(mres_new, xq(mres_new))";
+    for (int j = 0; j < NK; ++j) {
+      sumsq = "(" + sumsq + " + rc" + std::to_string(j) + " * rc" + std::to_string(j) + ")";
+      maxr = "fmax(" + maxr + ", fabs(rc" + std::to_string(j) + "))";
+    }
+    const std::string tail = "    ss = " + sumsq + ";\n    mres_new = " + maxr + ";\n";
+    couple_light = resid + tail;
+    couple_eval = resid + grads;
+    for (int j = 0; j < NK; ++j) {
+      std::snprintf(buf, sizeof(buf), "    gn%d = fma(cu%d, rc%d, gn%d);\n", FUj[j], j, j, FUj[j]);
+      couple_eval += buf;
+    }
+    couple_eval += tail;
+  } else if (pv) {
     FU = ev.blk_of_point[pv->couple_point];
     char buf[1024];
     const std::string hcl_home = ev.scalar_home("hcL");
@@ -1356,6 +1409,86 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     couple_eval += buf;
     couple_eval += "    ss = (ss + xq(ss)) + rc * rc;\n    mres_new = fmax(fmax(mres_new, xq(mres_new)), fabs(rc));\n";
   }
+
+  // ---- k > 1 joining rows: the pieces every kernel body shares (text; the single-row bodies keep their own) ----
+  // Per half: Dt = D + sum_j w_j w_j^T (own parts of the joining rows' rank-one terms, block-diagonal), Z = Dt^-1 W
+  // (k substitutions), G = W^T Z (k x k, symmetric), H = the partner's G.  A solution y of Dt y = b becomes the coupled
+  // system's x = y - Z a' with a' = (I - H G)^-1 (t - H s), s = W^T y of this half, t the partner's (derivation:
+  // x_o = y_o - Z_o a_p, a_o = s_o - G_o a_p, a_p = s_p - G_p a_o).  For k = 1 this is the 2 x 2 form of the bodies below.
+  auto sfmt = [](const char* format, auto... args) {
+    char line[512];
+    std::snprintf(line, sizeof(line), format, args...);
+    return std::string(line);
+  };
+  auto join_rank_one_src = [&]() {
+    std::string out;
+    for (int j = 0; j < NK; ++j)
+      for (int k = 0; k < 3; ++k)
+        out += sfmt("    %s = fma(cu%d, QB%d(cu%d), %s);\n", Gen::A(FUj[j], FUj[j], k).c_str(), j, k, j, Gen::A(FUj[j], FUj[j], k).c_str());
+    return out;
+  };
+  auto join_z_src = [&]() {  // after the factorisation: nz{j}_{F}, smG / smH / smM (leaves ev.out cleared)
+    std::string out;
+    for (int j = 0; j < NK; ++j) {
+      std::vector<std::string> rhs_w;
+      for (int F = 0; F < nf; ++F) rhs_w.push_back(F == FUj[j] ? "cu" + std::to_string(j) : "0.0");
+      for (int F = 0; F < nf; ++F) out += sfmt("    double nz%d_%d;\n", j, F);
+      ev.out.clear();
+      ev.emit_substitute(rhs_w, "sz");
+      out += "    {\n" + ev.out;
+      for (int F = 0; F < nf; ++F) out += sfmt("    nz%d_%d = sz%d;\n", j, F, F);
+      out += "    }\n";
+    }
+    ev.out.clear();
+    for (int i = 0; i < NK; ++i)
+      for (int j = i; j < NK; ++j) {
+        out += sfmt("    const double smG%d_%d = qsum(cu%d * nz%d_%d), smH%d_%d = xq(smG%d_%d);\n", i, j, i, j, FUj[i], i, j, i, j);
+        if (j != i) out += sfmt("    const double smG%d_%d = smG%d_%d, smH%d_%d = smH%d_%d;\n", j, i, i, j, j, i, i, j);
+      }
+    // (I - H G)^-1 by Gauss-Jordan on [N | I], unrolled here (no pivoting: N = I - (two matrices of norm < 1))
+    for (int i = 0; i < NK; ++i)
+      for (int j = 0; j < 2 * NK; ++j) {
+        std::string e = j < NK ? (i == j ? "1.0" : "0.0") : (j - NK == i ? "1.0" : "0.0");
+        if (j < NK)
+          for (int l = 0; l < NK; ++l) e += sfmt(" - smH%d_%d * smG%d_%d", i, l, l, j);
+        out += sfmt("    double smA%d_%d = %s;\n", i, j, e.c_str());
+      }
+    for (int piv = 0; piv < NK; ++piv) {
+      out += sfmt("    { const double smr = 1.0 / smA%d_%d;", piv, piv);
+      for (int j = 0; j < 2 * NK; ++j) out += sfmt(" smA%d_%d *= smr;", piv, j);
+      out += " }\n";
+      for (int i = 0; i < NK; ++i) {
+        if (i == piv) continue;
+        out += sfmt("    { const double smf = smA%d_%d;", i, piv);
+        for (int j = 0; j < 2 * NK; ++j) out += sfmt(" smA%d_%d = fma(-smf, smA%d_%d, smA%d_%d);", i, j, piv, j, i, j);
+        out += " }\n";
+      }
+    }
+    return out;
+  };
+  // corrects the solution whose block F is in_name(F); out_stmt(F, expression) is the statement that receives block F
+  auto join_correct_src = [&](const std::function<std::string(int)>& in_name,
+                              const std::function<std::string(int, const std::string&)>& out_stmt) {
+    std::string out;
+    for (int i = 0; i < NK; ++i)
+      out += sfmt("    const double smS%d = qsum(cu%d * %s), smT%d = xq(smS%d);\n", i, i, in_name(FUj[i]).c_str(), i, i);
+    for (int i = 0; i < NK; ++i) {
+      std::string e = "smT" + std::to_string(i);
+      for (int l = 0; l < NK; ++l) e += sfmt(" - smH%d_%d * smS%d", i, l, l);
+      out += sfmt("    const double smR%d = %s;\n", i, e.c_str());
+    }
+    for (int i = 0; i < NK; ++i) {
+      std::string e;
+      for (int l = 0; l < NK; ++l) e += sfmt("%ssmA%d_%d * smR%d", l ? " + " : "", i, NK + l, l);
+      out += sfmt("    const double sma%d = %s;\n", i, e.c_str());
+    }
+    for (int F = 0; F < nf; ++F) {
+      std::string e = in_name(F);
+      for (int j = 0; j < NK; ++j) e = sfmt("fma(-nz%d_%d, sma%d, %s)", j, F, j, e.c_str());
+      out += out_stmt(F, e);
+    }
+    return out;
+  };
 
   // which points must live in registers
   std::vector<bool> used(NP, false);
@@ -1769,6 +1902,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("        }");
     g.f("      }");
   }
+  if (getenv("OKX_PAIR_DEBUG_RC")) g.f("      double dbg0 = 0.0, dbg1 = 0.0, dbg2 = 0.0;  // (diagnostic build)");
   g.f("      while (wave_any(!done)) {");
   if (light_ok) {
     // Confirming pass: every active problem of this wavefront has a step in hand that is
@@ -1797,6 +1931,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int F = 0; F < nf; ++F) g.f("    p%d = mode == 2 ? x%d : x%d + dx%d;", ev.fp(F), F, F, F);
   g.out += eval_src;
   g.out += couple_eval;
+  if (getenv("OKX_PAIR_DEBUG_RC") && NK > 1) g.f("    if (mode == 0) { dbg0 = rc0; dbg1 = rc1; dbg2 = %s; }", NK > 2 ? "rc2" : "0.0");
   g.f("    const double Ft = 0.5 * ss;");
   // LM decision (mirrors okx_solve_kernel)
   g.f("    bool accept = true, stop = false, compromise = false;");
@@ -1889,6 +2024,36 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     // and the off-diagonal coupling u v^T + v u^T (u = (w_L, 0), v = (0, w_R)) goes through a 2 x 2 Woodbury
     // system: dx = y - z c, Dt y = -g, Dt z = w (per half), c = (s_partner - g_partner s_own) / (1 - g_own g_partner)
     // with g = w.z and s = w.y of each half.  (Plain Sherman-Morrison on D cancels catastrophically there.)
+    if (NK > 1) {
+      g.out += join_rank_one_src();
+      ev.out.clear();
+      ev.emit_factor();
+      g.out += ev.out;
+      g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
+      g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
+      std::vector<std::string> rhs_g;
+      for (int F = 0; F < nf; ++F) rhs_g.push_back("-gn" + std::to_string(F));
+      for (int F = 0; F < nf; ++F) g.f("    double ny%d;", F);
+      ev.out.clear();
+      ev.emit_substitute(rhs_g, "sy");
+      g.f("    {");
+      g.out += ev.out;
+      for (int F = 0; F < nf; ++F) g.f("    ny%d = sy%d;", F, F);
+      g.f("    }");
+      g.out += join_z_src();
+      for (int F = 0; F < nf; ++F) g.f("    double nx%d;", F);
+      g.f("    {");
+      g.out += join_correct_src([&](int F) { return "ny" + std::to_string(F); },
+                                [&](int F, const std::string& e) { return sfmt("    nx%d = %s;\n", F, e.c_str()); });
+      g.f("    }");
+      // tied modes: one per joining row, each judged as in the single-row case (the halves' compliances along w_j in parallel)
+      std::string kc = "1e300";
+      for (int j = 0; j < NK; ++j)
+        kc = sfmt("fmin(%s, (1.0 - smG%d_%d) * fast_rcp(smG%d_%d) + (1.0 - smH%d_%d) * fast_rcp(smH%d_%d))", kc.c_str(), j, j, j, j, j, j, j, j);
+      g.f("    const double kc = %s;", kc.c_str());
+      g.f("    const double pcoup = fmax(kc - 2.0 * lambda, 0.0);");
+      g.f("    pmin = fmin(pmin, fmax(kc, 0.0));");
+    } else {
     for (int k = 0; k < 3; ++k)
       g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
     ev.out.clear();
@@ -1924,6 +2089,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("    const double kc = (1.0 - sm_g) * fast_rcp(sm_g) + (1.0 - sm_gp) * fast_rcp(sm_gp);");
     g.f("    const double pcoup = fmax(kc - 2.0 * lambda, 0.0);");
     g.f("    pmin = fmin(pmin, fmax(kc, 0.0));");
+    }
   }
   g.f("    double sl = 0.0, pr = 0.0, dd = 0.0;");
   for (int F = 0; F < nf; ++F) g.f("    sl = fmax(sl, fabs(nx%d));", F);
@@ -2059,6 +2225,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    if (valid && c == 0%s) {", pv ? " && !q1" : "");
   g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
   if (getenv("OKX_PAIR_DEBUG_PIV")) g.f("      inf.cost = piv_hi; inf.last_step = piv_lo;  // (diagnostic build)");
+  if (getenv("OKX_PAIR_DEBUG_RC")) g.f("      inf.cost = dbg0; inf.last_step = dbg1; inf.max_residual = dbg2;  // (diagnostic build)");
   g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
   g.f("      a.info[bb] = inf;");
   g.f("    }");
@@ -2235,11 +2402,17 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       // off-diagonal coupling u v^T + v u^T (u = (w_L, 0), v = (0, w_R)) goes through a 2 x 2 Woodbury system:
       // q = y - z c,  Dt y = rhs,  Dt z = w (per half),  c = (s_partner - g_partner s_own) / (1 - g_own g_partner),
       // g = w.z and s = w.y of each half.
+      if (NK > 1) g.out += join_rank_one_src();
+      else
       for (int k = 0; k < 3; ++k)
         g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
     }
     g.out += factor_src;
-    if (pv) {
+    if (pv && NK > 1) {
+      g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
+      g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
+      g.out += join_z_src();
+    } else if (pv) {
       g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
       g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
       std::vector<std::string> rhs_w;
@@ -2272,7 +2445,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         for (auto& fv : it->second) rhs[fv.first] = pv ? "(ms * " + Gen::sx(fv.second) + ")" : Gen::sx(fv.second);
       ev.out.clear();
       ev.emit_substitute(rhs, pv ? "ty" : "tq");
-      if (pv) {
+      if (pv && NK > 1) {
+        ev.out += join_correct_src([&](int F) { return "ty" + std::to_string(F); },
+                                   [&](int F, const std::string& e) { return sfmt("    const double tq%d = %s;\n", F, e.c_str()); });
+      } else if (pv) {
         ev.f("    const double sm_s = qsum(cu * ty%d);", FU);
         ev.f("    const double sm_c = (xq(sm_s) - sm_gp * sm_s) / sm_det;");
         for (int F = 0; F < nf; ++F) ev.f("    const double tq%d = fma(-nz%d, sm_c, ty%d);", F, F, F);  // (q1 is the lane's half)
@@ -2365,7 +2541,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.out += eval_src;
     g.out += couple_eval;
     const int n_fd_dirs = NPAIR > 0 ? (HK - 1) + (HK - 1) * (HK - 2) / 2 : 0;
-    const int fd_rows = P.m + (pv ? 1 : 0);
+    const int fd_rows = P.m + NK;  // the joining rows follow each half's own rows
+    auto rcn = [&](int j) { return NK > 1 ? "rc" + std::to_string(j) : std::string("rc"); };
+    auto cun = [&](int j) { return NK > 1 ? "cu" + std::to_string(j) : std::string("cu"); };
     if (NPAIR > 0) {
       // second differences of the rows per direction, [direction][row][quad] in LDS (63 quad-uniform doubles would
       // otherwise sit in registers beside the factor); every one starts at -2 r(design state), while the r_i are at hand
@@ -2374,7 +2552,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       g.f("    const int hdq = lane >> 2;");
       for (int d = 0; d < n_fd_dirs; ++d) {
         for (int i = 0; i < P.m; ++i) g.f("    hDl[%d + hdq] = -2.0 * r%d;", (d * fd_rows + i) * 16, i);
-        if (pv) g.f("    hDl[%d + hdq] = -2.0 * rc;", (d * fd_rows + P.m) * 16);
+        for (int j = 0; j < NK; ++j) g.f("    hDl[%d + hdq] = -2.0 * %s;", (d * fd_rows + P.m + j) * 16, rcn(j).c_str());
       }
     }
     g.f("    double diag = 0.0;");
@@ -2391,11 +2569,17 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
             if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
           }
         }
+    if (pv && NK > 1) g.out += join_rank_one_src();
+    else
     if (pv)  // each half takes its own part of the joining row's rank-one term (see the solve kernel)
       for (int k = 0; k < 3; ++k)
         g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
     g.out += factor_src;
-    if (pv) {
+    if (pv && NK > 1) {
+      g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
+      g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
+      g.out += join_z_src();
+    } else if (pv) {
       g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
       g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
       std::vector<std::string> rhs_w;
@@ -2430,7 +2614,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       for (int F = 0; F < nf; ++F) g.f("    double hQ%d_%d;", k, F);
       g.f("    {");
       g.out += ev.out;
-      if (pv) {  // the coupling between the halves: 2 x 2 Woodbury, as in the solve kernel
+      if (pv && NK > 1) {
+        g.out += join_correct_src([&](int F) { return outn + std::to_string(F); },
+                                  [&](int F, const std::string& e) { return sfmt("    hQ%d_%d = %s;\n", k, F, e.c_str()); });
+      } else if (pv) {  // the coupling between the halves: 2 x 2 Woodbury, as in the solve kernel
         g.f("    const double sm_s = qsum(cu * %s%d);", outn.c_str(), FU);
         g.f("    const double sm_c = (xq(sm_s) - sm_gp * sm_s) / sm_det;");
         for (int F = 0; F < nf; ++F) g.f("    hQ%d_%d = fma(-nz%d, sm_c, %s%d);", k, F, F, outn.c_str(), F);
@@ -2493,7 +2680,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
           for (int i = 0; i < P.m; ++i) g.f("    hDl[%d + hdq] += r%d;", (int)(d * fd_rows + i) * 16, i);
           if (pv) {  // the joining row at the displaced halves (each half moved its own joined point)
             g.out += couple_light;
-            g.f("    hDl[%d + hdq] += rc;", (int)(d * fd_rows + P.m) * 16);
+            for (int j = 0; j < NK; ++j) g.f("    hDl[%d + hdq] += %s;", (int)(d * fd_rows + P.m + j) * 16, rcn(j).c_str());
           }
           g.f("    }");
         }
@@ -2539,8 +2726,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         g.out += jt.out;
         if (pv) {  // the joining row: its gradient lives in the joined point's block, its curvature term with it
           g.out += couple_eval;
-          for (int pi = 0; pi < NPAIR; ++pi)
-            g.f("    hR%d_g%d = fma(cu, %s, hR%d_g%d);", pi, FU, pair_value(pi, P.m).c_str(), pi, FU);
+          for (int j = 0; j < NK; ++j)
+            for (int pi = 0; pi < NPAIR; ++pi)
+              g.f("    hR%d_g%d = fma(%s, %s, hR%d_g%d);", pi, FUj[j], cun(j).c_str(), pair_value(pi, P.m + j).c_str(), pi, FUj[j]);
         }
         for (int F = 0; F < nf; ++F)
           for (int G = 0; G <= F; ++G)
@@ -2550,10 +2738,14 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
                 if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
               }
             }
+        if (pv && NK > 1) g.out += join_rank_one_src();
+        else
         if (pv)
           for (int k = 0; k < 3; ++k)
             g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
         g.out += factor_src;
+        if (pv && NK > 1) g.out += join_z_src();
+        else
         if (pv) {  // D~ z = w once more (the first scope's z is not kept alive across the residual passes above)
           std::vector<std::string> rhs_w;
           for (int F = 0; F < nf; ++F) rhs_w.push_back(F == FU ? "cu" : "0.0");
@@ -2575,7 +2767,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
           ev.emit_substitute(rhs, outn.c_str());
           g.f("    {");
           g.out += ev.out;
-          if (pv) {  // the coupling between the halves, as for the columns
+          if (pv && NK > 1) {
+            g.f("    double* hso = hs + (q1 ? %d : 0);  // this half's S block", head_s_side);
+            g.out += join_correct_src([&](int F) { return outn + std::to_string(F); }, [&](int F, const std::string& e) {
+              return sfmt("    if (valid) hso[%d + c] = c < 3 ? %s : 0.0;\n", head_s_off + 4 * (pi * nf + F), e.c_str());
+            });
+          } else if (pv) {  // the coupling between the halves, as for the columns
             g.f("    const double sm_s = qsum(cu * %s%d);", outn.c_str(), FU);
             g.f("    const double sm_c = (xq(sm_s) - sm_gp * sm_s) / sm_det;");
             g.f("    double* hso = hs + (q1 ? %d : 0);  // this half's S block", head_s_side);

@@ -1,8 +1,9 @@
 """
-GPU: the axle's shared hardware through the drop-in - rigid T-bar anti-roll bar (60 variables, three joining rows: the
-interpreter, one wavefront per problem), a rocker-to-rocker heave link on the U-bar axle (66 variables: pair-mode quad
-kernel, 11 free points per half) and on the T-bar axle (66 variables, no pair structure: the interpreter on two
-wavefronts per problem, LDL^T rows in LDS).  After the reference's tests/test_t_bar_arb.py:96-196 and tests/test_axle_rocker.py:143-175, plus the parity of the
+GPU: the axle's shared hardware through the drop-in - rigid T-bar anti-roll bar (60 variables; pair-mode quad kernel with
+three joining rows: rack, crossbar length, crossbar midpoint on the centre plane), a rocker-to-rocker heave link on the
+U-bar axle and on the T-bar axle (66 variables: pair mode with 11 free points per half).  The 66-variable programs also
+run through the interpreter's two-wavefront instantiation (LDL^T rows in LDS), forced here, so that the capacity path
+for programs without a generated kernel stays pinned.  After the reference's tests/test_t_bar_arb.py:96-196 and tests/test_axle_rocker.py:143-175, plus the parity of the
 two-wavefront kernels against the oracle and against the one-wavefront kernels on a program both can run.
 """
 
@@ -121,7 +122,7 @@ def test_heave_link_length_follows_the_rockers(golden):
 
 
 @pytest.mark.parametrize("name", ["t_axle_t_bar_heave", "t_axle_heave_link"])
-def test_two_wavefront_kernels_match_the_oracle(golden, name):
+def test_two_wavefront_kernels_match_the_oracle(golden, name, monkeypatch):
     """R1 / R1b / solve for a program of more than 63 variables: residuals, Jacobian, J^T J, J^T r at seeded points and
     the solved sweep, cold and chained, against the oracle; tangents against a central difference of solves."""
     from open_kinematics_amd.batch import DeviceProgram
@@ -131,10 +132,10 @@ def test_two_wavefront_kernels_match_the_oracle(golden, name):
     pinned = program.with_line_mode("pinned")
     assert pinned.n_vars > 63
     dp = DeviceProgram(pinned, "cuda:0")
-    # the T-bar variant has no generated kernel (three joining rows); the U-bar variant does (pair mode), and its
-    # interpreter instantiation is forced here
-    assert dp.kernel == ("wave" if name == "t_axle_t_bar_heave" else "quad"), dp.kernel_note
-    force = {} if dp.kernel == "wave" else {"kernel": "single"}
+    # both have a generated pair-mode kernel (one and three joining rows); the interpreter instantiation is forced here
+    assert dp.kernel == "quad", dp.kernel_note
+    force = {"kernel": "single"}
+    monkeypatch.setenv("OKX_TANGENT_GENERIC", "1")  # okx_tangent_batch: the interpreter's tangent kernel
     x, t = arrays["eval_x"], arrays["eval_targets"]
     r_o, jac_o = Oracle(pinned).eval(x, t)
     r, jac = dp.eval(x, t)
@@ -154,14 +155,20 @@ def test_two_wavefront_kernels_match_the_oracle(golden, name):
         pos = res.positions.cpu().numpy()
         assert np.max(np.abs(pos - orc.positions)) <= 1e-9                # north-star tolerance (mm)
         assert np.max(np.abs(pos - arrays["ref_tight_pos"])) <= 6e-8     # the reference's own floor
-    if force:  # the generated pair-mode kernel against the interpreter on the same program
-        quad = dp.solve(targets, chain_len=1)
-        assert dp.solve(targets, chain_len=1).info()["flags"].tolist() == [1] * len(targets)
-        assert float((quad.positions - dp.solve(targets, chain_len=1, **force).positions).abs().max()) <= 1e-10
-    # tangents (interpreter kernel for the T-bar variant, generated kernel for the U-bar one): d positions / d target
-    # against central differences of tight solves
+    # the generated pair-mode kernel against the interpreter on the same program
+    quad = dp.solve(targets, chain_len=1)
+    assert np.all((quad.info()["flags"] & 7) == 1)
+    assert float((quad.positions - dp.solve(targets, chain_len=1, **force).positions).abs().max()) <= 1e-10
+    assert np.max(np.abs(quad.positions.cpu().numpy() - orc.positions)) <= 1e-9
+    # tangents (the interpreter's kernel, forced above; then the generated one): d positions / d target against central
+    # differences of tight solves
     res = dp.solve(targets, chain_len=1)
     tan, tinfo = dp.tangents(res.positions)
+    monkeypatch.delenv("OKX_TANGENT_GENERIC")
+    tan_quad, tinfo_quad = dp.tangents(res.positions)
+    torch.cuda.synchronize()
+    assert np.all(dp.tangent_info(tinfo_quad)["flags"] == 1)
+    assert float((tan - tan_quad).abs().max()) <= 1e-9 * max(1.0, float(tan.abs().max()))
     torch.cuda.synchronize()
     assert np.all(dp.tangent_info(tinfo)["flags"] == 1)
     h = 1e-3
@@ -173,17 +180,17 @@ def test_two_wavefront_kernels_match_the_oracle(golden, name):
 
 
 def test_two_wavefront_factorisation_gives_the_damped_step(golden):
-    """The LDL^T of the two-wavefront kernels (rows in LDS, right-hand side as row n) where it is used: the first
-    damped step of the 66-variable program against numpy on the kernel's own J^T J."""
+    """The LDL^T of the interpreter's two-wavefront kernels (rows in LDS, right-hand side as row n): the first damped
+    step of a 66-variable program against numpy on the kernel's own J^T J."""
     from open_kinematics_amd.batch import DeviceProgram
 
     arrays, program = golden("t_axle_t_bar_heave")
     pinned = program.with_line_mode("pinned")
     dp = DeviceProgram(pinned, "cuda:0")
-    assert dp.kernel == "wave" and pinned.n_vars == 66
+    assert pinned.n_vars == 66
     targets = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
     # one LM step from the design state with max_iter = 1 is x0 - (J^T J + lambda I)^-1 J^T r
-    res = dp.solve(targets, chain_len=1, max_iter=1, shared_first_step=False)
+    res = dp.solve(targets, chain_len=1, max_iter=1, shared_first_step=False, kernel="single")
     torch.cuda.synchronize()
     n = pinned.n_vars
     x0 = pinned.design_pos[pinned.free_point].reshape(-1)
@@ -195,3 +202,42 @@ def test_two_wavefront_factorisation_gives_the_damped_step(golden):
         lam = dp.default_opts().lambda0 * np.max(np.diag(ata[b]))  # the damping a cold start begins with
         want = -np.linalg.solve(ata[b] + lam * np.eye(n), atr[b])
         assert np.max(np.abs(got[b] - want)) <= 1e-9 * max(1.0, np.abs(want).max()), b
+
+
+@pytest.mark.parametrize("name", ["t_axle_t_bar_roll", "t_axle_t_bar_bump", "t_axle_t_bar_heave"])
+def test_pair_mode_with_three_joining_rows_takes_the_coupled_step(golden, name):
+    """The T-bar axle in pair mode: rack length, crossbar length and crossbar midpoint plane join the halves (a 6 x 6
+    Woodbury system on per-half dot products).  Its first damped step from the design state against numpy on the oracle's
+    Jacobian, then cold and chained solves against the interpreter and the reference."""
+    from open_kinematics_amd.batch import DeviceProgram
+    from oracle.oracle import Oracle
+
+    arrays, program = golden(name)
+    pinned = program.with_line_mode("pinned")
+    dp = DeviceProgram(pinned, "cuda:0")
+    assert dp.kernel == "quad", dp.kernel_note
+    n = pinned.n_vars
+    t_host = arrays["targets_abs"].reshape(-1, pinned.n_targets)
+    targets = torch.as_tensor(t_host, device="cuda:0")
+    x0 = pinned.design_pos[pinned.free_point].reshape(-1)
+    xs = np.repeat(x0[None], len(t_host), 0)
+    r_o, jac_o = Oracle(pinned).eval(xs, t_host)
+    ata, atr = np.einsum("bij,bik->bjk", jac_o, jac_o), np.einsum("bij,bi->bj", jac_o, r_o)
+    res = dp.solve(targets, chain_len=1, max_iter=1, shared_first_step=False, predictor=False)
+    torch.cuda.synchronize()
+    free_out = [list(pinned.out_point).index(p) for p in pinned.free_point]
+    got = res.positions.cpu().numpy()[:, free_out].reshape(-1, n) - xs
+    lam0 = dp.default_opts().lambda0
+    accepted = 0
+    for b in range(len(t_host)):
+        want = -np.linalg.solve(ata[b] + lam0 * np.max(np.diag(ata[b])) * np.eye(n), atr[b])
+        if np.abs(got[b]).max() > 0.0:  # (a rejected trial leaves the design state in place)
+            accepted += 1
+            assert np.max(np.abs(got[b] - want)) <= 1e-9 * max(1.0, np.abs(want).max()), b
+    assert accepted >= len(t_host) // 2
+    wave = dp.solve(targets, chain_len=1, kernel="single").positions
+    for kw in (dict(chain_len=1), dict(chain=True), dict(chain_len=1, shared_first_step=False)):
+        out = dp.solve(targets, **kw)
+        assert np.all((out.info()["flags"] & 7) == 1)
+        assert float((out.positions - wave).abs().max()) <= 1e-10
+        assert np.max(np.abs(out.positions.cpu().numpy() - arrays["ref_tight_pos"])) <= 6e-8
