@@ -43,31 +43,38 @@ for g in rng.choice(n_geo, 12, replace=False):
     worst = max(worst, float(np.max(np.abs(pos[g][pick] - orc.positions))))
 print(f"oracle sample (12 geometries x 6 steps): max |device - oracle| = {worst:.2e} mm")
 
-# ---- the rocker axle in pair mode: perturbed geometries x random heave / roll lines, against the interpreter ----
+# ---- composed axles in pair mode: perturbed geometries x random heave / roll lines, against the interpreter ----
+#      rocker + U-bar axle (one joining row), T-bar axle (three), T-bar + heave-link axle (three, 11 free points per half)
 from open_kinematics_amd.workloads import axle_grid_problem
 
-program, _ = axle_grid_problem(2, 2)
-dp = DeviceProgram(program, "cuda:0")
-n_axle, s_axle = max(n_geo // 8, 16), 64
-hard = np.repeat(program.design_pos[None], n_axle, axis=0)
-moving = np.array([i for i in range(program.n_points) if program.role[i] != 2])
-hard[1:, moving] += rng.normal(0.0, 0.75, (n_axle - 1, len(moving), 3))
-gpos, gparam = dp.rebind(torch.as_tensor(hard, device="cuda:0"))
-base = torch.stack([gpos[:, program.tgt_point[k]] @ torch.as_tensor(program.tgt_dir[k], device="cuda:0") for k in range(program.n_targets)], 1)
-heave0, heave1 = rng.uniform(-35, 0, n_axle), rng.uniform(0, 35, n_axle)
-roll0, roll1 = rng.uniform(-18, 0, n_axle), rng.uniform(0, 18, n_axle)
-u = np.linspace(0.0, 1.0, s_axle)[None, :]
-heave = heave0[:, None] + u * (heave1 - heave0)[:, None]
-roll = roll0[:, None] + u * (roll1 - roll0)[:, None]
-rel = np.zeros((n_axle, s_axle, program.n_targets))
-rel[:, :, 0], rel[:, :, 1] = heave + roll, heave - roll   # left / right wheel-centre z; rack held
-targets = (base[:, None, :] + torch.as_tensor(rel, device="cuda:0")).reshape(-1, program.n_targets).contiguous()
-kw = dict(geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=s_axle)
-wave = dp.solve(targets, kernel="single", **kw)
-print(f"axle interpreter: not accepted {int((~wave.accepted(wave.info())).sum())} of {targets.shape[0]}")
-for cl in (1, -1, s_axle):
-    res = dp.solve(targets, chain_len=cl, **kw)
-    info = res.info(); ok = res.accepted(info)
-    both = torch.as_tensor(ok & wave.accepted(wave.info()), device="cuda:0")
-    print(f"axle pair mode chain_len={cl:3d}: not accepted {int((~ok).sum())}, evals {info['nfev'].mean():.2f} (max {info['nfev'].max()}), "
-          f"max |quad - interpreter| = {float((res.positions - wave.positions)[both].abs().max()):.1e}")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from conftest import load_golden
+
+axles = [("rocker + U-bar axle", axle_grid_problem(2, 2)[0])]
+for fixture in ("t_axle_t_bar_roll", "t_axle_t_bar_heave"):
+    axles.append((fixture, load_golden(fixture)[1].with_line_mode("pinned")))
+for label, program in axles:
+    dp = DeviceProgram(program, "cuda:0")
+    n_axle, s_axle = max(n_geo // 8, 16), 64
+    hard = np.repeat(program.design_pos[None], n_axle, axis=0)
+    moving = np.array([i for i in range(program.n_points) if program.role[i] != 2])
+    hard[1:, moving] += rng.normal(0.0, 0.75, (n_axle - 1, len(moving), 3))
+    gpos, gparam = dp.rebind(torch.as_tensor(hard, device="cuda:0"))
+    base = torch.stack([gpos[:, program.tgt_point[k]] @ torch.as_tensor(program.tgt_dir[k], device="cuda:0") for k in range(program.n_targets)], 1)
+    heave0, heave1 = rng.uniform(-35, 0, n_axle), rng.uniform(0, 35, n_axle)
+    roll0, roll1 = rng.uniform(-18, 0, n_axle), rng.uniform(0, 18, n_axle)
+    u = np.linspace(0.0, 1.0, s_axle)[None, :]
+    heave = heave0[:, None] + u * (heave1 - heave0)[:, None]
+    roll = roll0[:, None] + u * (roll1 - roll0)[:, None]
+    rel = np.zeros((n_axle, s_axle, program.n_targets))
+    rel[:, :, 0], rel[:, :, 1] = heave + roll, heave - roll   # left / right wheel-centre z; rack held
+    targets = (base[:, None, :] + torch.as_tensor(rel, device="cuda:0")).reshape(-1, program.n_targets).contiguous()
+    kw = dict(geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=s_axle)
+    wave = dp.solve(targets, kernel="single", **kw)
+    print(f"{label} ({dp.kernel}, n = {program.n_vars}): interpreter not accepted {int((~wave.accepted(wave.info())).sum())} of {targets.shape[0]}")
+    for cl in (1, -1, s_axle):
+        res = dp.solve(targets, chain_len=cl, **kw)
+        info = res.info(); ok = res.accepted(info)
+        both = torch.as_tensor(ok & wave.accepted(wave.info()), device="cuda:0")
+        print(f"  pair mode chain_len={cl:3d}: not accepted {int((~ok).sum())}, evals {info['nfev'].mean():.2f} (max {info['nfev'].max()}), "
+              f"max |quad - interpreter| = {float((res.positions - wave.positions)[both].abs().max()):.1e}")
