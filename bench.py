@@ -470,7 +470,15 @@ def measure_e2e_compact(dp, targets_host: np.ndarray, device, steps: int, cold_k
                     "pinned host buffers; never reported as `value`"}
 
 
-def measure_e2e_zero_copy(dp, targets_host: np.ndarray, device, steps: int, cold_kw: dict, n_slots: int = 3) -> dict:
+def zero_copy_buffers(program, targets_host: np.ndarray, n_slots: int = 3) -> list:
+    """Pinned host buffers of measure_e2e_zero_copy: (targets, free coordinates, info records) per slot."""
+    n = targets_host.shape[0]
+    h_t = torch.as_tensor(targets_host).pin_memory()
+    return [(h_t, torch.empty((n, program.n_free, 3), dtype=torch.float64).pin_memory(),
+             torch.empty((n, 40), dtype=torch.uint8).pin_memory()) for _ in range(n_slots)]
+
+
+def measure_e2e_zero_copy(dp, targets_host: np.ndarray, device, steps: int, cold_kw: dict, n_slots: int = 3, buffers=None) -> dict:
     """Host buffers in, host buffers out with NO copy commands: the boundary takes plain pointers, and pinned host memory
     is device-accessible, so the solve kernel reads its targets from and stores its compact output (free coordinates +
     info records) straight into the caller's pinned buffers - the bytes cross PCIe as the kernel issues them, three
@@ -478,12 +486,11 @@ def measure_e2e_zero_copy(dp, targets_host: np.ndarray, device, steps: int, cold
     engine's per-command latency that bounds the copy-based pipeline above."""
     p = dp.program
     n = targets_host.shape[0]
-    h_t = torch.as_tensor(targets_host).pin_memory()
+    buffers = buffers or zero_copy_buffers(p, targets_host, n_slots)
+    h_t = buffers[0][0]
     slots = []
-    for _ in range(n_slots):
+    for _, h_free, h_info in buffers:
         stream = torch.cuda.Stream(device)
-        h_free = torch.empty((n, p.n_free, 3), dtype=torch.float64).pin_memory()
-        h_info = torch.empty((n, 40), dtype=torch.uint8).pin_memory()
         with torch.cuda.stream(stream):
             launch = dp.plan(h_t, out=h_free, info_out=h_info, output="free", **cold_kw)
         slots.append(dict(stream=stream, launch=launch, h_free=h_free, h_info=h_info, done=torch.cuda.Event()))
@@ -510,7 +517,7 @@ def measure_e2e_zero_copy(dp, targets_host: np.ndarray, device, steps: int, cold
     same = bool(np.array_equal(slots[0]["h_free"].numpy(), ref.free.cpu().numpy()))
     bytes_out = int(n * (p.n_free * 24 + 40))
     return {"value": n / wall, "ms_per_sweep": wall * 1e3, "bytes_in_over_pcie": int(h_t.numel() * 8), "bytes_out_over_pcie": bytes_out,
-            "pcie_out_gbs": bytes_out / wall / 1e9, "all_converged": ok, "same_bits_as_device_buffers": same, "streams": n_slots,
+            "pcie_out_gbs": bytes_out / wall / 1e9, "all_converged": ok, "same_bits_as_device_buffers": same, "streams": len(buffers),
             "note": "d_targets / d_out_pos / d_info of okx_solve_batch are the caller's pinned host buffers (device-accessible): "
                     "no H2D / D2H commands at all; never reported as `value`"}
 
@@ -935,6 +942,12 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         sus_wall, sus_ms = time_launches(launches[0], 2000, 10, device)
         line["sustained"] = {"value": (hi - lo) / sus_wall, "kernel_ms": sus_ms, "launches": 2000,
                              "note": "the same launch 2000 times back to back on one stream, one HIP-event pair around them"}
+        # Zero-copy leg first among the extras.  Its rate depends on the state of the process in a way that is measured
+        # but not explained (tools/zc_order.py): 62 us per sweep (2.6e8 solves/s, 48 GB/s of PCIe stores) alone or as the
+        # first leg, 105 ... 360 us after a second DeviceProgram, the graph-replay leg or an earlier zero-copy leg have run.
+        zero_copy = measure_e2e_zero_copy(dp, targets_all[lo:hi], device, 200, dict(chain_len=args.chain_len, predictor=False))
+        zero_copy["note"] += ("; measured before every other extra leg: the same leg run later in the process has been seen at a "
+                              "fifth of this rate (profiles/r03/EXPERIMENTS.md section 6)")
         line["one_shot"] = measure_one_shot(program, targets, device, kernel_ms)
     if world == 1 and not args.no_extras and not args.rccl_world_one:
         extra_steps = max(5, min(args.steps, 50))
@@ -947,10 +960,6 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["pipelined"] = measure_pipelined(dp, targets, device, max(args.steps, 60))
         line["with_model"] = measure_with_model(program, targets, device, args.steps, args.warmup)
         line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, extra_steps, dict(chain_len=args.chain_len, predictor=False))
-        # zero-copy before the graph-replay pipeline: measured after it (same process) the kernel's PCIe stores run at a
-        # fifth of their rate (tools/zc_order.py: 62 us per sweep alone or after the other legs, 315 us after `compact`)
-        zero_copy = measure_e2e_zero_copy(dp, targets_all[lo:hi], device, max(extra_steps, 200),
-                                          dict(chain_len=args.chain_len, predictor=False))
         line["e2e"]["compact"] = measure_e2e_compact(dp, targets_all[lo:hi], device, max(extra_steps, 200),
                                                      dict(chain_len=args.chain_len, predictor=False))
         line["e2e"]["zero_copy"] = zero_copy
