@@ -905,7 +905,8 @@ def run_c2(args, world: int, rank: int, device) -> dict:
             "traffic": traffic,
             "traffic_source": traffic_src,
             "traffic_measured_in_this_run": False if traffic is not None else None,
-            "kernel": "okx_quad_solve_u" if dp.kernel == "quad" else "okx_solve_kernel",
+            "kernel": ("okx_lane_solve_u" if 0 < dp.lane_threshold <= (hi - lo) and (dp.lane_bodies & 1) else
+                       "okx_quad_solve_u" if dp.kernel == "quad" else "okx_solve_kernel"),
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_solve": bytes_per_solve,
             "note": "HBM is the bound north_star states and frac is reported against it, but at 392 B per solve the path is "
@@ -1039,7 +1040,9 @@ def run_c5(args, world: int, rank: int, device) -> dict:
                    "lm_evaluations_mean": nfev_mean, "all_converged": ok, "rebind_ms": rebind_ms,
                    "exchange": "all-gather of the solved free coordinates + expand on every rank, after each solve" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "okx_quad_solve_g", "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bytes_per},
+                     "kernel": ("okx_lane_solve_g" if 0 < dp.lane_threshold <= n_local and (dp.lane_bodies & 1) else
+                                "okx_quad_solve_g" if dp.kernel == "quad" else "okx_solve_kernel"),
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bytes_per},
         "solve_only": {"value": n_total / (kernel_ms * 1e-3) if world > 1 else n_local / (kernel_ms * 1e-3),
                        "kernel_ms_max_over_ranks": kernel_ms},
         "exchange": {"bytes_sent_per_rank_per_step": free_bytes if world > 1 else 0,
