@@ -241,3 +241,23 @@ def test_pair_mode_with_three_joining_rows_takes_the_coupled_step(golden, name):
         assert np.all((out.info()["flags"] & 7) == 1)
         assert float((out.positions - wave).abs().max()) <= 1e-10
         assert np.max(np.abs(out.positions.cpu().numpy() - arrays["ref_tight_pos"])) <= 6e-8
+
+
+@pytest.mark.parametrize("name", ["t_axle_t_bar_roll", "t_axle_heave_link", "t_axle_t_bar_heave", "t_corner_strut_rocker"])
+def test_reference_literal_line_rows_on_the_generated_kernels(golden, name):
+    """line_mode = softnorm (the reference's zero-gradient point-on-line rows, as flattened from its objects) on the
+    kernels round 3 added: three joining rows, 11 free points per half, the nine-point corner.  Linear convergence along
+    the valley (looser step tolerance, more passes), inside the reference's own floor."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden(name)
+    assert program.line_mode == "softnorm"
+    dp = DeviceProgram(program, "cuda:0")
+    assert dp.kernel == "quad", dp.kernel_note
+    targets = torch.as_tensor(arrays["targets_abs"].reshape(-1, program.n_targets), device="cuda:0")
+    res = dp.solve(targets, chain_len=1, step_tol=1e-8, max_iter=200)
+    torch.cuda.synchronize()
+    info = res.info()
+    assert res.accepted(info).all()
+    ref = arrays["ref_tight_pos"].reshape(len(targets), -1, 3)
+    assert np.max(np.abs(res.positions.cpu().numpy() - ref)) <= 6e-8
