@@ -18,8 +18,10 @@ with open(find("trace", "kernel_trace.csv")) as f, open(f"{P}/{tag}_kernel_trace
     g.writelines(line for i, line in enumerate(f) if i < 40)
 for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", "SQ"), ("sq2", "SQ2"), ("sq3", "SQ3")):
     src = find(d, "counter_collection.csv")
-    if src:
-        shutil.copy(src, f"{P}/{tag}_pmc_{name}.csv")
+    if src:  # the first 6000 counter rows (a default bench run has > 4000 dispatches: megabytes of identical rows); the
+        # per-dispatch medians in <tag>_pmc_traffic.json are taken over ALL dispatches, from summary.json
+        with open(src) as f, open(f"{P}/{tag}_pmc_{name}.csv", "w") as g:
+            g.writelines(line for i, line in enumerate(f) if i <= 6000)
 fetch = s["FETCH_SIZE"]["per_dispatch_kib_median"] * 1024
 write = s["WRITE_SIZE"]["per_dispatch_kib_median"] * 1024
 sq, w = s["SQ"], s["SQ"]["SQ_WAVES"]
