@@ -261,3 +261,71 @@ def test_reference_literal_line_rows_on_the_generated_kernels(golden, name):
     assert res.accepted(info).all()
     ref = arrays["ref_tight_pos"].reshape(len(targets), -1, 3)
     assert np.max(np.abs(res.positions.cpu().numpy() - ref)) <= 6e-8
+
+
+def _stack(a, b):
+    """Two independent constraint programs as one: b's points, rows, derived ops, targets and outputs after a's."""
+    from open_kinematics_amd.program import ConstraintProgram, NamedKey
+
+    pa = a.n_points
+
+    def shift(pts):
+        pts = np.asarray(pts).copy()
+        pts[pts >= 0] += pa
+        return pts
+
+    return ConstraintProgram(
+        point_keys=[NamedKey("a_" + str(k)) for k in range(pa)] + [NamedKey("b_" + str(k)) for k in range(b.n_points)],
+        role=np.concatenate([a.role, b.role]),
+        free_point=np.concatenate([a.free_point, shift(b.free_point)]).astype(np.int32),
+        dop_type=np.concatenate([a.dop_type, b.dop_type]).astype(np.int32),
+        dop_out=np.concatenate([a.dop_out, shift(b.dop_out)]).astype(np.int32),
+        dop_pts=np.concatenate([a.dop_pts.reshape(-1, 4), shift(b.dop_pts.reshape(-1, 4))]).astype(np.int32),
+        dop_param=np.concatenate([a.dop_param, b.dop_param]),
+        row_type=np.concatenate([a.row_type, b.row_type]).astype(np.int32),
+        row_pts=np.concatenate([a.row_pts, shift(b.row_pts)]).astype(np.int32),
+        row_param=np.concatenate([a.row_param, b.row_param]),
+        row_source=np.concatenate([a.row_source, b.row_source + (a.row_source.max() + 1 if len(a.row_source) else 0)]).astype(np.int32),
+        tgt_point=np.concatenate([a.tgt_point, shift(b.tgt_point)]).astype(np.int32),
+        tgt_dir=np.concatenate([a.tgt_dir, b.tgt_dir]),
+        out_point=np.concatenate([a.out_point, shift(b.out_point)]).astype(np.int32),
+        design_pos=np.concatenate([a.design_pos, b.design_pos]),
+        constraint_desc=list(a.constraint_desc) + list(b.constraint_desc),
+        target_desc=list(a.target_desc) + list(b.target_desc),
+        line_mode=a.line_mode,
+    )
+
+
+def test_two_wavefront_interpreter_at_ninety_six_variables(golden):
+    """Capacity beyond the reference's own compositions: the rocker + U-bar axle and the plain double-wishbone axle as
+    ONE program (96 variables, no pair structure, so no generated kernel).  The interpreter's two-wavefront kernels on it
+    against each part solved alone and against the oracle."""
+    from open_kinematics_amd.batch import DeviceProgram
+    from oracle.oracle import Oracle
+
+    arr_a, prog_a = golden("c3_axle_grid")
+    arr_b, prog_b = golden("t_axle_dw")
+    a, b = prog_a.with_line_mode("pinned"), prog_b.with_line_mode("pinned")
+    both = _stack(a, b)
+    both.validate()
+    assert both.n_vars == a.n_vars + b.n_vars == 96
+    n = min(len(arr_a["targets_abs"]), len(arr_b["targets_abs"]), 9)
+    t_a, t_b = arr_a["targets_abs"][:n], arr_b["targets_abs"][:n]
+    targets = np.concatenate([t_a, t_b], axis=1)
+    dp = DeviceProgram(both, "cuda:0")
+    assert dp.kernel == "wave", "a stacked program has no pair structure"
+    x = np.concatenate([arr_a["eval_x"][:4], arr_b["eval_x"][:4]], axis=1)
+    t_eval = np.concatenate([arr_a["eval_targets"][:4], arr_b["eval_targets"][:4]], axis=1)
+    r_o, jac_o = Oracle(both).eval(x, t_eval)
+    r, jac = dp.eval(x, t_eval)
+    assert np.all(np.abs(r.cpu().numpy() - r_o) <= 2.5e-13 + 1e-13 * np.abs(r_o))
+    assert np.max(np.abs(jac.cpu().numpy() - jac_o)) <= 1e-12 * max(1.0, np.abs(jac_o).max())
+    res = dp.solve(torch.as_tensor(targets, device="cuda:0"), chain_len=1)
+    torch.cuda.synchronize()
+    assert np.all((res.info()["flags"] & 7) == 1)
+    pos = res.positions.cpu().numpy()
+    alone_a = DeviceProgram(a, "cuda:0").solve(torch.as_tensor(t_a, device="cuda:0"), chain_len=1, kernel="single").positions.cpu().numpy()
+    alone_b = DeviceProgram(b, "cuda:0").solve(torch.as_tensor(t_b, device="cuda:0"), chain_len=1, kernel="single").positions.cpu().numpy()
+    assert np.max(np.abs(pos[:, : a.n_out] - alone_a)) <= 1e-9 and np.max(np.abs(pos[:, a.n_out:] - alone_b)) <= 1e-9
+    orc = Oracle(both).sweep(targets[:3], 1e-15, 1e-15, 1e-15, warm_start=False)
+    assert np.max(np.abs(pos[:3] - orc.positions)) <= 1e-9
