@@ -540,8 +540,10 @@ int32_t okx_precompile(const okx_program_desc* desc);
  * The second generated kernel family: ONE LANE PER PROBLEM, 64 problems per wavefront, no cross-lane
  * operand at all (the quad kernel moves every dot product, J^T J column and pivot through DPP and idles
  * one lane in four).  About a quarter of the quad kernel's instructions per problem, but one wavefront
- * holds 64 problems: it pays from the batch size at which the chip is full, one wavefront per SIMD
- * (okx_program_lane_threshold(), 65536 problems on an MI355X).  Programs with at most 6 free points
+ * holds 64 problems and takes 25 ... 29 us whatever it holds: it pays as soon as the quad kernel (16
+ * problems per wavefront, ~21 us per round) needs a second round - from okx_program_lane_threshold()
+ * problems on, 16385 on an MI355X - unless an ensemble has so few steps per geometry that its lanes
+ * would idle (a wave unit holds problems of ONE geometry).  Programs with at most 6 free points
  * (n <= 18) whose quad kernel is loaded have one; okx_program_lane_note() says why another has not.
  * Same algorithm, same evaluation points, same first-step tables; okx_solve_opts.kernel = 4 forces it.
  */

@@ -333,8 +333,10 @@ void attach_lane_kernel(okx_program* p) {
   p->lane_fn_u = p->lane_fn_g = p->lane_fn_eval = nullptr;
   p->lane_chain_u = p->lane_chain_g = nullptr;
   p->lane_note[0] = 0;
-  // one wavefront of 64 problems per SIMD fills the chip; below that the quad kernel (16 problems per wavefront) does
-  p->lane_min_problems = (long long)p->n_cu * 4 * 64;
+  // The quad kernel runs 16 problems per wavefront, one wavefront per SIMD: up to n_cu * 4 * 16 problems (16384) are ONE
+  // round of it (~21 us for the double wishbone).  One problem more is a second round (~38 us), while the lane kernel
+  // takes 25 ... 29 us for anything up to n_cu * 4 * 64 problems (tools/lane_threshold.py): auto selection switches there.
+  p->lane_min_problems = (long long)p->n_cu * 4 * 16 + 1;
   if (const char* env = getenv("OKX_LANE_MIN")) p->lane_min_problems = atoll(env);
   if (!p->quad_fn_u || p->quad_ppw != 16) {
     std::snprintf(p->lane_note, sizeof(p->lane_note), "no single-mode quad kernel to share first-step tables with");
@@ -696,8 +698,17 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   // quad kernel alone offers is asked for (fitted model, trace); kernel == 4 forces it.
   // (which body a launch needs is known once the chain length is: a body auto selection may not use sends the launch
   //  back to the quad kernel below)
+  // Rounds of each kernel for this launch (one wavefront per SIMD either way): lane wave units hold 64 problems of ONE
+  // geometry, so an ensemble with few steps per geometry leaves lanes idle and may be the quad kernel's after all.
+  const auto lane_pays = [&]() {
+    const long long simds = (long long)p->n_cu * 4;
+    const long long lane_waves = spg > 0 ? (n_problems / spg) * ((spg + 63) / 64) : (n_problems + 63) / 64;
+    const long long quad_waves = (n_problems + 15) / 16;
+    const long long lane_rounds = (lane_waves + simds - 1) / simds, quad_rounds = (quad_waves + simds - 1) / simds;
+    return 26 * lane_rounds < 19 * quad_rounds + 3;  // us per round of either kernel, measured on C2 / C4 shapes
+  };
   bool use_lane = p->lane_fn_u != nullptr && use_quad && opts->predictor == 0 && p->quad_trace == nullptr &&
-                  (opts->kernel == 4 || (opts->kernel == 0 && n_problems >= p->lane_min_problems));
+                  (opts->kernel == 4 || (opts->kernel == 0 && n_problems >= p->lane_min_problems && lane_pays()));
   bool lane_auto_cold = false;  // chain_len = -1 resolved to independent solves on the lane kernel
   if (use_lane && opts->kernel == 0) {
     const long long span0 = spg > 0 ? spg : n_problems;

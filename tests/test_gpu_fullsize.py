@@ -74,7 +74,7 @@ def test_c4_macpherson_512x512_grid():
     assert float((alone - res.positions[pick]).abs().max()) <= 1e-9
     _oracle_sample(program, targets, pos)
     # quad kernel: chains of 16 (one per resident quad), about one full pass and a confirmation per solve.  The lane kernel
-    # (auto selection from 65536 problems on) holds four times as many problems at once, so its chains are 4 steps long and
+    # (auto selection beyond one round of the quad kernel) holds four times as many problems at once, so its chains are 4 steps long and
     # the cold head weighs more - and it is still the faster launch (bench.py other_configs).
     assert info["nfev"].mean() <= (3.4 if dp.lane_bodies & 2 else 2.6)
     quad = dp.solve(t, chain_len=-1, kernel="quad")

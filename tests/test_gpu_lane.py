@@ -158,8 +158,9 @@ def test_lane_reports_infeasible_targets_like_the_quad_kernel(golden):
 
 
 def test_auto_selection_uses_the_lane_kernel_for_batches_that_fill_the_chip(golden):
-    """From lane_threshold problems on (one 64-problem wavefront per SIMD) auto selection takes the lane kernel's
-    independent-solve body; below it the quad kernel.  Same answers either way."""
+    """From lane_threshold problems on (one more than a single round of the quad kernel holds) auto selection takes the
+    lane kernel's independent-solve body; below it the quad kernel.  Same answers either way.  An ensemble with a handful
+    of steps per geometry stays with the quad kernel: a lane wave unit holds problems of one geometry."""
     from open_kinematics_amd.workloads import macpherson_grid_problem
 
     program, targets = macpherson_grid_problem(272, 272)  # 73984 problems: not a multiple of 64 x anything neat
@@ -176,3 +177,15 @@ def test_auto_selection_uses_the_lane_kernel_for_batches_that_fill_the_chip(gold
     assert torch.equal(auto.positions, lane.positions), "auto did not take the lane kernel"
     small = dp.solve(t[:4096], chain_len=1, predictor=False)
     assert torch.equal(small.positions, dp.solve(t[:4096], chain_len=1, predictor=False, kernel="quad").positions)
+    assert dp.lane_threshold == 4 * torch.cuda.get_device_properties(0).multi_processor_count * 16 + 1
+    mid = t[: dp.lane_threshold + 1000]   # a second round of the quad kernel, a part-filled round of the lane kernel
+    assert torch.equal(dp.solve(mid, chain_len=1, predictor=False).positions, dp.solve(mid, chain_len=1, predictor=False, kernel="lane").positions)
+    # 4096 geometries x 8 steps: 32768 problems, but 8 of 64 lanes per wave unit -> the quad kernel
+    from open_kinematics_amd.workloads import ensemble_problem
+
+    eprog, table, rel = ensemble_problem(4096, 8)
+    edp = _dp(eprog)
+    gpos, gparam = edp.rebind(torch.as_tensor(table, device="cuda:0"))
+    et = edp.ensemble_targets(gpos, rel)
+    kw = dict(geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=8, chain_len=1, predictor=False)
+    assert torch.equal(edp.solve(et, **kw).positions, edp.solve(et, kernel="quad", **kw).positions)
