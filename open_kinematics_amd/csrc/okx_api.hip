@@ -354,13 +354,18 @@ void attach_lane_kernel(okx_program* p) {
     return;
   }
   // A body that spills is only worth having while the spill is small.  Measured on MI355X: the double wishbone's
-  // independent-solve body (104 - 192 B of scratch) is still 1.8x the quad kernel on 4096 geometries x 256 steps, its chain
-  // body (668 B) is 8 % slower than the quad kernel's chains; MacPherson (0 B) wins both ways.
+  // independent-solve body (104 - 192 B of scratch) is still 1.8x the quad kernel on 4096 geometries x 256 steps, its
+  // looping chain body (668 B) was 8 % slower than the quad kernel's chains; MacPherson (0 B) wins both ways.
   p->lane_cold_scratch = okx::quad_code_scratch_bytes(code, "okx_lane_solve");
   p->lane_chain_scratch = okx::quad_code_scratch_bytes(code, "okx_lane_chain");
   const bool any = getenv("OKX_LANE_ALLOW_SCRATCH") != nullptr;
   p->lane_cold_ok = p->lane_cold_scratch >= 0 && (any || p->lane_cold_scratch <= 256);
-  p->lane_chain_ok = p->lane_chain_scratch >= 0 && (any || p->lane_chain_scratch == 0);
+  // ... and a flat chain body (okx_quad.hpp lane_chain_is_flat: the double wishbone; 0 B of scratch) is correct but does not
+  // pay: each chain step repeats the independent solve's prologue and its records leave lane by lane, so 4096 x 256 in
+  // chains of 4 takes 0.62 ms against 0.51 ms of independent solves, and a 1048576-step sweep of one geometry 0.47
+  // against 0.43 ms although its evaluations drop from 2.97 to 1.53 (tools/lane_chain_modes.py, lane_chain_own.py).
+  // Auto selection keeps resolving chain_len = -1 to independent solves there; kernel = 4 with chains runs it.
+  p->lane_chain_ok = p->lane_chain_scratch >= 0 && (any || (p->lane_chain_scratch == 0 && !okx::lane_chain_is_flat(p->host.n)));
   if (!p->lane_cold_ok && !p->lane_chain_ok) {
     std::snprintf(p->lane_note, sizeof(p->lane_note), "the lane kernel of this program spills (%d / %d B of scratch): not used",
                   p->lane_cold_scratch, p->lane_chain_scratch);
@@ -841,7 +846,15 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
       const int lane_grid = (int)(lane_units < lane_cap ? (lane_units < 1 ? 1 : lane_units) : lane_cap);
       hipFunction_t fn = a.chain_len == 1 ? (d_geom_pos ? p->lane_fn_g : p->lane_fn_u) : (d_geom_pos ? p->lane_chain_g : p->lane_chain_u);
       if (opts->output != OKX_OUTPUT_RECORDS) fn = p->lane_compact[(a.chain_len == 1 ? 0 : 2) + (d_geom_pos ? 1 : 0)];
+      void* ring = nullptr;
+      if (a.chain_len != 1 && okx::lane_chain_is_flat(p->host.n)) {
+        // what a flat chain body carries from step to step (okx_quad.hpp lane_chain_is_flat): scratch of this launch,
+        // allocated and freed in stream order (legal under stream capture, no device-wide synchronisation)
+        HIP_TRY(hipMallocAsync(&ring, sizeof(double) * (size_t)okx::lane_flat_chain_doubles(p->host.n) * (size_t)lane_grid, (hipStream_t)stream));
+        q.predictor = static_cast<const double*>(ring);
+      }
       HIP_TRY(hipModuleLaunchKernel(fn, lane_grid, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
+      if (ring) HIP_TRY(hipFreeAsync(ring, (hipStream_t)stream));
       return OKX_OK;
     }
     const long long wave_units = (units + p->quad_ppw - 1) / p->quad_ppw;

@@ -1098,6 +1098,11 @@ DEV double unpark(int lo, int hi) {
 
 int lane_variant_count() { return 8; }
 
+bool lane_chain_is_flat(int n_vars) {
+  if (const char* env = getenv("OKX_LANE_FLAT_CHAIN")) return env[0] == '1';
+  return 80 - 4 * n_vars < 16;  // fewer than 16 of the 80 LDS slots left for the factor's rows beside x, dx, xp, xq
+}
+
 bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant) {
   // Emission variants: the same arithmetic in the same order, differing only in hints to the compiler (opaque uses after
   // each row, a redefinition of the factorisation's inputs at its top, where the scheduling barriers of the factorisation
@@ -1267,7 +1272,10 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // chain loop, no history, 36 LDS slots.  CHAIN: consecutive problems of a lane form a chain with secant / quadratic
   // extrapolation: the history xp / xq takes another 36 slots.
   std::string lds_why;
-  auto body = [&](bool ch) -> bool {
+  const bool flat_chain = lane_chain_is_flat(n);
+  // `ch`: the chain loop inside the body, history in LDS.  `fl` (flat chain, see okx_quad.hpp lane_chain_is_flat): the
+  // independent-solve body walked over (wave unit, chain step) pairs, chain state in the launch's global scratch.
+  auto body = [&](bool ch, bool fl) -> bool {
     int n_slots = 0;
     auto slot_ref = [&](const std::string& name) { return "double& " + name + " = lds[" + std::to_string(64 * n_slots++) + " + lane];"; };
     std::string state_decl;
@@ -1279,7 +1287,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     const int state_doubles_before_l = 64 * n_slots;  // x, dx (and the chain history): live from the prologue on
     if (!ch) n_slots = evc.l_lds_base + evc.l_lds_slots > n_slots + (int)evc.j_home.size() ? evc.l_lds_base + evc.l_lds_slots : n_slots + (int)evc.j_home.size();  // + the rows' gradients / the factor's first rows
     const int state_doubles = 64 * n_slots;
-    const int stage_doubles = ch ? 0 : 64 * 3 * P.n_out;
+    const int stage_doubles = ch || fl ? 0 : 64 * 3 * P.n_out;
     int lds_doubles = state_doubles > stage_doubles ? state_doubles : stage_doubles;
     // the first-step table of the wave unit's geometry is staged behind the state (the area the factor's rows are parked
     // in later): the prologue's 100-odd table reads are LDS broadcasts instead of same-address global loads
@@ -1290,12 +1298,12 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       return false;
     }
     auto mark = [&](int k) {
-      if (marks && !ch) g.f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + k);
+      if (marks && !ch && !fl) g.f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + k);
     };
     // FULL: the kernel that writes full records (okx_solve_opts.output = 0) is compiled on its own, exactly as it was
     // before the compact outputs existed: the register allocator's result for the double wishbone is that fragile
     // (the same body with the output mode as a run-time switch: 0 -> 248 B of scratch).
-    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a) {", ch ? "chain" : "cold");
+    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a) {", ch || fl ? "chain" : "cold");
     g.f("  const int lane = threadIdx.x;");
     g.f("  __shared__ double lds[%d];", lds_doubles);
     g.f("  __shared__ double gl[%d];  // the wave unit's geometry tables: positions, row parameters, derived-op parameters", gl_size);
@@ -1303,7 +1311,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("  const long long spg = a.steps_per_geometry;");
     g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
     g.f("  const long long n_spans = spg > 0 ? a.n_problems / span : 1;");
-    if (ch) {
+    if (ch || fl) {
       g.f("  const long long unit_len = a.chain_len;");
       g.f("  const long long chains_per_span = (span + unit_len - 1) / unit_len;");
     } else {
@@ -1312,6 +1320,17 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     }
     g.f("  const long long waves_per_span = (chains_per_span + 63) / 64;");
     g.f("  const long long n_wave_units = n_spans * waves_per_span;");
+    if (fl) {
+      // every wavefront owns a contiguous block of wave units and walks (wave unit, step) pairs in order: the steps of a
+      // lane's chain are consecutive iterations of ONE loop whose body carries nothing from one iteration to the next
+      g.f("  const long long wu_per_wave = (n_wave_units + gridDim.x - 1) / gridDim.x;");
+      g.f("  const long long wu_lo = blockIdx.x * wu_per_wave, wu_hi = wu_lo + wu_per_wave < n_wave_units ? wu_lo + wu_per_wave : n_wave_units;");
+      g.f("  double* const ring = const_cast<double*>(a.predictor) + (long long)blockIdx.x * %lld + lane;  // [entry][slot][lane]", lane_flat_chain_doubles(n));
+      g.f("  long long staged_span = -1;");
+      g.f("  for (long long it = wu_lo * unit_len; it < wu_hi * unit_len; ++it) {");
+      g.f("    const long long wu = uni64(it / unit_len);");
+      g.f("    const int step = (int)uni64(it - wu * unit_len);  // wave-uniform: every lane of the wave unit is at this step of its chain");
+    } else
     g.f("  for (long long wu = blockIdx.x; wu < n_wave_units; wu += gridDim.x) {");
     // (the 64-bit division runs on the vector ALU; its result goes to scalar registers so that every table address
     //  derived from it is scalar arithmetic, not a pair of vector registers kept alive through the solve)
@@ -1321,18 +1340,28 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("    const bool have = chain_in_span < chains_per_span;");
     g.f("    if (!have) chain_in_span = chains_per_span - 1;");
     g.f("    const long long first_b = span_idx * span + chain_in_span * unit_len;");
-    if (ch) g.f("    const long long last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
+    if (ch || fl) g.f("    const long long last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
     g.f("    const double* gp = PG ? a.geom_pos + span_idx * %d : a.design_pos;", 3 * NP);
     g.f("    const double* gq = PG ? a.geom_row_param + span_idx * %d : a.row_param;", 8 * P.n_crows);
     g.f("    (void)gq;");
     if (ch)
       for (int t = 0; t < T; ++t) g.f("    double tn%d = a.targets[first_b * %d + %d], tp%d = 0.0, tq%d = 0.0, tr%d = 0.0;", t, T, t, t, t, t);
-    else
+    else if (fl) {
+      g.f("    const bool valid = have && first_b + step < last_b;");
+      g.f("    const long long bb = valid ? first_b + step : last_b - 1;");
+      for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[bb * %d + %d];", t, T, t);
+    } else
       for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[first_b * %d + %d];", t, T, t);
     g.f("    // the geometry's tables (and its first-step table) into LDS, lane k fetching entry k");
     g.f("    __syncthreads();  // (the previous wave unit's last reads of these areas are done)");
+    if (fl) {
+      g.f("    if (span_idx != staged_span) {  // wave-uniform: the tables stay while the geometry does");
+      stage_tables(g, "      ");
+      g.f("      staged_span = span_idx;");
+      g.f("    }");
+    } else
     stage_tables(g, "    ");
-    g.f("    const bool with_head = a.head != nullptr && a.grad_tol <= 0.0;");
+    g.f("    const bool with_head = a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
     g.f("    if (with_head) {");
     g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
     g.f("      for (int k = lane; k < %d; k += 64) lds[%d + k] = hp[k];", head_stride, head_l0);
@@ -1422,6 +1451,46 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      } else {");
       for (int i = 0; i < n; ++i) g.f("        { const double xo = x%d; xq%d = xp%d; xp%d = xo; }", i, i, i, i);
       g.f("      }");
+    } else if (fl) {
+      // Start of a chain step: from the ring of this lane's chain - the last three steps' solutions, whether each
+      // converged, the damping the last one ended with - exactly what the looping chain body keeps in x / xp / xq, hist
+      // and lambda_carry (the design state stands in for solutions the chain does not have yet; a predecessor that did
+      // not converge restarts the chain from the design state).
+      const int E = (n + 2) * 64;
+      g.f("    {");
+      for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
+      g.f("      double lambda_carry = 0.0;");
+      g.f("      if (step > 0) {");
+      g.f("        const double* r1 = ring + ((step + 2) %% 3) * %d;", E);
+      g.f("        const double* r2 = ring + ((step + 1) %% 3) * %d;", E);
+      g.f("        const double* r3 = ring + (step %% 3) * %d;", E);
+      g.f("        const bool ok1 = r1[%d] > 0.5, ok2 = ok1 && step >= 2 && r2[%d] > 0.5, ok3 = ok2 && step >= 3 && r3[%d] > 0.5;", 64 * n, 64 * n, 64 * n);
+      g.f("        if (ok1) {");
+      g.f("          lambda_carry = r1[%d];", 64 * (n + 1));
+      g.f("          const long long b2 = step >= 2 ? bb - 2 : bb, b3 = step >= 3 ? bb - 3 : bb;");
+      for (int t = 0; t < T; ++t)
+        g.f("          const double tp%d = a.targets[(bb - 1) * %d + %d], tq%d = ok2 ? a.targets[b2 * %d + %d] : td%d, tr%d = ok3 ? a.targets[b3 * %d + %d] : td%d;",
+            t, T, t, t, T, t, t, t, T, t, t);
+      g.f("          double num = 0.0, den = 0.0, nn = 0.0, num2 = 0.0, den2 = 0.0;");
+      for (int t = 0; t < T; ++t) {
+        g.f("          { const double dn = tv%d - tp%d, dold = tp%d - tq%d, dolder = tq%d - tr%d;", t, t, t, t, t, t);
+        g.f("            num = fma(dn, dold, num); den = fma(dold, dold, den); nn = fma(dn, dn, nn);");
+        g.f("            num2 = fma(dold, dolder, num2); den2 = fma(dolder, dolder, den2); }");
+      }
+      g.f("          double alpha = den > 0.0 ? num * fast_rcp(den) : 0.0;");
+      g.f("          alpha = fmin(fmax(alpha, 0.0), 2.0);");
+      g.f("          const double beta = den2 > 0.0 ? num2 * fast_rcp(den2) : 0.0;");
+      g.f("          const bool line = ok2 && alpha > 0.0 && beta >= 1e-3 && beta <= 2.0 && num * num >= 0.98 * nn * den && num2 * num2 >= 0.98 * den * den2;");
+      g.f("          const double bq = line ? fast_rcp(beta) : 1.0;");
+      g.f("          const double r1q = fast_rcp(1.0 + bq);");
+      g.f("          const double l0 = line ? (alpha + 1.0) * (alpha + 1.0 + bq) * r1q : 1.0 + alpha;");
+      g.f("          const double l1 = line ? -alpha * (alpha + 1.0 + bq) * beta : -alpha;");
+      g.f("          const double l2 = line ? alpha * (alpha + 1.0) * r1q * beta : 0.0;");
+      for (int i = 0; i < n; ++i)
+        g.f("          { const double xd = x%d, xo = r1[%d], xpo = ok2 ? r2[%d] : xd, xqo = ok3 ? r3[%d] : xd; x%d = fma(l0, xo, fma(l1, xpo, l2 * xqo)); }",
+            i, 64 * i, 64 * i, 64 * i, i);
+      g.f("        }");
+      g.f("      }");
     } else {
       g.f("    {");
       g.f("      const bool valid = have;");
@@ -1500,7 +1569,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     }
     mark(1);
     for (int i = 0; i < n; ++i) g.f("    %s = mode == 2 ? x%d : x%d + dx%d;", PF(i).c_str(), i, i, i);
-    g.out += (ch ? pass_chain : pass_cold).eval;
+    g.out += (ch ? pass_chain : pass_cold).eval;  // (the flat chain body runs the independent-solve body's pass)
     mark(2);
     g.f("    const double Ft = 0.5 * ss;");
     g.f("    bool accept = true, stop = false, compromise = false;");
@@ -1540,7 +1609,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("        if (!stop) {");
     g.f("          if (mode == 0) {");
     g.f("            dmax = diag; lambda = a.lambda0 * dmax;");
-    if (ch) g.f("            if (lambda_carry > 0.0) lambda = fmin(lambda, lambda_carry);");
+    if (ch || fl) g.f("            if (lambda_carry > 0.0) lambda = fmin(lambda, lambda_carry);");
     g.f("          }");
     g.f("          else if (mode == 1 && rho > 1e-4) {");
     g.f("            const double t = 2.0 * rho - 1.0;");
@@ -1613,12 +1682,17 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      lambda_carry = lambda;");
       g.f("    }");
     }
+    if (fl) {
+      g.f("    { double* r0 = ring + (step %% 3) * %d;  // this step's entry: solution, converged?, damping", (n + 2) * 64);
+      for (int i = 0; i < n; ++i) g.f("      r0[%d] = x%d;", 64 * i, i);
+      g.f("      r0[%d] = ((flags & INFO_CONVERGED) && !(flags & INFO_FAILED)) ? 1.0 : 0.0; r0[%d] = lambda; }", 64 * n, 64 * (n + 1));
+    }
     g.f("    if (valid) {");
     g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
     g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
     g.f("      a.info[bb] = inf;");
     g.f("    }");
-    if (!ch) {
+    if (!ch && !fl) {
       // Records of independent solves: the 64 problems of a wave unit are consecutive, their records one contiguous
       // block: transposed through LDS (which the state no longer needs) and written as full 16-byte-per-lane rows.
       // (okx_solve_opts.output: the full record, the free points alone in the program's free_point order, or nothing)
@@ -1666,7 +1740,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("");
     return true;
   };
-  if (!body(false) || !body(true)) {
+  if (!body(false, false) || !(flat_chain ? body(false, true) : body(true, false))) {
     *why = lds_why;
     return false;
   }

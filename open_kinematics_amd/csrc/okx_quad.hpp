@@ -130,6 +130,14 @@ bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, st
 // okx_lane_eval (QuadEvalArgs).  Returns false (and says why) when the program does not fit one lane's registers.
 // `variant` in [0, lane_variant_count()): the same arithmetic with other hints to the compiler (see lane_build).
 bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant = 0);
+// How the lane kernel walks chains.  While x, dx and the chain history (two previous solutions) leave at least 16 of the
+// 80 LDS slots to the factor's parked rows, a lane keeps its chain in LDS and loops over its steps (MacPherson: 60 + 20).
+// Otherwise (double wishbone: 72 + 8) the chain body IS the independent-solve body in one flat loop over
+// (wave unit, chain step), and everything a chain carries from step to step - the last three solutions, whether they
+// converged, the damping - lives in a per-launch global scratch of lane_flat_chain_doubles() per wavefront, passed in
+// QuadArgs.predictor (the lane kernel has no fitted model).  OKX_LANE_FLAT_CHAIN=0/1 forces either.
+bool lane_chain_is_flat(int n_vars);
+inline long long lane_flat_chain_doubles(int n_vars) { return 3LL * (n_vars + 2) * 64; }
 int lane_variant_count();
 // lane_generate + quad_compile over the emission variants: keeps the first variant whose independent-solve bodies
 // (okx_lane_solve_*) do not spill, else the one that spills least.  The choice is remembered next to the code objects
