@@ -492,7 +492,7 @@ def measure_e2e_zero_copy(dp, targets_host: np.ndarray, device, steps: int, cold
     for _, h_free, h_info in buffers:
         stream = torch.cuda.Stream(device)
         with torch.cuda.stream(stream):
-            launch = dp.plan(h_t, out=h_free, info_out=h_info, output="free", **cold_kw)
+            launch = dp.plan(h_t, out=h_free, info_out=h_info, output="free", zero_copy=True, **cold_kw)
         slots.append(dict(stream=stream, launch=launch, h_free=h_free, h_info=h_info, done=torch.cuda.Event()))
 
     def issue(slot):
@@ -683,6 +683,8 @@ def main() -> None:
     ap.add_argument("--config", choices=("c2", "c5"), default="c2",
                     help="c2: BASELINE config 2, weak scaling (default, the headline); c5: BASELINE config 5, 4096 perturbed "
                          "geometries x 256 steps, geometry-major shards (strong scaling)")
+    ap.add_argument("--preheat-ms", type=float, default=40.0,
+                    help="milliseconds of untimed launches ahead of the warm-up steps (GPU clocks leave their idle state); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip with_model / e2e / other_configs / dropin (what the profiling runs use)")
@@ -766,9 +768,22 @@ def self_launch(n_ranks: int, argv: list, dry: bool = False) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_launch_events: bool):
+def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_launch_events: bool, preheat_ms: float = 0.0):
     """The contract's timed region: W warm-up steps, barrier + synchronize, K steps, synchronize + barrier, MAX over
-    ranks.  `step(k, start_event, end_event)` records the events around its solve launch when they are given."""
+    ranks.  `step(k, start_event, end_event)` records the events around its solve launch when they are given.
+    `preheat_ms` > 0: the same step is launched for that long ahead of the W warm-up steps (reported in the line as
+    `preheat`): a GPU that has been idle runs its first few milliseconds of kernels at reduced clocks - 20 steps after 5
+    warm-up steps measured 8 % slower than the same kernel after 11 ms of launches (profiles/r03/EXPERIMENTS.md section 10)."""
+    preheat_steps = 0
+    if preheat_ms > 0.0:
+        torch.cuda.synchronize(device)
+        t_end = time.perf_counter() + preheat_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(32):
+                step(preheat_steps, None, None)
+                preheat_steps += 1
+        drain()
+    timed_region.preheat_steps = preheat_steps
     for k in range(warmup):
         step(k, None, None)
     drain()
@@ -819,12 +834,13 @@ def run_c2(args, world: int, rank: int, device) -> dict:
     # Two output slots: with N > 1 ranks the all-gather of step k (RCCL stream) overlaps the solve of step k + 1
     # (launch stream), dist.GatherPipeline.  The exchange ships the free coordinates of each solve (144 B) and every
     # rank rebuilds the full positions (360 B) itself (dist.FreeGatherPipeline / okx_expand_positions_batch).
-    pipe = FreeGatherPipeline(hi - lo, program.n_out, dp.free_out_index, dp.expand, torch.float64, device,
+    pipe = FreeGatherPipeline(hi - lo, program.n_out, program.n_free, dp.expand, torch.float64, device,
                               collective_at_world_one=args.rccl_world_one)
     use_model = args.start == "model" and bool(dp.fit_predictor(targets))
     cold_kw = dict(chain_len=args.chain_len, predictor=use_model)
     # pre-bound launches: per step the host only makes the C-ABI call
-    launches = [dp.plan(targets, out=buf, info_out=info, **cold_kw) for buf in pipe.local]
+    # (with an exchange the solve writes the free coordinates - the payload - straight into the send buffer)
+    launches = [dp.plan(targets, out=buf, info_out=info, output=pipe.output, **cold_kw) for buf in pipe.solve_buffers]
 
     def step(k, start, end):
         pipe.begin(k)
@@ -839,12 +855,15 @@ def run_c2(args, world: int, rank: int, device) -> dict:
     # per-launch pairs would add two stream markers per ~30 us kernel).  Several ranks: per-launch pairs, so the
     # exchange between launches is excluded from the kernel time.
     exchanging = world > 1 or args.rccl_world_one
-    elapsed, kernel_ms = timed_region(step, pipe.drain, args.steps, args.warmup, world, device, per_launch_events=exchanging)
+    elapsed, kernel_ms = timed_region(step, pipe.drain, args.steps, args.warmup, world, device, per_launch_events=exchanging,
+                                      preheat_ms=args.preheat_ms)
+    preheat_steps = timed_region.preheat_steps
     if args.rccl_world_one:
         # the gathered + expanded block of the last step must be the locally solved one, bit for bit
         gathered = pipe.drain()
-        if not torch.equal(gathered, pipe.local[pipe.last]):
-            raise SystemExit("rccl-world-one: the gathered and re-expanded positions differ from the solved ones")
+        records = dp.solve(targets, **cold_kw).positions
+        if not torch.equal(gathered, records):
+            raise SystemExit("rccl-world-one: the gathered and re-expanded positions differ from the solver's own records")
     nfev_mean, ok = info_summary(info)
     if rank != 0:
         return {}
@@ -863,6 +882,9 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "preheat": {"ms": args.preheat_ms, "steps": preheat_steps,
+                    "note": "untimed launches of the same step ahead of the W warm-up steps, so that the K timed steps run at the "
+                            "clocks of a GPU under load rather than of one leaving idle (--preheat-ms 0 switches it off)"},
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
@@ -906,7 +928,8 @@ def run_c2(args, world: int, rank: int, device) -> dict:
             "traffic_source": traffic_src,
             "traffic_measured_in_this_run": False if traffic is not None else None,
             "kernel": ("okx_lane_solve_u" if 0 < dp.lane_threshold <= (hi - lo) and (dp.lane_bodies & 1) else
-                       "okx_quad_solve_u" if dp.kernel == "quad" else "okx_solve_kernel"),
+                       ("okx_quad_cold_u" if dp.has_cold_body and not use_model and args.chain_len in (-1, 1) else "okx_quad_solve_u")
+                       if dp.kernel == "quad" else "okx_solve_kernel"),
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_solve": bytes_per_solve,
             "note": "HBM is the bound north_star states and frac is reported against it, but at 392 B per solve the path is "
@@ -952,7 +975,7 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["one_shot"] = measure_one_shot(program, targets, device, kernel_ms)
     if world == 1 and not args.no_extras and not args.rccl_world_one:
         extra_steps = max(5, min(args.steps, 50))
-        own = dp.plan(targets, out=pipe.local[0], info_out=info, chain_len=args.chain_len, predictor=False, shared_first_step=False)
+        own = dp.plan(targets, out=pipe.solve_buffers[0], info_out=info, chain_len=args.chain_len, predictor=False, shared_first_step=False)
         own_wall, own_ms = time_launches(own, args.steps, args.warmup, device)
         own_nfev, own_ok = info_summary(info)
         line["own_first_pass"] = {"value": (hi - lo) / own_wall, "kernel_ms": own_ms, "lm_evaluations_mean": own_nfev,
@@ -965,7 +988,7 @@ def run_c2(args, world: int, rank: int, device) -> dict:
                                                      dict(chain_len=args.chain_len, predictor=False))
         line["e2e"]["zero_copy"] = zero_copy
         from open_kinematics_amd.workloads import geometry_path
-        line["downstream"] = measure_downstream(dp, geometry_path("geometry.yaml"), pipe.local[0], device)
+        line["downstream"] = measure_downstream(dp, geometry_path("geometry.yaml"), pipe.solve_buffers[0], device)
         dp.close()
         line["other_configs"] = [
             measure_config("C3 rocker + U-bar axle, 256x256 heave x roll grid (n = 60, pair mode)",
@@ -1002,11 +1025,12 @@ def run_c5(args, world: int, rank: int, device) -> dict:
         torch.cuda.synchronize(device)
         rebind_ms = (time.perf_counter() - r0) * 1e3
     n_local, n_total = (ghi - glo) * spg, n_geom * spg
-    out = torch.empty((n_local, program.n_out, 3), dtype=torch.float64, device=device)
+    # N > 1: the solve writes the free coordinates - the exchange's payload - and every rank expands the gathered block;
+    # one rank: the records themselves
+    out = torch.empty((n_local, program.n_free if world > 1 else program.n_out, 3), dtype=torch.float64, device=device)
     info = torch.empty((n_local, 40), dtype=torch.uint8, device=device)
     launch = dp.plan(targets, out=out, info_out=info, chain_len=args.chain_len if args.chain_len != -1 else 1, predictor=False,
-                     geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=spg)
-    free_index = dp.free_out_index
+                     geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=spg, output="free" if world > 1 else "records")
     full = torch.empty((n_total, program.n_out, 3), dtype=torch.float64, device=device) if world > 1 else None
 
     def step(k, start, end):
@@ -1016,7 +1040,7 @@ def run_c5(args, world: int, rank: int, device) -> dict:
         if end is not None:
             end.record()
         if world > 1:
-            free_full = all_gather_rows(out.index_select(1, free_index), n_total, None, spans)
+            free_full = all_gather_rows(out, n_total, None, spans)
             dp.expand(free_full, out=full, geom_pos=gpos_all, steps_per_geometry=spg)
 
     elapsed, kernel_ms = timed_region(step, lambda: None, args.steps, args.warmup, world, device, per_launch_events=True)

@@ -526,6 +526,11 @@ const char* okx_program_kernel_note(const okx_program* prog);
  * table (okx_solve_opts.shared_first_step): okx_info.nfev of such a head does not count the design-state evaluation,
  * which was made once for all of them (the drop-in's SolverInfo.nfev adds it back, solver.py:766-771). */
 int32_t okx_program_shares_first_step(const okx_program* prog);
+/* 1 when launches of INDEPENDENT solves (chain length 1) on the program's own geometry with the shared first step run the
+ * quad kernel's cold body `okx_quad_cold_u` (no chain history, no fitted model, no trace: tables staged through LDS, the
+ * passes of an all-accepted solve under one exec mask, anything else redone through the general loop - same answers, bit
+ * for bit, as `okx_quad_solve_u`).  What bench.py names as the dominant kernel of the headline launch. */
+int32_t okx_program_has_cold_body(const okx_program* prog);
 
 /* Generated source of a program's quad kernel (no device needed).  Copies at most buflen - 1
  * bytes plus a terminator into buf (buf may be NULL) and returns the size the full text

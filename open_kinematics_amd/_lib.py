@@ -31,6 +31,7 @@ EXPORTS = (
     "okx_program_kernel",
     "okx_program_kernel_note",
     "okx_program_shares_first_step",
+    "okx_program_has_cold_body",
     "okx_quad_source",
     "okx_precompile",
     "okx_tangent_batch",
@@ -120,6 +121,8 @@ def load() -> C.CDLL:
     lib.okx_program_kernel_note.restype = C.c_char_p
     lib.okx_program_shares_first_step.argtypes = [vp]
     lib.okx_program_shares_first_step.restype = i32
+    lib.okx_program_has_cold_body.argtypes = [vp]
+    lib.okx_program_has_cold_body.restype = i32
     lib.okx_quad_source.argtypes = [C.POINTER(ProgramDesc), C.c_char_p, i64]
     lib.okx_quad_source.restype = i64
     lib.okx_precompile.argtypes = [C.POINTER(ProgramDesc)]

@@ -47,11 +47,27 @@ def _ptr(t: torch.Tensor | None) -> C.c_void_p:
 
 
 def _as_f64(t, device) -> torch.Tensor:
+    """A contiguous float64 tensor ON the device: always a snapshot of host data (synchronous copy), whatever its kind."""
     if not isinstance(t, torch.Tensor):
         t = torch.as_tensor(np.asarray(t, dtype=np.float64))
-    if not t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.is_pinned():
-        return t  # pinned host memory is device-accessible: the kernel reads it over PCIe, no copy (okx.h: d_* pointers)
     return t.to(device=device, dtype=torch.float64).contiguous()
+
+
+def _is_mapped_host(t) -> bool:
+    """A contiguous pinned host tensor: device-accessible memory, which ``okx.h`` accepts for its ``d_*`` pointers."""
+    return isinstance(t, torch.Tensor) and not t.is_cuda and t.is_contiguous() and t.is_pinned()
+
+
+def _check_buffer(name: str, t, device, zero_copy: bool) -> None:
+    """An output buffer of a launch must live where the kernel can write it: on the launch device, or - opted into with
+    ``zero_copy=True`` - in pinned host memory.  Pageable host memory would fault the GPU (XNACK is off)."""
+    if t is None or (t.is_cuda and t.device == device):
+        return
+    if zero_copy and _is_mapped_host(t):
+        return
+    raise ValueError(f"{name} must be a tensor on {device}" + (" or a contiguous pinned host tensor" if zero_copy else
+                     " (pinned host buffers are accepted with zero_copy=True)") + f", got {t.device}"
+                     + ("" if t.is_cuda or not t.is_pinned() else ", pinned"))
 
 
 class DeviceProgram:
@@ -89,6 +105,11 @@ class DeviceProgram:
     def shares_first_step(self) -> bool:
         """Chain heads of the own geometry take their first step from the shared first-step table (their ``nfev`` omits it)."""
         return bool(self.lib.okx_program_shares_first_step(self._handle))
+
+    @property
+    def has_cold_body(self) -> bool:
+        """Independent solves on the own geometry run the quad kernel's cold body (``okx_quad_cold_u``)."""
+        return bool(self.lib.okx_program_has_cold_body(self._handle))
 
     @property
     def lane_threshold(self) -> int:
@@ -142,6 +163,7 @@ class DeviceProgram:
         confirm_full_pass: bool | None = None,
         shared_first_step: bool | None = None,
         output: str = "records",
+        zero_copy: bool = False,
     ) -> BatchResult:
         """
         Solve ``B`` problems; ``targets`` is ``[B, T]`` of absolute target scalars.
@@ -162,12 +184,23 @@ class DeviceProgram:
         ``expand`` rebuilds the records, bit-identical) - what a PCIe link or an all-gather wants to carry; ``"none"``
         only the info records.  ``out`` is the buffer of whichever is written.
 
+        ``zero_copy=True``: ``targets``, ``out`` and ``info_out`` given as contiguous PINNED host tensors are handed to the
+        kernel as they are (``okx.h``: ``d_*`` pointers may be device-accessible host memory) - it reads the targets from
+        and stores its results into the caller's buffers over PCIe, no copy commands.  The caller then owns the
+        synchronisation: the buffers must stay untouched until the launch has completed on its stream.  Without the
+        flag host inputs are snapshotted by a synchronous copy and host output buffers are refused.
+
         ``chain_len`` groups consecutive problems into warm-started chains walked by one
         wavefront each (``1`` independent cold starts, ``-1`` one chain per resident wavefront,
         ``None`` follows ``chain``: whole-sweep chain or independent).
         """
         p = self.program
-        targets = _as_f64(targets, self.device).reshape(-1, max(p.n_targets, 1))
+        if zero_copy and _is_mapped_host(targets) and targets.dtype == torch.float64:
+            targets = targets.reshape(-1, max(p.n_targets, 1))  # read in place, over PCIe
+        else:
+            targets = _as_f64(targets, self.device).reshape(-1, max(p.n_targets, 1))
+        _check_buffer("out", out, self.device, zero_copy)
+        _check_buffer("info_out", info_out, self.device, zero_copy)
         b = targets.shape[0] if p.n_targets > 0 else int(targets.numel())
         opts = self.default_opts()
         opts.chain = 1 if chain else 0

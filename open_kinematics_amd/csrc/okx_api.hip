@@ -53,6 +53,7 @@ struct okx_program {
   long long predictor_len;  // doubles in it
   // shared first step of the chain heads (okx_quad_head_u/_g; null functions: not generated for this program)
   hipFunction_t quad_fn_head_u, quad_fn_head_g;
+  hipFunction_t quad_fn_cold_u;  // independent solves from the own geometry's design state with its first-step table (null: none)
   int head_stride;          // doubles per geometry in the table (okx::quad_head_stride)
   // own geometry's tables, one per lambda0 ever asked for (never overwritten: launches on other streams may still be
   // reading an older one); the default lambda0's is filled synchronously at okx_program_create, any other on first use on
@@ -214,7 +215,7 @@ int own_head_table(okx_program* p, double lambda0, hipStream_t stream, double** 
   okx_program::HeadTable t;
   t.lambda0 = lambda0;
   t.filled_on = stream;
-  HIP_TRY(hipMalloc((void**)&t.dev, sizeof(double) * (size_t)p->head_stride));
+  HIP_TRY(hipMalloc((void**)&t.dev, sizeof(double) * ((size_t)p->head_stride + 2)));  // (+ pad: the cold body reads the table in 16-byte pieces)
   if (hipEventCreateWithFlags(&t.ready, hipEventDisableTiming) != hipSuccess) {
     (void)hipFree(t.dev);
     return fail(OKX_ERR_DEVICE, "hipEventCreate failed");
@@ -248,6 +249,7 @@ int own_head_table(okx_program* p, double lambda0, hipStream_t stream, double** 
 void attach_quad_kernel(okx_program* p) {
   p->quad_mod = nullptr;
   p->quad_fn_u = p->quad_fn_g = nullptr;
+  p->quad_fn_cold_u = nullptr;
   p->quad_fn_eval = nullptr;
   p->quad_fn_expand = nullptr;
   p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
@@ -306,6 +308,7 @@ void attach_quad_kernel(okx_program* p) {
       hipModuleGetFunction(&p->quad_fn_tan_g, mod, "okx_quad_tangent_g") != hipSuccess)
     p->quad_fn_tan_u = p->quad_fn_tan_g = nullptr;
   p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
+  if (hipModuleGetFunction(&p->quad_fn_cold_u, mod, "okx_quad_cold_u") != hipSuccess) p->quad_fn_cold_u = nullptr;
   p->head_stride = okx::quad_head_stride(p->host);
   if (!(p->head_stride > 0 && hipModuleGetFunction(&p->quad_fn_head_u, mod, "okx_quad_head_u") == hipSuccess &&
         hipModuleGetFunction(&p->quad_fn_head_g, mod, "okx_quad_head_g") == hipSuccess))
@@ -557,6 +560,7 @@ const char* okx_program_kernel_note(const okx_program* p) { return p ? p->quad_n
 /* 1 when chain heads of this program's own geometry take their first step from the shared first-step table
    (okx_solve_opts.shared_first_step with a generated head kernel): their okx_info.nfev then omits that evaluation. */
 int32_t okx_program_shares_first_step(const okx_program* p) { return p && p->quad_fn_head_u ? 1 : 0; }
+int32_t okx_program_has_cold_body(const okx_program* p) { return p && p->quad_fn_cold_u && p->quad_fn_head_u ? 1 : 0; }
 
 /* Why the program has no lane kernel (empty string: it has one), and the batch size from which auto selection uses it. */
 const char* okx_program_lane_note(const okx_program* p) { return p ? p->lane_note : ""; }
@@ -860,8 +864,13 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     const long long wave_units = (units + p->quad_ppw - 1) / p->quad_ppw;
     const long long cap = (long long)p->n_cu * p->quad_waves_per_cu;
     const int grid = (int)(wave_units < cap ? (wave_units < 1 ? 1 : wave_units) : cap);
-    HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->quad_fn_g : p->quad_fn_u, grid, 1, 1, okx::kWave, 1, 1, 0,
-                                  (hipStream_t)stream, kargs, nullptr));
+    hipFunction_t fn = d_geom_pos ? p->quad_fn_g : p->quad_fn_u;
+    // independent solves from the own geometry's design state with its first-step table and nothing the general body
+    // alone offers (fitted model, LM trace, gradient stop): the cold body
+    if (p->quad_fn_cold_u && !d_geom_pos && a.chain_len == 1 && q.head != nullptr && q.predictor == nullptr && (q.trace == nullptr || getenv("OKX_QUAD_TIMELINE")) &&
+        opts->grad_tol <= 0.0 && !getenv("OKX_QUAD_NO_COLD"))
+      fn = p->quad_fn_cold_u;
+    HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
     return OKX_OK;
   }
   if (opts->output != OKX_OUTPUT_RECORDS)

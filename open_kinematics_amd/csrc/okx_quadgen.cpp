@@ -694,7 +694,7 @@ class Gen {
         if (comp == 0) {
           // reported as the reference's single softnorm residual (constraints.py:560-576)
           std::string c2 = dot(cv, cv);
-          ro->absres = "fabs(sqrt(" + c2 + " + EPS_SQ) - EPS)";
+          ro->absres = "fabs(lean_sqrt(" + c2 + " + EPS_SQ) - EPS)";  // (a reported quantity: 2^-48 is plenty, an IEEE sqrt is ~20 instructions)
         } else {
           ro->absres.clear();
         }
@@ -790,8 +790,10 @@ class Gen {
   // OKX_QUAD_MARK=1: `s_nop 11..17` between the sections of a pass (tools/quad_sections.py counts the instructions
   // in between; scheduling barriers keep the sections apart, so the marked kernel is for counting, not for timing)
   bool marks = false;
+  bool tl_marks = false;  // OKX_QUAD_TIMELINE=1: section stamps inside a pass (OKX_TL is defined per kernel body)
   void mark(int n) {
     if (marks) f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + n);
+    if (tl_marks && n >= 5) f("    OKX_TL(%d)", n);
   }
   // jtv_rhs non-empty: only J^T v is formed, for every listed right-hand side q (v_i = the variable {q}{i}, result
   // {q}g{F}): the second Jacobian pass of the first-step table's second-order terms (okx_quad_head_*).
@@ -1144,6 +1146,12 @@ DEV void fast_sqrt_rsqrt(double x, double* root, double* inv) {
   *root = g;
   *inv = h + h;
 }
+// sqrt(x), x > 0 and normal, to ~2^-48: one Goldschmidt step (values that are only reported).
+DEV double lean_sqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double g = x * y, h = 0.5 * y;
+  return fma(g, fma(-h, g, 0.5), g);
+}
 // atan2(y, x), y >= 0, result in [0, pi]: fdlibm-style reduction + odd polynomial (see okx_kernels.hip).
 // In the register-bound pair kernels (TAB) the eleven polynomial coefficients are READ WHERE THEY ARE USED, from a table in LDS (`tab`, filled once per
 // workgroup from kAtanCoef; every lane reads the same address: a broadcast), through an index the optimiser cannot see
@@ -1242,6 +1250,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   if (const char* env = getenv(pv ? "OKX_PAIR_COL_FENCE" : "OKX_QUAD_COL_FENCE")) ev.col_fence = atoi(env);
   ev.pin_ata = ev.pin_atr = getenv("OKX_QUAD_NO_PIN") == nullptr;  // (experiment switch)
   ev.marks = getenv("OKX_QUAD_MARK") != nullptr;
+  ev.tl_marks = !pv && getenv("OKX_QUAD_TIMELINE") != nullptr;
   for (int e = 0; e < P.n_derived; ++e) ev.dp(e);  // every derived-op parameter is chain-constant
   ev.f("    // ---- active derived points with chain-rule blocks ----");
   for (int idx = 0; idx < P.n_active; ++idx)
@@ -1249,10 +1258,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       *why = ev.why;
       return false;
     }
+  ev.mark(8);  // (derived points done)
   if (!ev.emit_rows()) {
     *why = ev.why;
     return false;
   }
+  ev.mark(9);  // (rows done)
   std::string eval_src = ev.out;
   ev.out.clear();
   ev.emit_solve();
@@ -1504,6 +1515,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int k = 0; k < nf; ++k) used[P.free_point[k]] = true;
 
   g.out += kPreamble;
+  if (ev.tl_marks) g.f("#define OKX_TL(k)");
   g.f("");
   if (pv) {
     g.f("// Two quads own one problem: `xq` reads the other quad's lane with the same component");
@@ -1533,18 +1545,82 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("#define PJOIN_SUM(v) (v)");
   }
   g.f("");
-  g.f("template <bool PG> DEV void okx_quad_body(const QArgs& a) {");
+  // The solve body is emitted twice in single mode: the general one (chains, fitted model, trace) and a COLD one for
+  // launches of independent solves from the design state with a first-step table (chain_len 1: the headline shape) -
+  // no chain history, no model, no trace, the first step applied from registers.  Same passes, same answers.
+  const std::string lds_decl =
+      "  const int qs = lane >> 2;  // quad(-side) slot of this lane inside the wavefront\n"
+      "  __shared__ double hsl[" + std::to_string(16 * (ev.n_scalar_slots + 1)) + "];  // chain-constant scalars [slot][quad]\n"
+      "  __shared__ double hql[" + std::to_string(64 * (ev.n_lane_slots + 1)) + "];  // chain-constant lane components [slot][lane]\n";
+  std::string final_src;
+  bool body_failed = false;
+  auto emit_body = [&](const bool CD) {
+  const bool tl_body = CD && ev.tl_marks;
+  if (tl_body)  // sections of the SECOND full pass of a wavefront go to a second table behind the first: a.trace[16 (waves + w) + k]
+    g.f("#undef OKX_TL\n#define OKX_TL(k) if (a.trace && tl_pass == 4 && (threadIdx.x & 63) == 0) a.trace[(gridDim.x + blockIdx.x) * 16 + (k)] = (double)__builtin_readcyclecounter();");
+  if (CD) {
+    g.f("DEV void okx_quad_cold_body(const QArgs& a) {");
+    g.f("  constexpr bool PG = false;  // the program's own geometry only (per-geometry tables differ from quad to quad)");
+  } else {
+    g.f("template <bool PG> DEV void okx_quad_body(const QArgs& a) {");
+  }
+  // (developer build, OKX_QUAD_TIMELINE=1: wavefront w stamps the shader clock into a.trace[16 w + k] - 0 entry, 1 loads
+  //  consumed / first step in hand, 2 ... 11 top of each LM pass, 13 passes done, 14 records stored; tools/quad_timeline.py)
+  const bool timeline = CD && getenv("OKX_QUAD_TIMELINE") != nullptr;
+  auto stamp = [&](const char* slot) {
+    if (timeline) g.f("    if (a.trace && (threadIdx.x & 63) == 0) a.trace[blockIdx.x * 16 + (%s)] = (double)__builtin_readcyclecounter();", slot);
+  };
+  if (CD) {
+    // every kernel argument the body reads, asked for at once: left alone the compiler fetches them in three dependent
+    // scalar loads (each a round trip a lone wavefront waits for)
+    g.f("  asm volatile(\"\" :: \"s\"(a.targets), \"s\"(a.out_pos), \"s\"(a.info), \"s\"(a.n_problems), \"s\"(a.steps_per_geometry), \"s\"(a.head),"
+        " \"s\"(a.design_pos), \"s\"(a.row_param), \"s\"(a.dop_param), \"s\"(a.out_mode), \"s\"(a.max_iter), \"s\"(a.confirm));");
+  }
+  stamp("0");
   if (pv)
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1_lane = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
   else
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
   g.out += atan_decl;
   g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
-  if (!pv) g.f("  __shared__ double pls[%d];  // LDS copy of the chain-head predictor's table", kPredictorLdsDoubles);
-  const std::string lds_decl =
-      "  const int qs = lane >> 2;  // quad(-side) slot of this lane inside the wavefront\n"
-      "  __shared__ double hsl[" + std::to_string(16 * (ev.n_scalar_slots + 1)) + "];  // chain-constant scalars [slot][quad]\n"
-      "  __shared__ double hql[" + std::to_string(64 * (ev.n_lane_slots + 1)) + "];  // chain-constant lane components [slot][lane]\n";
+  if (!pv && !CD) g.f("  __shared__ double pls[%d];  // LDS copy of the chain-head predictor's table", kPredictorLdsDoubles);
+  // Cold body: every table the prologue reads - first-step table, design positions, row and derived-op parameters - is
+  // staged into LDS with a handful of coalesced loads per lane and read from there.  Read directly, each of the ~85
+  // values is a 64-lane load of 8 ... 32 distinct bytes: the four wavefronts of a CU queue ~330 of them on its one L1,
+  // ~4000 cycles before the first pass starts (timeline stamps, tools/quad_timeline.py).
+  const int cs_head = 0, cs_pos = (head_stride + 1) / 2 * 2, cs_rp = cs_pos + (3 * prog_points + 1) / 2 * 2,
+            cs_dp = cs_rp + 8 * (prog_crows + prog_targets), cs_end = cs_dp + (P.n_derived + 1) / 2 * 2 + 2;
+  if (CD) {
+    g.f("  __shared__ __attribute__((aligned(16))) double cst[%d];  // [first-step table | design positions | row parameters | derived-op parameters]", cs_end);
+    g.f("  {");
+    g.f("    const double2* h2 = reinterpret_cast<const double2*>(a.head);  // (hipMalloc'ed: 256-byte aligned)");
+    g.f("    double2* c2 = reinterpret_cast<double2*>(cst);");
+    // every load first (clamped indices: no branch), then the stores: one round trip
+    struct Piece { const char* src; int n, off; };
+    const Piece pieces[] = {{"a.design_pos", 3 * prog_points, cs_pos}, {"a.row_param", 8 * (prog_crows + prog_targets), cs_rp}, {"a.dop_param", P.n_derived, cs_dp}};
+    const int n2 = (head_stride + 1) / 2;  // (the table's allocation is rounded up to an even count of doubles)
+    for (int k = 0; 64 * k < n2; ++k) g.f("    double2 sh%d = h2[min(lane + %d, %d)];", k, 64 * k, n2 - 1);
+    for (int q = 0; q < 3; ++q)
+      for (int k = 0; 64 * k < pieces[q].n; ++k) g.f("    double sp%d_%d = %s[min(lane + %d, %d)];", q, k, pieces[q].src, 64 * k, pieces[q].n - 1);
+    {  // (an opaque use of everything loaded: the compiler would sink each load into the branch that stores it)
+      std::string pin = "    asm volatile(\"\" : ";
+      bool first = true;
+      for (int k = 0; 64 * k < n2; ++k) {
+        pin += std::string(first ? "" : ", ") + "\"+v\"(sh" + std::to_string(k) + ".x), \"+v\"(sh" + std::to_string(k) + ".y)";
+        first = false;
+      }
+      for (int q = 0; q < 3; ++q)
+        for (int k = 0; 64 * k < pieces[q].n; ++k) pin += ", \"+v\"(sp" + std::to_string(q) + "_" + std::to_string(k) + ")";
+      g.out += pin + ");\n";
+    }
+    for (int k = 0; 64 * k < n2; ++k) g.f("    if (lane + %d < %d) c2[lane + %d] = sh%d;", 64 * k, n2, 64 * k, k);
+    for (int q = 0; q < 3; ++q)
+      for (int k = 0; 64 * k < pieces[q].n; ++k) g.f("    if (lane + %d < %d) cst[%d + lane] = sp%d_%d;", 64 * k, pieces[q].n, pieces[q].off + 64 * k, q, k);
+    g.f("    __syncthreads();");
+    g.f("  }");
+    g.f("  const double* const c_rp = cst + %d; const double* const c_dp = cst + %d; (void)c_dp; (void)c_rp;", cs_rp, cs_dp);
+  }
+  (void)cs_head;
   if (ev.lds_constants) {
     g.out += lds_decl;
     g.f("  __shared__ double xsl[%d];  // accepted point, chain history and the step in hand [block][lane]", 64 * 4 * nf);
@@ -1553,7 +1629,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     if (!fixed_in_regs) g.f("  __shared__ double psl[%d];  // fixed points [point][lane]", 64 * (n_fixed > 0 ? n_fixed : 1));
   } else {
     if (pair_state_lds) g.f("  const int qs = lane >> 2;  // quad(-side) slot of this lane inside the wavefront");
-    g.f("  __shared__ double xql[%d];  // third chain-history point [block][lane] (registers are full)", 64 * nf);
+    if (!CD) g.f("  __shared__ double xql[%d];  // third chain-history point [block][lane] (registers are full)", 64 * nf);
     if (lds_state) {
       int n_fixed = 0;
       for (int p = 0; p < NP; ++p) n_fixed += ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
@@ -1563,9 +1639,13 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   g.f("  const long long spg = a.steps_per_geometry;");
   g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
-  g.f("  const long long unit_len = a.chain_len;");
+  g.f("  const long long unit_len = %s;", CD ? "1" : "a.chain_len");
+  if (CD) {
+    g.f("  const long long n_units = a.n_problems; (void)span;");
+  } else {
   g.f("  const long long chains_per_span = unit_len == 1 ? span : (span + unit_len - 1) / unit_len;");
   g.f("  const long long n_units = spg > 0 ? (a.n_problems / span) * chains_per_span : chains_per_span;");
+  }
   g.f("  for (long long wu = blockIdx.x; wu * %d < n_units; wu += gridDim.x) {", PPW);
   if (pv) {
     // the side bit as a value the optimiser cannot see through: every per-side table index is then computed where it
@@ -1576,11 +1656,15 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    const bool have = unit < n_units;");
   g.f("    if (!have) unit = n_units - 1;");
   // (64-bit divisions are ~100 instructions each: only ensembles with chains need them)
+  if (CD) {  // a unit is a problem; only the per-geometry variant needs to know whose (one 64-bit division)
+    g.f("    const long long span_idx = PG ? unit / spg : 0;");
+  } else {
   g.f("    long long span_idx = 0, chain_in_span = unit;");
   g.f("    if (spg > 0) {");
   g.f("      if (unit_len == 1) { span_idx = unit / spg; chain_in_span = unit - span_idx * spg; }");
   g.f("      else { span_idx = unit / chains_per_span; chain_in_span = unit - span_idx * chains_per_span; }");
   g.f("    }");
+  }
   if (pair_state_lds) {
     // the chain's index bookkeeping and the table pointers (quad-uniform too) in LDS as well: [slot][quad side]
     g.f("    __shared__ long long lmi[%d];", 16 * 5);
@@ -1590,11 +1674,20 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("#define gp (PG ? a.geom_pos + geom * %d : a.design_pos)", 3 * prog_points);
     g.f("#define gq (PG ? a.geom_row_param + geom * %d : a.row_param)", 8 * prog_crows);
   } else {
+  if (CD) {
+    g.f("    const long long first_b = unit;");
+  } else {
   g.f("    const long long first_b = span_idx * span + chain_in_span * unit_len;");
   g.f("    const long long last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
+  }
   g.f("    const long long geom = span_idx;");
+  if (CD) {
+    g.f("    const double* gp = cst + %d;", cs_pos);
+    g.f("    const double* gq = c_rp;");
+  } else {
   g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * prog_points);
   g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * prog_crows);
+  }
   }
   // Every load of the prologue is issued before the first dependent instruction: first-step targets, chain
   // constants, points and (single mode) the predictor table's copy into LDS share one round trip.
@@ -1606,7 +1699,14 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         state_ref("tq" + std::to_string(t), "0.0").c_str(), state_ref("tr" + std::to_string(t), "0.0").c_str());
   }
   g.f("    // chain-constant lane-component parameters (line points / directions, target directions)");
+  if (CD) {  // the same loads, from the staged copies
+    std::string h = ev.hoisted;
+    for (const auto& sub : {std::make_pair(std::string("a.row_param"), std::string("c_rp")), std::make_pair(std::string("a.dop_param"), std::string("c_dp"))})
+      for (size_t at = h.find(sub.first); at != std::string::npos; at = h.find(sub.first, at + sub.second.size())) h.replace(at, sub.first.size(), sub.second);
+    g.out += h;
+  } else {
   g.out += ev.hoisted;
+  }
   g.out += couple_hoist;
   // point registers; in the register-bound pair kernel the fixed points (read once or twice per pass, never
   // written) live in LDS instead: the compiler would otherwise park them in scratch
@@ -1636,8 +1736,25 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         g.f("    double x%d = p%d, xp%d = x%d; double& dx%d = dxl[%d + lane]; dx%d = 0.0; double& xq%d = xql[%d + lane]; xq%d = x%d;", F,
             ev.fp(F), F, F, F, 64 * F, F, F, 64 * F, F, F);
       else
+        if (CD) g.f("    double x%d = p%d, dx%d = 0.0;", F, ev.fp(F), F);
+      else
         g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0; double& xq%d = xql[%d + lane]; xq%d = x%d;", F, ev.fp(F), F, F, F, F, 64 * F, F, F);
     }
+  }
+  if (CD && head_ok) {
+    // the first-step table's entries travel with the loads above: ONE batch, nothing computed in between (a scheduling
+    // barrier keeps the arithmetic below from being interleaved, which would issue the rest of the loads a round trip later)
+    g.f("    const double* hp = cst;");
+    g.f("    const double* hqb = hp;");
+    g.f("    const double* hsb = hp; (void)hsb;");
+    for (int k = 0; k < HK; ++k)
+      for (int F = 0; F < nf; ++F) g.f("    const double hq%d_%d = hqb[%d + c];", k, F, 4 * (k * nf + F));
+    for (int j = 0; j < HK; ++j)
+      for (int k = j; k < HK; ++k) g.f("    const double hm%d_%d = hp[%d];", j, k, head_off - 2 * HK * HK + j * HK + k);
+    for (int i = 0; i < 7; ++i) g.f("    const double hs%d = hp[%d];", i, head_off + i);
+    for (int pi = 0; pi < NPAIR; ++pi)
+      for (int F = 0; F < nf; ++F) g.f("    const double hS%d_%d = hsb[%d + c];", pi, F, head_s_off + 4 * (pi * nf + F));
+    g.f("    __builtin_amdgcn_sched_barrier(0);");
   }
   // The design state is a solved state too (of its own design targets): it seeds the chain's history, so the
   // second step of a chain already extrapolates (secant through design and head) and the third quadratically.
@@ -1662,23 +1779,34 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     // table loads travel with the prologue's other loads (inside the chain loop the compiler serialises them - two
     // loads, wait, fma, next load: a dozen dependent L2 round trips, ~3 us per unit) and nothing of the table stays
     // live across the chain loop: the step and its seven scalars go to LDS and are picked up by the first chain step.
+    if (CD) {
+      // cold body: the launch guarantees the table (okx_solve_batch), the step and its scalars stay in registers
+      for (int F = 0; F < nf; ++F) g.f("    double hcx%d;", F);
+      g.f("    double hc_step, hc_M, hc_N, hc_ss, hc_mr, hc_dmax, hc_pmin, hc_pmax, hc_ok;");
+      g.f("    {");
+    } else {
     g.f("    __shared__ double hxl[%d];  // first step of the unit's head problem [block][lane]", 64 * nf);
     g.f("    __shared__ double hsc[%d];  // its scalars [slot][quad]: step length, dx.g, |dx|^2, cost x 2, max |r|, dmax, min / max pivot, ok", 16 * 9);
     g.f("    bool head_ready = false;");
     g.f("    if (a.head != nullptr && a.grad_tol <= 0.0 && (PG || a.predictor == nullptr)) {");
+    }
+    if (!CD) {
     g.f("      const double* hp = a.head + (PG ? geom * %d : 0);", head_stride);
     // pair mode: each half reads its own Q and S blocks; the Gram matrices and scalars belong to the whole problem
     g.f("      const double* hqb = hp%s;", pv ? (" + (q1 ? " + std::to_string(head_side) + " : 0)").c_str() : "");
     g.f("      const double* hsb = hp%s;", pv ? (" + (q1 ? " + std::to_string(head_s_side) + " : 0)").c_str() : "");
+    }
     // single mode: every table load issued at once (they travel with the prologue's other loads).  Pair mode: 2 x 100
     // values at once do not fit beside the chain's invariants (152 B of scratch); there the entries are read where they
     // are used, two blocks between scheduling barriers.
-    if (!pv)
+    if (!pv && !CD)
       for (int k = 0; k < HK; ++k)
         for (int F = 0; F < nf; ++F) g.f("      const double hq%d_%d = hqb[%d + c];", k, F, 4 * (k * nf + F));
+    if (!CD) {
     for (int j = 0; j < HK; ++j)
       for (int k = j; k < HK; ++k) g.f("      const double hm%d_%d = hp[%d];", j, k, head_off - 2 * HK * HK + j * HK + k);
     for (int i = 0; i < 6; ++i) g.f("      const double hs%d = hp[%d];", i, head_off + i);
+    }
     g.f("      const double hr0 = 1.0;  // weight of the constraint rows' own gradient");
     for (int k = 1; k < HK; ++k) {
       const HeadCol& col = head_cols[k];
@@ -1691,7 +1819,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     if (NPAIR > 0) {
       // first-order step d1 and the second-order correction d2 = -1/2 sum_st w_s w_t S_st (see okx_quad_head_*); d2 is
       // taken while it is a correction, 2 |d2| <= 0.75 |d1| (Transtrum & Sethna's acceptance rule)
-      g.f("      const double hs6 = hp[%d];", head_off + 6);
+      if (!CD) g.f("      const double hs6 = hp[%d];", head_off + 6);
       g.f("      double hst1 = 0.0, hst2 = 0.0;");
       if (pv)
         for (int pi = 0; pi < NPAIR; ++pi)
@@ -1706,7 +1834,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
           const int s2 = head_pairs[pi].first, t2 = head_pairs[pi].second;
           const std::string w = pv ? "hv" + std::to_string(pi)
                                    : std::string(s2 == t2 ? "0.5" : "1.0") + " * hr" + std::to_string(s2) + " * hr" + std::to_string(t2);
-          e2 += (pi ? " + " : "") + w + " * hsb[" + std::to_string(head_s_off + 4 * (pi * nf + F)) + " + c]";
+          e2 += (pi ? " + " : "") + w + (CD ? " * hS" + std::to_string(pi) + "_" + std::to_string(F)
+                                            : " * hsb[" + std::to_string(head_s_off + 4 * (pi * nf + F)) + " + c]");
         }
         g.f("      const double hxa%d = -(%s), hxb%d = -(%s);", F, e.c_str(), F, e2.c_str());
         g.f("      hst1 = fmax(hst1, fabs(hxa%d)); hst2 = fmax(hst2, fabs(hxb%d));", F, F);
@@ -1718,6 +1847,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       g.f("      hst1 = PMAX(hst1); hst2 = PMAX(hst2);");
       g.f("      const double hw2 = (hs6 > 0.5 && hst2 <= 0.375 * hst1) ? 1.0 : 0.0;");
       for (int F = 0; F < nf; ++F)
+        if (CD)
+          g.f("      { const double hx = fma(hw2, hxb%d, hxa%d); hcx%d = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", F, F, F);
+        else
         g.f("      { const double hx = fma(hw2, hxb%d, %s); hxl[%d + lane] = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", F,
             pv ? ("hxl[" + std::to_string(64 * F) + " + lane]").c_str() : ("hxa" + std::to_string(F)).c_str(), 64 * F);
     } else {
@@ -1726,6 +1858,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       for (int k = 0; k < HK; ++k)
         e += (k ? " + hr" : "hr") + std::to_string(k) + " * " +
              (pv ? "hqb[" + std::to_string(4 * (k * nf + F)) + " + c]" : "hq" + std::to_string(k) + "_" + std::to_string(F));
+      if (CD) g.f("      { const double hx = -(%s); hcx%d = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", e.c_str(), F);
+      else
       g.f("      { const double hx = -(%s); hxl[%d + lane] = hx; hstep = fmax(hstep, fabs(hx)); hN = fma(hx, hx, hN); }", e.c_str(), 64 * F);
     }
     }
@@ -1734,12 +1868,20 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       for (int k = j; k < HK; ++k)
         g.f("      hM = fma(%shr%d * hr%d, hm%d_%d, hM);", j == k ? "" : "2.0 * ", j, k, j, k);  // M is symmetric: Q_j . G_k = G_j^T (A + lambda I)^-1 G_k
     for (int k = 1; k < HK; ++k) g.f("      hss = fma(hr%d, hr%d, hss); hmr = fmax(hmr, fabs(hr%d));", k, k, k);
+    if (CD) {
+      g.f("      hc_step = hstep; hc_M = hM; hc_N = hN; hc_ss = hss; hc_mr = hmr; hc_dmax = hs0; hc_pmin = hs1; hc_pmax = hs5; hc_ok = hs4;");
+      g.f("    }");
+    } else {
     g.f("      const int hq_ = lane >> 2;");
     g.f("      hsc[0 + hq_] = hstep; hsc[16 + hq_] = hM; hsc[32 + hq_] = hN; hsc[48 + hq_] = hss; hsc[64 + hq_] = hmr;");
     g.f("      hsc[80 + hq_] = hs0; hsc[96 + hq_] = hs1; hsc[112 + hq_] = hs5; hsc[128 + hq_] = hs4;");
     g.f("      head_ready = true;");
     g.f("    }");
+    }
   }
+  if (CD) {
+    g.f("    const int hist = 1; const bool cold = false; const double lambda_carry = 0.0; (void)hist; (void)cold; (void)lambda_carry;");
+  } else {
   if (pair_state_lds) {
     g.f("    __shared__ int lmk[%d];  // per-quad counters [slot][quad side]", 16 * 6);
     g.f("    int& hist = lmk[0 + qs]; hist = 1;                // solved states in the history (the design state counts)");
@@ -1750,15 +1892,23 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   g.f("    bool cold = false;  // the previous chain step failed: restart from the design state, not the predictor");
   g.f("    %s  // damping a converged chain step ended with (0: none)", state_ref("lambda_carry", "0.0").c_str());
+  }
   // targets: the next step's values are fetched while the current step is being solved, and the two
   // previous steps' values (secant predictor) stay in registers
-  if (!pv) {
+  if (!pv && !CD) {
     g.f("    const bool model_lds = !PG && a.predictor != nullptr && a.predictor_len <= %d;", kPredictorLdsDoubles);
     g.f("    if (model_lds) {");
     g.f("      for (int k = lane; k < (int)a.predictor_len; k += 64) pls[k] = a.predictor[k];");
     g.f("      __syncthreads();");
     g.f("    }");
   }
+  if (CD) {
+    g.f("    {  // the unit's one problem");
+    g.f("      const bool valid = have;");
+    g.f("      const long long bb = first_b;");
+    for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
+    g.f("      const bool from_model = false;");
+  } else {
   g.f("    for (long long b = first_b; wave_any(have && b < last_b); ++b) {");
   g.f("      const bool valid = have && b < last_b;");
   g.f("      const long long bb = valid ? b : last_b - 1;");
@@ -1766,6 +1916,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
   for (int t = 0; t < T; ++t) g.f("      tn%d = a.targets[nb * %d + %s];", t, prog_targets, ev.target_slot(t).c_str());
   g.f("      bool from_model = false;");
+  }
   // Chain heads (and the step after, which has no secant history yet) start from the polynomial model fitted
   // by okx_program_fit_predictor instead of the design state / the previous solution:
   // x(t) = sum_k coef_k prod_t T_{k_t}(u_t), Chebyshev polynomials in the targets normalised to the fitted box
@@ -1775,7 +1926,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // ~20 % (registers, code size) whether it runs or not.  Own-geometry launches only; a restart after a failed
   // step goes back to the design state.  Not generated in pair mode: that kernel is register-bound and the mere
   // presence of the block cost the axle 18 % on chained grids for a 3 % gain (profiles/r01/config_sweep_pred.txt).
-  if (!pv || getenv("OKX_PAIR_MODEL")) {
+  if (!CD && (!pv || getenv("OKX_PAIR_MODEL"))) {
     const int TT = prog_targets;
     std::vector<int> ordinal(program.n_points, 0);  // program point -> its free ordinal
     for (int k = 0; k < program.n_free; ++k) ordinal[program.free_point[k]] = k;
@@ -1836,6 +1987,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // two states -> secant x + alpha (x - xp), alpha = the new target increment over the old one; three states on
   // one line of target space with comparable spacing -> the quadratic through them (error O(h^3) instead of
   // O(h^2): one full pass then suffices at the step sizes of the grids and ensembles).  The history shifts either way.
+  if (!CD) {
   g.f("      if (!from_model && hist >= 2) {");
   g.f("        double num = 0.0, den = 0.0, nn = 0.0, num2 = 0.0, den2 = 0.0;");
   for (int t = 0; t < T; ++t) {
@@ -1859,6 +2011,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      } else if (!from_model) {");
   for (int F = 0; F < nf; ++F) g.f("        xq%d = xp%d; xp%d = x%d;", F, F, F, F);
   g.f("      }");
+  }
   if (pair_state_lds) {
     // (declared once per chain step: the slots are the same every time)
     const int first_slot = n_state_slots;
@@ -1885,6 +2038,40 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     // Q_t = (J^T J + lambda I)^-1 J^T e_t tabulated once per geometry (okx_quad_head_*), and the problem enters the
     // loop below exactly where its own first pass would have left it: trial point x + dx in hand (mode 1), cost and
     // damping of the design state, predicted reduction 0.5 (lambda |dx|^2 - dx . g) from the table's Gram matrices.
+    if (CD) {
+    g.f("#define HEAD_APPLY \\");
+    const size_t head_apply_from = g.out.size();
+    g.f("      {");
+    g.f("        const bool at_design = valid && hc_ok > 0.5;  // the table is good");
+    g.f("        if (at_design) {");
+    for (int F = 0; F < nf; ++F) g.f("          dx%d = hcx%d;", F, F);
+    g.f("          const double hstep = hc_step;");
+    g.f("          Fc = 0.5 * hc_ss; mres = hc_mr; dmax = hc_dmax; lambda = a.lambda0 * dmax;");
+    g.f("          step_len = hstep; pred = 0.5 * fma(lambda, hc_N, hc_M); iters = 1; mode = 1;");
+    g.f("          piv_lo = hc_pmin - lambda; piv_hi = hc_pmax;");
+    g.f("          if (hstep <= a.step_tol) { flags |= INFO_CONVERGED; last_step = hstep; done = true; }");
+    g.f("          else {");
+    g.f("            want_light = hstep <= 1e-3 && (100.0 * lambda * fast_rcp(hc_pmin) + hstep) * hstep <= a.step_tol;");
+    g.f("            prev_sl = hstep;");
+    g.f("          }");
+    g.f("        }");
+    g.f("      }");
+    {  // (a macro body: strip the comments, continue every line but the last)
+      std::string body = g.out.substr(head_apply_from), cont;
+      g.out.resize(head_apply_from);
+      size_t pos = 0;
+      while (pos < body.size()) {
+        size_t eol = body.find('\n', pos);
+        std::string line = body.substr(pos, eol - pos);
+        const size_t cm = line.find("//");
+        if (cm != std::string::npos) line.resize(cm);
+        pos = eol + 1;
+        cont += line + (pos < body.size() ? " \\\n" : "\n");
+      }
+      g.out += cont;
+    }
+    g.f("      HEAD_APPLY");
+    } else {
     g.f("      if (head_ready && b == first_b) {  // wave-uniform: every quad of the wavefront is at its unit's first problem");
     g.f("        const int hq_ = lane >> 2;");
     g.f("        const bool at_design = valid && hist == 1 && !from_model && hsc[128 + hq_] > 0.5;  // x is the design state, the table is good");
@@ -1901,9 +2088,101 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("          }");
     g.f("        }");
     g.f("      }");
+    }
   }
   if (getenv("OKX_PAIR_DEBUG_RC")) g.f("      double dbg0 = 0.0, dbg1 = 0.0, dbg2 = 0.0;  // (diagnostic build)");
+  if (timeline) g.f("      int tl_pass = 2;");
+  stamp("1");
+  const bool fast_loop = CD && getenv("OKX_QUAD_NO_FAST") == nullptr;
+  if (fast_loop) {
+    // ---- the cold body's fast loop ----
+    // The passes of a cold start whose every trial point is accepted - what a sweep inside the reach does - written for
+    // exactly that: the quads that are still iterating run under ONE exec mask per pass (no per-statement predication),
+    // no modes, no rejected-step bookkeeping.  The first quad that needs anything else (a rejected or non-finite trial
+    // point, a stop on the cost test, a failed factorisation, the iteration cap, no usable table) sends its WAVEFRONT
+    // back to the start of the unit and through the general loop below, which reproduces the general body pass for pass.
+    // Same evaluation, factorisation and update formulas as there (eval_src / solve_src / light_src are the same text).
+    g.f("      bool redo = wave_any(valid && mode != 1 && !done);  // a quad without a usable first step: the general loop");
+    // full passes while some quad that is still iterating has no step in hand that is predicted to be its last ...
+    g.f("      const bool lights = a.confirm == 0;  // confirming passes are on");
+    g.f("      while (!redo && wave_any(!done && !(lights && want_light))) {");
+    stamp("tl_pass < 12 ? tl_pass++ : 12");
+    g.f("        if (!done) {");
+    g.f("    want_light = false;");
+    for (int F = 0; F < nf; ++F) g.f("    p%d = x%d + dx%d;", ev.fp(F), F, F);
+    g.out += eval_src;
+    g.f("    const double Ft = 0.5 * ss;");
+    g.f("    const double rho = (Fc - Ft) * fast_rcp(pred);");
+    g.f("    const bool plain = Ft < 1e300 && pred > 0.0 && rho > 1e-4 && !(Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) && iters < a.max_iter;");
+    g.f("    if (wave_any(!plain)) { redo = true; break; }");
+    for (int F = 0; F < nf; ++F) g.f("    x%d = p%d;", F, ev.fp(F));
+    g.f("    last_step = step_len; Fc = Ft; mres = mres_new; ++nfev;");
+    g.f("    { const double t = 2.0 * rho - 1.0;");
+    g.f("      lambda *= (rho > 0.99 && (step_len <= 1.0 || Ft <= 1e-2)) ? 1e-3 : (rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t)); }");
+    if (timeline) g.f("    OKX_TL(10)");
+    for (int F = 0; F < nf; ++F)
+      for (int G = 0; G <= F; ++G)
+        if (ev.fillf[F][G])
+          for (int k = 0; k < 3; ++k) {
+            if (!(F == G && k == 2)) g.f("    double %s;", Gen::Ln(F, G, k).c_str());
+            if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
+          }
+    g.out += solve_src;
+    g.f("    double sl = 0.0, pr = 0.0, dd = 0.0;");
+    for (int F = 0; F < nf; ++F) g.f("    sl = fmax(sl, fabs(nx%d));", F);
+    g.f("    sl = PMAX(sl);");
+    for (int F = 0; F < nf; ++F) g.f("    pr = fma(nx%d, fma(lambda, nx%d, -gn%d), pr); dd = fma(nx%d, nx%d, dd);", F, F, F, F, F);
+    g.f("    pr = 0.5 * PSUM(pr);");
+    g.f("    dd = PSUM(dd);");
+    // every pivot positive = the smallest one is (the eighteen separate tests of the general loop are never asked for here);
+    // a NaN anywhere in the matrix reaches the step, hence dd
+    g.f("    if (wave_any(!(pmin > 0.0 && dd == dd))) { redo = true; break; }");
+    g.f("    const double rq = dd > 0.0 ? (2.0 * pr - lambda * dd) * fast_rcp(dd) - lambda : 1e300;");
+    g.f("    ++iters;");
+    g.f("    piv_lo = fmin(pmin - lambda, rq); piv_hi = pmax;");
+    for (int F = 0; F < nf; ++F) g.f("    dx%d = nx%d;", F, F);
+    g.f("    step_len = sl; pred = pr;");
+    g.f("    if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
+    g.f("    else {");
+    g.f("      const double cq = prev_sl > 0.0 ? fmax(3.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
+    g.f("      const double rho_lin = 100.0 * lambda * fast_rcp(pmin);");
+    g.f("      want_light = sl <= 1e-3 && (rho_lin + cq * sl) * sl <= a.step_tol;");
+    g.f("      prev_sl = sl;");
+    g.f("    }");
+    if (timeline) g.f("    OKX_TL(11)");
+    g.f("        }  // quads still iterating");
+    g.f("      }  // full passes");
+    // ... then ONE confirming pass (residuals only) for the quads that are left, all of which want it (the general loop's
+    // rule: a confirming pass only when every quad still iterating asks for one).  A quad whose cost rose there needs more
+    // full passes: with the rest of its wavefront it goes back through the general loop.
+    if (light_ok) {
+      g.f("      if (!redo && wave_any(!done)) {");
+      stamp("tl_pass < 12 ? tl_pass++ : 12");
+      g.f("        if (!done) {");
+      for (int F = 0; F < nf; ++F) g.f("      p%d = x%d + dx%d;", ev.fp(F), F, F);
+      g.out += light_src;
+      g.f("      const double Fl = 0.5 * ss;");
+      g.f("      if (wave_any(!(Fl <= Fc * (1.0 + 1e-6) + 1e-28))) redo = true;");
+      g.f("      else {");
+      g.f("        ++nfev;");
+      for (int F = 0; F < nf; ++F) g.f("        x%d = p%d;", F, ev.fp(F));
+      g.f("        Fc = Fl; mres = mres_new; last_step = step_len; flags |= INFO_CONVERGED; done = true;");
+      g.f("      }");
+      g.f("        }");
+      g.f("      }");
+    } else {
+      g.f("      if (!redo && wave_any(!done)) redo = true;  // (never: no quad asks for a confirming pass)");
+    }
+    g.f("      if (redo) {  // back to the unit's start, through the general loop");
+    for (int F = 0; F < nf; ++F) g.f("        x%d = ld3(gp + %s + cc, c); dx%d = 0.0;", F, ev.point3(ev.fp(F)).c_str(), F);
+    g.f("        Fc = 0.0; lambda = 0.0; nu = 2.0; dmax = 0.0; step_len = 0.0; last_step = 0.0; mres = 0.0; pred = 0.0;");
+    g.f("        nfev = 0; iters = 0; flags = 0; nfail = 0; mode = 0; done = !valid; want_light = false;");
+    g.f("        prev_sl = 0.0; piv_lo = 0.0; piv_hi = 0.0;");
+    g.f("        HEAD_APPLY");
+    g.f("      }");
+  }
   g.f("      while (wave_any(!done)) {");
+  stamp("tl_pass < 12 ? tl_pass++ : 12");
   if (light_ok) {
     // Confirming pass: every active problem of this wavefront has a step in hand that is
     // predicted to land within step_tol of its solution.  Apply it, evaluate the residuals only
@@ -1998,10 +2277,13 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      }");
   g.f("      if (stop || iters >= a.max_iter) done = true;");
   g.f("    }");
+  if (!CD) {
   g.f("    if (a.trace && valid && bb == a.trace_problem && c == 0 && nfev < 256) {");
   g.f("      double* tr = a.trace + 8 * nfev;");
   g.f("      tr[0] = mode; tr[1] = Ft; tr[2] = Fc; tr[3] = lambda; tr[4] = step_len; tr[5] = rho; tr[6] = accept ? 1.0 : 0.0; tr[7] = done ? 1.0 : 0.0;");
   g.f("    }");
+  }
+  if (timeline) g.f("    OKX_TL(10)");
   g.f("    const bool solve_now = !done && accept;");
   g.f("    if (!done && !accept) mode = 2;");
   g.f("    if (wave_any(solve_now)) {");
@@ -2130,8 +2412,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("        mode = 2;");
   g.f("      }");
   g.f("    }");
+  if (timeline) g.f("    OKX_TL(11)");
   g.f("    }  // any quad solves");
   g.f("      }  // LM passes");
+  stamp("13");
   // final state and output
   g.f("      {");
   for (int F = 0; F < nf; ++F) g.f("    p%d = x%d;", ev.fp(F), F);
@@ -2141,12 +2425,13 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int e = 0; e < P.n_derived; ++e)
     if (!fin.derived_op(e, false)) {
       *why = fin.why;
-      return false;
+      body_failed = true;
+      return;
     }
   g.f("    if (a.out_mode == 0) {  // the derived points only matter to the full records");
   g.out += fin.out;
   g.f("    }");
-  const std::string final_src = fin.out;
+  final_src = fin.out;
   g.f("    if (mres > a.residual_tolerance) flags |= INFO_RESIDUAL_EXCEEDED;");
   g.f("    if (piv_hi > 0.0 && piv_lo <= ILL_CONDITIONED_PIVOT_RATIO * piv_hi) flags |= INFO_ILL_CONDITIONED;");
   // Record stores.  Independent problems (chain_len 1): the 16 problems of a wavefront are
@@ -2222,6 +2507,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int k = 0; k < P.n_out; ++k) g.f("      o[%d] = p%d;", 3 * k, P.out_point[k]);
   }
   g.f("    }");
+  stamp("14");
   g.f("    if (valid && c == 0%s) {", pv ? " && !q1" : "");
   g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
   if (getenv("OKX_PAIR_DEBUG_PIV")) g.f("      inf.cost = piv_hi; inf.last_step = piv_lo;  // (diagnostic build)");
@@ -2229,7 +2515,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
   g.f("      a.info[bb] = inf;");
   g.f("    }");
+  stamp("15");
   // chains never continue from a state that failed to converge
+  if (!CD) {
   for (int t = 0; t < T; ++t) g.f("    tr%d = tq%d; tq%d = tp%d; tp%d = tv%d;", t, t, t, t, t, t);
   g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
   if (pv) {  // restart addresses are built here, from a fresh opaque copy of the side bit, not carried through the kernel
@@ -2246,12 +2534,21 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      cold = false;");
   g.f("      lambda_carry = lambda;");
   g.f("    }");
+  }
   g.f("      }");
   g.f("    }  // chain steps");
   g.f("  }  // wave units");
   g.f("}");
+  if (tl_body) g.f("#undef OKX_TL\n#define OKX_TL(k)");
+  if (CD) g.f("#undef HEAD_APPLY");
   if (pair_state_lds) g.f("#undef gp\n#undef gq");
   g.f("");
+  };  // emit_body
+  emit_body(false);
+  if (body_failed) return false;
+  const bool cold_body = !pv && head_ok;
+  if (cold_body) emit_body(true);
+  if (body_failed) return false;
   if (!pv) {
   // ---- output positions from free coordinates (okx_expand_positions_batch): fixed points from the design table,
   //      every derived point re-evaluated, records written like the solve kernel's ----
@@ -2804,6 +3101,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       waves_per_simd);
   g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_solve_g(QArgs a) { okx_quad_body<true>(a); }",
       waves_per_simd);
+  if (cold_body) {
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_cold_u(QArgs a) { okx_quad_cold_body(a); }", waves_per_simd);
+  }
   *src = g.out;
   return true;
 }

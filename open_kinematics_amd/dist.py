@@ -106,50 +106,66 @@ class GatherPipeline:
         return self.full[self.last] if self.exchange else self.local[self.last]
 
 
-class FreeGatherPipeline(GatherPipeline):
+class FreeGatherPipeline:
     """
-    ``GatherPipeline`` that ships the free coordinates of each solve (``3 n_free`` doubles) instead of its output
-    positions (``3 n_out``) and rebuilds the positions on the receiving side (``expand``: fixed points from the
-    design state, derived points re-evaluated) — 144 B instead of 360 B per double-wishbone solve.  The exchange is
-    what bounds N > 1, so the payload is what matters.
+    The pipelined exchange of the bench step with the compact payload: the solve writes the FREE coordinates of its
+    problems (``3 n_free`` doubles each, ``okx_solve_opts.output = OKX_OUTPUT_FREE``) straight into the send buffer, the
+    all-gather of step ``k`` runs on the collective's stream while step ``k + 1`` solves into the other slot, and one
+    ``expand`` per step rebuilds every rank's output records from the gathered block (fixed points from the design
+    state, derived points re-evaluated: bit-identical to what the solver would have written) - 144 B instead of 360 B
+    per double-wishbone solve on the links, no packing pass, no second copy of the local records.
 
-        pipe = FreeGatherPipeline(rows_per_rank, n_out, free_out_index, expand, dtype, device)
-        out = pipe.begin(k); ... solve into out ...; pipe.submit(k); ...; full = pipe.drain()
+        pipe = FreeGatherPipeline(rows_per_rank, n_out, n_free, expand, dtype, device)
+        launches = [plan(out=buf, output=pipe.output) for buf in pipe.solve_buffers]
+        for k in range(steps):
+            pipe.begin(k)                          # the slot's previous exchange is complete, its buffers are free
+            launches[k % len(launches)]()          # solve into pipe.solve_buffers[k % depth]
+            pipe.submit(k)                         # asynchronous all-gather of what was just solved
+        positions = pipe.drain()                   # [rows_per_rank * world, n_out, 3] of the last step
 
-    ``free_out_index``: output-list index of every free point; ``expand(free [R, n_free, 3], out [R, n_out, 3])``
-    fills ``out`` (``DeviceProgram.expand``).  With one rank it degenerates to the local buffer.
+    ``expand(free [R, n_free, 3], out [R, n_out, 3])`` fills ``out`` (``DeviceProgram.expand``).  With one rank and no
+    collective the solve writes its records itself (``output == "records"``) and ``drain`` returns them.
     """
 
-    def __init__(self, rows_per_rank: int, n_out: int, free_out_index: torch.Tensor, expand, dtype, device, group=None,
-                 depth: int = 2, collective_at_world_one: bool = False):
-        super().__init__(rows_per_rank, (n_out, 3), dtype, device, group, depth, collective_at_world_one)
-        self.free_out_index = free_out_index
+    def __init__(self, rows_per_rank: int, n_out: int, n_free: int, expand, dtype, device, group=None, depth: int = 2,
+                 collective_at_world_one: bool = False):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # one rank with an initialised process group can still run the collective (a one-GPU box rehearsing the RCCL
+        # path: communicator set-up, stream ordering of the pipeline, the expand on the gathered buffer)
+        self.exchange = self.world > 1 or (collective_at_world_one and dist.is_available() and dist.is_initialized())
+        self.depth = depth
         self.expand = expand
-        n_free = int(free_out_index.numel())
-        self.free_local = [torch.empty((rows_per_rank, n_free, 3), dtype=dtype, device=device) for _ in range(depth)]
-        self.free_full = [torch.empty((rows_per_rank * self.world, n_free, 3), dtype=dtype, device=device)
-                          if self.exchange else None for _ in range(depth)]
+        self.output = "free" if self.exchange else "records"
+        width = n_free if self.exchange else n_out
+        self.solve_buffers = [torch.empty((rows_per_rank, width, 3), dtype=dtype, device=device) for _ in range(depth)]
+        self.gathered = [torch.empty((rows_per_rank * self.world, n_free, 3), dtype=dtype, device=device)
+                         if self.exchange else None for _ in range(depth)]
+        self.full = [torch.empty((rows_per_rank * self.world, n_out, 3), dtype=dtype, device=device)
+                     if self.exchange else None for _ in range(depth)]
+        self.work = [None] * depth
         self.pending = [False] * depth  # gathered free coordinates not expanded yet
+        self.last = -1
+        self.bytes_sent_per_step = rows_per_rank * n_free * 3 * torch.empty((), dtype=dtype).element_size() if self.exchange else 0
 
     def _finish(self, slot: int) -> None:
         if self.work[slot] is not None:
-            self.work[slot].wait()
+            self.work[slot].wait()  # NCCL: the current stream waits; gloo: the host does
             self.work[slot] = None
         if self.pending[slot]:
-            self.expand(self.free_full[slot], self.full[slot])
+            self.expand(self.gathered[slot], self.full[slot])
             self.pending[slot] = False
 
     def begin(self, k: int) -> torch.Tensor:
         slot = k % self.depth
-        self._finish(slot)  # the previous exchange of this slot: positions of that step are complete now
-        return self.local[slot]
+        self._finish(slot)  # the previous exchange of this slot: the positions of that step are complete now
+        return self.solve_buffers[slot]
 
     def submit(self, k: int) -> None:
         slot = k % self.depth
         self.last = slot
         if self.exchange:
-            torch.index_select(self.local[slot], 1, self.free_out_index, out=self.free_local[slot])
-            self.work[slot] = dist.all_gather_into_tensor(self.free_full[slot], self.free_local[slot], group=self.group,
+            self.work[slot] = dist.all_gather_into_tensor(self.gathered[slot], self.solve_buffers[slot], group=self.group,
                                                           async_op=True)
             self.pending[slot] = True
 
@@ -158,14 +174,14 @@ class FreeGatherPipeline(GatherPipeline):
             self._finish(slot)
         if self.last < 0:
             raise RuntimeError("nothing was submitted")
-        return self.full[self.last] if self.exchange else self.local[self.last]
+        return self.full[self.last] if self.exchange else self.solve_buffers[self.last]
 
 
 @dataclass
 class EnsembleShard:
     """What ``solve_sharded(..., hardpoints=...)`` returns next to the gathered positions."""
 
-    local: object                      # BatchResult of this rank's geometries
+    local: object                      # BatchResult of this rank's geometries (exchange="free" with N > 1: free coordinates, no records)
     geometry_range: tuple              # [lo, hi) of the geometries this rank solved
     free_full: torch.Tensor | None     # gathered free coordinates [G * S, n_free, 3] (exchange="free")
     info_full: torch.Tensor | None     # gathered okx_info records [G * S, 40] uint8
@@ -230,22 +246,22 @@ def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = Tru
         local_targets = device_program.ensemble_targets(my_pos, targets_full)
     else:
         local_targets = targets_full[glo * steps : ghi * steps]
+    # compact exchange: the solve writes the free coordinates alone (okx_solve_opts.output = OKX_OUTPUT_FREE) - they ARE the
+    # payload, and one expand of the gathered block rebuilds every rank's records, this rank's own included
+    compact = gather and world > 1 and exchange == "free"
     result = device_program.solve(local_targets, geom_pos=my_pos, geom_row_param=my_param, steps_per_geometry=steps,
-                                  **solve_kw)
+                                  **(dict(solve_kw, output="free") if compact else solve_kw))
     if not gather or world == 1:
         return result.positions, EnsembleShard(result, (glo, ghi), None, result.info_raw if gather else None, 0)
     n_total = n_geom * steps
     spans = [tuple(steps * g for g in shard_range(n_geom, r, world)) for r in range(world)]
     info_full = all_gather_rows(result.info_raw, n_total, group, spans)
     sent = result.info_raw.numel() * result.info_raw.element_size()
-    if exchange == "positions":
+    if not compact:
         positions = all_gather_rows(result.positions, n_total, group, spans)
         sent += result.positions.numel() * result.positions.element_size()
         return positions, EnsembleShard(result, (glo, ghi), None, info_full, sent)
-    free_local = result.positions.index_select(1, device_program.free_out_index)
-    sent += free_local.numel() * free_local.element_size()
-    free_full = all_gather_rows(free_local, n_total, group, spans)
+    sent += result.free.numel() * result.free.element_size()
+    free_full = all_gather_rows(result.free, n_total, group, spans)
     positions = device_program.expand(free_full, geom_pos=gpos, steps_per_geometry=steps)
-    # this rank's own block is bit-identical either way; keep the solver's records for it
-    positions[glo * steps : ghi * steps] = result.positions
     return positions, EnsembleShard(result, (glo, ghi), free_full, info_full, sent)

@@ -27,9 +27,11 @@ SOLVE_ACCEPT_RESIDUAL = 1e-3
 
 class SolverConfig(NamedTuple):
     """
-    Reference fields first (``solver.py:65-80``).  ``ftol``/``xtol``/``gtol`` steer MINPACK in
-    the reference; the device solver always iterates to its fixed point and uses the extra
-    fields instead.
+    Reference fields first (``solver.py:65-80``), then the device solver's own controls.
+
+    ``ftol`` / ``xtol`` / ``gtol`` are MINPACK's stopping tests in the reference (``solver.py:158-169``).  At the
+    reference's default values or tighter the device solver simply iterates to its own fixed point (``step_tol``), which
+    satisfies all three and costs no extra pass; values LOOSER than the defaults are honoured, see ``device_tolerances``.
     """
 
     ftol: float = SOLVE_TOLERANCE_VALUE
@@ -43,6 +45,34 @@ class SolverConfig(NamedTuple):
     step_tol: float = 1e-11     # mm
     max_iter: int = 100
     parallel_chains: bool = True  # long warm-started sweeps: several chains at once, verified against the sequential path
+
+
+def device_tolerances(cfg: "SolverConfig", program: ConstraintProgram) -> dict:
+    """
+    ``okx_solve_opts`` stopping tolerances for a ``SolverConfig``.
+
+    MINPACK stops on ``xtol`` when the step is at most ``xtol * ||x||`` (``lmder``: ``delta <= xtol * xnorm``, unit
+    scaling) and on ``ftol`` when the actual and the predicted relative cost reductions of an accepted step are both at
+    most ``ftol``.  The device solver has the same two tests (``step_tol`` in millimetres on the largest coordinate
+    change, ``ftol`` relative).  A caller who loosens ``xtol`` / ``ftol`` beyond the reference's defaults gets them:
+    ``step_tol = max(cfg.step_tol, xtol * ||x0||_2)`` with ``x0`` the free coordinates of the design state, and
+    ``ftol`` passed through - the solve stops earlier, with fewer evaluations, like the reference's would.  Defaults and
+    tighter values leave the device's fixed-point stop (``cfg.step_tol``, device ``ftol`` 1e-10) in charge.  ``gtol``
+    has no device counterpart (MINPACK's is a scaled cosine, ``okx_solve_opts.grad_tol`` an absolute gradient): a
+    loosened ``gtol`` is reported with a warning and otherwise ignored - the solve only ends closer to the solution.
+    """
+    tolerances = {"step_tol": float(cfg.step_tol)}
+    if cfg.xtol > SOLVE_TOLERANCE_STEP:
+        x0 = np.asarray(program.design_pos, dtype=np.float64)[np.asarray(program.free_point, dtype=np.int64)]
+        tolerances["step_tol"] = max(tolerances["step_tol"], float(cfg.xtol) * float(np.linalg.norm(x0)))
+    if cfg.ftol > SOLVE_TOLERANCE_VALUE:
+        tolerances["ftol"] = float(cfg.ftol)
+    if cfg.gtol > SOLVE_TOLERANCE_GRAD:
+        import warnings
+
+        warnings.warn(f"SolverConfig.gtol = {cfg.gtol:g} is looser than the reference's default {SOLVE_TOLERANCE_GRAD:g}: the device "
+                      "solver has no orthogonality stop and iterates to its step / cost tolerances instead", RuntimeWarning, stacklevel=3)
+    return tolerances
 
 
 @dataclass
@@ -239,8 +269,8 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     program, table = dropin_program(initial_state, constraints, sweep_config, derived_manager, cfg, output_points)
     dp = _device_program(program, device)
     n_steps = table.shape[0]
-    solve_kw = dict(max_iter=cfg.max_iter, step_tol=cfg.step_tol, residual_tolerance=cfg.residual_tolerance,
-                    predictor=False)  # one sweep = a few chains (or explicit cold starts): nothing for a fitted model to save
+    solve_kw = dict(max_iter=cfg.max_iter, residual_tolerance=cfg.residual_tolerance, predictor=False,
+                    **device_tolerances(cfg, program))  # (one sweep = a few chains or explicit cold starts: nothing for a fitted model to save)
     targets = torch.as_tensor(table)
     positions = info = None
     positions_from_segments = False
@@ -301,8 +331,8 @@ def _solve_sweep_in_runs(initial_state, constraints, sweep_config, derived_manag
         program = flatten_problem(start_state, constraints, spec, heads, output_points=None,
                                   line_mode="softnorm").with_line_mode(cfg.line_mode)
         dp = _device_program(program, device)
-        result = dp.solve(torch.as_tensor(table), chain=bool(cfg.warm_start), max_iter=cfg.max_iter, step_tol=cfg.step_tol,
-                          residual_tolerance=cfg.residual_tolerance, predictor=False)
+        result = dp.solve(torch.as_tensor(table), chain=bool(cfg.warm_start), max_iter=cfg.max_iter,
+                          residual_tolerance=cfg.residual_tolerance, predictor=False, **device_tolerances(cfg, program))
         positions = result.positions.cpu().numpy()
         info = result.info()
         _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg, first_step=lo)

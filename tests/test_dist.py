@@ -49,16 +49,17 @@ def _worker(rank: int, world: int, port: int, n_total: int, out_dir: str) -> Non
             out.copy_(_fake_solve(targets[lo:hi] + float(k)))
             pipe.submit(k)
         torch.save(pipe.drain().clone(), os.path.join(out_dir, f"pipe{rank}.pt"))
-        # the compact exchange: "free" points 1 and 3 travel, the receiver rebuilds the other three of five
-        index = torch.tensor([1, 3])
-
+        # the compact exchange: the solve writes the "free" points 1 and 3 (output = free) into the send buffer, they
+        # travel, and the receiver rebuilds all five points of every rank's rows
         def expand(free, out):  # stand-in for DeviceProgram.expand: _fake_solve's points are all equal
             out.copy_(free[:, :1, :].expand(-1, 5, -1))
 
-        compact = FreeGatherPipeline(hi - lo, 5, index, expand, torch.float64, "cpu")
+        compact = FreeGatherPipeline(hi - lo, 5, 2, expand, torch.float64, "cpu")
+        assert compact.output == "free" and compact.solve_buffers[0].shape == (hi - lo, 2, 3)
+        assert compact.bytes_sent_per_step == (hi - lo) * 2 * 24
         for k in range(5):
             out = compact.begin(k)
-            out.copy_(_fake_solve(targets[lo:hi] + float(k)))
+            out.copy_(_fake_solve(targets[lo:hi] + float(k))[:, [1, 3]])
             compact.submit(k)
         torch.save(compact.drain().clone(), os.path.join(out_dir, f"compact{rank}.pt"))
     dist.barrier()
@@ -93,6 +94,7 @@ class _StandInProgram:
 
     def __init__(self):
         self.rebound = []
+        self.outputs = []
 
     def rebind(self, table):
         table = torch.as_tensor(table, dtype=torch.float64)
@@ -113,14 +115,16 @@ class _StandInProgram:
         out[:, 4] = free[:, 1] + fixed
         return out
 
-    def solve(self, targets, *, geom_pos, geom_row_param, steps_per_geometry, **kw):
+    def solve(self, targets, *, geom_pos, geom_row_param, steps_per_geometry, output="records", **kw):
         assert geom_pos.shape[0] * steps_per_geometry == targets.shape[0] and geom_row_param.shape[0] == geom_pos.shape[0]
         fixed = geom_pos[:, 0].repeat_interleave(steps_per_geometry, dim=0)
         t = targets[:, :1]
-        free = torch.stack([t * fixed, t + 2.0 * fixed], dim=1)
+        solved = torch.stack([t * fixed, t + 2.0 * fixed], dim=1)
+        self.outputs.append(output)
 
-        class _Result:
-            positions = self._assemble(free, fixed)
+        class _Result:  # like BatchResult: records with output="records", the free points alone with "free"
+            positions = self._assemble(solved, fixed) if output == "records" else None
+            free = solved if output == "free" else None
             info_raw = (targets[:, :1].abs() * 7).to(torch.uint8).expand(-1, 40).contiguous()
 
         return _Result
@@ -148,7 +152,7 @@ def _ensemble_worker(rank: int, world: int, port: int, n_geom: int, steps: int, 
         dp = _StandInProgram()
         positions, shard = solve_sharded(dp, relative, hardpoints=table, steps_per_geometry=steps, exchange=exchange)
         torch.save({"positions": positions, "info": shard.info_full, "range": shard.geometry_range,
-                    "rebound": dp.rebound, "sent": shard.exchange_bytes_per_rank},
+                    "rebound": dp.rebound, "sent": shard.exchange_bytes_per_rank, "outputs": dp.outputs},
                    os.path.join(out_dir, f"{exchange}{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -177,6 +181,8 @@ def test_two_rank_gloo_ensemble_is_geometry_major(tmp_path, n_geom):
             assert got["sent"] == payload
             # the compact exchange rebinds the replicated table in full, the positions exchange only its slice
             assert got["rebound"] == [n_geom if exchange == "free" else spans[rank][1] - spans[rank][0]]
+            # ... and its solve writes the payload itself (okx_solve_opts.output = free): no packing pass after the solve
+            assert got["outputs"] == ["free" if exchange == "free" else "records"]
 
 
 def test_single_process_ensemble_needs_no_collective():
@@ -202,7 +208,8 @@ def test_single_process_pipeline_degenerates_to_the_local_buffer():
 
 
 def test_single_process_compact_pipeline_degenerates_to_the_local_buffer():
-    pipe = FreeGatherPipeline(4, 3, torch.tensor([0, 2]), lambda free, out: None, torch.float64, "cpu")
+    pipe = FreeGatherPipeline(4, 3, 2, lambda free, out: None, torch.float64, "cpu")
+    assert pipe.output == "records" and pipe.bytes_sent_per_step == 0  # one rank, no collective: the solver's own records
     for k in range(3):
         pipe.begin(k).fill_(float(k))
         pipe.submit(k)

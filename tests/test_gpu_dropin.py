@@ -307,3 +307,41 @@ def test_solver_info_counts_the_shared_design_state_evaluation_for_chain_heads()
     own = dp.solve(torch.as_tensor(table), chain_len=1, predictor=False, shared_first_step=False).info()["nfev"]
     assert np.all(np.abs(own - (raw_cold + 1)) <= 1)   # the same count as a problem that evaluates the design state itself
     solver.clear_program_cache()
+
+
+def test_loosened_minpack_tolerances_are_honoured(golden):
+    """SolverConfig.xtol / ftol beyond the reference's defaults (solver.py:65-80, :158-169) reach the device as its step and
+    cost tolerances: the sweep stops earlier (fewer evaluations) and stays inside the reference's own default-tolerance band
+    (5e-5 mm); the defaults and tighter values keep the fixed-point stop; a loosened gtol warns."""
+    import warnings
+
+    import yaml
+
+    from open_kinematics_amd.input import build_sweep
+    from open_kinematics_amd.solver import SolverConfig, device_tolerances
+    from open_kinematics_amd.sweep import solve_sweep
+
+    arrays, program = golden("c1_dw_corner")
+    sus = _dw()
+    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)
+    out = sus.output_points()
+
+    def run(cfg):
+        states, infos = solve_sweep(sus, sweep, cfg)
+        return np.array([[s.positions[k].data for k in out] for s in states]), sum(i.nfev for i in infos)
+
+    tight_pos, tight_nfev = run(SolverConfig(warm_start=False))
+    loose_pos, loose_nfev = run(SolverConfig(warm_start=False, xtol=1e-6, ftol=1e-4))
+    assert loose_nfev < tight_nfev
+    assert np.abs(loose_pos - arrays["ref_tight_pos"]).max() <= 5e-5
+    assert np.abs(loose_pos - tight_pos).max() > 0.0            # it really stopped somewhere else
+    same_pos, same_nfev = run(SolverConfig(warm_start=False, ftol=1e-15, xtol=1e-15, gtol=1e-15))  # the "tight" rung: nothing to loosen
+    assert same_nfev == tight_nfev and np.array_equal(same_pos, tight_pos)
+    norm = float(np.linalg.norm(program.design_pos[program.free_point]))
+    assert device_tolerances(SolverConfig(), program) == {"step_tol": 1e-11}
+    loose = device_tolerances(SolverConfig(xtol=1e-6, ftol=1e-4), program)
+    assert loose["ftol"] == 1e-4 and abs(loose["step_tol"] - 1e-6 * norm) <= 1e-12 * norm
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        device_tolerances(SolverConfig(gtol=1e-3), program)
+    assert any("gtol" in str(w.message) for w in caught)

@@ -110,10 +110,49 @@ def test_pinned_host_buffers_are_accepted_as_device_accessible_pointers(golden):
     for mode, shape in (("free", (n, program.n_free, 3)), ("records", (n, program.n_out, 3))):
         h_out = torch.full(shape, -7.0, dtype=torch.float64).pin_memory()
         h_info = torch.zeros((n, 40), dtype=torch.uint8).pin_memory()
-        dp.solve(h_t, out=h_out, info_out=h_info, output=mode, chain_len=-1)
+        dp.solve(h_t, out=h_out, info_out=h_info, output=mode, chain_len=-1, zero_copy=True)
         torch.cuda.synchronize()
         ref = dp.solve(torch.as_tensor(arrays["targets_abs"], device="cuda:0"), output=mode, chain_len=-1)
         torch.cuda.synchronize()
         want = ref.free if mode == "free" else ref.positions
         assert np.array_equal(h_out.numpy(), want.cpu().numpy())
         assert np.array_equal(h_info.numpy(), ref.info_raw.cpu().numpy())
+
+
+def test_pinned_inputs_are_snapshotted_unless_zero_copy_is_asked_for(golden):
+    """pinned host tensors passed to rebind / eval / solve WITHOUT zero_copy are copied to the device like any
+    other host data (no pointer into host memory reaches a kernel), pinned OUTPUT buffers are refused without the flag, and
+    pageable host buffers always."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden("c2_dw_subset")
+    program = program.with_line_mode("pinned")
+    dp = DeviceProgram(program, "cuda:0")
+    t_host = torch.as_tensor(arrays["targets_abs"]).pin_memory()
+    t_dev = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
+    # rebind with a pinned hardpoint table: outputs live on the device and match the device-input call
+    hp = torch.as_tensor(np.repeat(program.design_pos[None], 3, axis=0)).pin_memory()
+    gpos, gparam = dp.rebind(hp)
+    gpos_d, gparam_d = dp.rebind(hp.to("cuda:0"))
+    assert gpos.is_cuda and gparam.is_cuda and torch.equal(gpos, gpos_d) and torch.equal(gparam, gparam_d)
+    # eval with pinned x and targets
+    x = torch.as_tensor(np.repeat(program.design_pos[program.free_point].reshape(1, -1), t_host.shape[0], axis=0)).pin_memory()
+    r_pinned = dp.eval(x, t_host)
+    r_dev = dp.eval(x.to("cuda:0"), t_dev)
+    assert all(a.is_cuda and torch.equal(a, b) for a, b in zip(r_pinned, r_dev))
+    # solve: a pinned input is snapshotted - overwriting it right after the call does not change the answer
+    scratch = t_host.clone().pin_memory()
+    res = dp.solve(scratch, chain_len=1)
+    scratch.zero_()
+    torch.cuda.synchronize()
+    ref = dp.solve(t_dev, chain_len=1)
+    assert torch.equal(res.positions, ref.positions)
+    # output buffers on the host need the flag; pageable ones are never accepted
+    n = t_host.shape[0]
+    h_out = torch.empty((n, program.n_out, 3), dtype=torch.float64).pin_memory()
+    h_info = torch.zeros((n, 40), dtype=torch.uint8).pin_memory()
+    with pytest.raises(ValueError, match="zero_copy=True"):
+        dp.solve(t_dev, out=h_out, info_out=h_info)
+    with pytest.raises(ValueError, match="pinned host tensor"):
+        dp.solve(t_dev, out=torch.empty((n, program.n_out, 3), dtype=torch.float64), info_out=h_info, zero_copy=True)
+    dp.close()

@@ -105,3 +105,92 @@ def test_flatten_positions_uses_public_names():
 
     flat = flatten_positions({PointID.WHEEL_CENTER: Point3([1, 2, 3])}, [PointID.WHEEL_CENTER, PointID.AXLE_INBOARD])
     assert flat == {"wheel_center": (1.0, 2.0, 3.0)}
+
+
+def _spec_frame():
+    """The frame of the reference's tests/test_metric_export_metadata.py:17-27, built from the drop-in's own types."""
+    from open_kinematics_amd.results_writer import MetricKind, MetricSpec, MetricUnit, Scope
+
+    spec = MetricSpec("camber", "Camber", MetricUnit.DEG, MetricKind.STATE, Scope.CORNER)
+    return SolutionFrame(positions={"wheel_center": (1.0, 2.0, 3.0)}, solver_info=SolverInfo(True, 3, 1e-8),
+                         metrics={"camber": -1.25}, metric_specs={"camber": spec})
+
+
+def test_csv_writes_explicit_column_unit_metadata(tmp_path):
+    """tests/test_metric_export_metadata.py:30-45 of the reference, against the drop-in writer."""
+    output = tmp_path / "result.csv"
+    writer = CsvWriter(output)
+    writer.add_frame(0, _spec_frame())
+    writer.write()
+    units_line = next(line for line in output.read_text().splitlines() if line.startswith("# column_units:"))
+    units = json.loads(units_line.partition(":")[2].strip())
+    assert units["camber"] == "deg"
+    assert units["wheel_center_z"] == "mm"
+
+
+def test_parquet_writes_units_on_arrow_fields(tmp_path):
+    """tests/test_metric_export_metadata.py:48-58 of the reference, against the drop-in writer."""
+    import pyarrow.parquet as pq
+
+    output = tmp_path / "result.parquet"
+    writer = ParquetWriter(output)
+    writer.add_frame(0, _spec_frame())
+    writer.write()
+    schema = pq.read_schema(output)
+    assert schema.field("camber").metadata == {b"unit": b"deg"}
+    assert schema.field("wheel_center_x").metadata == {b"unit": b"mm"}
+
+
+def test_bulk_table_equals_the_per_frame_path(golden, tmp_path):
+    """ResultTable.from_batch (arrays in, no per-row objects) writes the same bytes as frames through add_frame."""
+    from open_kinematics_amd.results_writer import ResultTable, provenance
+
+    arrays, program = golden("e2e_sweep")
+    pos = arrays["ref_default_pos"]
+    info = np.zeros(pos.shape[0], dtype=[("flags", "<i4"), ("nfev", "<i4"), ("max_residual", "<f8")])
+    info["flags"], info["nfev"], info["max_residual"] = 1, arrays["ref_default_nfev"], arrays["ref_default_maxres"]
+    info["flags"][3] = 3  # a step whose residual exceeded the tolerance: not converged
+    metrics = {"camber": np.linspace(-2.0, 1.0, pos.shape[0]), "damper_length": np.where(np.arange(pos.shape[0]) % 2, np.nan, 300.5)}
+    meta = provenance(tool="t")
+    table = ResultTable.from_batch(program, pos, info, metrics)
+    table.write_csv(tmp_path / "bulk.csv", meta)
+    writer = CsvWriter(tmp_path / "frames.csv")
+    writer.metadata = meta
+    for b, frame in enumerate(frames_from_batch(program, pos, info, metrics)):
+        writer.add_frame(b, frame)
+    writer.write()
+    assert (tmp_path / "bulk.csv").read_bytes() == (tmp_path / "frames.csv").read_bytes()
+    rows = list(csv.DictReader(ln for ln in (tmp_path / "bulk.csv").read_text().splitlines() if not ln.startswith("#")))
+    assert rows[3]["solver_converged"] == "False" and rows[2]["solver_converged"] == "True"
+    assert rows[1]["damper_length"] == "" and rows[0]["damper_length"] == "300.5"
+    table.write_parquet(tmp_path / "bulk.parquet", meta)
+    import pyarrow.parquet as pq
+
+    back = pq.read_table(tmp_path / "bulk.parquet")
+    assert back.column_names == list(table.columns)
+    assert back.column("damper_length").null_count == pos.shape[0] // 2
+    assert back.schema.field("solver_nfev").type == "int64" and back.schema.field("solver_converged").type == "bool"
+
+
+def test_a_million_row_ensemble_goes_to_parquet_in_seconds(tmp_path):
+    """BASELINE config 5's size (4096 geometries x 256 steps, 15 output points): arrays -> Parquet without per-row objects."""
+    import time
+
+    from open_kinematics_amd.results_writer import write_batch
+    from open_kinematics_amd.workloads import bump_sweep_problem
+
+    program, _ = bump_sweep_problem(2)
+    n = 4096 * 256
+    rng = np.random.default_rng(0)
+    pos = rng.normal(size=(n, program.n_out, 3))
+    info = np.zeros(n, dtype=[("flags", "<i4"), ("nfev", "<i4"), ("max_residual", "<f8")])
+    info["flags"], info["nfev"] = 1, 3
+    metrics = {"camber": rng.normal(size=n), "caster": rng.normal(size=n)}
+    t0 = time.perf_counter()
+    write_batch(tmp_path / "c5.parquet", program, pos, info, metrics)
+    elapsed = time.perf_counter() - t0
+    import pyarrow.parquet as pq
+
+    meta = pq.read_metadata(tmp_path / "c5.parquet")
+    assert meta.num_rows == n and meta.num_columns == 4 + 2 + 3 * program.n_out
+    assert elapsed < 5.0, f"{elapsed:.1f} s"

@@ -31,7 +31,7 @@ for targets_mapped in (False, True):
         h_info = torch.empty((n, 40), dtype=torch.uint8).pin_memory()
         with torch.cuda.stream(stream):
             d_t = torch.empty_like(h_t, device=dev)
-            launch = dp.plan(h_t if targets_mapped else d_t, out=h_free, info_out=h_info, output="free", **kw)
+            launch = dp.plan(h_t if targets_mapped else d_t, out=h_free, info_out=h_info, output="free", zero_copy=True, **kw)
         slots.append(dict(stream=stream, d_t=d_t, launch=launch, h_free=h_free, h_info=h_info, done=torch.cuda.Event()))
 
     def issue(slot):

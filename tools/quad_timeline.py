@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""C2 cold sweep: the cold body against the general body (same answers? time per launch), and - from a build generated with
+OKX_QUAD_TIMELINE=1 - where a wavefront's cycles go (shader-clock stamps of every wavefront: entry, first step in hand, top of
+each LM pass, passes done, records stored, end).
+   OKX_QUAD_TIMELINE=1 OKX_KERNEL_CACHE=/tmp/tl python3 tools/quad_timeline.py [n_problems]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from open_kinematics_amd.batch import DeviceProgram
+from open_kinematics_amd.workloads import bump_sweep_problem
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+dev = torch.device("cuda:0")
+program, targets = bump_sweep_problem(n)
+dp = DeviceProgram(program, dev)
+t = torch.as_tensor(targets, device=dev)
+out = torch.empty((n, program.n_out, 3), dtype=torch.float64, device=dev)
+info = torch.empty((n, 40), dtype=torch.uint8, device=dev)
+
+
+def run(label):
+    launch = dp.plan(t, out=out, info_out=info, chain_len=1, predictor=False)
+    for _ in range(300):
+        launch()
+    wall, ms = bench.time_launches(launch, 2000, 100, dev)
+    torch.cuda.synchronize()
+    pos = out.cpu().numpy().copy()
+    inf = np.frombuffer(info.cpu().numpy().tobytes(), dtype=[("max_residual", "f8"), ("cost", "f8"), ("last_step", "f8"), ("iterations", "i4"),
+                                                              ("nfev", "i4"), ("flags", "i4"), ("reserved", "i4")])
+    print(f"{label:10s}: {1e3 * ms:7.2f} us per launch, nfev mean {inf['nfev'].mean():.3f}, converged {np.all((inf['flags'] & 7) == 1)}")
+    return pos, inf
+
+
+if os.environ.get("OKX_QUAD_TIMELINE"):
+    waves = (n + 15) // 16
+    tr = torch.zeros((2 * waves, 16), dtype=torch.float64, device=dev)
+    dp.lib.okx_debug_quad_trace(dp._handle, C.c_void_p(tr.data_ptr()), -1)
+    launch = dp.plan(t, out=out, info_out=info, chain_len=1, predictor=False)
+    for _ in range(200):
+        launch()
+    torch.cuda.synchronize()
+    tr.zero_()
+    launch()
+    torch.cuda.synchronize()
+    both = tr.cpu().numpy()
+    a, sec = both[:waves], both[waves:]
+    dp.lib.okx_debug_quad_trace(dp._handle, None, -1)
+    t0 = a[:, 0].min()
+    rel = a - t0
+    names = ["entry", "first step in hand"] + [f"pass {k} top" for k in range(1, 11)] + ["(pass overflow)", "passes done", "records stored", "end"]
+    print("stamp (shader clock ticks since the first wavefront's entry): median / min / max over wavefronts; delta to previous stamp (median)")
+    prev = None
+    for k in range(16):
+        col = rel[:, k]
+        ok = a[:, k] > 0
+        if not ok.any():
+            continue
+        med = np.median(col[ok])
+        d = "" if prev is None else f"  +{med - prev:9.0f}"
+        print(f"  {k:2d} {names[k]:22s} n={ok.sum():5d}  {med:10.0f} {col[ok].min():10.0f} {col[ok].max():10.0f}{d}")
+        prev = med
+    per_wave = a[:, 15] - a[:, 0]
+    print(f"wavefront lifetime entry -> end: median {np.median(per_wave):.0f}, min {per_wave.min():.0f}, max {per_wave.max():.0f} ticks;"
+          f" whole launch (first entry -> last end) {(a[:, 15].max() - t0):.0f} ticks")
+    # sections of the second full pass (wavefronts that ran one): deltas along top -> derived points -> rows -> LM decision ->
+    # factorisation -> substitution -> end of pass
+    has = sec[:, 11] > 0
+    if has.any():
+        order = [(8, "derived points + chain blocks"), (9, "rows: residuals, gradients, J^T r, J^T J"), (10, "LM decision"),
+                 (5, "(to factorisation)"), (6, "LDL^T factorisation"), (7, "substitutions"), (11, "step norms, next-pass logic")]
+        prev = a[has, 3]
+        print(f"sections of the second full pass (median ticks over {has.sum()} wavefronts):")
+        for k, label in order:
+            cur = sec[has, k]
+            print(f"  {label:44s} {np.median(cur - prev):8.0f}")
+            prev = cur
+        nxt = np.where(a[has, 4] > 0, a[has, 4], a[has, 13])
+        print(f"  {'(to the next pass top / loop exit)':44s} {np.median(nxt - prev):8.0f}")
+    passes = (a[:, 2:12] > 0).sum(axis=1)
+    print("LM passes per wavefront:", dict(zip(*[x.tolist() for x in np.unique(passes, return_counts=True)])))
+    sys.exit(0)
+
+pos_c, inf_c = run("cold body")
+os.environ["OKX_QUAD_NO_COLD"] = "1"
+pos_g, inf_g = run("general")
+print(f"max |cold - general| = {np.max(np.abs(pos_c - pos_g)):.3e} mm; nfev equal: {np.array_equal(inf_c['nfev'], inf_g['nfev'])}")
