@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OKX_ABI_VERSION 3   /* 3: okx_solve_opts.output (+ reserved); lane kernel entry points.  2: confirm_full_pass; diagnostics moved to okx_debug.h */
+#define OKX_ABI_VERSION 4   /* 4: okx_rotation_role.kind / point_b (hardware metrics of composed axles), okx_program_has_cold_body, okx_program_ready.  3: okx_solve_opts.output (+ reserved); lane kernel entry points.  2: confirm_full_pass; diagnostics moved to okx_debug.h */
 
 /* Hard limits of one problem (one wavefront owns one problem). */
 #define OKX_MAX_VARS 126     /* n = 3 * free points (one thread per variable: one wavefront up to 63, two beyond) */
@@ -419,13 +419,31 @@ int32_t okx_axle_metrics_batch(const okx_corner_roles* left, const okx_corner_ro
  * A point on its axis (either perpendicular below 1e-6) reads NaN where the reference raises.
  */
 #define OKX_MAX_ROTATIONS 8
+/* What a role measures (`kind`).  0 is the rotation described above; the others are the state metrics of an axle's
+ * shared hardware that are not rotations of one point about a fixed axis (axle/mechanisms.py:718-815, :903-944),
+ * evaluated by the same kernel, with the same derivative columns:
+ *   1  rotation about the fixed axis of the MIDPOINT of output points `point` and `point_b` from `design` (a rigid T-bar's
+ *      t_bar_heave_angle: crossbar midpoint about the pivot's lateral axis, mechanisms.py:763-798), degrees x scale;
+ *   2  twist of the segment `point` - `point_b` about the MOVING stem from `axis_point` (the pivot) to the segment's
+ *      midpoint, measured from `axis_dir` (the lateral direction) and taken relative to `design[0]` (the design twist in
+ *      degrees): a T-bar's arb_twist (mechanisms.py:800-815), degrees;
+ *   3  distance between `point` and `point_b` (a rocker-to-rocker heave link's heave_link_length, mechanisms.py:934-944), mm;
+ *   4  coordinate of the midpoint of `point` and `point_b` along `axis_dir` from `axis_point` (t_bar_center_x and its
+ *      rate, mechanisms.py:718-761), mm. */
+#define OKX_ROLE_AXIS_ROTATION 0
+#define OKX_ROLE_MIDPOINT_ROTATION 1
+#define OKX_ROLE_STEM_TWIST 2
+#define OKX_ROLE_DISTANCE 3
+#define OKX_ROLE_MIDPOINT_COORDINATE 4
 typedef struct okx_rotation_role {
   int32_t point;         /* output-point index of the moving pickup   */
-  int32_t pad;
-  double design[3];      /* its design position                        */
+  int32_t point_b;       /* second output point (kinds 1-4; unused by kind 0) */
+  double design[3];      /* its design position (kind 2: design[0] = the design twist in degrees) */
   double axis_point[3];  /* a point on the fixed axis                  */
   double axis_dir[3];    /* unit direction of the axis                 */
   double scale;          /* Side.lateral_sign, or 1                    */
+  int32_t kind;          /* OKX_ROLE_* */
+  int32_t reserved;
 } okx_rotation_role;
 
 int32_t okx_axis_rotation_batch(const okx_rotation_role* roles, int32_t n_roles, int64_t n_states, int32_t n_out,
@@ -531,6 +549,14 @@ int32_t okx_program_shares_first_step(const okx_program* prog);
  * passes of an all-accepted solve under one exec mask, anything else redone through the general loop - same answers, bit
  * for bit, as `okx_quad_solve_u`).  What bench.py names as the dominant kernel of the headline launch. */
 int32_t okx_program_has_cold_body(const okx_program* prog);
+/* Tiered start.  okx_program_create loads a program's generated kernels when the kernel cache holds them (what
+ * okx_precompile and __graft_entry__.build() are for).  When it does not, the call still returns at once: a host thread
+ * runs the compiler (10 ... 80 s per module) while the interpreter kernels solve - same answers to 1e-9 mm, 20 ... 100 x
+ * slower - and the first launch after the job has finished switches the program over to the generated kernels (never in
+ * the middle of a launch, never blocking a stream).  okx_program_ready returns 1 when nothing is pending any more and 0
+ * while the job runs; wait != 0 blocks until it has finished and switches over before returning (benchmarks and tests
+ * that must know which kernel they time).  okx_program_kernel() / okx_program_kernel_note() report the current state. */
+int32_t okx_program_ready(okx_program* prog, int32_t wait);
 
 /* Generated source of a program's quad kernel (no device needed).  Copies at most buflen - 1
  * bytes plus a terminator into buf (buf may be NULL) and returns the size the full text

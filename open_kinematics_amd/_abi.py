@@ -8,7 +8,7 @@ import numpy as np
 
 from .program import ConstraintProgram
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)

@@ -32,6 +32,7 @@ EXPORTS = (
     "okx_program_kernel_note",
     "okx_program_shares_first_step",
     "okx_program_has_cold_body",
+    "okx_program_ready",
     "okx_quad_source",
     "okx_precompile",
     "okx_tangent_batch",
@@ -123,6 +124,8 @@ def load() -> C.CDLL:
     lib.okx_program_shares_first_step.restype = i32
     lib.okx_program_has_cold_body.argtypes = [vp]
     lib.okx_program_has_cold_body.restype = i32
+    lib.okx_program_ready.argtypes = [vp, i32]
+    lib.okx_program_ready.restype = i32
     lib.okx_quad_source.argtypes = [C.POINTER(ProgramDesc), C.c_char_p, i64]
     lib.okx_quad_source.restype = i64
     lib.okx_precompile.argtypes = [C.POINTER(ProgramDesc)]

@@ -73,7 +73,7 @@ def _check_buffer(name: str, t, device, zero_copy: bool) -> None:
 class DeviceProgram:
     """A constraint program resident on one GPU."""
 
-    def __init__(self, program: ConstraintProgram, device: torch.device | str | None = None):
+    def __init__(self, program: ConstraintProgram, device: torch.device | str | None = None, wait_for_kernels: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError(
                 "open_kinematics_amd needs a ROCm GPU: torch.cuda.is_available() is False "
@@ -87,6 +87,11 @@ class DeviceProgram:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.okx_program_create(self.host.byref(), C.byref(handle)), "okx_program_create")
         self._handle = handle
+        # Generated kernels that are not in the kernel cache are compiled on a host thread (okx.h: tiered start).  The batch
+        # API waits for them by default - its callers time and compare kernels; the drop-in passes False and starts
+        # solving at once on the interpreter kernels.
+        if wait_for_kernels:
+            self.wait_ready()
         self._predictor: bool | None = None  # None: no fit attempted yet (fit_predictor)
         self.predictor_box = None
         self._predictor_note = ""
@@ -105,6 +110,17 @@ class DeviceProgram:
     def shares_first_step(self) -> bool:
         """Chain heads of the own geometry take their first step from the shared first-step table (their ``nfev`` omits it)."""
         return bool(self.lib.okx_program_shares_first_step(self._handle))
+
+    @property
+    def ready(self) -> bool:
+        """False while the program's generated kernels are still being compiled (the interpreter kernels serve it)."""
+        with torch.cuda.device(self.device):
+            return bool(self.lib.okx_program_ready(self._handle, 0))
+
+    def wait_ready(self) -> None:
+        """Block until the compile job (if any) has finished and the program has switched to its generated kernels."""
+        with torch.cuda.device(self.device):
+            _lib.check(0 if self.lib.okx_program_ready(self._handle, 1) >= 0 else -1, "okx_program_ready")
 
     @property
     def has_cold_body(self) -> bool:

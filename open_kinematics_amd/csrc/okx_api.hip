@@ -10,8 +10,10 @@
 
 #include <cmath>
 #include <functional>
+#include <atomic>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "okx_kernels.hip"
@@ -61,6 +63,12 @@ struct okx_program {
   struct HeadTable { double lambda0; double* dev; hipEvent_t ready; hipStream_t filled_on; };
   std::vector<HeadTable>* head_tables;
   std::mutex* head_mutex;
+  // Tiered start.  A program whose generated kernels are not in the kernel cache is served by the interpreter kernels
+  // while a host thread runs the compiler (hiprtc: no device call on that thread); the first entry point that finds the
+  // job finished loads the code objects and switches the program over, under `head_mutex`.  Null: nothing pending.
+  struct JitJob { std::thread thread; std::atomic<int> finished{0}; };
+  JitJob* jit;
+  std::mutex* jit_mutex;
   double* head_geom_dev;    // scratch table of the latest launch with geometry tables (grow-only)
   long long head_geom_cap;  // geometries it holds
   double* quad_trace;            // diagnostic hook, see okx_debug_quad_trace (null: off)
@@ -186,18 +194,10 @@ int resident_blocks_per_cu(const void* fn, size_t lds_bytes, int threads = okx::
   const int by_lds = (int)((160 * 1024) / (lds_bytes ? lds_bytes : 1));
   if (by_lds < occ) occ = by_lds;
   if (occ < 1) occ = 1;
-  if (const char* cap = getenv("OKX_BLOCKS_PER_CU")) {  // tuning knob
-    const int c = atoi(cap);
-    if (c >= 1 && c < occ) occ = c;
-  }
   return occ;
 }
 
 int quad_waves_per_simd() {
-  if (const char* env = getenv("OKX_QUAD_WAVES")) {
-    const int w = atoi(env);
-    if (w >= 1 && w <= 8) return w;
-  }
   return 1;
 }
 
@@ -246,7 +246,9 @@ int own_head_table(okx_program* p, double lambda0, hipStream_t stream, double** 
 // Generate, compile (or fetch from the cache) and load the kernel specialised to this program.
 // Failure is not an error of okx_program_create: the generic kernels stay in charge and
 // okx_program_kernel_note() says why.
-void attach_quad_kernel(okx_program* p) {
+// `cache_only`: only what the kernel cache already holds (okx_program_create); a miss sets *pending and leaves the
+// interpreter kernels in charge until the compile job has filled the cache.
+void attach_quad_kernel(okx_program* p, bool cache_only = false, bool* pending = nullptr) {
   p->quad_mod = nullptr;
   p->quad_fn_u = p->quad_fn_g = nullptr;
   p->quad_fn_cold_u = nullptr;
@@ -256,14 +258,17 @@ void attach_quad_kernel(okx_program* p) {
   p->quad_waves_per_cu = 0;
   p->quad_ppw = p->host.n_free > okx::kQuadMaxFree ? 8 : 16;
   p->quad_note[0] = 0;
-  if (const char* env = getenv("OKX_QUAD")) {
-    if (env[0] == '0') {
-      std::snprintf(p->quad_note, sizeof(p->quad_note), "disabled by OKX_QUAD=0");
-      return;
-    }
+  if (okx::dev_switch("no_quad")) {  // (tests: the interpreter kernels on a program that has generated ones)
+    std::snprintf(p->quad_note, sizeof(p->quad_note), "disabled by OKX_DEV=no_quad");
+    return;
   }
   std::string src, why, code;
-  if (!okx::quad_build(p->host, quad_waves_per_simd(), &src, &code, &why)) {
+  if (!okx::quad_build(p->host, quad_waves_per_simd(), &src, &code, &why, false, cache_only)) {
+    if (cache_only && why == okx::kNotCached) {
+      if (pending) *pending = true;
+      std::snprintf(p->quad_note, sizeof(p->quad_note), "being compiled (the interpreter kernels serve the program until then)");
+      return;
+    }
     std::snprintf(p->quad_note, sizeof(p->quad_note), "not generated: %.200s", why.c_str());
     if (getenv("OKX_VERBOSE")) std::fprintf(stderr, "okx: quad kernel: %s\n", why.c_str());
     return;
@@ -295,12 +300,7 @@ void attach_quad_kernel(okx_program* p) {
     if (per_simd > 8) per_simd = 8;
     if (per_simd < 1) per_simd = 1;
   }
-  if (const char* cap = getenv("OKX_QUAD_RESIDENT")) {
-    const int c = atoi(cap);
-    if (c >= 1 && c < per_simd) per_simd = c;
-  }
   p->quad_mod = mod;
-  p->quad_fn_u = fu;
   p->quad_fn_g = fg;
   if (hipModuleGetFunction(&p->quad_fn_eval, mod, "okx_quad_eval") != hipSuccess) p->quad_fn_eval = nullptr;
   if (hipModuleGetFunction(&p->quad_fn_expand, mod, "okx_quad_expand") != hipSuccess) p->quad_fn_expand = nullptr;
@@ -327,11 +327,14 @@ void attach_quad_kernel(okx_program* p) {
       p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
     }
   }
+  // the gate every launch path tests, published last (a program may be switched over while it is in use)
+  std::atomic_thread_fence(std::memory_order_release);
+  p->quad_fn_u = fu;
 }
 
 // The lane kernel of a program that has a quad kernel (same policy: failure only means the quad kernel serves every
 // batch size; okx_program_lane_note() says why).
-void attach_lane_kernel(okx_program* p) {
+void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending = nullptr) {
   p->lane_mod = nullptr;
   p->lane_fn_u = p->lane_fn_g = p->lane_fn_eval = nullptr;
   p->lane_chain_u = p->lane_chain_g = nullptr;
@@ -340,19 +343,21 @@ void attach_lane_kernel(okx_program* p) {
   // round of it (~21 us for the double wishbone).  One problem more is a second round (~38 us), while the lane kernel
   // takes 25 ... 29 us for anything up to n_cu * 4 * 64 problems (tools/lane_threshold.py): auto selection switches there.
   p->lane_min_problems = (long long)p->n_cu * 4 * 16 + 1;
-  if (const char* env = getenv("OKX_LANE_MIN")) p->lane_min_problems = atoll(env);
   if (!p->quad_fn_u || p->quad_ppw != 16) {
     std::snprintf(p->lane_note, sizeof(p->lane_note), "no single-mode quad kernel to share first-step tables with");
     return;
   }
-  if (const char* env = getenv("OKX_LANE")) {
-    if (env[0] == '0') {
-      std::snprintf(p->lane_note, sizeof(p->lane_note), "disabled by OKX_LANE=0");
-      return;
-    }
+  if (okx::dev_switch("no_lane")) {
+    std::snprintf(p->lane_note, sizeof(p->lane_note), "disabled by OKX_DEV=no_lane");
+    return;
   }
   std::string src, why, code;
-  if (!okx::lane_build(p->host, &src, &code, &why)) {
+  if (!okx::lane_build(p->host, &src, &code, &why, false, nullptr, 256, cache_only)) {
+    if (cache_only && why == okx::kNotCached) {
+      if (pending) *pending = true;
+      std::snprintf(p->lane_note, sizeof(p->lane_note), "being compiled");
+      return;
+    }
     std::snprintf(p->lane_note, sizeof(p->lane_note), "not generated: %.200s", why.c_str());
     return;
   }
@@ -361,14 +366,13 @@ void attach_lane_kernel(okx_program* p) {
   // looping chain body (668 B) was 8 % slower than the quad kernel's chains; MacPherson (0 B) wins both ways.
   p->lane_cold_scratch = okx::quad_code_scratch_bytes(code, "okx_lane_solve");
   p->lane_chain_scratch = okx::quad_code_scratch_bytes(code, "okx_lane_chain");
-  const bool any = getenv("OKX_LANE_ALLOW_SCRATCH") != nullptr;
-  p->lane_cold_ok = p->lane_cold_scratch >= 0 && (any || p->lane_cold_scratch <= 256);
+  p->lane_cold_ok = p->lane_cold_scratch >= 0 && p->lane_cold_scratch <= 256;
   // ... and a flat chain body (okx_quad.hpp lane_chain_is_flat: the double wishbone; 0 B of scratch) is correct but does not
   // pay: each chain step repeats the independent solve's prologue and its records leave lane by lane, so 4096 x 256 in
   // chains of 4 takes 0.62 ms against 0.51 ms of independent solves, and a 1048576-step sweep of one geometry 0.47
   // against 0.43 ms although its evaluations drop from 2.97 to 1.53 (tools/lane_chain_modes.py, lane_chain_own.py).
   // Auto selection keeps resolving chain_len = -1 to independent solves there; kernel = 4 with chains runs it.
-  p->lane_chain_ok = p->lane_chain_scratch >= 0 && (any || (p->lane_chain_scratch == 0 && !okx::lane_chain_is_flat(p->host.n)));
+  p->lane_chain_ok = p->lane_chain_scratch == 0 && !okx::lane_chain_is_flat(p->host.n);
   if (!p->lane_cold_ok && !p->lane_chain_ok) {
     std::snprintf(p->lane_note, sizeof(p->lane_note), "the lane kernel of this program spills (%d / %d B of scratch): not used",
                   p->lane_cold_scratch, p->lane_chain_scratch);
@@ -376,16 +380,17 @@ void attach_lane_kernel(okx_program* p) {
   }
   hipModule_t mod = nullptr;
   hipError_t e = hipModuleLoadData(&mod, code.data());
-  if (e != hipSuccess) {
+  if (e != hipSuccess && !cache_only) {
     (void)hipGetLastError();
-    if (okx::lane_build(p->host, &src, &code, &why, true)) e = hipModuleLoadData(&mod, code.data());
+    if (okx::lane_build(p->host, &src, &code, &why, true, nullptr, 256)) e = hipModuleLoadData(&mod, code.data());
   }
   if (e != hipSuccess) {
     (void)hipGetLastError();
     std::snprintf(p->lane_note, sizeof(p->lane_note), "hipModuleLoadData: %s", hipGetErrorString(e));
     return;
   }
-  if (hipModuleGetFunction(&p->lane_fn_u, mod, "okx_lane_solve_u") != hipSuccess ||
+  hipFunction_t lane_u = nullptr;
+  if (hipModuleGetFunction(&lane_u, mod, "okx_lane_solve_u") != hipSuccess ||
       hipModuleGetFunction(&p->lane_fn_g, mod, "okx_lane_solve_g") != hipSuccess ||
       hipModuleGetFunction(&p->lane_chain_u, mod, "okx_lane_chain_u") != hipSuccess ||
       hipModuleGetFunction(&p->lane_chain_g, mod, "okx_lane_chain_g") != hipSuccess ||
@@ -402,6 +407,39 @@ void attach_lane_kernel(okx_program* p) {
     return;
   }
   p->lane_mod = mod;
+  std::atomic_thread_fence(std::memory_order_release);
+  p->lane_fn_u = lane_u;  // the gate of the lane kernel's launch path, published last
+}
+
+// The compile job of a program whose kernels were not in the cache: fills the cache (same calls, same policy as the
+// attach functions make), touches nothing of the program but its host copy.  No device call on this thread.
+void jit_job(okx_program* p) {
+  std::string src, code, why;
+  if (okx::quad_build(p->host, quad_waves_per_simd(), &src, &code, &why) && p->host.n_free <= okx::kQuadMaxFree &&
+      !okx::dev_switch("no_lane")) {
+    std::string lsrc, lcode, lwhy;
+    (void)okx::lane_build(p->host, &lsrc, &lcode, &lwhy, false, nullptr, 256);
+  }
+  p->jit->finished.store(1, std::memory_order_release);
+}
+
+// Switches a program over to its generated kernels once the compile job is done (`wait`: block until it is).  Called at
+// the top of every entry point that launches; costs one pointer test when nothing is pending.
+void attach_when_ready(okx_program* p, bool wait) {
+  if (!p->jit) return;
+  if (!wait && !p->jit->finished.load(std::memory_order_acquire)) return;
+  std::lock_guard<std::mutex> lock(*p->jit_mutex);
+  if (!p->jit) return;  // another caller got here first
+  okx_program::JitJob* job = p->jit;
+  job->thread.join();
+  int current = p->device;
+  (void)hipGetDevice(&current);
+  if (current != p->device) (void)hipSetDevice(p->device);
+  attach_quad_kernel(p);  // a cache hit now - or the failure the job met, reported through the notes as usual
+  attach_lane_kernel(p);
+  if (current != p->device) (void)hipSetDevice(current);
+  p->jit = nullptr;
+  delete job;
 }
 
 // frees the first-step tables and the host-side containers (every exit path of okx_program_create / _destroy)
@@ -416,6 +454,8 @@ void release_host_side(okx_program* p) {
   }
   delete p->head_mutex;
   p->head_mutex = nullptr;
+  delete p->jit_mutex;
+  p->jit_mutex = nullptr;
 }
 
 int grid_for(const okx_program* p, long long units) {
@@ -465,9 +505,11 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   std::memset(p, 0, sizeof(*p));
   p->head_tables = new (std::nothrow) std::vector<okx_program::HeadTable>();
   p->head_mutex = new (std::nothrow) std::mutex();
-  if (!p->head_tables || !p->head_mutex) {
+  p->jit_mutex = new (std::nothrow) std::mutex();
+  if (!p->head_tables || !p->head_mutex || !p->jit_mutex) {
     delete p->head_tables;
     delete p->head_mutex;
+    delete p->jit_mutex;
     delete p;
     return fail(OKX_ERR_ALLOC, "out of host memory");
   }
@@ -526,21 +568,50 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
     if (e != hipSuccess) {
       (void)hipFree(p->dev);
       release_host_side(p);
-      release_host_side(p);
-    delete p;
+      delete p;
       return fail(OKX_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
     }
   }
   p->blocks_per_cu = resident_blocks_per_cu(p->solve_fn, p->solve_lds_bytes, p->threads);
   p->packed_blocks_per_cu = p->packed_fn ? resident_blocks_per_cu(p->packed_fn, p->packed_lds_bytes) : 0;
-  attach_quad_kernel(p);
-  attach_lane_kernel(p);
+  // Generated kernels: loaded here when the kernel cache has them (the usual case: __graft_entry__.build() and
+  // okx_precompile fill it).  Otherwise a host thread compiles them (10 ... 80 s per module) while this call returns at
+  // once and the interpreter kernels solve; the first launch after the job is done switches the program over.
+  bool pending = false;
+  attach_quad_kernel(p, true, &pending);
+  if (!pending) attach_lane_kernel(p, true, &pending);
+  if (pending) {
+    p->jit = new (std::nothrow) okx_program::JitJob;
+    if (p->jit) {
+      try {
+        p->jit->thread = std::thread(jit_job, p);
+      } catch (...) {  // no thread to be had: compile here, as before
+        delete p->jit;
+        p->jit = nullptr;
+      }
+    }
+    if (!p->jit) {
+      attach_quad_kernel(p);
+      attach_lane_kernel(p);
+    }
+  }
   *out = p;
   return OKX_OK;
 }
 
+int32_t okx_program_ready(okx_program* p, int32_t wait) {
+  if (!p) return fail(OKX_ERR_INVALID, "null program");
+  attach_when_ready(p, wait != 0);
+  return p->jit ? 0 : 1;
+}
+
 void okx_program_destroy(okx_program* p) {
   if (!p) return;
+  if (p->jit) {  // a compile job still running: let it finish (it fills the cache for the next program), load nothing
+    p->jit->thread.join();
+    delete p->jit;
+    p->jit = nullptr;
+  }
   if (p->quad_mod) (void)hipModuleUnload(p->quad_mod);
   if (p->lane_mod) (void)hipModuleUnload(p->lane_mod);
   if (p->predictor_dev) (void)hipFree(p->predictor_dev);
@@ -666,6 +737,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
                         const double* d_geom_row_param, double* d_out_pos, okx_info* d_info,
                         void* stream) {
   if (!p || !opts) return fail(OKX_ERR_INVALID, "null program or options");
+  attach_when_ready(p, false);
   if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
   if (n_problems == 0) return OKX_OK;
   if (opts->output < OKX_OUTPUT_RECORDS || opts->output > OKX_OUTPUT_NONE) return fail(OKX_ERR_INVALID, "unknown output mode");
@@ -692,7 +764,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   // point-on-line valley: the step length says nothing about the distance there
   bool degenerate_line = false;
   for (int i = 0; i < p->host.n_crows; ++i) degenerate_line = degenerate_line || p->host.row_type[i] == OKX_ROW_POINT_ON_LINE;
-  a.confirm = (opts->confirm_full_pass != 0 || degenerate_line || getenv("OKX_QUAD_CONFIRM") != nullptr) ? 1 : 0;
+  a.confirm = (opts->confirm_full_pass != 0 || degenerate_line) ? 1 : 0;
   // Kernel choice (profiles/r01/config_sweep_v3.txt).  The packed kernel keeps more problems in
   // flight per CU (G lane groups x resident waves): measured 1.5x on saturating batches of
   // n <= 15 systems (MacPherson grid), no gain for n = 18 (DW corner), so auto = packed only
@@ -739,7 +811,6 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   if (p->packed_fn && !use_quad) {
     if (opts->kernel == 2) use_packed = true;
     else if (opts->kernel == 0) use_packed = p->nreg <= 15 && n_problems >= 8 * single_slots;
-    if (const char* env = getenv("OKX_PACKED")) use_packed = env[0] == '1';
   }
   {
     const long long span = spg > 0 ? spg : n_problems;
@@ -867,8 +938,10 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     hipFunction_t fn = d_geom_pos ? p->quad_fn_g : p->quad_fn_u;
     // independent solves from the own geometry's design state with its first-step table and nothing the general body
     // alone offers (fitted model, LM trace, gradient stop): the cold body
-    if (p->quad_fn_cold_u && !d_geom_pos && a.chain_len == 1 && q.head != nullptr && q.predictor == nullptr && (q.trace == nullptr || getenv("OKX_QUAD_TIMELINE")) &&
-        opts->grad_tol <= 0.0 && !getenv("OKX_QUAD_NO_COLD"))
+    // (not for programs with the reference's zero-gradient line row: their solves reject steps as a matter of course,
+    //  which the cold body answers by starting over in its general loop - measured 4 % slower than the general body)
+    if (p->quad_fn_cold_u && !degenerate_line && !d_geom_pos && a.chain_len == 1 && q.head != nullptr && q.predictor == nullptr && (q.trace == nullptr || okx::dev_switch("quad_timeline")) &&
+        opts->grad_tol <= 0.0 && !okx::dev_switch("no_cold"))
       fn = p->quad_fn_cold_u;
     HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
     return OKX_OK;
@@ -904,8 +977,9 @@ int32_t okx_program_has_predictor(const okx_program* p) { return p && p->predict
    replaces the previous model. */
 int32_t okx_program_fit_predictor(okx_program* p, const double* lo, const double* hi, int32_t degree, void* stream) {
   if (!p || !lo || !hi) return fail(OKX_ERR_INVALID, "null pointer");
+  attach_when_ready(p, false);
   if (!p->quad_fn_u) return fail(OKX_ERR_INVALID, "the predictor belongs to the quad kernel: %s", p->quad_note);
-  if (p->quad_ppw != 16 && !getenv("OKX_PAIR_MODEL")) return fail(OKX_ERR_INVALID, "pair-mode kernels carry no predictor (register-bound)");
+  if (p->quad_ppw != 16) return fail(OKX_ERR_INVALID, "pair-mode kernels carry no predictor (register-bound)");
   const okx::DevProgram& H = p->host;
   const int T = H.n_targets;
   if (T < 1) return fail(OKX_ERR_INVALID, "program has no targets");
@@ -1095,13 +1169,14 @@ int32_t okx_rebind_design(okx_program* p, int64_t n_geometries, const double* d_
 int32_t okx_expand_positions_batch(okx_program* p, int64_t n_problems, int64_t steps_per_geometry, const double* d_free,
                                    const double* d_geom_pos, double* d_out_pos, void* stream) {
   if (!p) return fail(OKX_ERR_INVALID, "null program");
+  attach_when_ready(p, false);
   if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
   if (n_problems == 0) return OKX_OK;
   if (!d_free || !d_out_pos) return fail(OKX_ERR_INVALID, "null pointer");
   if (steps_per_geometry < 0 || (d_geom_pos && steps_per_geometry == 0) ||
       (steps_per_geometry > 0 && n_problems % steps_per_geometry != 0))
     return fail(OKX_ERR_INVALID, "bad steps_per_geometry");
-  if (p->quad_fn_expand && !getenv("OKX_EXPAND_GENERIC")) {  // generated form: 16 states per wavefront, coalesced records
+  if (p->quad_fn_expand) {  // generated form: 16 states per wavefront, coalesced records
     okx::QuadExpandArgs q;
     q.free = d_free;
     q.geom_pos = d_geom_pos;
@@ -1135,6 +1210,7 @@ int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_
                           const double* d_geom_pos, const double* d_geom_row_param, double* d_tangents,
                           okx_tangent_info* d_tinfo, void* stream) {
   if (!p) return fail(OKX_ERR_INVALID, "null program");
+  attach_when_ready(p, false);
   if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
   if (n_problems == 0) return OKX_OK;
   if (!d_pos || !d_tangents || !d_tinfo) return fail(OKX_ERR_INVALID, "null pointer");
@@ -1144,7 +1220,7 @@ int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_
       (steps_per_geometry > 0 && n_problems % steps_per_geometry != 0))
     return fail(OKX_ERR_INVALID, "bad steps_per_geometry");
   if (p->host.n_targets == 0) return OKX_OK;
-  if (!p->quad_fn_tan_u || getenv("OKX_TANGENT_GENERIC")) {
+  if (!p->quad_fn_tan_u || okx::dev_switch("tangent_generic")) {  // (tests: the interpreter's tangent kernel on a program with a generated one)
     // generic interpreter form: one wavefront per state (programs without a quad kernel)
     okx::TangentArgs t;
     t.pos = d_pos;
@@ -1226,6 +1302,10 @@ int32_t okx_axis_rotation_batch(const okx_rotation_role* roles, int32_t n_roles,
   okx::RotationArgs a;
   for (int k = 0; k < n_roles; ++k) {
     if (roles[k].point < 0 || roles[k].point >= n_out) return fail(OKX_ERR_INVALID, "rotation %d: not an output point", k);
+    if (roles[k].kind < OKX_ROLE_AXIS_ROTATION || roles[k].kind > OKX_ROLE_MIDPOINT_COORDINATE)
+      return fail(OKX_ERR_INVALID, "rotation %d: unknown kind %d", k, roles[k].kind);
+    if (roles[k].kind != OKX_ROLE_AXIS_ROTATION && (roles[k].point_b < 0 || roles[k].point_b >= n_out))
+      return fail(OKX_ERR_INVALID, "rotation %d: second point is not an output point", k);
     const double* d = roles[k].axis_dir;
     const double len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     if (!(std::fabs(len - 1.0) <= 1e-9)) return fail(OKX_ERR_INVALID, "rotation %d: axis_dir must be a unit vector", k);
@@ -1345,6 +1425,7 @@ int32_t okx_debug_quad_eval(okx_program* p, int64_t n_problems, const double* d_
                             double lambda, double* d_r, double* d_ata, double* d_atr, double* d_dx,
                             void* stream) {
   if (!p || !d_x || !d_r || !d_ata || !d_atr || !d_dx) return fail(OKX_ERR_INVALID, "null pointer");
+  attach_when_ready(p, false);
   if (!p->quad_fn_eval) return fail(OKX_ERR_INVALID, "no quad kernel: %s", p->quad_note);
   if (n_problems <= 0) return OKX_OK;
   okx::QuadEvalArgs q;
@@ -1372,6 +1453,7 @@ int32_t okx_debug_lane_eval(okx_program* p, int64_t n_problems, const double* d_
                             double lambda, double* d_r, double* d_ata, double* d_atr, double* d_dx,
                             void* stream) {
   if (!p || !d_x || !d_r || !d_ata || !d_atr || !d_dx) return fail(OKX_ERR_INVALID, "null pointer");
+  attach_when_ready(p, false);
   if (!p->lane_fn_eval) return fail(OKX_ERR_INVALID, "no lane kernel: %s", p->lane_note);
   if (n_problems <= 0) return OKX_OK;
   okx::QuadEvalArgs q;

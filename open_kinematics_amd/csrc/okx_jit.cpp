@@ -17,6 +17,23 @@
 #include "okx_quad.hpp"
 
 namespace okx {
+bool dev_switch(const char* name) {
+  const char* env = getenv("OKX_DEV");
+  if (!env || !name) return false;
+  const size_t n = std::strlen(name);
+  for (const char* at = env; *at;) {
+    const char* end = std::strchr(at, ',');
+    const size_t len = end ? (size_t)(end - at) : std::strlen(at);
+    if (len >= n && std::strncmp(at, name, n) == 0 && (len == n || at[n] == '=')) {
+      // `name` or `name=1` switch it on, `name=0` leaves it off
+      return !(len == n + 2 && at[n + 1] == '0');
+    }
+    if (!end) break;
+    at = end + 1;
+  }
+  return false;
+}
+
 namespace {
 
 // fp contraction stays at HIP's default (fast-honor-pragmas): the generated source switches it
@@ -94,37 +111,27 @@ void write_file_atomic(const std::string& path, const std::string& data) {
 
 }  // namespace
 
-bool quad_compile(const std::string& src, std::string* code, std::string* err, bool ignore_cached) {
+const char* const kNotCached = "not in the kernel cache";
+
+bool quad_compile(const std::string& src, std::string* code, std::string* err, bool ignore_cached, bool cache_only) {
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
   unsigned long long h = fnv1a(src);
   for (int k = 0; k < kNumOptions; ++k) h = fnv1a(kOptions[k], h);
-  // OKX_KERNEL_EXTRA_OPTS: extra compiler options (space separated) for A/B experiments; part of the cache key
-  std::vector<std::string> extra;
-  if (const char* env = getenv("OKX_KERNEL_EXTRA_OPTS")) {
-    std::string word;
-    for (const char* ch = env;; ++ch) {
-      if (*ch == ' ' || *ch == '\0') {
-        if (!word.empty()) extra.push_back(word);
-        word.clear();
-        if (*ch == '\0') break;
-      } else {
-        word += *ch;
-      }
-    }
-  }
-  for (const std::string& o : extra) h = fnv1a(o, h);
   h = fnv1a(std::to_string(major) + "." + std::to_string(minor), h);
   char name[64];
   std::snprintf(name, sizeof(name), "/okxq_%016llx", h);
   const std::string dir = cache_dir();
   const std::string path = dir + name + ".okxc";  // header + gfx950 code object
-  const bool no_cache = getenv("OKX_KERNEL_NOCACHE") != nullptr;
-  if (!no_cache && !ignore_cached) {
+  if (!ignore_cached) {
     std::string file;
     if (read_file(path, &file) && unwrap_entry(file, code)) return true;
   }
 
+  if (cache_only) {
+    *err = kNotCached;
+    return false;
+  }
   hiprtcProgram prog;
   hiprtcResult rc = hiprtcCreateProgram(&prog, src.c_str(), "okx_quad.hip", 0, nullptr, nullptr);
   if (rc != HIPRTC_SUCCESS) {
@@ -132,7 +139,6 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err, b
     return false;
   }
   std::vector<const char*> options(kOptions, kOptions + kNumOptions);
-  for (const std::string& o : extra) options.push_back(o.c_str());
   rc = hiprtcCompileProgram(prog, (int)options.size(), options.data());
   if (rc != HIPRTC_SUCCESS) {
     size_t log_size = 0;
@@ -158,11 +164,9 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err, b
     *err = "hiprtcGetCode failed";
     return false;
   }
-  if (!no_cache) {
-    (void)mkdir(dir.c_str(), 0777);
-    write_file_atomic(path, wrap_entry(*code));
-    if (getenv("OKX_KERNEL_KEEP_SOURCE")) write_file_atomic(dir + name + ".hip", src);
-  }
+  (void)mkdir(dir.c_str(), 0777);
+  write_file_atomic(path, wrap_entry(*code));
+  if (dev_switch("keep_source")) write_file_atomic(dir + name + ".hip", src);
   return true;
 }
 
@@ -208,16 +212,15 @@ int quad_code_lds_bytes(const std::string& code, const char* prefix) {
   return code_kernel_field(code, prefix, ".group_segment_fixed_size", true);
 }
 
-bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::string* why, bool ignore_cached, int* variant_out) {
+bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::string* why, bool ignore_cached, int* variant_out,
+                int good_enough_scratch, bool cache_only) {
   std::string src0, err;
   if (!lane_generate(P, &src0, why, 0)) return false;
   char name[64];
   std::snprintf(name, sizeof(name), "/okxl_%016llx.lanevar", fnv1a(src0));
   const std::string memo = cache_dir() + name;
-  const bool no_cache = getenv("OKX_KERNEL_NOCACHE") != nullptr;
   int first = 0, last = lane_variant_count() - 1;
-  if (const char* env = getenv("OKX_LANE_VARIANT")) first = last = atoi(env);  // (experiment switch: one variant only)
-  else if (!no_cache) {
+  {
     std::string text;
     if (read_file(memo, &text)) {
       const int v = atoi(text.c_str());
@@ -230,8 +233,9 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
     std::string s1, c1, w1;
     if (v == 0) s1 = src0;
     else if (!lane_generate(P, &s1, &w1, v)) continue;
-    if (!quad_compile(s1, &c1, &err, ignore_cached)) {
-      if (best < 0) *why = "compile failed: " + err;
+    if (!quad_compile(s1, &c1, &err, ignore_cached, cache_only)) {
+      if (best < 0) *why = err == kNotCached ? err : "compile failed: " + err;
+      if (cache_only) break;  // (a variant search is a compile job)
       continue;
     }
     const int scratch = quad_code_scratch_bytes(c1, "okx_lane_solve");
@@ -241,10 +245,10 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
       best_src.swap(s1);
       best_code.swap(c1);
     }
-    if (best_scratch == 0) break;
+    if (best_scratch <= good_enough_scratch) break;
   }
   if (best < 0) return false;
-  if (first != last && !no_cache) {
+  if (first != last && best_scratch == 0) {  // (only a search that ran to its goal is remembered)
     (void)mkdir(cache_dir().c_str(), 0777);
     write_file_atomic(memo, std::to_string(best) + "\n");
   }
@@ -257,23 +261,28 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
 constexpr int kPairScratchOk = 256;
 
 bool quad_build(const DevProgram& P, int waves_per_simd, std::string* src, std::string* code, std::string* why,
-                bool ignore_cached) {
+                bool ignore_cached, bool cache_only) {
   std::string err;
-  const char* layout = getenv("OKX_PAIR_LAYOUT");  // "regs" / "lds": force one of the two pair-mode layouts (measurement)
-  const bool force_lds = layout && std::string(layout) == "lds" && P.n_free > kQuadMaxFree;
+  const bool force_lds = dev_switch("pair_lds_homes") && P.n_free > kQuadMaxFree;  // (tests: the LDS-homes layout of a pair program)
   if (!quad_generate(P, waves_per_simd, src, why, force_lds)) return false;
-  if (!quad_compile(*src, code, &err, ignore_cached)) {
-    *why = "compile failed: " + err;
+  if (!quad_compile(*src, code, &err, ignore_cached, cache_only)) {
+    *why = err == kNotCached ? err : "compile failed: " + err;
     return false;
   }
-  if (layout) return true;
+  if (force_lds) return true;
   // Pair mode: up to kPairScratchOk bytes of scratch the register-resident layout stays - measured on the axle grid with
   // the second-order first step (164 B, almost all of it prologue temporaries): 0.403 ms per cold grid against 0.796 ms
   // for the LDS-homes layout, whose 42 KB of LDS leave three wavefronts per CU instead of four.
   if (P.n_free <= kQuadMaxFree || quad_code_scratch_bytes(*code, "okx_quad_solve") <= kPairScratchOk) return true;
   // beyond that (round 1's 636 B, re-read in every pass): constants and fixed points back to LDS, if that fits
   std::string src2, code2, why2;
-  if (!quad_generate(P, waves_per_simd, &src2, &why2, true) || !quad_compile(src2, &code2, &err, ignore_cached)) return true;
+  if (!quad_generate(P, waves_per_simd, &src2, &why2, true) || !quad_compile(src2, &code2, &err, ignore_cached, cache_only)) {
+    if (cache_only && err == kNotCached) {  // the fallback layout was never compiled: the compile job decides
+      *why = kNotCached;
+      return false;
+    }
+    return true;
+  }
   if (quad_code_lds_bytes(code2, "okx_quad_solve") > 40 * 1024) return true;  // four wavefronts per CU need <= 40 KB each
   if (quad_code_scratch_bytes(code2, "okx_quad_solve") < quad_code_scratch_bytes(*code, "okx_quad_solve")) {
     *src = src2;

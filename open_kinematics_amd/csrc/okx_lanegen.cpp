@@ -857,16 +857,8 @@ class LGen {
   // whole factor through the AGPRs (measured: 912 moves for 1407 fp64 instructions in this block) and spills.
   // Leaves L{i}_{j} (parked or resident), dinv{j}, y{i}, ok, pmin, pmax.
   int col_fence = 3;     // scheduling barrier after every col_fence columns (keeps the late assembly late)
-  // A HARD fence: an opaque, never-taken branch with a side effect ends the basic block, so neither instruction
-  // selection nor the machine scheduler (both work per block) can pull the next section's independent multiplications
-  // up into this one.  Measured on the double wishbone: rows alone 288 registers, factorisation alone 312, both in one
-  // block 590 (spilling) - the compiler starts assembling J^T J while the rows are still being evaluated.
-  bool hard_fence = false;
   bool launder = true;
-  void fence() {
-    if (hard_fence) f("    { int fz = 0; asm volatile(\"\" : \"+s\"(fz)); if (fz) __builtin_trap(); }");
-    else f("    __builtin_amdgcn_sched_barrier(0);");
-  }
+  void fence() { f("    __builtin_amdgcn_sched_barrier(0);"); }
   int resident_rows = 1 << 20; // rows of the factor (counted from the last) that are NOT parked in accumulation registers by hand: all of them
   std::set<std::pair<int, int>> parked;
   // ... or in LDS, where the body has slots to spare: [l_lds_base + k][lane], first rows first (they wait longest)
@@ -1099,7 +1091,6 @@ DEV double unpark(int lo, int hi) {
 int lane_variant_count() { return 8; }
 
 bool lane_chain_is_flat(int n_vars) {
-  if (const char* env = getenv("OKX_LANE_FLAT_CHAIN")) return env[0] == '1';
   return 80 - 4 * n_vars < 16;  // fewer than 16 of the 80 LDS slots left for the factor's rows beside x, dx, xp, xq
 }
 
@@ -1130,18 +1121,13 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // what is left of 40 KiB per wavefront once the geometry tables (gl) have their share
   int cold_j_slots = (40 * 1024 - 8 * (3 * P.n_points + 8 * (P.n_crows + P.n_targets) + (P.n_derived > 0 ? P.n_derived : 1)) - 256) / 512 - kColdStateSlots;
   if (cold_j_slots < 0) cold_j_slots = 0;
-  if (const char* env = getenv("OKX_LANE_J_SLOTS")) cold_j_slots = atoi(env);
   struct PassSrc { std::string eval, factor, subst; };
   auto make_pass = [&](LGen& gen, PassSrc* out) -> bool {
-    // (experiment switches.  Measured on the double wishbone, scratch bytes of the independent-solve bodies _u / _g:
-    //  pins + launder 0 / 188, pins only 160 / -, launder only 96 / 96, neither 0 / 0.  The register allocator's result
-    //  is not monotonic in anything; tools/lane_isa.sh + tools/lane_meta.py show it in ten seconds.)
-    gen.pin_acc = V.pin || getenv("OKX_LANE_PIN") != nullptr;
-    gen.hard_fence = getenv("OKX_LANE_HARD_FENCE") != nullptr;
-    gen.launder = V.launder || getenv("OKX_LANE_LAUNDER") != nullptr;
+    // (measured on the double wishbone, scratch bytes of the independent-solve bodies _u / _g: pins + launder 0 / 188, pins
+    //  only 160 / -, launder only 96 / 96, neither 0 / 0: the register allocator's result is not monotonic in anything)
+    gen.pin_acc = V.pin;
+    gen.launder = V.launder;
     gen.col_fence = V.col_fence;
-    if (const char* env = getenv("OKX_LANE_COL_FENCE")) gen.col_fence = atoi(env);
-    if (const char* env = getenv("OKX_LANE_RESIDENT_ROWS")) gen.resident_rows = atoi(env);
     for (int e = 0; e < P.n_derived; ++e) gen.dp(e);
     gen.f("    // ---- active derived points with chain-rule blocks ----");
     for (int idx = 0; idx < P.n_active; ++idx)
@@ -1171,14 +1157,12 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // 104 B, to the rows' gradients 432 B, hand-parked AGPR rows on top of either 250 - 1000 B (the allocator needs the
   // accumulation registers for its own spilling).  So: the factor's first rows in LDS, nothing parked by hand.
   int cold_l_slots = cold_j_slots;
-  if (const char* env = getenv("OKX_LANE_L_SLOTS")) cold_l_slots = atoi(env);
-  if (cold_l_slots > cold_j_slots) cold_l_slots = cold_j_slots;
   cold_j_slots -= cold_l_slots;
   evc.j_lds_base = kColdStateSlots;
   evc.j_lds_slots = cold_j_slots;
   evc.l_lds_base = kColdStateSlots + cold_j_slots;
   evc.l_lds_slots = cold_l_slots;
-  evc.late_diag = V.late_diag || getenv("OKX_LANE_LATE_DIAG") != nullptr;
+  evc.late_diag = V.late_diag;
   if (!make_pass(evc, &pass_cold)) {
     *why = evc.why;
     return false;
@@ -1243,7 +1227,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     gg.f("%sif (lane < %d) gl[%d + lane] = a.row_param[%d + lane];", indent, 8 * T, ev.gl_tq0, 8 * P.n_crows);
     gg.f("%sif (lane < %d) gl[%d + lane] = a.dop_param[lane];", indent, P.n_derived, ev.gl_dp0);
   };
-  const bool marks = getenv("OKX_LANE_MARK") != nullptr;  // `s_nop 11..16` between the sections of a pass (tools/lane_isa.sh)
+  const bool marks = dev_switch("lane_mark");  // `s_nop 11..16` between the sections of a pass (tools/lane_isa.sh)
 
   LGen g(P);
   g.out += kLanePreamble;
@@ -1524,7 +1508,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     // Two nested loops: the inner one runs full passes while any lane needs one; when every active lane only has a step to
     // confirm, the outer loop takes the residual-only pass and comes back (a lane whose step is not confirmed goes on with
     // full passes).  Same order of evaluations as one loop with the confirming pass as a branch at its top.
-    const bool nested = light_ok && getenv("OKX_LANE_FLAT_LOOP") == nullptr;
+    const bool nested = light_ok;
     if (nested) {
       g.f("      while (wave_any(!done)) {");
       g.f("    %s", refresh_kz);
@@ -1767,7 +1751,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     // solve kernels never hold it in that form
     LGen ee(P);
     ee.uid = 500000;
-    ee.early_ata = getenv("OKX_LANE_EVAL_NO_E") == nullptr;
+    ee.early_ata = true;
     ee.pin_acc = false;
     ee.hoisted_names = ev.hoisted_names;
     for (int idx = 0; idx < P.n_active; ++idx) (void)ee.derived_op(P.active_op[idx], true);

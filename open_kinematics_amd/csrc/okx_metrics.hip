@@ -284,13 +284,33 @@ struct RotationArgs {
   int n_out, n_targets;
 };
 
-// metrics/kernels.py:58-76 on duals; geometric.py:47-51: undefined for a point on the axis
+// metrics/kernels.py:58-76 on duals; geometric.py:47-51: undefined for a point on the axis.  The other kinds: the
+// hardware metrics of a composed axle (okx.h OKX_ROLE_*; axle/mechanisms.py:718-815, :903-944), same duals.
 __device__ __forceinline__ Dual axis_rotation_deg(const okx_rotation_role& R, const double* pos, const double* vel) {
   const double kDeg = 57.29577951308232;
   const DVec a = {{R.axis_dir[0], 0.0}, {R.axis_dir[1], 0.0}, {R.axis_dir[2], 0.0}};
   const DVec origin = {{R.axis_point[0], 0.0}, {R.axis_point[1], 0.0}, {R.axis_point[2], 0.0}};
+  DVec moving = load_point(pos, vel, R.point);
+  if (R.kind != OKX_ROLE_AXIS_ROTATION) {
+    const DVec other = load_point(pos, vel, R.point_b);
+    const DVec span = dsub(moving, other);  // `point` - `point_b` (left end - right end of a crossbar)
+    if (R.kind == OKX_ROLE_DISTANCE) return dsqrt(ddot(span, span));
+    const Dual half = {0.5, 0.0};
+    const DVec mid = dadd(moving, dscale(half, dsub(other, moving)));  // a + (b - a) / 2, the reference's midpoint
+    if (R.kind == OKX_ROLE_MIDPOINT_COORDINATE) return ddot(a, dsub(mid, origin));
+    if (R.kind == OKX_ROLE_STEM_TWIST) {  // mechanisms.py:800-815
+      DVec stem = dsub(mid, origin);
+      const Dual len = dsqrt(ddot(stem, stem));
+      if (!(len.v >= kEpsGeometric)) return dnan();
+      stem = dunit(stem, len);
+      const DVec crossbar = dsub(span, dscale(ddot(span, stem), stem));
+      const Dual twist = kDeg * datan2(ddot(stem, dcross(a, crossbar)), ddot(crossbar, a));
+      return {twist.v - R.design[0], twist.d};
+    }
+    moving = mid;  // OKX_ROLE_MIDPOINT_ROTATION: the midpoint about the fixed axis
+  }
   const DVec dr = {{R.design[0] - R.axis_point[0], 0.0}, {R.design[1] - R.axis_point[1], 0.0}, {R.design[2] - R.axis_point[2], 0.0}};
-  const DVec cr = dsub(load_point(pos, vel, R.point), origin);
+  const DVec cr = dsub(moving, origin);
   const DVec dperp = dsub(dr, dscale(ddot(dr, a), a)), cperp = dsub(cr, dscale(ddot(cr, a), a));
   if (!(sqrt(ddot(dperp, dperp).v) >= kEpsGeometric) || !(sqrt(ddot(cperp, cperp).v) >= kEpsGeometric)) return dnan();
   return (R.scale * kDeg) * datan2(ddot(a, dcross(dr, cr)), ddot(dperp, cperp));

@@ -9,6 +9,16 @@
 
 namespace okx {
 
+// Developer switches.  ONE environment variable, OKX_DEV, holds a comma-separated list of `name` or `name=value` items;
+// nothing in it is needed to run the product (the two product variables are OKX_KERNEL_CACHE - where compiled kernels are
+// kept - and OKX_VERBOSE).  The names that exist are listed in tools/README.md, each is covered by
+// tests/test_dev_switches.py (generated source still compiles and is deterministic); the switches that change generated
+// source are part of its text and therefore of the kernel cache key.
+//   generators   quad_mark, quad_timeline, quad_no_light, quad_no_head, quad_no_fast, pair_no_head, pair_first_order_head,
+//                pair_lds_homes, lane_mark
+//   library      no_quad, no_lane, no_cold, tangent_generic, keep_source
+bool dev_switch(const char* name);
+
 // default / largest degree of the chain-head predictor's Chebyshev series
 constexpr int kPredictorDegree = 7;
 constexpr int kPredictorMaxDegree = 12;
@@ -142,15 +152,20 @@ int lane_variant_count();
 // lane_generate + quad_compile over the emission variants: keeps the first variant whose independent-solve bodies
 // (okx_lane_solve_*) do not spill, else the one that spills least.  The choice is remembered next to the code objects
 // (<hash of variant 0's source>.lanevar in the kernel cache), so a later call compiles nothing.  `variant_out` (may be
-// null) receives the variant kept.
+// null) receives the variant kept.  `good_enough_scratch`: the search stops at the first variant whose independent-solve
+// bodies spill at most that many bytes - 0 for okx_precompile (the full search, whose result is remembered), the 256 B
+// auto selection accepts for okx_program_create (a program nobody precompiled must not wait for eight hiprtc runs).
 bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::string* why, bool ignore_cached = false,
-                int* variant_out = nullptr);
+                int* variant_out = nullptr, int good_enough_scratch = 0, bool cache_only = false);
 
 // Compiles `src` for gfx950 with hiprtc (no device needed) or fetches it from the on-disk cache
 // (<dir of libokx.so>/_kcache/<hash>.okxc, override with OKX_KERNEL_CACHE).  Returns the code
 // object in `code`; false + message on failure.
 // `ignore_cached` recompiles and overwrites the cache entry (used once when a cached object fails to load).
-bool quad_compile(const std::string& src, std::string* code, std::string* err, bool ignore_cached = false);
+// `cache_only`: never run the compiler - a source that is not in the cache fails with kNotCached in `err` (what
+// okx_program_create asks first: a miss is compiled on a host thread while the interpreter kernels serve the program).
+extern const char* const kNotCached;
+bool quad_compile(const std::string& src, std::string* code, std::string* err, bool ignore_cached = false, bool cache_only = false);
 
 // Largest private-segment (scratch) size among the kernels of a code object whose name starts with `prefix`, read from
 // the code object's metadata note; -1 when no such kernel is found.
@@ -161,6 +176,6 @@ int quad_code_lds_bytes(const std::string& code, const char* prefix);  // static
 // compiler then spills in the solve kernels (a larger half program than the BASELINE axle), the variant with LDS homes
 // is generated and compiled instead.  `src` receives the source of the variant that was kept.
 bool quad_build(const DevProgram& P, int waves_per_simd, std::string* src, std::string* code, std::string* why,
-                bool ignore_cached = false);
+                bool ignore_cached = false, bool cache_only = false);
 
 }  // namespace okx

@@ -184,9 +184,6 @@ class Gen {
   }
 
   // ---- quad data movement ----
-  int row_fence = 0;  // > 0: a scheduling barrier after every row_fence rows of the evaluation
-  bool fence_after_row = false;
-  int col_fence = 0;  // > 0: a scheduling barrier after every col_fence columns of the factorisation
   std::string bcast(const std::string& n, int r) {
     std::vector<std::string>& slot = bc_[n];
     if (slot.empty()) slot.resize(3);
@@ -869,7 +866,6 @@ class Gen {
       }
       if (jtv) continue;
       if (P.row_type[i] == kRowTarget) target_j[(int)P.row_param[i][3]] = jv;
-      if (row_fence > 0 && (i + 1) % row_fence == 0) fence_after_row = true;
       // J^T r and J^T J (lower block triangle: F >= G)
       for (auto& fv : jv) f("    gn%d = fma(%s, %s, gn%d);", fv.first, sx(fv.second).c_str(), ro.r.c_str(), fv.first);
       if (pin_atr)
@@ -898,11 +894,6 @@ class Gen {
       if (pin_ata)
         for (auto& an : touched) f("    asm volatile(\"\" : \"+v\"(%s));", an.c_str());
       mark(4);
-      if (fence_after_row) {
-        // keep the scheduler from interleaving many rows' temporaries (the kernel is register-bound)
-        f("    __builtin_amdgcn_sched_barrier(0);");
-        fence_after_row = false;
-      }
     }
     // diagonal blocks that no row touched still exist (as zeros)
     for (int F = 0; F < nf && !jtv; ++F)
@@ -962,7 +953,6 @@ class Gen {
           }
         }
         f("    }");
-        if (col_fence > 0 && (3 * G + k + 1) % col_fence == 0) f("    __builtin_amdgcn_sched_barrier(0);");
       }
     for (int F = 0; F < nf; ++F)
       for (int G = 0; G < nf; ++G) fillf[F][G] = fill[F][G];
@@ -1229,7 +1219,6 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   Gen g(P, pv);
   const int nf = P.n_free, NP = P.n_points, T = P.n_targets;
-  const bool lds_state = !pv && getenv("OKX_QUAD_LDS_STATE") != nullptr;  // experiment: cold per-pass state of the single-mode kernel in LDS
   const int PPW = pv ? 8 : 16;                                  // problems per wavefront
   const int prog_points = pv ? pv->n_prog_points : NP;          // strides of the caller's tables
   const int prog_crows = pv ? pv->n_prog_crows : P.n_crows;
@@ -1242,15 +1231,13 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // layout on); the chain constants and the fixed points stay in registers unless the caller asks for LDS homes (the
   // fallback of quad_build for half programs that would spill) - measured on the axle grid: -8.5 % chained, -10 % cold
   // against everything in LDS (130 -> 60 LDS round trips per pass, which a lone wavefront cannot hide).
-  if (getenv("OKX_PAIR_LDS_HOMES")) lds_homes = true;  // (experiment switch)
-  ev.lds_constants = pv != nullptr || getenv("OKX_QUAD_LDS") != nullptr;
+  if (dev_switch("pair_lds_homes")) lds_homes = true;  // (tests: the fallback layout of a pair program that would spill)
+  ev.lds_constants = pv != nullptr;
   ev.scalars_in_regs = ev.lanes_in_regs = pv != nullptr && !lds_homes;
   const bool fixed_in_regs = pv != nullptr && !lds_homes;
-  if (const char* env = getenv(pv ? "OKX_PAIR_ROW_FENCE" : "OKX_QUAD_ROW_FENCE")) ev.row_fence = atoi(env);
-  if (const char* env = getenv(pv ? "OKX_PAIR_COL_FENCE" : "OKX_QUAD_COL_FENCE")) ev.col_fence = atoi(env);
-  ev.pin_ata = ev.pin_atr = getenv("OKX_QUAD_NO_PIN") == nullptr;  // (experiment switch)
-  ev.marks = getenv("OKX_QUAD_MARK") != nullptr;
-  ev.tl_marks = !pv && getenv("OKX_QUAD_TIMELINE") != nullptr;
+  ev.pin_ata = ev.pin_atr = true;
+  ev.marks = dev_switch("quad_mark");
+  ev.tl_marks = !pv && dev_switch("quad_timeline");
   for (int e = 0; e < P.n_derived; ++e) ev.dp(e);  // every derived-op parameter is chain-constant
   ev.f("    // ---- active derived points with chain-rule blocks ----");
   for (int idx = 0; idx < P.n_active; ++idx)
@@ -1272,7 +1259,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // confirming evaluation (residuals only).  Not offered for programs with the reference's
   // zero-gradient point-on-line row: along that row's valley the step length says nothing about
   // the distance to the minimiser, so those always take full passes.
-  bool light_ok = getenv("OKX_QUAD_NO_LIGHT") == nullptr;  // (experiment switch: no residual-only confirming pass)
+  bool light_ok = !dev_switch("quad_no_light");  // (developer switch: a kernel without the residual-only confirming pass, for instruction counts)
   for (int i = 0; i < P.n_crows; ++i) light_ok = light_ok && P.row_type[i] != OKX_ROW_POINT_ON_LINE;
   std::string light_src;
   if (light_ok) {
@@ -1295,7 +1282,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // Pair mode carries the first-order table (OKX_PAIR_NO_HEAD=1 leaves it out).  Measured on the axle grid, round 3:
   // cold starts 5.57 -> 4.72 evaluations, 0.483 -> 0.455 ms; chained grids unchanged (0.211 vs 0.212 ms) - in round 2
   // the block's registers still cost the chained grid 3 %, before the LM scalars and constants had homes in LDS.
-  const bool head_ok = T >= 1 && getenv("OKX_QUAD_NO_HEAD") == nullptr && (!pv || getenv("OKX_PAIR_NO_HEAD") == nullptr);
+  const bool head_ok = T >= 1 && !dev_switch("quad_no_head") && (!pv || !dev_switch("pair_no_head"));
   // columns of the table: the constraint gradient, then one per PROGRAM target (pair mode: a side target stands for one
   // program target per half that carries it; the column's weight is that half's residual, its Q spans both halves)
   struct HeadCol { int t, side, prog_t; };
@@ -1314,7 +1301,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // columns s <= t, [pair][F][4] after the scalars (pair mode: one such block per half, the left half's first);
   // scalar 6 says how many pairs the table carries.
   std::vector<std::pair<int, int>> head_pairs;
-  if (getenv("OKX_QUAD_FIRST_ORDER_HEAD") == nullptr && !(pv && getenv("OKX_PAIR_FIRST_ORDER_HEAD") != nullptr))
+  if (!(pv && dev_switch("pair_first_order_head")))
     for (int s2 = 1; s2 < HK; ++s2)
       for (int t2 = s2; t2 < HK; ++t2) head_pairs.push_back({s2, t2});
   const int NPAIR = (int)head_pairs.size();
@@ -1331,7 +1318,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // Pair mode: the quad-uniform Levenberg-Marquardt scalars and the chain's target history live in LDS, one slot per
   // quad side like the chain constants (all lanes of a quad write the same value).  Left in registers the compiler
   // spills them to scratch, and the pass re-reads ~60 of them from there at memory latency (profiles/r02/c3_*).
-  const bool pair_state_lds = pv && getenv("OKX_PAIR_STATE_REGS") == nullptr;
+  const bool pair_state_lds = pv != nullptr;
   int n_state_slots = 0;
   auto state_ref = [&](const std::string& name, const std::string& init) {
     // declaration of one per-quad scalar: a register, or a reference into lms[slot][quad side]
@@ -1521,21 +1508,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("// Two quads own one problem: `xq` reads the other quad's lane with the same component");
     g.f("// (ds_swizzle, lane ^ 4: data path only, no LDS memory); PSUM / PMAX reduce over both quads and");
     g.f("// are bit-identical in all eight lanes (commutative combination of the two quad results).");
-    if (getenv("OKX_PAIR_XQ_DPP")) {
-      // lane ^ 4 as two masked row shifts on the vector ALU: quads 1 and 3 of a row read four lanes down, quads 0 and 2
-      // four lanes up (bank masks 0xA / 0x5)
-      g.f("DEV int xq32(int v) {");
-      g.f("  int t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xA, false);");
-      g.f("  return __builtin_amdgcn_update_dpp(t, v, 0x104, 0xf, 0x5, false);");
-      g.f("}");
-      g.f("DEV double xq(double v) { return __hiloint2double(xq32(__double2hiint(v)), xq32(__double2loint(v))); }");
-    } else {
     g.f("DEV double xq(double v) {");
     g.f("  int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x101F);");
     g.f("  int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x101F);");
     g.f("  return __hiloint2double(hi, lo);");
     g.f("}");
-    }
     g.f("DEV double PSUM(double v) { const double s = qsum(v); return s + xq(s); }");
     g.f("DEV double PMAX(double v) { const double s = qmax(v); return fmax(s, xq(s)); }");
     g.f("#define PJOIN_SUM(v) ((v) + xq(v))");
@@ -1566,7 +1543,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   // (developer build, OKX_QUAD_TIMELINE=1: wavefront w stamps the shader clock into a.trace[16 w + k] - 0 entry, 1 loads
   //  consumed / first step in hand, 2 ... 11 top of each LM pass, 13 passes done, 14 records stored; tools/quad_timeline.py)
-  const bool timeline = CD && getenv("OKX_QUAD_TIMELINE") != nullptr;
+  const bool timeline = CD && dev_switch("quad_timeline");
   auto stamp = [&](const char* slot) {
     if (timeline) g.f("    if (a.trace && (threadIdx.x & 63) == 0) a.trace[blockIdx.x * 16 + (%s)] = (double)__builtin_readcyclecounter();", slot);
   };
@@ -1592,7 +1569,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
             cs_dp = cs_rp + 8 * (prog_crows + prog_targets), cs_end = cs_dp + (P.n_derived + 1) / 2 * 2 + 2;
   if (CD) {
     g.f("  __shared__ __attribute__((aligned(16))) double cst[%d];  // [first-step table | design positions | row parameters | derived-op parameters]", cs_end);
+    for (int t = 0; t < T; ++t) g.f("  double tpre%d;", t);
     g.f("  {");
+    // the targets of this wavefront's first unit travel with the tables (after the staging they would be a round trip of their own)
+    g.f("    long long tu0 = (long long)blockIdx.x * %d + (lane >> 2); if (tu0 >= a.n_problems) tu0 = a.n_problems - 1;", PPW);
+    for (int t = 0; t < T; ++t) g.f("    tpre%d = a.targets[tu0 * %d + %s];", t, prog_targets, ev.target_slot(t).c_str());
     g.f("    const double2* h2 = reinterpret_cast<const double2*>(a.head);  // (hipMalloc'ed: 256-byte aligned)");
     g.f("    double2* c2 = reinterpret_cast<double2*>(cst);");
     // every load first (clamped indices: no branch), then the stores: one round trip
@@ -1605,6 +1586,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     {  // (an opaque use of everything loaded: the compiler would sink each load into the branch that stores it)
       std::string pin = "    asm volatile(\"\" : ";
       bool first = true;
+      for (int t = 0; t < T; ++t) {
+        pin += std::string(first ? "" : ", ") + "\"+v\"(tpre" + std::to_string(t) + ")";
+        first = false;
+      }
       for (int k = 0; 64 * k < n2; ++k) {
         pin += std::string(first ? "" : ", ") + "\"+v\"(sh" + std::to_string(k) + ".x), \"+v\"(sh" + std::to_string(k) + ".y)";
         first = false;
@@ -1616,7 +1601,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     for (int k = 0; 64 * k < n2; ++k) g.f("    if (lane + %d < %d) c2[lane + %d] = sh%d;", 64 * k, n2, 64 * k, k);
     for (int q = 0; q < 3; ++q)
       for (int k = 0; 64 * k < pieces[q].n; ++k) g.f("    if (lane + %d < %d) cst[%d + lane] = sp%d_%d;", 64 * k, pieces[q].n, pieces[q].off + 64 * k, q, k);
-    g.f("    __syncthreads();");
+    // (one wavefront per workgroup: its LDS instructions execute in order, only the compiler must keep them in order)
+    g.f("    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
     g.f("  }");
     g.f("  const double* const c_rp = cst + %d; const double* const c_dp = cst + %d; (void)c_dp; (void)c_rp;", cs_rp, cs_dp);
   }
@@ -1630,12 +1616,6 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   } else {
     if (pair_state_lds) g.f("  const int qs = lane >> 2;  // quad(-side) slot of this lane inside the wavefront");
     if (!CD) g.f("  __shared__ double xql[%d];  // third chain-history point [block][lane] (registers are full)", 64 * nf);
-    if (lds_state) {
-      int n_fixed = 0;
-      for (int p = 0; p < NP; ++p) n_fixed += ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
-      g.f("  __shared__ double psl[%d];  // fixed points [point][lane]", 64 * (n_fixed > 0 ? n_fixed : 1));
-      g.f("  __shared__ double dxl[%d];  // the step in hand [block][lane]", 64 * nf);
-    }
   }
   g.f("  const long long spg = a.steps_per_geometry;");
   g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
@@ -1694,6 +1674,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   if (pair_state_lds) g.f("    __shared__ double lms[%d];  // per-quad scalars [slot][quad side]", 16 * (5 * T + 12));
   for (int t = 0; t < T; ++t) {
     char init[160];
+    if (CD)  // the first unit's targets came with the staged tables; later units of the grid-stride loop load theirs here
+      std::snprintf(init, sizeof(init), "wu == (long long)blockIdx.x ? tpre%d : a.targets[first_b * %d + %s]", t, prog_targets, ev.target_slot(t).c_str());
+    else
     std::snprintf(init, sizeof(init), "a.targets[first_b * %d + %s]", prog_targets, ev.target_slot(t).c_str());
     g.f("    %s %s %s %s", state_ref("tn" + std::to_string(t), init).c_str(), state_ref("tp" + std::to_string(t), "0.0").c_str(),
         state_ref("tq" + std::to_string(t), "0.0").c_str(), state_ref("tr" + std::to_string(t), "0.0").c_str());
@@ -1715,7 +1698,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     for (int p = 0; p < NP; ++p) {
       if (!used[p]) continue;
       const bool fixed = ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
-      if ((ev.lds_constants || lds_state) && fixed && !fixed_in_regs)
+      if (ev.lds_constants && fixed && !fixed_in_regs)
         g.f("    double& p%d = psl[%d + lane]; p%d = ld3(gp + %s + cc, c);", p, 64 * slot++, p, ev.point3(p).c_str());
       else
         g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
@@ -1725,18 +1708,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     if (ev.lds_constants) {  // cold per-pass state lives in LDS (register-bound kernel): plain references, same code below
       g.f("    double& x%d = xsl[%d + lane]; double& xp%d = xsl[%d + lane]; double& xq%d = xsl[%d + lane];", F, 64 * (2 * F), F,
           64 * (2 * F + 1), F, 64 * (2 * nf + F));
-      if (getenv("OKX_PAIR_DX_REGS") == nullptr) {
-        g.f("    double& dx%d = xsl[%d + lane];", F, 64 * (3 * nf + F));
-        g.f("    x%d = p%d; xp%d = x%d; xq%d = x%d; dx%d = 0.0;", F, ev.fp(F), F, F, F, F, F);
-      } else {
-        g.f("    x%d = p%d; xp%d = x%d; xq%d = x%d; double dx%d = 0.0;", F, ev.fp(F), F, F, F, F, F);
-      }
+      g.f("    double& dx%d = xsl[%d + lane];", F, 64 * (3 * nf + F));
+      g.f("    x%d = p%d; xp%d = x%d; xq%d = x%d; dx%d = 0.0;", F, ev.fp(F), F, F, F, F, F);
     } else {
-      if (lds_state)
-        g.f("    double x%d = p%d, xp%d = x%d; double& dx%d = dxl[%d + lane]; dx%d = 0.0; double& xq%d = xql[%d + lane]; xq%d = x%d;", F,
-            ev.fp(F), F, F, F, 64 * F, F, F, 64 * F, F, F);
-      else
-        if (CD) g.f("    double x%d = p%d, dx%d = 0.0;", F, ev.fp(F), F);
+      if (CD) g.f("    double x%d = p%d, dx%d = 0.0;", F, ev.fp(F), F);
       else
         g.f("    double x%d = p%d, xp%d = x%d, dx%d = 0.0; double& xq%d = xql[%d + lane]; xq%d = x%d;", F, ev.fp(F), F, F, F, F, 64 * F, F, F);
     }
@@ -1926,7 +1901,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // ~20 % (registers, code size) whether it runs or not.  Own-geometry launches only; a restart after a failed
   // step goes back to the design state.  Not generated in pair mode: that kernel is register-bound and the mere
   // presence of the block cost the axle 18 % on chained grids for a 3 % gain (profiles/r01/config_sweep_pred.txt).
-  if (!CD && (!pv || getenv("OKX_PAIR_MODEL"))) {
+  if (!CD && !pv) {
     const int TT = prog_targets;
     std::vector<int> ordinal(program.n_points, 0);  // program point -> its free ordinal
     for (int k = 0; k < program.n_free; ++k) ordinal[program.free_point[k]] = k;
@@ -2090,10 +2065,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("      }");
     }
   }
-  if (getenv("OKX_PAIR_DEBUG_RC")) g.f("      double dbg0 = 0.0, dbg1 = 0.0, dbg2 = 0.0;  // (diagnostic build)");
   if (timeline) g.f("      int tl_pass = 2;");
   stamp("1");
-  const bool fast_loop = CD && getenv("OKX_QUAD_NO_FAST") == nullptr;
+  const bool fast_loop = CD && !dev_switch("quad_no_fast");  // (developer switch: the cold body with the general loop only)
   if (fast_loop) {
     // ---- the cold body's fast loop ----
     // The passes of a cold start whose every trial point is accepted - what a sweep inside the reach does - written for
@@ -2210,7 +2184,6 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int F = 0; F < nf; ++F) g.f("    p%d = mode == 2 ? x%d : x%d + dx%d;", ev.fp(F), F, F, F);
   g.out += eval_src;
   g.out += couple_eval;
-  if (getenv("OKX_PAIR_DEBUG_RC") && NK > 1) g.f("    if (mode == 0) { dbg0 = rc0; dbg1 = rc1; dbg2 = %s; }", NK > 2 ? "rc2" : "0.0");
   g.f("    const double Ft = 0.5 * ss;");
   // LM decision (mirrors okx_solve_kernel)
   g.f("    bool accept = true, stop = false, compromise = false;");
@@ -2442,8 +2415,30 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     // okx_solve_opts.output = OKX_OUTPUT_FREE: the solved free points alone, [n_free][3] in the program's free_point order
     std::vector<int> ordinal(program.n_points, 0);
     for (int k = 0; k < program.n_free; ++k) ordinal[program.free_point[k]] = k;
+    if (CD) {
+      // cold body: the wavefront's free coordinates form one contiguous block (16 consecutive problems): through LDS and out in
+      // 16-byte-per-lane rows like the records - whole cache lines for HBM, whole packets for a caller's pinned host buffer
+      // (lane-by-lane 8-byte stores leave 24-byte fragments whose merging on the way out depends on timing)
+      g.f("    __shared__ __attribute__((aligned(16))) double fstage[16 * %d];", 3 * program.n_free);
+      g.f("    if (a.out_mode == 1) {");
+      g.f("      if (c < 3) {");
+      g.f("        double* st = fstage + quad * %d + c;", 3 * program.n_free);
+      for (int F = 0; F < nf; ++F) g.f("        st[%d] = x%d;", 3 * ordinal[ev.fp(F)], F);
+      g.f("      }");
+      g.f("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
+      g.f("      const long long rem = a.n_problems - wu * 16;");
+      g.f("      const int n_doubles = (int)(rem < 16 ? rem : 16) * %d;", 3 * program.n_free);
+      g.f("      double2* dst = reinterpret_cast<double2*>(a.out_pos + wu * 16 * %d);", 3 * program.n_free);
+      g.f("      const double2* src = reinterpret_cast<const double2*>(fstage);");
+      g.f("      for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
+      g.f("      if ((n_doubles & 1) && lane == 0) a.out_pos[wu * 16 * %d + n_doubles - 1] = fstage[n_doubles - 1];", 3 * program.n_free);
+      g.f("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();");
+      g.f("    }");
+      g.f("    if (false) { long long bf = 0;");
+    } else {
     g.f("    if (a.out_mode == 1 && valid && c < 3) {");
     g.f("      long long bf = bb; asm volatile(\"\" : \"+v\"(bf));");
+    }
     g.f("      double* o = a.out_pos + bf * %d + c;", 3 * program.n_free);
     for (int F = 0; F < nf; ++F) {
       const int pt = ev.fp(F);
@@ -2494,6 +2489,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("        double* st = stage + quad * %d + c;", 3 * P.n_out);
   for (int k = 0; k < P.n_out; ++k) g.f("        st[%d] = p%d;", 3 * k, P.out_point[k]);
   g.f("      }");
+  if (CD) g.f("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
+  else
   g.f("      __syncthreads();");
   g.f("      const long long rem = a.n_problems - wu * 16;");
   g.f("      const int n_doubles = (int)(rem < 16 ? rem : 16) * %d;", 3 * P.n_out);
@@ -2501,6 +2498,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      const double2* src = reinterpret_cast<const double2*>(stage);");
   g.f("      for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
   g.f("      if ((n_doubles & 1) && lane == 0) a.out_pos[wu * 16 * %d + n_doubles - 1] = stage[n_doubles - 1];", 3 * P.n_out);
+  // (cold body: no workgroup barrier here - it is a release fence, i.e. a wait for every record store of this unit to
+  //  complete, ~1500 cycles at the end of the ONLY unit most wavefronts have; one wavefront's LDS accesses are ordered anyway)
+  if (CD) g.f("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();");
+  else
   g.f("      __syncthreads();  // stage is reused by the next unit of this wavefront");
   g.f("    } else if (valid && c < 3) {");
   g.f("      double* o = a.out_pos + bb * %d + c;", 3 * P.n_out);
@@ -2508,13 +2509,31 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   g.f("    }");
   stamp("14");
+  if (CD) {
+    // the sixteen 40-byte records of the wavefront are contiguous too: one staged block, 8 bytes per lane
+    g.f("    __shared__ __attribute__((aligned(16))) okx_info istage[16];");
+    g.f("    if (c == 0) {");
+    g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
+    g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
+    g.f("      istage[quad] = inf;");
+    g.f("    }");
+    g.f("    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
+    g.f("    {");
+    g.f("      const long long rem = a.n_problems - wu * 16;");
+    g.f("      const int n_words = (int)(rem < 16 ? rem : 16) * 5;  // doubles of info records");
+    g.f("      double* dst = reinterpret_cast<double*>(a.info + wu * 16);");
+    g.f("      const double* src = reinterpret_cast<const double*>(istage);");
+    g.f("      if (lane < n_words) dst[lane] = src[lane];");
+    g.f("      if (lane + 64 < n_words) dst[lane + 64] = src[lane + 64];");
+    g.f("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();");
+    g.f("    }");
+  } else {
   g.f("    if (valid && c == 0%s) {", pv ? " && !q1" : "");
   g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
-  if (getenv("OKX_PAIR_DEBUG_PIV")) g.f("      inf.cost = piv_hi; inf.last_step = piv_lo;  // (diagnostic build)");
-  if (getenv("OKX_PAIR_DEBUG_RC")) g.f("      inf.cost = dbg0; inf.last_step = dbg1; inf.max_residual = dbg2;  // (diagnostic build)");
   g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
   g.f("      a.info[bb] = inf;");
   g.f("    }");
+  }
   stamp("15");
   // chains never continue from a state that failed to converge
   if (!CD) {

@@ -130,8 +130,24 @@ def corner_roles(suspension, program, side=None) -> CornerRoles:
 class RotationRole(C.Structure):
     """ctypes mirror of ``okx_rotation_role``."""
 
-    _fields_ = [("point", C.c_int32), ("pad", C.c_int32), ("design", C.c_double * 3), ("axis_point", C.c_double * 3),
-                ("axis_dir", C.c_double * 3), ("scale", C.c_double)]
+    _fields_ = [("point", C.c_int32), ("point_b", C.c_int32), ("design", C.c_double * 3), ("axis_point", C.c_double * 3),
+                ("axis_dir", C.c_double * 3), ("scale", C.c_double), ("kind", C.c_int32), ("reserved", C.c_int32)]
+
+
+# okx.h OKX_ROLE_*
+ROLE_AXIS_ROTATION, ROLE_MIDPOINT_ROTATION, ROLE_STEM_TWIST, ROLE_DISTANCE, ROLE_MIDPOINT_COORDINATE = range(5)
+
+
+def _vec3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def pair_role(kind: int, point_a: int, point_b: int, *, design=(0.0, 0.0, 0.0), axis_point=(0.0, 0.0, 0.0),
+              axis_dir=(1.0, 0.0, 0.0), scale: float = 1.0) -> RotationRole:
+    """A role over TWO output points (``okx.h`` OKX_ROLE_* kinds 1-4: midpoint rotation, stem twist, distance, midpoint
+    coordinate); ``axis_dir`` must be a unit vector."""
+    return RotationRole(point=int(point_a), point_b=int(point_b), design=_vec3(design), axis_point=_vec3(axis_point),
+                        axis_dir=_vec3(axis_dir), scale=float(scale), kind=int(kind))
 
 
 def rotation_role(point: int, design, axis_a, axis_b, scale: float = 1.0) -> RotationRole:
@@ -140,8 +156,8 @@ def rotation_role(point: int, design, axis_a, axis_b, scale: float = 1.0) -> Rot
     length = float(np.linalg.norm(b - a))
     if length < 1e-6:
         raise ValueError("rotation axis points must be distinct")
-    vec = lambda v: (C.c_double * 3)(*[float(x) for x in v])  # noqa: E731
-    return RotationRole(point=int(point), design=vec(design), axis_point=vec(a), axis_dir=vec((b - a) / length), scale=float(scale))
+    return RotationRole(point=int(point), design=_vec3(design), axis_point=_vec3(a), axis_dir=_vec3((b - a) / length),
+                        scale=float(scale), kind=ROLE_AXIS_ROTATION)
 
 
 def topology_rotation_roles(suspension, program, side=None) -> tuple[list[str], list[RotationRole]]:
@@ -227,79 +243,54 @@ def axle_topology_metrics(axle, program, positions: torch.Tensor, tangents: torc
     return out
 
 
-def _response_with_rates(fn, positions: torch.Tensor, tangents: torch.Tensor | None):
-    """``fn(positions [B, n_out, 3]) -> [B]`` and, with tangents ``[B, T, n_out, 3]``, its rate along every target's
-    tangent ``[B, T]`` (the reference pushes dual numbers through the same closed forms: ``metrics/derivatives.py``);
-    every state's value depends on its own positions only, so one reverse pass of the batch sum gives all gradients."""
-    if tangents is None:
-        return fn(positions), None
-    with torch.enable_grad():
-        pos = positions.detach().clone().requires_grad_(True)
-        value = fn(pos)
-        (grad,) = torch.autograd.grad(value.sum(), pos)
-    return value.detach(), torch.einsum("bpc,btpc->bt", grad, tangents)
+def hardware_roles(axle, program) -> tuple[list[str], list[RotationRole]]:
+    """
+    ``(column names, roles)`` of the state metrics of an axle's shared hardware that are not rotations of one point about
+    a fixed axis: a rigid T-bar's ``t_bar_heave_angle`` (crossbar midpoint about the pivot's lateral axis, design ->
+    current), ``arb_twist`` (crossbar rotation about the moving stem, minus its design value) and ``t_bar_center_x``, a
+    rocker-to-rocker heave link's ``heave_link_length`` (``axle/mechanisms.py:718-815,903-944``) - evaluated by the
+    rotation kernel (``okx_axis_rotation_batch``, role kinds 1-4) together with their rates along the tangents.
+    """
+    out_keys = [program.point_keys[k] for k in program.out_point]
+    design = axle.initial_state().positions
+    names, roles = [], []
+    if getattr(axle, "arb_kind", "") == "t_bar":
+        il = out_keys.index(PointRef(Side.LEFT, PointID.DROPLINK_T_BAR))
+        ir = out_keys.index(PointRef(Side.RIGHT, PointID.DROPLINK_T_BAR))
+        pivot = np.asarray(axle.arb_center_points[PointID.ARB_T_BAR_PIVOT].data, dtype=np.float64)
+        lateral = np.array([0.0, 1.0, 0.0])
+        left = np.asarray(design[PointRef(Side.LEFT, PointID.DROPLINK_T_BAR)].data, dtype=np.float64)
+        right = np.asarray(design[PointRef(Side.RIGHT, PointID.DROPLINK_T_BAR)].data, dtype=np.float64)
+        center = left + (right - left) / 2.0
+        stem = (center - pivot) / np.linalg.norm(center - pivot)
+        crossbar = (left - right) - stem * float(np.dot(left - right, stem))
+        design_twist = float(np.degrees(np.arctan2(np.dot(stem, np.cross(lateral, crossbar)), crossbar[1])))  # mechanisms.py:800-815
+        names += ["t_bar_heave_angle", "arb_twist", "t_bar_center_x"]
+        roles += [pair_role(ROLE_MIDPOINT_ROTATION, il, ir, design=center, axis_point=pivot, axis_dir=lateral),
+                  pair_role(ROLE_STEM_TWIST, il, ir, design=(design_twist, 0.0, 0.0), axis_point=pivot, axis_dir=lateral),
+                  pair_role(ROLE_MIDPOINT_COORDINATE, il, ir, axis_dir=(1.0, 0.0, 0.0))]
+    if getattr(axle, "heave_link", False):
+        names.append("heave_link_length")
+        roles.append(pair_role(ROLE_DISTANCE, out_keys.index(PointRef(Side.LEFT, PointID.HEAVE_LINK_ROCKER)),
+                               out_keys.index(PointRef(Side.RIGHT, PointID.HEAVE_LINK_ROCKER))))
+    return names, roles
 
 
 def axle_hardware_metrics(axle, program, positions: torch.Tensor, tangents: torch.Tensor | None = None) -> dict:
     """
-    State metrics of the axle's shared hardware that are not rotations about a fixed axis, on the device tensors the
-    solve returned: a rigid T-bar's ``t_bar_heave_angle`` (crossbar midpoint about the pivot's lateral axis, design ->
-    current) and ``arb_twist`` (crossbar rotation about the moving stem, minus its design value), and a
-    rocker-to-rocker heave link's ``heave_link_length`` (``axle/mechanisms.py:763-815,934-944``).  With tangents also
-    ``d_t_bar_center_x``, ``d_arb_twist`` and ``d_heave_link_length``: rates ``[B, T]`` along every target's tangent
-    (``mechanisms.py:718-761,903-928``).  Values in deg / mm like the reference's rows.
+    The hardware metrics of ``hardware_roles`` on the device tensors the solve returned, one kernel launch: name ->
+    ``[B]`` (deg / mm like the reference's rows) and, with tangents, ``d_<name>`` -> ``[B, T]`` rates along every
+    target's tangent (``mechanisms.py:718-761,903-928``).
     """
     if not positions.is_cuda:
         raise RuntimeError("axle_hardware_metrics needs device tensors (there is no CPU fallback)")
-    out_keys = [program.point_keys[k] for k in program.out_point]
-    pos = positions.to(torch.float64)
-    out: dict = {}
-    design = axle.initial_state().positions
-    dev = pos.device
-    vec = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float64), device=dev)  # noqa: E731
-    if getattr(axle, "arb_kind", "") == "t_bar":
-        il = out_keys.index(PointRef(Side.LEFT, PointID.DROPLINK_T_BAR))
-        ir = out_keys.index(PointRef(Side.RIGHT, PointID.DROPLINK_T_BAR))
-        pivot = vec(axle.arb_center_points[PointID.ARB_T_BAR_PIVOT].data)
-        lateral = vec([0.0, 1.0, 0.0])
-        d_left = design[PointRef(Side.LEFT, PointID.DROPLINK_T_BAR)].data
-        d_right = design[PointRef(Side.RIGHT, PointID.DROPLINK_T_BAR)].data
-
-        def center(p, a=il, b=ir):
-            return p[:, a] + (p[:, b] - p[:, a]) / 2.0
-
-        def shaft_twist(p, a=il, b=ir):  # mechanisms.py:800-815
-            stem = center(p, a, b) - pivot
-            stem = stem / stem.norm(dim=1, keepdim=True)
-            crossbar = p[:, a] - p[:, b]
-            crossbar = crossbar - stem * (crossbar * stem).sum(1, keepdim=True)
-            sine = (stem * torch.linalg.cross(lateral.expand_as(crossbar), crossbar)).sum(1)
-            return torch.atan2(sine, crossbar[:, 1])
-
-        design_pair = vec(np.stack([d_left, d_right]))[None]  # [1, 2, 3]: (left end, right end) of the design state
-        design_center, design_twist = center(design_pair, 0, 1)[0], shaft_twist(design_pair, 0, 1)[0]
-        radius0 = design_center - pivot
-        perp0 = radius0 - lateral * radius0[1]
-
-        def heave_angle(p):  # signed_angle_about_axis, vector_utils/geometric.py:31-52
-            radius = center(p) - pivot
-            perp = radius - lateral * radius[:, 1:2]
-            sine = (lateral * torch.linalg.cross(radius0.expand_as(radius), radius)).sum(1)
-            return torch.rad2deg(torch.atan2(sine, (perp * perp0).sum(1)))
-
-        out["t_bar_heave_angle"] = heave_angle(pos)
-        twist, d_twist = _response_with_rates(lambda p: torch.rad2deg(shaft_twist(p)), pos, tangents)
-        out["arb_twist"] = twist - torch.rad2deg(design_twist)
-        if tangents is not None:
-            out["d_arb_twist"] = d_twist
-            out["d_t_bar_center_x"] = (tangents[:, :, il, 0] + (tangents[:, :, ir, 0] - tangents[:, :, il, 0]) / 2.0).to(torch.float64)
-    if getattr(axle, "heave_link", False):
-        hl = out_keys.index(PointRef(Side.LEFT, PointID.HEAVE_LINK_ROCKER))
-        hr = out_keys.index(PointRef(Side.RIGHT, PointID.HEAVE_LINK_ROCKER))
-        length, d_length = _response_with_rates(lambda p: (p[:, hl] - p[:, hr]).norm(dim=1), pos, tangents)
-        out["heave_link_length"] = length
-        if tangents is not None:
-            out["d_heave_link_length"] = d_length
+    names, roles = hardware_roles(axle, program)
+    if not names:
+        return {}
+    values, rates = axis_rotation_metrics(roles, positions, tangents)
+    out = {n: values[:, k] for k, n in enumerate(names)}
+    if rates is not None:
+        out.update({f"d_{n}": rates[:, :, k] for k, n in enumerate(names)})
     return out
 
 

@@ -102,7 +102,7 @@ _MM, _DEG, _PCT = "mm", "deg", "%"
 # units of the metric columns this package produces (reference: metrics/catalog.py, axle_metrics.py, mechanisms.py)
 METRIC_UNITS = {
     **{k: _DEG for k in ("camber", "caster", "kpi", "roadwheel_angle", "svsa_angle", "roll", "rocker_angle", "torsion_bar_twist",
-                         "arb_arm_angle", "arb_twist")},
+                         "arb_arm_angle", "arb_twist", "t_bar_heave_angle")},
     **{k: _MM for k in ("wheel_travel", "half_track", "scrub_radius", "mechanical_trail", "svic_x", "svic_z", "svsa_length",
                         "fvic_y", "fvic_z", "fvsa_length", "damper_length", "heave", "ride_height_change", "track",
                         "roll_center_y", "roll_center_z", "rack_displacement", "t_bar_center_x", "heave_link_length")},

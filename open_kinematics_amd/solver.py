@@ -216,7 +216,7 @@ def _device_program(program: ConstraintProgram, device=None):
         if dp is not None:
             _PROGRAM_CACHE.move_to_end(key)
             return dp
-    dp = DeviceProgram(program, device)
+    dp = DeviceProgram(program, device, wait_for_kernels=False)  # start solving at once; generated kernels take over when compiled
     with _PROGRAM_CACHE_LOCK:
         _PROGRAM_CACHE[key] = dp
         # an evicted program is only DROPPED: another caller (another thread, a BatchResult's owner) may still hold it,

@@ -135,7 +135,7 @@ def test_two_wavefront_kernels_match_the_oracle(golden, name, monkeypatch):
     # both have a generated pair-mode kernel (one and three joining rows); the interpreter instantiation is forced here
     assert dp.kernel == "quad", dp.kernel_note
     force = {"kernel": "single"}
-    monkeypatch.setenv("OKX_TANGENT_GENERIC", "1")  # okx_tangent_batch: the interpreter's tangent kernel
+    monkeypatch.setenv("OKX_DEV", "tangent_generic")  # okx_tangent_batch: the interpreter's tangent kernel
     x, t = arrays["eval_x"], arrays["eval_targets"]
     r_o, jac_o = Oracle(pinned).eval(x, t)
     r, jac = dp.eval(x, t)
@@ -164,7 +164,7 @@ def test_two_wavefront_kernels_match_the_oracle(golden, name, monkeypatch):
     # differences of tight solves
     res = dp.solve(targets, chain_len=1)
     tan, tinfo = dp.tangents(res.positions)
-    monkeypatch.delenv("OKX_TANGENT_GENERIC")
+    monkeypatch.delenv("OKX_DEV")
     tan_quad, tinfo_quad = dp.tangents(res.positions)
     torch.cuda.synchronize()
     assert np.all(dp.tangent_info(tinfo_quad)["flags"] == 1)

@@ -278,7 +278,8 @@ def test_positions_rebuilt_with_per_geometry_tables(golden):
 
 
 def test_compact_exchange_pipeline_on_the_device(golden, monkeypatch):
-    """FreeGatherPipeline with a stand-in two-rank all-gather: pack, gather, rebuild on the GPU gives the full positions."""
+    """FreeGatherPipeline with a stand-in two-rank all-gather: solve into the send buffer (output = free), gather, one expand
+    of the gathered block on the GPU gives every rank's full positions."""
     import torch.distributed as dist
 
     from open_kinematics_amd import dist as okx_dist
@@ -306,12 +307,12 @@ def test_compact_exchange_pipeline_on_the_device(golden, monkeypatch):
     monkeypatch.setattr(dist, "is_initialized", lambda: True)
     monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
     monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather)
-    pipe = okx_dist.FreeGatherPipeline(half, pinned.n_out, dp.free_out_index, dp.expand, torch.float64, dp.device)
-    assert pipe.world == 2 and pipe.free_full[0].shape == (2 * half, pinned.n_free, 3)
+    pipe = okx_dist.FreeGatherPipeline(half, pinned.n_out, pinned.n_free, dp.expand, torch.float64, dp.device)
+    assert pipe.world == 2 and pipe.output == "free" and pipe.gathered[0].shape == (2 * half, pinned.n_free, 3)
     other["free"] = ref[half:, dp.free_out_index].contiguous()
     for k in range(3):
-        out = pipe.begin(k)
-        dp.solve(t[:half], out=out)
+        out = pipe.begin(k)                       # the send buffer: the solve writes the free coordinates into it itself
+        dp.solve(t[:half], out=out, output=pipe.output)
         pipe.submit(k)
     full = pipe.drain()
     torch.cuda.synchronize()

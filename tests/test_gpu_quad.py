@@ -207,7 +207,7 @@ def test_pair_mode_fallback_variant_with_lds_homes_gives_the_same_answers(golden
     pinned = program.with_line_mode("pinned")
     t = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
     ref = DeviceProgram(pinned, "cuda:0").solve(t, kernel="quad", predictor=False)
-    monkeypatch.setenv("OKX_PAIR_LDS_HOMES", "1")
+    monkeypatch.setenv("OKX_DEV", "pair_lds_homes")
     monkeypatch.setenv("OKX_KERNEL_CACHE", str(tmp_path))
     dp = DeviceProgram(pinned, "cuda:0")
     assert dp.kernel == "quad", dp.kernel_note

@@ -119,13 +119,13 @@ def test_axle_tangents_in_pair_mode_and_from_the_generic_kernel_match_the_refere
     info = dp.tangent_info(tinfo)
     assert np.all(info["flags"] == 1) and np.all(info["min_pivot"] > 0)
     assert np.max(np.abs(tan.cpu().numpy() - tg["vel"])) <= 1e-9
-    monkeypatch.setenv("OKX_TANGENT_GENERIC", "1")
+    monkeypatch.setenv("OKX_DEV", "tangent_generic")
     wave, winfo = dp.tangents(tg["pos"])
     torch.cuda.synchronize()
     assert np.all(dp.tangent_info(winfo)["flags"] == 1)
     assert np.max(np.abs(wave.cpu().numpy() - tg["vel"])) <= 1e-9
     assert float((tan - wave).abs().max()) <= 1e-10
-    monkeypatch.delenv("OKX_TANGENT_GENERIC")
+    monkeypatch.delenv("OKX_DEV")
     # per-geometry tables; the batch is ragged anyway (fewer states than the 8 of a wavefront)
     n = tg["pos"].shape[0]
     assert n % 8 != 0
@@ -140,7 +140,7 @@ def test_generic_and_generated_tangent_kernels_agree(golden, monkeypatch):
     dp = _dp(program.with_line_mode("pinned"))
     tg = _tg("c4_macpherson_grid")
     quad, _ = dp.tangents(tg["pos"])
-    monkeypatch.setenv("OKX_TANGENT_GENERIC", "1")
+    monkeypatch.setenv("OKX_DEV", "tangent_generic")
     wave, tinfo = dp.tangents(tg["pos"])
     torch.cuda.synchronize()
     assert np.all(dp.tangent_info(tinfo)["flags"] == 1)

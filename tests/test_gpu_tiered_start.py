@@ -1,0 +1,77 @@
+"""
+Tiered start (okx.h, okx_program_ready): a program whose generated kernels are not in the kernel cache is usable at once on
+the interpreter kernels while a host thread compiles; when the job is done the program switches over, and the answers
+before and after the switch agree to 1e-9 mm.  The drop-in's first solve_sweep of an uncached axle returns in well under a
+second instead of waiting for the compiler (10 ... 80 s per module).
+"""
+
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def test_uncached_program_solves_at_once_and_switches_over(golden, monkeypatch, tmp_path):
+    from open_kinematics_amd.batch import DeviceProgram
+
+    monkeypatch.setenv("OKX_KERNEL_CACHE", str(tmp_path))       # an empty kernel cache: nothing of this program is compiled
+    monkeypatch.setenv("OKX_DEV", "no_lane")                    # (one module to compile is enough for the test)
+    arrays, program = golden("c4_macpherson_grid")
+    program = program.with_line_mode("pinned")
+    targets = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
+    t0 = time.perf_counter()
+    dp = DeviceProgram(program, "cuda:0", wait_for_kernels=False)
+    created = time.perf_counter() - t0
+    assert created < 2.0, f"okx_program_create took {created:.1f} s"
+    assert not dp.ready and dp.kernel == "wave" and "compiled" in dp.kernel_note
+    before = dp.solve(targets, chain_len=1, predictor=False)
+    torch.cuda.synchronize()
+    info_before = before.info()
+    assert before.accepted(info_before).all()
+    assert dp.kernel == "wave"                                   # the compiler is not done within a solve's time
+    dp.wait_ready()                                              # ... now it is: the program has switched over
+    assert dp.ready and dp.kernel == "quad", dp.kernel_note
+    assert any(name.endswith(".okxc") for name in os.listdir(tmp_path))
+    after = dp.solve(targets, chain_len=1, predictor=False)
+    torch.cuda.synchronize()
+    assert after.accepted(after.info()).all()
+    assert float((before.positions - after.positions).abs().max()) <= 1e-9
+    # a second program of the same source finds the cache: generated kernels from the first call on
+    again = DeviceProgram(program, "cuda:0", wait_for_kernels=False)
+    assert again.ready and again.kernel == "quad"
+    again.close()
+    dp.close()
+
+
+def test_first_solve_sweep_of_an_uncached_axle_does_not_wait_for_the_compiler(monkeypatch, tmp_path):
+    from open_kinematics_amd import solver
+    from open_kinematics_amd.input import load_geometry, load_sweep
+    from open_kinematics_amd.sweep import solve_sweep
+
+    geom = os.path.join(GOLDEN, "geometry")
+    axle = load_geometry(os.path.join(geom, "axle_geometry.yaml"))
+    sweep = load_sweep(os.path.join(geom, "axle_sweep.yaml"), axle)
+    solver.clear_program_cache()
+    warm = solve_sweep(axle, sweep)                              # kernels from the in-tree cache: the reference answer
+    solver.clear_program_cache()
+    monkeypatch.setenv("OKX_KERNEL_CACHE", str(tmp_path))
+    t0 = time.perf_counter()
+    states, infos = solve_sweep(axle, sweep)
+    elapsed = time.perf_counter() - t0
+    assert elapsed < 0.5, f"first solve_sweep of an uncached axle took {elapsed:.2f} s"
+    assert all(i.converged for i in infos)
+    dp = next(iter(solver._PROGRAM_CACHE.values()))
+    assert dp.kernel == "wave"                                   # served by the interpreter kernels
+    out = axle.output_points()
+    a = np.array([[s.positions[k].data for k in out] for s in states])
+    b = np.array([[s.positions[k].data for k in out] for s in warm[0]])
+    assert np.abs(a - b).max() <= 1e-9
+    solver.clear_program_cache()                                 # (joins the compile job: the module lands in tmp_path)
+    del dp

@@ -85,7 +85,7 @@ def test_pair_mode_constants_live_in_registers_unless_lds_homes_are_asked_for(go
     pinned = program.with_line_mode("pinned")
     src = _source(pinned)
     assert "psl[" not in src and " = hsl[" not in src and "const double hcL = gq[" in src
-    monkeypatch.setenv("OKX_PAIR_LDS_HOMES", "1")
+    monkeypatch.setenv("OKX_DEV", "pair_lds_homes")
     src = _source(pinned)
     assert "psl[" in src and " = hsl[" in src and "#define hcL hsl[" in src
 
@@ -131,7 +131,7 @@ def test_header_documents_the_kernel_choice():
 
 def test_first_step_table_kernels_are_generated_where_they_pay(golden, monkeypatch):
     """okx_quad_head_u/_g: single-mode programs with targets carry them and take the unit's head step
-    in the prologue; pair-mode kernels only on request; OKX_QUAD_NO_HEAD removes them."""
+    in the prologue; pair-mode kernels only on request; OKX_DEV=quad_no_head removes them."""
     _, dw = golden("c1_dw_corner")
     src = _source(dw.with_line_mode("pinned"))
     assert "okx_quad_head_u(QHeadArgs a)" in src and "okx_quad_head_g(QHeadArgs a)" in src
@@ -151,13 +151,11 @@ def test_first_step_table_kernels_are_generated_where_they_pay(golden, monkeypat
     side_free = axle.n_free // 2
     stride = 2 * 4 * side_free * k + 2 * k * k + 8 + 2 * 4 * side_free * axle.n_targets * (axle.n_targets + 1) // 2
     assert f"double* hs = a.head + geom * {stride};" in pair
-    monkeypatch.setenv("OKX_PAIR_FIRST_ORDER_HEAD", "1")
+    monkeypatch.setenv("OKX_DEV", "pair_first_order_head")
     assert "hS0_" not in _source(axle.with_line_mode("pinned"))
-    monkeypatch.delenv("OKX_PAIR_FIRST_ORDER_HEAD")
-    monkeypatch.setenv("OKX_PAIR_NO_HEAD", "1")
+    monkeypatch.setenv("OKX_DEV", "pair_no_head")
     assert "okx_quad_head_u(QHeadArgs" not in _source(axle.with_line_mode("pinned"))
-    monkeypatch.delenv("OKX_PAIR_NO_HEAD")
-    monkeypatch.setenv("OKX_QUAD_NO_HEAD", "1")
+    monkeypatch.setenv("OKX_DEV", "quad_no_head")
     assert "okx_quad_head_u(QHeadArgs" not in _source(dw.with_line_mode("pinned"))
 
 

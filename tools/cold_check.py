@@ -39,11 +39,11 @@ def case(label, program, targets, timed=True, **kw):
     t = torch.as_tensor(targets, device=dev)
     geo = {k: torch.as_tensor(v, device=dev) for k, v in kw.items() if isinstance(v, np.ndarray)}
     other = {k: v for k, v in kw.items() if not isinstance(v, np.ndarray)}
-    os.environ.pop("OKX_QUAD_NO_COLD", None)
+    os.environ.pop("OKX_DEV", None)
     pc, ic, mc = run(dp, t, program.n_out, timed, **geo, **other)
-    os.environ["OKX_QUAD_NO_COLD"] = "1"
+    os.environ["OKX_DEV"] = "no_cold"
     pg, ig, mg = run(dp, t, program.n_out, timed, **geo, **other)
-    os.environ.pop("OKX_QUAD_NO_COLD", None)
+    os.environ.pop("OKX_DEV", None)
     ok = (ig["flags"] & 7) == 1
     d = np.abs(pc - pg).reshape(len(ok), -1).max(axis=1)
     print(f"{label:46s} n={len(ok):7d} cold {1e3 * mc:8.2f} us  general {1e3 * mg:8.2f} us  nfev {ic['nfev'].mean():.3f} / {ig['nfev'].mean():.3f}"

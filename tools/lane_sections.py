@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Instruction counts per section of the lane kernel's full pass, from a kernel generated with OKX_LANE_MARK=1
-(`OKX_LANE_MARK=1 bash tools/lane_isa.sh dw` writes /tmp/q/lane_okx_lane_solve_u.s).  Sections are delimited by
+"""Instruction counts per section of the lane kernel's full pass, from a kernel generated with OKX_DEV=lane_mark
+(`OKX_DEV=lane_mark bash tools/lane_isa.sh dw` writes /tmp/q/lane_okx_lane_solve_u.s).  Sections are delimited by
 `s_nop 11..16`: 1 rows (residuals, gradients, J^T r, diagonal), 2 LM decision, 3 factorisation + forward substitution,
 4 backward substitution, 5 step bookkeeping, 6 rest of the kernel."""
 import collections, re, sys

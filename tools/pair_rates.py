@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel time of the pair-mode fixtures at 16384 problems (cold / chained), for A/B of generator switches:
-   OKX_PAIR_XQ_DPP=1 OKX_KERNEL_CACHE=... python3 tools/pair_rates.py [fixture ...]"""
+   OKX_DEV=1 OKX_KERNEL_CACHE=... python3 tools/pair_rates.py [fixture ...]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,24 +1,21 @@
 #!/bin/bash
-# Instruction mix of the generated quad kernel for a BASELINE program (no GPU needed).
-#   tools/quad_isa.sh dw|mac|axle [waves]
+# Registers, scratch, LDS and the instruction mix of the generated quad kernels of a BASELINE program (no GPU needed):
+# compiles into a scratch kernel cache (developer switches in OKX_DEV are honoured, the source is kept beside the code).
+#   tools/quad_isa.sh dw|mac|axle [cache dir]
 set -e
 cd "$(dirname "$0")/.."
-which=${1:-dw}; waves=${2:-1}
-export OKX_KERNEL_CACHE=/tmp/q/cache_${which}_${waves} OKX_QUAD_WAVES=$waves
-rm -rf $OKX_KERNEL_CACHE; mkdir -p $OKX_KERNEL_CACHE
-python - "$which" <<'PY'
-import sys
-from open_kinematics_amd import _lib
-from open_kinematics_amd._abi import HostProgram
-from open_kinematics_amd.workloads import axle_grid_problem, bump_sweep_problem, macpherson_grid_problem
-lib = _lib.load()
-program, _ = {"dw": lambda: bump_sweep_problem(5), "mac": lambda: macpherson_grid_problem(4, 4), "axle": lambda: axle_grid_problem(4, 4)}[sys.argv[1]]()
-rc = lib.okx_precompile(HostProgram(program).byref())
-print("precompile", rc, _lib.last_error() if rc else "")
-PY
-tail -c +25 $OKX_KERNEL_CACHE/*.okxc > /tmp/q/k.hsaco   # strip the 24-byte cache header
-/opt/rocm/lib/llvm/bin/llvm-objdump -d /tmp/q/k.hsaco > /tmp/q/k.s
-awk '/<okx_quad_solve_u>:/{f=1} /<okx_quad_solve_g>:/{f=0} f' /tmp/q/k.s > /tmp/q/u.s
-echo "total instrs: $(grep -c '^\s*[a-z]' /tmp/q/u.s)"
-for pat in v_fma_f64 v_mul_f64 v_add_f64 v_fmac_f64 v_mov_b32_dpp v_accvgpr_read v_accvgpr_write v_cndmask v_mov_b32_e32 scratch_ s_waitcnt s_nop global_load v_rcp_f64 v_rsq_f64 v_cmp v_max_f64; do echo "  $pat: $(grep -c "$pat" /tmp/q/u.s)"; done
-/opt/rocm/lib/llvm/bin/llvm-readelf --notes /tmp/q/k.hsaco | grep -E "\.name:|vgpr_count|agpr_count|sgpr_count|private_segment_fixed|vgpr_spill" | paste - - - - - - | head -5
+which=${1:-dw}; d=${2:-/tmp/okx_isa_$which}
+rm -rf "$d"; mkdir -p "$d"
+OKX_KERNEL_CACHE=$d OKX_DEV="${OKX_DEV:+$OKX_DEV,}keep_source,no_lane" python3 tools/precompile.py "$which"
+cd "$d"
+for f in okxq*.okxc; do
+  b=$(basename "$f" .okxc); tail -c +25 "$f" > "$b.hsaco"   # strip the 24-byte cache header
+  /opt/rocm/lib/llvm/bin/llvm-objdump -d "$b.hsaco" > "$b.s"
+  grep -q "okx_quad_solve_u" "$b.s" || continue
+  /opt/rocm/lib/llvm/bin/llvm-readelf --notes "$b.hsaco" | grep -E "\.name:|\.vgpr_count|agpr_count|\.sgpr_count|private_segment_fixed|group_segment_fixed" | paste - - - - - - | grep -E "solve|cold"
+  for k in okx_quad_solve_u okx_quad_cold_u; do
+    awk -v k="<$k>:" '$0 ~ /^[0-9a-f]+ <.*>:/{f = index($0,k)>0} f' "$b.s" > "$k.s"
+    [ -s "$k.s" ] || continue
+    echo "== $k: $(grep -c '^\s*[a-z]' $k.s) instructions; fp64 $(grep -c -E 'v_(fma|mul|add|fmac)_f64' $k.s) dpp $(grep -c dpp $k.s) accvgpr $(grep -c accvgpr $k.s) cndmask $(grep -c cndmask $k.s) s_waitcnt $(grep -c s_waitcnt $k.s) global loads $(grep -c -E 'global_load|flat_load' $k.s) lane spills $(grep -c -E 'v_readlane|v_writelane' $k.s) scratch $(grep -c scratch_ $k.s)   ($d/$k.s)"
+  done
+done

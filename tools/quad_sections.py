@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Instruction counts per section of the quad kernel's full pass, from a kernel generated with OKX_QUAD_MARK=1
-(`OKX_QUAD_MARK=1 OKX_QUAD_NO_LIGHT=1 bash tools/quad_isa.sh dw` writes /tmp/q/u.s).  Sections are delimited by
+"""Instruction counts per section of the quad kernel's full pass, from a kernel generated with OKX_DEV=quad_mark
+(`OKX_DEV=quad_mark,quad_no_light bash tools/quad_isa.sh dw` writes /tmp/q/u.s).  Sections are delimited by
 `s_nop 11..17`: 1 row residual + gradient, 2 chain blocks + J^T r, 3 J^T J, 4 after the row, 5 factorisation,
 6 substitution, 7 after the solve."""
 import collections, re, sys

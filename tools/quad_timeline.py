@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """C2 cold sweep: the cold body against the general body (same answers? time per launch), and - from a build generated with
-OKX_QUAD_TIMELINE=1 - where a wavefront's cycles go (shader-clock stamps of every wavefront: entry, first step in hand, top of
+OKX_DEV=quad_timeline - where a wavefront's cycles go (shader-clock stamps of every wavefront: entry, first step in hand, top of
 each LM pass, passes done, records stored, end).
-   OKX_QUAD_TIMELINE=1 OKX_KERNEL_CACHE=/tmp/tl python3 tools/quad_timeline.py [n_problems]"""
+   OKX_DEV=quad_timeline OKX_KERNEL_CACHE=build/kc_tl python3 tools/quad_timeline.py [n_problems]"""
 import ctypes as C
 import os
 import sys
@@ -37,7 +37,7 @@ def run(label):
     return pos, inf
 
 
-if os.environ.get("OKX_QUAD_TIMELINE"):
+if "quad_timeline" in os.environ.get("OKX_DEV", ""):
     waves = (n + 15) // 16
     tr = torch.zeros((2 * waves, 16), dtype=torch.float64, device=dev)
     dp.lib.okx_debug_quad_trace(dp._handle, C.c_void_p(tr.data_ptr()), -1)
@@ -87,6 +87,6 @@ if os.environ.get("OKX_QUAD_TIMELINE"):
     sys.exit(0)
 
 pos_c, inf_c = run("cold body")
-os.environ["OKX_QUAD_NO_COLD"] = "1"
+os.environ["OKX_DEV"] = "no_cold"
 pos_g, inf_g = run("general")
 print(f"max |cold - general| = {np.max(np.abs(pos_c - pos_g)):.3e} mm; nfev equal: {np.array_equal(inf_c['nfev'], inf_g['nfev'])}")
