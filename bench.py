@@ -966,14 +966,8 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         sus_wall, sus_ms = time_launches(launches[0], 2000, 10, device)
         line["sustained"] = {"value": (hi - lo) / sus_wall, "kernel_ms": sus_ms, "launches": 2000,
                              "note": "the same launch 2000 times back to back on one stream, one HIP-event pair around them"}
-        # Zero-copy leg first among the extras.  Its rate depends on the state of the process in a way that is measured
-        # but not explained (tools/zc_order.py): 62 us per sweep (2.6e8 solves/s, 48 GB/s of PCIe stores) alone or as the
-        # first leg, 105 ... 360 us after a second DeviceProgram, the graph-replay leg or an earlier zero-copy leg have run.
-        zero_copy = measure_e2e_zero_copy(dp, targets_all[lo:hi], device, 200, dict(chain_len=args.chain_len, predictor=False))
-        zero_copy["note"] += ("; measured before every other extra leg: the same leg run later in the process has been seen at a "
-                              "fifth of this rate (profiles/r03/EXPERIMENTS.md section 6)")
-        line["one_shot"] = measure_one_shot(program, targets, device, kernel_ms)
     if world == 1 and not args.no_extras and not args.rccl_world_one:
+        line["one_shot"] = measure_one_shot(program, targets, device, kernel_ms)
         extra_steps = max(5, min(args.steps, 50))
         own = dp.plan(targets, out=pipe.solve_buffers[0], info_out=info, chain_len=args.chain_len, predictor=False, shared_first_step=False)
         own_wall, own_ms = time_launches(own, args.steps, args.warmup, device)
@@ -986,7 +980,10 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, extra_steps, dict(chain_len=args.chain_len, predictor=False))
         line["e2e"]["compact"] = measure_e2e_compact(dp, targets_all[lo:hi], device, max(extra_steps, 200),
                                                      dict(chain_len=args.chain_len, predictor=False))
-        line["e2e"]["zero_copy"] = zero_copy
+        # (last of the host-to-host legs on purpose: round 3 measured this leg at a fifth of its rate whenever another leg had
+        #  run before it; the cause - 24-byte store fragments whose merging on the way to the host depended on timing - is
+        #  gone with the cold body's staged stores, profiles/r04/EXPERIMENTS.md section 5)
+        line["e2e"]["zero_copy"] = measure_e2e_zero_copy(dp, targets_all[lo:hi], device, 200, dict(chain_len=args.chain_len, predictor=False))
         from open_kinematics_amd.workloads import geometry_path
         line["downstream"] = measure_downstream(dp, geometry_path("geometry.yaml"), pipe.solve_buffers[0], device)
         dp.close()

@@ -996,6 +996,11 @@ class LGen {
 const char* kLanePreamble = R"SRC(
 // Generated by okx_lanegen.cpp for one constraint program — do not edit.
 typedef struct { double max_residual, cost, last_step; int iterations, nfev, flags, reserved; } okx_info;
+// One wavefront per workgroup: its LDS instructions execute in program order, so what separates a lane's LDS writes from
+// another lane's reads is an ordering for the COMPILER.  __syncthreads() is more than that: a workgroup-scope release
+// fence, i.e. a wait for every global store the wavefront has in flight - the record stores of a wave unit (4 us of HBM
+// time for 64 records) would be waited for before the next unit may start instead of draining behind it.
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 struct QArgs {
   const double* targets; const double* geom_pos; const double* geom_row_param;
   double* out_pos; okx_info* info;
@@ -1337,7 +1342,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     } else
       for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[first_b * %d + %d];", t, T, t);
     g.f("    // the geometry's tables (and its first-step table) into LDS, lane k fetching entry k");
-    g.f("    __syncthreads();  // (the previous wave unit's last reads of these areas are done)");
+    g.f("    WAVE_SYNC();  // (the previous wave unit's last reads of these areas are done)");
     if (fl) {
       g.f("    if (span_idx != staged_span) {  // wave-uniform: the tables stay while the geometry does");
       stage_tables(g, "      ");
@@ -1350,7 +1355,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
     g.f("      for (int k = lane; k < %d; k += 64) lds[%d + k] = hp[k];", head_stride, head_l0);
     g.f("    }");
-    g.f("    __syncthreads();");
+    g.f("    WAVE_SYNC();");
     g.f("    %s", refresh_kz);
     for (int p = 0; p < NP; ++p) {
       if (!used[p] || is_fixed(p)) continue;
@@ -1682,7 +1687,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       // (okx_solve_opts.output: the full record, the free points alone in the program's free_point order, or nothing)
       g.f("      if (FULL || a.out_mode == 1) {");
       g.f("      const int rec = FULL ? %d : %d;", 3 * P.n_out, n);
-      g.f("      __syncthreads();");
+      g.f("      WAVE_SYNC();");
       g.f("      if (FULL) {");
       g.f("      double* st = lds + lane * %d;", 3 * P.n_out);
       for (int k = 0; k < P.n_out; ++k)
@@ -1691,7 +1696,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      double* st = lds + lane * %d;", n);
       for (int i = 0; i < n; ++i) g.f("      st[%d] = %s;", 3 * ev.perm[i / 3] + i % 3, PF(i).c_str());
       g.f("      }");
-      g.f("      __syncthreads();");
+      g.f("      WAVE_SYNC();");
       g.f("      const long long base_b = span_idx * span + wave_in_span * 64;");
       g.f("      const long long rem = (span_idx + 1) * span - base_b;");
       g.f("      const int n_doubles = (int)(rem < 64 ? rem : 64) * rec;");
@@ -1704,7 +1709,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      } else {");
       g.f("        for (int i = lane; i < n_doubles; i += 64) dst[i] = lds[i];");
       g.f("      }");
-      g.f("      __syncthreads();");
+      g.f("      WAVE_SYNC();");
       g.f("      }");
     } else {
       // chains: a lane's problems are far apart in memory, every lane stores its own record

@@ -1237,7 +1237,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   const bool fixed_in_regs = pv != nullptr && !lds_homes;
   ev.pin_ata = ev.pin_atr = true;
   ev.marks = dev_switch("quad_mark");
-  ev.tl_marks = !pv && dev_switch("quad_timeline");
+  ev.tl_marks = dev_switch("quad_timeline");
   for (int e = 0; e < P.n_derived; ++e) ev.dp(e);  // every derived-op parameter is chain-constant
   ev.f("    // ---- active derived points with chain-rule blocks ----");
   for (int idx = 0; idx < P.n_active; ++idx)
@@ -1532,6 +1532,98 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   std::string final_src;
   bool body_failed = false;
   auto emit_body = [&](const bool CD) {
+  // One damped step from the normal equations in hand: declarations of the factor's registers, then (single mode) LDL^T +
+  // substitutions, or (pair mode) each half's factorisation and the Woodbury system of the joining rows.  Leaves nx{F}, ok,
+  // pmin, pmax (pair mode also pcoup, kc).  Emitted in the general loop and in the cold body's fast loop: the same text.
+  auto emit_solve_step = [&]() {
+  // declare factor / fill-in registers
+  for (int F = 0; F < nf; ++F)
+    for (int G = 0; G <= F; ++G)
+      if (ev.fillf[F][G]) {
+        for (int k = 0; k < 3; ++k) {
+          if (!(F == G && k == 2)) g.f("    double %s;", Gen::Ln(F, G, k).c_str());
+          if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
+        }
+      }
+  // the diagonal-block factor entry for k == 2 is never needed (no row below inside the block)
+  if (!pv) {
+    g.out += solve_src;
+  } else {
+    // (D + w w^T) dx = -g with D = blockdiag of the two halves' damped J^T J and w = (w_L, w_R) the joining row's
+    // Jacobian.  D alone is nearly singular once the damping has decayed (the partner's rack pickup slides along
+    // its line), so each half takes its own part of the rank-one term, Dt = D + blockdiag(w_L w_L^T, w_R w_R^T),
+    // and the off-diagonal coupling u v^T + v u^T (u = (w_L, 0), v = (0, w_R)) goes through a 2 x 2 Woodbury
+    // system: dx = y - z c, Dt y = -g, Dt z = w (per half), c = (s_partner - g_partner s_own) / (1 - g_own g_partner)
+    // with g = w.z and s = w.y of each half.  (Plain Sherman-Morrison on D cancels catastrophically there.)
+    if (NK > 1) {
+      g.out += join_rank_one_src();
+      ev.out.clear();
+      ev.emit_factor();
+      g.out += ev.out;
+      g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
+      g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
+      std::vector<std::string> rhs_g;
+      for (int F = 0; F < nf; ++F) rhs_g.push_back("-gn" + std::to_string(F));
+      for (int F = 0; F < nf; ++F) g.f("    double ny%d;", F);
+      ev.out.clear();
+      ev.emit_substitute(rhs_g, "sy");
+      g.f("    {");
+      g.out += ev.out;
+      for (int F = 0; F < nf; ++F) g.f("    ny%d = sy%d;", F, F);
+      g.f("    }");
+      g.out += join_z_src();
+      for (int F = 0; F < nf; ++F) g.f("    double nx%d;", F);
+      g.f("    {");
+      g.out += join_correct_src([&](int F) { return "ny" + std::to_string(F); },
+                                [&](int F, const std::string& e) { return sfmt("    nx%d = %s;\n", F, e.c_str()); });
+      g.f("    }");
+      // tied modes: one per joining row, each judged as in the single-row case (the halves' compliances along w_j in parallel)
+      std::string kc = "1e300";
+      for (int j = 0; j < NK; ++j)
+        kc = sfmt("fmin(%s, (1.0 - smG%d_%d) * fast_rcp(smG%d_%d) + (1.0 - smH%d_%d) * fast_rcp(smH%d_%d))", kc.c_str(), j, j, j, j, j, j, j, j);
+      g.f("    const double kc = %s;", kc.c_str());
+      g.f("    const double pcoup = fmax(kc - 2.0 * lambda, 0.0);");
+      g.f("    pmin = fmin(pmin, fmax(kc, 0.0));");
+    } else {
+    for (int k = 0; k < 3; ++k)
+      g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
+    ev.out.clear();
+    ev.emit_factor();
+    g.out += ev.out;
+    g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
+    g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
+    std::vector<std::string> rhs_g, rhs_w;
+    for (int F = 0; F < nf; ++F) rhs_g.push_back("-gn" + std::to_string(F)), rhs_w.push_back(F == FU ? "cu" : "0.0");
+    for (int F = 0; F < nf; ++F) g.f("    double ny%d, nz%d;", F, F);
+    ev.out.clear();
+    ev.emit_substitute(rhs_g, "sy");
+    g.f("    {");
+    g.out += ev.out;
+    for (int F = 0; F < nf; ++F) g.f("    ny%d = sy%d;", F, F);
+    g.f("    }");
+    ev.out.clear();
+    ev.emit_substitute(rhs_w, "sz");
+    g.f("    {");
+    g.out += ev.out;
+    for (int F = 0; F < nf; ++F) g.f("    nz%d = sz%d;", F, F);
+    g.f("    }");
+    g.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g), sm_s = qsum(cu * ny%d);", FU, FU);
+    g.f("    const double sm_k = (xq(sm_s) - sm_gp * sm_s) * fast_rcp(1.0 - sm_g * sm_gp);");
+    for (int F = 0; F < nf; ++F) g.f("    const double nx%d = fma(-nz%d, sm_k, ny%d);", F, F, F);
+    // Conditioning of the COUPLED system.  Each half was regularised with its own part of the joining row (Dt = D + w w^T,
+    // |w| = 1), so the halves' pivots say nothing about the one mode the joining row ties together: both joined points
+    // moving along w.  With s = w^T D^-1 w of a half (the compliance of that half along w), g = w^T Dt^-1 w = s / (1 + s),
+    // so 1 / s = (1 - g) / g, and the stiffness of the tied mode is the two halves' in parallel: (1 - g_L) / g_L +
+    // (1 - g_R) / g_R.  It joins the pivots in the ill-conditioned test (and in the predicted-convergence bound).
+    // With damping each half's share is at least lambda (s <= 1 / lambda), so what the damping did not put there is
+    // kc - 2 lambda; `pcoup` carries it to the conditioning test, kc itself bounds the predicted convergence with the pivots.
+    g.f("    const double kc = (1.0 - sm_g) * fast_rcp(sm_g) + (1.0 - sm_gp) * fast_rcp(sm_gp);");
+    g.f("    const double pcoup = fmax(kc - 2.0 * lambda, 0.0);");
+    g.f("    pmin = fmin(pmin, fmax(kc, 0.0));");
+    }
+  }
+  };
+  n_state_slots = 0;  // (pair mode: each body numbers its LDS homes from zero)
   const bool tl_body = CD && ev.tl_marks;
   if (tl_body)  // sections of the SECOND full pass of a wavefront go to a second table behind the first: a.trace[16 (waves + w) + k]
     g.f("#undef OKX_TL\n#define OKX_TL(k) if (a.trace && tl_pass == 4 && (threadIdx.x & 63) == 0) a.trace[(gridDim.x + blockIdx.x) * 16 + (k)] = (double)__builtin_readcyclecounter();");
@@ -1566,19 +1658,20 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // values is a 64-lane load of 8 ... 32 distinct bytes: the four wavefronts of a CU queue ~330 of them on its one L1,
   // ~4000 cycles before the first pass starts (timeline stamps, tools/quad_timeline.py).
   const int cs_head = 0, cs_pos = (head_stride + 1) / 2 * 2, cs_rp = cs_pos + (3 * prog_points + 1) / 2 * 2,
-            cs_dp = cs_rp + 8 * (prog_crows + prog_targets), cs_end = cs_dp + (P.n_derived + 1) / 2 * 2 + 2;
+            cs_dp = cs_rp + 8 * (prog_crows + prog_targets), cs_end = cs_dp + (program.n_derived + 1) / 2 * 2 + 2;
   if (CD) {
     g.f("  __shared__ __attribute__((aligned(16))) double cst[%d];  // [first-step table | design positions | row parameters | derived-op parameters]", cs_end);
     for (int t = 0; t < T; ++t) g.f("  double tpre%d;", t);
     g.f("  {");
     // the targets of this wavefront's first unit travel with the tables (after the staging they would be a round trip of their own)
-    g.f("    long long tu0 = (long long)blockIdx.x * %d + (lane >> 2); if (tu0 >= a.n_problems) tu0 = a.n_problems - 1;", PPW);
+    g.f("    long long tu0 = (long long)blockIdx.x * %d + quad; if (tu0 >= a.n_problems) tu0 = a.n_problems - 1;", PPW);
+    if (pv) g.f("    const int q1 = q1_lane; (void)q1;");
     for (int t = 0; t < T; ++t) g.f("    tpre%d = a.targets[tu0 * %d + %s];", t, prog_targets, ev.target_slot(t).c_str());
     g.f("    const double2* h2 = reinterpret_cast<const double2*>(a.head);  // (hipMalloc'ed: 256-byte aligned)");
     g.f("    double2* c2 = reinterpret_cast<double2*>(cst);");
     // every load first (clamped indices: no branch), then the stores: one round trip
     struct Piece { const char* src; int n, off; };
-    const Piece pieces[] = {{"a.design_pos", 3 * prog_points, cs_pos}, {"a.row_param", 8 * (prog_crows + prog_targets), cs_rp}, {"a.dop_param", P.n_derived, cs_dp}};
+    const Piece pieces[] = {{"a.design_pos", 3 * prog_points, cs_pos}, {"a.row_param", 8 * (prog_crows + prog_targets), cs_rp}, {"a.dop_param", program.n_derived, cs_dp}};  // (the PROGRAM's tables: both halves')
     const int n2 = (head_stride + 1) / 2;  // (the table's allocation is rounded up to an even count of doubles)
     for (int k = 0; 64 * k < n2; ++k) g.f("    double2 sh%d = h2[min(lane + %d, %d)];", k, 64 * k, n2 - 1);
     for (int q = 0; q < 3; ++q)
@@ -1594,8 +1687,14 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         pin += std::string(first ? "" : ", ") + "\"+v\"(sh" + std::to_string(k) + ".x), \"+v\"(sh" + std::to_string(k) + ".y)";
         first = false;
       }
+      g.out += pin + ");\n";  // (an asm statement takes 30 operands: the three tables' values in one of their own)
+      pin = "    asm volatile(\"\" : ";
+      first = true;
       for (int q = 0; q < 3; ++q)
-        for (int k = 0; 64 * k < pieces[q].n; ++k) pin += ", \"+v\"(sp" + std::to_string(q) + "_" + std::to_string(k) + ")";
+        for (int k = 0; 64 * k < pieces[q].n; ++k) {
+          pin += std::string(first ? "" : ", ") + "\"+v\"(sp" + std::to_string(q) + "_" + std::to_string(k) + ")";
+          first = false;
+        }
       g.out += pin + ");\n";
     }
     for (int k = 0; 64 * k < n2; ++k) g.f("    if (lane + %d < %d) c2[lane + %d] = sh%d;", 64 * k, n2, 64 * k, k);
@@ -1609,7 +1708,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   (void)cs_head;
   if (ev.lds_constants) {
     g.out += lds_decl;
-    g.f("  __shared__ double xsl[%d];  // accepted point, chain history and the step in hand [block][lane]", 64 * 4 * nf);
+    g.f("  __shared__ double xsl[%d];  // accepted point, chain history and the step in hand [block][lane]", 64 * (CD ? 2 : 4) * nf);
     int n_fixed = 0;
     for (int p = 0; p < NP; ++p) n_fixed += ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
     if (!fixed_in_regs) g.f("  __shared__ double psl[%d];  // fixed points [point][lane]", 64 * (n_fixed > 0 ? n_fixed : 1));
@@ -1645,7 +1744,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      else { span_idx = unit / chains_per_span; chain_in_span = unit - span_idx * chains_per_span; }");
   g.f("    }");
   }
-  if (pair_state_lds) {
+  if (pair_state_lds && CD) {
+    g.f("    const long long first_b = unit, geom = 0; (void)geom; (void)span_idx;");
+    g.f("    const double* gp = cst + %d;", cs_pos);
+    g.f("    const double* gq = c_rp;");
+  } else if (pair_state_lds) {
     // the chain's index bookkeeping and the table pointers (quad-uniform too) in LDS as well: [slot][quad side]
     g.f("    __shared__ long long lmi[%d];", 16 * 5);
     g.f("    long long& first_b = lmi[0 + qs]; first_b = span_idx * span + chain_in_span * unit_len;");
@@ -1705,7 +1808,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     }
   }
   for (int F = 0; F < nf; ++F) {
-    if (ev.lds_constants) {  // cold per-pass state lives in LDS (register-bound kernel): plain references, same code below
+    if (ev.lds_constants && CD) {  // cold pair body: the accepted point and the step in hand, no chain history
+      g.f("    double& x%d = xsl[%d + lane]; double& dx%d = xsl[%d + lane]; x%d = p%d; dx%d = 0.0;", F, 64 * F, F, 64 * (nf + F), F, ev.fp(F), F);
+    } else if (ev.lds_constants) {  // cold per-pass state lives in LDS (register-bound kernel): plain references, same code below
       g.f("    double& x%d = xsl[%d + lane]; double& xp%d = xsl[%d + lane]; double& xq%d = xsl[%d + lane];", F, 64 * (2 * F), F,
           64 * (2 * F + 1), F, 64 * (2 * nf + F));
       g.f("    double& dx%d = xsl[%d + lane];", F, 64 * (3 * nf + F));
@@ -1719,14 +1824,17 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   if (CD && head_ok) {
     // the first-step table's entries travel with the loads above: ONE batch, nothing computed in between (a scheduling
     // barrier keeps the arithmetic below from being interleaved, which would issue the rest of the loads a round trip later)
+    // (pair mode: each half reads its own Q and S blocks of the staged table where they are used - LDS reads, nothing to batch)
     g.f("    const double* hp = cst;");
-    g.f("    const double* hqb = hp;");
-    g.f("    const double* hsb = hp; (void)hsb;");
+    g.f("    const double* hqb = hp%s;", pv ? (" + (q1 ? " + std::to_string(head_side) + " : 0)").c_str() : "");
+    g.f("    const double* hsb = hp%s; (void)hsb;", pv ? (" + (q1 ? " + std::to_string(head_s_side) + " : 0)").c_str() : "");
+    if (!pv)
     for (int k = 0; k < HK; ++k)
       for (int F = 0; F < nf; ++F) g.f("    const double hq%d_%d = hqb[%d + c];", k, F, 4 * (k * nf + F));
     for (int j = 0; j < HK; ++j)
       for (int k = j; k < HK; ++k) g.f("    const double hm%d_%d = hp[%d];", j, k, head_off - 2 * HK * HK + j * HK + k);
     for (int i = 0; i < 7; ++i) g.f("    const double hs%d = hp[%d];", i, head_off + i);
+    if (!pv)
     for (int pi = 0; pi < NPAIR; ++pi)
       for (int F = 0; F < nf; ++F) g.f("    const double hS%d_%d = hsb[%d + c];", pi, F, head_s_off + 4 * (pi * nf + F));
     g.f("    __builtin_amdgcn_sched_barrier(0);");
@@ -1809,12 +1917,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
           const int s2 = head_pairs[pi].first, t2 = head_pairs[pi].second;
           const std::string w = pv ? "hv" + std::to_string(pi)
                                    : std::string(s2 == t2 ? "0.5" : "1.0") + " * hr" + std::to_string(s2) + " * hr" + std::to_string(t2);
-          e2 += (pi ? " + " : "") + w + (CD ? " * hS" + std::to_string(pi) + "_" + std::to_string(F)
+          e2 += (pi ? " + " : "") + w + (CD && !pv ? " * hS" + std::to_string(pi) + "_" + std::to_string(F)
                                             : " * hsb[" + std::to_string(head_s_off + 4 * (pi * nf + F)) + " + c]");
         }
         g.f("      const double hxa%d = -(%s), hxb%d = -(%s);", F, e.c_str(), F, e2.c_str());
         g.f("      hst1 = fmax(hst1, fabs(hxa%d)); hst2 = fmax(hst2, fabs(hxb%d));", F, F);
-        if (pv) {  // the first-order part waits in LDS, where the finished step goes anyway
+        if (pv && !CD) {  // the first-order part waits in LDS, where the finished step goes anyway
           g.f("      hxl[%d + lane] = hxa%d;", 64 * F, F);
           if (F % 2 == 1) g.f("      __builtin_amdgcn_sched_barrier(0);");
         }
@@ -1856,6 +1964,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   if (CD) {
     g.f("    const int hist = 1; const bool cold = false; const double lambda_carry = 0.0; (void)hist; (void)cold; (void)lambda_carry;");
+    if (pair_state_lds) g.f("    __shared__ int lmk[%d];  // per-quad counters [slot][quad side]", 16 * 6);
   } else {
   if (pair_state_lds) {
     g.f("    __shared__ int lmk[%d];  // per-quad counters [slot][quad side]", 16 * 6);
@@ -2073,87 +2182,86 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     // The passes of a cold start whose every trial point is accepted - what a sweep inside the reach does - written for
     // exactly that: the quads that are still iterating run under ONE exec mask per pass (no per-statement predication),
     // no modes, no rejected-step bookkeeping.  The first quad that needs anything else (a rejected or non-finite trial
-    // point, a stop on the cost test, a failed factorisation, the iteration cap, no usable table) sends its WAVEFRONT
-    // back to the start of the unit and through the general loop below, which reproduces the general body pass for pass.
-    // Same evaluation, factorisation and update formulas as there (eval_src / solve_src / light_src are the same text).
-    g.f("      bool redo = wave_any(valid && mode != 1 && !done);  // a quad without a usable first step: the general loop");
+    // point, a stop on the cost test, the iteration cap, a failed factorisation, a confirming pass whose cost rose, no
+    // usable table) hands its WAVEFRONT over to the general loop below, in place: the state the fast loop keeps IS the
+    // general loop's state (mode 1, trial step in hand), so that loop takes the very evaluation the fast loop was about to
+    // judge once more and goes on as the general body would have - same decisions, same counts, same answers.
+    // Same evaluation, factorisation and update formulas as there (eval_src / the solve step / light_src are the same text).
+    g.f("      bool hand_over = wave_any(valid && mode != 1 && !done);  // a quad without a usable first step");
     // full passes while some quad that is still iterating has no step in hand that is predicted to be its last ...
     g.f("      const bool lights = a.confirm == 0;  // confirming passes are on");
-    g.f("      while (!redo && wave_any(!done && !(lights && want_light))) {");
+    g.f("      while (!hand_over && wave_any(!done && !(lights && want_light))) {");
     stamp("tl_pass < 12 ? tl_pass++ : 12");
     g.f("        if (!done) {");
     g.f("    want_light = false;");
     for (int F = 0; F < nf; ++F) g.f("    p%d = x%d + dx%d;", ev.fp(F), F, F);
     g.out += eval_src;
+    g.out += couple_eval;
     g.f("    const double Ft = 0.5 * ss;");
     g.f("    const double rho = (Fc - Ft) * fast_rcp(pred);");
     g.f("    const bool plain = Ft < 1e300 && pred > 0.0 && rho > 1e-4 && !(Fc - Ft <= a.ftol * Fc && pred <= a.ftol * Fc) && iters < a.max_iter;");
-    g.f("    if (wave_any(!plain)) { redo = true; break; }");
+    g.f("    if (wave_any(!plain)) { hand_over = true; break; }  // (nothing of this evaluation has been used yet)");
     for (int F = 0; F < nf; ++F) g.f("    x%d = p%d;", F, ev.fp(F));
     g.f("    last_step = step_len; Fc = Ft; mres = mres_new; ++nfev;");
     g.f("    { const double t = 2.0 * rho - 1.0;");
     g.f("      lambda *= (rho > 0.99 && (step_len <= 1.0 || Ft <= 1e-2)) ? 1e-3 : (rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t)); }");
     if (timeline) g.f("    OKX_TL(10)");
-    for (int F = 0; F < nf; ++F)
-      for (int G = 0; G <= F; ++G)
-        if (ev.fillf[F][G])
-          for (int k = 0; k < 3; ++k) {
-            if (!(F == G && k == 2)) g.f("    double %s;", Gen::Ln(F, G, k).c_str());
-            if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
-          }
-    g.out += solve_src;
+    emit_solve_step();
     g.f("    double sl = 0.0, pr = 0.0, dd = 0.0;");
     for (int F = 0; F < nf; ++F) g.f("    sl = fmax(sl, fabs(nx%d));", F);
     g.f("    sl = PMAX(sl);");
     for (int F = 0; F < nf; ++F) g.f("    pr = fma(nx%d, fma(lambda, nx%d, -gn%d), pr); dd = fma(nx%d, nx%d, dd);", F, F, F, F, F);
     g.f("    pr = 0.5 * PSUM(pr);");
     g.f("    dd = PSUM(dd);");
-    // every pivot positive = the smallest one is (the eighteen separate tests of the general loop are never asked for here);
-    // a NaN anywhere in the matrix reaches the step, hence dd
-    g.f("    if (wave_any(!(pmin > 0.0 && dd == dd))) { redo = true; break; }");
     g.f("    const double rq = dd > 0.0 ? (2.0 * pr - lambda * dd) * fast_rcp(dd) - lambda : 1e300;");
     g.f("    ++iters;");
-    g.f("    piv_lo = fmin(pmin - lambda, rq); piv_hi = pmax;");
-    for (int F = 0; F < nf; ++F) g.f("    dx%d = nx%d;", F, F);
-    g.f("    step_len = sl; pred = pr;");
-    g.f("    if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
-    g.f("    else {");
-    g.f("      const double cq = prev_sl > 0.0 ? fmax(3.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
-    g.f("      const double rho_lin = 100.0 * lambda * fast_rcp(pmin);");
-    g.f("      want_light = sl <= 1e-3 && (rho_lin + cq * sl) * sl <= a.step_tol;");
-    g.f("      prev_sl = sl;");
+    // every pivot positive = the smallest one is (the eighteen separate tests of the general loop are never asked for here);
+    // a NaN anywhere in the matrix reaches the step, hence dd.  (Pair mode: `ok` is part of the solve text - both halves
+    // must factor - so it is there anyway.)  A quad whose factorisation failed is left as the general loop leaves it.
+    g.f("    const bool factored = %s && dd == dd;", pv ? "ok" : "pmin > 0.0");
+    g.f("    if (factored) {");
+    if (pv) g.f("      piv_lo = fmin(fmin(pmin - lambda, pcoup), rq); piv_hi = pmax;");
+    else g.f("      piv_lo = fmin(pmin - lambda, rq); piv_hi = pmax;");
+    for (int F = 0; F < nf; ++F) g.f("      dx%d = nx%d;", F, F);
+    g.f("      step_len = sl; pred = pr;");
+    g.f("      if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
+    g.f("      else {");
+    g.f("        const double cq = prev_sl > 0.0 ? fmax(3.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
+    g.f("        const double rho_lin = 100.0 * lambda * fast_rcp(pmin);");
+    g.f("        want_light = sl <= 1e-3 && (rho_lin + cq * sl) * sl <= a.step_tol;");
+    g.f("        prev_sl = sl;");
+    g.f("      }");
+    g.f("    } else {");
+    g.f("      lambda = fmax(lambda * 10.0, 1e-12 * dmax);");
+    g.f("      if (++nfail > 60 || !(lambda < 1e30)) { flags |= INFO_FAILED; done = true; }");
+    g.f("      mode = 2;");
     g.f("    }");
+    g.f("    if (wave_any(!factored)) { hand_over = true; break; }");
     if (timeline) g.f("    OKX_TL(11)");
     g.f("        }  // quads still iterating");
     g.f("      }  // full passes");
     // ... then ONE confirming pass (residuals only) for the quads that are left, all of which want it (the general loop's
-    // rule: a confirming pass only when every quad still iterating asks for one).  A quad whose cost rose there needs more
-    // full passes: with the rest of its wavefront it goes back through the general loop.
+    // rule: a confirming pass only when every quad still iterating asks for one).  A quad whose cost rose there goes on
+    // with full passes: in the general loop, with the rest of its wavefront.
     if (light_ok) {
-      g.f("      if (!redo && wave_any(!done)) {");
+      g.f("      if (!hand_over && wave_any(!done)) {");
       stamp("tl_pass < 12 ? tl_pass++ : 12");
       g.f("        if (!done) {");
       for (int F = 0; F < nf; ++F) g.f("      p%d = x%d + dx%d;", ev.fp(F), F, F);
       g.out += light_src;
+      g.out += couple_light;
       g.f("      const double Fl = 0.5 * ss;");
-      g.f("      if (wave_any(!(Fl <= Fc * (1.0 + 1e-6) + 1e-28))) redo = true;");
-      g.f("      else {");
-      g.f("        ++nfev;");
+      g.f("      ++nfev;");
+      g.f("      if (Fl == Fl && Fl <= Fc * (1.0 + 1e-6) + 1e-28) {");
       for (int F = 0; F < nf; ++F) g.f("        x%d = p%d;", F, ev.fp(F));
       g.f("        Fc = Fl; mres = mres_new; last_step = step_len; flags |= INFO_CONVERGED; done = true;");
+      g.f("      } else {");
+      g.f("        want_light = false;");
       g.f("      }");
       g.f("        }");
       g.f("      }");
-    } else {
-      g.f("      if (!redo && wave_any(!done)) redo = true;  // (never: no quad asks for a confirming pass)");
     }
-    g.f("      if (redo) {  // back to the unit's start, through the general loop");
-    for (int F = 0; F < nf; ++F) g.f("        x%d = ld3(gp + %s + cc, c); dx%d = 0.0;", F, ev.point3(ev.fp(F)).c_str(), F);
-    g.f("        Fc = 0.0; lambda = 0.0; nu = 2.0; dmax = 0.0; step_len = 0.0; last_step = 0.0; mres = 0.0; pred = 0.0;");
-    g.f("        nfev = 0; iters = 0; flags = 0; nfail = 0; mode = 0; done = !valid; want_light = false;");
-    g.f("        prev_sl = 0.0; piv_lo = 0.0; piv_hi = 0.0;");
-    g.f("        HEAD_APPLY");
-    g.f("      }");
+    // (whatever is not done by now - handed over, or a confirming pass that did not confirm - is the general loop's)
   }
   g.f("      while (wave_any(!done)) {");
   stamp("tl_pass < 12 ? tl_pass++ : 12");
@@ -2260,92 +2368,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    const bool solve_now = !done && accept;");
   g.f("    if (!done && !accept) mode = 2;");
   g.f("    if (wave_any(solve_now)) {");
-  // declare factor / fill-in registers
-  for (int F = 0; F < nf; ++F)
-    for (int G = 0; G <= F; ++G)
-      if (ev.fillf[F][G]) {
-        for (int k = 0; k < 3; ++k) {
-          if (!(F == G && k == 2)) g.f("    double %s;", Gen::Ln(F, G, k).c_str());
-          if (!ev.nz[F][G]) g.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
-        }
-      }
-  // the diagonal-block factor entry for k == 2 is never needed (no row below inside the block)
-  if (!pv) {
-    g.out += solve_src;
-  } else {
-    // (D + w w^T) dx = -g with D = blockdiag of the two halves' damped J^T J and w = (w_L, w_R) the joining row's
-    // Jacobian.  D alone is nearly singular once the damping has decayed (the partner's rack pickup slides along
-    // its line), so each half takes its own part of the rank-one term, Dt = D + blockdiag(w_L w_L^T, w_R w_R^T),
-    // and the off-diagonal coupling u v^T + v u^T (u = (w_L, 0), v = (0, w_R)) goes through a 2 x 2 Woodbury
-    // system: dx = y - z c, Dt y = -g, Dt z = w (per half), c = (s_partner - g_partner s_own) / (1 - g_own g_partner)
-    // with g = w.z and s = w.y of each half.  (Plain Sherman-Morrison on D cancels catastrophically there.)
-    if (NK > 1) {
-      g.out += join_rank_one_src();
-      ev.out.clear();
-      ev.emit_factor();
-      g.out += ev.out;
-      g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
-      g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
-      std::vector<std::string> rhs_g;
-      for (int F = 0; F < nf; ++F) rhs_g.push_back("-gn" + std::to_string(F));
-      for (int F = 0; F < nf; ++F) g.f("    double ny%d;", F);
-      ev.out.clear();
-      ev.emit_substitute(rhs_g, "sy");
-      g.f("    {");
-      g.out += ev.out;
-      for (int F = 0; F < nf; ++F) g.f("    ny%d = sy%d;", F, F);
-      g.f("    }");
-      g.out += join_z_src();
-      for (int F = 0; F < nf; ++F) g.f("    double nx%d;", F);
-      g.f("    {");
-      g.out += join_correct_src([&](int F) { return "ny" + std::to_string(F); },
-                                [&](int F, const std::string& e) { return sfmt("    nx%d = %s;\n", F, e.c_str()); });
-      g.f("    }");
-      // tied modes: one per joining row, each judged as in the single-row case (the halves' compliances along w_j in parallel)
-      std::string kc = "1e300";
-      for (int j = 0; j < NK; ++j)
-        kc = sfmt("fmin(%s, (1.0 - smG%d_%d) * fast_rcp(smG%d_%d) + (1.0 - smH%d_%d) * fast_rcp(smH%d_%d))", kc.c_str(), j, j, j, j, j, j, j, j);
-      g.f("    const double kc = %s;", kc.c_str());
-      g.f("    const double pcoup = fmax(kc - 2.0 * lambda, 0.0);");
-      g.f("    pmin = fmin(pmin, fmax(kc, 0.0));");
-    } else {
-    for (int k = 0; k < 3; ++k)
-      g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
-    ev.out.clear();
-    ev.emit_factor();
-    g.out += ev.out;
-    g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
-    g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
-    std::vector<std::string> rhs_g, rhs_w;
-    for (int F = 0; F < nf; ++F) rhs_g.push_back("-gn" + std::to_string(F)), rhs_w.push_back(F == FU ? "cu" : "0.0");
-    for (int F = 0; F < nf; ++F) g.f("    double ny%d, nz%d;", F, F);
-    ev.out.clear();
-    ev.emit_substitute(rhs_g, "sy");
-    g.f("    {");
-    g.out += ev.out;
-    for (int F = 0; F < nf; ++F) g.f("    ny%d = sy%d;", F, F);
-    g.f("    }");
-    ev.out.clear();
-    ev.emit_substitute(rhs_w, "sz");
-    g.f("    {");
-    g.out += ev.out;
-    for (int F = 0; F < nf; ++F) g.f("    nz%d = sz%d;", F, F);
-    g.f("    }");
-    g.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g), sm_s = qsum(cu * ny%d);", FU, FU);
-    g.f("    const double sm_k = (xq(sm_s) - sm_gp * sm_s) * fast_rcp(1.0 - sm_g * sm_gp);");
-    for (int F = 0; F < nf; ++F) g.f("    const double nx%d = fma(-nz%d, sm_k, ny%d);", F, F, F);
-    // Conditioning of the COUPLED system.  Each half was regularised with its own part of the joining row (Dt = D + w w^T,
-    // |w| = 1), so the halves' pivots say nothing about the one mode the joining row ties together: both joined points
-    // moving along w.  With s = w^T D^-1 w of a half (the compliance of that half along w), g = w^T Dt^-1 w = s / (1 + s),
-    // so 1 / s = (1 - g) / g, and the stiffness of the tied mode is the two halves' in parallel: (1 - g_L) / g_L +
-    // (1 - g_R) / g_R.  It joins the pivots in the ill-conditioned test (and in the predicted-convergence bound).
-    // With damping each half's share is at least lambda (s <= 1 / lambda), so what the damping did not put there is
-    // kc - 2 lambda; `pcoup` carries it to the conditioning test, kc itself bounds the predicted convergence with the pivots.
-    g.f("    const double kc = (1.0 - sm_g) * fast_rcp(sm_g) + (1.0 - sm_gp) * fast_rcp(sm_gp);");
-    g.f("    const double pcoup = fmax(kc - 2.0 * lambda, 0.0);");
-    g.f("    pmin = fmin(pmin, fmax(kc, 0.0));");
-    }
-  }
+  emit_solve_step();
   g.f("    double sl = 0.0, pr = 0.0, dd = 0.0;");
   for (int F = 0; F < nf; ++F) g.f("    sl = fmax(sl, fabs(nx%d));", F);
   g.f("    sl = PMAX(sl);");
@@ -2419,19 +2442,24 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       // cold body: the wavefront's free coordinates form one contiguous block (16 consecutive problems): through LDS and out in
       // 16-byte-per-lane rows like the records - whole cache lines for HBM, whole packets for a caller's pinned host buffer
       // (lane-by-lane 8-byte stores leave 24-byte fragments whose merging on the way out depends on timing)
-      g.f("    __shared__ __attribute__((aligned(16))) double fstage[16 * %d];", 3 * program.n_free);
+      g.f("    __shared__ __attribute__((aligned(16))) double fstage[%d * %d];", PPW, 3 * program.n_free);
       g.f("    if (a.out_mode == 1) {");
       g.f("      if (c < 3) {");
+      if (pv) g.f("        int q1f = q1; asm volatile(\"\" : \"+v\"(q1f));");
       g.f("        double* st = fstage + quad * %d + c;", 3 * program.n_free);
-      for (int F = 0; F < nf; ++F) g.f("        st[%d] = x%d;", 3 * ordinal[ev.fp(F)], F);
+      for (int F = 0; F < nf; ++F) {
+        const int pt = ev.fp(F);
+        if (pv) g.f("        st[q1f ? %d : %d] = x%d;", 3 * ordinal[pv->pt[1][pt]], 3 * ordinal[pv->pt[0][pt]], F);
+        else g.f("        st[%d] = x%d;", 3 * ordinal[pt], F);
+      }
       g.f("      }");
       g.f("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
-      g.f("      const long long rem = a.n_problems - wu * 16;");
-      g.f("      const int n_doubles = (int)(rem < 16 ? rem : 16) * %d;", 3 * program.n_free);
-      g.f("      double2* dst = reinterpret_cast<double2*>(a.out_pos + wu * 16 * %d);", 3 * program.n_free);
+      g.f("      const long long rem = a.n_problems - wu * %d;", PPW);
+      g.f("      const int n_doubles = (int)(rem < %d ? rem : %d) * %d;", PPW, PPW, 3 * program.n_free);
+      g.f("      double2* dst = reinterpret_cast<double2*>(a.out_pos + wu * %d * %d);", PPW, 3 * program.n_free);
       g.f("      const double2* src = reinterpret_cast<const double2*>(fstage);");
       g.f("      for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
-      g.f("      if ((n_doubles & 1) && lane == 0) a.out_pos[wu * 16 * %d + n_doubles - 1] = fstage[n_doubles - 1];", 3 * program.n_free);
+      g.f("      if ((n_doubles & 1) && lane == 0) a.out_pos[wu * %d * %d + n_doubles - 1] = fstage[n_doubles - 1];", PPW, 3 * program.n_free);
       g.f("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();");
       g.f("    }");
       g.f("    if (false) { long long bf = 0;");
@@ -2447,7 +2475,33 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     }
     g.f("    }");
   }
-  if (pv) {
+  if (pv && CD) {
+    // cold pair body: the wavefront's eight records are one contiguous block as well - staged and written in whole rows
+    // (the general body's lane-by-lane 8-byte stores leave 24-byte fragments: 1.3x the bytes on the way to HBM)
+    g.f("    if (a.out_mode == 0) {");
+    g.f("      __shared__ __attribute__((aligned(16))) double stage[%d * %d];", PPW, 3 * prog_out);
+    g.f("      if (c < 3) {");
+    g.f("        int q1s = q1; asm volatile(\"\" : \"+v\"(q1s));");
+    g.f("        double* st = stage + quad * %d + c;", 3 * prog_out);
+    for (int k = 0; k < P.n_out; ++k) {
+      const int k0 = pv->out[0][k], k1 = pv->out[1][k];
+      if (k1 >= 0) g.f("        st[q1s ? %d : %d] = p%d;", 3 * k1, 3 * k0, P.out_point[k]);
+      else g.f("        if (!q1s) st[%d] = p%d;", 3 * k0, P.out_point[k]);
+    }
+    for (size_t k = 0; k < pv->shared_out.size(); ++k)
+      g.f("        if (!q1s) st[%d] = gp[%d + c];", 3 * pv->shared_out[k], 3 * pv->shared_pt[k]);
+    g.f("      }");
+    g.f("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
+    g.f("      const long long rem = a.n_problems - wu * %d;", PPW);
+    g.f("      const int n_doubles = (int)(rem < %d ? rem : %d) * %d;", PPW, PPW, 3 * prog_out);
+    g.f("      double2* dst = reinterpret_cast<double2*>(a.out_pos + wu * %d * %d);", PPW, 3 * prog_out);
+    g.f("      const double2* src = reinterpret_cast<const double2*>(stage);");
+    g.f("      for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
+    g.f("      if ((n_doubles & 1) && lane == 0) a.out_pos[wu * %d * %d + n_doubles - 1] = stage[n_doubles - 1];", PPW, 3 * prog_out);
+    g.f("      __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();");
+    g.f("    }");
+    g.f("    if (false) {");
+  } else if (pv) {
     g.f("    if (a.out_mode == 0 && valid && c < 3) {");
     // (the record's address is rebuilt from an opaque copy of the problem index: as an induction variable the compiler
     //  keeps one strength-reduced 64-bit address per output point alive across the chain loop and spills all of them)
@@ -2511,17 +2565,17 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   stamp("14");
   if (CD) {
     // the sixteen 40-byte records of the wavefront are contiguous too: one staged block, 8 bytes per lane
-    g.f("    __shared__ __attribute__((aligned(16))) okx_info istage[16];");
-    g.f("    if (c == 0) {");
+    g.f("    __shared__ __attribute__((aligned(16))) okx_info istage[%d];", PPW);
+    g.f("    if (c == 0%s) {", pv ? " && !q1" : "");
     g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
     g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
     g.f("      istage[quad] = inf;");
     g.f("    }");
     g.f("    __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
     g.f("    {");
-    g.f("      const long long rem = a.n_problems - wu * 16;");
-    g.f("      const int n_words = (int)(rem < 16 ? rem : 16) * 5;  // doubles of info records");
-    g.f("      double* dst = reinterpret_cast<double*>(a.info + wu * 16);");
+    g.f("      const long long rem = a.n_problems - wu * %d;", PPW);
+    g.f("      const int n_words = (int)(rem < %d ? rem : %d) * 5;  // doubles of info records", PPW, PPW);
+    g.f("      double* dst = reinterpret_cast<double*>(a.info + wu * %d);", PPW);
     g.f("      const double* src = reinterpret_cast<const double*>(istage);");
     g.f("      if (lane < n_words) dst[lane] = src[lane];");
     g.f("      if (lane + 64 < n_words) dst[lane + 64] = src[lane + 64];");
@@ -2565,7 +2619,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   };  // emit_body
   emit_body(false);
   if (body_failed) return false;
-  const bool cold_body = !pv && head_ok;
+  const bool cold_body = head_ok;
   if (cold_body) emit_body(true);
   if (body_failed) return false;
   if (!pv) {

@@ -79,6 +79,16 @@ which_rack = 1 - which_bump
 t2[:, :, which_bump] += bump[:, None]
 t2[:, :, which_rack] += rack[None, :]
 r = case("MacPherson grid beyond the reach (redo path)", p, t2.reshape(-1, t.shape[1])); worst = max(worst, r[0]); same &= r[1]
+p, t = W.axle_grid_problem(128, 128)
+r = case("C3 rocker + U-bar axle 128 x 128 grid (pair mode)", p, t); worst = max(worst, r[0]); same &= r[1]
+for n in (1, 7, 9):
+    r = case(f"  the same, {n} problems", p, t[:n], timed=False); worst = max(worst, r[0]); same &= r[1]
+p, t = W.axle_grid_problem(256, 256)
+r = case("C3 at full size, 256 x 256", p, t); worst = max(worst, r[0]); same &= r[1]
+hr, rr = np.meshgrid(np.linspace(-75.0, 75.0, 64), np.linspace(-45.0, 45.0, 64), indexing="ij")  # heave x roll beyond the reach
+base3 = 0.5 * (t[0] + t[-1])
+t3 = np.stack([base3[0] + (hr + rr).ravel(), base3[1] + (hr - rr).ravel(), np.full(hr.size, base3[2])], axis=1)
+r = case("axle grid beyond the reach (redo path, pair mode)", p, t3); worst = max(worst, r[0]); same &= r[1]
 program, table, rel = W.ensemble_problem(256, 64)
 dpe = DeviceProgram(program, dev)
 gpos, gparam = dpe.rebind(torch.as_tensor(table, device=dev))

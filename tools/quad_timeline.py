@@ -2,7 +2,7 @@
 """C2 cold sweep: the cold body against the general body (same answers? time per launch), and - from a build generated with
 OKX_DEV=quad_timeline - where a wavefront's cycles go (shader-clock stamps of every wavefront: entry, first step in hand, top of
 each LM pass, passes done, records stored, end).
-   OKX_DEV=quad_timeline OKX_KERNEL_CACHE=build/kc_tl python3 tools/quad_timeline.py [n_problems]"""
+   OKX_DEV=quad_timeline OKX_KERNEL_CACHE=build/kc_tl python3 tools/quad_timeline.py [n_problems | c3]"""
 import ctypes as C
 import os
 import sys
@@ -15,9 +15,15 @@ import bench
 from open_kinematics_amd.batch import DeviceProgram
 from open_kinematics_amd.workloads import bump_sweep_problem
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+what = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].isdigit() else "c2"
 dev = torch.device("cuda:0")
-program, targets = bump_sweep_problem(n)
+if what == "c3":   # one round of the pair-mode kernel: 8 problems per wavefront, 1024 wavefronts
+    from open_kinematics_amd.workloads import axle_grid_problem
+    program, targets = axle_grid_problem(128, 64)
+    n, per_wave = targets.shape[0], 8
+else:
+    n, per_wave = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, 16
+    program, targets = bump_sweep_problem(n)
 dp = DeviceProgram(program, dev)
 t = torch.as_tensor(targets, device=dev)
 out = torch.empty((n, program.n_out, 3), dtype=torch.float64, device=dev)
@@ -38,7 +44,7 @@ def run(label):
 
 
 if "quad_timeline" in os.environ.get("OKX_DEV", ""):
-    waves = (n + 15) // 16
+    waves = (n + per_wave - 1) // per_wave
     tr = torch.zeros((2 * waves, 16), dtype=torch.float64, device=dev)
     dp.lib.okx_debug_quad_trace(dp._handle, C.c_void_p(tr.data_ptr()), -1)
     launch = dp.plan(t, out=out, info_out=info, chain_len=1, predictor=False)
@@ -52,19 +58,18 @@ if "quad_timeline" in os.environ.get("OKX_DEV", ""):
     a, sec = both[:waves], both[waves:]
     dp.lib.okx_debug_quad_trace(dp._handle, None, -1)
     t0 = a[:, 0].min()
-    rel = a - t0
     names = ["entry", "first step in hand"] + [f"pass {k} top" for k in range(1, 11)] + ["(pass overflow)", "passes done", "records stored", "end"]
-    print("stamp (shader clock ticks since the first wavefront's entry): median / min / max over wavefronts; delta to previous stamp (median)")
-    prev = None
-    for k in range(16):
-        col = rel[:, k]
-        ok = a[:, k] > 0
-        if not ok.any():
-            continue
-        med = np.median(col[ok])
-        d = "" if prev is None else f"  +{med - prev:9.0f}"
-        print(f"  {k:2d} {names[k]:22s} n={ok.sum():5d}  {med:10.0f} {col[ok].min():10.0f} {col[ok].max():10.0f}{d}")
-        prev = med
+    # (the shader clocks of the eight XCDs have different bases: only differences inside one wavefront mean anything)
+    print("per wavefront: ticks from the previous stamp it has to this one - median / min / max over the wavefronts that have it")
+    order = [k for k in range(16) if (a[:, k] > 0).any()]
+    for k in order[1:]:
+        have = a[:, k] > 0
+        prev = np.zeros(have.sum())
+        for j in order[:order.index(k)]:
+            col = a[have, j]
+            prev = np.where(col > 0, col, prev)
+        d = a[have, k] - prev
+        print(f"  {k:2d} {names[k]:22s} n={have.sum():5d}  {np.median(d):9.0f} {d.min():9.0f} {d.max():9.0f}")
     per_wave = a[:, 15] - a[:, 0]
     print(f"wavefront lifetime entry -> end: median {np.median(per_wave):.0f}, min {per_wave.min():.0f}, max {per_wave.max():.0f} ticks;"
           f" whole launch (first entry -> last end) {(a[:, 15].max() - t0):.0f} ticks")
