@@ -204,14 +204,34 @@ int quad_waves_per_simd() {
 // The first-step table of the program's own geometry for `lambda0`: found, or filled by one wavefront of okx_quad_head_u
 // on `stream` (a new buffer per lambda0: an older table may still be read by launches in flight).  A launch on another
 // stream than the one that filled the table waits for the fill's event.
+constexpr size_t kMaxHeadTables = 16;  // distinct lambda0 values with a table of their own per program
+
+// true while `stream` records into a HIP graph: nothing may be allocated, filled or waited for on its behalf then
+bool stream_is_capturing(hipStream_t stream) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &status) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return status != hipStreamCaptureStatusNone;
+}
+
+// *table = nullptr with OKX_OK: no table for this launch (the chain heads take their own first pass): a launch that is
+// being captured into a graph and finds no table of its lambda0 yet, or a program whose table list is full.
 int own_head_table(okx_program* p, double lambda0, hipStream_t stream, double** table) {
+  *table = nullptr;
   std::lock_guard<std::mutex> lock(*p->head_mutex);
+  const bool capturing = stream_is_capturing(stream);
   for (okx_program::HeadTable& t : *p->head_tables)
     if (t.lambda0 == lambda0) {
-      if (t.filled_on != stream) HIP_TRY(hipStreamWaitEvent(stream, t.ready, 0));
+      // (always ordered behind the fill: an event that has completed costs nothing, and a stream handle can be reused.
+      //  Under capture the wait would become a graph dependency on an event outside the graph: the table of a captured
+      //  launch must have been filled before the capture began - okx_program_create fills the default's synchronously.)
+      if (!capturing) HIP_TRY(hipStreamWaitEvent(stream, t.ready, 0));
       *table = t.dev;
       return OKX_OK;
     }
+  if (capturing || p->head_tables->size() >= kMaxHeadTables) return OKX_OK;
   okx_program::HeadTable t;
   t.lambda0 = lambda0;
   t.filled_on = stream;
@@ -751,6 +771,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   if (d_geom_pos && spg == 0 )
     return fail(OKX_ERR_INVALID, "a geometry table needs steps_per_geometry > 0");
   if (opts->max_iter < 1) return fail(OKX_ERR_INVALID, "max_iter must be >= 1");
+  if (!(opts->lambda0 >= 0.0) || !(opts->lambda0 < 1e300)) return fail(OKX_ERR_INVALID, "lambda0 must be finite and >= 0");
   okx::SolveArgs a;
   a.targets = d_targets;
   a.geom_pos = d_geom_pos;
@@ -781,12 +802,20 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   //  back to the quad kernel below)
   // Rounds of each kernel for this launch (one wavefront per SIMD either way): lane wave units hold 64 problems of ONE
   // geometry, so an ensemble with few steps per geometry leaves lanes idle and may be the quad kernel's after all.
+  // The parallel unit is a CHAIN (a problem when chains have length 1): an explicit chain length - or chain = 1, the whole
+  // span - is counted as such; chain_len = -1 (auto) sizes its chains to the kernel chosen here, from the problem count.
   const auto lane_pays = [&]() {
     const long long simds = (long long)p->n_cu * 4;
-    const long long lane_waves = spg > 0 ? (n_problems / spg) * ((spg + 63) / 64) : (n_problems + 63) / 64;
-    const long long quad_waves = (n_problems + 15) / 16;
+    const long long span0 = spg > 0 ? spg : n_problems, n_spans = n_problems / span0;
+    long long len0 = opts->chain_len;
+    if (len0 == 0) len0 = opts->chain ? span0 : 1;
+    if (len0 < 1) len0 = 1;  // (auto)
+    if (len0 > span0) len0 = span0;
+    const long long chains_per_span = (span0 + len0 - 1) / len0;
+    const long long lane_waves = n_spans * ((chains_per_span + 63) / 64);
+    const long long quad_waves = (n_spans * chains_per_span + 15) / 16;
     const long long lane_rounds = (lane_waves + simds - 1) / simds, quad_rounds = (quad_waves + simds - 1) / simds;
-    return 26 * lane_rounds < 19 * quad_rounds + 3;  // us per round of either kernel, measured on C2 / C4 shapes
+    return 26 * lane_rounds < 19 * quad_rounds + 3;  // us per round (and chain step) of either kernel, measured on C2 / C4 shapes
   };
   bool use_lane = p->lane_fn_u != nullptr && use_quad && opts->predictor == 0 && p->quad_trace == nullptr &&
                   (opts->kernel == 4 || (opts->kernel == 0 && n_problems >= p->lane_min_problems && lane_pays()));
@@ -887,23 +916,32 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
         double* table = nullptr;  // own geometry: once per lambda0 (the default's at program creation), then cached
         const int rc = own_head_table(p, opts->lambda0, (hipStream_t)stream, &table);
         if (rc != OKX_OK) return rc;
-        q.head = table;
+        q.head = table;  // (null: no table for this launch - see own_head_table)
       } else if (spg >= 4 && (n_problems / spg) * (long long)p->head_stride * 8 <= (256LL << 20)) {
         // (one table row costs about 1.3 passes of one quad: with fewer than four steps per geometry, or a table beyond
         //  256 MiB, the heads run their own first pass)
         const long long n_geom = n_problems / spg;
-        if (n_geom > p->head_geom_cap) {
+        bool have_scratch = n_geom <= p->head_geom_cap;
+        if (!have_scratch && !stream_is_capturing((hipStream_t)stream)) {
           // grow-only scratch, replaced in stream order: launches of this program with geometry tables are stream-ordered
-          // (okx.h), so the old table's readers are ahead of the free on this stream - no device-wide synchronisation
+          // (okx.h), so the old table's readers are ahead of the free on this stream - no device-wide synchronisation.
+          // Never inside a stream capture (the allocation would become a node of the graph while the pointer is cached
+          // here): a captured launch that finds the scratch too small runs without the shared first step - warm the launch
+          // up once outside the capture.
           if (p->head_geom_dev) {
-            HIP_TRY(hipFreeAsync(p->head_geom_dev, (hipStream_t)stream));
+            double* old = p->head_geom_dev;
             p->head_geom_dev = nullptr;
             p->head_geom_cap = 0;
+            HIP_TRY(hipFreeAsync(old, (hipStream_t)stream));
           }
           const size_t bytes = sizeof(double) * (size_t)n_geom * (size_t)p->head_stride;
-          HIP_TRY(hipMallocAsync((void**)&p->head_geom_dev, bytes, (hipStream_t)stream));
+          double* fresh = nullptr;
+          HIP_TRY(hipMallocAsync((void**)&fresh, bytes, (hipStream_t)stream));
+          p->head_geom_dev = fresh;
           p->head_geom_cap = n_geom;
+          have_scratch = true;
         }
+        if (have_scratch) {
         h.head = p->head_geom_dev;
         h.n_geometries = n_geom;
         const long long head_waves = (n_geom + p->quad_ppw - 1) / p->quad_ppw;
@@ -911,6 +949,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
         HIP_TRY(hipModuleLaunchKernel(p->quad_fn_head_g, (int)(head_waves < head_cap ? head_waves : head_cap), 1, 1, okx::kWave, 1, 1,
                                       0, (hipStream_t)stream, hargs, nullptr));
         q.head = p->head_geom_dev;
+        }
       }
     }
     void* kargs[] = {(void*)&q};

@@ -156,3 +156,22 @@ def test_pinned_inputs_are_snapshotted_unless_zero_copy_is_asked_for(golden):
     with pytest.raises(ValueError, match="pinned host tensor"):
         dp.solve(t_dev, out=torch.empty((n, program.n_out, 3), dtype=torch.float64), info_out=h_info, zero_copy=True)
     dp.close()
+
+
+def test_a_non_finite_lambda0_is_refused(golden):
+    """every distinct lambda0 owns a first-step table; NaN never matches a cached one and used to allocate a table
+    per launch.  The launch is refused instead, and the table list of a program is capped."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden("c2_dw_subset")
+    dp = DeviceProgram(program.with_line_mode("pinned"), "cuda:0")
+    t = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
+    for bad in (float("nan"), float("inf"), -1.0):
+        with pytest.raises(ValueError, match="lambda0"):
+            dp.solve(t, lambda0=bad)
+    ref = dp.solve(t, chain_len=1).positions
+    for k in range(24):  # more distinct values than a program keeps tables for: the later ones solve without a table
+        res = dp.solve(t, chain_len=1, lambda0=1e-6 * (1.0 + 0.01 * k))
+        assert res.accepted(res.info()).all()
+        assert float((res.positions - ref).abs().max()) <= 1e-9
+    dp.close()
