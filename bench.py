@@ -777,11 +777,17 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
     preheat_steps = 0
     if preheat_ms > 0.0:
         torch.cuda.synchronize(device)
-        t_end = time.perf_counter() + preheat_ms * 1e-3
-        while time.perf_counter() < t_end:
-            for _ in range(32):
+        if world > 1:
+            # several ranks: a FIXED count (every step is a collective call - the ranks must make the same number of them)
+            for _ in range(int(preheat_ms * 50)):  # ~20 us per step
                 step(preheat_steps, None, None)
                 preheat_steps += 1
+        else:
+            t_end = time.perf_counter() + preheat_ms * 1e-3
+            while time.perf_counter() < t_end:
+                for _ in range(32):
+                    step(preheat_steps, None, None)
+                    preheat_steps += 1
         drain()
     timed_region.preheat_steps = preheat_steps
     for k in range(warmup):

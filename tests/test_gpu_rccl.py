@@ -32,3 +32,25 @@ def test_bench_step_with_an_rccl_all_gather_on_one_rank():
     assert line["exchange"]["collective"] == "all_gather_into_tensor (RCCL)"
     assert line["solve_only"]["value"] >= line["value"] > 0.0   # the exchange-inclusive rate cannot beat the solve alone
     assert line["roofline"]["kernel_ms"] > 0.0
+
+
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """The N = 2 bench step end to end on a one-GPU box: two ranks (both on cuda:0), index shards, the solve writing its
+    free coordinates into the send buffer, the pipelined all-gather (over gloo here), one expand per step of the gathered
+    block, a fixed-count preheat (every step is a collective call), MAX over ranks.  The numbers mean nothing; the line's
+    structure and the agreement of every rank on the step count do."""
+    if not gpu_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "10",
+                           "--warmup", "3", "--preheat-ms", "2", "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True,
+                          text=True, timeout=600)
+    assert proc.returncode == 0, (proc.stdout + proc.stderr)[-3000:]
+    line = [json.loads(l) for l in proc.stdout.splitlines() if l.startswith("{")][-1]
+    assert line["n_gpus"] == 2 and line["config"]["all_converged"] and line["scaling"] == "weak"
+    assert line["config"]["problems_per_gpu"] == 16384 and line["preheat"]["steps"] == 100
+    assert line["exchange"]["bytes_sent_per_rank_per_step"] == 16384 * 6 * 24      # the free coordinates, not the records
+    assert line["exchange"]["bytes_received_per_rank_per_step"] == 16384 * 6 * 24
+    assert line["solve_only"]["value"] >= line["value"] > 0.0
