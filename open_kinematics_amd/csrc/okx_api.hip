@@ -817,7 +817,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     const long long lane_rounds = (lane_waves + simds - 1) / simds, quad_rounds = (quad_waves + simds - 1) / simds;
     return 26 * lane_rounds < 19 * quad_rounds + 3;  // us per round (and chain step) of either kernel, measured on C2 / C4 shapes
   };
-  bool use_lane = p->lane_fn_u != nullptr && use_quad && opts->predictor == 0 && p->quad_trace == nullptr &&
+  bool use_lane = p->lane_fn_u != nullptr && use_quad && opts->predictor == 0 && (p->quad_trace == nullptr || okx::dev_switch("lane_timeline")) &&
                   (opts->kernel == 4 || (opts->kernel == 0 && n_problems >= p->lane_min_problems && lane_pays()));
   bool lane_auto_cold = false;  // chain_len = -1 resolved to independent solves on the lane kernel
   if (use_lane && opts->kernel == 0) {

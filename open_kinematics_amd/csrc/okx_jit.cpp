@@ -228,6 +228,7 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
     }
   }
   int best = -1, best_scratch = 1 << 30;
+  bool searched_all = true;  // every variant compiled and looked at (not cut short by `good_enough_scratch` or a failure)
   std::string best_src, best_code;
   for (int v = first; v <= last; ++v) {
     std::string s1, c1, w1;
@@ -235,6 +236,7 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
     else if (!lane_generate(P, &s1, &w1, v)) continue;
     if (!quad_compile(s1, &c1, &err, ignore_cached, cache_only)) {
       if (best < 0) *why = err == kNotCached ? err : "compile failed: " + err;
+      searched_all = false;
       if (cache_only) break;  // (a variant search is a compile job)
       continue;
     }
@@ -245,10 +247,15 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
       best_src.swap(s1);
       best_code.swap(c1);
     }
-    if (best_scratch <= good_enough_scratch) break;
+    if (best_scratch <= good_enough_scratch) {
+      searched_all = searched_all && (v == last || best_scratch == 0);
+      break;
+    }
   }
   if (best < 0) return false;
-  if (first != last && best_scratch == 0) {  // (only a search that ran to its goal is remembered)
+  // (only a search that ran to its goal - no scratch, or the least of all variants - is remembered: a program whose every
+  //  variant spills a little would otherwise be given the FIRST variant under the create-time bound at every start)
+  if (first != last && (best_scratch == 0 || searched_all)) {
     (void)mkdir(cache_dir().c_str(), 0777);
     write_file_atomic(memo, std::to_string(best) + "\n");
   }

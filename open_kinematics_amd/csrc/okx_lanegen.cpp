@@ -217,7 +217,7 @@ class LGen {
   std::map<std::pair<int, int>, std::string> hoisted_names;
   void add_const(const char* name, int offset) {
     char line[256];
-    std::snprintf(line, sizeof(line), "#define %s gl[%d + kz]\n", name, offset);
+    std::snprintf(line, sizeof(line), "#define %s GL(%d)\n", name, offset);
     defines.insert(line);
     std::snprintf(line, sizeof(line), "#undef %s\n", name);
     undefs.insert(line);
@@ -1000,6 +1000,7 @@ typedef struct { double max_residual, cost, last_step; int iterations, nfev, fla
 // another lane's reads is an ordering for the COMPILER.  __syncthreads() is more than that: a workgroup-scope release
 // fence, i.e. a wait for every global store the wavefront has in flight - the record stores of a wave unit (4 us of HBM
 // time for 64 records) would be waited for before the next unit may start instead of draining behind it.
+typedef const __attribute__((address_space(4))) double* okx_cptr;  // loads through it are scalar-cache loads (s_load)
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 struct QArgs {
   const double* targets; const double* geom_pos; const double* geom_row_param;
@@ -1123,8 +1124,16 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // LDS slots to spare for the rows' gradients, the chain body has not.  `ev` is the chain body's generator (no LDS
   // homes) and the owner of the chain constants; `evc` the independent-solve body's.
   const int kColdStateSlots = 2 * n;                               // x, dx
-  // what is left of 40 KiB per wavefront once the geometry tables (gl) have their share
-  int cold_j_slots = (40 * 1024 - 8 * (3 * P.n_points + 8 * (P.n_crows + P.n_targets) + (P.n_derived > 0 ? P.n_derived : 1)) - 256) / 512 - kColdStateSlots;
+  // first-step table layout (shared with okx_quadgen.cpp: quad_head_stride)
+  const int HK = T + 1;
+  const int head_off = 4 * nf * HK + 2 * HK * HK;
+  const int head_s_off = head_off + 8;                                   // second-order vectors S_st, [pair][F][4]
+  const int head_stride = head_s_off + 4 * nf * (HK - 1) * HK / 2;
+  // The geometry's tables are read through the scalar cache where they are used (see the chain constants above); the
+  // developer switch lane_lds_tables brings back round 3's staging into LDS (and takes its share of the 40 KiB).
+  const bool scalar_tables = !dev_switch("lane_lds_tables");
+  const int table_doubles = scalar_tables ? 0 : 3 * P.n_points + 8 * (P.n_crows + P.n_targets) + (P.n_derived > 0 ? P.n_derived : 1);
+  int cold_j_slots = (40 * 1024 - 8 * table_doubles - 256) / 512 - kColdStateSlots;
   if (cold_j_slots < 0) cold_j_slots = 0;
   struct PassSrc { std::string eval, factor, subst; };
   auto make_pass = [&](LGen& gen, PassSrc* out) -> bool {
@@ -1210,12 +1219,6 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   for (int k = 0; k < nf; ++k) used[P.free_point[k]] = true;
   auto is_fixed = [&](int p) { return ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0; };
 
-  // first-step table layout (shared with okx_quadgen.cpp: quad_head_stride)
-  const int HK = T + 1;
-  const int head_off = 4 * nf * HK + 2 * HK * HK;
-  const int head_s_off = head_off + 8;                                   // second-order vectors S_st, [pair][F][4]
-  const int head_stride = head_s_off + 4 * nf * (HK - 1) * HK / 2;
-
   // the fixed points are chain constants too (macros p{k}_{c} -> cl[...])
   for (int p = 0; p < NP; ++p)
     if (used[p] && is_fixed(p))
@@ -1233,6 +1236,11 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     gg.f("%sif (lane < %d) gl[%d + lane] = a.dop_param[lane];", indent, P.n_derived, ev.gl_dp0);
   };
   const bool marks = dev_switch("lane_mark");  // `s_nop 11..16` between the sections of a pass (tools/lane_isa.sh)
+  // developer build: every wave unit of the independent-solve body stamps the shader clock into a.trace[16 wu + k] - 0 unit
+  // start, 1 tables staged, 16 state set up, 2 first step in hand, 3 passes done (4 / 5: full / confirming passes it ran,
+  // 6 ... 11: cycles of its last full pass by section), 13 final state, 14 info stored, 17 records in LDS, 15 records
+  // stored; 32 slots per wave unit (tools/lane_timeline.py)
+  const bool timeline = dev_switch("lane_timeline");
 
   LGen g(P);
   g.out += kLanePreamble;
@@ -1244,12 +1252,12 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     char line[96];
     for (int i = 0; i < P.m; ++i)
       for (int k = 0; k < 8; ++k) {
-        std::snprintf(line, sizeof(line), "#define hs%d_%d gl[%d + kz]\n", i, k,
+        std::snprintf(line, sizeof(line), "#define hs%d_%d GL(%d)\n", i, k,
                       i < P.n_crows ? ev.gl_gq0 + 8 * i + k : ev.gl_tq0 + 8 * (i - P.n_crows) + k);
         defs.insert(line);
       }
     for (int e = 0; e < P.n_derived; ++e) {
-      std::snprintf(line, sizeof(line), "#define hd%d gl[%d + kz]\n", e, ev.gl_dp0 + e);
+      std::snprintf(line, sizeof(line), "#define hd%d GL(%d)\n", e, ev.gl_dp0 + e);
       defs.insert(line);
     }
     for (const std::string& d : defs) g.out += d;
@@ -1281,21 +1289,41 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     // the first-step table of the wave unit's geometry is staged behind the state (the area the factor's rows are parked
     // in later): the prologue's 100-odd table reads are LDS broadcasts instead of same-address global loads
     const int head_l0 = state_doubles_before_l;
-    if (lds_doubles < head_l0 + head_stride) lds_doubles = head_l0 + head_stride;
-    if ((lds_doubles + gl_size) * 8 > 40 * 1024) {
+    const bool cold = !ch && !fl;
+    const bool sc = scalar_tables;      // no tables in LDS at all: read where they are used through the scalar cache
+    if (!sc && lds_doubles < head_l0 + head_stride) lds_doubles = head_l0 + head_stride;
+    const int gl_doubles = sc ? 0 : gl_size;
+    const std::string refresh_s = sc ? std::string(refresh_kz) + " asm volatile(\"\" : \"+s\"(kzs));" : std::string(refresh_kz);
+    const char* const refresh_kz = refresh_s.c_str();  // (shadows the LDS-only form: this body's passes refresh both opaque zeros)
+    if ((lds_doubles + gl_doubles) * 8 > 40 * 1024) {
       lds_why = "per-wavefront LDS state exceeds 40 KiB";
       return false;
     }
+    const bool tl = timeline && !ch && !fl;
+    auto stamp = [&](int slot) {
+      if (tl) g.f("    if (a.trace && lane == 0) a.trace[wu * 32 + %d] = (double)__builtin_readcyclecounter();", slot);
+    };
     auto mark = [&](int k) {
       if (marks && !ch && !fl) g.f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + k);
+      if (tl) g.f("    { const long long tl_now = __builtin_readcyclecounter(); tl_sec%d = (double)(tl_now - tl_at); tl_at = tl_now; }", k);
     };
     // FULL: the kernel that writes full records (okx_solve_opts.output = 0) is compiled on its own, exactly as it was
     // before the compact outputs existed: the register allocator's result for the double wishbone is that fragile
     // (the same body with the output mode as a run-time switch: 0 -> 248 B of scratch).
+    g.f("#undef GL");
+    if (sc) {
+      // a table entry by its place in the (former) LDS image: positions, constraint-row parameters, target-row parameters,
+      // derived-op parameters - the offset is a literal, the chain of conditions folds to one array
+      g.f("#define GL(o) ((o) < %d ? gpc[(o) + kzs] : (o) < %d ? gqc[(o) - %d + kzs] : (o) < %d ? rpc[(o) - %d + kzs] : dpc[(o) - %d + kzs])",
+          ev.gl_gq0, ev.gl_tq0, ev.gl_gq0, ev.gl_dp0, ev.gl_tq0 - 8 * P.n_crows, ev.gl_dp0);
+    } else
+      g.f("#define GL(o) gl[(o) + kz]");
     g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a) {", ch || fl ? "chain" : "cold");
     g.f("  const int lane = threadIdx.x;");
     g.f("  __shared__ double lds[%d];", lds_doubles);
-    g.f("  __shared__ double gl[%d];  // the wave unit's geometry tables: positions, row parameters, derived-op parameters", gl_size);
+    if (sc) g.f("  int kzs = 0;  // an opaque zero in a scalar register: a table read inside a pass is a load of that pass, not a loop invariant");
+    else
+    g.f("  __shared__ double gl[%d];  // the wave unit's geometry tables: positions, row parameters, derived-op parameters", gl_doubles);
     g.f("  int kz = 0;");
     g.f("  const long long spg = a.steps_per_geometry;");
     g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
@@ -1319,8 +1347,18 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("  for (long long it = wu_lo * unit_len; it < wu_hi * unit_len; ++it) {");
       g.f("    const long long wu = uni64(it / unit_len);");
       g.f("    const int step = (int)uni64(it - wu * unit_len);  // wave-uniform: every lane of the wave unit is at this step of its chain");
+    } else if (cold) {
+      // Own geometry: the tables are staged once per wavefront, the wave units dealt out round-robin (a unit's cost goes with
+      // its place in the sweep: neighbours to different wavefronts).  Per-geometry tables: every wavefront takes a contiguous
+      // block of wave units, so that the units of one geometry follow each other and its tables are staged once.
+      g.f("  const long long wu_per_wave = (n_wave_units + gridDim.x - 1) / gridDim.x;");
+      g.f("  const long long wu_lo = PG ? blockIdx.x * wu_per_wave : blockIdx.x, wu_step = PG ? 1 : gridDim.x;");
+      g.f("  const long long wu_hi = PG ? (wu_lo + wu_per_wave < n_wave_units ? wu_lo + wu_per_wave : n_wave_units) : n_wave_units;");
+      g.f("  for (long long wu = wu_lo; wu < wu_hi; wu += wu_step) {");
     } else
     g.f("  for (long long wu = blockIdx.x; wu < n_wave_units; wu += gridDim.x) {");
+    stamp(0);
+    if (tl) g.f("    long long tl_at = 0; double tl_sec1 = 0.0, tl_sec2 = 0.0, tl_sec3 = 0.0, tl_sec4 = 0.0, tl_sec5 = 0.0, tl_sec6 = 0.0, tl_full = 0.0, tl_light = 0.0;");
     // (the 64-bit division runs on the vector ALU; its result goes to scalar registers so that every table address
     //  derived from it is scalar arithmetic, not a pair of vector registers kept alive through the solve)
     g.f("    const long long span_idx = uni64(n_spans > 1 ? wu / waves_per_span : 0);  // wave-uniform: one geometry per wave unit");
@@ -1341,6 +1379,12 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[bb * %d + %d];", t, T, t);
     } else
       for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[first_b * %d + %d];", t, T, t);
+    if (sc) {
+      g.f("    const okx_cptr gpc = (okx_cptr)gp, gqc = (okx_cptr)gq, rpc = (okx_cptr)a.row_param, dpc = (okx_cptr)a.dop_param;");
+      g.f("    (void)gqc; (void)rpc; (void)dpc;");
+      g.f("    const bool with_head = a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
+      g.f("    WAVE_SYNC();  // (the previous wave unit's last LDS reads are done)");
+    } else {
     g.f("    // the geometry's tables (and its first-step table) into LDS, lane k fetching entry k");
     g.f("    WAVE_SYNC();  // (the previous wave unit's last reads of these areas are done)");
     if (fl) {
@@ -1356,16 +1400,21 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("      for (int k = lane; k < %d; k += 64) lds[%d + k] = hp[k];", head_stride, head_l0);
     g.f("    }");
     g.f("    WAVE_SYNC();");
+    }
+    stamp(1);
     g.f("    %s", refresh_kz);
     for (int p = 0; p < NP; ++p) {
       if (!used[p] || is_fixed(p)) continue;
-      for (int c = 0; c < 3; ++c) g.f("    double p%d_%d = gp[%d];", p, c, 3 * p + c);
+      for (int c = 0; c < 3; ++c)
+        if (sc) g.f("    double p%d_%d = GL(%d);", p, c, ev.gl_gp0 + 3 * p + c);
+        else g.f("    double p%d_%d = gp[%d];", p, c, 3 * p + c);
     }
     g.out += state_decl;
     for (int i = 0; i < n; ++i) {
       g.f("    x%d = %s; dx%d = 0.0;", i, PF(i).c_str(), i);
       if (ch) g.f("    xp%d = %s; xq%d = %s;", i, PF(i).c_str(), i, PF(i).c_str());
     }
+    stamp(16);
     // the design state is a solved state of its own design targets: it seeds the chain's history
     for (int i = P.n_crows; i < P.m; ++i) {
       const int t = ev.target_of_row(i);
@@ -1380,7 +1429,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("    bool head_ready = false;");
     g.f("    double hstep = 0.0, hN = 0.0, hM = 0.0, hss = 0.0, hmr = 0.0, hs0 = 0.0, hs1 = 0.0, hs4 = 0.0, hs5 = 0.0;");
     g.f("    if (with_head) {");
-    g.f("      const double* hp = lds + %d + kz;  // the staged table", head_l0);
+    if (sc) g.f("      const okx_cptr hp = (okx_cptr)(a.head + (PG ? span_idx * %d : 0)) + kzs;", head_stride);
+    else g.f("      const double* hp = lds + %d + kz;  // the staged table", head_l0);
     g.f("      const double hr0 = 1.0;");
     for (int k = 1; k < HK; ++k) g.f("      const double hr%d = td%d - tn%d;", k, k - 1, k - 1);
     // first-order step d1 and, when the table carries them (scalar 6), the second-order correction
@@ -1514,10 +1564,12 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     // confirm, the outer loop takes the residual-only pass and comes back (a lane whose step is not confirmed goes on with
     // full passes).  Same order of evaluations as one loop with the confirming pass as a branch at its top.
     const bool nested = light_ok;
+    stamp(2);
     if (nested) {
       g.f("      while (wave_any(!done)) {");
       g.f("    %s", refresh_kz);
       g.f("    if (a.confirm == 0 && !wave_any(!done && !want_light)) {");
+      if (tl) g.f("      tl_light += 1.0;");
       for (int i = 0; i < n; ++i) g.f("      %s = x%d + dx%d;", PF(i).c_str(), i, i);
       g.out += light_src;
       g.f("      const double Fl = 0.5 * ss;");
@@ -1534,6 +1586,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("    while (wave_any(!done) && (a.confirm != 0 || wave_any(!done && !want_light))) {");
       g.f("    %s", refresh_kz);
       g.f("    want_light = false;");
+      if (tl) g.f("    tl_full += 1.0; tl_at = __builtin_readcyclecounter();");
     } else {
     g.f("      while (wave_any(!done)) {");
     g.f("    %s", refresh_kz);
@@ -1650,6 +1703,11 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("    }  // any lane solves");
     if (nested) g.f("    }  // full passes");
     g.f("      }  // LM passes");
+    stamp(3);
+    if (tl) {
+      g.f("    if (a.trace && lane == 0) { double* tr = a.trace + wu * 32; tr[4] = tl_full; tr[5] = tl_light; tr[6] = tl_sec1; tr[7] = tl_sec2;");
+      g.f("      tr[8] = tl_sec3; tr[9] = tl_sec4; tr[10] = tl_sec5; tr[11] = tl_sec6; }");
+    }
     // final state and output
     g.f("      {");
     g.f("    %s", refresh_kz);
@@ -1663,7 +1721,9 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       // chain bookkeeping
       for (int t = 0; t < T; ++t) g.f("    tr%d = tq%d; tq%d = tp%d; tp%d = tv%d;", t, t, t, t, t, t);
       g.f("    if (!(flags & INFO_CONVERGED) || (flags & INFO_FAILED)) {");
-      for (int i = 0; i < n; ++i) g.f("      x%d = gp[%d];", i, 3 * ev.fp(i / 3) + i % 3);
+      for (int i = 0; i < n; ++i)
+        if (sc) g.f("      x%d = GL(%d);", i, ev.gl_gp0 + 3 * ev.fp(i / 3) + i % 3);
+        else g.f("      x%d = gp[%d];", i, 3 * ev.fp(i / 3) + i % 3);
       g.f("      hist = 1; lambda_carry = 0.0;");
       for (int t = 0; t < T; ++t) g.f("      tp%d = td%d;", t, t);
       g.f("    } else {");
@@ -1676,11 +1736,13 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       for (int i = 0; i < n; ++i) g.f("      r0[%d] = x%d;", 64 * i, i);
       g.f("      r0[%d] = ((flags & INFO_CONVERGED) && !(flags & INFO_FAILED)) ? 1.0 : 0.0; r0[%d] = lambda; }", 64 * n, 64 * (n + 1));
     }
+    stamp(13);
     g.f("    if (valid) {");
     g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
     g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
     g.f("      a.info[bb] = inf;");
     g.f("    }");
+    stamp(14);
     if (!ch && !fl) {
       // Records of independent solves: the 64 problems of a wave unit are consecutive, their records one contiguous
       // block: transposed through LDS (which the state no longer needs) and written as full 16-byte-per-lane rows.
@@ -1697,12 +1759,15 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       for (int i = 0; i < n; ++i) g.f("      st[%d] = %s;", 3 * ev.perm[i / 3] + i % 3, PF(i).c_str());
       g.f("      }");
       g.f("      WAVE_SYNC();");
+      stamp(17);
       g.f("      const long long base_b = span_idx * span + wave_in_span * 64;");
       g.f("      const long long rem = (span_idx + 1) * span - base_b;");
       g.f("      const int n_doubles = (int)(rem < 64 ? rem : 64) * rec;");
       g.f("      double* dst = a.out_pos + base_b * rec;");
       g.f("      double2* dst2 = reinterpret_cast<double2*>(dst);");
       g.f("      const double2* src2 = reinterpret_cast<const double2*>(lds);");
+      // (measured: the same copy with a fixed trip count, unrolled - the compiler hoists its 23 store addresses out of the
+      //  wave-unit loop and spills them; no faster where it did not)
       g.f("      if ((reinterpret_cast<unsigned long long>(dst) & 15ull) == 0ull) {");
       g.f("        for (int i = lane; i < n_doubles / 2; i += 64) dst2[i] = src2[i];");
       g.f("        if ((n_doubles & 1) && lane == 0) dst[n_doubles - 1] = lds[n_doubles - 1];");
@@ -1711,6 +1776,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      }");
       g.f("      WAVE_SYNC();");
       g.f("      }");
+      stamp(15);
     } else {
       // chains: a lane's problems are far apart in memory, every lane stores its own record
       g.f("    if (valid && FULL) {");
@@ -1736,6 +1802,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // ---- parity / debug kernel: r, J^T J, J^T r at given x, and the damped step for a given lambda ----
   g.f("struct QEvalArgs { const double* x; const double* targets; double* r; double* ata; double* atr; double* dx;");
   g.f("  double lambda; long long n_problems; const double* design_pos; const double* row_param; const double* dop_param; };");
+  g.f("#undef GL\n#define GL(o) gl[(o) + kz]");
   g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_eval(QEvalArgs a) {");
   g.f("  const double* gp = a.design_pos; const double* gq = a.row_param; (void)gq;");
   g.f("  __shared__ double gl[%d];", gl_size);

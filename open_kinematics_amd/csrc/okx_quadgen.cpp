@@ -1646,6 +1646,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         " \"s\"(a.design_pos), \"s\"(a.row_param), \"s\"(a.dop_param), \"s\"(a.out_mode), \"s\"(a.max_iter), \"s\"(a.confirm));");
   }
   stamp("0");
+  // (the device's 100 MHz real-time counter, the same on every XCD, at entry and at the end: slots 0 / 1 of the second half)
+  if (timeline) g.f("    if (a.trace && (threadIdx.x & 63) == 0) a.trace[(gridDim.x + blockIdx.x) * 16 + 0] = (double)__builtin_amdgcn_s_memrealtime();");
   if (pv)
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1_lane = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
   else
@@ -2589,6 +2591,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("    }");
   }
   stamp("15");
+  if (timeline) g.f("    if (a.trace && (threadIdx.x & 63) == 0) a.trace[(gridDim.x + blockIdx.x) * 16 + 1] = (double)__builtin_amdgcn_s_memrealtime();");
   // chains never continue from a state that failed to converge
   if (!CD) {
   for (int t = 0; t < T; ++t) g.f("    tr%d = tq%d; tq%d = tp%d; tp%d = tv%d;", t, t, t, t, t, t);

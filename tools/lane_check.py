@@ -9,6 +9,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open_kinematics_amd import _lib
+_lib.LIB_PATH = os.environ.get("LANE_TL_LIB", _lib.LIB_PATH)   # (A/B against another build of the library)
 from open_kinematics_amd import workloads as W
 from open_kinematics_amd.batch import DeviceProgram
 

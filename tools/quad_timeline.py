@@ -70,6 +70,13 @@ if "quad_timeline" in os.environ.get("OKX_DEV", ""):
             prev = np.where(col > 0, col, prev)
         d = a[have, k] - prev
         print(f"  {k:2d} {names[k]:22s} n={have.sum():5d}  {np.median(d):9.0f} {d.min():9.0f} {d.max():9.0f}")
+    # the 100 MHz real-time counter (one time base for the whole device): when the wavefronts start and end within the launch
+    rt0, rt1 = sec[:, 0], sec[:, 1]
+    if (rt0 > 0).all():
+        base = rt0.min()
+        print(f"real time (10 ns ticks): wavefront starts spread over {rt0.max() - base:.0f} ticks (median start {np.median(rt0 - base):.0f}), "
+              f"ends {np.median(rt1 - base):.0f} median / {(rt1 - base).max():.0f} last; lifetime median {np.median(rt1 - rt0):.0f} ticks "
+              f"= {np.median(a[:, 15] - a[:, 0]) / np.median(rt1 - rt0) / 10:.3f} shader cycles per ns")
     per_wave = a[:, 15] - a[:, 0]
     print(f"wavefront lifetime entry -> end: median {np.median(per_wave):.0f}, min {per_wave.min():.0f}, max {per_wave.max():.0f} ticks;"
           f" whole launch (first entry -> last end) {(a[:, 15].max() - t0):.0f} ticks")
