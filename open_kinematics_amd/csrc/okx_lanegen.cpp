@@ -1305,7 +1305,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     };
     auto mark = [&](int k) {
       if (marks && !ch && !fl) g.f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + k);
-      if (tl) g.f("    { const long long tl_now = __builtin_readcyclecounter(); tl_sec%d = (double)(tl_now - tl_at); tl_at = tl_now; }", k);
+      // (scheduling barriers on both sides: without them the compiler moves a section's arithmetic across the clock read)
+      if (tl) g.f("    __builtin_amdgcn_sched_barrier(0); { const long long tl_now = __builtin_readcyclecounter(); tl_sec%d = (double)(tl_now - tl_at); tl_at = tl_now; } __builtin_amdgcn_sched_barrier(0);", k);
     };
     // FULL: the kernel that writes full records (okx_solve_opts.output = 0) is compiled on its own, exactly as it was
     // before the compact outputs existed: the register allocator's result for the double wishbone is that fragile
@@ -1586,7 +1587,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("    while (wave_any(!done) && (a.confirm != 0 || wave_any(!done && !want_light))) {");
       g.f("    %s", refresh_kz);
       g.f("    want_light = false;");
-      if (tl) g.f("    tl_full += 1.0; tl_at = __builtin_readcyclecounter();");
+      if (tl) g.f("    __builtin_amdgcn_sched_barrier(0); tl_full += 1.0; tl_at = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);");
     } else {
     g.f("      while (wave_any(!done)) {");
     g.f("    %s", refresh_kz);
