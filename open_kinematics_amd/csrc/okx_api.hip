@@ -76,6 +76,7 @@ struct okx_program {
   // lane kernel (okx_lanegen.cpp): one lane per problem, for batches of at least lane_min_problems; null when the
   // program does not fit one lane's registers (or the quad kernel, whose first-step tables it shares, is absent)
   hipModule_t lane_mod;
+  std::vector<hipModule_t>* lane_extra_mods;  // modules single kernels are taken from (okx::LaneOverride), or null
   hipFunction_t lane_fn_u, lane_fn_g, lane_fn_eval;  // independent solves (chain_len 1), parity kernel
   hipFunction_t lane_chain_u, lane_chain_g;          // chains
   hipFunction_t lane_compact[4];                     // the same four with compact outputs (solve_u, solve_g, chain_u, chain_g)
@@ -354,8 +355,23 @@ void attach_quad_kernel(okx_program* p, bool cache_only = false, bool* pending =
 
 // The lane kernel of a program that has a quad kernel (same policy: failure only means the quad kernel serves every
 // batch size; okx_program_lane_note() says why).
+// Largest scratch among the four kernels `prefix`_u / _u_c / _g / _g_c as they will be launched: a kernel that spills less in
+// another emission variant's module is taken from there (okx::LaneOverride).
+static int lane_worst_scratch(const std::string& code, const std::vector<okx::LaneOverride>& overrides, const char* prefix) {
+  int worst = -1;
+  for (const char* tail : {"_u", "_u_c", "_g", "_g_c"}) {
+    const std::string kernel = std::string(prefix) + tail;
+    int sc = okx::quad_code_kernel_scratch_bytes(code, kernel.c_str());
+    for (const okx::LaneOverride& o : overrides)
+      if (o.kernel == kernel && o.scratch >= 0) sc = o.scratch;
+    if (sc > worst) worst = sc;
+  }
+  return worst;
+}
+
 void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending = nullptr) {
   p->lane_mod = nullptr;
+  p->lane_extra_mods = nullptr;
   p->lane_fn_u = p->lane_fn_g = p->lane_fn_eval = nullptr;
   p->lane_chain_u = p->lane_chain_g = nullptr;
   p->lane_note[0] = 0;
@@ -372,7 +388,8 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
     return;
   }
   std::string src, why, code;
-  if (!okx::lane_build(p->host, &src, &code, &why, false, nullptr, 256, cache_only)) {
+  std::vector<okx::LaneOverride> overrides;
+  if (!okx::lane_build(p->host, &src, &code, &why, false, nullptr, 256, cache_only, &overrides)) {
     if (cache_only && why == okx::kNotCached) {
       if (pending) *pending = true;
       std::snprintf(p->lane_note, sizeof(p->lane_note), "being compiled");
@@ -384,8 +401,8 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
   // A body that spills is only worth having while the spill is small.  Measured on MI355X: the double wishbone's
   // independent-solve body (104 - 192 B of scratch) is still 1.8x the quad kernel on 4096 geometries x 256 steps, its
   // looping chain body (668 B) was 8 % slower than the quad kernel's chains; MacPherson (0 B) wins both ways.
-  p->lane_cold_scratch = okx::quad_code_scratch_bytes(code, "okx_lane_solve");
-  p->lane_chain_scratch = okx::quad_code_scratch_bytes(code, "okx_lane_chain");
+  p->lane_cold_scratch = lane_worst_scratch(code, overrides, "okx_lane_solve");
+  p->lane_chain_scratch = lane_worst_scratch(code, overrides, "okx_lane_chain");
   p->lane_cold_ok = p->lane_cold_scratch >= 0 && p->lane_cold_scratch <= 256;
   // ... and a flat chain body (okx_quad.hpp lane_chain_is_flat: the double wishbone; 0 B of scratch) is correct but does not
   // pay: each chain step repeats the independent solve's prologue and its records leave lane by lane, so 4096 x 256 in
@@ -425,6 +442,26 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
     p->lane_chain_u = p->lane_chain_g = nullptr;
     std::snprintf(p->lane_note, sizeof(p->lane_note), "kernel symbols missing in the code object");
     return;
+  }
+  for (const okx::LaneOverride& o : overrides) {
+    hipFunction_t* slot = o.kernel == "okx_lane_solve_u" ? &lane_u : o.kernel == "okx_lane_solve_g" ? &p->lane_fn_g :
+                          o.kernel == "okx_lane_chain_u" ? &p->lane_chain_u : o.kernel == "okx_lane_chain_g" ? &p->lane_chain_g :
+                          o.kernel == "okx_lane_solve_u_c" ? &p->lane_compact[0] : o.kernel == "okx_lane_solve_g_c" ? &p->lane_compact[1] :
+                          o.kernel == "okx_lane_chain_u_c" ? &p->lane_compact[2] : o.kernel == "okx_lane_chain_g_c" ? &p->lane_compact[3] : nullptr;
+    hipModule_t extra = nullptr;
+    hipFunction_t fn = nullptr;
+    if (!slot || hipModuleLoadData(&extra, o.code.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;  // (the kept module's kernel stays)
+    }
+    if (hipModuleGetFunction(&fn, extra, o.kernel.c_str()) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipModuleUnload(extra);
+      continue;
+    }
+    if (!p->lane_extra_mods) p->lane_extra_mods = new std::vector<hipModule_t>;
+    p->lane_extra_mods->push_back(extra);
+    *slot = fn;
   }
   p->lane_mod = mod;
   std::atomic_thread_fence(std::memory_order_release);
@@ -634,6 +671,10 @@ void okx_program_destroy(okx_program* p) {
   }
   if (p->quad_mod) (void)hipModuleUnload(p->quad_mod);
   if (p->lane_mod) (void)hipModuleUnload(p->lane_mod);
+  if (p->lane_extra_mods) {
+    for (hipModule_t m : *p->lane_extra_mods) (void)hipModuleUnload(m);
+    delete p->lane_extra_mods;
+  }
   if (p->predictor_dev) (void)hipFree(p->predictor_dev);
   release_host_side(p);
   if (p->head_geom_dev) (void)hipFree(p->head_geom_dev);
@@ -710,7 +751,8 @@ int32_t okx_precompile(const okx_program_desc* desc) {
   if (rc == OKX_OK && tmp->n_free <= okx::kQuadMaxFree) {
     // the lane kernel of the same program (programs it does not fit simply have none)
     std::string lsrc, lwhy, lcode;
-    if (okx::lane_generate(*tmp, &lsrc, &lwhy, 0) && !okx::lane_build(*tmp, &lsrc, &lcode, &lwhy))
+    std::vector<okx::LaneOverride> overrides;  // (asked for so that the per-kernel choice is made and remembered)
+    if (okx::lane_generate(*tmp, &lsrc, &lwhy, 0) && !okx::lane_build(*tmp, &lsrc, &lcode, &lwhy, false, nullptr, 0, false, &overrides))
       rc = fail(OKX_ERR_DEVICE, "lane kernel: %s", lwhy.c_str());
   }
   delete tmp;
@@ -742,12 +784,13 @@ int32_t okx_debug_lane_scratch(const okx_program_desc* desc, int32_t* out3) {
   int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
   std::string src, why, code;
   int variant = -1;
-  if (rc == OKX_OK && !okx::lane_build(*tmp, &src, &code, &why, false, &variant))
+  std::vector<okx::LaneOverride> overrides;
+  if (rc == OKX_OK && !okx::lane_build(*tmp, &src, &code, &why, false, &variant, 0, false, &overrides))
     rc = fail(OKX_ERR_LIMIT, "no lane kernel for this program: %s", why.c_str());
   delete tmp;
   if (rc != OKX_OK) return rc;
-  out3[0] = okx::quad_code_scratch_bytes(code, "okx_lane_solve");
-  out3[1] = okx::quad_code_scratch_bytes(code, "okx_lane_chain");
+  out3[0] = lane_worst_scratch(code, overrides, "okx_lane_solve");
+  out3[1] = lane_worst_scratch(code, overrides, "okx_lane_chain");
   out3[2] = variant;
   return OKX_OK;
 }

@@ -173,7 +173,7 @@ bool quad_compile(const std::string& src, std::string* code, std::string* err, b
 // Minimal reader for the two msgpack fields needed from the AMDGPU metadata note: kernel-level maps list their keys in
 // alphabetical order, so the ".name" string nearest before a ".private_segment_fixed_size" key is that kernel's name
 // (argument names sit under ".args", earlier in the map).
-static int code_kernel_field(const std::string& code, const char* prefix, const char* key, bool name_follows) {
+static int code_kernel_field(const std::string& code, const char* prefix, const char* key, bool name_follows, bool exact = false) {
   static const char kName[] = ".name";
   const size_t klen = std::strlen(key), nlen = sizeof(kName) - 1, plen = std::strlen(prefix);
   int best = -1;
@@ -195,7 +195,7 @@ static int code_kernel_field(const std::string& code, const char* prefix, const 
     else if (s[0] == 0xd9) len = s[1], skip = 2;
     else if (s[0] == 0xda) len = (s[1] << 8) | s[2], skip = 3;
     else continue;
-    if ((!name_follows && nm + nlen + skip + len > at) || len < plen) continue;
+    if ((!name_follows && nm + nlen + skip + len > at) || len < plen || (exact && len != plen)) continue;
     if (std::memcmp(s + skip, prefix, plen) != 0) continue;
     if (value > best) best = (int)value;
   }
@@ -206,30 +206,49 @@ int quad_code_scratch_bytes(const std::string& code, const char* prefix) {
   return code_kernel_field(code, prefix, ".private_segment_fixed_size", false);
 }
 
+int quad_code_kernel_scratch_bytes(const std::string& code, const char* name) {
+  return code_kernel_field(code, name, ".private_segment_fixed_size", false, true);
+}
+
 // Static LDS bytes (largest over the kernels whose name starts with `prefix`): ".group_segment_fixed_size" sorts before
 // ".name" in the kernel's metadata map.
 int quad_code_lds_bytes(const std::string& code, const char* prefix) {
   return code_kernel_field(code, prefix, ".group_segment_fixed_size", true);
 }
 
+static const char* const kLaneKernels[8] = {"okx_lane_solve_u", "okx_lane_solve_u_c", "okx_lane_solve_g", "okx_lane_solve_g_c",
+                                            "okx_lane_chain_u", "okx_lane_chain_u_c", "okx_lane_chain_g", "okx_lane_chain_g_c"};
+
 bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::string* why, bool ignore_cached, int* variant_out,
-                int good_enough_scratch, bool cache_only) {
+                int good_enough_scratch, bool cache_only, std::vector<LaneOverride>* overrides) {
   std::string src0, err;
   if (!lane_generate(P, &src0, why, 0)) return false;
+  if (overrides) overrides->clear();
   char name[64];
   std::snprintf(name, sizeof(name), "/okxl_%016llx.lanevar", fnv1a(src0));
   const std::string memo = cache_dir() + name;
   int first = 0, last = lane_variant_count() - 1;
+  std::vector<std::pair<std::string, int>> remembered;  // kernel -> the variant to take it from
   {
+    // "<variant>" or "<variant> <kernel>=<variant> ..."
     std::string text;
     if (read_file(memo, &text)) {
       const int v = atoi(text.c_str());
-      if (v >= 0 && v < lane_variant_count()) first = last = v;
+      if (v >= 0 && v < lane_variant_count()) {
+        first = last = v;
+        for (size_t at = text.find(' '); at != std::string::npos; at = text.find(' ', at + 1)) {
+          const size_t eq = text.find('=', at);
+          if (eq == std::string::npos) break;
+          const int ov = atoi(text.c_str() + eq + 1);
+          if (ov >= 0 && ov < lane_variant_count() && ov != v) remembered.push_back({text.substr(at + 1, eq - at - 1), ov});
+        }
+      }
     }
   }
   int best = -1, best_scratch = 1 << 30;
   bool searched_all = true;  // every variant compiled and looked at (not cut short by `good_enough_scratch` or a failure)
   std::string best_src, best_code;
+  std::vector<std::pair<int, std::string>> seen;  // (variant, code) of a search, for the per-kernel choice
   for (int v = first; v <= last; ++v) {
     std::string s1, c1, w1;
     if (v == 0) s1 = src0;
@@ -241,6 +260,7 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
       continue;
     }
     const int scratch = quad_code_scratch_bytes(c1, "okx_lane_solve");
+    if (overrides && first != last) seen.push_back({v, c1});
     if (scratch >= 0 && scratch < best_scratch) {
       best = v;
       best_scratch = scratch;
@@ -253,11 +273,33 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
     }
   }
   if (best < 0) return false;
+  std::string memo_text = std::to_string(best);
+  if (overrides && first == last) {
+    // a remembered choice: the other modules come from the cache (one that is not there any more is simply not used)
+    for (const auto& rk : remembered) {
+      std::string s1, c1, w1;
+      if (!lane_generate(P, &s1, &w1, rk.second) || !quad_compile(s1, &c1, &err, false, true)) continue;
+      overrides->push_back({rk.first, c1, rk.second, quad_code_kernel_scratch_bytes(c1, rk.first.c_str())});
+    }
+  } else if (overrides && searched_all && best_scratch > 0) {
+    for (const char* kernel : kLaneKernels) {
+      int have = quad_code_kernel_scratch_bytes(best_code, kernel), from = -1;
+      if (have <= 0) continue;
+      for (size_t k = 0; k < seen.size(); ++k) {
+        if (!lane_variants_same_arithmetic(seen[k].first, best)) continue;
+        const int sc = quad_code_kernel_scratch_bytes(seen[k].second, kernel);
+        if (sc >= 0 && sc < have) have = sc, from = (int)k;
+      }
+      if (from < 0) continue;
+      overrides->push_back({kernel, seen[from].second, seen[from].first, have});
+      memo_text += std::string(" ") + kernel + "=" + std::to_string(seen[from].first);
+    }
+  }
   // (only a search that ran to its goal - no scratch, or the least of all variants - is remembered: a program whose every
   //  variant spills a little would otherwise be given the FIRST variant under the create-time bound at every start)
   if (first != last && (best_scratch == 0 || searched_all)) {
     (void)mkdir(cache_dir().c_str(), 0777);
-    write_file_atomic(memo, std::to_string(best) + "\n");
+    write_file_atomic(memo, memo_text + "\n");
   }
   *src = best_src;
   *code = best_code;

@@ -1094,21 +1094,33 @@ DEV double unpark(int lo, int hi) {
 
 }  // namespace
 
-int lane_variant_count() { return 8; }
+int lane_variant_count() { return 12; }
+
+namespace {
+// Emission variants: the same arithmetic, differing only in hints to the compiler (opaque uses after each row, a
+// redefinition of the factorisation's inputs at its top, where the scheduling barriers of the factorisation sit) - except
+// `late_diag`, which assembles the diagonal of J^T J in another order (other rounding).
+const struct { bool pin, launder, late_diag; int col_fence; } kVariants[12] = {
+    {false, false, false, 3}, {true, true, false, 3}, {false, true, false, 3}, {true, false, false, 3},
+    {false, false, false, 1}, {false, false, false, 6}, {false, false, true, 3}, {false, false, false, 0},
+    {false, false, false, 2}, {false, false, true, 1}, {false, true, true, 3}, {true, false, true, 6}};
+}  // namespace
+
+bool lane_variants_same_arithmetic(int a, int b) {
+  const int n = lane_variant_count();
+  return a >= 0 && a < n && b >= 0 && b < n && kVariants[a].late_diag == kVariants[b].late_diag;
+}
 
 bool lane_chain_is_flat(int n_vars) {
   return 80 - 4 * n_vars < 16;  // fewer than 16 of the 80 LDS slots left for the factor's rows beside x, dx, xp, xq
 }
 
 bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant) {
-  // Emission variants: the same arithmetic in the same order, differing only in hints to the compiler (opaque uses after
-  // each row, a redefinition of the factorisation's inputs at its top, where the scheduling barriers of the factorisation
-  // sit, whether the diagonal is assembled late).  The register allocator's result for an 18-unknown program sits at the
-  // edge of the 512-register file and is not monotonic in any of them (0 ... 250 B of scratch across these for the double
-  // wishbone), so lane_build (okx_jit.cpp) compiles them in this order and keeps the first one that does not spill.
-  static const struct { bool pin, launder, late_diag; int col_fence; } kVariants[8] = {
-      {false, false, false, 3}, {true, true, false, 3}, {false, true, false, 3}, {true, false, false, 3},
-      {false, false, false, 1}, {false, false, false, 6}, {false, false, true, 3}, {false, false, false, 0}};
+  // Emission variants (kVariants above): the register allocator's result for an 18-unknown program sits at the edge of the
+  // 512-register file and is not monotonic in any of the hints (0 ... 250 B of scratch across them for the double
+  // wishbone, and not the same variant for every kernel of the module), so lane_build (okx_jit.cpp) compiles them in this
+  // order, keeps the first one whose independent-solve kernels do not spill - or, after a full search, the one that spills
+  // least, with single kernels taken from other variants of the same arithmetic.
   if (variant < 0 || variant >= lane_variant_count()) variant = 0;
   const auto& V = kVariants[variant];
   if (P.n_free > kLaneMaxFree) {
@@ -1132,9 +1144,19 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // The geometry's tables are read through the scalar cache where they are used (see the chain constants above); the
   // developer switch lane_lds_tables brings back round 3's staging into LDS (and takes its share of the 40 KiB).
   const bool scalar_tables = !dev_switch("lane_lds_tables");
-  const int table_doubles = scalar_tables ? 0 : 3 * P.n_points + 8 * (P.n_crows + P.n_targets) + (P.n_derived > 0 ? P.n_derived : 1);
+  const int all_table_doubles = 3 * P.n_points + 8 * (P.n_crows + P.n_targets) + (P.n_derived > 0 ? P.n_derived : 1);
+  const int table_doubles = scalar_tables ? 0 : all_table_doubles;
   int cold_j_slots = (40 * 1024 - 8 * table_doubles - 256) / 512 - kColdStateSlots;
   if (cold_j_slots < 0) cold_j_slots = 0;
+  // Independent solves on PER-GEOMETRY tables get a body of their own: every wave unit (or every few) has another
+  // geometry, the wavefronts of a CU read 3 KB each of different tables, and those reads miss the 16 KB scalar cache - a
+  // round trip to L2 per batch of reads, in every pass (measured: the scalar tables gave the ensemble kernel 2.5 % where
+  // 15 % of its time was staging).  There the tables - and the first-step table, in an area of its own - are staged into
+  // LDS once per geometry, every load of the batch in flight together, and a wavefront takes a contiguous block of wave
+  // units (developer switch lane_g_scalar: one body for both, as for the chains).
+  const bool split_g = scalar_tables && !dev_switch("lane_g_scalar");
+  int g_l_slots = (40 * 1024 - 8 * (all_table_doubles + head_stride) - 256) / 512 - kColdStateSlots;
+  if (g_l_slots < 0) g_l_slots = 0;
   struct PassSrc { std::string eval, factor, subst; };
   auto make_pass = [&](LGen& gen, PassSrc* out) -> bool {
     // (measured on the double wishbone, scratch bytes of the independent-solve bodies _u / _g: pins + launder 0 / 188, pins
@@ -1180,6 +1202,20 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   if (!make_pass(evc, &pass_cold)) {
     *why = evc.why;
     return false;
+  }
+  LGen evg(P);
+  PassSrc pass_g;
+  if (split_g) {
+    evg.hoisted_names = ev.hoisted_names;
+    evg.j_lds_base = kColdStateSlots;
+    evg.j_lds_slots = 0;
+    evg.l_lds_base = kColdStateSlots;
+    evg.l_lds_slots = g_l_slots;
+    evg.late_diag = V.late_diag;
+    if (!make_pass(evg, &pass_g)) {
+      *why = evg.why;
+      return false;
+    }
   }
 
   // confirming evaluation (residuals only); not for programs with the reference's zero-gradient point-on-line row
@@ -1235,6 +1271,37 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     gg.f("%sif (lane < %d) gl[%d + lane] = a.row_param[%d + lane];", indent, 8 * T, ev.gl_tq0, 8 * P.n_crows);
     gg.f("%sif (lane < %d) gl[%d + lane] = a.dop_param[lane];", indent, P.n_derived, ev.gl_dp0);
   };
+  // The same as ONE batch: every load first (lane k fetching entries k, k + 64, ... of each table, the index clamped so
+  // that no load sits under a branch), then the LDS writes; the first-step table too (under `with_head`), to gl[head_into].
+  // (a `for` with a load and an LDS store per trip is compiled to one memory round trip per trip: seven to HBM-resident
+  //  tables were 13 900 cycles per wave unit of the ensemble kernel)
+  struct Piece { const char* src; int src_off, count, dst; };
+  auto stage_pieces = [&](LGen& gg, const char* indent, const std::vector<Piece>& pieces, int id) -> std::string {
+    std::string stores;
+    char line[160];
+    for (const Piece& pc : pieces)
+      for (int k0 = 0; k0 < pc.count; k0 += 64, ++id) {
+        const int left = pc.count - k0;
+        if (left >= 64) {
+          gg.f("%sconst double sv%d = %s[%d + lane];", indent, id, pc.src, pc.src_off + k0);
+          std::snprintf(line, sizeof(line), "%sgl[%d + lane] = sv%d;\n", indent, pc.dst + k0, id);
+        } else {
+          gg.f("%sconst double sv%d = %s[%d + (lane < %d ? lane : %d)];", indent, id, pc.src, pc.src_off + k0, left, left - 1);
+          std::snprintf(line, sizeof(line), "%sif (lane < %d) gl[%d + lane] = sv%d;\n", indent, left, pc.dst + k0, id);
+        }
+        stores += line;
+      }
+    return stores;
+  };
+  auto stage_tables_batched = [&](LGen& gg, const char* indent, int head_into) {
+    const std::string stores = stage_pieces(gg, indent, {{"gp", 0, 3 * NP, ev.gl_gp0}, {"gq", 0, 8 * P.n_crows, ev.gl_gq0},
+                                                         {"a.row_param", 8 * P.n_crows, 8 * T, ev.gl_tq0}, {"a.dop_param", 0, P.n_derived, ev.gl_dp0}}, 0);
+    gg.f("%sif (with_head) {", indent);
+    const std::string deeper = std::string(indent) + "  ";
+    gg.out += stage_pieces(gg, deeper.c_str(), {{"hsrc", 0, head_stride, head_into}}, 100);
+    gg.f("%s}", indent);
+    gg.out += stores;
+  };
   const bool marks = dev_switch("lane_mark");  // `s_nop 11..16` between the sections of a pass (tools/lane_isa.sh)
   // developer build: every wave unit of the independent-solve body stamps the shader clock into a.trace[16 wu + k] - 0 unit
   // start, 1 tables staged, 16 state set up, 2 first step in hand, 3 passes done (4 / 5: full / confirming passes it ran,
@@ -1248,7 +1315,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   {
     // every table entry a constant's name can stand for (unused macros cost nothing)
     std::set<std::string> defs;
-    for (LGen* gen : {&ev, &evc}) defs.insert(gen->defines.begin(), gen->defines.end());
+    for (LGen* gen : {&ev, &evc, &evg}) defs.insert(gen->defines.begin(), gen->defines.end());
     char line[96];
     for (int i = 0; i < P.m; ++i)
       for (int k = 0; k < 8; ++k) {
@@ -1272,7 +1339,12 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   const bool flat_chain = lane_chain_is_flat(n);
   // `ch`: the chain loop inside the body, history in LDS.  `fl` (flat chain, see okx_quad.hpp lane_chain_is_flat): the
   // independent-solve body walked over (wave unit, chain step) pairs, chain state in the launch's global scratch.
-  auto body = [&](bool ch, bool fl) -> bool {
+  LGen& evc_ = evc;
+  const PassSrc& pass_cold_ = pass_cold;
+  // `gb`: the independent-solve body of per-geometry launches (tables and first-step table staged in LDS, see split_g)
+  auto body = [&](bool ch, bool fl, bool gb) -> bool {
+    LGen& evc = gb ? evg : evc_;
+    const PassSrc& pass_cold = gb ? pass_g : pass_cold_;
     int n_slots = 0;
     auto slot_ref = [&](const std::string& name) { return "double& " + name + " = lds[" + std::to_string(64 * n_slots++) + " + lane];"; };
     std::string state_decl;
@@ -1290,9 +1362,9 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     // in later): the prologue's 100-odd table reads are LDS broadcasts instead of same-address global loads
     const int head_l0 = state_doubles_before_l;
     const bool cold = !ch && !fl;
-    const bool sc = scalar_tables;      // no tables in LDS at all: read where they are used through the scalar cache
-    if (!sc && lds_doubles < head_l0 + head_stride) lds_doubles = head_l0 + head_stride;
-    const int gl_doubles = sc ? 0 : gl_size;
+    const bool sc = scalar_tables && !gb;  // no tables in LDS at all: read where they are used through the scalar cache
+    if (!sc && !gb && lds_doubles < head_l0 + head_stride) lds_doubles = head_l0 + head_stride;
+    const int gl_doubles = sc ? 0 : gl_size + (gb ? head_stride : 0);
     const std::string refresh_s = sc ? std::string(refresh_kz) + " asm volatile(\"\" : \"+s\"(kzs));" : std::string(refresh_kz);
     const char* const refresh_kz = refresh_s.c_str();  // (shadows the LDS-only form: this body's passes refresh both opaque zeros)
     if ((lds_doubles + gl_doubles) * 8 > 40 * 1024) {
@@ -1319,12 +1391,13 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
           ev.gl_gq0, ev.gl_tq0, ev.gl_gq0, ev.gl_dp0, ev.gl_tq0 - 8 * P.n_crows, ev.gl_dp0);
     } else
       g.f("#define GL(o) gl[(o) + kz]");
-    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a) {", ch || fl ? "chain" : "cold");
+    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a) {", ch || fl ? "chain" : gb ? "coldg" : "cold");
     g.f("  const int lane = threadIdx.x;");
     g.f("  __shared__ double lds[%d];", lds_doubles);
     if (sc) g.f("  int kzs = 0;  // an opaque zero in a scalar register: a table read inside a pass is a load of that pass, not a loop invariant");
     else
-    g.f("  __shared__ double gl[%d];  // the wave unit's geometry tables: positions, row parameters, derived-op parameters", gl_doubles);
+    g.f("  __shared__ double gl[%d];  // the wave unit's geometry tables: positions, row parameters, derived-op parameters%s", gl_doubles,
+        gb ? ", first-step table" : "");
     g.f("  int kz = 0;");
     g.f("  const long long spg = a.steps_per_geometry;");
     g.f("  const long long span = spg > 0 ? spg : a.n_problems;");
@@ -1355,6 +1428,10 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("  const long long wu_per_wave = (n_wave_units + gridDim.x - 1) / gridDim.x;");
       g.f("  const long long wu_lo = PG ? blockIdx.x * wu_per_wave : blockIdx.x, wu_step = PG ? 1 : gridDim.x;");
       g.f("  const long long wu_hi = PG ? (wu_lo + wu_per_wave < n_wave_units ? wu_lo + wu_per_wave : n_wave_units) : n_wave_units;");
+      if (gb) {
+        g.f("  const bool with_head = a.head != nullptr && a.grad_tol <= 0.0;");
+        g.f("  long long staged_span = -1;");
+      }
       g.f("  for (long long wu = wu_lo; wu < wu_hi; wu += wu_step) {");
     } else
     g.f("  for (long long wu = blockIdx.x; wu < n_wave_units; wu += gridDim.x) {");
@@ -1393,13 +1470,21 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       stage_tables(g, "      ");
       g.f("      staged_span = span_idx;");
       g.f("    }");
+    } else if (gb) {
+      g.f("    if (span_idx != staged_span) {  // wave-uniform: the tables stay while the geometry does");
+      g.f("      const double* hsrc = a.head + span_idx * %d;", head_stride);
+      stage_tables_batched(g, "      ", gl_size);
+      g.f("      staged_span = span_idx;");
+      g.f("    }");
     } else
     stage_tables(g, "    ");
+    if (!gb) {
     g.f("    const bool with_head = a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
     g.f("    if (with_head) {");
     g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
     g.f("      for (int k = lane; k < %d; k += 64) lds[%d + k] = hp[k];", head_stride, head_l0);
     g.f("    }");
+    }
     g.f("    WAVE_SYNC();");
     }
     stamp(1);
@@ -1407,7 +1492,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     for (int p = 0; p < NP; ++p) {
       if (!used[p] || is_fixed(p)) continue;
       for (int c = 0; c < 3; ++c)
-        if (sc) g.f("    double p%d_%d = GL(%d);", p, c, ev.gl_gp0 + 3 * p + c);
+        if (sc || gb) g.f("    double p%d_%d = GL(%d);", p, c, ev.gl_gp0 + 3 * p + c);
         else g.f("    double p%d_%d = gp[%d];", p, c, 3 * p + c);
     }
     g.out += state_decl;
@@ -1431,6 +1516,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("    double hstep = 0.0, hN = 0.0, hM = 0.0, hss = 0.0, hmr = 0.0, hs0 = 0.0, hs1 = 0.0, hs4 = 0.0, hs5 = 0.0;");
     g.f("    if (with_head) {");
     if (sc) g.f("      const okx_cptr hp = (okx_cptr)(a.head + (PG ? span_idx * %d : 0)) + kzs;", head_stride);
+    else if (gb) g.f("      const double* hp = gl + %d + kz;  // the staged table", gl_size);
     else g.f("      const double* hp = lds + %d + kz;  // the staged table", head_l0);
     g.f("      const double hr0 = 1.0;");
     for (int k = 1; k < HK; ++k) g.f("      const double hr%d = td%d - tn%d;", k, k - 1, k - 1);
@@ -1796,7 +1882,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("");
     return true;
   };
-  if (!body(false, false) || !(flat_chain ? body(false, true) : body(true, false))) {
+  if (!body(false, false, false) || (split_g && !body(false, false, true)) || !(flat_chain ? body(false, true, false) : body(true, false, false))) {
     *why = lds_why;
     return false;
   }
@@ -1864,7 +1950,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     for (const char* geo : {"u", "g"})
       for (const char* out : {"", "_c"})   // _c: compact outputs (free coordinates or nothing)
         g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_%s_%s%s(QArgs a) { okx_lane_body_%s<%s, %s>(a); }", body, geo,
-            out, body[0] == 's' ? "cold" : "chain", geo[0] == 'g' ? "true" : "false", out[0] ? "false" : "true");
+            out, body[0] != 's' ? "chain" : (split_g && geo[0] == 'g') ? "coldg" : "cold", geo[0] == 'g' ? "true" : "false", out[0] ? "false" : "true");
   (void)ev.undefs;  // (the macros live to the end of the translation unit: one program per module)
   *src = g.out;
   return true;

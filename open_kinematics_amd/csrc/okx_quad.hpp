@@ -149,14 +149,27 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
 bool lane_chain_is_flat(int n_vars);
 inline long long lane_flat_chain_doubles(int n_vars) { return 3LL * (n_vars + 2) * 64; }
 int lane_variant_count();
+bool lane_variants_same_arithmetic(int a, int b);  // same operations in the same order: bit-identical results
 // lane_generate + quad_compile over the emission variants: keeps the first variant whose independent-solve bodies
 // (okx_lane_solve_*) do not spill, else the one that spills least.  The choice is remembered next to the code objects
 // (<hash of variant 0's source>.lanevar in the kernel cache), so a later call compiles nothing.  `variant_out` (may be
 // null) receives the variant kept.  `good_enough_scratch`: the search stops at the first variant whose independent-solve
 // bodies spill at most that many bytes - 0 for okx_precompile (the full search, whose result is remembered), the 256 B
 // auto selection accepts for okx_program_create (a program nobody precompiled must not wait for eight hiprtc runs).
+// `overrides` (may be null): the register allocator's result differs from kernel to kernel of one module, so after a FULL
+// search every solve / chain kernel that spills less in another variant's module than in the kept one is listed here with
+// that module (the caller loads it and takes this one kernel from it); remembered in the same file.  Only variants with the
+// kept one's arithmetic are candidates: a program's kernels give the same bits whichever output they write.
+struct LaneOverride {
+  std::string kernel;  // e.g. "okx_lane_solve_g"
+  std::string code;    // the code object to take it from
+  int variant, scratch;
+};
 bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::string* why, bool ignore_cached = false,
-                int* variant_out = nullptr, int good_enough_scratch = 0, bool cache_only = false);
+                int* variant_out = nullptr, int good_enough_scratch = 0, bool cache_only = false,
+                std::vector<LaneOverride>* overrides = nullptr);
+// Scratch bytes of the kernel called exactly `name` (-1: no such kernel).
+int quad_code_kernel_scratch_bytes(const std::string& code, const char* name);
 
 // Compiles `src` for gfx950 with hiprtc (no device needed) or fetches it from the on-disk cache
 // (<dir of libokx.so>/_kcache/<hash>.okxc, override with OKX_KERNEL_CACHE).  Returns the code

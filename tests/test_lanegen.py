@@ -37,8 +37,13 @@ def test_lane_source_is_generated_for_corner_topologies(golden, name, mode):
     for i in range(n):
         assert f"A{i}_{i} = 0.0" in src and f"const double dinv{i} = pivot_rcp(C{i}_{i});" in src
     assert "__builtin_amdgcn_mov_dpp" not in src and "ds_swizzle" not in src  # no cross-lane operand anywhere
-    # the geometry's tables are staged into LDS with coalesced loads and read where they are used
-    assert "#define hs0_0 gl[" in src and "+ kz]" in src and "gl[0 + k] = gp[k]" in src
+    # a table entry's name is a macro over GL(offset).  Own geometry and chains: wave-uniform reads through the scalar cache
+    # (constant-address-space copies of the table pointers, an opaque scalar offset); independent solves on per-geometry
+    # tables: a body of its own that stages them into LDS once per geometry, the loads in one batch
+    assert "#define hs0_0 GL(" in src and "const okx_cptr gpc = (okx_cptr)gp" in src and '"+s"(kzs)' in src
+    assert "void okx_lane_body_coldg(const QArgs& a)" in src and "#define GL(o) gl[(o) + kz]" in src
+    assert "okx_lane_solve_g(QArgs a) { okx_lane_body_coldg<true, true>(a); }" in src
+    assert "if (span_idx != staged_span) {" in src and "gl[0 + lane] = sv0;" in src
     # structure only: no geometry value is baked into the text
     assert "471.69" not in src and "559.01" not in src and "410.0" not in src
 
@@ -81,6 +86,10 @@ def test_independent_solve_bodies_of_the_baseline_programs_do_not_spill(golden, 
     host = _abi.HostProgram(program.with_line_mode("pinned"))
     out = (C.c_int32 * 3)()
     assert lib.okx_debug_lane_scratch(host.byref(), out) == 0, _lib.last_error()
-    assert out[0] == 0, f"independent-solve bodies spill {out[0]} B (variant {out[2]})"
+    # (the worst of the four kernels as they are launched - a kernel that spills less in another variant's module is taken
+    #  from there.  MacPherson: nothing spills.  The double wishbone: the full-record kernels keep everything in registers,
+    #  the compact per-geometry one keeps 20 B of prologue values in scratch in its best variant - measured harmless,
+    #  where 100 B inside the passes cost a quarter of the rate: profiles/r04/EXPERIMENTS.md section 6)
+    assert out[0] <= (0 if name == "c4_macpherson_grid" else 32), f"independent-solve bodies spill {out[0]} B (variant {out[2]})"
     if name == "c4_macpherson_grid":
         assert out[1] == 0

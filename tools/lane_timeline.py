@@ -46,6 +46,12 @@ for _ in range(20):
     launch()
 wall, ms = bench.time_launches(launch, 50, 5, dev)
 print(f"{1e3 * ms:.1f} us per launch ({n / (ms * 1e-3):.3e} solves/s)")
+free = torch.empty((n, program.n_vars // 3, 3), dtype=torch.float64, device=dev)
+launch_free = dp.plan(t, out=free, info_out=info, chain_len=1, predictor=False, kernel="lane", output="free", **kw)
+for _ in range(20):
+    launch_free()
+wall, ms_free = bench.time_launches(launch_free, 50, 5, dev)
+print(f"{1e3 * ms_free:.1f} us per launch with output = free (the compact kernel)")
 if "lane_timeline" not in os.environ.get("OKX_DEV", ""):
     sys.exit(0)
 tr = torch.zeros((units, 32), dtype=torch.float64, device=dev)
