@@ -1727,6 +1727,19 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("  const long long chains_per_span = unit_len == 1 ? span : (span + unit_len - 1) / unit_len;");
   g.f("  const long long n_units = spg > 0 ? (a.n_problems / span) * chains_per_span : chains_per_span;");
   }
+  if (CD && pv) {
+    // (pair mode; the single-mode cold body - the headline's one unit per wavefront - keeps the plain loop: with this one it
+    //  measured 16.3 -> 16.7 us per C2 sweep, 22 more scalar-register spills in its code)
+    // round k of the grid-stride loop gives wavefront w the unit k G + (w + 131 k) mod G: a wavefront's units are spread
+    // over the sweep instead of sitting G apart (on a 256-wide grid with G = 1024 that is the same columns - the same
+    // distance from the design state, the same number of passes - in every round: C3 cold 0.3375 -> 0.3307 ms; chains,
+    // whose neighbours in memory are neighbours in time, lose 1.6 % with it and keep the plain stride)
+    g.f("  const unsigned wu_g = gridDim.x, wu_rot_step = 131u %% wu_g;");
+    g.f("  unsigned wu_rot = blockIdx.x;");
+    g.f("  for (long long wu0 = 0; wu0 * %d < n_units; wu0 += wu_g, wu_rot = wu_rot + wu_rot_step >= wu_g ? wu_rot + wu_rot_step - wu_g : wu_rot + wu_rot_step) {", PPW);
+    g.f("    const long long wu = wu0 + wu_rot;");
+    g.f("    if (wu * %d >= n_units) continue;", PPW);
+  } else
   g.f("  for (long long wu = blockIdx.x; wu * %d < n_units; wu += gridDim.x) {", PPW);
   if (pv) {
     // the side bit as a value the optimiser cannot see through: every per-side table index is then computed where it
