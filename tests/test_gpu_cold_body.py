@@ -114,3 +114,32 @@ def test_the_reference_line_row_keeps_the_general_body(monkeypatch):
 
     program, targets = bump_sweep_problem(256, line_mode="softnorm")
     _assert_same(*_both_bodies(program, targets, monkeypatch))
+
+
+def test_a_partial_last_round_of_the_rotated_unit_loop(monkeypatch):
+    """Independent solves deal a wavefront's units out rotated over the sweep (round k: unit k G + (w + 131 k) mod G).  Batches
+    that fill the grid once and a part of a second round: every problem solved exactly once - the pair-mode cold body (8
+    problems per wavefront) against the general body bit for bit, the lane kernel (64 per wavefront, own geometry) against the
+    quad kernel to 1e-9 mm, and nothing written past the batch."""
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.workloads import axle_grid_problem, macpherson_grid_problem
+
+    props = torch.cuda.get_device_properties(0)
+    waves = props.multi_processor_count * 4
+    program, targets = axle_grid_problem(130, 100)                       # 13000 problems
+    n = min(targets.shape[0], waves * 8 + 8 * 301 + 3)                   # one full round + 301 wavefront units + a ragged one
+    cold, general = _both_bodies(program, targets[:n], monkeypatch)
+    assert _assert_same(cold, general).mean() > 0.9
+    program, targets = macpherson_grid_problem(300, 300)                 # 90000 problems
+    n = min(targets.shape[0], waves * 64 + 64 * 333 + 17)
+    dp = DeviceProgram(program, "cuda:0")
+    assert dp.lane_threshold > 0, dp.lane_note
+    t = torch.as_tensor(targets[:n], device="cuda:0")
+    guard = torch.full((n + 1, program.n_out, 3), -7.0, dtype=torch.float64, device="cuda:0")
+    lane = dp.solve(t, chain_len=1, predictor=False, kernel="lane", out=guard[:n])
+    quad = dp.solve(t, chain_len=1, predictor=False, kernel="quad")
+    torch.cuda.synchronize()
+    assert np.all((lane.info()["flags"] & 7) == 1) and np.all((quad.info()["flags"] & 7) == 1)
+    assert float((lane.positions - quad.positions).abs().max()) <= 1e-9
+    assert float((guard[n] + 7.0).abs().max()) == 0.0, "wrote past the batch"
+    dp.close()

@@ -93,3 +93,8 @@ def test_independent_solve_bodies_of_the_baseline_programs_do_not_spill(golden, 
     assert out[0] <= (0 if name == "c4_macpherson_grid" else 32), f"independent-solve bodies spill {out[0]} B (variant {out[2]})"
     if name == "c4_macpherson_grid":
         assert out[1] == 0
+    # the choice (kept variant + the kernels taken from other variants) is remembered beside the code objects: asking again
+    # reads it back instead of searching, and must come to the same kernels
+    again = (C.c_int32 * 3)()
+    assert lib.okx_debug_lane_scratch(host.byref(), again) == 0, _lib.last_error()
+    assert list(again) == list(out)
