@@ -685,6 +685,10 @@ def main() -> None:
                          "geometries x 256 steps, geometry-major shards (strong scaling)")
     ap.add_argument("--preheat-ms", type=float, default=40.0,
                     help="milliseconds of untimed launches ahead of the warm-up steps (GPU clocks leave their idle state); 0 = none")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="one GPU: submit the K timed steps as K stream launches instead of ONE HIP graph of K kernel nodes "
+                         "(measured on a quiet host: 16.09 against 16.30 us per step at K = 2000, no difference at K = 20; the graph "
+                         "keeps 0.3 ms of GPU work independent of the host's launch loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip with_model / e2e / other_configs / dropin (what the profiling runs use)")
@@ -768,12 +772,16 @@ def self_launch(n_ranks: int, argv: list, dry: bool = False) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_launch_events: bool, preheat_ms: float = 0.0):
+def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_launch_events: bool, preheat_ms: float = 0.0,
+                 graph_steps: bool = False):
     """The contract's timed region: W warm-up steps, barrier + synchronize, K steps, synchronize + barrier, MAX over
     ranks.  `step(k, start_event, end_event)` records the events around its solve launch when they are given.
     `preheat_ms` > 0: the same step is launched for that long ahead of the W warm-up steps (reported in the line as
     `preheat`): a GPU that has been idle runs its first few milliseconds of kernels at reduced clocks - 20 steps after 5
-    warm-up steps measured 8 % slower than the same kernel after 11 ms of launches (profiles/r03/EXPERIMENTS.md section 10)."""
+    warm-up steps measured 8 % slower than the same kernel after 11 ms of launches (profiles/r03/EXPERIMENTS.md section 10).
+    `graph_steps` (one rank, no exchange; the current stream must not be the default stream): the K timed steps are captured
+    ahead of the timed region into ONE HIP graph of K kernel nodes and the timed region launches that graph - the same K
+    kernels, submitted in one call, so that 0.3 ms of GPU work are not at the mercy of the host's launch loop."""
     preheat_steps = 0
     if preheat_ms > 0.0:
         torch.cuda.synchronize(device)
@@ -793,6 +801,21 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
     for k in range(warmup):
         step(k, None, None)
     drain()
+    graph = None
+    timed_region.graph_note = None
+    if graph_steps and world == 1 and not per_launch_events:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=torch.cuda.current_stream(device)):
+                for k in range(steps):
+                    step(k, None, None)
+            graph.replay()  # (the first launch of a graph uploads it: untimed, part of the warm-up)
+            drain()
+        except Exception as exc:  # a runtime that refuses the capture: the K steps are launched one by one, and the line says so
+            graph = None
+            timed_region.graph_note = f"graph capture failed ({type(exc).__name__}: {exc}); stream launches"
+            torch.cuda.synchronize(device)
+    timed_region.graph = graph is not None
     n_pairs = steps if per_launch_events else 1
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
@@ -807,8 +830,11 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
     t0 = time.perf_counter()
     if not per_launch_events:
         starts[0].record()
-    for k in range(steps):
-        step(k, starts[k] if per_launch_events else None, ends[k] if per_launch_events else None)
+    if graph is not None:
+        graph.replay()
+    else:
+        for k in range(steps):
+            step(k, starts[k] if per_launch_events else None, ends[k] if per_launch_events else None)
     if not per_launch_events:
         ends[0].record()
     drain()
@@ -834,6 +860,11 @@ def run_c2(args, world: int, rank: int, device) -> dict:
     n_total = STEPS_PER_RANK * world
     program, targets_all = bump_sweep_problem(n_total)
     lo, hi = shard_range(n_total, rank, world)
+    use_graph = world == 1 and not args.rccl_world_one and not args.no_graph
+    if world == 1:
+        # one GPU: everything below (plans, events, the extra legs) runs on a stream of its own - stream capture, which the
+        # graph submission of the timed steps needs, is not allowed on the default stream
+        torch.cuda.set_stream(torch.cuda.Stream(device))
     dp = DeviceProgram(program, device)
     targets = torch.as_tensor(targets_all[lo:hi], device=device).contiguous()
     info = torch.empty((hi - lo, 40), dtype=torch.uint8, device=device)
@@ -862,7 +893,7 @@ def run_c2(args, world: int, rank: int, device) -> dict:
     # exchange between launches is excluded from the kernel time.
     exchanging = world > 1 or args.rccl_world_one
     elapsed, kernel_ms = timed_region(step, pipe.drain, args.steps, args.warmup, world, device, per_launch_events=exchanging,
-                                      preheat_ms=args.preheat_ms)
+                                      preheat_ms=args.preheat_ms, graph_steps=use_graph)
     preheat_steps = timed_region.preheat_steps
     if args.rccl_world_one:
         # the gathered + expanded block of the last step must be the locally solved one, bit for bit
@@ -891,6 +922,10 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         "preheat": {"ms": args.preheat_ms, "steps": preheat_steps,
                     "note": "untimed launches of the same step ahead of the W warm-up steps, so that the K timed steps run at the "
                             "clocks of a GPU under load rather than of one leaving idle (--preheat-ms 0 switches it off)"},
+        "submission": ({"mode": "hip graph", "note": "the K timed steps are K kernel nodes of ONE HIP graph, captured ahead of the timed "
+                        "region and launched once inside it (--no-graph: K stream launches, as `sustained` below)"}
+                       if getattr(timed_region, "graph", False) else
+                       {"mode": "stream launches", **({"note": timed_region.graph_note} if getattr(timed_region, "graph_note", None) else {})}),
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
