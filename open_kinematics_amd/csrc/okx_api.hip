@@ -1446,6 +1446,23 @@ int32_t okx_corner_metrics_batch(const okx_corner_roles* roles, int64_t n_states
   a.n_states = n_states;
   a.n_out = n_out;
   a.n_targets = n_targets;
+  // Records of up to 21 points (corners): 64 states per wavefront, records, tangent rows and results staged through LDS
+  // (okx_corner_metrics_tiled); longer records (the corners of a composed axle): one thread per state.  The same
+  // formulas either way: same bits.
+  okx::TileArgs ta;
+  ta.rec = 3u * (uint32_t)n_out;
+  ta.rec_inv = (uint32_t)((1ull << 32) / ta.rec) + 1u;
+  ta.stride = ta.rec | 1u;
+  const size_t lds_bytes = sizeof(double) * okx::kTileStates * (ta.stride > OKX_METRIC_COUNT ? ta.stride : OKX_METRIC_COUNT);
+  const long long tiles = (n_states + okx::kTileStates - 1) / okx::kTileStates;
+  if (ta.rec <= 63 && tiles < 0x7fffffffll) {
+    if (d_tangents)
+      hipLaunchKernelGGL(okx::okx_corner_metrics_tiled<true>, dim3((unsigned)tiles), dim3(okx::kTileStates), lds_bytes, (hipStream_t)stream, a, ta);
+    else
+      hipLaunchKernelGGL(okx::okx_corner_metrics_tiled<false>, dim3((unsigned)tiles), dim3(okx::kTileStates), lds_bytes, (hipStream_t)stream, a, ta);
+    HIP_TRY(hipGetLastError());
+    return OKX_OK;
+  }
   const long long blocks = (n_states + 255) / 256;
   hipLaunchKernelGGL(okx::okx_corner_metrics_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());

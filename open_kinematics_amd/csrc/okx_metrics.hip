@@ -87,21 +87,69 @@ __device__ __forceinline__ bool intersect_two_planes(DVec n1, Dual d1, DVec n2, 
   return true;
 }
 
+// Where a state's role points come from.  The metric formulas name their points by ROLE SLOT (a compile-time constant at
+// every use); a source turns a slot into the point as a dual vector.
+enum RoleSlot {
+  SLOT_WHEEL_CENTER, SLOT_CONTACT_PATCH, SLOT_AXLE_OUTBOARD, SLOT_AXLE_INBOARD, SLOT_STEER_LOWER, SLOT_STEER_UPPER,
+  SLOT_DAMPER_TOP, SLOT_DAMPER_BOTTOM, SLOT_INSTANT_AXIS_0,  // ... SLOT_INSTANT_AXIS_0 + 5
+  SLOT_COUNT = SLOT_INSTANT_AXIS_0 + 6
+};
+__device__ __forceinline__ int role_point(const okx_corner_roles& R, int slot) {
+  switch (slot) {
+    case SLOT_WHEEL_CENTER: return R.wheel_center;
+    case SLOT_CONTACT_PATCH: return R.contact_patch;
+    case SLOT_AXLE_OUTBOARD: return R.axle_outboard;
+    case SLOT_AXLE_INBOARD: return R.axle_inboard;
+    case SLOT_STEER_LOWER: return R.steer_lower;
+    case SLOT_STEER_UPPER: return R.steer_upper;
+    case SLOT_DAMPER_TOP: return R.damper_top;
+    case SLOT_DAMPER_BOTTOM: return R.damper_bottom;
+    default: return R.instant_axis_point[slot - SLOT_INSTANT_AXIS_0];
+  }
+}
+// ... the record (and a tangent row, or none) read where the point is used: one thread per state
+struct RecordPoints {
+  const okx_corner_roles& R;
+  const double* pos;
+  const double* vel;
+  __device__ __forceinline__ DVec at(int slot) const { return load_point(pos, vel, role_point(R, slot)); }
+};
+// ... positions gathered into registers once per state, the tangent row (or none) read where it is used (the tiled kernels)
+struct GatheredPoints {
+  const okx_corner_roles& R;
+  double pv[SLOT_COUNT][3];
+  const double* vel;
+  __device__ __forceinline__ void gather(const double* pos) {
+#pragma unroll
+    for (int s = 0; s < SLOT_COUNT; ++s) {
+      const int k = role_point(R, s);  // (an absent role, -1: its value is never used)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pv[s][c] = pos[3 * (k < 0 ? 0 : k) + c];
+    }
+  }
+  __device__ __forceinline__ DVec at(int slot) const {
+    const int k = role_point(R, slot);
+    DVec p;
+    p.x = {pv[slot][0], vel ? vel[3 * k] : 0.0};
+    p.y = {pv[slot][1], vel ? vel[3 * k + 1] : 0.0};
+    p.z = {pv[slot][2], vel ? vel[3 * k + 2] : 0.0};
+    return p;
+  }
+};
+
 // corner/double_wishbone.py:376-403, corner/macpherson.py:325-355
-__device__ __forceinline__ bool instant_axis(const okx_corner_roles& R, const double* pos, const double* vel,
-                                             DVec* point, DVec* dir) {
-  const int32_t* ip = R.instant_axis_point;
+template <class Points>
+__device__ __forceinline__ bool instant_axis(const okx_corner_roles& R, const Points& pts, DVec* point, DVec* dir) {
+  constexpr int ip = SLOT_INSTANT_AXIS_0;
   DVec n1, n2;
   Dual d1, d2;
   if (R.instant_axis_kind == OKX_IA_TWO_PLANES) {
-    if (!plane_from_three_points(load_point(pos, vel, ip[0]), load_point(pos, vel, ip[1]), load_point(pos, vel, ip[2]),
-                                 &n1, &d1) ||
-        !plane_from_three_points(load_point(pos, vel, ip[3]), load_point(pos, vel, ip[4]), load_point(pos, vel, ip[5]),
-                                 &n2, &d2))
+    if (!plane_from_three_points(pts.at(ip + 0), pts.at(ip + 1), pts.at(ip + 2), &n1, &d1) ||
+        !plane_from_three_points(pts.at(ip + 3), pts.at(ip + 4), pts.at(ip + 5), &n2, &d2))
       return false;
   } else if (R.instant_axis_kind == OKX_IA_PLANE_AND_STRUT) {
-    const DVec ball = load_point(pos, vel, ip[2]), top = load_point(pos, vel, ip[3]);
-    if (!plane_from_three_points(load_point(pos, vel, ip[0]), load_point(pos, vel, ip[1]), ball, &n1, &d1)) return false;
+    const DVec ball = pts.at(ip + 2), top = pts.at(ip + 3);
+    if (!plane_from_three_points(pts.at(ip + 0), pts.at(ip + 1), ball, &n1, &d1)) return false;
     const DVec strut = dsub(top, ball);
     n2 = dunit(strut, dsqrt(ddot(strut, strut)));
     d2 = -ddot(n2, top);
@@ -121,13 +169,13 @@ __device__ __forceinline__ bool line_at_coordinate(DVec point, DVec dir, int axi
 }
 
 // The catalog's metrics of one state as duals (value, derivative along `vel`).
-__device__ __forceinline__ void corner_metrics(const okx_corner_roles& R, const double* pos, const double* vel,
-                                               Dual out[OKX_METRIC_COUNT]) {
+template <class Points>
+__device__ __forceinline__ void corner_metrics(const okx_corner_roles& R, const Points& pts, Dual out[OKX_METRIC_COUNT]) {
   const double kDeg = 57.29577951308232;  // 180 / pi (numpy rad2deg)
   const double side = R.side_sign;
-  const DVec wc = load_point(pos, vel, R.wheel_center), cp = load_point(pos, vel, R.contact_patch);
-  const DVec axle = dsub(load_point(pos, vel, R.axle_outboard), load_point(pos, vel, R.axle_inboard));
-  const DVec lower = load_point(pos, vel, R.steer_lower), upper = load_point(pos, vel, R.steer_upper);
+  const DVec wc = pts.at(SLOT_WHEEL_CENTER), cp = pts.at(SLOT_CONTACT_PATCH);
+  const DVec axle = dsub(pts.at(SLOT_AXLE_OUTBOARD), pts.at(SLOT_AXLE_INBOARD));
+  const DVec lower = pts.at(SLOT_STEER_LOWER), upper = pts.at(SLOT_STEER_UPPER);
   const DVec steer = dsub(upper, lower);
   // angles.py:22-50: wheel_up = (axle x X) * -side = -side * (0, axle_z, -axle_y); front-view angle from Z
   const Dual up_y = (-side) * axle.z, up_z = side * axle.y;
@@ -149,7 +197,7 @@ __device__ __forceinline__ void corner_metrics(const okx_corner_roles& R, const 
 
   // travel.py:48-62
   if (R.damper_top >= 0 && R.damper_bottom >= 0) {
-    const DVec strut = dsub(load_point(pos, vel, R.damper_top), load_point(pos, vel, R.damper_bottom));
+    const DVec strut = dsub(pts.at(SLOT_DAMPER_TOP), pts.at(SLOT_DAMPER_BOTTOM));
     out[OKX_METRIC_DAMPER_LENGTH] = dsqrt(ddot(strut, strut));
   } else {
     out[OKX_METRIC_DAMPER_LENGTH] = dnan();
@@ -159,7 +207,7 @@ __device__ __forceinline__ void corner_metrics(const okx_corner_roles& R, const 
   for (int k = OKX_METRIC_SVIC_X; k <= OKX_METRIC_FVSA_LENGTH; ++k) out[k] = dnan();
   for (int k = OKX_METRIC_SVSA_ANGLE; k <= OKX_METRIC_ANTI_SQUAT; ++k) out[k] = dnan();
   DVec ap, ad, svic, fvic;
-  if (!instant_axis(R, pos, vel, &ap, &ad)) return;
+  if (!instant_axis(R, pts, &ap, &ad)) return;
   if (line_at_coordinate(ap, ad, 0, wc.x, &fvic)) {  // double_wishbone.py:405-430
     out[OKX_METRIC_FVIC_Y] = fvic.y;
     out[OKX_METRIC_FVIC_Z] = fvic.z;
@@ -205,17 +253,148 @@ __global__ void __launch_bounds__(256) okx_corner_metrics_kernel(MetricsArgs a) 
   if (b >= a.n_states) return;
   const double* pos = a.pos + b * 3 * a.n_out;
   Dual m[OKX_METRIC_COUNT];
-  corner_metrics(a.roles, pos, nullptr, m);
+  corner_metrics(a.roles, RecordPoints{a.roles, pos, nullptr}, m);
   double* out = a.metrics + b * OKX_METRIC_COUNT;
 #pragma unroll
   for (int k = 0; k < OKX_METRIC_COUNT; ++k) out[k] = m[k].v;
   if (a.tan && a.dmetrics)
     for (int t = 0; t < a.n_targets; ++t) {
-      corner_metrics(a.roles, pos, a.tan + (b * a.n_targets + t) * 3 * a.n_out, m);
+      corner_metrics(a.roles, RecordPoints{a.roles, pos, a.tan + (b * a.n_targets + t) * 3 * a.n_out}, m);
       double* dout = a.dmetrics + (b * a.n_targets + t) * OKX_METRIC_COUNT;
 #pragma unroll
       for (int k = 0; k < OKX_METRIC_COUNT; ++k) dout[k] = m[k].d;
     }
+}
+
+// ---- the same metrics, records staged through LDS (the forms okx_corner_metrics_batch launches for corners: records of
+// up to 42 points) ----
+// One thread per state reads its own 360-byte record at a 360-byte stride: every load instruction of the kernel above
+// touches 64 different lines and a workgroup's records (92 KB) do not stay in the L1 (29 - 45 % of HBM,
+// profiles/r04/EXPERIMENTS.md section 9).  Here a wavefront takes a TILE of 64 consecutive states: their records are one
+// contiguous block, copied into LDS with coalesced loads (row stride odd in doubles: the per-state reads that follow are
+// conflict-free).  Every lane gathers its state's fourteen role points into registers, which frees the buffer: the
+// tangent rows of one target at a time ([B][T][n_out][3]: 64 segments of one record each) go through the same 23 KB,
+// and so do the 19 results per state on their way out (one contiguous block per tile).  Same arithmetic, same bits.
+constexpr int kTileStates = 64;
+
+// e / d for e < 2^16 by one multiply-high (inv = 2^32 / d + 1, exact in that range)
+__device__ __forceinline__ uint32_t tile_div(uint32_t e, uint32_t inv) { return __umulhi(e, inv); }
+
+// `n` doubles at `src` (rows of `rec` doubles, back to back) -> dst[row * stride + col]
+__device__ __forceinline__ void stage_contiguous(double* dst, uint32_t stride, const double* __restrict__ src, uint32_t n,
+                                                 uint32_t rec, uint32_t rec_inv, int lane) {
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const double2* __restrict__ s2 = reinterpret_cast<const double2*>(src);
+    const uint32_t n2 = n >> 1;
+    constexpr int kBatch = 6;  // loads in flight per lane and batch (6 KB per wavefront)
+    for (uint32_t i0 = 0; i0 < n2; i0 += kTileStates * kBatch) {
+      double2 v[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const uint32_t i = i0 + kTileStates * u + lane;
+        if (i < n2) v[u] = s2[i];
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const uint32_t i = i0 + kTileStates * u + lane;
+        if (i < n2) {
+          const uint32_t e = 2 * i, q = tile_div(e, rec_inv), c = e - q * rec;
+          dst[q * stride + c] = v[u].x;
+          const bool wrap = c + 1 == rec;
+          dst[(wrap ? q + 1 : q) * stride + (wrap ? 0 : c + 1)] = v[u].y;
+        }
+      }
+    }
+    if ((n & 1) && lane == 0) {
+      const uint32_t e = n - 1, q = tile_div(e, rec_inv);
+      dst[q * stride + (e - q * rec)] = src[e];
+    }
+  } else {
+    for (uint32_t e = lane; e < n; e += kTileStates) {
+      const uint32_t q = tile_div(e, rec_inv);
+      dst[q * stride + (e - q * rec)] = src[e];
+    }
+  }
+}
+
+// a tile's results, staged as [64][19], to their contiguous block in HBM
+__device__ __forceinline__ void store_tile_results(double* __restrict__ dst, const double* stage, uint32_t n, int lane) {
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    for (uint32_t i = lane; i < n / 2; i += kTileStates) reinterpret_cast<double2*>(dst)[i] = reinterpret_cast<const double2*>(stage)[i];
+    if ((n & 1) && lane == 0) dst[n - 1] = stage[n - 1];
+  } else {
+    for (uint32_t e = lane; e < n; e += kTileStates) dst[e] = stage[e];
+  }
+}
+
+struct TileArgs {
+  uint32_t rec, rec_inv, stride;  // doubles per record, 2^32 / rec + 1, LDS row stride (odd)
+};
+
+// One tile per workgroup.  Values alone: 100 registers, the LDS buffer bounds the occupancy at seven wavefronts per CU.
+// With derivative columns (1 + T evaluations per state, the dual ones at ~270 registers): one wavefront per SIMD.
+// (Measured and dropped, profiles/r04/EXPERIMENTS.md section 9: the dual kernel held to 256 registers for two
+//  wavefronts per SIMD - 44 B of scratch, slower; persistent wavefronts prefetching the next phase's rows into
+//  registers - 160 B of scratch, slower.)
+template <bool TAN>
+__global__ void __launch_bounds__(kTileStates) okx_corner_metrics_tiled(MetricsArgs a, TileArgs ta) {
+  extern __shared__ double okx_tile_lds[];  // [64][max(stride, 19)]: records, then tangent rows of one target / results
+  double* const buf = okx_tile_lds;
+  const int lane = threadIdx.x;
+  const long long b0 = (long long)blockIdx.x * kTileStates;
+  const long long left = a.n_states - b0;
+  const uint32_t rows = left < kTileStates ? (uint32_t)left : kTileStates;
+  const uint32_t rec = ta.rec, stride = ta.stride;
+  // (a ragged last tile: the lanes beyond it work on the tile's last record and store nothing)
+  const uint32_t my_row = (lane < (int)rows ? lane : (int)rows - 1) * stride;
+  stage_contiguous(buf, stride, a.pos + b0 * rec, rows * rec, rec, ta.rec_inv, lane);
+  __syncthreads();
+  GatheredPoints pts{a.roles};
+  pts.gather(buf + my_row);
+  pts.vel = nullptr;
+  Dual m[OKX_METRIC_COUNT];
+  corner_metrics(a.roles, pts, m);
+  __syncthreads();  // (every lane has gathered its points: the buffer is free)
+#pragma unroll
+  for (int k = 0; k < OKX_METRIC_COUNT; ++k) buf[lane * OKX_METRIC_COUNT + k] = m[k].v;
+  __syncthreads();
+  store_tile_results(a.metrics + b0 * OKX_METRIC_COUNT, buf, rows * OKX_METRIC_COUNT, lane);
+  if (TAN) {
+    const int T = a.n_targets;
+    for (int t = 0; t < T; ++t) {
+      // tangent rows of target t: state q's row starts at ((b0 + q) T + t) rec
+      const double* __restrict__ src = a.tan + (b0 * T + t) * rec;
+      const uint32_t n = rows * rec, hop = (uint32_t)(T - 1) * rec;
+      constexpr int kBatch = 8;
+      for (uint32_t e0 = 0; e0 < n; e0 += kTileStates * kBatch) {
+        double v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const uint32_t e = e0 + kTileStates * u + lane;
+          if (e < n) v[u] = src[e + tile_div(e, ta.rec_inv) * hop];
+        }
+        if (e0 == 0) __syncthreads();  // (the results staged in the buffer have been read; the loads above are in flight)
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const uint32_t e = e0 + kTileStates * u + lane;
+          if (e < n) {
+            const uint32_t q = tile_div(e, ta.rec_inv);
+            buf[q * stride + (e - q * rec)] = v[u];
+          }
+        }
+      }
+      __syncthreads();
+      pts.vel = buf + my_row;
+      corner_metrics(a.roles, pts, m);
+      __syncthreads();  // (every lane has read its tangent row)
+#pragma unroll
+      for (int k = 0; k < OKX_METRIC_COUNT; ++k) buf[lane * OKX_METRIC_COUNT + k] = m[k].d;
+      __syncthreads();
+      double* __restrict__ dst = a.dmetrics + (b0 * T + t) * OKX_METRIC_COUNT;
+      const uint32_t no = rows * OKX_METRIC_COUNT, ohop = (uint32_t)(T - 1) * OKX_METRIC_COUNT;
+      for (uint32_t e = lane; e < no; e += kTileStates) dst[e + (e / OKX_METRIC_COUNT) * ohop] = buf[e];
+    }
+  }
 }
 
 struct AxleMetricsArgs {
@@ -243,7 +422,7 @@ __global__ void __launch_bounds__(256) okx_axle_metrics_kernel(AxleMetricsArgs a
     contact_dz[s] = cp[2] - R.design_contact_patch_z;
     DVec ap, ad, fvic;
     const DVec wcd = load_point(pos, nullptr, R.wheel_center);
-    if (instant_axis(R, pos, nullptr, &ap, &ad) && line_at_coordinate(ap, ad, 0, wcd.x, &fvic)) {
+    if (instant_axis(R, RecordPoints{R, pos, nullptr}, &ap, &ad) && line_at_coordinate(ap, ad, 0, wcd.x, &fvic)) {
       line[s][0] = cp[1];
       line[s][1] = cp[2];
       line[s][2] = fvic.y.v - cp[1];

@@ -245,3 +245,40 @@ def test_bad_roles_are_rejected(golden):
     pos = torch.rand((4, 15, 3), dtype=torch.float64, device="cuda:0")
     values = corner_state_metrics(make_roles(**base), pos).values.cpu().numpy()
     assert np.isfinite(values[:, :8]).all() and np.isnan(values[:, 8:]).all()
+
+
+def test_tiled_kernel_gives_the_bits_of_the_one_thread_per_state_kernel(golden):
+    """
+    okx_corner_metrics_batch stages records of up to 21 points through LDS, 64 states per wavefront; longer records run
+    one thread per state.  Same arithmetic: the same states padded to 22-point records must give the same bits - values,
+    derivative columns, NaN pattern - for ragged batch sizes, one state, and bases that are not 16-byte aligned.
+    """
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.input import load_geometry
+    from open_kinematics_amd.metrics import corner_roles, corner_state_metrics
+    from open_kinematics_amd.workloads import bump_sweep_problem, geometry_path
+
+    program, targets = bump_sweep_problem(1000)
+    roles = corner_roles(load_geometry(geometry_path("geometry.yaml")), program)
+    dp = DeviceProgram(program, "cuda:0")
+    pos = dp.solve(torch.as_tensor(targets, device="cuda:0"), chain_len=-1).positions
+    tan, _ = dp.tangents(pos)
+    n_out, T = pos.shape[1], tan.shape[1]
+    assert 3 * n_out <= 63  # the tiled path
+    wide = torch.zeros((pos.shape[0], 22, 3), dtype=torch.float64, device="cuda:0")
+    wide[:, :n_out] = pos
+    wide_tan = torch.zeros((pos.shape[0], T, 22, 3), dtype=torch.float64, device="cuda:0")
+    wide_tan[:, :, :n_out] = tan
+    ref = corner_state_metrics(roles, wide, wide_tan)
+    ref_v, ref_d = ref.values.cpu().numpy(), ref.derivatives.cpu().numpy()
+    assert np.isfinite(ref_v[:, :8]).all() and np.isfinite(ref_d[:, :, :8]).all()
+
+    def same(a, b):
+        return np.array_equal(a.view(np.int64), b.view(np.int64))
+
+    for lo, hi in ((0, 1000), (0, 1), (0, 63), (0, 64), (0, 65), (1, 130), (7, 8), (333, 1000)):
+        got = corner_state_metrics(roles, pos[lo:hi], tan[lo:hi])  # (an odd `lo`: a base that is 8-byte aligned only)
+        assert same(got.values.cpu().numpy(), ref_v[lo:hi]), (lo, hi)
+        assert same(got.derivatives.cpu().numpy(), ref_d[lo:hi]), (lo, hi)
+        alone = corner_state_metrics(roles, pos[lo:hi], None)
+        assert alone.derivatives is None and same(alone.values.cpu().numpy(), ref_v[lo:hi]), (lo, hi)
