@@ -1281,8 +1281,11 @@ int32_t okx_expand_positions_batch(okx_program* p, int64_t n_problems, int64_t s
   a.out_pos = d_out_pos;
   a.n_problems = n_problems;
   a.steps_per_geometry = steps_per_geometry > 0 ? steps_per_geometry : n_problems;
-  const long long blocks = (n_problems + 255) / 256;
-  hipLaunchKernelGGL(okx::okx_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+  const long long blocks = (n_problems + okx::kExpandThreads - 1) / okx::kExpandThreads;
+  if (blocks > 0x7fffffffll) return fail(OKX_ERR_INVALID, "too many problems for one launch");
+  // derived positions [3 n_derived][64] and the point -> source table
+  const size_t expand_lds = sizeof(double) * 3 * p->host.n_derived * okx::kExpandThreads + sizeof(int) * p->host.n_points;
+  hipLaunchKernelGGL(okx::okx_expand_kernel, dim3((unsigned)blocks), dim3(okx::kExpandThreads), expand_lds, (hipStream_t)stream,
                      (const okx::DevProgram*)p->dev, a);
   HIP_TRY(hipGetLastError());
   return OKX_OK;

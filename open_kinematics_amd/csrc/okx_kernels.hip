@@ -358,16 +358,18 @@ __device__ __forceinline__ void init_slice(const DevProgram* P, const Lds& S, in
 // ------------------------------------------------------------------------------------
 
 // Position of one derived op (reference points/derived/definitions.py); uniform over lanes.
-__device__ __forceinline__ V3 dop_position(int type, const int* pts, double c, const double* pos,
-                                           V3* u_out, double* nrm_out, V3* a_out,
-                                           double* vn_out, double* ga_out) {
+// `at(pt)`: the current position of point pt
+template <class At>
+__device__ __forceinline__ V3 dop_position_at(int type, const int* pts, double c, At at,
+                                              V3* u_out, double* nrm_out, V3* a_out,
+                                              double* vn_out, double* ga_out) {
   if (type == OKX_DOP_MIDPOINT) {  // definitions.py:76-89
-    V3 a = ld3(pos + 3 * pts[0]), b = ld3(pos + 3 * pts[1]);
+    V3 a = at(pts[0]), b = at(pts[1]);
     return {a.x + (b.x - a.x) / 2, a.y + (b.y - a.y) / 2, a.z + (b.z - a.z) / 2};
   }
   if (type == OKX_DOP_ALONG) {  // definitions.py:24-33, :92-155
-    V3 base = ld3(pos + 3 * pts[0]);
-    V3 v = sub(ld3(pos + 3 * pts[1]), ld3(pos + 3 * pts[2]));
+    V3 base = at(pts[0]);
+    V3 v = sub(at(pts[1]), at(pts[2]));
     double nrm, inrm;
     fast_sqrt_rsqrt(v.x * v.x + v.y * v.y + v.z * v.z, &nrm, &inrm);
     V3 u = {v.x * inrm, v.y * inrm, v.z * inrm};
@@ -376,8 +378,8 @@ __device__ __forceinline__ V3 dop_position(int type, const int* pts, double c, c
     return {base.x + u.x * c, base.y + u.y * c, base.z + u.z * c};
   }
   // OKX_DOP_CONTACT_PATCH: definitions.py:36-73, :158-180
-  V3 wc = ld3(pos + 3 * pts[0]);
-  V3 v = sub(ld3(pos + 3 * pts[2]), ld3(pos + 3 * pts[1]));
+  V3 wc = at(pts[0]);
+  V3 v = sub(at(pts[2]), at(pts[1]));
   double vn, ivn;
   fast_sqrt_rsqrt(v.x * v.x + v.y * v.y + v.z * v.z, &vn, &ivn);
   V3 a = {v.x * ivn, v.y * ivn, v.z * ivn};
@@ -392,6 +394,11 @@ __device__ __forceinline__ V3 dop_position(int type, const int* pts, double c, c
   *vn_out = ivn;
   *ga_out = ga;
   return {wc.x + wu.x * c, wc.y + wu.y * c, wc.z + wu.z * c};
+}
+__device__ __forceinline__ V3 dop_position(int type, const int* pts, double c, const double* pos,
+                                           V3* u_out, double* nrm_out, V3* a_out,
+                                           double* vn_out, double* ga_out) {
+  return dop_position_at(type, pts, c, [pos](int pt) { return ld3(pos + 3 * pt); }, u_out, nrm_out, a_out, vn_out, ga_out);
 }
 
 // Row r of the local 3x3 block d(out)/d(input s) of a derived op (inrm, ivn: INVERSE norms).
@@ -1397,7 +1404,11 @@ okx_tangent_kernel(const DevProgram* __restrict__ P, TangentArgs args) {
 
 // Full output positions from free-point coordinates: fixed points from the (per-geometry) design table, derived
 // points re-evaluated in program order.  One thread per problem — the receiving side of the multi-GPU exchange,
-// which ships the 3 n_free free coordinates of a solve instead of its 3 n_out output coordinates.
+// which ships the 3 n_free free coordinates of a solve instead of its 3 n_out output coordinates.  The interpreter
+// form (programs without a generated okx_quad_expand: composed axles).  A point is read where it is used - a fixed one
+// from the table (wave-uniform for the program's own geometry), a free one from the thread's input row, a derived one
+// from LDS ([component][thread]: conflict-free) - so that no thread carries a private table of every position
+// (round 3's form: 2.3 KB of scratch per thread, 0.9 TB/s on axle states).
 struct ExpandArgs {
   const double* free;      // [B][n_free][3]
   const double* geom_pos;  // [G][P][3] or null (program's own geometry)
@@ -1405,35 +1416,47 @@ struct ExpandArgs {
   long long n_problems, steps_per_geometry;
 };
 
-__global__ void __launch_bounds__(256) okx_expand_kernel(const DevProgram* __restrict__ P, ExpandArgs a) {
-  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.n_problems) return;
-  double pos[3 * kMaxPoints];
-  const int np = P->n_points;
+constexpr int kExpandThreads = 64;
+
+__global__ void __launch_bounds__(kExpandThreads) okx_expand_kernel(const DevProgram* __restrict__ P, ExpandArgs a) {
+  extern __shared__ double okx_expand_lds[];  // [3 n_derived][64] derived positions, then the point -> source table
+  const int lane = threadIdx.x;
+  const int np = P->n_points, nd = P->n_derived;
+  double* const dv = okx_expand_lds;
+  int* const source = reinterpret_cast<int*>(okx_expand_lds + 3 * nd * kExpandThreads);  // -1 fixed, k free point k, 1000 + e derived op e
+  for (int p = lane; p < np; p += kExpandThreads) source[p] = -1;
+  __syncthreads();
+  for (int k = lane; k < P->n_free; k += kExpandThreads) source[P->free_point[k]] = k;
+  for (int e = lane; e < nd; e += kExpandThreads) source[P->dop_out[e]] = 1000 + e;
+  __syncthreads();
+  long long b = (long long)blockIdx.x * kExpandThreads + lane;
+  const bool valid = b < a.n_problems;
+  if (!valid) b = a.n_problems - 1;
   const double* base = a.geom_pos ? a.geom_pos + (b / a.steps_per_geometry) * 3 * np : &P->design_pos[0][0];
-  for (int e = 0; e < 3 * np; ++e) pos[e] = base[e];
   const double* x = a.free + b * 3 * P->n_free;
-  for (int k = 0; k < P->n_free; ++k) {
-    const int pt = P->free_point[k];
-    pos[3 * pt] = x[3 * k];
-    pos[3 * pt + 1] = x[3 * k + 1];
-    pos[3 * pt + 2] = x[3 * k + 2];
-  }
-  for (int e = 0; e < P->n_derived; ++e) {
+  auto at = [&](int pt) -> V3 {
+    const int s = source[pt];  // (wave-uniform)
+    if (s < 0) return ld3(base + 3 * pt);
+    if (s < 1000) return ld3(x + 3 * s);
+    const double* d = dv + 3 * (s - 1000) * kExpandThreads + lane;
+    return {d[0], d[kExpandThreads], d[2 * kExpandThreads]};
+  };
+  for (int e = 0; e < nd; ++e) {
     V3 u, av;
     double nrm, vn, ga;
-    const V3 out = dop_position(P->dop_type[e], P->dop_pts[e], P->dop_param[e], pos, &u, &nrm, &av, &vn, &ga);
-    const int pt = P->dop_out[e];
-    pos[3 * pt] = out.x;
-    pos[3 * pt + 1] = out.y;
-    pos[3 * pt + 2] = out.z;
+    const V3 out = dop_position_at(P->dop_type[e], P->dop_pts[e], P->dop_param[e], at, &u, &nrm, &av, &vn, &ga);
+    double* d = dv + 3 * e * kExpandThreads + lane;
+    d[0] = out.x;
+    d[kExpandThreads] = out.y;
+    d[2 * kExpandThreads] = out.z;
   }
+  if (!valid) return;
   double* o = a.out_pos + b * 3 * P->n_out;
   for (int k = 0; k < P->n_out; ++k) {
-    const int pt = P->out_point[k];
-    o[3 * k] = pos[3 * pt];
-    o[3 * k + 1] = pos[3 * pt + 1];
-    o[3 * k + 2] = pos[3 * pt + 2];
+    const V3 v = at(P->out_point[k]);
+    o[3 * k] = v.x;
+    o[3 * k + 1] = v.y;
+    o[3 * k + 2] = v.z;
   }
 }
 
