@@ -782,6 +782,33 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
     `graph_steps` (one rank, no exchange; the current stream must not be the default stream): the K timed steps are captured
     ahead of the timed region into ONE HIP graph of K kernel nodes and the timed region launches that graph - the same K
     kernels, submitted in one call, so that 0.3 ms of GPU work are not at the mercy of the host's launch loop."""
+    # The graph is captured FIRST: capture and instantiation are host work during which the GPU idles (milliseconds) - after
+    # the preheat they would hand the timed region a GPU that is leaving idle again (kernel_ms 17.2 instead of 16.1 us).
+    graph = None
+    timed_region.graph_note = None
+    if graph_steps and world == 1 and not per_launch_events:
+        step(0, None, None)  # (whatever a first launch sets up - first-step tables, plans - happens outside the capture)
+        drain()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=torch.cuda.current_stream(device)):
+                for k in range(steps):
+                    step(k, None, None)
+            graph.replay()  # (the first launch of a graph uploads it: untimed)
+            drain()
+        except Exception as exc:  # a runtime that refuses the capture: the K steps are launched one by one, and the line says so
+            graph = None
+            timed_region.graph_note = f"graph capture failed ({type(exc).__name__}: {exc}); stream launches"
+            torch.cuda.synchronize(device)
+    timed_region.graph = graph is not None
+    n_pairs = steps if per_launch_events else 1
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
+    # torch creates the HIP event at its first record(), and the process's first timing event initialises the runtime's
+    # timestamp machinery (~45 us, measured): both happen here, ahead of the preheat, not inside the K timed steps and not
+    # between the warm-up and them
+    for ev in starts + ends:
+        ev.record()
     preheat_steps = 0
     if preheat_ms > 0.0:
         torch.cuda.synchronize(device)
@@ -796,34 +823,13 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
                 for _ in range(32):
                     step(preheat_steps, None, None)
                     preheat_steps += 1
-        drain()
     timed_region.preheat_steps = preheat_steps
     for k in range(warmup):
         step(k, None, None)
+    if graph is not None:
+        graph.replay()  # (untimed: the launch that precedes the timed one is of the same kind - a graph launch after
+        #                  thousands of stream launches took 50 - 80 us to reach the GPU, 3 us per step at K = 20)
     drain()
-    graph = None
-    timed_region.graph_note = None
-    if graph_steps and world == 1 and not per_launch_events:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=torch.cuda.current_stream(device)):
-                for k in range(steps):
-                    step(k, None, None)
-            graph.replay()  # (the first launch of a graph uploads it: untimed, part of the warm-up)
-            drain()
-        except Exception as exc:  # a runtime that refuses the capture: the K steps are launched one by one, and the line says so
-            graph = None
-            timed_region.graph_note = f"graph capture failed ({type(exc).__name__}: {exc}); stream launches"
-            torch.cuda.synchronize(device)
-    timed_region.graph = graph is not None
-    n_pairs = steps if per_launch_events else 1
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(n_pairs)]
-    # torch creates the HIP event at its first record(), and the process's first timing event initialises the runtime's
-    # timestamp machinery (~45 us, measured): both happen here, with the warm-up, not inside the K timed steps
-    for ev in starts + ends:
-        ev.record()
-    torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
