@@ -623,7 +623,49 @@ def measure_downstream(dp, suspension_yaml: str, positions, device, reps: int = 
 
     t_tan, (tangents, _) = timed(lambda: dp.tangents(positions))
     t_met, _ = timed(lambda: corner_state_metrics(roles, positions, tangents))
-    return {"states": n,
+
+    # ... and at C5 scale (a million states: 377 MB of records, past the Infinity Cache), HIP-event time of each kernel and its
+    # algorithmic GB/s: the kernels beside the solve are the streaming ones (tools/stream_rates.py, profiles/r04/EXPERIMENTS.md 9)
+    def streaming(n_big: int = 1 << 20) -> dict:
+        reps_of = -(-n_big // n)
+        big = positions.repeat(reps_of, 1, 1)[:n_big].contiguous()
+        free = big[:, dp.free_out_index].contiguous()
+        out = torch.empty_like(big)
+
+        def ev(fn, k=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(k):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(device)
+            return e0.elapsed_time(e1) / k
+
+        T, n_out, n_free = program.n_targets, program.n_out, program.n_free
+        rows = {}
+
+        def row(name, ms, bytes_per_state):
+            rows[name] = {"ms": ms, "states_per_s": n_big / ms * 1e3, "bytes_per_state": bytes_per_state,
+                          "algorithmic_gbs": bytes_per_state * n_big / ms / 1e6, "hbm_frac": bytes_per_state * n_big / ms / 1e6 / HBM_PEAK_GBS}
+
+        row("expand_free_to_records", ev(lambda: dp.expand(free, out=out)), 24 * n_free + 24 * n_out)
+        row("copy_of_the_records_reference", ev(lambda: out.copy_(big)), 48 * n_out)
+        tan_big, _ = dp.tangents(big)
+        row("tangents", ev(lambda: dp.tangents(big)), 24 * n_out * (1 + T) + 24)
+        row("corner_metrics", ev(lambda: corner_state_metrics(roles, big, None)), 24 * n_out + 152)
+        row("corner_metrics_with_derivatives", ev(lambda: corner_state_metrics(roles, big, tan_big)), 24 * n_out * (1 + T) + 152 * (1 + T))
+        return {"states": n_big, "rows": rows,
+                "note": "HIP events around 10 launches each, the sweep's states tiled to a million; bound: HBM for expand / corner_metrics "
+                        "(a torch copy of the records is the practical ceiling), fp64 issue for tangents and the derivative columns"}
+
+    try:
+        c5_scale = streaming()
+    except Exception as exc:  # (an extra leg must not take the headline down with it)
+        c5_scale = {"error": f"{type(exc).__name__}: {exc}"}
+    return {"states": n, "c5_scale": c5_scale,
             "tangents": {"value": n / t_tan, "unit": "states/s", "ms": t_tan * 1e3,
                          "bytes_per_state": 24 * program.n_out * (1 + program.n_targets) + 24},
             "corner_metrics_with_derivatives": {"value": n / t_met, "unit": "states/s", "ms": t_met * 1e3,
