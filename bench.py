@@ -885,6 +885,10 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
             step(k, starts[k] if per_launch_events else None, ends[k] if per_launch_events else None)
     if not per_launch_events:
         ends[0].record()
+        # (the host polls the end event before it synchronises: a poll sees the end of the GPU's work within microseconds, an
+        #  interrupt-driven wait wakes the host later; the synchronize below then finds an idle GPU - tools/region_latency.py)
+        while not ends[0].query():
+            pass
     drain()
     torch.cuda.synchronize(device)
     if world > 1:
