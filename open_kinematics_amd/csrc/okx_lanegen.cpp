@@ -1094,7 +1094,7 @@ DEV double unpark(int lo, int hi) {
 
 }  // namespace
 
-int lane_variant_count() { return 12; }
+int lane_variant_count() { return 24; }
 
 namespace {
 // Emission variants: the same arithmetic, differing only in hints to the compiler (opaque uses after each row, a
@@ -1106,9 +1106,11 @@ const struct { bool pin, launder, late_diag; int col_fence; } kVariants[12] = {
     {false, false, false, 2}, {false, false, true, 1}, {false, true, true, 3}, {true, false, true, 6}};
 }  // namespace
 
+// Variants 12 .. 23 are variants 0 .. 11 with a small program's state and factor back in LDS (lane_generate): where a value is
+// kept does not enter the arithmetic.
 bool lane_variants_same_arithmetic(int a, int b) {
   const int n = lane_variant_count();
-  return a >= 0 && a < n && b >= 0 && b < n && kVariants[a].late_diag == kVariants[b].late_diag;
+  return a >= 0 && a < n && b >= 0 && b < n && kVariants[a % 12].late_diag == kVariants[b % 12].late_diag;
 }
 
 bool lane_chain_is_flat(int n_vars) {
@@ -1122,7 +1124,16 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // order, keeps the first one whose independent-solve kernels do not spill - or, after a full search, the one that spills
   // least, with single kernels taken from other variants of the same arithmetic.
   if (variant < 0 || variant >= lane_variant_count()) variant = 0;
-  const auto& V = kVariants[variant];
+  const auto& V = kVariants[variant % 12];
+  // Programs of up to 15 variables (the MacPherson corner) have registers to spare: variants 0 .. 11 keep the accepted
+  // point, the step in hand and the whole factor of their independent-solve body in registers, variants 12 .. 23 are the
+  // same hints with the LDS layout every larger program has (a 15-variable program with one row of each class spills
+  // 272 B in registers and nothing in LDS).  For larger programs the second dozen would repeat the first: not generated.
+  const bool small_in_registers = 3 * P.n_free <= 15 && variant < 12;
+  if (3 * P.n_free > 15 && variant >= 12) {
+    *why = "variant " + std::to_string(variant) + " is variant " + std::to_string(variant - 12) + " for this program";
+    return false;
+  }
   if (P.n_free > kLaneMaxFree) {
     *why = "more than " + std::to_string(kLaneMaxFree) + " free points: the lower triangle of J^T J does not fit one lane's registers";
     return false;
@@ -1192,8 +1203,11 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // Measured on the double wishbone (scratch bytes of okx_lane_solve_u): the spare slots given to the factor's rows
   // 104 B, to the rows' gradients 432 B, hand-parked AGPR rows on top of either 250 - 1000 B (the allocator needs the
   // accumulation registers for its own spilling).  So: the factor's first rows in LDS, nothing parked by hand.
-  int cold_l_slots = cold_j_slots;
+  // (a program of up to 15 variables - the MacPherson corner - holds its whole factor in registers: 369 of 512 without a
+  //  parked row; C4 cold 0.105 -> 0.097 ms: what a parked row costs a lone wavefront is its round trip, not its instruction)
+  int cold_l_slots = small_in_registers ? 0 : cold_j_slots;
   cold_j_slots -= cold_l_slots;
+  if (small_in_registers) cold_j_slots = 0;  // (... nor a gradient)
   evc.j_lds_base = kColdStateSlots;
   evc.j_lds_slots = cold_j_slots;
   evc.l_lds_base = kColdStateSlots + cold_j_slots;
@@ -1347,9 +1361,15 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     const PassSrc& pass_cold = gb ? pass_g : pass_cold_;
     int n_slots = 0;
     auto slot_ref = [&](const std::string& name) { return "double& " + name + " = lds[" + std::to_string(64 * n_slots++) + " + lane];"; };
+    // A program of up to 15 variables (the MacPherson corner) keeps the accepted point and the step in hand in registers
+    // too: 30 LDS slots less, and - what counts for a lone wavefront - their round trips out of the passes.  7 % more
+    // instructions (a value parked in accumulation registers costs two moves, one in LDS one access) and C4 cold
+    // 0.0973 -> 0.0889 ms; with the factor's rows out of LDS as well (below) 2.46e9 -> 2.85e9 solves/s.
+    const bool reg_state = !ch && !fl && !gb && small_in_registers;  // (the chain body, its history on top, spills 56 B with it)
     std::string state_decl;
     for (int i = 0; i < n; ++i) {
-      state_decl += "    " + slot_ref("x" + std::to_string(i)) + " " + slot_ref("dx" + std::to_string(i));
+      if (reg_state) state_decl += "    double x" + std::to_string(i) + ", dx" + std::to_string(i) + ";";
+      else state_decl += "    " + slot_ref("x" + std::to_string(i)) + " " + slot_ref("dx" + std::to_string(i));
       if (ch) state_decl += " " + slot_ref("xp" + std::to_string(i)) + " " + slot_ref("xq" + std::to_string(i));
       state_decl += "\n";
     }
