@@ -249,7 +249,18 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
   bool searched_all = true;  // every variant compiled and looked at (not cut short by `good_enough_scratch` or a failure)
   std::string best_src, best_code;
   std::vector<std::pair<int, std::string>> seen;  // (variant, code) of a search, for the per-kernel choice
-  for (int v = first; v <= last; ++v) {
+  // Search order: 0, 12, 1, 13, ... - a small program's register layout (variants 0 - 11, okx_lanegen.cpp) alternates with
+  // the LDS layout of the same hints (12 - 23), so that a program whose register form spills reaches the layout every
+  // larger program has at its second compile (variants 12 - 23 do not exist for larger programs: skipped).
+  std::vector<int> order;
+  if (first == last) order.push_back(first);
+  else
+    for (int k = 0; k < lane_variant_count() / 2; ++k) {
+      order.push_back(k);
+      order.push_back(k + lane_variant_count() / 2);
+    }
+  for (size_t at = 0; at < order.size(); ++at) {
+    const int v = order[at];
     std::string s1, c1, w1;
     if (v == 0) s1 = src0;
     else if (!lane_generate(P, &s1, &w1, v)) continue;
@@ -268,7 +279,7 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
       best_code.swap(c1);
     }
     if (best_scratch <= good_enough_scratch) {
-      searched_all = searched_all && (v == last || best_scratch == 0);
+      searched_all = searched_all && (at + 1 == order.size() || best_scratch == 0);
       break;
     }
   }

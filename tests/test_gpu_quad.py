@@ -289,14 +289,17 @@ def test_a_damaged_cache_entry_is_rebuilt(golden, tmp_path, monkeypatch):
     assert dp.kernel == "quad"
     dp.close()
     files = [f for f in os.listdir(tmp_path) if f.endswith(".okxc")]
-    assert len(files) == 2  # the quad kernel's code object and the lane kernel's
+    # the quad kernel's code object and the lane kernel's (two of them when a small program's register layout spills and the
+    # LDS layout of the same hints is compiled next: okx_jit.cpp lane_build)
+    assert 2 <= len(files) <= 3
     for name in files:      # both truncated: the headers' size / checksum no longer match
         path = tmp_path / name
         path.write_bytes(path.read_bytes()[:1000])
     dp = DeviceProgram(program, "cuda:0")
     assert dp.kernel == "quad", dp.kernel_note
     assert dp.lane_threshold > 0, dp.lane_note
-    assert all((tmp_path / name).stat().st_size > 10000 for name in files)
+    # (what the program loads is rebuilt: its quad kernel and the lane variant it remembered - a variant that was only tried is not)
+    assert sum((tmp_path / name).stat().st_size > 10000 for name in files) >= 2
     res = dp.solve(arrays["targets_abs"])
     assert np.all((res.info()["flags"] & 7) == 1)
 
