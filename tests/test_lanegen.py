@@ -98,3 +98,21 @@ def test_independent_solve_bodies_of_the_baseline_programs_do_not_spill(golden, 
     again = (C.c_int32 * 3)()
     assert lib.okx_debug_lane_scratch(host.byref(), again) == 0, _lib.last_error()
     assert list(again) == list(out)
+
+
+def test_small_programs_keep_the_independent_solve_state_in_registers(golden):
+    """Programs of up to 15 variables (the MacPherson corner) have registers to spare: the independent-solve body of emission
+    variants 0 - 11 keeps the accepted point, the step in hand and the whole factor in registers (an LDS round trip costs a
+    lone wavefront more than the two moves of a parked register: profiles/r04/EXPERIMENTS.md section 11); the chain body and
+    every larger program keep the LDS layout."""
+    _, mac = golden("c4_macpherson_grid")
+    src = _lane_source(mac.with_line_mode("pinned"))
+    cold = src[src.index("void okx_lane_body_cold(const QArgs& a)"):src.index("void okx_lane_body_coldg(const QArgs& a)")]
+    chain = src[src.index("void okx_lane_body_chain(const QArgs& a)"):]
+    assert mac.n_vars == 15
+    assert "    double x0, dx0;" in cold and "double& x0 = lds[" not in cold
+    assert "double& x0 = lds[" in chain and "double& xp0 = lds[" in chain
+    _, dw = golden("c1_dw_corner")
+    src = _lane_source(dw.with_line_mode("pinned"))
+    cold = src[src.index("void okx_lane_body_cold(const QArgs& a)"):src.index("void okx_lane_body_coldg(const QArgs& a)")]
+    assert dw.n_vars == 18 and "double& x0 = lds[" in cold and "    double x0, dx0;" not in cold
