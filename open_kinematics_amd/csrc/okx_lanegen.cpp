@@ -1224,7 +1224,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     evg.j_lds_base = kColdStateSlots;
     evg.j_lds_slots = 0;
     evg.l_lds_base = kColdStateSlots;
-    evg.l_lds_slots = g_l_slots;
+    evg.l_lds_slots = small_in_registers ? 0 : g_l_slots;  // (a small program's factor stays in registers here too)
     evg.late_diag = V.late_diag;
     if (!make_pass(evg, &pass_g)) {
       *why = evg.why;
@@ -1365,7 +1365,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     // too: 30 LDS slots less, and - what counts for a lone wavefront - their round trips out of the passes.  7 % more
     // instructions (a value parked in accumulation registers costs two moves, one in LDS one access) and C4 cold
     // 0.0973 -> 0.0889 ms; with the factor's rows out of LDS as well (below) 2.46e9 -> 2.85e9 solves/s.
-    const bool reg_state = !ch && !fl && !gb && small_in_registers;  // (the chain body, its history on top, spills 56 B with it)
+    const bool reg_state = !ch && !fl && small_in_registers;  // (the chain body, its history on top, spills 56 B with it)
     std::string state_decl;
     for (int i = 0; i < n; ++i) {
       if (reg_state) state_decl += "    double x" + std::to_string(i) + ", dx" + std::to_string(i) + ";";

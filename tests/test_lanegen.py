@@ -111,6 +111,8 @@ def test_small_programs_keep_the_independent_solve_state_in_registers(golden):
     chain = src[src.index("void okx_lane_body_chain(const QArgs& a)"):]
     assert mac.n_vars == 15
     assert "    double x0, dx0;" in cold and "double& x0 = lds[" not in cold
+    coldg = src[src.index("void okx_lane_body_coldg(const QArgs& a)"):src.index("void okx_lane_body_chain(const QArgs& a)")]
+    assert "    double x0, dx0;" in coldg and "double& x0 = lds[" not in coldg  # (per-geometry tables: the same layout)
     assert "double& x0 = lds[" in chain and "double& xp0 = lds[" in chain
     _, dw = golden("c1_dw_corner")
     src = _lane_source(dw.with_line_mode("pinned"))
