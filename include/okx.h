@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OKX_ABI_VERSION 4   /* 4: okx_rotation_role.kind / point_b (hardware metrics of composed axles), okx_program_has_cold_body, okx_program_ready.  3: okx_solve_opts.output (+ reserved); lane kernel entry points.  2: confirm_full_pass; diagnostics moved to okx_debug.h */
+#define OKX_ABI_VERSION 5   /* 5: the evaluated solve (okx_program_enable_evaluation, okx_solve_evaluated_batch, okx_evaluate_batch, okx_precompile_evaluation).  4: okx_rotation_role.kind / point_b (hardware metrics of composed axles), okx_program_has_cold_body, okx_program_ready.  3: okx_solve_opts.output (+ reserved); lane kernel entry points.  2: confirm_full_pass; diagnostics moved to okx_debug.h */
 
 /* Hard limits of one problem (one wavefront owns one problem). */
 #define OKX_MAX_VARS 126     /* n = 3 * free points (one thread per variable: one wavefront up to 63, two beyond) */
@@ -408,6 +408,51 @@ int32_t okx_axle_metrics_batch(const okx_corner_roles* left, const okx_corner_ro
                                const double* d_pos,  /* [B][n_out][3] */
                                double* d_metrics,    /* [B][OKX_AXLE_METRIC_COUNT] */
                                void* stream);
+
+/*
+ * The EVALUATED solve (SURVEY.md section 8f.1-2 as ONE launch).  Replaces solve_evaluated_sweep / evaluate_solved_sweep
+ * (core/sweep.py:217-270: solve -> compute_sweep_tangents -> compute_sweep_metrics; diagnostics excluded) for a batch:
+ * the generated solve kernels end every problem with an epilogue that, at the converged state still in registers,
+ * evaluates the Jacobian once more, factors the undamped J^T J, substitutes once per target for the solution-manifold
+ * tangent (sensitivity.py:57-143) and evaluates the corner metric catalog and its derivatives along every tangent
+ * (metrics/catalog.py, metrics/derivatives.py) - no position records are re-read, no tangent tensor is materialised
+ * unless asked for.
+ *
+ * d_eval [B][1 + T][OKX_EVAL_COLUMNS] receives, per problem,
+ *   row 0      : columns 0 .. OKX_METRIC_COUNT-1 the metric values (NaN where the reference reports None),
+ *                OKX_EVAL_MIN_PIVOT / _MAX_PIVOT / _TANGENT_FLAGS the health of the tangent solve (okx_tangent_info's
+ *                fields; the flags as a double), the rest 0;
+ *   row 1 + t  : columns 0 .. OKX_METRIC_COUNT-1 d metric / d target t, OKX_EVAL_RATE_WHEEL_CENTER_X .. _Z the wheel centre's
+ *                velocity along that tangent, OKX_EVAL_RATE_RACK_Y the rack pickup's lateral velocity (NaN: no rack) - the
+ *                driver rates the reference's deriv_<response>_wrt_<driver> columns divide by (derivatives.py:265-320).
+ * The role POINTS of `roles` are compiled into the program's evaluated kernels (okx_program_enable_evaluation: generated
+ * and compiled like the solve kernels, kept in the same cache; a miss compiles in place, 10 ... 60 s - okx_precompile_evaluation
+ * fills the cache ahead of time); its numbers (side sign, vehicle data, design references) are kernel arguments and may
+ * change from call to call through okx_program_enable_evaluation at no cost.  With geometry tables the design references
+ * (wheel travel, ride height, rack displacement) are each geometry's own design state, taken from d_geom_pos.
+ * Programs with a single-mode quad kernel (corners: up to 9 free points, every free point an output point, at least one
+ * target); okx_solve_opts.output still says what goes to d_out_pos (OKX_OUTPUT_NONE: nothing - metrics only).
+ */
+#define OKX_EVAL_COLUMNS 24
+enum {
+  OKX_EVAL_MIN_PIVOT = 19, OKX_EVAL_MAX_PIVOT = 20, OKX_EVAL_TANGENT_FLAGS = 21,                 /* row 0 */
+  OKX_EVAL_RATE_WHEEL_CENTER_X = 19, OKX_EVAL_RATE_WHEEL_CENTER_Y = 20, OKX_EVAL_RATE_WHEEL_CENTER_Z = 21,
+  OKX_EVAL_RATE_RACK_Y = 22                                                                      /* rows 1 + t */
+};
+int32_t okx_program_enable_evaluation(okx_program* prog, const okx_corner_roles* roles);
+/* bit0: the program has evaluated kernels for the roles last enabled; bit1: a lane form exists as well. */
+int32_t okx_program_evaluation(const okx_program* prog);
+const char* okx_program_evaluation_note(const okx_program* prog);
+/* okx_solve_batch with the epilogue: d_tangents [B][T][n_out][3] and d_eval may each be NULL (not both). */
+int32_t okx_solve_evaluated_batch(okx_program* prog, const okx_solve_opts* opts, int64_t n_problems,
+                                  const double* d_targets, const double* d_geom_pos, const double* d_geom_row_param,
+                                  double* d_out_pos, okx_info* d_info, double* d_tangents, double* d_eval, void* stream);
+/* The same epilogue on given solved states d_pos [B][n_out][3] (evaluate_solved_sweep, core/sweep.py:217-245). */
+int32_t okx_evaluate_batch(okx_program* prog, int64_t n_problems, int64_t steps_per_geometry, const double* d_pos,
+                           const double* d_geom_pos, const double* d_geom_row_param, double* d_tangents, double* d_eval,
+                           void* stream);
+/* Generate + compile a program's evaluated kernels for `roles` into the on-disk cache (no device needed). */
+int32_t okx_precompile_evaluation(const okx_program_desc* desc, const okx_corner_roles* roles);
 
 /*
  * Signed rotation of output points about fixed axes from their design positions, in degrees

@@ -8,7 +8,7 @@ import numpy as np
 
 from .program import ConstraintProgram
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -88,6 +88,11 @@ TANGENT_INFO_DTYPE = np.dtype([("min_pivot", "<f8"), ("max_pivot", "<f8"), ("fla
 assert TANGENT_INFO_DTYPE.itemsize == 24
 TANGENT_OK = 1
 TANGENT_RANK_DEFICIENT = 2
+
+# okx_solve_evaluated_batch / okx_evaluate_batch: d_eval [B][1 + T][EVAL_COLUMNS] (include/okx.h OKX_EVAL_*)
+EVAL_COLUMNS = 24
+EVAL_MIN_PIVOT, EVAL_MAX_PIVOT, EVAL_TANGENT_FLAGS = 19, 20, 21                      # row 0
+EVAL_RATE_WHEEL_CENTER_X, EVAL_RATE_WHEEL_CENTER_Z, EVAL_RATE_RACK_Y = 19, 21, 22    # rows 1 + t
 
 INFO_CONVERGED = 1
 INFO_RESIDUAL_EXCEEDED = 2

@@ -47,6 +47,12 @@ EXPORTS = (
     "okx_program_lane_threshold",
     "okx_program_lane_bodies",
     "okx_lane_source",
+    "okx_program_enable_evaluation",
+    "okx_program_evaluation",
+    "okx_program_evaluation_note",
+    "okx_solve_evaluated_batch",
+    "okx_evaluate_batch",
+    "okx_precompile_evaluation",
 )
 
 # include/okx_debug.h: test hooks and profiling aids, not part of the drop-in boundary
@@ -158,6 +164,18 @@ def load() -> C.CDLL:
     lib.okx_program_lane_bodies.restype = i32
     lib.okx_lane_source.argtypes = [C.POINTER(ProgramDesc), C.c_char_p, i64]
     lib.okx_lane_source.restype = i64
+    lib.okx_program_enable_evaluation.argtypes = [vp, vp]
+    lib.okx_program_enable_evaluation.restype = i32
+    lib.okx_program_evaluation.argtypes = [vp]
+    lib.okx_program_evaluation.restype = i32
+    lib.okx_program_evaluation_note.argtypes = [vp]
+    lib.okx_program_evaluation_note.restype = C.c_char_p
+    lib.okx_solve_evaluated_batch.argtypes = [vp, C.POINTER(SolveOpts), i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.okx_solve_evaluated_batch.restype = i32
+    lib.okx_evaluate_batch.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp]
+    lib.okx_evaluate_batch.restype = i32
+    lib.okx_precompile_evaluation.argtypes = [C.POINTER(ProgramDesc), vp]
+    lib.okx_precompile_evaluation.restype = i32
     if lib.okx_abi_version() != ABI_VERSION:
         raise RuntimeError("libokx.so ABI version mismatch")
     _lib = lib

@@ -16,8 +16,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._abi import (INFO_CONVERGED, INFO_DTYPE, INFO_FAILED, INFO_RESIDUAL_EXCEEDED, TANGENT_INFO_DTYPE, HostProgram,
-                   SolveOpts)
+from ._abi import (EVAL_COLUMNS, EVAL_MAX_PIVOT, EVAL_MIN_PIVOT, EVAL_RATE_RACK_Y, EVAL_RATE_WHEEL_CENTER_X,
+                   EVAL_TANGENT_FLAGS, INFO_CONVERGED, INFO_DTYPE, INFO_FAILED, INFO_RESIDUAL_EXCEEDED, TANGENT_INFO_DTYPE,
+                   HostProgram, SolveOpts)
 from .program import ConstraintProgram
 
 
@@ -40,6 +41,49 @@ class BatchResult:
         """Converged and within the residual tolerance (reference ``solver.py:726-747``)."""
         f = info["flags"]
         return ((f & INFO_CONVERGED) != 0) & ((f & (INFO_RESIDUAL_EXCEEDED | INFO_FAILED)) == 0)
+
+
+N_METRICS = 19  # OKX_METRIC_COUNT
+
+
+@dataclass
+class EvaluatedResult(BatchResult):
+    """
+    What ``DeviceProgram.solve_evaluated`` / ``evaluate`` return: the solve's own results plus the epilogue's
+    (``okx_solve_evaluated_batch``): ``eval [B, 1 + T, 24]`` - row 0 the metric values and the tangent solve's pivots,
+    row 1 + t the derivatives along target t and the driver rates - and, when asked for, ``tangents [B, T, n_out, 3]``.
+    The properties are views, nothing is copied.
+    """
+
+    eval: torch.Tensor | None = None
+    tangents: torch.Tensor | None = None
+
+    @property
+    def metrics(self) -> torch.Tensor:
+        """``[B, 19]`` metric values in ``metrics.METRIC_NAMES`` order (NaN where the reference reports None)."""
+        return self.eval[:, 0, :N_METRICS]
+
+    @property
+    def derivatives(self) -> torch.Tensor:
+        """``[B, T, 19]``: d metric / d target."""
+        return self.eval[:, 1:, :N_METRICS]
+
+    @property
+    def wheel_center_rates(self) -> torch.Tensor:
+        """``[B, T, 3]``: d wheel centre / d target (the ``hub_z`` driver and the ``wheel_center_x`` response)."""
+        return self.eval[:, 1:, EVAL_RATE_WHEEL_CENTER_X:EVAL_RATE_WHEEL_CENTER_X + 3]
+
+    @property
+    def rack_rates(self) -> torch.Tensor:
+        """``[B, T]``: d rack pickup y / d target (NaN without a rack)."""
+        return self.eval[:, 1:, EVAL_RATE_RACK_Y]
+
+    def tangent_info(self) -> np.ndarray:
+        """The tangent solves' health as ``_abi.TANGENT_INFO_DTYPE`` records (host)."""
+        row = self.eval[:, 0, EVAL_MIN_PIVOT:EVAL_TANGENT_FLAGS + 1].cpu().numpy()
+        out = np.zeros(row.shape[0], dtype=TANGENT_INFO_DTYPE)
+        out["min_pivot"], out["max_pivot"], out["flags"] = row[:, 0], row[:, 1], row[:, 2].astype(np.int32)
+        return out
 
 
 def _ptr(t: torch.Tensor | None) -> C.c_void_p:
@@ -269,6 +313,113 @@ class DeviceProgram:
                 _ptr(out), _ptr(info_out), C.c_void_p(stream))
         keep = (opts, targets, geom_pos, geom_row_param)  # tensors / structs the raw pointers refer to
         return args, keep, BatchResult(out if mode == 0 else None, info_out, out if mode == 1 else None)
+
+    # ---- the evaluated solve: tangents and metrics as the solve kernels' epilogue (okx.h) ----
+
+    def enable_evaluation(self, roles) -> None:
+        """
+        ``okx_program_enable_evaluation``: generate / load the program's evaluated kernels for the metric roles
+        ``roles`` (``metrics.corner_roles`` / ``make_roles``).  The role points are compiled in (a first call with new
+        role points compiles for 10 - 60 s unless ``__graft_entry__.build()`` has filled the cache); the numbers of the
+        roles are kernel arguments, a call that only changes them costs nothing.
+        """
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.okx_program_enable_evaluation(self._handle, C.byref(roles)), "okx_program_enable_evaluation")
+        self._roles = roles
+
+    @property
+    def evaluation(self) -> int:
+        """bit0: evaluated kernels are loaded, bit1: with a lane form (one lane per problem) for large batches."""
+        return int(self.lib.okx_program_evaluation(self._handle))
+
+    @property
+    def evaluation_note(self) -> str:
+        return self.lib.okx_program_evaluation_note(self._handle).decode()
+
+    def _eval_buffers(self, b: int, tangents, eval_out):
+        p = self.program
+        if eval_out is None:
+            eval_out = torch.empty((b, 1 + p.n_targets, EVAL_COLUMNS), dtype=torch.float64, device=self.device)
+        elif eval_out.shape != (b, 1 + p.n_targets, EVAL_COLUMNS) or eval_out.dtype != torch.float64 or not eval_out.is_contiguous():
+            raise ValueError(f"eval_out must be a contiguous float64 [B, 1 + T, {EVAL_COLUMNS}] tensor")
+        tan = None
+        if isinstance(tangents, torch.Tensor):
+            tan = tangents
+            if tan.shape != (b, p.n_targets, p.n_out, 3) or tan.dtype != torch.float64 or not tan.is_contiguous():
+                raise ValueError("tangents must be a contiguous float64 [B, T, n_out, 3] tensor")
+        elif tangents:
+            tan = torch.empty((b, p.n_targets, p.n_out, 3), dtype=torch.float64, device=self.device)
+        _check_buffer("eval_out", eval_out, self.device, False)
+        _check_buffer("tangents", tan, self.device, False)
+        return tan, eval_out
+
+    def _prepare_evaluated(self, targets, roles, tangents, eval_out, **kw):
+        if roles is not None:
+            self.enable_evaluation(roles)
+        if not self.evaluation:
+            raise RuntimeError("solve_evaluated needs metric roles: pass roles= or call enable_evaluation first")
+        args, keep, res = self._prepare(targets, **kw)
+        b = res.info_raw.shape[0]
+        tan, ev = self._eval_buffers(b, tangents, eval_out)
+        args = args[:-1] + (_ptr(tan), _ptr(ev), args[-1])
+        return args, keep, EvaluatedResult(res.positions, res.info_raw, res.free, ev, tan)
+
+    def solve_evaluated(self, targets, *, roles=None, tangents=False, eval_out=None, **kw) -> EvaluatedResult:
+        """
+        ``okx_solve_evaluated_batch``: ``solve`` (same keywords) whose kernels end every problem with the evaluation
+        epilogue - the reference's ``solve_evaluated_sweep`` (``core/sweep.py:248-270``) for a batch, ONE launch:
+        solution-manifold tangents at the converged state, the corner metric catalog and its derivative along every
+        target's tangent.  ``output="none"`` returns metrics and derivative columns without ever writing positions.
+        ``tangents=True`` (or a buffer) also materialises ``[B, T, n_out, 3]``.
+        """
+        args, _keep, result = self._prepare_evaluated(targets, roles, tangents, eval_out, **kw)
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_solve_evaluated_batch(*args)
+        _lib.check(rc, "okx_solve_evaluated_batch")
+        return result
+
+    def plan_evaluated(self, targets, *, roles=None, tangents=False, eval_out=None, **kw):
+        """``plan`` for ``solve_evaluated``: a zero-argument callable whose only work is the C-ABI call."""
+        args, keep, result = self._prepare_evaluated(targets, roles, tangents, eval_out, **kw)
+        fn, check = self.lib.okx_solve_evaluated_batch, _lib.check
+
+        def launch() -> EvaluatedResult:
+            rc = fn(*args)
+            if rc != 0:
+                check(rc, "okx_solve_evaluated_batch")
+            return result
+
+        launch.keep = keep
+        return launch
+
+    def evaluate(self, positions, *, roles=None, tangents=False, eval_out=None, geom_pos=None, geom_row_param=None,
+                 steps_per_geometry: int = 0) -> EvaluatedResult:
+        """
+        ``okx_evaluate_batch``: the same epilogue on GIVEN solved states ``positions [B, n_out, 3]`` - the reference's
+        ``evaluate_solved_sweep`` (``core/sweep.py:217-245``) in one launch instead of tangents -> metrics.
+        """
+        if roles is not None:
+            self.enable_evaluation(roles)
+        if not self.evaluation:
+            raise RuntimeError("evaluate needs metric roles: pass roles= or call enable_evaluation first")
+        p = self.program
+        pos = _as_f64(positions, self.device).reshape(-1, p.n_out, 3)
+        b = pos.shape[0]
+        if geom_pos is not None:
+            geom_pos = _as_f64(geom_pos, self.device)
+            geom_row_param = _as_f64(geom_row_param, self.device)
+            if geom_pos.shape[1:] != (p.n_points, 3) or geom_row_param.shape != (geom_pos.shape[0], p.n_rows, 8):
+                raise ValueError("geometry table has the wrong shape")
+            if steps_per_geometry <= 0 or geom_pos.shape[0] * steps_per_geometry != b:
+                raise ValueError("B must equal n_geometries * steps_per_geometry")
+        tan, ev = self._eval_buffers(b, tangents, eval_out)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_evaluate_batch(self._handle, b, int(steps_per_geometry), _ptr(pos), _ptr(geom_pos),
+                                             _ptr(geom_row_param), _ptr(tan), _ptr(ev), C.c_void_p(stream))
+        _lib.check(rc, "okx_evaluate_batch")
+        info = torch.zeros((0, INFO_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        return EvaluatedResult(pos, info, None, ev, tan)
 
     def solve(self, targets, **kw) -> BatchResult:
         """See ``_prepare`` for the arguments: validates, then launches ``okx_solve_batch`` once."""

@@ -84,6 +84,15 @@ struct okx_program {
   int lane_cold_scratch, lane_chain_scratch;  // private-segment bytes of the two bodies (code object metadata)
   bool lane_cold_ok, lane_chain_ok;           // bodies that auto selection may use
   char lane_note[256];
+  // evaluated modules (okx_program_enable_evaluation): the solve bodies with the tangent / metric epilogue, specialised to
+  // one set of metric role points; null until enabled
+  hipModule_t ev_mod, ev_lane_mod;
+  hipFunction_t ev_solve_u, ev_solve_g, ev_cold_u, ev_pos_u, ev_pos_g;  // quad form (single mode)
+  hipFunction_t ev_lane_u, ev_lane_g;                                   // lane form: independent solves (null: none)
+  int ev_lane_scratch;
+  okx::EvalSpec ev_spec;     // the role points compiled into them
+  okx::EvalScalars ev_cfg;   // the roles' numeric part, a kernel argument
+  char ev_note[256];         // why there are none / no lane form
 };
 
 namespace {
@@ -669,6 +678,8 @@ void okx_program_destroy(okx_program* p) {
     delete p->jit;
     p->jit = nullptr;
   }
+  if (p->ev_mod) (void)hipModuleUnload(p->ev_mod);
+  if (p->ev_lane_mod) (void)hipModuleUnload(p->ev_lane_mod);
   if (p->quad_mod) (void)hipModuleUnload(p->quad_mod);
   if (p->lane_mod) (void)hipModuleUnload(p->lane_mod);
   if (p->lane_extra_mods) {
@@ -795,12 +806,20 @@ int32_t okx_debug_lane_scratch(const okx_program_desc* desc, int32_t* out3) {
   return OKX_OK;
 }
 
-int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_problems,
-                        const double* d_targets, const double* d_geom_pos,
-                        const double* d_geom_row_param, double* d_out_pos, okx_info* d_info,
-                        void* stream) {
+static int32_t check_corner_roles(const okx_corner_roles* roles, int32_t n_out, const char* who);
+
+// okx_solve_batch and okx_solve_evaluated_batch (`evaluated`: the launch runs the program's evaluated kernels, whose
+// epilogue writes d_tangents / d_eval)
+static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_problems,
+                          const double* d_targets, const double* d_geom_pos,
+                          const double* d_geom_row_param, double* d_out_pos, okx_info* d_info,
+                          void* stream, bool evaluated, double* d_tangents, double* d_eval) {
   if (!p || !opts) return fail(OKX_ERR_INVALID, "null program or options");
   attach_when_ready(p, false);
+  if (evaluated) {
+    if (!p->ev_solve_u) return fail(OKX_ERR_INVALID, "evaluated solves need okx_program_enable_evaluation first%s%s", p->ev_note[0] ? ": " : "", p->ev_note);
+    if (!d_tangents && !d_eval) return fail(OKX_ERR_INVALID, "an evaluated solve needs d_tangents or d_eval");
+  }
   if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
   if (n_problems == 0) return OKX_OK;
   if (opts->output < OKX_OUTPUT_RECORDS || opts->output > OKX_OUTPUT_NONE) return fail(OKX_ERR_INVALID, "unknown output mode");
@@ -838,6 +857,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   bool use_quad = p->quad_fn_u != nullptr && (opts->kernel == 0 || opts->kernel == 3 || opts->kernel == 4);
   if (opts->kernel == 3 && !use_quad)
     return fail(OKX_ERR_INVALID, "quad kernel requested but not available: %s", p->quad_note);
+  if (evaluated && !use_quad) return fail(OKX_ERR_INVALID, "evaluated solves run the generated kernels only (kernel = 0, 3 or 4)");
   const long long quad_slots = (long long)p->n_cu * p->quad_waves_per_cu * p->quad_ppw;
   // Lane kernel (one lane per problem, 64 per wavefront): auto selection from lane_min_problems on, when nothing the
   // quad kernel alone offers is asked for (fitted model, trace); kernel == 4 forces it.
@@ -875,6 +895,18 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
       lane_auto_cold = true;
     } else if (cold_launch ? !p->lane_cold_ok : !p->lane_chain_ok) {
       use_lane = false;
+    }
+  }
+  if (evaluated && use_lane) {
+    // the lane form of the evaluated module has the independent-solve bodies only: chains go to the quad kernel
+    const long long span0 = spg > 0 ? spg : n_problems;
+    long long len0 = opts->chain_len;
+    if (len0 == 0) len0 = opts->chain ? span0 : 1;
+    const bool cold_launch = len0 == 1 || span0 == 1 || lane_auto_cold;
+    if (!p->ev_lane_u || !cold_launch) {
+      if (opts->kernel == 4) return fail(OKX_ERR_INVALID, "no evaluated lane kernel for this launch: %s", p->ev_lane_u ? "chains" : p->ev_note);
+      use_lane = false;
+      lane_auto_cold = false;
     }
   }
   if (opts->kernel == 4 && !use_lane)
@@ -995,7 +1027,11 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
         }
       }
     }
-    void* kargs[] = {(void*)&q};
+    okx::QuadEvArgs qe;  // evaluated launches: the same arguments, then the epilogue's outputs and the roles' numbers
+    qe.tan = d_tangents;
+    qe.ev = d_eval;
+    qe.cfg = p->ev_cfg;
+    void* kargs[] = {evaluated ? (void*)&qe : (void*)&q};
     if (use_lane) {
       const long long chains_per_span = (span_ + a.chain_len - 1) / a.chain_len;
       const long long lane_units = (n_problems / span_) * ((chains_per_span + 63) / 64);
@@ -1003,6 +1039,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
       const int lane_grid = (int)(lane_units < lane_cap ? (lane_units < 1 ? 1 : lane_units) : lane_cap);
       hipFunction_t fn = a.chain_len == 1 ? (d_geom_pos ? p->lane_fn_g : p->lane_fn_u) : (d_geom_pos ? p->lane_chain_g : p->lane_chain_u);
       if (opts->output != OKX_OUTPUT_RECORDS) fn = p->lane_compact[(a.chain_len == 1 ? 0 : 2) + (d_geom_pos ? 1 : 0)];
+      if (evaluated) fn = d_geom_pos ? p->ev_lane_g : p->ev_lane_u;
       void* ring = nullptr;
       if (a.chain_len != 1 && okx::lane_chain_is_flat(p->host.n)) {
         // what a flat chain body carries from step to step (okx_quad.hpp lane_chain_is_flat): scratch of this launch,
@@ -1010,6 +1047,7 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
         HIP_TRY(hipMallocAsync(&ring, sizeof(double) * (size_t)okx::lane_flat_chain_doubles(p->host.n) * (size_t)lane_grid, (hipStream_t)stream));
         q.predictor = static_cast<const double*>(ring);
       }
+      qe.q = q;
       HIP_TRY(hipModuleLaunchKernel(fn, lane_grid, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
       if (ring) HIP_TRY(hipFreeAsync(ring, (hipStream_t)stream));
       return OKX_OK;
@@ -1025,6 +1063,8 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
     if (p->quad_fn_cold_u && !degenerate_line && !d_geom_pos && a.chain_len == 1 && q.head != nullptr && q.predictor == nullptr && (q.trace == nullptr || okx::dev_switch("quad_timeline")) &&
         opts->grad_tol <= 0.0 && !okx::dev_switch("no_cold"))
       fn = p->quad_fn_cold_u;
+    if (evaluated) fn = fn == p->quad_fn_cold_u && p->ev_cold_u ? p->ev_cold_u : d_geom_pos ? p->ev_solve_g : p->ev_solve_u;
+    qe.q = q;
     HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
     return OKX_OK;
   }
@@ -1046,6 +1086,154 @@ int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_pr
   HIP_TRY(hipLaunchKernel(p->solve_fn, dim3(grid), dim3(p->threads), kargs, p->lds_bytes,
                           (hipStream_t)stream));
   return OKX_OK;
+}
+
+int32_t okx_solve_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_problems,
+                        const double* d_targets, const double* d_geom_pos,
+                        const double* d_geom_row_param, double* d_out_pos, okx_info* d_info,
+                        void* stream) {
+  return solve_impl(p, opts, n_problems, d_targets, d_geom_pos, d_geom_row_param, d_out_pos, d_info, stream, false, nullptr, nullptr);
+}
+
+int32_t okx_solve_evaluated_batch(okx_program* p, const okx_solve_opts* opts, int64_t n_problems,
+                                  const double* d_targets, const double* d_geom_pos, const double* d_geom_row_param,
+                                  double* d_out_pos, okx_info* d_info, double* d_tangents, double* d_eval, void* stream) {
+  return solve_impl(p, opts, n_problems, d_targets, d_geom_pos, d_geom_row_param, d_out_pos, d_info, stream, true, d_tangents, d_eval);
+}
+
+static void release_evaluation(okx_program* p) {
+  if (p->ev_mod) (void)hipModuleUnload(p->ev_mod);
+  if (p->ev_lane_mod) (void)hipModuleUnload(p->ev_lane_mod);
+  p->ev_mod = p->ev_lane_mod = nullptr;
+  p->ev_solve_u = p->ev_solve_g = p->ev_cold_u = p->ev_pos_u = p->ev_pos_g = nullptr;
+  p->ev_lane_u = p->ev_lane_g = nullptr;
+}
+
+int32_t okx_program_enable_evaluation(okx_program* p, const okx_corner_roles* roles) {
+  if (!p || !roles) return fail(OKX_ERR_INVALID, "null program or roles");
+  if (int32_t rc = check_corner_roles(roles, p->host.n_out, "roles")) return rc;
+  attach_when_ready(p, true);  // the evaluated kernels share the solve kernels' first-step tables: those first
+  if (!p->quad_fn_u || p->quad_ppw != 16) {
+    std::snprintf(p->ev_note, sizeof(p->ev_note), "no single-mode quad kernel (%.180s)", p->quad_note[0] ? p->quad_note : "a pair-mode program");
+    return fail(OKX_ERR_INVALID, "evaluated solves need the program's single-mode quad kernel: %s", p->ev_note);
+  }
+  okx::EvalSpec spec;
+  std::string why;
+  if (!okx::eval_spec_from_roles(p->host, *roles, &spec, &why)) return fail(OKX_ERR_INVALID, "%s", why.c_str());
+  okx::eval_scalars_from_roles(*roles, &p->ev_cfg);
+  if (p->ev_solve_u && std::memcmp(&spec, &p->ev_spec, sizeof(spec)) == 0) return OKX_OK;  // same role points: only the numbers changed
+  if (p->ev_mod) {
+    HIP_TRY(hipDeviceSynchronize());  // launches in flight may still run the modules about to be replaced
+    release_evaluation(p);
+  }
+  p->ev_note[0] = 0;
+  std::string code;
+  if (!okx::quad_eval_build(p->host, spec, quad_waves_per_simd(), &code, &why)) {
+    std::snprintf(p->ev_note, sizeof(p->ev_note), "%.250s", why.c_str());
+    return fail(OKX_ERR_LIMIT, "no evaluated kernels for this program: %s", why.c_str());
+  }
+  hipModule_t mod = nullptr;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(OKX_ERR_DEVICE, "hipModuleLoadData failed for the evaluated module");
+  }
+  hipFunction_t su = nullptr;
+  if (hipModuleGetFunction(&su, mod, "okx_quad_evsolve_u") != hipSuccess ||
+      hipModuleGetFunction(&p->ev_solve_g, mod, "okx_quad_evsolve_g") != hipSuccess ||
+      hipModuleGetFunction(&p->ev_pos_u, mod, "okx_quad_evaluate_u") != hipSuccess ||
+      hipModuleGetFunction(&p->ev_pos_g, mod, "okx_quad_evaluate_g") != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipModuleUnload(mod);
+    p->ev_solve_g = p->ev_pos_u = p->ev_pos_g = nullptr;
+    return fail(OKX_ERR_DEVICE, "kernel symbols missing in the evaluated module");
+  }
+  if (hipModuleGetFunction(&p->ev_cold_u, mod, "okx_quad_evcold_u") != hipSuccess) {
+    (void)hipGetLastError();
+    p->ev_cold_u = nullptr;
+  }
+  p->ev_mod = mod;
+  p->ev_spec = spec;
+  // the lane form, for programs whose solves have one (failure only means the quad form serves every batch size)
+  if (p->lane_fn_u && !okx::dev_switch("no_lane")) {
+    std::string lcode, lwhy;
+    int scratch = -1;
+    if (!okx::lane_eval_build(p->host, spec, &lcode, &lwhy, false, &scratch)) {
+      std::snprintf(p->ev_note, sizeof(p->ev_note), "no lane form: %.230s", lwhy.c_str());
+    } else if (scratch > 512) {
+      std::snprintf(p->ev_note, sizeof(p->ev_note), "the lane form spills %d B of scratch: not used", scratch);
+    } else {
+      hipModule_t lmod = nullptr;
+      if (hipModuleLoadData(&lmod, lcode.data()) == hipSuccess &&
+          hipModuleGetFunction(&p->ev_lane_u, lmod, "okx_lane_evsolve_u") == hipSuccess &&
+          hipModuleGetFunction(&p->ev_lane_g, lmod, "okx_lane_evsolve_g") == hipSuccess) {
+        p->ev_lane_mod = lmod;
+        p->ev_lane_scratch = scratch;
+      } else {
+        (void)hipGetLastError();
+        if (lmod) (void)hipModuleUnload(lmod);
+        p->ev_lane_u = p->ev_lane_g = nullptr;
+        std::snprintf(p->ev_note, sizeof(p->ev_note), "the lane form's code object did not load");
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_release);
+  p->ev_solve_u = su;  // the gate of the evaluated launch paths, published last
+  return OKX_OK;
+}
+
+int32_t okx_program_evaluation(const okx_program* p) { return p && p->ev_solve_u ? 1 | (p->ev_lane_u ? 2 : 0) : 0; }
+const char* okx_program_evaluation_note(const okx_program* p) { return p ? p->ev_note : ""; }
+
+int32_t okx_evaluate_batch(okx_program* p, int64_t n_problems, int64_t steps_per_geometry, const double* d_pos,
+                           const double* d_geom_pos, const double* d_geom_row_param, double* d_tangents, double* d_eval,
+                           void* stream) {
+  if (!p) return fail(OKX_ERR_INVALID, "null program");
+  if (!p->ev_solve_u) return fail(OKX_ERR_INVALID, "okx_evaluate_batch needs okx_program_enable_evaluation first%s%s", p->ev_note[0] ? ": " : "", p->ev_note);
+  if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
+  if (n_problems == 0) return OKX_OK;
+  if (!d_pos || (!d_tangents && !d_eval)) return fail(OKX_ERR_INVALID, "null pointer");
+  if ((d_geom_pos == nullptr) != (d_geom_row_param == nullptr))
+    return fail(OKX_ERR_INVALID, "geometry positions and row parameters must be given together");
+  if (steps_per_geometry < 0 || (d_geom_pos && steps_per_geometry == 0) ||
+      (steps_per_geometry > 0 && n_problems % steps_per_geometry != 0))
+    return fail(OKX_ERR_INVALID, "bad steps_per_geometry");
+  okx::QuadEvPosArgs q;
+  q.pos = d_pos;
+  q.geom_pos = d_geom_pos;
+  q.geom_row_param = d_geom_row_param;
+  q.tan = d_tangents;
+  q.ev = d_eval;
+  q.n_problems = n_problems;
+  q.steps_per_geometry = steps_per_geometry > 0 ? steps_per_geometry : n_problems;
+  const char* base = reinterpret_cast<const char*>(p->dev);
+  q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
+  q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
+  q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
+  q.cfg = p->ev_cfg;
+  const long long waves = (n_problems + 15) / 16;
+  const long long cap = (long long)p->n_cu * p->quad_waves_per_cu * 8;  // (a streaming launch: several rounds' worth of workgroups)
+  void* kargs[] = {(void*)&q};
+  HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->ev_pos_g : p->ev_pos_u, (int)(waves < cap ? waves : cap), 1, 1, okx::kWave, 1, 1, 0,
+                                (hipStream_t)stream, kargs, nullptr));
+  return OKX_OK;
+}
+
+int32_t okx_precompile_evaluation(const okx_program_desc* desc, const okx_corner_roles* roles) {
+  if (!desc || !roles) return fail(OKX_ERR_INVALID, "null pointer");
+  okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
+  if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
+  int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
+  okx::EvalSpec spec;
+  std::string why, code;
+  if (rc == OKX_OK && !okx::eval_spec_from_roles(*tmp, *roles, &spec, &why)) rc = fail(OKX_ERR_INVALID, "%s", why.c_str());
+  if (rc == OKX_OK && !okx::quad_eval_build(*tmp, spec, quad_waves_per_simd(), &code, &why))
+    rc = fail(why.compare(0, 14, "compile failed") == 0 ? OKX_ERR_DEVICE : OKX_ERR_LIMIT, "no evaluated kernels for this program: %s", why.c_str());
+  if (rc == OKX_OK && tmp->n_free <= okx::kLaneMaxFree) {
+    std::string lcode, lwhy;
+    (void)okx::lane_eval_build(*tmp, spec, &lcode, &lwhy);  // (programs / variants it does not fit simply have no lane form)
+  }
+  delete tmp;
+  return rc;
 }
 
 int32_t okx_program_has_predictor(const okx_program* p) { return p && p->predictor_dev ? 1 : 0; }

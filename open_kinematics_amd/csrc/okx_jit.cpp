@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -98,7 +99,8 @@ bool unwrap_entry(const std::string& file, std::string* code) {
 }
 
 void write_file_atomic(const std::string& path, const std::string& data) {
-  const std::string part = path + ".tmp" + std::to_string((long)getpid());
+  static std::atomic<unsigned> serial{0};  // (two compile threads of one process may write the same entry)
+  const std::string part = path + ".tmp" + std::to_string((long)getpid()) + "_" + std::to_string(serial.fetch_add(1));
   FILE* fh = std::fopen(part.c_str(), "wb");
   if (!fh) return;  // a read-only cache directory only costs recompilation
   const size_t put = std::fwrite(data.data(), 1, data.size(), fh);
@@ -315,6 +317,63 @@ bool lane_build(const DevProgram& P, std::string* src, std::string* code, std::s
   *src = best_src;
   *code = best_code;
   if (variant_out) *variant_out = best;
+  return true;
+}
+
+bool quad_eval_build(const DevProgram& P, const EvalSpec& spec, int waves_per_simd, std::string* code, std::string* why, bool cache_only) {
+  std::string src, err;
+  if (!quad_generate(P, waves_per_simd, &src, why, false, &spec)) return false;
+  if (!quad_compile(src, code, &err, false, cache_only)) {
+    *why = err == kNotCached ? err : "compile failed: " + err;
+    return false;
+  }
+  return true;
+}
+
+// The lane form of the evaluated module: the emission variant whose okx_lane_evsolve_* kernels spill least (the search stops
+// at the first one without scratch); the choice is remembered next to the code objects like lane_build's.
+bool lane_eval_build(const DevProgram& P, const EvalSpec& spec, std::string* code, std::string* why, bool cache_only, int* scratch_out) {
+  std::string src0, err;
+  if (!lane_generate(P, &src0, why, 0, &spec)) return false;
+  char name[64];
+  std::snprintf(name, sizeof(name), "/okxe_%016llx.lanevar", fnv1a(src0));
+  const std::string memo = cache_dir() + name;
+  int first = 0, last = lane_variant_count() - 1;
+  {
+    std::string text;
+    if (read_file(memo, &text)) {
+      const int v = atoi(text.c_str());
+      if (v >= 0 && v < lane_variant_count()) first = last = v;
+    }
+  }
+  int best = -1, best_scratch = 1 << 30;
+  std::string best_code;
+  bool searched_all = true;
+  for (int v = first; v <= last; ++v) {
+    std::string s1, c1, w1;
+    if (v == 0) s1 = src0;
+    else if (!lane_generate(P, &s1, &w1, v, &spec)) continue;
+    if (!quad_compile(s1, &c1, &err, false, cache_only)) {
+      if (best < 0) *why = err == kNotCached ? err : "compile failed: " + err;
+      searched_all = false;
+      if (cache_only) break;
+      continue;
+    }
+    const int scratch = quad_code_scratch_bytes(c1, "okx_lane_evsolve");
+    if (scratch >= 0 && scratch < best_scratch) {
+      best = v;
+      best_scratch = scratch;
+      best_code.swap(c1);
+    }
+    if (best_scratch == 0) break;
+  }
+  if (best < 0) return false;
+  if (first != last && (best_scratch == 0 || searched_all)) {
+    (void)mkdir(cache_dir().c_str(), 0777);
+    write_file_atomic(memo, std::to_string(best) + "\n");
+  }
+  *code = best_code;
+  if (scratch_out) *scratch_out = best_scratch;
   return true;
 }
 

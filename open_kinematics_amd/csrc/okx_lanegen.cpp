@@ -1117,7 +1117,11 @@ bool lane_chain_is_flat(int n_vars) {
   return 80 - 4 * n_vars < 16;  // fewer than 16 of the 80 LDS slots left for the factor's rows beside x, dx, xp, xq
 }
 
-bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant) {
+bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant, const EvalSpec* es) {
+  if (es != nullptr) {
+    *why = "the lane form of the evaluated module is not generated yet";
+    return false;
+  }
   // Emission variants (kVariants above): the register allocator's result for an 18-unknown program sits at the edge of the
   // 512-register file and is not monotonic in any of the hints (0 ... 250 B of scratch across them for the double
   // wishbone, and not the same variant for every kernel of the module), so lane_build (okx_jit.cpp) compiles them in this

@@ -106,6 +106,45 @@ struct QuadTanArgs {
   const double* dop_param;
 };
 
+// ---- evaluated solve (okx_solve_evaluated_batch): tangents and the metric catalog as the solve kernels' epilogue ----
+// The role POINTS of okx_corner_roles (indices into the program's output list, -1 = absent) are compile-time constants of
+// the generated "evaluated" module; the numeric part travels as a kernel argument.
+constexpr int kEvalSlots = 15;  // wheel centre, contact patch, axle outboard / inboard, steer lower / upper, damper top / bottom, 6 instant-axis points, rack
+struct EvalSpec {
+  int wheel_center, contact_patch, axle_inboard, axle_outboard, steer_lower, steer_upper;
+  int ia_kind, ia_point[6];
+  int damper_top, damper_bottom, rack;
+};
+struct EvalScalars {  // mirrors `struct EvCfg` of the generated source (okx_evalsrc.cpp)
+  double side_sign, design_wheel_center_z, design_contact_patch_z, design_rack_y, wheelbase, cg_z, front_brake_bias;
+  int axle_position, driven_axle;
+};
+bool eval_spec_from_roles(const DevProgram& P, const okx_corner_roles& roles, EvalSpec* spec, std::string* why);
+void eval_scalars_from_roles(const okx_corner_roles& roles, EvalScalars* scalars);
+int eval_slot_point(const EvalSpec& spec, int slot);         // output-list index of a role slot (-1: absent)
+std::string eval_metrics_source(const EvalSpec& spec);       // role #defines + the catalog on duals
+// Arguments of the evaluated solve kernels okx_quad_evsolve_u/_g, okx_quad_evcold_u, okx_lane_evsolve_u/_g (mirrors
+// `struct QEvArgs`): the solve's own arguments, then what the epilogue writes and the roles' numeric part.
+struct QuadEvArgs {
+  QuadArgs q;
+  double* tan;    // [B][T][n_out][3] or null
+  double* ev;     // [B][1 + T][OKX_EVAL_COLUMNS] or null
+  EvalScalars cfg;
+};
+// Arguments of okx_quad_evaluate_u/_g (mirrors `struct QEvPosArgs`): the same epilogue on given solved states.
+struct QuadEvPosArgs {
+  const double* pos;
+  const double* geom_pos;
+  const double* geom_row_param;
+  double* tan;
+  double* ev;
+  long long n_problems, steps_per_geometry;
+  const double* design_pos;
+  const double* row_param;
+  const double* dop_param;
+  EvalScalars cfg;
+};
+
 // A program made of two structurally identical halves joined by one distance row (the composed
 // axle), seen as its half ("side") program plus the index maps of both sides (okx_pairview.cpp).
 struct PairView {
@@ -133,13 +172,18 @@ bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why);
 // interpreter kernels of okx_kernels.hip.
 // `lds_homes` (pair mode only): the chain constants and the fixed points live in LDS instead of registers - the
 // fallback for a half program whose register-resident variant spills (see quad_build).
-bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why, bool lds_homes = false);
+// `eval` non-null: the EVALUATED module of the program instead - the solve bodies with the tangent / metric epilogue
+// (kernels okx_quad_evsolve_u/_g, okx_quad_evcold_u) and the same epilogue on given states (okx_quad_evaluate_u/_g);
+// single mode only.
+bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why, bool lds_homes = false,
+                   const EvalSpec* eval = nullptr);
 
 // Emits the HIP source of the LANE kernel specialised to `P` (okx_lanegen.cpp): one lane per problem, 64 problems per
 // wavefront, for batches that fill the chip several times over.  Kernels okx_lane_solve_u/_g (arguments: QuadArgs) and
 // okx_lane_eval (QuadEvalArgs).  Returns false (and says why) when the program does not fit one lane's registers.
 // `variant` in [0, lane_variant_count()): the same arithmetic with other hints to the compiler (see lane_build).
-bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant = 0);
+// `eval` non-null: the evaluated module (okx_lane_evsolve_u/_g: independent solves with the tangent / metric epilogue).
+bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant = 0, const EvalSpec* eval = nullptr);
 // How the lane kernel walks chains.  While x, dx and the chain history (two previous solutions) leave at least 16 of the
 // 80 LDS slots to the factor's parked rows, a lane keeps its chain in LDS and loops over its steps (MacPherson: 60 + 20).
 // Otherwise (double wishbone: 72 + 8) the chain body IS the independent-solve body in one flat loop over
@@ -190,5 +234,9 @@ int quad_code_lds_bytes(const std::string& code, const char* prefix);  // static
 // is generated and compiled instead.  `src` receives the source of the variant that was kept.
 bool quad_build(const DevProgram& P, int waves_per_simd, std::string* src, std::string* code, std::string* why,
                 bool ignore_cached = false, bool cache_only = false);
+// The evaluated modules of a program for one set of metric roles: quad (single mode) and, when the program has a lane
+// kernel, lane (the emission variant with the least scratch in okx_lane_evsolve_*; remembered in the cache like lane_build's).
+bool quad_eval_build(const DevProgram& P, const EvalSpec& spec, int waves_per_simd, std::string* code, std::string* why, bool cache_only = false);
+bool lane_eval_build(const DevProgram& P, const EvalSpec& spec, std::string* code, std::string* why, bool cache_only = false, int* scratch_out = nullptr);
 
 }  // namespace okx

@@ -1198,11 +1198,19 @@ int quad_head_stride(const DevProgram& program) {
   return 2 * 4 * pv.side.n_free * k + 2 * k * k + 8 + 2 * 4 * pv.side.n_free * pairs;  // both halves' Q and S blocks
 }
 
-bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* src, std::string* why, bool lds_homes) {
+bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* src, std::string* why, bool lds_homes,
+                   const EvalSpec* es) {
   // Small programs: one quad per problem.  Larger ones only when they are two identical halves
   // joined by one distance row (composed axle): one quad per half, a 2 x 2 Woodbury correction for the joint.
   PairView pair_store;
   const PairView* pv = nullptr;
+  // EV: the evaluated module (okx_solve_evaluated_batch) - the solve bodies end in an epilogue that solves for the
+  // solution-manifold tangents at the converged state and evaluates the metric catalog along them (okx_evalsrc.cpp)
+  const bool EV = es != nullptr;
+  if (EV && program.n_free > kQuadMaxFree) {
+    *why = "pair-mode programs have no evaluated module (their tangents and metrics run as separate launches)";
+    return false;
+  }
   if (program.n_free > kQuadMaxFree) {
     std::string pair_why;
     if (!build_pair_view(program, &pair_store, &pair_why) || pair_store.side.n_free > kQuadMaxFreePerSide) {
@@ -1502,6 +1510,11 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   for (int k = 0; k < nf; ++k) used[P.free_point[k]] = true;
 
   g.out += kPreamble;
+  if (EV) {
+    g.out += eval_metrics_source(*es);
+    g.f("struct QEvArgs { QArgs q; double* tan; double* ev; EvCfg cfg; };");
+    g.f("#define EV_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\"); } while (0)");
+  }
   if (ev.tl_marks) g.f("#define OKX_TL(k)");
   g.f("");
   if (pv) {
@@ -1531,6 +1544,140 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       "  __shared__ double hql[" + std::to_string(64 * (ev.n_lane_slots + 1)) + "];  // chain-constant lane components [slot][lane]\n";
   std::string final_src;
   bool body_failed = false;
+  // ---- evaluated module: the epilogue every body (and okx_quad_evaluate_*) ends a problem with ----
+  // At the solved state (every point p{k} in registers, the output record staged in `stage`): J once more, undamped
+  // J^T J = L D L^T, one substitution per target for the solution-manifold tangent q_t = (J^T J)^-1 J^T e_t
+  // (reference sensitivity.py:57-143; the pinned line rows play the part of its _degenerate_constraint_pins), the
+  // velocity of every point by the derived ops' closed-form directional derivatives, staged in LDS [quad][t][record].
+  // Then the metric catalog (okx_evalsrc.cpp) ONCE per quad: lane c evaluates direction c - 1 - lane 0 the values (a zero
+  // tangent), lanes 1 .. T the derivative along target 0 .. T - 1 - on duals with one tangent component, its role points
+  // gathered from the staged record and its own direction's velocities.  Results leave as one contiguous block per
+  // wavefront: [problem][1 + T][OKX_EVAL_COLUMNS] (row 0: values + the factorisation's pivots, row 1 + t: d / d target t,
+  // then the wheel centre's and the rack pickup's rates - the drivers of the reference's derivative columns).
+  // `contig`: C expression, true when the wavefront's problems are consecutive (bb = wu * 16 + quad).
+  const int REC = 3 * P.n_out, EVC = OKX_EVAL_COLUMNS;
+  std::string epi_factor_src;
+  if (EV) {
+    if (T < 1) {
+      *why = "an evaluated module needs at least one target";
+      return false;
+    }
+    std::vector<int> oi(NP, -1);
+    for (int k = 0; k < P.n_out; ++k) oi[P.out_point[k]] = k;
+    for (int F = 0; F < nf; ++F)
+      if (oi[ev.fp(F)] < 0) {
+        *why = "an evaluated module needs every free point among the output points";
+        return false;
+      }
+    ev.out.clear();
+    ev.emit_factor();
+    epi_factor_src = ev.out;
+    ev.out.clear();
+  }
+  auto epilogue_src = [&](const std::string& contig) -> std::string {
+    ev.out.clear();
+    ev.reset_caches();
+    ev.f("    {  // ---- evaluated epilogue: tangents at the solved state, metrics and their derivatives along them ----");
+    ev.out += eval_src;
+    ev.f("    const double lambda = 0.0;  // (an undamped factorisation; shadows the solve's damping)");
+    for (int F = 0; F < nf; ++F)
+      for (int G = 0; G <= F; ++G)
+        if (ev.fillf[F][G])
+          for (int k = 0; k < 3; ++k) {
+            if (!(F == G && k == 2)) ev.f("    double %s;", Gen::Ln(F, G, k).c_str());
+            if (!ev.nz[F][G]) ev.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
+          }
+    ev.out += epi_factor_src;
+    ev.f("    __shared__ __attribute__((aligned(16))) double vst[16 * %d];  // velocities [quad][target][record]", T * REC);
+    for (int t = 0; t < T; ++t) {
+      ev.f("    {  // target %d: (J^T J) q = J^T e_t, then the velocity of every point", t);
+      std::vector<std::string> rhs(nf, "0.0");
+      auto it = ev.target_j.find(t);
+      if (it != ev.target_j.end())
+        for (auto& fv : it->second) rhs[fv.first] = Gen::sx(fv.second);
+      ev.emit_substitute(rhs, "tq");
+      const std::string vp = "w" + std::to_string(t) + "_";
+      for (int p = 0; p < NP; ++p) {
+        if (!used[p] || ev.dop_of_point[p] >= 0) continue;
+        if (ev.blk_of_point[p] >= 0) ev.f("    const double %s%d = tq%d;", vp.c_str(), p, ev.blk_of_point[p]);
+        else ev.f("    const double %s%d = 0.0;", vp.c_str(), p);
+      }
+      for (int e = 0; e < P.n_derived; ++e)
+        if (!ev.derived_jvp(e, vp)) return std::string();
+      ev.f("    if (c < 3) {");
+      ev.f("      double* vs = vst + (quad * %d + %d) * %d + c;", T, t, REC);
+      for (int k = 0; k < P.n_out; ++k) ev.f("      vs[%d] = ok ? %s%d : __builtin_nan(\"\");", 3 * k, vp.c_str(), P.out_point[k]);
+      ev.f("    }");
+      ev.f("    }");
+    }
+    ev.f("    EV_WAVE_SYNC();");
+    ev.f("    const long long ev_rem = a.n_problems - wu * 16;");
+    ev.f("    const int ev_rows = (int)(ev_rem < 16 ? ev_rem : 16);  // problems of a contiguous wavefront block");
+    auto copy_out = [&](const char* dst, const char* stage_name, int per_problem) {
+      ev.f("      if (%s) {", contig.c_str());
+      ev.f("        const int n_doubles = ev_rows * %d;", per_problem);
+      ev.f("        double2* dst = reinterpret_cast<double2*>(%s + wu * 16 * %d);", dst, per_problem);
+      ev.f("        const double2* src = reinterpret_cast<const double2*>(%s);", stage_name);
+      ev.f("        for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
+      ev.f("        if ((n_doubles & 1) && lane == 0) (%s + wu * 16 * %d)[n_doubles - 1] = %s[n_doubles - 1];", dst, per_problem, stage_name);
+      ev.f("      } else if (valid) {  // chains: a quad's problems are far apart in memory");
+      ev.f("        double* dst = %s + bb * %d;", dst, per_problem);
+      ev.f("        const double* src = %s + quad * %d;", stage_name, per_problem);
+      ev.f("        for (int i = c; i < %d; i += 4) dst[i] = src[i];", per_problem);
+      ev.f("      }");
+    };
+    ev.f("    if (ea.tan != nullptr) {");
+    copy_out("ea.tan", "vst", T * REC);
+    ev.f("    }");
+    ev.f("    if (ea.ev != nullptr) {");
+    ev.f("      __shared__ __attribute__((aligned(16))) double est[16 * %d];  // [quad][row][column]", (1 + T) * EVC);
+    ev.f("      EvCfg cfg = ea.cfg;");
+    ev.f("      if (PG) {  // an ensemble's design references are its geometry's own");
+    ev.f("        cfg.design_wheel_center_z = gp[%d]; cfg.design_contact_patch_z = gp[%d];", 3 * P.out_point[es->wheel_center] + 2,
+         3 * P.out_point[es->contact_patch] + 2);
+    if (es->rack >= 0) ev.f("        cfg.design_rack_y = gp[%d];", 3 * P.out_point[es->rack] + 1);
+    ev.f("      }");
+    ev.f("      const double ev_flags = (ok ? 1.0 : 0.0) + ((!ok || pmin <= %d * 2.220446049250313e-16 * pmax) ? 2.0 : 0.0);", 3 * nf);
+    ev.f("      _Pragma(\"unroll 1\")");
+    ev.f("      for (int ep = 0; 4 * ep <= %d; ++ep) {", T);
+    ev.f("        const int evt = 4 * ep + c - 1;  // this lane's direction: -1 the values, t the derivative along target t");
+    ev.f("        const bool dir = evt >= 0 && evt < %d;", T);
+    ev.f("        const double* ps = stage + quad * %d;", REC);
+    ev.f("        const double* vs = vst + (quad * %d + (dir ? evt : 0)) * %d;", T, REC);
+    ev.f("        DV<1> RP[EV_SLOTS];");
+    for (int sl = 0; sl < kEvalSlots; ++sl) {
+      const int k = eval_slot_point(*es, sl);
+      if (k < 0) {
+        ev.f("        RP[%d].x = du_const<1>(0.0); RP[%d].y = du_const<1>(0.0); RP[%d].z = du_const<1>(0.0);", sl, sl, sl);
+        continue;
+      }
+      for (int cc2 = 0; cc2 < 3; ++cc2)
+        ev.f("        RP[%d].%c.v = ps[%d]; RP[%d].%c.d[0] = dir ? vs[%d] : 0.0;", sl, "xyz"[cc2], 3 * k + cc2, sl, "xyz"[cc2], 3 * k + cc2);
+    }
+    ev.f("        Du<1> em[%d];", OKX_METRIC_COUNT);
+    ev.f("        ev_corner_metrics<1>(cfg, RP, em);");
+    ev.f("        if (evt < %d) {", T);
+    ev.f("          double* eo = est + (quad * %d + evt + 1) * %d;", 1 + T, EVC);
+    ev.f("          if (evt < 0) {");
+    for (int k = 0; k < OKX_METRIC_COUNT; ++k) ev.f("            eo[%d] = em[%d].v;", k, k);
+    ev.f("            eo[19] = pmin; eo[20] = pmax; eo[21] = ev_flags; eo[22] = 0.0; eo[23] = 0.0;");
+    ev.f("          } else {");
+    for (int k = 0; k < OKX_METRIC_COUNT; ++k) ev.f("            eo[%d] = em[%d].d[0];", k, k);
+    ev.f("            eo[19] = RP[EV_SLOT_WHEEL_CENTER].x.d[0]; eo[20] = RP[EV_SLOT_WHEEL_CENTER].y.d[0]; eo[21] = RP[EV_SLOT_WHEEL_CENTER].z.d[0];");
+    ev.f("            eo[22] = %s; eo[23] = 0.0;", es->rack >= 0 ? "RP[EV_SLOT_RACK].y.d[0]" : "__builtin_nan(\"\")");
+    ev.f("          }");
+    ev.f("        }");
+    ev.f("      }");
+    ev.f("      EV_WAVE_SYNC();");
+    copy_out("ea.ev", "est", (1 + T) * EVC);
+    ev.f("    }");
+    ev.f("    EV_WAVE_SYNC();  // (vst / est are reused by the next problem of this wavefront)");
+    ev.f("    }");
+    std::string text = ev.out;
+    ev.out.clear();
+    ev.reset_caches();
+    return text;
+  };
   auto emit_body = [&](const bool CD) {
   // One damped step from the normal equations in hand: declarations of the factor's registers, then (single mode) LDL^T +
   // substitutions, or (pair mode) each half's factorisation and the Woodbury system of the joining rows.  Leaves nx{F}, ok,
@@ -1628,10 +1775,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   if (tl_body)  // sections of the SECOND full pass of a wavefront go to a second table behind the first: a.trace[16 (waves + w) + k]
     g.f("#undef OKX_TL\n#define OKX_TL(k) if (a.trace && tl_pass == 4 && (threadIdx.x & 63) == 0) a.trace[(gridDim.x + blockIdx.x) * 16 + (k)] = (double)__builtin_readcyclecounter();");
   if (CD) {
-    g.f("DEV void okx_quad_cold_body(const QArgs& a) {");
+    g.f("DEV void okx_quad_cold_body(const QArgs& a%s) {", EV ? ", const QEvArgs& ea" : "");
     g.f("  constexpr bool PG = false;  // the program's own geometry only (per-geometry tables differ from quad to quad)");
   } else {
-    g.f("template <bool PG> DEV void okx_quad_body(const QArgs& a) {");
+    g.f("template <bool PG> DEV void okx_quad_body(const QArgs& a%s) {", EV ? ", const QEvArgs& ea" : "");
   }
   // (developer build, OKX_QUAD_TIMELINE=1: wavefront w stamps the shader clock into a.trace[16 w + k] - 0 entry, 1 loads
   //  consumed / first step in hand, 2 ... 11 top of each LM pass, 13 passes done, 14 records stored; tools/quad_timeline.py)
@@ -2439,6 +2586,8 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       body_failed = true;
       return;
     }
+  if (EV) g.f("    {  // (the evaluated module needs every derived point: records or not)");
+  else
   g.f("    if (a.out_mode == 0) {  // the derived points only matter to the full records");
   g.out += fin.out;
   g.f("    }");
@@ -2490,7 +2639,30 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     }
     g.f("    }");
   }
-  if (pv && CD) {
+  if (EV) {
+    // evaluated module: the record is staged in any case (the epilogue gathers the metric roles from it) and written as
+    // the output mode says - whole rows where the wavefront's records are contiguous
+    g.f("    __shared__ __attribute__((aligned(16))) double stage[16 * %d];", 3 * P.n_out);
+    g.f("    if (c < 3) {");
+    g.f("      double* st = stage + quad * %d + c;", 3 * P.n_out);
+    for (int k = 0; k < P.n_out; ++k) g.f("      st[%d] = p%d;", 3 * k, P.out_point[k]);
+    g.f("    }");
+    g.f("    EV_WAVE_SYNC();");
+    g.f("    if (a.out_mode == 0) {");
+    g.f("      if (unit_len == 1) {");
+    g.f("        const long long rem = a.n_problems - wu * 16;");
+    g.f("        const int n_doubles = (int)(rem < 16 ? rem : 16) * %d;", 3 * P.n_out);
+    g.f("        double2* dst = reinterpret_cast<double2*>(a.out_pos + wu * 16 * %d);", 3 * P.n_out);
+    g.f("        const double2* src = reinterpret_cast<const double2*>(stage);");
+    g.f("        for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
+    g.f("        if ((n_doubles & 1) && lane == 0) a.out_pos[wu * 16 * %d + n_doubles - 1] = stage[n_doubles - 1];", 3 * P.n_out);
+    g.f("      } else if (valid && c < 3) {");
+    g.f("        double* o = a.out_pos + bb * %d + c;", 3 * P.n_out);
+    for (int k = 0; k < P.n_out; ++k) g.f("        o[%d] = p%d;", 3 * k, P.out_point[k]);
+    g.f("      }");
+    g.f("    }");
+    g.f("    if (false) {");
+  } else if (pv && CD) {
     // cold pair body: the wavefront's eight records are one contiguous block as well - staged and written in whole rows
     // (the general body's lane-by-lane 8-byte stores leave 24-byte fragments: 1.3x the bytes on the way to HBM)
     g.f("    if (a.out_mode == 0) {");
@@ -2603,6 +2775,15 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("      a.info[bb] = inf;");
   g.f("    }");
   }
+  if (EV) {
+    const std::string epi = epilogue_src(CD ? "true" : "unit_len == 1");
+    if (epi.empty()) {
+      *why = ev.why;
+      body_failed = true;
+      return;
+    }
+    g.out += epi;
+  }
   stamp("15");
   if (timeline) g.f("    if (a.trace && (threadIdx.x & 63) == 0) a.trace[(gridDim.x + blockIdx.x) * 16 + 1] = (double)__builtin_amdgcn_s_memrealtime();");
   // chains never continue from a state that failed to converge
@@ -2638,6 +2819,59 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   const bool cold_body = head_ok;
   if (cold_body) emit_body(true);
   if (body_failed) return false;
+  if (EV) {
+    // ---- the same epilogue on GIVEN solved states (okx_evaluate_batch; reference core/sweep.py:217-245,
+    //      evaluate_solved_sweep): free points from the records, fixed points from the geometry, every derived point
+    //      re-evaluated - one launch instead of tangents -> metrics, no tangent tensor in between unless asked for ----
+    g.f("struct QEvPosArgs { const double* pos; const double* geom_pos; const double* geom_row_param; double* tan; double* ev;");
+    g.f("  long long n_problems, steps_per_geometry; const double* design_pos; const double* row_param; const double* dop_param; EvCfg cfg; };");
+    g.f("template <bool PG> DEV void okx_quad_evaluate_body(const QEvPosArgs& a) {");
+    g.f("  const QEvPosArgs& ea = a;");
+    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 2, cc = c < 3 ? c : 2;");
+    g.out += atan_decl;
+    g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+    g.f("  __shared__ __attribute__((aligned(16))) double stage[16 * %d];", 3 * P.n_out);
+    g.f("  for (long long wu = blockIdx.x; wu * 16 < a.n_problems; wu += gridDim.x) {");
+    g.f("    long long bb = wu * 16 + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;");
+    g.f("    const long long geom = PG ? bb / a.steps_per_geometry : 0;");
+    g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * NP);
+    g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * P.n_crows);
+    g.out += ev.hoisted;
+    for (int p = 0; p < NP; ++p)
+      if (used[p]) g.f("    double p%d = ld3(gp + %d + cc, c);", p, 3 * p);
+    {
+      std::vector<int> oi(NP, -1);
+      for (int k = 0; k < P.n_out; ++k) oi[P.out_point[k]] = k;
+      for (int F = 0; F < nf; ++F) g.f("    p%d = ld3(a.pos + bb * %d + %d + cc, c);", ev.fp(F), 3 * P.n_out, 3 * oi[ev.fp(F)]);
+    }
+    for (int t = 0; t < T; ++t) g.f("    const double tv%d = 0.0;  // target values do not enter the Jacobian", t);
+    g.f("    {");
+    g.out += final_src;
+    g.f("    }");
+    g.f("    if (c < 3) {");
+    g.f("      double* st = stage + quad * %d + c;", 3 * P.n_out);
+    for (int k = 0; k < P.n_out; ++k) g.f("      st[%d] = p%d;", 3 * k, P.out_point[k]);
+    g.f("    }");
+    g.f("    EV_WAVE_SYNC();");
+    {
+      const std::string epi = epilogue_src("true");
+      if (epi.empty()) {
+        *why = ev.why;
+        return false;
+      }
+      g.out += epi;
+    }
+    g.f("  }");
+    g.f("}");
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evaluate_u(QEvPosArgs a) { okx_quad_evaluate_body<false>(a); }", waves_per_simd);
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evaluate_g(QEvPosArgs a) { okx_quad_evaluate_body<true>(a); }", waves_per_simd);
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evsolve_u(QEvArgs ea) { okx_quad_body<false>(ea.q, ea); }", waves_per_simd);
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evsolve_g(QEvArgs ea) { okx_quad_body<true>(ea.q, ea); }", waves_per_simd);
+    if (cold_body)
+      g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evcold_u(QEvArgs ea) { okx_quad_cold_body(ea.q, ea); }", waves_per_simd);
+    *src = g.out;
+    return true;
+  }
   if (!pv) {
   // ---- output positions from free coordinates (okx_expand_positions_batch): fixed points from the design table,
   //      every derived point re-evaluated, records written like the solve kernel's ----

@@ -1,0 +1,167 @@
+"""
+GPU: the EVALUATED solve (okx_solve_evaluated_batch / okx_evaluate_batch) - tangents and the metric catalog as the
+solve kernels' epilogue, ONE launch (reference core/sweep.py:217-270 solve_evaluated_sweep / evaluate_solved_sweep) -
+against the reference's tangent and metric goldens, against the three-launch path (solve -> okx_tangent_batch ->
+okx_corner_metrics_batch) and, for the positions, bit for bit against the plain solve.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, gpu_available
+from test_gpu_metrics import _roles
+from test_metrics_oracle import close, derivative_plan, load_metrics_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not gpu_available():
+        pytest.skip("no GPU")
+
+
+def _tg(name):
+    return dict(np.load(os.path.join(GOLDEN, f"tangents_{name}.npz"), allow_pickle=False))
+
+
+def _evaluated_program(golden, name, line_mode="pinned"):
+    from open_kinematics_amd.batch import DeviceProgram
+
+    _, program = golden(name)
+    program = program.with_line_mode(line_mode)
+    mg = load_metrics_golden(name)
+    roles, ridx = _roles(program, mg)
+    dp = DeviceProgram(program, "cuda:0")
+    assert dp.kernel == "quad", dp.kernel_note
+    dp.enable_evaluation(roles)
+    assert dp.evaluation & 1, dp.evaluation_note
+    return dp, program, roles, ridx, mg
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid", "e2e_sweep"])
+def test_evaluate_matches_the_reference_metrics_and_derivatives(golden, name):
+    """okx_evaluate_batch at the reference's own solved states: the tolerances of tests/test_gpu_metrics.py."""
+    dp, program, roles, ridx, mg = _evaluated_program(golden, name)
+    res = dp.evaluate(mg["pos"], tangents=True)
+    torch.cuda.synchronize()
+    assert np.all(res.tangent_info()["flags"] == 1)
+    values = res.metrics.cpu().numpy()
+    assert np.max(np.abs(values[:, :8] - mg["values"][:, :8])) <= 1e-9
+    assert close(values, mg["values"], 1e-9)  # NaN exactly where the reference reports None
+    deriv = res.derivatives.cpu().numpy()
+    tan = res.tangents.cpu().numpy()
+    plan = derivative_plan(program, mg["deriv_names"])
+    assert len(plan) >= 8
+    for j, (what, t) in plan.items():
+        got = tan[:, t, ridx["wheel_center"], what[1]] if isinstance(what, tuple) else deriv[:, t, what]
+        ref = mg["deriv"][:, j]
+        assert np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) <= 1e-7, mg["deriv_names"][j]
+    # the driver rates are the tangents' entries
+    rates = res.wheel_center_rates.cpu().numpy()
+    assert np.array_equal(rates, tan[:, :, ridx["wheel_center"], :])
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid"])
+def test_fused_tangents_match_the_reference(golden, name):
+    """Tangents of the evaluation epilogue at the reference's solved states: <= 1e-9 (tests/golden/tangents_*.npz)."""
+    dp, program, roles, ridx, mg = _evaluated_program(golden, name)
+    tg = _tg(name)
+    res = dp.evaluate(tg["pos"], tangents=True)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(res.tangents.cpu().numpy() - tg["vel"])) <= 1e-9
+    info = res.tangent_info()
+    assert np.all(info["flags"] == 1) and np.all(info["min_pivot"] > 0)
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid"])
+@pytest.mark.parametrize("shape", ["cold", "chained", "ragged"])
+def test_evaluated_solve_is_the_solve_plus_the_separate_launches(golden, name, shape):
+    """One launch against three: positions and info records bit for bit, tangents / metrics / derivatives to rounding."""
+    from open_kinematics_amd.metrics import corner_state_metrics
+
+    dp, program, roles, ridx, mg = _evaluated_program(golden, name)
+    arrays, _ = golden(name)
+    t = arrays["targets_abs"]
+    kw = {}
+    if shape == "chained":
+        kw = dict(chain_len=7)
+    if shape == "ragged":
+        t = t[:37]
+    plain = dp.solve(t, kernel="quad", **kw)
+    fused = dp.solve_evaluated(t, tangents=True, kernel="quad", **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.positions, fused.positions)
+    assert torch.equal(plain.info_raw, fused.info_raw)
+    info = fused.info()
+    assert np.all((info["flags"] & 7) == 1)
+    tan, tinfo = dp.tangents(plain.positions)
+    sep = corner_state_metrics(roles, plain.positions, tan)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(fused.tangents.cpu().numpy() - tan.cpu().numpy())) <= 1e-9
+    assert close(fused.metrics.cpu().numpy(), sep.values.cpu().numpy(), 1e-9)
+    got, ref = fused.derivatives.cpu().numpy(), sep.derivatives.cpu().numpy()
+    both = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), both)
+    assert np.max(np.abs(got[both] - ref[both]) / np.maximum(1.0, np.abs(ref[both]))) <= 1e-7
+    ti = dp.tangent_info(tinfo)
+    fi = fused.tangent_info()
+    assert np.array_equal(fi["flags"], ti["flags"])
+    assert np.allclose(fi["min_pivot"], ti["min_pivot"], rtol=1e-9) and np.allclose(fi["max_pivot"], ti["max_pivot"], rtol=1e-9)
+    # metrics only: nothing of the positions is written
+    lean = dp.solve_evaluated(t, output="none", kernel="quad", **kw)
+    torch.cuda.synchronize()
+    assert lean.positions is None and lean.tangents is None
+    assert torch.equal(torch.nan_to_num(lean.eval), torch.nan_to_num(fused.eval))
+
+
+def test_evaluated_ensemble_uses_each_geometrys_own_design_references(golden):
+    """Geometry tables: wheel travel is measured from every geometry's own design state."""
+    from open_kinematics_amd.metrics import METRIC_NAMES, corner_state_metrics
+
+    dp, program, roles, ridx, mg = _evaluated_program(golden, "c1_dw_corner")
+    rng = np.random.default_rng(3)
+    g, s = 5, 16
+    hard = np.repeat(program.design_pos[None], g, axis=0) + rng.normal(0.0, 0.5, size=(g, program.n_points, 3))
+    gpos, grow = dp.rebind(hard)
+    rel = np.stack([np.zeros(s), np.linspace(-30.0, 40.0, s)], axis=1)
+    targets = dp.ensemble_targets(gpos, rel)
+    kw = dict(geom_pos=gpos, geom_row_param=grow, steps_per_geometry=s, kernel="quad")
+    plain = dp.solve(targets, **kw)
+    fused = dp.solve_evaluated(targets, tangents=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.positions, fused.positions)
+    tan, _ = dp.tangents(plain.positions, geom_pos=gpos, geom_row_param=grow, steps_per_geometry=s)
+    assert np.max(np.abs(fused.tangents.cpu().numpy() - tan.cpu().numpy())) <= 1e-9
+    travel = fused.metrics[:, METRIC_NAMES.index("wheel_travel")].cpu().numpy().reshape(g, s)
+    wc = program.out_point[ridx["wheel_center"]]
+    z0 = gpos[:, wc, 2].cpu().numpy()
+    z = plain.positions[:, ridx["wheel_center"], 2].cpu().numpy().reshape(g, s)
+    assert np.max(np.abs(travel - (z - z0[:, None]))) <= 1e-12
+    assert np.max(np.abs(travel - rel[None, :, 1])) <= 1e-8  # the bump target is the wheel centre's rise
+    # everything else against the separate metric kernel on one geometry's block
+    sep = corner_state_metrics(roles, plain.positions[:s], tan[:s])
+    cols = [k for k, n in enumerate(METRIC_NAMES) if n != "wheel_travel"]
+    assert close(fused.metrics[:s][:, cols].cpu().numpy(), sep.values[:, cols].cpu().numpy(), 1e-9)
+    # okx_evaluate_batch with the same tables gives the same numbers as the solve's epilogue
+    again = dp.evaluate(plain.positions, tangents=True, geom_pos=gpos, geom_row_param=grow, steps_per_geometry=s)
+    torch.cuda.synchronize()
+    assert close(again.eval.cpu().numpy(), fused.eval.cpu().numpy(), 1e-9)
+
+
+def test_evaluated_entry_points_fail_loudly(golden):
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden("c1_dw_corner")
+    dp = DeviceProgram(program.with_line_mode("pinned"), "cuda:0")
+    with pytest.raises(RuntimeError, match="metric roles"):
+        dp.solve_evaluated(arrays["targets_abs"])
+    _, axle = golden("c3_axle_grid")
+    mg = load_metrics_golden("c1_dw_corner")
+    roles, _ = _roles(program.with_line_mode("pinned"), mg)
+    axle_dp = DeviceProgram(axle.with_line_mode("pinned"), "cuda:0")
+    with pytest.raises(ValueError, match="single-mode quad kernel"):
+        axle_dp.enable_evaluation(roles)
