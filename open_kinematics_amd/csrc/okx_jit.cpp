@@ -346,10 +346,19 @@ bool lane_eval_build(const DevProgram& P, const EvalSpec& spec, std::string* cod
       if (v >= 0 && v < lane_variant_count()) first = last = v;
     }
   }
+  // only variants with the arithmetic of the program's plain lane module (lane_build's remembered choice): an evaluated
+  // solve returns the plain solve's positions bit for bit
+  int plain = 0;
+  {
+    std::string a1, a2, a3;
+    int v = -1;
+    if (lane_build(P, &a1, &a2, &a3, false, &v, 256, true) && v >= 0) plain = v;
+  }
   int best = -1, best_scratch = 1 << 30;
   std::string best_code;
   bool searched_all = true;
   for (int v = first; v <= last; ++v) {
+    if (!lane_variants_same_arithmetic(v, plain)) continue;
     std::string s1, c1, w1;
     if (v == 0) s1 = src0;
     else if (!lane_generate(P, &s1, &w1, v, &spec)) continue;

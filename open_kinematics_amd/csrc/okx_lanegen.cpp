@@ -450,6 +450,110 @@ class LGen {
     return false;
   }
 
+  // ---- directional derivatives of the derived points (forward mode, closed form; the evaluated module's epilogue) ----
+  // vel[d][p]: velocity of point p along direction d as three names ("" = structurally zero: fixed points and what
+  // only depends on them).  Replaces the reference's dual-number pass (sensitivity.py:127-131, primitives/dual.py).
+  S3 add(const S3& a, const S3& b) {
+    S3 r;
+    for (int k = 0; k < 3; ++k) {
+      if (a.c[k].empty() && b.c[k].empty()) continue;
+      if (b.c[k].empty()) r.c[k] = emit("v", sgn(a, k));
+      else if (a.c[k].empty()) r.c[k] = emit("v", sgn(b, k));
+      else r.c[k] = emit("v", sgn(a, k) + " + " + sgn(b, k));
+    }
+    return r;
+  }
+  // k * (a - u * s) per component, s a scalar expression ("" = zero)
+  S3 scaled_reject(const std::string& k, const S3& a, const S3& u, const std::string& s) {
+    S3 r;
+    for (int i = 0; i < 3; ++i) {
+      const bool ha = !a.c[i].empty(), hu = !u.c[i].empty() && !s.empty() && s != "0.0";
+      if (ha && hu) r.c[i] = emit("jv", k + " * fma(-" + u.c[i] + ", " + s + ", " + sgn(a, i) + ")");
+      else if (ha) r.c[i] = emit("jv", k + " * " + sgn(a, i));
+      else if (hu) r.c[i] = emit("jv", "-(" + k + " * " + u.c[i] + " * " + s + ")");
+    }
+    return r;
+  }
+  static bool is_zero(const S3& a) { return a.c[0].empty() && a.c[1].empty() && a.c[2].empty(); }
+  bool derived_jvp(int e, std::vector<std::vector<S3>>& vel) {
+    const int type = P.dop_type[e];
+    const int* pts = P.dop_pts[e];
+    const int o = P.dop_out[e];
+    const int D = (int)vel.size();
+    f("    // velocity of derived point %d (op %d, type %d)", o, e, type);
+    if (type == OKX_DOP_MIDPOINT) {
+      for (int d = 0; d < D; ++d) {
+        const S3 &a = vel[d][pts[0]], &b = vel[d][pts[1]];
+        S3 r;
+        for (int k = 0; k < 3; ++k) {
+          if (a.c[k].empty() && b.c[k].empty()) continue;
+          if (a.c[k].empty()) r.c[k] = emit("jv", "0.5 * " + sgn(b, k));
+          else if (b.c[k].empty()) r.c[k] = emit("jv", "0.5 * " + sgn(a, k));
+          else r.c[k] = emit("jv", "fma(" + sgn(b, k) + " - " + sgn(a, k) + ", 0.5, " + sgn(a, k) + ")");
+        }
+        vel[d][o] = r;
+      }
+      return true;
+    }
+    if (type == OKX_DOP_ALONG) {  // out = base + c u, u = w / |w|, w = a - b
+      const S3 w = sub(pt(pts[1]), pt(pts[2]));
+      const std::string ww = dot(w, w);
+      std::string nrm, inrm;
+      sqrt_rsqrt(ww, &nrm, &inrm);
+      const S3 u = scale(inrm, w);
+      const std::string k = emit("k", dp(e) + " * " + inrm);
+      for (int d = 0; d < D; ++d) {
+        const S3 dw = sub(vel[d][pts[1]], vel[d][pts[2]]);
+        S3 r = vel[d][pts[0]];
+        if (!is_zero(dw)) {
+          const std::string ud = dot(u, dw);
+          r = add(vel[d][pts[0]], scaled_reject(k, dw, u, ud));
+        }
+        vel[d][o] = r;
+      }
+      return true;
+    }
+    if (type == OKX_DOP_CONTACT_PATCH) {  // out = wc + R wu, wu = wd / |wd|, wd = a_z a - e_z, a = v / |v|, v = axo - axi
+      const S3 v = sub(pt(pts[2]), pt(pts[1]));
+      const std::string vv = dot(v, v);
+      std::string vn, ivn;
+      sqrt_rsqrt(vv, &vn, &ivn);
+      const S3 ax = scale(ivn, v);
+      const std::string az = ax.c[2];
+      S3 wd;
+      wd.c[0] = emit("wd", az + " * " + ax.c[0]);
+      wd.c[1] = emit("wd", az + " * " + ax.c[1]);
+      wd.c[2] = emit("wd", "fma(" + az + ", " + ax.c[2] + ", -1.0)");
+      const std::string ww = dot(wd, wd);
+      std::string wn, iwn;
+      sqrt_rsqrt(ww, &wn, &iwn);
+      const S3 wu = scale(iwn, wd);
+      const std::string rk = emit("rk", iwn + " * " + dp(e));
+      for (int d = 0; d < D; ++d) {
+        const S3 dv = sub(vel[d][pts[2]], vel[d][pts[1]]);
+        S3 r = vel[d][pts[0]];
+        if (!is_zero(dv)) {
+          const std::string adv = dot(ax, dv);
+          const S3 dax = scaled_reject(ivn, dv, ax, adv);
+          const std::string daz = dax.c[2];  // (never structurally zero: a_z' has a part along every component of dv)
+          S3 dwd;
+          for (int i = 0; i < 3; ++i) {
+            std::string ex;
+            if (!daz.empty()) ex = daz + " * " + ax.c[i];
+            if (!dax.c[i].empty()) ex = ex.empty() ? az + " * " + dax.c[i] : "fma(" + az + ", " + dax.c[i] + ", " + ex + ")";
+            dwd.c[i] = emit("dw", ex);
+          }
+          const std::string wdw = dot(wu, dwd);
+          r = add(vel[d][pts[0]], scaled_reject(rk, dwd, wu, wdw));
+        }
+        vel[d][o] = r;
+      }
+      return true;
+    }
+    why = "unknown derived op";
+    return false;
+  }
+
   // ---- rows ----
   struct RowOut {
     std::string r;
@@ -864,7 +968,10 @@ class LGen {
   // ... or in LDS, where the body has slots to spare: [l_lds_base + k][lane], first rows first (they wait longest)
   int l_lds_base = 0, l_lds_slots = 0;
   std::map<std::pair<int, int>, int> l_home;
-  void emit_factor(const std::vector<std::string>& rhs) {
+  void emit_factor(const std::vector<std::string>& rhs) { emit_factor_multi({rhs}, {"y"}); }
+  // ... with several right-hand sides: set s forward-substitutes into {yp[s]}{j} (the evaluated module's epilogue: one
+  // per target, J^T e_t)
+  void emit_factor_multi(const std::vector<std::vector<std::string>>& rhs_sets, const std::vector<std::string>& yp) {
     const int n = 3 * P.n_free;
     symbolic();
     parked.clear();
@@ -922,11 +1029,11 @@ class LGen {
       for (int k = 0; k < j; ++k)
         if (fill[j][k]) cols.push_back(k);
       for (int k : cols) f("    const double %s = C%d_%d * dinv%d;", L(j, k).c_str(), j, k, k);
-      {
+      for (size_t si = 0; si < rhs_sets.size(); ++si) {
         std::vector<std::pair<std::string, std::string>> pr;
-        for (int k : cols) pr.push_back({"(-" + L(j, k) + ")", "y" + std::to_string(k)});
-        const std::string e = sum_expr(pr, rhs[j] == "0.0" ? "" : rhs[j]);
-        f("    const double y%d = %s;", j, e.empty() ? "0.0" : e.c_str());
+        for (int k : cols) pr.push_back({"(-" + L(j, k) + ")", yp[si] + std::to_string(k)});
+        const std::string e = sum_expr(pr, rhs_sets[si][j] == "0.0" ? "" : rhs_sets[si][j]);
+        f("    const double %s%d = %s;", yp[si].c_str(), j, e.empty() ? "0.0" : e.c_str());
       }
       for (int i = j; i < n; ++i) {
         if (!fill[i][j]) continue;
@@ -975,10 +1082,10 @@ class LGen {
   }
 
   // D z = y, L^T x = z, row-oriented: x_j is final once every later row has been scattered; row j of L is read once.
-  void emit_backward(const char* outn) {
+  void emit_backward(const char* outn, const char* yp = "y") {
     const int n = 3 * P.n_free;
     f("    // ---- D z = y, L^T x = z (row by row, last row first) ----");
-    for (int i = 0; i < n; ++i) f("    double %s%d = y%d * dinv%d;", outn, i, i, i);
+    for (int i = 0; i < n; ++i) f("    double %s%d = %s%d * dinv%d;", outn, i, yp, i, i);
     for (int j = n - 1; j >= 0; --j) {
       for (int k = 0; k < j; ++k) {
         if (!fill[j][k]) continue;
@@ -1118,10 +1225,10 @@ bool lane_chain_is_flat(int n_vars) {
 }
 
 bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int variant, const EvalSpec* es) {
-  if (es != nullptr) {
-    *why = "the lane form of the evaluated module is not generated yet";
-    return false;
-  }
+  // EV: the lane form of the evaluated module (okx_solve_evaluated_batch): the independent-solve bodies end every wave
+  // unit with the tangent / metric epilogue (see the quad form in okx_quadgen.cpp; here a lane holds a whole problem, so the
+  // catalog runs on duals with ALL the targets' directions at once, its role points straight from the lane's registers)
+  const bool EV = es != nullptr;
   // Emission variants (kVariants above): the register allocator's result for an 18-unknown program sits at the edge of the
   // 512-register file and is not monotonic in any of the hints (0 ... 250 B of scratch across them for the double
   // wishbone, and not the same variant for every kernel of the module), so lane_build (okx_jit.cpp) compiles them in this
@@ -1236,6 +1343,62 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     }
   }
 
+  // evaluated module: the epilogue's pass - J at the solved state, the undamped LDL^T with one forward substitution per
+  // target (right-hand side J^T e_t, the target row's gradient), one backward substitution each: tq{t}_{i} = d x_i / d target t
+  struct EpiSrc { std::string eval, factor, subst; };
+  auto make_epilogue_pass = [&](LGen& gen, const LGen& like, EpiSrc* out) -> bool {
+    gen.uid = 700000;
+    gen.hoisted_names = ev.hoisted_names;
+    gen.j_lds_base = like.j_lds_base;
+    gen.j_lds_slots = like.j_lds_slots;
+    gen.l_lds_base = like.l_lds_base;
+    gen.l_lds_slots = like.l_lds_slots;
+    gen.late_diag = like.late_diag;
+    gen.pin_acc = false;   // (J^T r is not wanted here: without the opaque uses the compiler drops its accumulation)
+    gen.launder = false;
+    gen.col_fence = V.col_fence;
+    gen.f("    // ---- active derived points with chain-rule blocks ----");
+    for (int idx = 0; idx < P.n_active; ++idx)
+      if (!gen.derived_op(P.active_op[idx], true)) return false;
+    if (!gen.emit_rows()) return false;
+    out->eval = gen.out;
+    gen.out.clear();
+    std::vector<std::vector<std::string>> rhs_sets;
+    std::vector<std::string> yp;
+    for (int t = 0; t < T; ++t) {
+      std::vector<std::string> rhs(n, "0.0");
+      auto it = gen.target_j.find(t);
+      if (it != gen.target_j.end())
+        for (auto& fv : it->second)
+          for (int a = 0; a < 3; ++a)
+            if (!fv.second.c[a].empty()) rhs[3 * fv.first + a] = LGen::sgn(fv.second, a);
+      rhs_sets.push_back(rhs);
+      yp.push_back("yq" + std::to_string(t) + "_");
+    }
+    gen.emit_factor_multi(rhs_sets, yp);
+    out->factor = gen.out;
+    gen.out.clear();
+    for (int t = 0; t < T; ++t) gen.emit_backward(("tq" + std::to_string(t) + "_").c_str(), yp[t].c_str());
+    out->subst = gen.out;
+    gen.out.clear();
+    return true;
+  };
+  LGen epc(P), epg(P);
+  EpiSrc epi_cold, epi_g;
+  if (EV) {
+    std::vector<int> oi(NP, -1);
+    for (int k = 0; k < P.n_out; ++k) oi[P.out_point[k]] = k;
+    for (int F = 0; F < nf; ++F)
+      if (oi[ev.fp(F)] < 0) {
+        *why = "an evaluated module needs every free point among the output points";
+        return false;
+      }
+    if (!make_epilogue_pass(epc, evc, &epi_cold) || (split_g && !make_epilogue_pass(epg, evg, &epi_g))) {
+      *why = epc.why.empty() ? epg.why : epc.why;
+      return false;
+    }
+  }
+
   // confirming evaluation (residuals only); not for programs with the reference's zero-gradient point-on-line row
   bool light_ok = true;
   for (int i = 0; i < P.n_crows; ++i) light_ok = light_ok && P.row_type[i] != OKX_ROW_POINT_ON_LINE;
@@ -1330,10 +1493,14 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   LGen g(P);
   g.out += kLanePreamble;
   g.f("");
+  if (EV) {
+    g.out += eval_metrics_source(*es);
+    g.f("struct QEvArgs { QArgs q; double* tan; double* ev; EvCfg cfg; };");
+  }
   {
     // every table entry a constant's name can stand for (unused macros cost nothing)
     std::set<std::string> defs;
-    for (LGen* gen : {&ev, &evc, &evg}) defs.insert(gen->defines.begin(), gen->defines.end());
+    for (LGen* gen : {&ev, &evc, &evg, &epc, &epg}) defs.insert(gen->defines.begin(), gen->defines.end());
     char line[96];
     for (int i = 0; i < P.m; ++i)
       for (int k = 0; k < 8; ++k) {
@@ -1382,6 +1549,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     const int state_doubles = 64 * n_slots;
     const int stage_doubles = ch || fl ? 0 : 64 * 3 * P.n_out;
     int lds_doubles = state_doubles > stage_doubles ? state_doubles : stage_doubles;
+    if (EV && lds_doubles < 64 * ((3 * P.n_out) | 1)) lds_doubles = 64 * ((3 * P.n_out) | 1);  // (tangent rows [lane][record | 1]; result rows [lane][25])
+    if (EV && lds_doubles < 64 * 25) lds_doubles = 64 * 25;
     // the first-step table of the wave unit's geometry is staged behind the state (the area the factor's rows are parked
     // in later): the prologue's 100-odd table reads are LDS broadcasts instead of same-address global loads
     const int head_l0 = state_doubles_before_l;
@@ -1415,7 +1584,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
           ev.gl_gq0, ev.gl_tq0, ev.gl_gq0, ev.gl_dp0, ev.gl_tq0 - 8 * P.n_crows, ev.gl_dp0);
     } else
       g.f("#define GL(o) gl[(o) + kz]");
-    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a) {", ch || fl ? "chain" : gb ? "coldg" : "cold");
+    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a%s) {", ch || fl ? "chain" : gb ? "coldg" : "cold", EV ? ", const QEvArgs& ea" : "");
     g.f("  const int lane = threadIdx.x;");
     g.f("  __shared__ double lds[%d];", lds_doubles);
     if (sc) g.f("  int kzs = 0;  // an opaque zero in a scalar register: a table read inside a pass is a load of that pass, not a loop invariant");
@@ -1829,6 +1998,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("      {");
     g.f("    %s", refresh_kz);
     for (int i = 0; i < n; ++i) g.f("    %s = x%d;", PF(i).c_str(), i);
+    if (EV) g.f("    {  // (the evaluated module needs every derived point: records or not)");
+    else
     g.f("    if (FULL) {  // the derived points only matter to the full records");
     g.out += final_src;
     g.f("    }");
@@ -1864,10 +2035,18 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       // Records of independent solves: the 64 problems of a wave unit are consecutive, their records one contiguous
       // block: transposed through LDS (which the state no longer needs) and written as full 16-byte-per-lane rows.
       // (okx_solve_opts.output: the full record, the free points alone in the program's free_point order, or nothing)
+      if (EV) {  // (the evaluated module's kernels take the output mode at run time)
+        g.f("      const bool full_rec = a.out_mode == 0;");
+        g.f("      if (a.out_mode != 2) {");
+        g.f("      const int rec = full_rec ? %d : %d;", 3 * P.n_out, n);
+        g.f("      WAVE_SYNC();");
+        g.f("      if (full_rec) {");
+      } else {
       g.f("      if (FULL || a.out_mode == 1) {");
       g.f("      const int rec = FULL ? %d : %d;", 3 * P.n_out, n);
       g.f("      WAVE_SYNC();");
       g.f("      if (FULL) {");
+      }
       g.f("      double* st = lds + lane * %d;", 3 * P.n_out);
       for (int k = 0; k < P.n_out; ++k)
         for (int c = 0; c < 3; ++c) g.f("      st[%d] = p%d_%d;", 3 * k + c, P.out_point[k], c);
@@ -1894,6 +2073,103 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      WAVE_SYNC();");
       g.f("      }");
       stamp(15);
+      if (EV) {
+        // ---- evaluated epilogue (see okx_quadgen.cpp for the quad form): J at the solved state, undamped LDL^T with one
+        // substitution per target, the points' velocities in forward mode, then the metric catalog on duals with all T
+        // directions - role points and their velocities straight from this lane's registers.  Rows leave through LDS
+        // ([lane][25]: an odd stride) as 192-byte fragments of the [problem][1 + T][24] records.
+        LGen& eg = gb ? epg : epc;
+        const EpiSrc& ep = gb ? epi_g : epi_cold;
+        const int REC = 3 * P.n_out, RS = REC | 1, EVC = OKX_EVAL_COLUMNS;
+        g.f("      {");
+        g.f("      WAVE_SYNC();  // (the record copy's last LDS reads are done)");
+        g.f("      %s", refresh_kz);
+        g.out += ep.eval;
+        g.f("      const double lambda = 0.0;  // (an undamped factorisation; shadows the solve's damping)");
+        g.out += ep.factor;
+        g.out += ep.subst;
+        eg.out.clear();
+        std::vector<std::vector<S3>> vel(T, std::vector<S3>(NP));
+        for (int t = 0; t < T; ++t)
+          for (int F = 0; F < nf; ++F)
+            for (int c = 0; c < 3; ++c) vel[t][eg.fp(F)].c[c] = "tq" + std::to_string(t) + "_" + std::to_string(3 * F + c);
+        for (int e = 0; e < P.n_derived; ++e)
+          if (!eg.derived_jvp(e, vel)) {
+            lds_why = eg.why;
+            return false;
+          }
+        const std::string jvp_src = eg.out;
+        eg.out.clear();
+        g.f("      const double ev_flags = (ok ? 1.0 : 0.0) + ((!ok || pmin <= %d * 2.220446049250313e-16 * pmax) ? 2.0 : 0.0);", n);
+        g.f("      const long long ev_base = span_idx * span + wave_in_span * 64;");
+        g.f("      const long long ev_rem = (span_idx + 1) * span - ev_base;");
+        g.f("      const int ev_rows = (int)(ev_rem < 64 ? ev_rem : 64);");
+        g.f("      if (ea.tan != nullptr) {  // the tangents themselves: [problem][target][record], one target at a time through LDS");
+        g.out += jvp_src;
+        for (int t = 0; t < T; ++t) {
+          g.f("        WAVE_SYNC();");
+          g.f("        { double* st = lds + lane * %d;", RS);
+          for (int k = 0; k < P.n_out; ++k)
+            for (int c = 0; c < 3; ++c) {
+              const std::string& nm = vel[t][P.out_point[k]].c[c];
+              if (nm.empty()) g.f("          st[%d] = ok ? 0.0 : __builtin_nan(\"\");", 3 * k + c);
+              else g.f("          st[%d] = ok ? %s : __builtin_nan(\"\");", 3 * k + c, nm.c_str());
+            }
+          g.f("        }");
+          g.f("        WAVE_SYNC();");
+          g.f("        for (int i = lane; i < ev_rows * %d; i += 64) { const int j = i / %d, col = i - j * %d; ea.tan[((ev_base + j) * %d + %d) * %d + col] = lds[j * %d + col]; }",
+              REC, REC, REC, T, t, REC, RS);
+        }
+        g.f("        WAVE_SYNC();");
+        g.f("      }");
+        g.f("      if (ea.ev != nullptr) {");
+        g.out += jvp_src;
+        g.f("        EvCfg cfg = ea.cfg;");
+        g.f("        if (PG) {  // an ensemble's design references are its geometry's own");
+        g.f("          cfg.design_wheel_center_z = GL(%d); cfg.design_contact_patch_z = GL(%d);", ev.gl_gp0 + 3 * P.out_point[es->wheel_center] + 2,
+            ev.gl_gp0 + 3 * P.out_point[es->contact_patch] + 2);
+        if (es->rack >= 0) g.f("          cfg.design_rack_y = GL(%d);", ev.gl_gp0 + 3 * P.out_point[es->rack] + 1);
+        g.f("        }");
+        g.f("        DV<%d> RP[EV_SLOTS];", T);
+        for (int sl = 0; sl < kEvalSlots; ++sl) {
+          const int k = eval_slot_point(*es, sl);
+          for (int c = 0; c < 3; ++c) {
+            if (k < 0) {
+              g.f("        RP[%d].%c = du_const<%d>(0.0);", sl, "xyz"[c], T);
+              continue;
+            }
+            const int pnt = P.out_point[k];
+            g.f("        RP[%d].%c.v = p%d_%d;", sl, "xyz"[c], pnt, c);
+            for (int t = 0; t < T; ++t) {
+              const std::string& nm = vel[t][pnt].c[c];
+              g.f("        RP[%d].%c.d[%d] = %s;", sl, "xyz"[c], t, nm.empty() ? "0.0" : ("(ok ? " + nm + " : __builtin_nan(\"\"))").c_str());
+            }
+          }
+        }
+        g.f("        Du<%d> em[%d];", T, OKX_METRIC_COUNT);
+        g.f("        ev_corner_metrics<%d>(cfg, RP, em);", T);
+        for (int r = 0; r <= T; ++r) {
+          g.f("        WAVE_SYNC();");
+          g.f("        { double* st = lds + lane * 25;");
+          if (r == 0) {
+            for (int k = 0; k < OKX_METRIC_COUNT; ++k) g.f("          st[%d] = em[%d].v;", k, k);
+            g.f("          st[19] = pmin; st[20] = pmax; st[21] = ev_flags; st[22] = 0.0; st[23] = 0.0;");
+          } else {
+            for (int k = 0; k < OKX_METRIC_COUNT; ++k) g.f("          st[%d] = em[%d].d[%d];", k, k, r - 1);
+            g.f("          st[19] = RP[EV_SLOT_WHEEL_CENTER].x.d[%d]; st[20] = RP[EV_SLOT_WHEEL_CENTER].y.d[%d]; st[21] = RP[EV_SLOT_WHEEL_CENTER].z.d[%d];", r - 1, r - 1, r - 1);
+            if (es->rack >= 0) g.f("          st[22] = RP[EV_SLOT_RACK].y.d[%d]; st[23] = 0.0;", r - 1);
+            else g.f("          st[22] = __builtin_nan(\"\"); st[23] = 0.0;");
+          }
+          g.f("        }");
+          g.f("        WAVE_SYNC();");
+          g.f("        for (int i = lane; i < ev_rows * %d; i += 64) { const int j = i / %d, c2 = i - j * %d;", EVC / 2, EVC / 2, EVC / 2);
+          g.f("          double2 v2; v2.x = lds[j * 25 + 2 * c2]; v2.y = lds[j * 25 + 2 * c2 + 1];");
+          g.f("          reinterpret_cast<double2*>(ea.ev + ((ev_base + j) * %d + %d) * %d)[c2] = v2; }", 1 + T, r, EVC);
+        }
+        g.f("        WAVE_SYNC();");
+        g.f("      }");
+        g.f("      }");
+      }
     } else {
       // chains: a lane's problems are far apart in memory, every lane stores its own record
       g.f("    if (valid && FULL) {");
@@ -1912,6 +2188,16 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("");
     return true;
   };
+  if (EV) {
+    if (!body(false, false, false) || (split_g && !body(false, false, true))) {
+      *why = lds_why;
+      return false;
+    }
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_evsolve_u(QEvArgs ea) { okx_lane_body_cold<false, true>(ea.q, ea); }");
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_evsolve_g(QEvArgs ea) { okx_lane_body_%s<true, true>(ea.q, ea); }", split_g ? "coldg" : "cold");
+    *src = g.out;
+    return true;
+  }
   if (!body(false, false, false) || (split_g && !body(false, false, true)) || !(flat_chain ? body(false, true, false) : body(true, false, false))) {
     *why = lds_why;
     return false;

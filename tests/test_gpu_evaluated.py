@@ -78,7 +78,7 @@ def test_fused_tangents_match_the_reference(golden, name):
 
 
 @pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid"])
-@pytest.mark.parametrize("shape", ["cold", "chained", "ragged"])
+@pytest.mark.parametrize("shape", ["cold", "chained", "ragged", "lane", "lane_ragged"])
 def test_evaluated_solve_is_the_solve_plus_the_separate_launches(golden, name, shape):
     """One launch against three: positions and info records bit for bit, tangents / metrics / derivatives to rounding."""
     from open_kinematics_amd.metrics import corner_state_metrics
@@ -86,13 +86,17 @@ def test_evaluated_solve_is_the_solve_plus_the_separate_launches(golden, name, s
     dp, program, roles, ridx, mg = _evaluated_program(golden, name)
     arrays, _ = golden(name)
     t = arrays["targets_abs"]
-    kw = {}
+    kw = dict(kernel="quad")
     if shape == "chained":
-        kw = dict(chain_len=7)
+        kw = dict(kernel="quad", chain_len=7)
     if shape == "ragged":
         t = t[:37]
-    plain = dp.solve(t, kernel="quad", **kw)
-    fused = dp.solve_evaluated(t, tangents=True, kernel="quad", **kw)
+    if shape.startswith("lane"):  # one lane per problem: the catalog on duals with all T directions at once
+        assert dp.evaluation & 2, dp.evaluation_note
+        kw = dict(kernel="lane", chain_len=1)
+        t = np.concatenate([t, t[::-1], t])[: 200 if shape == "lane" else 131]
+    plain = dp.solve(t, **kw)
+    fused = dp.solve_evaluated(t, tangents=True, **kw)
     torch.cuda.synchronize()
     assert torch.equal(plain.positions, fused.positions)
     assert torch.equal(plain.info_raw, fused.info_raw)
@@ -112,24 +116,25 @@ def test_evaluated_solve_is_the_solve_plus_the_separate_launches(golden, name, s
     assert np.array_equal(fi["flags"], ti["flags"])
     assert np.allclose(fi["min_pivot"], ti["min_pivot"], rtol=1e-9) and np.allclose(fi["max_pivot"], ti["max_pivot"], rtol=1e-9)
     # metrics only: nothing of the positions is written
-    lean = dp.solve_evaluated(t, output="none", kernel="quad", **kw)
+    lean = dp.solve_evaluated(t, output="none", **kw)
     torch.cuda.synchronize()
     assert lean.positions is None and lean.tangents is None
     assert torch.equal(torch.nan_to_num(lean.eval), torch.nan_to_num(fused.eval))
 
 
-def test_evaluated_ensemble_uses_each_geometrys_own_design_references(golden):
+@pytest.mark.parametrize("kernel", ["quad", "lane"])
+def test_evaluated_ensemble_uses_each_geometrys_own_design_references(golden, kernel):
     """Geometry tables: wheel travel is measured from every geometry's own design state."""
     from open_kinematics_amd.metrics import METRIC_NAMES, corner_state_metrics
 
     dp, program, roles, ridx, mg = _evaluated_program(golden, "c1_dw_corner")
     rng = np.random.default_rng(3)
-    g, s = 5, 16
+    g, s = (5, 16) if kernel == "quad" else (3, 70)
     hard = np.repeat(program.design_pos[None], g, axis=0) + rng.normal(0.0, 0.5, size=(g, program.n_points, 3))
     gpos, grow = dp.rebind(hard)
     rel = np.stack([np.zeros(s), np.linspace(-30.0, 40.0, s)], axis=1)
     targets = dp.ensemble_targets(gpos, rel)
-    kw = dict(geom_pos=gpos, geom_row_param=grow, steps_per_geometry=s, kernel="quad")
+    kw = dict(geom_pos=gpos, geom_row_param=grow, steps_per_geometry=s, kernel=kernel, chain_len=1)
     plain = dp.solve(targets, **kw)
     fused = dp.solve_evaluated(targets, tangents=True, **kw)
     torch.cuda.synchronize()
