@@ -247,7 +247,7 @@ def dropin_program(initial_state, constraints, sweep_config, derived_manager, so
 
 
 def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_manager,
-                           solver_config=SolverConfig(), *, output_points=None, device=None):
+                           solver_config=SolverConfig(), *, output_points=None, device=None, evaluation=None):
     """
     Solve every step of a sweep on the GPU (reference ``solver.py:654-776``).
 
@@ -256,19 +256,34 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     whose worst residual exceeds ``residual_tolerance`` — with the reference's messages.
     ``output_points`` (extension, default ``None`` = every point like the reference, ``solver.py:763``)
     restricts the returned states to those point keys.
+    ``evaluation`` (extension; what ``sweep.solve_evaluated_sweep`` passes): a callable ``program -> (okx_corner_roles,
+    want_tangents)``.  The launch that solves the sweep then also evaluates it (``okx_solve_evaluated_batch``: tangents
+    and metrics as the solve kernel's epilogue) and a third value is returned: ``(program, EvaluatedResult)``, or ``None``
+    when this sweep had to be solved without (no evaluated kernels for the program, target rows that change between steps).
     """
     import torch
 
     cfg = _coerce_config(solver_config)
+    with_extra = (lambda states, infos, extra=None: (states, infos, extra)) if evaluation is not None else (lambda states, infos, extra=None: (states, infos))
     if sweep_config.n_steps == 0:
-        return [], []
+        return with_extra([], [])
     segments = target_segments(sweep_config)
     if len(segments) > 1:
-        return _solve_sweep_in_runs(initial_state, constraints, sweep_config, derived_manager, cfg, segments,
-                                    output_points, device)
+        return with_extra(*_solve_sweep_in_runs(initial_state, constraints, sweep_config, derived_manager, cfg, segments,
+                                                output_points, device))
     program, table = dropin_program(initial_state, constraints, sweep_config, derived_manager, cfg, output_points)
     dp = _device_program(program, device)
     n_steps = table.shape[0]
+    solve, evaluated = dp.solve, None
+    if evaluation is not None and program.n_targets > 0:
+        try:
+            roles, want_tangents = evaluation(program)
+            dp.enable_evaluation(roles)
+
+            def solve(targets, **kw):  # noqa: F811 - the same launch, ending in the evaluation epilogue
+                return dp.solve_evaluated(targets, tangents=want_tangents, **kw)
+        except (ValueError, RuntimeError):  # no evaluated kernels for this program: solve now, evaluate after
+            solve = dp.solve
     solve_kw = dict(max_iter=cfg.max_iter, residual_tolerance=cfg.residual_tolerance, predictor=False,
                     **device_tolerances(cfg, program))  # (one sweep = a few chains or explicit cold starts: nothing for a fitted model to save)
     targets = torch.as_tensor(table)
@@ -280,7 +295,7 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
         # is therefore cut into a few chains that run side by side (chain heads start at the design state) and the
         # result is kept only if it is what the sequential warm start would have produced: every step accepted and
         # every chain head where the extrapolation of the chain before it says it should be.
-        result = dp.solve(targets, chain_len=segment, **solve_kw)
+        result = solve(targets, chain_len=segment, **solve_kw)
         positions = result.positions.cpu().numpy()
         info = result.info()
         positions_from_segments = True
@@ -288,7 +303,7 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
             positions = info = None
             positions_from_segments = False
     if positions is None:
-        result = dp.solve(targets, chain=bool(cfg.warm_start), **solve_kw)
+        result = solve(targets, chain=bool(cfg.warm_start), **solve_kw)
         # one D2H copy each; .cpu() synchronises with the launch stream
         positions = result.positions.cpu().numpy()
         info = result.info()
@@ -296,7 +311,9 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
             positions_from_segments, segment = True, 1  # every step is a chain head
     _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg)
     states = _states_from_positions(initial_state, program, positions)
-    return states, _solver_infos(info, dp, segment if positions_from_segments else n_steps)
+    if solve is not dp.solve:
+        evaluated = (program, result)
+    return with_extra(states, _solver_infos(info, dp, segment if positions_from_segments else n_steps), evaluated)
 
 
 def _solver_infos(info: np.ndarray, dp, chain_len: int) -> list:

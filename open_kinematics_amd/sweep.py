@@ -103,21 +103,22 @@ def _none_if_nan(value: float):
     return None if value != value else float(value)
 
 
-def _driver_ratio(response_rate, tangents, driver_idx: int, axis: int, candidates, column: str = ""):
+def _driver_ratio(response_rate, driver_rate, candidates, column: str = ""):
     """
     ``DerivativeMetricDefinition.select_tangent`` + ``evaluate`` (``metrics/derivatives.py:265-320``) for a whole
     batch: along the candidate target whose tangent moves the driver coordinate most, response rate / driver rate.
-    ``response_rate [B, T]``, ``tangents [B, T, n_out, 3]`` -> ``[B]`` (NaN where no candidate drives it).  Two
-    candidates of equal strength (within ``EPS_GEOMETRIC``) are the reference's "Ambiguous derivative driver"
+    ``response_rate [B, T]``, ``driver_rate [B, T]`` (the driver coordinate's velocity along every target's tangent:
+    ``tangents[:, :, point, axis]``, or the evaluated solve's rate columns) -> ``[B]`` (NaN where no candidate drives
+    it).  Two candidates of equal strength (within ``EPS_GEOMETRIC``) are the reference's "Ambiguous derivative driver"
     ``ValueError`` (``derivatives.py:296-305``).
     """
     import torch
 
     b = response_rate.shape[0]
-    if not candidates:
+    if not candidates or driver_rate is None:
         return torch.full((b,), float("nan"), dtype=torch.float64, device=response_rate.device)
     cand = torch.as_tensor(candidates, device=response_rate.device)
-    rates = tangents[:, cand, driver_idx, axis]                       # [B, C]
+    rates = driver_rate[:, cand]                                      # [B, C]
     strength = rates.abs()
     pick = strength.argmax(dim=1, keepdim=True)                       # strongest driver rate
     rate = rates.gather(1, pick).squeeze(1)
@@ -132,28 +133,41 @@ def _driver_ratio(response_rate, tangents, driver_idx: int, axis: int, candidate
     return torch.where(rate.abs() >= EPS_GEOMETRIC, out, torch.full_like(out, float("nan")))
 
 
-def _corner_rows(corner, program, positions, tangents, side=None, rotation=None, actuators=()):
-    """Catalog + topology + derivative columns of one corner for every state -> list of OrderedDict."""
+def _corner_rows(corner, program, positions, tangents, side=None, rotation=None, actuators=(), evaluated=None):
+    """
+    Catalog + topology + derivative columns of one corner for every state -> list of OrderedDict.
+    ``evaluated``: an ``EvaluatedResult`` (``DeviceProgram.evaluate`` / ``solve_evaluated``) that already holds this
+    corner's metric values, derivatives and driver rates - nothing is launched then, and ``tangents`` may be None.
+    """
     from collections import OrderedDict
 
     from .enums import PointID, PointRef
     from .metrics import CATALOG_ORDER, METRIC_NAMES, corner_roles, corner_state_metrics
 
-    roles = corner_roles(corner, program, side)
-    res = corner_state_metrics(roles, positions, tangents)
-    values = res.values.cpu().numpy()
     key = (lambda p: PointRef(side, p)) if side is not None else (lambda p: p)
     out_keys = [program.point_keys[k] for k in program.out_point]
+    rack_point = corner.rack_attachment_point()
+    rack_idx = out_keys.index(key(rack_point)) if rack_point is not None else -1
+    if evaluated is not None:
+        values = evaluated.metrics.cpu().numpy()
+        derivatives, wc_rates = evaluated.derivatives, evaluated.wheel_center_rates
+        rack_rates = evaluated.rack_rates if rack_point is not None else None
+        have_rates = True
+    else:
+        roles = corner_roles(corner, program, side)
+        res = corner_state_metrics(roles, positions, tangents)
+        values = res.values.cpu().numpy()
+        have_rates = tangents is not None
+        derivatives = res.derivatives
+        wc_rates = tangents[:, :, out_keys.index(key(PointID.WHEEL_CENTER)), :] if have_rates else None
+        rack_rates = tangents[:, :, rack_idx, 1] if have_rates and rack_point is not None else None
     columns: "OrderedDict[str, Any]" = OrderedDict((n, values[:, METRIC_NAMES.index(n)]) for n in CATALOG_ORDER)
     rot_names, rot_values, rot_derivs = rotation if rotation is not None else ([], None, None)
     for k, name in enumerate(rot_names):
         columns[name] = rot_values[:, k].cpu().numpy()
-    if tangents is not None:
-        wc = out_keys.index(key(PointID.WHEEL_CENTER))
+    if have_rates:
         tgt_keys = [program.point_keys[p] for p in program.tgt_point]
         hub = [t for t, k in enumerate(tgt_keys) if k == key(PointID.WHEEL_CENTER)]
-        rack_point = corner.rack_attachment_point()
-        rack_idx = out_keys.index(key(rack_point)) if rack_point is not None else -1
         # a shared actuator (the axle's rack) drives both corners: its targets count for either side
         # (metrics/main.py:103-148 _corner_tangents / _local_tangent_target)
         rack_keys = {key(rack_point)} if rack_point is not None else set()
@@ -161,24 +175,24 @@ def _corner_rows(corner, program, positions, tangents, side=None, rotation=None,
             if rack_keys & set(actuator.point_keys):
                 rack_keys |= set(actuator.point_keys)
         rack = [t for t, k in enumerate(tgt_keys) if k in rack_keys]
-        drivers = {"hub_z": (wc, 2, hub), "rack_displacement": (rack_idx, 1, rack)}
+        drivers = {"hub_z": (wc_rates[:, :, 2], hub), "rack_displacement": (rack_rates, rack)}
 
         def add(response: str, driver: str, rate):
-            idx, axis, cand = drivers[driver]
+            driver_rate, cand = drivers[driver]
             column = f"deriv_{response}_wrt_{driver}"
-            columns[column] = _driver_ratio(rate, tangents, idx, axis, cand, column).cpu().numpy()
+            columns[column] = _driver_ratio(rate, driver_rate, cand, column).cpu().numpy()
 
         for response, driver in _CORNER_DERIVATIVES:
             if driver == "rack_displacement" and rack_point is None:
                 continue  # catalog.py: rack-driven derivatives are omitted without a steering rack
-            rate = tangents[:, :, wc, 0] if response == "wheel_center_x" else res.derivatives[:, :, METRIC_NAMES.index(response)]
+            rate = wc_rates[:, :, 0] if response == "wheel_center_x" else derivatives[:, :, METRIC_NAMES.index(response)]
             add(response, driver, rate)
         # topology declarations (corner/double_wishbone.py, macpherson.py:224-245): actuation first, then the spring
         for k, name in enumerate(rot_names):
             if name == "rocker_angle":
                 add(name, "hub_z", rot_derivs[:, :, k])
         if corner.damper_points() is not None:
-            add("damper_length", "hub_z", res.derivatives[:, :, METRIC_NAMES.index("damper_length")])
+            add("damper_length", "hub_z", derivatives[:, :, METRIC_NAMES.index("damper_length")])
         for k, name in enumerate(rot_names):
             if name != "rocker_angle":
                 add(name, "hub_z", rot_derivs[:, :, k])
@@ -211,14 +225,27 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
     out_keys = [program.point_keys[k] for k in program.out_point]
     positions = torch.as_tensor(_positions_array(states, out_keys), device=dp.device)
     tangents = None
+    is_axle = hasattr(suspension, "corners")
+    names, roles = topology_rotation_roles(suspension, program)
+    if not is_axle and program.n_targets > 0:
+        # a corner: tangents -> catalog -> derivatives in ONE launch (okx_evaluate_batch, the solve kernels' evaluation
+        # epilogue on given states); the tangents themselves are only materialised for a topology's rotation metrics
+        evaluated = _evaluate_states(dp, suspension, program, positions, want_tangents=bool(names))
+        if evaluated is not None:
+            from .sensitivity import solve_infos_from_records
+
+            rot_values = rot_derivs = None
+            if names:
+                rot_values, rot_derivs = axis_rotation_metrics(roles, positions, evaluated.tangents)
+            rows = _corner_rows(suspension, program, positions, evaluated.tangents, None, (names, rot_values, rot_derivs),
+                                evaluated=evaluated)
+            return SweepMetricsResult(rows, None, solve_infos_from_records(evaluated.tangent_info(), program.n_vars))
     if program.n_targets > 0:
         try:
             tangents, tinfo = dp.tangents(positions)
             tangent_infos = solve_infos_from_records(dp.tangent_info(tinfo), program.n_vars)
         except Exception as error:  # noqa: BLE001 - metrics degrade without derivatives (core/sweep.py:155-160)
             derivative_error = f"{type(error).__name__}: {error}"
-    is_axle = hasattr(suspension, "corners")
-    names, roles = topology_rotation_roles(suspension, program)
     rot_values = rot_derivs = None
     if names:
         rot_values, rot_derivs = axis_rotation_metrics(roles, positions, tangents)
@@ -253,7 +280,7 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
             key = PointRef(side, PointID.WHEEL_CENTER)
             cand = [t for t, k in enumerate(tgt_keys) if k == key]
             column = f"deriv_{response}_wrt_hub_z_{side.name.lower()}"
-            columns[column] = _driver_ratio(rate, tangents, out_keys.index(key), 2, cand, column).cpu().numpy()
+            columns[column] = _driver_ratio(rate, tangents[:, :, out_keys.index(key), 2], cand, column).cpu().numpy()
         return columns
 
     # the shared hardware's state metrics, then its derivative columns: anti-roll bar first, heave link second
@@ -284,3 +311,116 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
         for side, col in arm_values.items():
             row.corners[side]["arb_arm_angle"] = _none_if_nan(col[s])
     return SweepMetricsResult(rows, derivative_error, tangent_infos)
+
+
+def _evaluate_states(dp, suspension, program, positions, want_tangents: bool):
+    """``DeviceProgram.evaluate`` for a corner whose program has evaluated kernels; None when it has none (the callers
+    then run tangents and metrics as separate launches)."""
+    from .metrics import corner_roles
+
+    try:
+        dp.enable_evaluation(corner_roles(suspension, program))
+    except (ValueError, RuntimeError):  # no single-mode quad kernel, a role point outside the outputs, no compiler ...
+        return None
+    return dp.evaluate(positions, tangents=want_tangents)
+
+
+# --------------------------------------------------------------------------------------
+# the evaluated sweep (reference core/sweep.py:91-113, :217-270)
+# --------------------------------------------------------------------------------------
+
+
+class DerivativeIssue:
+    """The advisory the reference attaches when the tangent computation failed or met a rank-deficient system
+    (``core/sweep.py:176-214`` ``_derivative_issues``; its ``DiagnosticIssue`` fields, category ``derivatives``)."""
+
+    category = "derivatives"
+    severity = "warning"
+
+    def __init__(self, step, message: str, value=None):
+        self.step, self.message, self.value = step, message, value
+
+    def __repr__(self) -> str:
+        return f"DerivativeIssue(step={self.step!r}, message={self.message!r}, value={self.value!r})"
+
+
+class EvaluatedSweep:
+    """
+    ``core/sweep.py:91-113``: solved states, solver statistics and metric rows of one sweep, the same length each.
+    ``diagnostics`` carries the derivative advisories only: the reference's sweep diagnostics (``core/diagnostics.py``)
+    are outside this package's scope.
+    """
+
+    def __init__(self, states, solver_stats, metrics, diagnostics):
+        lengths = (len(states), len(solver_stats), len(metrics.rows))
+        if len(set(lengths)) != 1:
+            raise ValueError("Evaluated sweep state, solver-stat, and metric counts must match: "
+                             f"{lengths[0]} states, {lengths[1]} solver stats, {lengths[2]} metric rows.")
+        self.states, self.solver_stats, self.metrics, self.diagnostics = states, solver_stats, metrics, diagnostics
+
+
+def _derivative_issues(result: SweepMetricsResult) -> list:
+    """``core/sweep.py:176-214``."""
+    issues = []
+    if result.derivative_error is not None:
+        issues.append(DerivativeIssue(None, "Derivative metrics unavailable: tangent computation failed "
+                                            f"({result.derivative_error}); derivative columns are omitted."))
+    infos = result.tangent_solve_infos or []
+    deficient = [step for step, info in enumerate(infos) if info.rank_deficient]
+    if deficient:
+        first = deficient[0]
+        min_sv = min(infos[step].smallest_singular_value for step in deficient)
+        issues.append(DerivativeIssue(
+            first, f"Tangent system rank-deficient at {len(deficient)} of {len(infos)} steps (first at step {first}, rank "
+                   f"{infos[first].rank}/{infos[first].n_variables}, smallest singular value {min_sv:.3g}); derivative "
+                   "values may not be unique.", min_sv))
+    return issues
+
+
+def evaluate_solved_sweep(suspension, sweep_config, states, solver_stats, *, device=None) -> EvaluatedSweep:
+    """
+    Drop-in for ``kinematics.core.sweep.evaluate_solved_sweep`` (``core/sweep.py:217-245``): metric rows and the
+    derivative advisories of an already solved sweep.  For a corner the tangents, the catalog and its derivative columns
+    are ONE kernel launch on the given states (``okx_evaluate_batch``).
+    """
+    if len(states) != len(solver_stats):
+        raise ValueError(f"Solved state and solver-stat counts must match: {len(states)} states, {len(solver_stats)} solver stats.")
+    metrics = compute_sweep_metrics(suspension, sweep_config, states, device=device)
+    return EvaluatedSweep(states, solver_stats, metrics, _derivative_issues(metrics))
+
+
+def solve_evaluated_sweep(suspension, sweep_config, solver_config: SolverConfig = SolverConfig(), *, device=None) -> EvaluatedSweep:
+    """
+    Drop-in for ``kinematics.core.sweep.solve_evaluated_sweep`` (``core/sweep.py:248-270``): solve one sweep and compute
+    its metric rows.  For a corner whose program has evaluated kernels the whole of it - every step's solve, its
+    solution-manifold tangents, the metric catalog and the derivative columns - is ONE kernel launch
+    (``okx_solve_evaluated_batch``: the tangents and metrics are the solve kernel's epilogue, taken at the converged state
+    while it is still in registers); axles and programs without such kernels solve first and evaluate after
+    (``evaluate_solved_sweep``).  Same states, same error behaviour as ``solve_sweep``.
+    """
+    from .metrics import axis_rotation_metrics, corner_roles, topology_rotation_roles
+    from .sensitivity import solve_infos_from_records
+
+    validate_sweep_controls(sweep_config, suspension.actuator_dofs())
+    fused = not hasattr(suspension, "corners") and getattr(suspension, "config", True) is not None and sweep_config.n_steps > 0
+    if fused:
+        def roles_of(program):
+            return corner_roles(suspension, program), bool(topology_rotation_roles(suspension, program)[0])
+
+        states, stats, extra = solve_suspension_sweep(
+            initial_state=suspension.initial_state(), constraints=suspension.constraints(), sweep_config=sweep_config,
+            derived_manager=suspension.derived_spec(), solver_config=solver_config, device=device, evaluation=roles_of)
+        if extra is not None:
+            program, evaluated = extra
+            names, roles = topology_rotation_roles(suspension, program)
+            rot_values = rot_derivs = None
+            positions = evaluated.positions
+            if names:
+                rot_values, rot_derivs = axis_rotation_metrics(roles, positions, evaluated.tangents)
+            rows = _corner_rows(suspension, program, positions, evaluated.tangents, None, (names, rot_values, rot_derivs),
+                                evaluated=evaluated)
+            metrics = SweepMetricsResult(rows, None, solve_infos_from_records(evaluated.tangent_info(), program.n_vars))
+            return EvaluatedSweep(states, stats, metrics, _derivative_issues(metrics))
+    else:
+        states, stats = solve_sweep(suspension, sweep_config, solver_config, device=device)
+    return evaluate_solved_sweep(suspension, sweep_config, states, stats, device=device)

@@ -170,3 +170,37 @@ def test_evaluated_entry_points_fail_loudly(golden):
     axle_dp = DeviceProgram(axle.with_line_mode("pinned"), "cuda:0")
     with pytest.raises(ValueError, match="single-mode quad kernel"):
         axle_dp.enable_evaluation(roles)
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid", "t_corner_rocker"])
+def test_solve_evaluated_sweep_is_solve_sweep_plus_compute_sweep_metrics(golden, name):
+    """The drop-in (core/sweep.py:248-270): same states and statistics as solve_sweep, the rows of compute_sweep_metrics
+    on those states - from ONE launch for a corner (a rocker corner's rotation metrics take a second, on the tangents)."""
+    import yaml
+
+    from open_kinematics_amd.input import build_suspension, build_sweep
+    from open_kinematics_amd.sweep import EvaluatedSweep, compute_sweep_metrics, evaluate_solved_sweep, solve_evaluated_sweep, solve_sweep
+
+    arrays, _ = golden(name)
+    sus = build_suspension(yaml.safe_load(str(arrays["geometry_yaml"])))
+    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)
+    states, stats = solve_sweep(sus, sweep)
+    ref = compute_sweep_metrics(sus, sweep, states)
+    ev = solve_evaluated_sweep(sus, sweep)
+    assert isinstance(ev, EvaluatedSweep) and len(ev.states) == len(states) == len(ev.solver_stats) == len(ev.metrics.rows)
+    assert ev.diagnostics == [] and ev.metrics.derivative_error is None
+    for a, b in zip(states, ev.states):
+        for key, p in a.positions.items():
+            assert np.array_equal(np.asarray(p.data), np.asarray(b.positions[key].data)), key
+    assert [(s.converged, s.nfev) for s in stats] == [(s.converged, s.nfev) for s in ev.solver_stats]
+    assert list(ev.metrics.rows[0]) == list(ref.rows[0])
+    for got, want in zip(ev.metrics.rows, ref.rows):
+        for key, value in want.items():
+            if value is None:
+                assert got[key] is None, key
+            else:
+                assert abs(got[key] - value) <= 1e-7 * max(1.0, abs(value)), key
+    again = evaluate_solved_sweep(sus, sweep, states, stats)
+    assert [list(r.items()) for r in again.metrics.rows] == [list(r.items()) for r in ref.rows]
+    with pytest.raises(ValueError, match="counts must match"):
+        evaluate_solved_sweep(sus, sweep, states, stats[:-1])
