@@ -8,7 +8,8 @@ the one launch of okx_solve_evaluated_batch (the epilogue of the solve kernels),
   c2   BASELINE config 2: one 16384-step sweep of the program's own geometry (quad cold body)
   c4   the MacPherson 512 x 512 grid (lane kernels, own geometry)
 
-  python tools/evaluated_rates.py [c5 c2 c4] [--reps 20]
+  python tools/evaluated_rates.py [c5 c2 c4] [--reps 20] [--only evaluated_metrics_only]   (one row: what
+                                                                 tools/profile_run.sh wraps in rocprofv3)
 """
 
 from __future__ import annotations
@@ -36,7 +37,7 @@ def ev_ms(fn, device, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def measure(which: str, device, reps: int) -> dict:
+def measure(which: str, device, reps: int, only: str = "") -> dict:
     from open_kinematics_amd.batch import DeviceProgram
     from open_kinematics_amd.input import load_geometry
     from open_kinematics_amd.metrics import corner_roles, corner_state_metrics
@@ -69,6 +70,11 @@ def measure(which: str, device, reps: int) -> dict:
     evb = torch.empty((n, 1 + T, 24), dtype=torch.float64, device=device)
     skw = dict(chain_len=1, predictor=False, **kw)
     rows = {}
+    if only == "evaluated_metrics_only":
+        rows[only] = ev_ms(dp.plan_evaluated(targets, info_out=info, eval_out=evb, output="none", **skw), device, reps)
+        return {"workload": which, "states": n, "ms": rows, "states_per_s": {k: n / v * 1e3 for k, v in rows.items()},
+                "roofline": {"kernel_ms": rows[only]},  # (the field tools/save_profile.py reads)
+                "algorithmic_bytes_per_state": 8 * T + 8 * 24 * (1 + T) + 16}
     solve = dp.plan(targets, out=out, info_out=info, **skw)
     rows["solve_records"] = ev_ms(solve, device, reps)
     rows["solve_output_none"] = ev_ms(dp.plan(targets, info_out=info, output="none", **skw), device, reps)
@@ -89,13 +95,21 @@ def measure(which: str, device, reps: int) -> dict:
 
 
 def main():
-    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c5", "c2", "c4"]
-    reps = 20
-    if "--reps" in sys.argv:
-        reps = int(sys.argv[sys.argv.index("--reps") + 1])
+    args = sys.argv[1:]
+    reps, only = 20, ""
+    for flag in ("--reps", "--only"):
+        if flag in args:
+            at = args.index(flag)
+            value = args[at + 1]
+            del args[at:at + 2]
+            if flag == "--reps":
+                reps = int(value)
+            else:
+                only = value
+    which = args or ["c5", "c2", "c4"]
     device = torch.device("cuda:0")
     for w in which:
-        print(json.dumps(measure(w, device, reps)), flush=True)
+        print(json.dumps(measure(w, device, reps, only)), flush=True)
 
 
 if __name__ == "__main__":
