@@ -49,7 +49,7 @@ import torch.distributed as dist
 STEPS_PER_RANK = 16384
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor fp64 vector peak, secondary ceiling
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 INFO_FIELDS = np.dtype([("max_residual", "<f8"), ("cost", "<f8"), ("last_step", "<f8"), ("iterations", "<i4"),
                         ("nfev", "<i4"), ("flags", "<i4"), ("reserved", "<i4")])
 
@@ -522,8 +522,10 @@ def measure_e2e_zero_copy(dp, targets_host: np.ndarray, device, steps: int, cold
                     "no H2D / D2H commands at all; never reported as `value`"}
 
 
-def measure_config(name: str, make, device, steps: int, warmup: int, modes=("cold", "chained")) -> dict:
-    """One BASELINE configuration at full size: cold independent solves (section 8d's rule) and the product's chained mode."""
+def measure_config(name: str, make, device, steps: int, warmup: int, modes=("cold", "chained"), roles_geometry: str | None = None) -> dict:
+    """One BASELINE configuration at full size: cold independent solves (section 8d's rule) and the product's chained mode.
+    `roles_geometry` (a corner's geometry file): also the EVALUATED launch - solve + tangents + metric catalog with derivative
+    columns as one kernel (okx_solve_evaluated_batch), against the same as three launches."""
     from open_kinematics_amd.batch import DeviceProgram
 
     t0 = time.perf_counter()
@@ -592,6 +594,11 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
             q_launch = dp.plan(targets, out=out, info_out=info, chain_len=chain_len, predictor=False, kernel="quad", **kw)
             q_wall, q_ms = time_launches(q_launch, steps, warmup, device)
             res[tag]["quad_kernel"] = {"value": n / q_wall, "kernel_ms": q_ms, "lm_evaluations_mean": info_summary(info)[0]}
+    if roles_geometry is not None and dp.kernel == "quad":
+        try:
+            res["evaluated"] = measure_evaluated(dp, roles_geometry, targets, out, info, kw, device, steps, warmup)
+        except Exception as exc:  # (an extra leg must not take the line down with it)
+            res["evaluated"] = {"error": f"{type(exc).__name__}: {exc}"}
     if "cold" in res:
         res["cold"]["start"] = "every problem an independent cold start from its geometry's design state (SURVEY.md section 8d)"
     if "chained" in res:
@@ -601,7 +608,50 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
     return res
 
 
-def measure_downstream(dp, suspension_yaml: str, positions, device, reps: int = 20) -> dict:
+def measure_evaluated(dp, suspension_yaml: str, targets, out, info, kw: dict, device, steps: int, warmup: int) -> dict:
+    """What an EVALUATED state costs (reference core/sweep.py:217-270, solve_evaluated_sweep for a batch): the solve, its
+    solution-manifold tangents and the corner metric catalog with every derivative column - as three launches (the state
+    records written by the solve and re-read twice, the tangents written and re-read) and as ONE (okx_solve_evaluated_batch:
+    tangents and metrics are the solve kernel's epilogue, taken at the converged state while it is in registers;
+    output = none: nothing but the info records and the [1 + T][24] evaluation rows leaves the chip)."""
+    from open_kinematics_amd.input import load_geometry
+    from open_kinematics_amd.metrics import corner_roles, corner_state_metrics
+
+    program = dp.program
+    roles = corner_roles(load_geometry(suspension_yaml), program)
+    dp.enable_evaluation(roles)
+    n, T = targets.shape[0], program.n_targets
+    evb = torch.empty((n, 1 + T, 24), dtype=torch.float64, device=device)
+    skw = dict(chain_len=1, predictor=False, **kw)
+    tkw = {k: v for k, v in kw.items() if k in ("geom_pos", "geom_row_param", "steps_per_geometry")}
+    solve = dp.plan(targets, out=out, info_out=info, **skw)
+    _, solve_ms = time_launches(solve, steps, warmup, device)
+    solve()
+    tan, _ = dp.tangents(out, **tkw)
+    _, tan_ms = time_launches(lambda: dp.tangents(out, **tkw), steps, warmup, device)
+    _, met_ms = time_launches(lambda: corner_state_metrics(roles, out, tan), steps, warmup, device)
+    del tan
+    fused = dp.plan_evaluated(targets, info_out=info, eval_out=evb, output="none", **skw)
+    wall, fused_ms = time_launches(fused, steps, warmup, device)
+    nfev, ok = info_summary(info)
+    _, fused_rec_ms = time_launches(dp.plan_evaluated(targets, out=out, info_out=info, eval_out=evb, **skw), steps, warmup, device)
+    flags = evb[:, 0, 21]
+    bytes_out = 8 * T + 8 * 24 * (1 + T) + 16
+    return {"unit": "evaluated states/s", "value": n / (fused_ms * 1e-3), "kernel_ms": fused_ms, "wall_value": n / wall,
+            "kernel": "lane form (one lane per problem, duals with all target directions)" if dp.evaluation & 2 and n >= max(dp.lane_threshold, 1)
+                      else "quad form (lane c of a quad evaluates direction c - 1)",
+            "with_records_kernel_ms": fused_rec_ms,
+            "three_launches": {"solve_ms": solve_ms, "tangents_ms": tan_ms, "metrics_with_derivatives_ms": met_ms,
+                               "total_ms": solve_ms + tan_ms + met_ms, "value": n / ((solve_ms + tan_ms + met_ms) * 1e-3)},
+            "speedup": (solve_ms + tan_ms + met_ms) / fused_ms, "all_converged": ok, "lm_evaluations_mean": nfev,
+            "tangent_solves_ok": bool((flags == 1.0).all().item()),
+            "algorithmic_bytes_per_state": bytes_out, "algorithmic_gbs": bytes_out * n / (fused_ms * 1e-3) / 1e9,
+            "hbm_frac": bytes_out * n / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "HIP events; output = none: 8 T in, 24 (1 + T) doubles + 16 B of info out per state (the three-launch path moves "
+                    "24 n_out (2 + 2 T) + 152 (1 + T) B per state through HBM); issue-bound like the solve"}
+
+
+def measure_downstream(dp, suspension_yaml: str, positions, device, reps: int = 20, sweep_targets=None) -> dict:
     """The callers after the solve on the same 16384 solved states, each one launch: solution-manifold
     tangents (okx_tangent_batch) and the corner metric catalog with its derivative columns (okx_corner_metrics_batch)."""
     from open_kinematics_amd.input import load_geometry
@@ -657,6 +707,24 @@ def measure_downstream(dp, suspension_yaml: str, positions, device, reps: int = 
         row("tangents", ev(lambda: dp.tangents(big)), 24 * n_out * (1 + T) + 24)
         row("corner_metrics", ev(lambda: corner_state_metrics(roles, big, None)), 24 * n_out + 152)
         row("corner_metrics_with_derivatives", ev(lambda: corner_state_metrics(roles, big, tan_big)), 24 * n_out * (1 + T) + 152 * (1 + T))
+        del tan_big
+        # ... and the same evaluation as the solve kernel's epilogue: one launch from targets to metric / derivative rows
+        # (the sweep's targets tiled to a million problems of the own geometry; the ensemble form - per-geometry tables,
+        # BASELINE config 5 itself - is other_configs[C5].evaluated)
+        try:
+            dp.enable_evaluation(roles)
+            big_t = sweep_targets.repeat(reps_of, 1)[:n_big].contiguous()
+            info_big = torch.empty((n_big, 40), dtype=torch.uint8, device=device)
+            evb = torch.empty((n_big, 1 + T, 24), dtype=torch.float64, device=device)
+            solve_ms = ev(dp.plan(big_t, out=out, info_out=info_big, chain_len=1, predictor=False))
+            row("solve_records", solve_ms, 8 * T + 24 * n_out + 16)
+            row("evaluated_one_launch", ev(dp.plan_evaluated(big_t, info_out=info_big, eval_out=evb, output="none", chain_len=1, predictor=False)),
+                8 * T + 8 * 24 * (1 + T) + 16)
+            three = solve_ms + rows["tangents"]["ms"] + rows["corner_metrics_with_derivatives"]["ms"]
+            rows["evaluated_three_launches"] = {"ms": three, "states_per_s": n_big / three * 1e3}
+            rows["evaluated_one_launch"]["speedup_over_three_launches"] = three / rows["evaluated_one_launch"]["ms"]
+        except Exception as exc:  # noqa: BLE001
+            rows["evaluated_one_launch"] = {"error": f"{type(exc).__name__}: {exc}"}
         return {"states": n_big, "rows": rows,
                 "note": "HIP events around 10 launches each, the sweep's states tiled to a million; bound: HBM for expand / corner_metrics "
                         "(a torch copy of the records is the practical ceiling), fp64 issue for tangents and the derivative columns"}
@@ -1078,14 +1146,15 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         #  gone with the cold body's staged stores, profiles/r04/EXPERIMENTS.md section 5)
         line["e2e"]["zero_copy"] = measure_e2e_zero_copy(dp, targets_all[lo:hi], device, 200, dict(chain_len=args.chain_len, predictor=False))
         from open_kinematics_amd.workloads import geometry_path
-        line["downstream"] = measure_downstream(dp, geometry_path("geometry.yaml"), pipe.solve_buffers[0], device)
+        line["downstream"] = measure_downstream(dp, geometry_path("geometry.yaml"), pipe.solve_buffers[0], device, sweep_targets=targets)
         dp.close()
         line["other_configs"] = [
             measure_config("C3 rocker + U-bar axle, 256x256 heave x roll grid (n = 60, pair mode)",
                            lambda: axle_grid_problem(256, 256), device, 20, 3),
-            measure_config("C4 MacPherson corner, 512x512 bump x rack grid", lambda: macpherson_grid_problem(512, 512), device, 20, 3),
+            measure_config("C4 MacPherson corner, 512x512 bump x rack grid", lambda: macpherson_grid_problem(512, 512), device, 20, 3,
+                           roles_geometry=geometry_path("macpherson_geometry.yaml")),
             measure_config("C5 4096 perturbed double-wishbone geometries x 256-step bump sweep (one GPU)",
-                           lambda: ensemble_problem(4096, 256), device, 20, 3),
+                           lambda: ensemble_problem(4096, 256), device, 20, 3, roles_geometry=geometry_path("geometry.yaml")),
         ]
         line["dropin"] = measure_dropin(device)
     if world == 1 and not args.no_cpu_baseline:
