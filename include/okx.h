@@ -596,11 +596,15 @@ int32_t okx_program_shares_first_step(const okx_program* prog);
 int32_t okx_program_has_cold_body(const okx_program* prog);
 /* Tiered start.  okx_program_create loads a program's generated kernels when the kernel cache holds them (what
  * okx_precompile and __graft_entry__.build() are for).  When it does not, the call still returns at once: a host thread
- * runs the compiler (10 ... 80 s per module) while the interpreter kernels solve - same answers to 1e-9 mm, 20 ... 100 x
- * slower - and the first launch after the job has finished switches the program over to the generated kernels (never in
- * the middle of a launch, never blocking a stream).  okx_program_ready returns 1 when nothing is pending any more and 0
- * while the job runs; wait != 0 blocks until it has finished and switches over before returning (benchmarks and tests
- * that must know which kernel they time).  okx_program_kernel() / okx_program_kernel_note() report the current state. */
+ * runs the compiler (10 ... 80 s per module; it owns its inputs, so destroying the program does not wait for it) while the
+ * interpreter kernels solve - same answers to 1e-9 mm, 20 ... 100 x slower - and the first launching call after the job
+ * has finished switches the program over: it loads the job's code objects from memory (a few milliseconds on the calling
+ * thread; never the compiler, never a synchronise of the legacy stream) while holding the program's kernel state
+ * exclusively - launches of the same program from other threads wait for it, launches in progress finish first.  A call
+ * whose stream is recording a HIP graph never switches over (module loads are illegal in a capture): the interpreter
+ * serves it and a later call does.  okx_program_ready returns 1 when nothing is pending any more and 0 while the job
+ * runs; wait != 0 blocks until it has finished and switches over before returning (benchmarks and tests that must know
+ * which kernel they time).  okx_program_kernel() / okx_program_kernel_note() report the current state. */
 int32_t okx_program_ready(okx_program* prog, int32_t wait);
 
 /* Generated source of a program's quad kernel (no device needed).  Copies at most buflen - 1

@@ -12,6 +12,7 @@
 #include <functional>
 #include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -66,9 +67,23 @@ struct okx_program {
   // Tiered start.  A program whose generated kernels are not in the kernel cache is served by the interpreter kernels
   // while a host thread runs the compiler (hiprtc: no device call on that thread); the first entry point that finds the
   // job finished loads the code objects and switches the program over, under `head_mutex`.  Null: nothing pending.
-  struct JitJob { std::thread thread; std::atomic<int> finished{0}; };
-  JitJob* jit;
+  // The job owns everything it touches (its own copy of the host program, the code objects it produced): the program may
+  // be destroyed while the compiler runs, and the switch-over loads the job's results from memory - the kernel cache on disk
+  // is only a cache (a read-only cache directory must not cost a second compile).
+  struct JitJob {
+    std::thread thread;
+    std::atomic<int> finished{0};
+    okx::DevProgram host;
+    bool want_quad = false, want_lane = false;   // what was not in the cache at create
+    bool quad_ok = false, lane_ok = false;
+    std::string quad_code, quad_why, lane_code, lane_why;
+    std::vector<okx::LaneOverride> lane_overrides;
+  };
+  std::atomic<JitJob*> jit;
   std::mutex* jit_mutex;
+  // Generated-kernel state (module handles, function pointers, notes) is read by every launching entry point under a
+  // shared lock and rewritten by the switch-over / okx_program_enable_evaluation under the exclusive one.
+  std::shared_mutex* kern_mutex;
   double* head_geom_dev;    // scratch table of the latest launch with geometry tables (grow-only)
   long long head_geom_cap;  // geometries it holds
   double* quad_trace;            // diagnostic hook, see okx_debug_quad_trace (null: off)
@@ -278,7 +293,8 @@ int own_head_table(okx_program* p, double lambda0, hipStream_t stream, double** 
 // okx_program_kernel_note() says why.
 // `cache_only`: only what the kernel cache already holds (okx_program_create); a miss sets *pending and leaves the
 // interpreter kernels in charge until the compile job has filled the cache.
-void attach_quad_kernel(okx_program* p, bool cache_only = false, bool* pending = nullptr) {
+// `job`: the compile job's results (switch-over): the code object comes from memory, the compiler is never run here.
+void attach_quad_kernel(okx_program* p, bool cache_only = false, bool* pending = nullptr, const okx_program::JitJob* job = nullptr) {
   p->quad_mod = nullptr;
   p->quad_fn_u = p->quad_fn_g = nullptr;
   p->quad_fn_cold_u = nullptr;
@@ -293,7 +309,14 @@ void attach_quad_kernel(okx_program* p, bool cache_only = false, bool* pending =
     return;
   }
   std::string src, why, code;
-  if (!okx::quad_build(p->host, quad_waves_per_simd(), &src, &code, &why, false, cache_only)) {
+  if (job) {
+    if (!job->quad_ok) {
+      std::snprintf(p->quad_note, sizeof(p->quad_note), "not generated: %.200s", job->quad_why.c_str());
+      if (getenv("OKX_VERBOSE")) std::fprintf(stderr, "okx: quad kernel: %s\n", job->quad_why.c_str());
+      return;
+    }
+    code = job->quad_code;
+  } else if (!okx::quad_build(p->host, quad_waves_per_simd(), &src, &code, &why, false, cache_only)) {
     if (cache_only && why == okx::kNotCached) {
       if (pending) *pending = true;
       std::snprintf(p->quad_note, sizeof(p->quad_note), "being compiled (the interpreter kernels serve the program until then)");
@@ -305,7 +328,7 @@ void attach_quad_kernel(okx_program* p, bool cache_only = false, bool* pending =
   }
   hipModule_t mod = nullptr;
   hipError_t e = hipModuleLoadData(&mod, code.data());
-  if (e != hipSuccess) {
+  if (e != hipSuccess && !job) {
     // a damaged cache entry (truncated file, other toolchain): rebuild it once
     (void)hipGetLastError();
     if (okx::quad_build(p->host, quad_waves_per_simd(), &src, &code, &why, true)) e = hipModuleLoadData(&mod, code.data());
@@ -346,13 +369,18 @@ void attach_quad_kernel(okx_program* p, bool cache_only = false, bool* pending =
   (void)hipGetLastError();  // optional kernels absent from a module must not leave a sticky error behind
   p->quad_waves_per_cu = 4 * per_simd;
   // The first-step table of the program's own geometry for the default damping belongs to the program's set-up, like the
-  // kernel itself: filled here, synchronously (one wavefront, ~10 us), so that no solve launch ever pays for it or has to
-  // order itself against it.
+  // kernel itself: filled here (one wavefront, ~10 us) on a private non-blocking stream that is waited for before this
+  // returns - no solve launch ever pays for it, a later stream capture finds it complete, and nothing is ordered against
+  // the legacy stream (a synchronise there would serialise every blocking stream of the process).
   if (p->quad_fn_head_u) {
     okx_solve_opts o;
     okx_default_opts(&o);
     double* unused = nullptr;
-    if (own_head_table(p, o.lambda0, nullptr, &unused) != OKX_OK || hipStreamSynchronize(nullptr) != hipSuccess) {
+    hipStream_t fill = nullptr;
+    bool ok = hipStreamCreateWithFlags(&fill, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && own_head_table(p, o.lambda0, fill, &unused) == OKX_OK && hipStreamSynchronize(fill) == hipSuccess;
+    if (fill) (void)hipStreamDestroy(fill);
+    if (!ok) {
       (void)hipGetLastError();
       p->quad_fn_head_u = p->quad_fn_head_g = nullptr;
     }
@@ -378,7 +406,7 @@ static int lane_worst_scratch(const std::string& code, const std::vector<okx::La
   return worst;
 }
 
-void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending = nullptr) {
+void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending = nullptr, const okx_program::JitJob* job = nullptr) {
   p->lane_mod = nullptr;
   p->lane_extra_mods = nullptr;
   p->lane_fn_u = p->lane_fn_g = p->lane_fn_eval = nullptr;
@@ -398,7 +426,14 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
   }
   std::string src, why, code;
   std::vector<okx::LaneOverride> overrides;
-  if (!okx::lane_build(p->host, &src, &code, &why, false, nullptr, 256, cache_only, &overrides)) {
+  if (job) {
+    if (!job->lane_ok) {
+      std::snprintf(p->lane_note, sizeof(p->lane_note), "not generated: %.200s", job->lane_why.c_str());
+      return;
+    }
+    code = job->lane_code;
+    overrides = job->lane_overrides;
+  } else if (!okx::lane_build(p->host, &src, &code, &why, false, nullptr, 256, cache_only, &overrides)) {
     if (cache_only && why == okx::kNotCached) {
       if (pending) *pending = true;
       std::snprintf(p->lane_note, sizeof(p->lane_note), "being compiled");
@@ -426,7 +461,7 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
   }
   hipModule_t mod = nullptr;
   hipError_t e = hipModuleLoadData(&mod, code.data());
-  if (e != hipSuccess && !cache_only) {
+  if (e != hipSuccess && !cache_only && !job) {
     (void)hipGetLastError();
     if (okx::lane_build(p->host, &src, &code, &why, true, nullptr, 256)) e = hipModuleLoadData(&mod, code.data());
   }
@@ -477,34 +512,70 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
   p->lane_fn_u = lane_u;  // the gate of the lane kernel's launch path, published last
 }
 
-// The compile job of a program whose kernels were not in the cache: fills the cache (same calls, same policy as the
-// attach functions make), touches nothing of the program but its host copy.  No device call on this thread.
-void jit_job(okx_program* p) {
-  std::string src, code, why;
-  if (okx::quad_build(p->host, quad_waves_per_simd(), &src, &code, &why) && p->host.n_free <= okx::kQuadMaxFree &&
-      !okx::dev_switch("no_lane")) {
-    std::string lsrc, lcode, lwhy;
-    (void)okx::lane_build(p->host, &lsrc, &lcode, &lwhy, false, nullptr, 256);
+// The compile job of a program whose kernels were not in the cache: compiles what was missing (same calls, same policy as
+// the attach functions), keeps the results in the job and - through quad_compile - in the cache.  Touches nothing but
+// the job.  No device call on this thread.
+void jit_job(okx_program::JitJob* job) {
+  std::string src;
+  if (job->want_quad) job->quad_ok = okx::quad_build(job->host, quad_waves_per_simd(), &src, &job->quad_code, &job->quad_why);
+  if (job->want_lane && (job->quad_ok || !job->want_quad) && job->host.n_free <= okx::kQuadMaxFree && !okx::dev_switch("no_lane")) {
+    std::string lsrc;
+    job->lane_ok = okx::lane_build(job->host, &lsrc, &job->lane_code, &job->lane_why, false, nullptr, 256, false, &job->lane_overrides);
+  } else if (job->want_lane) {
+    job->lane_why = "no quad kernel to share first-step tables with";
   }
-  p->jit->finished.store(1, std::memory_order_release);
+  job->finished.store(1, std::memory_order_release);
 }
 
+// Jobs of programs that were destroyed while their compiler was still running: joined (and freed) by a later destroy that
+// finds them finished, or at process exit - a short script that drops its program early still leaves a filled cache behind,
+// at the price of waiting for the compiler when it exits.
+std::mutex g_orphan_mutex;
+std::vector<okx_program::JitJob*> g_orphans;
+void reap_orphans(bool wait) {
+  std::lock_guard<std::mutex> lock(g_orphan_mutex);
+  for (size_t k = 0; k < g_orphans.size();) {
+    okx_program::JitJob* job = g_orphans[k];
+    if (!wait && !job->finished.load(std::memory_order_acquire)) {
+      ++k;
+      continue;
+    }
+    job->thread.join();
+    delete job;
+    g_orphans.erase(g_orphans.begin() + (long)k);
+  }
+}
+void reap_orphans_at_exit() { reap_orphans(true); }
+
 // Switches a program over to its generated kernels once the compile job is done (`wait`: block until it is).  Called at
-// the top of every entry point that launches; costs one pointer test when nothing is pending.
-void attach_when_ready(okx_program* p, bool wait) {
-  if (!p->jit) return;
-  if (!wait && !p->jit->finished.load(std::memory_order_acquire)) return;
+// the top of every entry point that launches; costs one atomic load when nothing is pending.  Never while the caller's
+// stream records a graph (`stream` non-null: the launch's stream) - module loads and allocations are illegal inside a
+// capture; the interpreter serves that launch and a later one switches over.
+void attach_when_ready(okx_program* p, bool wait, const hipStream_t* stream = nullptr) {
+  okx_program::JitJob* job = p->jit.load(std::memory_order_acquire);
+  if (!job) return;
+  if (!wait && !job->finished.load(std::memory_order_acquire)) return;
+  if (!wait && stream && stream_is_capturing(*stream)) return;
   std::lock_guard<std::mutex> lock(*p->jit_mutex);
-  if (!p->jit) return;  // another caller got here first
-  okx_program::JitJob* job = p->jit;
+  job = p->jit.load(std::memory_order_acquire);
+  if (!job) return;  // another caller got here first
   job->thread.join();
   int current = p->device;
   (void)hipGetDevice(&current);
   if (current != p->device) (void)hipSetDevice(p->device);
-  attach_quad_kernel(p);  // a cache hit now - or the failure the job met, reported through the notes as usual
-  attach_lane_kernel(p);
+  // (another thread of the process may be capturing in global mode - torch's default: this thread's module loads and
+  //  allocations must not invalidate that capture)
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  const bool exchanged = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+  {
+    std::unique_lock<std::shared_mutex> kernels(*p->kern_mutex);  // launches in progress finish first, later ones see the new set
+    if (job->want_quad) attach_quad_kernel(p, false, nullptr, job);
+    if (job->want_lane) attach_lane_kernel(p, false, nullptr, job);
+  }
+  if (exchanged) (void)hipThreadExchangeStreamCaptureMode(&mode);
+  (void)hipGetLastError();
   if (current != p->device) (void)hipSetDevice(current);
-  p->jit = nullptr;
+  p->jit.store(nullptr, std::memory_order_release);
   delete job;
 }
 
@@ -522,6 +593,8 @@ void release_host_side(okx_program* p) {
   p->head_mutex = nullptr;
   delete p->jit_mutex;
   p->jit_mutex = nullptr;
+  delete p->kern_mutex;
+  p->kern_mutex = nullptr;
 }
 
 int grid_for(const okx_program* p, long long units) {
@@ -572,10 +645,12 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   p->head_tables = new (std::nothrow) std::vector<okx_program::HeadTable>();
   p->head_mutex = new (std::nothrow) std::mutex();
   p->jit_mutex = new (std::nothrow) std::mutex();
-  if (!p->head_tables || !p->head_mutex || !p->jit_mutex) {
+  p->kern_mutex = new (std::nothrow) std::shared_mutex();
+  if (!p->head_tables || !p->head_mutex || !p->jit_mutex || !p->kern_mutex) {
     delete p->head_tables;
     delete p->head_mutex;
     delete p->jit_mutex;
+    delete p->kern_mutex;
     delete p;
     return fail(OKX_ERR_ALLOC, "out of host memory");
   }
@@ -643,21 +718,25 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
   // Generated kernels: loaded here when the kernel cache has them (the usual case: __graft_entry__.build() and
   // okx_precompile fill it).  Otherwise a host thread compiles them (10 ... 80 s per module) while this call returns at
   // once and the interpreter kernels solve; the first launch after the job is done switches the program over.
-  bool pending = false;
-  attach_quad_kernel(p, true, &pending);
-  if (!pending) attach_lane_kernel(p, true, &pending);
-  if (pending) {
-    p->jit = new (std::nothrow) okx_program::JitJob;
-    if (p->jit) {
+  bool pending_quad = false, pending_lane = false;
+  attach_quad_kernel(p, true, &pending_quad);
+  if (!pending_quad) attach_lane_kernel(p, true, &pending_lane);
+  if (pending_quad || pending_lane) {
+    okx_program::JitJob* job = new (std::nothrow) okx_program::JitJob;
+    if (job) {
+      job->host = p->host;
+      job->want_quad = pending_quad;
+      job->want_lane = true;  // (a pending quad kernel means the lane kernel, which shares its tables, was not looked at yet)
       try {
-        p->jit->thread = std::thread(jit_job, p);
+        job->thread = std::thread(jit_job, job);
+        p->jit.store(job, std::memory_order_release);
       } catch (...) {  // no thread to be had: compile here, as before
-        delete p->jit;
-        p->jit = nullptr;
+        delete job;
+        job = nullptr;
       }
     }
-    if (!p->jit) {
-      attach_quad_kernel(p);
+    if (!job) {
+      if (pending_quad) attach_quad_kernel(p);
       attach_lane_kernel(p);
     }
   }
@@ -668,16 +747,28 @@ int32_t okx_program_create(const okx_program_desc* desc, okx_program** out) {
 int32_t okx_program_ready(okx_program* p, int32_t wait) {
   if (!p) return fail(OKX_ERR_INVALID, "null program");
   attach_when_ready(p, wait != 0);
-  return p->jit ? 0 : 1;
+  return p->jit.load(std::memory_order_acquire) ? 0 : 1;
 }
 
 void okx_program_destroy(okx_program* p) {
   if (!p) return;
-  if (p->jit) {  // a compile job still running: let it finish (it fills the cache for the next program), load nothing
-    p->jit->thread.join();
-    delete p->jit;
-    p->jit = nullptr;
+  if (okx_program::JitJob* job = p->jit.exchange(nullptr)) {
+    // a compile job still pending: it owns what it works on, so the program goes now and the job is joined when it has
+    // finished (by a later destroy, or at exit: it still fills the cache for the next program) - never a wait of minutes here
+    if (job->finished.load(std::memory_order_acquire)) {
+      job->thread.join();
+      delete job;
+    } else {
+      std::lock_guard<std::mutex> lock(g_orphan_mutex);
+      static bool registered = false;
+      if (!registered) {
+        registered = true;
+        std::atexit(reap_orphans_at_exit);
+      }
+      g_orphans.push_back(job);
+    }
   }
+  reap_orphans(false);
   if (p->ev_mod) (void)hipModuleUnload(p->ev_mod);
   if (p->ev_lane_mod) (void)hipModuleUnload(p->ev_lane_mod);
   if (p->quad_mod) (void)hipModuleUnload(p->quad_mod);
@@ -815,7 +906,11 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
                           const double* d_geom_row_param, double* d_out_pos, okx_info* d_info,
                           void* stream, bool evaluated, double* d_tangents, double* d_eval) {
   if (!p || !opts) return fail(OKX_ERR_INVALID, "null program or options");
-  attach_when_ready(p, false);
+  {
+    const hipStream_t launch_stream = (hipStream_t)stream;
+    attach_when_ready(p, false, &launch_stream);
+  }
+  std::shared_lock<std::shared_mutex> kernels(*p->kern_mutex);
   if (evaluated) {
     if (!p->ev_solve_u) return fail(OKX_ERR_INVALID, "evaluated solves need okx_program_enable_evaluation first%s%s", p->ev_note[0] ? ": " : "", p->ev_note);
     if (!d_tangents && !d_eval) return fail(OKX_ERR_INVALID, "an evaluated solve needs d_tangents or d_eval");
@@ -1113,25 +1208,43 @@ int32_t okx_program_enable_evaluation(okx_program* p, const okx_corner_roles* ro
   if (!p || !roles) return fail(OKX_ERR_INVALID, "null program or roles");
   if (int32_t rc = check_corner_roles(roles, p->host.n_out, "roles")) return rc;
   attach_when_ready(p, true);  // the evaluated kernels share the solve kernels' first-step tables: those first
-  if (!p->quad_fn_u || p->quad_ppw != 16) {
-    std::snprintf(p->ev_note, sizeof(p->ev_note), "no single-mode quad kernel (%.180s)", p->quad_note[0] ? p->quad_note : "a pair-mode program");
-    return fail(OKX_ERR_INVALID, "evaluated solves need the program's single-mode quad kernel: %s", p->ev_note);
-  }
   okx::EvalSpec spec;
   std::string why;
   if (!okx::eval_spec_from_roles(p->host, *roles, &spec, &why)) return fail(OKX_ERR_INVALID, "%s", why.c_str());
-  okx::eval_scalars_from_roles(*roles, &p->ev_cfg);
-  if (p->ev_solve_u && std::memcmp(&spec, &p->ev_spec, sizeof(spec)) == 0) return OKX_OK;  // same role points: only the numbers changed
+  bool with_lane = false;
+  {
+    std::shared_lock<std::shared_mutex> readers(*p->kern_mutex);
+    if (!p->quad_fn_u || p->quad_ppw != 16) {
+      const std::string note = p->quad_note[0] ? p->quad_note : "a pair-mode program";
+      readers.unlock();
+      std::unique_lock<std::shared_mutex> writer(*p->kern_mutex);
+      std::snprintf(p->ev_note, sizeof(p->ev_note), "no single-mode quad kernel (%.180s)", note.c_str());
+      return fail(OKX_ERR_INVALID, "evaluated solves need the program's single-mode quad kernel: %s", p->ev_note);
+    }
+    if (p->ev_solve_u && std::memcmp(&spec, &p->ev_spec, sizeof(spec)) == 0) {
+      // same role points as before: only the numbers change (launches read them as a kernel argument)
+      readers.unlock();
+      std::unique_lock<std::shared_mutex> writer(*p->kern_mutex);
+      okx::eval_scalars_from_roles(*roles, &p->ev_cfg);
+      return OKX_OK;
+    }
+    with_lane = p->lane_fn_u != nullptr && !okx::dev_switch("no_lane");
+  }
+  // generate + compile (or fetch from the cache) outside the lock: launches of this program go on meanwhile
+  std::string code, lcode, lwhy;
+  int lane_scratch = -1;
+  if (!okx::quad_eval_build(p->host, spec, quad_waves_per_simd(), &code, &why)) {
+    std::unique_lock<std::shared_mutex> writer(*p->kern_mutex);
+    std::snprintf(p->ev_note, sizeof(p->ev_note), "%.250s", why.c_str());
+    return fail(OKX_ERR_LIMIT, "no evaluated kernels for this program: %s", why.c_str());
+  }
+  const bool lane_built = with_lane && okx::lane_eval_build(p->host, spec, &lcode, &lwhy, false, &lane_scratch);
+  std::unique_lock<std::shared_mutex> kernels(*p->kern_mutex);
   if (p->ev_mod) {
     HIP_TRY(hipDeviceSynchronize());  // launches in flight may still run the modules about to be replaced
     release_evaluation(p);
   }
   p->ev_note[0] = 0;
-  std::string code;
-  if (!okx::quad_eval_build(p->host, spec, quad_waves_per_simd(), &code, &why)) {
-    std::snprintf(p->ev_note, sizeof(p->ev_note), "%.250s", why.c_str());
-    return fail(OKX_ERR_LIMIT, "no evaluated kernels for this program: %s", why.c_str());
-  }
   hipModule_t mod = nullptr;
   if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
     (void)hipGetLastError();
@@ -1153,31 +1266,27 @@ int32_t okx_program_enable_evaluation(okx_program* p, const okx_corner_roles* ro
   }
   p->ev_mod = mod;
   p->ev_spec = spec;
+  okx::eval_scalars_from_roles(*roles, &p->ev_cfg);
   // the lane form, for programs whose solves have one (failure only means the quad form serves every batch size)
-  if (p->lane_fn_u && !okx::dev_switch("no_lane")) {
-    std::string lcode, lwhy;
-    int scratch = -1;
-    if (!okx::lane_eval_build(p->host, spec, &lcode, &lwhy, false, &scratch)) {
-      std::snprintf(p->ev_note, sizeof(p->ev_note), "no lane form: %.230s", lwhy.c_str());
-    } else if (scratch > 512) {
-      std::snprintf(p->ev_note, sizeof(p->ev_note), "the lane form spills %d B of scratch: not used", scratch);
+  if (with_lane && !lane_built) {
+    std::snprintf(p->ev_note, sizeof(p->ev_note), "no lane form: %.230s", lwhy.c_str());
+  } else if (with_lane && lane_scratch > 512) {
+    std::snprintf(p->ev_note, sizeof(p->ev_note), "the lane form spills %d B of scratch: not used", lane_scratch);
+  } else if (with_lane) {
+    hipModule_t lmod = nullptr;
+    if (hipModuleLoadData(&lmod, lcode.data()) == hipSuccess &&
+        hipModuleGetFunction(&p->ev_lane_u, lmod, "okx_lane_evsolve_u") == hipSuccess &&
+        hipModuleGetFunction(&p->ev_lane_g, lmod, "okx_lane_evsolve_g") == hipSuccess) {
+      p->ev_lane_mod = lmod;
+      p->ev_lane_scratch = lane_scratch;
     } else {
-      hipModule_t lmod = nullptr;
-      if (hipModuleLoadData(&lmod, lcode.data()) == hipSuccess &&
-          hipModuleGetFunction(&p->ev_lane_u, lmod, "okx_lane_evsolve_u") == hipSuccess &&
-          hipModuleGetFunction(&p->ev_lane_g, lmod, "okx_lane_evsolve_g") == hipSuccess) {
-        p->ev_lane_mod = lmod;
-        p->ev_lane_scratch = scratch;
-      } else {
-        (void)hipGetLastError();
-        if (lmod) (void)hipModuleUnload(lmod);
-        p->ev_lane_u = p->ev_lane_g = nullptr;
-        std::snprintf(p->ev_note, sizeof(p->ev_note), "the lane form's code object did not load");
-      }
+      (void)hipGetLastError();
+      if (lmod) (void)hipModuleUnload(lmod);
+      p->ev_lane_u = p->ev_lane_g = nullptr;
+      std::snprintf(p->ev_note, sizeof(p->ev_note), "the lane form's code object did not load");
     }
   }
-  std::atomic_thread_fence(std::memory_order_release);
-  p->ev_solve_u = su;  // the gate of the evaluated launch paths, published last
+  p->ev_solve_u = su;  // the gate of the evaluated launch paths
   return OKX_OK;
 }
 
@@ -1188,6 +1297,7 @@ int32_t okx_evaluate_batch(okx_program* p, int64_t n_problems, int64_t steps_per
                            const double* d_geom_pos, const double* d_geom_row_param, double* d_tangents, double* d_eval,
                            void* stream) {
   if (!p) return fail(OKX_ERR_INVALID, "null program");
+  std::shared_lock<std::shared_mutex> kernels(*p->kern_mutex);
   if (!p->ev_solve_u) return fail(OKX_ERR_INVALID, "okx_evaluate_batch needs okx_program_enable_evaluation first%s%s", p->ev_note[0] ? ": " : "", p->ev_note);
   if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
   if (n_problems == 0) return OKX_OK;
@@ -1248,8 +1358,11 @@ int32_t okx_program_has_predictor(const okx_program* p) { return p && p->predict
 int32_t okx_program_fit_predictor(okx_program* p, const double* lo, const double* hi, int32_t degree, void* stream) {
   if (!p || !lo || !hi) return fail(OKX_ERR_INVALID, "null pointer");
   attach_when_ready(p, false);
-  if (!p->quad_fn_u) return fail(OKX_ERR_INVALID, "the predictor belongs to the quad kernel: %s", p->quad_note);
-  if (p->quad_ppw != 16) return fail(OKX_ERR_INVALID, "pair-mode kernels carry no predictor (register-bound)");
+  {
+    std::shared_lock<std::shared_mutex> kernels(*p->kern_mutex);  // (released before the node solve takes it itself)
+    if (!p->quad_fn_u) return fail(OKX_ERR_INVALID, "the predictor belongs to the quad kernel: %s", p->quad_note);
+    if (p->quad_ppw != 16) return fail(OKX_ERR_INVALID, "pair-mode kernels carry no predictor (register-bound)");
+  }
   const okx::DevProgram& H = p->host;
   const int T = H.n_targets;
   if (T < 1) return fail(OKX_ERR_INVALID, "program has no targets");
@@ -1439,7 +1552,11 @@ int32_t okx_rebind_design(okx_program* p, int64_t n_geometries, const double* d_
 int32_t okx_expand_positions_batch(okx_program* p, int64_t n_problems, int64_t steps_per_geometry, const double* d_free,
                                    const double* d_geom_pos, double* d_out_pos, void* stream) {
   if (!p) return fail(OKX_ERR_INVALID, "null program");
-  attach_when_ready(p, false);
+  {
+    const hipStream_t launch_stream = (hipStream_t)stream;
+    attach_when_ready(p, false, &launch_stream);
+  }
+  std::shared_lock<std::shared_mutex> kernels(*p->kern_mutex);
   if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
   if (n_problems == 0) return OKX_OK;
   if (!d_free || !d_out_pos) return fail(OKX_ERR_INVALID, "null pointer");
@@ -1483,7 +1600,11 @@ int32_t okx_tangent_batch(okx_program* p, int64_t n_problems, int64_t steps_per_
                           const double* d_geom_pos, const double* d_geom_row_param, double* d_tangents,
                           okx_tangent_info* d_tinfo, void* stream) {
   if (!p) return fail(OKX_ERR_INVALID, "null program");
-  attach_when_ready(p, false);
+  {
+    const hipStream_t launch_stream = (hipStream_t)stream;
+    attach_when_ready(p, false, &launch_stream);
+  }
+  std::shared_lock<std::shared_mutex> kernels(*p->kern_mutex);
   if (n_problems < 0) return fail(OKX_ERR_INVALID, "negative problem count");
   if (n_problems == 0) return OKX_OK;
   if (!d_pos || !d_tangents || !d_tinfo) return fail(OKX_ERR_INVALID, "null pointer");
@@ -1716,6 +1837,7 @@ int32_t okx_debug_quad_eval(okx_program* p, int64_t n_problems, const double* d_
                             void* stream) {
   if (!p || !d_x || !d_r || !d_ata || !d_atr || !d_dx) return fail(OKX_ERR_INVALID, "null pointer");
   attach_when_ready(p, false);
+  std::shared_lock<std::shared_mutex> kernels(*p->kern_mutex);
   if (!p->quad_fn_eval) return fail(OKX_ERR_INVALID, "no quad kernel: %s", p->quad_note);
   if (n_problems <= 0) return OKX_OK;
   okx::QuadEvalArgs q;
@@ -1744,6 +1866,7 @@ int32_t okx_debug_lane_eval(okx_program* p, int64_t n_problems, const double* d_
                             void* stream) {
   if (!p || !d_x || !d_r || !d_ata || !d_atr || !d_dx) return fail(OKX_ERR_INVALID, "null pointer");
   attach_when_ready(p, false);
+  std::shared_lock<std::shared_mutex> kernels(*p->kern_mutex);
   if (!p->lane_fn_eval) return fail(OKX_ERR_INVALID, "no lane kernel: %s", p->lane_note);
   if (n_problems <= 0) return OKX_OK;
   okx::QuadEvalArgs q;
