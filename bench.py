@@ -806,6 +806,9 @@ def main() -> None:
                     help="design: cold starts from the design state (section 8d, the headline); model: the fitted chain-head model "
                          "(profiling runs of the predictor path; never the default)")
     ap.add_argument("--chain-len", type=int, default=-1, help="-1 auto (16384 steps fit the chip: independent solves), 1 = independent")
+    ap.add_argument("--c5-chunks", type=int, default=0, help="--config c5, N > 1: chunks of the pipelined exchange per rank (0: auto, up to 8)")
+    ap.add_argument("--c5-gather", choices=("records", "free"), default="records",
+                    help="--config c5, N > 1: every rank ends with all output records (default) or with the free coordinates only (no expand)")
     ap.add_argument("--rccl-world-one", action="store_true",
                     help="one rank, but with an RCCL process group and the all-gather in the step: what a one-GPU box can "
                          "rehearse of the N > 1 path (communicator, stream ordering of the pipeline, expand of the gathered block)")
@@ -1166,7 +1169,7 @@ def run_c5(args, world: int, rank: int, device) -> dict:
     """BASELINE config 5: 4096 perturbed geometries x 256 steps, sharded geometry-major over the ranks (strong scaling:
     the total is fixed).  Reports the solve-only and the exchange-inclusive rate separately."""
     from open_kinematics_amd.batch import DeviceProgram
-    from open_kinematics_amd.dist import all_gather_rows, shard_range
+    from open_kinematics_amd.dist import ShardedEnsemble, shard_range
     from open_kinematics_amd.workloads import ensemble_problem
 
     n_geom, spg = 4096, 256
@@ -1190,19 +1193,29 @@ def run_c5(args, world: int, rank: int, device) -> dict:
     info = torch.empty((n_local, 40), dtype=torch.uint8, device=device)
     launch = dp.plan(targets, out=out, info_out=info, chain_len=args.chain_len if args.chain_len != -1 else 1, predictor=False,
                      geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=spg, output="free" if world > 1 else "records")
-    full = torch.empty((n_total, program.n_out, 3), dtype=torch.float64, device=device) if world > 1 else None
+    # N > 1: the pipelined exchange (dist.ShardedEnsemble): the shard in chunks of whole geometries, chunk k + 1 solving while
+    # chunk k travels (coordinates + info records, one grouped point-to-point call, from and into their final place) and
+    # chunk k - 1 is expanded on a third stream; --c5-gather free leaves the expand out (coordinates on every rank)
+    pipe = None
+    if world > 1:
+        pipe = ShardedEnsemble(dp, table_dev, rel, spg, chunks=args.c5_chunks or None, records=args.c5_gather == "records",
+                               chain_len=args.chain_len if args.chain_len != -1 else 1, predictor=False)
 
     def step(k, start, end):
         if start is not None:
             start.record()
-        launch()
+        if pipe is not None:
+            pipe.step()
+        else:
+            launch()
         if end is not None:
             end.record()
-        if world > 1:
-            free_full = all_gather_rows(out, n_total, None, spans)
-            dp.expand(free_full, out=full, geom_pos=gpos_all, steps_per_geometry=spg)
 
-    elapsed, kernel_ms = timed_region(step, lambda: None, args.steps, args.warmup, world, device, per_launch_events=True)
+    elapsed, step_ms = timed_region(step, lambda: None, args.steps, args.warmup, world, device, per_launch_events=True)
+    kernel_ms = step_ms
+    if pipe is not None:  # the solve alone, for `solve_only`: the whole shard as one launch, outside the timed region
+        _, kernel_ms = time_launches(launch, max(3, min(args.steps, 10)), 2, device)
+        info = pipe.info_full[glo * spg : ghi * spg]
     nfev_mean, ok = info_summary(info)
     if rank != 0:
         return {}
@@ -1221,15 +1234,19 @@ def run_c5(args, world: int, rank: int, device) -> dict:
                    "start": "independent cold starts from each geometry's design state (SURVEY.md section 8d)" if args.chain_len in (-1, 1)
                             else f"chains of {args.chain_len}",
                    "lm_evaluations_mean": nfev_mean, "all_converged": ok, "rebind_ms": rebind_ms,
-                   "exchange": "all-gather of the solved free coordinates + expand on every rank, after each solve" if world > 1 else "none"},
+                   "exchange": ("pipelined: the shard in %d chunks of whole geometries, chunk k + 1 solving while chunk k travels "
+                                "(coordinates + info records in one grouped point-to-point call, from and into their final place)%s"
+                                % (pipe.chunks, " and chunk k - 1 is expanded into records on a third stream" if pipe.records else
+                                   "; coordinates only, no expand (--c5-gather free)")) if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                      "kernel": ("okx_lane_solve_g" if 0 < dp.lane_threshold <= n_local and (dp.lane_bodies & 1) else
                                 "okx_quad_solve_g" if dp.kernel == "quad" else "okx_solve_kernel"),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bytes_per},
         "solve_only": {"value": n_total / (kernel_ms * 1e-3) if world > 1 else n_local / (kernel_ms * 1e-3),
                        "kernel_ms_max_over_ranks": kernel_ms},
-        "exchange": {"bytes_sent_per_rank_per_step": free_bytes if world > 1 else 0,
-                     "bytes_received_per_rank_per_step": (n_total - n_local) * program.n_free * 24 if world > 1 else 0},
+        "exchange": {"bytes_sent_per_rank_per_step": pipe.exchange_bytes_per_rank if world > 1 else 0,
+                     "bytes_received_per_rank_per_step": (n_total - n_local) * (program.n_free * 24 + 40) if world > 1 else 0,
+                     "chunks": pipe.chunks if world > 1 else 0, "step_ms_with_exchange": step_ms if world > 1 else None},
     }
 
 

@@ -1574,9 +1574,11 @@ int32_t okx_expand_positions_batch(okx_program* p, int64_t n_problems, int64_t s
     q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
     q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
     q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
-    const long long waves = (n_problems + 15) / 16;
+    const long long waves = (n_problems + p->quad_ppw - 1) / p->quad_ppw;
+    // (pair mode: a persistent grid - the wavefront reads its fixed points once and walks its wave units)
+    const long long grid_cap = p->quad_ppw == 8 ? (long long)p->n_cu * 32 : 65536;
     void* kargs[] = {(void*)&q};
-    HIP_TRY(hipModuleLaunchKernel(p->quad_fn_expand, (int)(waves < 65536 ? waves : 65536), 1, 1, okx::kWave, 1, 1, 0,
+    HIP_TRY(hipModuleLaunchKernel(p->quad_fn_expand, (int)(waves < grid_cap ? waves : grid_cap), 1, 1, okx::kWave, 1, 1, 0,
                                   (hipStream_t)stream, kargs, nullptr));
     return OKX_OK;
   }

@@ -2872,6 +2872,78 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     *src = g.out;
     return true;
   }
+  if (pv) {
+    // ---- pair mode: output positions from free coordinates (okx_expand_positions_batch; the receiving side of a multi-GPU
+    //      exchange expands every gathered step).  One quad per half: its fixed points from the design table, its free points
+    //      from the input row, its derived points re-evaluated by the solve kernel's own final-state code (same bits); the
+    //      wavefront's eight records leave through LDS as whole rows, like the cold pair body's ----
+    std::vector<int> ordinal(program.n_points, 0);
+    for (int k = 0; k < program.n_free; ++k) ordinal[program.free_point[k]] = k;
+    g.f("struct QExpandArgs { const double* free; const double* geom_pos; double* out_pos; long long n_problems, steps_per_geometry;");
+    g.f("  const double* design_pos; const double* row_param; const double* dop_param; };");
+    g.f("extern \"C\" __global__ void __launch_bounds__(64) okx_quad_expand(QExpandArgs a) {");
+    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1 = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
+    g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+    g.f("  (void)e0; (void)e1; (void)e2;");
+    g.out += lds_decl;
+    g.f("  __shared__ __attribute__((aligned(16))) double stage[%d * %d];", PPW, 3 * prog_out);
+    g.f("  __shared__ __attribute__((aligned(16))) double fin[%d * %d];  // the wavefront's input rows", PPW, 3 * program.n_free);
+    // own geometry: the fixed points and the derived-op parameters are the same for every problem - read once per
+    // wavefront, ahead of the loop over its wave units (a persistent grid: okx_expand_positions_batch caps it)
+    g.f("  const bool own = a.geom_pos == nullptr;");
+    g.f("  const double* gp = a.design_pos;");
+    g.f("  const double* gq = a.row_param; (void)gq;");
+    g.out += ev.hoisted;
+    for (int p = 0; p < NP; ++p)
+      if (used[p]) g.f("  double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
+    g.f("  for (long long wu = blockIdx.x; wu * %d < a.n_problems; wu += gridDim.x) {", PPW);
+    g.f("    long long bb = wu * %d + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;", PPW);
+    g.f("    {  // input rows: one contiguous block, 16 bytes per lane, then each lane its components from LDS");
+    g.f("      const long long rem_in = a.n_problems - wu * %d;", PPW);
+    g.f("      const int n_in = (int)(rem_in < %d ? rem_in : %d) * %d;", PPW, PPW, 3 * program.n_free);
+    g.f("      const double* src = a.free + wu * %d * %d;", PPW, 3 * program.n_free);
+    g.f("      if ((reinterpret_cast<unsigned long long>(src) & 15ull) == 0ull) {");
+    g.f("        for (int i = lane; i < n_in / 2; i += 64) reinterpret_cast<double2*>(fin)[i] = reinterpret_cast<const double2*>(src)[i];");
+    g.f("        if ((n_in & 1) && lane == 0) fin[n_in - 1] = src[n_in - 1];");
+    g.f("      } else {");
+    g.f("        for (int i = lane; i < n_in; i += 64) fin[i] = src[i];");
+    g.f("      }");
+    g.f("    }");
+    g.f("    if (!own) {");
+    g.f("      const long long geom = bb / a.steps_per_geometry;");
+    g.f("      gp = a.geom_pos + geom * %d;", 3 * prog_points);
+    for (int p = 0; p < NP; ++p)
+      if (used[p] && ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0) g.f("      p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
+    g.f("    }");
+    g.f("    __syncthreads();");
+    for (int F = 0; F < nf; ++F) {
+      const int pt = ev.fp(F);
+      g.f("    p%d = ld3(fin + (valid ? quad : 0) * %d + %s + cc, c);", pt, 3 * program.n_free,
+          Gen::sel(3 * ordinal[pv->pt[0][pt]], 3 * ordinal[pv->pt[1][pt]]).c_str());
+    }
+    g.out += final_src;
+    g.f("    if (c < 3) {");
+    g.f("      double* st = stage + quad * %d + c;", 3 * prog_out);
+    for (int k = 0; k < P.n_out; ++k) {
+      const int k0 = pv->out[0][k], k1 = pv->out[1][k];
+      if (k1 >= 0) g.f("      st[q1 ? %d : %d] = p%d;", 3 * k1, 3 * k0, P.out_point[k]);
+      else g.f("      if (!q1) st[%d] = p%d;", 3 * k0, P.out_point[k]);
+    }
+    for (size_t k = 0; k < pv->shared_out.size(); ++k)
+      g.f("      if (!q1) st[%d] = gp[%d + c];", 3 * pv->shared_out[k], 3 * pv->shared_pt[k]);
+    g.f("    }");
+    g.f("    __syncthreads();");
+    g.f("    const long long rem = a.n_problems - wu * %d;", PPW);
+    g.f("    const int n_doubles = (int)(rem < %d ? rem : %d) * %d;", PPW, PPW, 3 * prog_out);
+    g.f("    double2* dst = reinterpret_cast<double2*>(a.out_pos + wu * %d * %d);", PPW, 3 * prog_out);
+    g.f("    const double2* src = reinterpret_cast<const double2*>(stage);");
+    g.f("    for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
+    g.f("    if ((n_doubles & 1) && lane == 0) a.out_pos[wu * %d * %d + n_doubles - 1] = stage[n_doubles - 1];", PPW, 3 * prog_out);
+    g.f("    __syncthreads();");
+    g.f("  }");
+    g.f("}");
+    g.f("");
+  }
   if (!pv) {
   // ---- output positions from free coordinates (okx_expand_positions_batch): fixed points from the design table,
   //      every derived point re-evaluated, records written like the solve kernel's ----

@@ -188,14 +188,197 @@ class EnsembleShard:
     exchange_bytes_per_rank: int       # payload this rank contributed to the all-gather(s)
 
 
+@dataclass
+class _LocalShard:
+    """This rank's part of a pipelined ensemble, shaped like the ``BatchResult`` of a compact solve."""
+
+    free: torch.Tensor
+    info_raw: torch.Tensor
+    positions: object = None
+
+
 def _world(group):
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     return world, (dist.get_rank(group) if world > 1 else 0)
 
 
-def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = True, group=None, *, hardpoints=None,
+def chunk_pieces(n_geom: int, world: int, chunks: int) -> list:
+    """
+    The piece table of a chunked ensemble exchange, the same on every rank: ``pieces[k][r] = (g_lo, g_hi)`` - the
+    geometries rank ``r`` solves in chunk ``k`` (its ``shard_range`` block cut into ``chunks`` contiguous runs; runs may
+    be empty when a rank has fewer geometries than chunks).
+    """
+    table = []
+    for k in range(chunks):
+        row = []
+        for r in range(world):
+            lo, hi = shard_range(n_geom, r, world)
+            a, b = shard_range(hi - lo, k, chunks)
+            row.append((lo + a, lo + b))
+        table.append(row)
+    return table
+
+
+class ShardedEnsemble:
+    """
+    BASELINE config 5 on N GPUs as a PIPELINE (geometry-major contiguous shards, one exchange of the
+    solved states).  Every rank cuts its shard into ``chunks`` runs of whole geometries and, chunk by chunk,
+
+      * solves chunk k on the compute stream - the solve writes the free coordinates (``okx_solve_opts.output = free``, the
+        exchange's payload) and the info records straight into THEIR FINAL PLACE in the gathered arrays: nothing is packed,
+        staged or copied on the sending side;
+      * exchanges chunk k with every peer in ONE grouped point-to-point call (``batch_isend_irecv``: on RCCL a single
+        ncclGroup, every peer over its own xGMI link at once, coordinates and info records together; the receives land in
+        their final place too) while chunk k + 1 solves;
+      * optionally (``records=True``) rebuilds the output records of chunk k's pieces on a third stream while chunk k + 1
+        travels and chunk k + 2 solves.
+
+    A step therefore costs about ``max(solve, exchange, expand)`` of the whole batch plus one chunk of each, instead of
+    their sum.  ``records=False`` returns the gathered free coordinates (what a consumer that evaluates metrics per rank,
+    or writes per-rank result files, needs) and skips the expand altogether.  Chunked and unchunked runs give the same
+    bits: a chunk is just a smaller launch of the same independent solves.
+    """
+
+    def __init__(self, device_program, hardpoints, targets, steps_per_geometry: int, *, group=None, chunks: int | None = None,
+                 records: bool = True, relative_targets: bool = True, **solve_kw):
+        self.dp = device_program
+        self.group = group
+        self.world, self.rank = _world(group)
+        self.steps = int(steps_per_geometry)
+        self.records = bool(records)
+        self.solve_kw = solve_kw
+        program = device_program.program
+        self.n_geom = int(hardpoints.shape[0])
+        self.n_total = self.n_geom * self.steps
+        glo, ghi = shard_range(self.n_geom, self.rank, self.world)
+        self.geometry_range = (glo, ghi)
+        if chunks is None:  # at least 8 chunks once a rank has 8 x 4096 problems to cut; never below one geometry per chunk
+            chunks = max(1, min(8, ((ghi - glo) * self.steps) // 4096, ghi - glo)) if self.world > 1 else 1
+        self.chunks = max(1, int(chunks))
+        self.pieces = chunk_pieces(self.n_geom, self.world, self.chunks)
+        # per-geometry emission: the expand on the receiving side needs every geometry's fixed points (a small table,
+        # replicated as SURVEY.md section 8e allows); without records only this rank's slice is rebound
+        everyone = self.records and self.world > 1
+        table = hardpoints if everyone else hardpoints[glo:ghi]
+        gpos, gparam = device_program.rebind(table)
+        self.gpos_all = gpos if everyone else None
+        self.my_pos = gpos[glo:ghi] if everyone else gpos
+        self.my_param = gparam[glo:ghi] if everyone else gparam
+        targets = torch.as_tensor(targets)
+        if relative_targets:
+            self.local_targets = device_program.ensemble_targets(self.my_pos, targets)
+        else:
+            self.local_targets = targets[glo * self.steps : ghi * self.steps]
+        device = self.my_pos.device
+        self.free_full = torch.empty((self.n_total, program.n_free, 3), dtype=torch.float64, device=device)
+        self.info_full = torch.empty((self.n_total, 40), dtype=torch.uint8, device=device)
+        self.positions = torch.empty((self.n_total, program.n_out, 3), dtype=torch.float64, device=device) if self.records else None
+        self.expand_stream = torch.cuda.Stream(device=device) if device.type == "cuda" and self.records else None
+        self.exchange_bytes_per_rank = (ghi - glo) * self.steps * (program.n_free * 24 + 40) if self.world > 1 else 0
+
+    def _rows(self, span):
+        return slice(span[0] * self.steps, span[1] * self.steps)
+
+    def _solve_chunk(self, k: int) -> None:
+        glo = self.geometry_range[0]
+        a, b = self.pieces[k][self.rank]
+        if b <= a:
+            return
+        rows = self._rows((a, b))
+        local = slice((a - glo) * self.steps, (b - glo) * self.steps)
+        out, info = self.free_full[rows], self.info_full[rows]
+        res = self.dp.solve(self.local_targets[local], geom_pos=self.my_pos[a - glo : b - glo], geom_row_param=self.my_param[a - glo : b - glo],
+                            steps_per_geometry=self.steps, output="free", out=out, info_out=info, **self.solve_kw)
+        # (a stand-in program of the CPU tests returns fresh tensors instead of filling the buffers it was given)
+        if res.free.data_ptr() != out.data_ptr():
+            out.copy_(res.free)
+        if res.info_raw.data_ptr() != info.data_ptr():
+            info.copy_(res.info_raw)
+
+    def _exchange_chunk(self, k: int) -> list:
+        if self.world == 1:
+            return []
+        if self.free_full.is_cuda and dist.get_backend(self.group) == "gloo":
+            return self._exchange_chunk_through_the_host(k)
+        ops = []
+        mine = self.pieces[k][self.rank]
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            dst = dist.get_global_rank(self.group, peer) if self.group is not None else peer
+            theirs = self.pieces[k][peer]
+            if mine[1] > mine[0]:
+                ops.append(dist.P2POp(dist.isend, self.free_full[self._rows(mine)], dst, self.group))
+                ops.append(dist.P2POp(dist.isend, self.info_full[self._rows(mine)], dst, self.group))
+            if theirs[1] > theirs[0]:
+                ops.append(dist.P2POp(dist.irecv, self.free_full[self._rows(theirs)], dst, self.group))
+                ops.append(dist.P2POp(dist.irecv, self.info_full[self._rows(theirs)], dst, self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _exchange_chunk_through_the_host(self, k: int) -> list:
+        """Device tensors over gloo (two ranks rehearsing on one GPU: gloo's point-to-point calls take host tensors): the
+        same pieces, staged through host copies, complete on return."""
+        mine = self.pieces[k][self.rank]
+        ops, landing = [], []
+        for peer in range(self.world):
+            if peer == self.rank:
+                continue
+            dst = dist.get_global_rank(self.group, peer) if self.group is not None else peer
+            theirs = self.pieces[k][peer]
+            for full in (self.free_full, self.info_full):
+                if mine[1] > mine[0]:
+                    ops.append(dist.P2POp(dist.isend, full[self._rows(mine)].cpu(), dst, self.group))
+                if theirs[1] > theirs[0]:
+                    host = torch.empty_like(full[self._rows(theirs)], device="cpu")
+                    ops.append(dist.P2POp(dist.irecv, host, dst, self.group))
+                    landing.append((full[self._rows(theirs)], host))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        for device_rows, host in landing:
+            device_rows.copy_(host)
+        return []
+
+    def _expand_chunk(self, k: int, works: list) -> None:
+        def run():
+            for w in works:
+                w.wait()  # NCCL: this stream waits for the transfers; gloo: the host does
+            for r in range(self.world):
+                a, b = self.pieces[k][r]
+                if b <= a:
+                    continue
+                rows = self._rows((a, b))
+                gp = self.gpos_all[a:b] if self.gpos_all is not None else self.my_pos[a - self.geometry_range[0] : b - self.geometry_range[0]]
+                got = self.dp.expand(self.free_full[rows], out=self.positions[rows], geom_pos=gp, steps_per_geometry=self.steps)
+                if got.data_ptr() != self.positions[rows].data_ptr():
+                    self.positions[rows].copy_(got)
+
+        if self.expand_stream is None:
+            run()
+            return
+        self.expand_stream.wait_stream(torch.cuda.current_stream(self.expand_stream.device))  # (the own piece was solved there)
+        with torch.cuda.stream(self.expand_stream):
+            run()
+
+    def step(self):
+        """One pass over the whole ensemble: returns ``positions`` (``records=True``) or the gathered free coordinates."""
+        pending = []
+        for k in range(self.chunks):
+            self._solve_chunk(k)
+            works = self._exchange_chunk(k)
+            if self.records:
+                self._expand_chunk(k, works)
+            else:
+                pending += works
+        for w in pending:
+            w.wait()
+        if self.expand_stream is not None:
+            torch.cuda.current_stream(self.expand_stream.device).wait_stream(self.expand_stream)
+        return self.positions if self.records else self.free_full
+
+
+def solve_sharded(device_program, targets_full: torch.Tensor, gather=True, group=None, *, hardpoints=None,
                   steps_per_geometry: int = 0, exchange: str = "free", relative_targets: bool | None = None,
-                  **solve_kw):
+                  chunks: int | None = None, **solve_kw):
     """
     Solve this rank's index block and (optionally) all-gather the solved positions.
 
@@ -211,8 +394,12 @@ def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = Tru
     themselves, plus the 40-byte info records.  ``targets_full`` is either ``[S, T]`` RELATIVE displacements
     applied to every geometry's own design coordinates (the reference's relative target mode) or ``[G * S, T]``
     absolute values (``relative_targets`` says which; ``None`` infers it from the row count, absolute when both
-    fit); ``steps_per_geometry`` = S.  Returns ``(positions [G * S, n_out, 3], EnsembleShard)``;
-    uneven geometry counts are padded inside the collective and trimmed again.
+    fit); ``steps_per_geometry`` = S.  Returns ``(positions [G * S, n_out, 3], EnsembleShard)``.
+    The compact exchange runs as a pipeline (``ShardedEnsemble``): the shard is cut into ``chunks`` runs of whole
+    geometries (default: up to 8), chunk k + 1 solves while chunk k travels - coordinates and info records in one grouped
+    point-to-point call, straight from and into their final place - and chunk k - 1 is expanded on a third stream.
+    ``gather="free"`` skips the expand and returns the gathered free coordinates ``[G * S, n_free, 3]`` instead of the
+    records (``EnsembleShard.free_full`` holds them either way).  Uneven geometry counts need no padding.
     """
     world, rank = _world(group)
     if hardpoints is None:
@@ -223,6 +410,8 @@ def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = Tru
         return positions, result
     if exchange not in ("free", "positions"):
         raise ValueError("exchange must be 'free' or 'positions'")
+    if gather == "free" and exchange != "free":
+        raise ValueError("gather='free' returns the compact exchange's payload: exchange must be 'free'")
     steps = int(steps_per_geometry)
     n_geom = int(hardpoints.shape[0])
     if steps <= 0:
@@ -234,6 +423,12 @@ def solve_sharded(device_program, targets_full: torch.Tensor, gather: bool = Tru
         (targets_full.shape[0] == steps and n_geom * steps != steps)
     if targets_full.shape[0] != (steps if relative else n_geom * steps):
         raise ValueError("targets must be [S, T] relative displacements or [G * S, T] absolute values")
+    if gather and world > 1 and exchange == "free":
+        pipe = ShardedEnsemble(device_program, hardpoints, targets_full, steps, group=group, chunks=chunks,
+                               records=gather != "free", relative_targets=relative, **solve_kw)
+        result = pipe.step()
+        local = _LocalShard(pipe.free_full[pipe._rows(pipe.geometry_range)], pipe.info_full[pipe._rows(pipe.geometry_range)])
+        return result, EnsembleShard(local, pipe.geometry_range, pipe.free_full, pipe.info_full, pipe.exchange_bytes_per_rank)
     # Per-geometry emission.  The expand on the receiving side needs every geometry's fixed points, so with the
     # compact exchange the (small: G x P x 24 B) hardpoint table is rebound in full on every rank — replicated
     # inputs, as SURVEY.md section 8e allows; otherwise only this rank's slice.

@@ -92,9 +92,11 @@ class _StandInProgram:
 
     free_out_index = torch.tensor([1, 3])
 
-    def __init__(self):
+    def __init__(self, fill_buffers: bool = True):
         self.rebound = []
         self.outputs = []
+        self.launch_rows = []
+        self.fill_buffers = fill_buffers  # False: fresh tensors come back, as from a program that ignores out= / info_out=
 
     def rebind(self, table):
         table = torch.as_tensor(table, dtype=torch.float64)
@@ -115,22 +117,34 @@ class _StandInProgram:
         out[:, 4] = free[:, 1] + fixed
         return out
 
-    def solve(self, targets, *, geom_pos, geom_row_param, steps_per_geometry, output="records", **kw):
+    def solve(self, targets, *, geom_pos, geom_row_param, steps_per_geometry, output="records", out=None, info_out=None, **kw):
         assert geom_pos.shape[0] * steps_per_geometry == targets.shape[0] and geom_row_param.shape[0] == geom_pos.shape[0]
         fixed = geom_pos[:, 0].repeat_interleave(steps_per_geometry, dim=0)
         t = targets[:, :1]
         solved = torch.stack([t * fixed, t + 2.0 * fixed], dim=1)
         self.outputs.append(output)
+        self.launch_rows.append(targets.shape[0])
+        info = (targets[:, :1].abs() * 7).to(torch.uint8).expand(-1, 40).contiguous()
+        if self.fill_buffers and out is not None:  # like DeviceProgram: the caller's buffers are what is written
+            out.copy_(solved if output == "free" else self._assemble(solved, fixed))
+            solved = out if output == "free" else solved
+        if self.fill_buffers and info_out is not None:
+            info_out.copy_(info)
+            info = info_out
 
         class _Result:  # like BatchResult: records with output="records", the free points alone with "free"
             positions = self._assemble(solved, fixed) if output == "records" else None
             free = solved if output == "free" else None
-            info_raw = (targets[:, :1].abs() * 7).to(torch.uint8).expand(-1, 40).contiguous()
+            info_raw = info
 
         return _Result
 
-    def expand(self, free, geom_pos=None, steps_per_geometry=0):
-        return self._assemble(free, geom_pos[:, 0].repeat_interleave(steps_per_geometry, dim=0))
+    def expand(self, free, out=None, geom_pos=None, steps_per_geometry=0):
+        full = self._assemble(free, geom_pos[:, 0].repeat_interleave(steps_per_geometry, dim=0))
+        if out is not None and self.fill_buffers:
+            out.copy_(full)
+            return out
+        return full
 
 
 def _ensemble_inputs(n_geom: int, steps: int):
@@ -150,10 +164,18 @@ def _ensemble_worker(rank: int, world: int, port: int, n_geom: int, steps: int, 
     table, relative = _ensemble_inputs(n_geom, steps)
     for exchange in ("free", "positions"):
         dp = _StandInProgram()
-        positions, shard = solve_sharded(dp, relative, hardpoints=table, steps_per_geometry=steps, exchange=exchange)
+        positions, shard = solve_sharded(dp, relative, hardpoints=table, steps_per_geometry=steps, exchange=exchange, chunks=1)
         torch.save({"positions": positions, "info": shard.info_full, "range": shard.geometry_range,
                     "rebound": dp.rebound, "sent": shard.exchange_bytes_per_rank, "outputs": dp.outputs},
                    os.path.join(out_dir, f"{exchange}{rank}.pt"))
+    # the pipelined exchange: the shard in chunks of whole geometries (more chunks than a rank has geometries included),
+    # with a program that fills the buffers it is given and with one that returns fresh tensors; records or coordinates only
+    for tag, chunks, fill, gather in (("chunk3", 3, True, True), ("chunk8", 8, False, True), ("coords", 2, True, "free")):
+        dp = _StandInProgram(fill_buffers=fill)
+        got, shard = solve_sharded(dp, relative, gather=gather, hardpoints=table, steps_per_geometry=steps, chunks=chunks)
+        torch.save({"result": got, "info": shard.info_full, "free": shard.free_full, "range": shard.geometry_range,
+                    "rebound": dp.rebound, "sent": shard.exchange_bytes_per_rank, "launch_rows": dp.launch_rows,
+                    "local_free": shard.local.free, "outputs": dp.outputs}, os.path.join(out_dir, f"{tag}{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -183,6 +205,20 @@ def test_two_rank_gloo_ensemble_is_geometry_major(tmp_path, n_geom):
             assert got["rebound"] == [n_geom if exchange == "free" else spans[rank][1] - spans[rank][0]]
             # ... and its solve writes the payload itself (okx_solve_opts.output = free): no packing pass after the solve
             assert got["outputs"] == ["free" if exchange == "free" else "records"]
+    # chunked == unchunked, bit for bit, whatever the chunk count and whether or not the program fills the given buffers
+    free_expect = expect.positions[:, [1, 3]]
+    for rank in range(2):
+        lo, hi = spans[rank]
+        for tag, chunks in (("chunk3", 3), ("chunk8", 8)):
+            got = torch.load(os.path.join(tmp_path, f"{tag}{rank}.pt"))
+            assert torch.equal(got["result"], expect.positions) and torch.equal(got["info"], expect.info_raw)
+            assert torch.equal(got["free"], free_expect) and torch.equal(got["local_free"], free_expect[lo * steps : hi * steps])
+            assert got["rebound"] == [n_geom] and set(got["outputs"]) == {"free"}
+            assert got["sent"] == (hi - lo) * steps * (2 * 24 + 40)
+            assert sum(got["launch_rows"]) == (hi - lo) * steps and len(got["launch_rows"]) == min(chunks, hi - lo)
+        got = torch.load(os.path.join(tmp_path, f"coords{rank}.pt"))  # gather="free": the coordinates, no expand, own slice rebound only
+        assert torch.equal(got["result"], free_expect) and torch.equal(got["info"], expect.info_raw)
+        assert got["rebound"] == [hi - lo]
 
 
 def test_single_process_ensemble_needs_no_collective():

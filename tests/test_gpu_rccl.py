@@ -54,3 +54,25 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert line["exchange"]["bytes_sent_per_rank_per_step"] == 16384 * 6 * 24      # the free coordinates, not the records
     assert line["exchange"]["bytes_received_per_rank_per_step"] == 16384 * 6 * 24
     assert line["solve_only"]["value"] >= line["value"] > 0.0
+
+
+def test_two_rank_c5_pipeline_rehearsal_on_one_gpu():
+    """BASELINE config 5's N = 2 step on a one-GPU box (both ranks on cuda:0, gloo in place of RCCL): geometry-major shards
+    cut into chunks, every chunk's solve writing coordinates and info records into their final place, the grouped
+    point-to-point exchange, the expand of the pieces on a third stream - and the same with coordinates only."""
+    if not gpu_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    for extra in ([], ["--c5-gather", "free", "--c5-chunks", "5"]):
+        proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--config", "c5", "--gpus", "2", "--rehearse-on-one-gpu",
+                               "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"] + extra, env=env,
+                              capture_output=True, text=True, timeout=900)
+        assert proc.returncode == 0, (proc.stdout + proc.stderr)[-3000:]
+        line = [json.loads(l) for l in proc.stdout.splitlines() if l.startswith("{")][-1]
+        assert line["n_gpus"] == 2 and line["config"]["all_converged"] and line["scaling"] == "strong"
+        assert line["config"]["problems_per_gpu"] == 2048 * 256
+        assert line["exchange"]["chunks"] == (5 if extra else 8)
+        assert line["exchange"]["bytes_sent_per_rank_per_step"] == 2048 * 256 * (6 * 24 + 40)   # coordinates + info records
+        assert line["solve_only"]["value"] > 0.0 and line["value"] > 0.0
