@@ -25,7 +25,7 @@ constexpr int kPredictorMaxDegree = 12;
 constexpr int kPredictorLdsDoubles = 1024;  // single mode: tables up to this size are staged through LDS (8 KB per wavefront)
 constexpr int kQuadMaxFree = 9;          // n <= 27 unknowns (a corner with pushrod, rocker and coil-over): up to 8 free points the lane-owned
                                          // rows of J^T J stay in registers, the ninth costs ~400 B of scratch (3.2e8 solves/s against 1.5e7 on the interpreter)
-constexpr int kQuadMaxJoins = 3;          // pair mode: rows joining the two halves (rack; T-bar crossbar length and centre plane)
+constexpr int kQuadMaxJoins = 4;          // pair mode: rows joining the two halves (rack; T-bar crossbar length and centre plane; rocker-to-rocker heave link)
 constexpr int kQuadMaxFreePerSide = 11;  // pair mode (two identical halves, one quad each): free points per half (rocker corner + droplink + heave pickup)
 constexpr int kLaneMaxFree = 6;          // lane kernel (one lane per problem): n <= 18 unknowns, lower triangle of J^T J <= 171 doubles
 

@@ -17,7 +17,7 @@ from conftest import load_golden
 from open_kinematics_amd.batch import DeviceProgram
 
 NAMES = ["c1_dw_corner", "c4_macpherson_grid", "t_corner_strut", "t_corner_rocker", "t_corner_strut_rocker", "t_axle_macpherson",
-         "t_axle_dw", "c3_axle_grid", "t_axle_t_bar_roll", "t_axle_heave_link"]
+         "t_axle_dw", "c3_axle_grid", "t_axle_t_bar_roll", "t_axle_heave_link", "t_axle_t_bar_heave"]
 dev = torch.device("cuda", 0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 rows = []
