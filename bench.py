@@ -957,7 +957,7 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
     if not per_launch_events:
         ends[0].record()
         # (the host polls the end event before it synchronises: a poll sees the end of the GPU's work within microseconds, an
-        #  interrupt-driven wait wakes the host later; the synchronize below then finds an idle GPU - tools/region_latency.py)
+        #  interrupt-driven wait wakes the host later; the synchronize below then finds an idle GPU - profiles/r04/EXPERIMENTS.md section 10)
         while not ends[0].query():
             pass
     drain()
@@ -1162,6 +1162,26 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["dropin"] = measure_dropin(device)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(STEPS_PER_RANK)
+    # the figures a reader of the line's first 2000 characters should not miss, right behind the contract's own fields:
+    # what the same launch gives without the amortised design-state pass, a fresh program's first launch, the evaluated rates
+    digest = {}
+    if "own_first_pass" in line:
+        digest["own_first_pass"] = line["own_first_pass"]["value"]
+    if "one_shot" in line:
+        digest["one_shot_first_launch"] = line["one_shot"]["value_first_launch"]
+    if "sustained" in line:
+        digest["sustained"] = line["sustained"]["value"]
+    for cfg in line.get("other_configs", []):
+        tag = cfg["workload"].split(" ")[0].lower()
+        if "cold" in cfg:
+            digest[f"{tag}_cold"] = cfg["cold"]["value"]
+        if isinstance(cfg.get("evaluated"), dict) and "value" in cfg["evaluated"]:
+            digest[f"{tag}_evaluated_states_per_s"] = cfg["evaluated"]["value"]
+    if digest:
+        digest["note"] = "solves/s unless named otherwise; each is detailed under its own key further on"
+        head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data")
+        line = {**{k: line[k] for k in head if k in line}, "digest": digest, **{k: v for k, v in line.items() if k not in head}}
     return line
 
 

@@ -414,7 +414,7 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
   p->lane_note[0] = 0;
   // The quad kernel runs 16 problems per wavefront, one wavefront per SIMD: up to n_cu * 4 * 16 problems (16384) are ONE
   // round of it (~21 us for the double wishbone).  One problem more is a second round (~38 us), while the lane kernel
-  // takes 25 ... 29 us for anything up to n_cu * 4 * 64 problems (tools/lane_threshold.py): auto selection switches there.
+  // takes 25 ... 29 us for anything up to n_cu * 4 * 64 problems (profiles/r03/EXPERIMENTS.md): auto selection switches there.
   p->lane_min_problems = (long long)p->n_cu * 4 * 16 + 1;
   if (!p->quad_fn_u || p->quad_ppw != 16) {
     std::snprintf(p->lane_note, sizeof(p->lane_note), "no single-mode quad kernel to share first-step tables with");

@@ -202,15 +202,17 @@ def _coordinate_columns(positions) -> np.ndarray:
 class ResultTable:
     """
     Columns of a result file: ``name -> 1-D array`` in file order (bool, int64, float64 or str), a unit per column where
-    one is known, and a validity mask for float columns whose NaNs mean "undefined here" (written as empty cells / nulls).
+    one is known, and per column an optional mask of MISSING values (the reference's ``None``: an empty CSV cell, a Parquet
+    null).  A NaN that is not masked is a value and is written as one (``nan`` / NaN), like the reference writes it.
     """
 
     def __init__(self) -> None:
         self.columns: dict[str, np.ndarray] = {}
         self.units: dict[str, str] = {}
+        self.missing: dict[str, np.ndarray] = {}
         self.n_rows: int | None = None
 
-    def add(self, name: str, values, unit: str | None = None) -> None:
+    def add(self, name: str, values, unit: str | None = None, missing=None) -> None:
         array = _host(values)
         if array.ndim != 1:
             raise ValueError(f"column '{name}' is not one-dimensional: shape {array.shape}")
@@ -229,6 +231,12 @@ class ResultTable:
         elif array.dtype.kind not in "UO":
             raise ValueError(f"column '{name}' has unsupported dtype {array.dtype}")
         self.columns[name] = array
+        if missing is not None:
+            mask = np.asarray(missing, dtype=np.bool_)
+            if mask.shape != array.shape:
+                raise ValueError(f"column '{name}': the missing-value mask has shape {mask.shape}, the column {array.shape}")
+            if mask.any():
+                self.missing[name] = mask
         if unit is not None:
             self.set_unit(name, unit)
 
@@ -247,6 +255,7 @@ class ResultTable:
         out = ResultTable()
         out.n_rows, out.units = self.n_rows, dict(self.units)
         out.columns = {name: values[order] for name, values in self.columns.items()}
+        out.missing = {name: mask[order] for name, mask in self.missing.items()}
         return out
 
     @classmethod
@@ -254,8 +263,9 @@ class ResultTable:
                    metric_units: Mapping[str, Any] | None = None, step_index=None) -> "ResultTable":
         """
         The table of a batched device run: ``positions [B, n_out, 3]`` (tensor or array), ``info`` the structured array of
-        ``BatchResult.info()``, ``metrics`` ``name -> [B]`` in file order (NaN = undefined), ``metric_units`` overrides /
-        additions to the units known by name (strings, units or specs).
+        ``BatchResult.info()``, ``metrics`` ``name -> [B]`` in file order (NaN = undefined: the device's spelling of the
+        reference's ``None``, written as missing), ``metric_units`` overrides / additions to the units known by name
+        (strings, units or specs).  A NaN in a solver column or a coordinate is a value and stays one.
         """
         from ._abi import INFO_CONVERGED, INFO_FAILED, INFO_RESIDUAL_EXCEEDED
 
@@ -270,7 +280,8 @@ class ResultTable:
         table.add("solver_nfev", np.asarray(info["nfev"]))
         overrides = {name: _unit_symbol(u) for name, u in (metric_units or {}).items()}
         for name, values in (metrics or {}).items():
-            table.add(name, np.asarray(_host(values), dtype=np.float64), overrides.get(name) or metric_unit(name))
+            column = np.asarray(_host(values), dtype=np.float64)
+            table.add(name, column, overrides.get(name) or metric_unit(name), missing=np.isnan(column))
         coordinates = _coordinate_columns(positions)
         for k, index in enumerate(program.out_point):
             name = point_key_name(program.point_keys[index])
@@ -287,13 +298,11 @@ class ResultTable:
         table = self.sorted_by_step()
         arrays, fields = [], []
         for name, values in table.columns.items():
-            if values.dtype == np.float64:
-                missing = np.isnan(values)
-                array = pa.array(values, type=pa.float64(), mask=missing if missing.any() else None)
-            elif values.dtype.kind in "UO":
+            missing = table.missing.get(name)
+            if values.dtype.kind in "UO":
                 array = pa.array([None if v is None else str(v) for v in values.tolist()], type=pa.string())
             else:
-                array = pa.array(values)
+                array = pa.array(values, mask=missing)
             unit = table.units.get(name)
             arrays.append(array)
             fields.append(pa.field(name, array.type, metadata={b"unit": unit.encode("utf-8")} if unit else None))
@@ -311,7 +320,7 @@ class ResultTable:
             text.write(f"# {key}: {value}\n")
         text.write(f"# column_units: {json.dumps(table.units, sort_keys=True)}\n#\n")
         text.write(",".join(_csv_cell(name) for name in table.columns) + "\n")
-        cells = [_csv_column(values) for values in table.columns.values()]
+        cells = [_csv_column(values, table.missing.get(name)) for name, values in table.columns.items()]
         text.write("\n".join(map(",".join, zip(*cells))))
         if table.n_rows:
             text.write("\n")
@@ -327,13 +336,16 @@ def _csv_cell(value: str) -> str:
     return value
 
 
-def _csv_column(values: np.ndarray) -> list[str]:
-    """Cells of one column: ``repr`` of bools / ints / floats (what ``csv.writer`` emits), empty for NaN / None."""
-    if values.dtype == np.float64:
-        return ["" if v != v else repr(v) for v in values.tolist()]
+def _csv_column(values: np.ndarray, missing=None) -> list[str]:
+    """Cells of one column: ``repr`` of bools / ints / floats (what ``csv.writer`` emits; a NaN reads ``nan``), empty where
+    the value is missing (the reference's ``None``)."""
     if values.dtype.kind in "UO":
         return ["" if v is None else _csv_cell(str(v)) for v in values.tolist()]
-    return [repr(v) for v in values.tolist()]
+    cells = [repr(v) for v in values.tolist()]
+    if missing is not None:
+        for k in np.nonzero(missing)[0].tolist():
+            cells[k] = ""
+    return cells
 
 
 # ---- the reference's per-step calling convention ---------------------------------------------------------------------
@@ -420,20 +432,22 @@ class _FrameWriter:
             raise ValueError(self._column_error)
         table = ResultTable()
         for name, values in zip(self._names, self._values):
-            kinds = {type(v) for v in values if v is not None}
-            if kinds <= {bool} and kinds:
-                array = np.asarray(values, dtype=np.bool_)
-            elif kinds <= {int} and kinds and not name.endswith(("_x", "_y", "_z")) and None not in values:
-                array = np.asarray(values, dtype=np.int64)
-            elif kinds <= {int, float, bool, np.float64}:
-                array = np.asarray([np.nan if v is None else float(v) for v in values], dtype=np.float64)
-            elif kinds <= {str}:
-                array = np.asarray(values, dtype=object)
-            else:
-                bad = next(v for v in values if v is not None and not isinstance(v, (bool, int, float, str)))
+            # the reference's type inference (cli/io/results_writer.py:316-335), None = a missing value
+            bad = next((v for v in values if v is not None and not isinstance(v, (bool, int, float, str))), None)
+            if bad is not None:
                 raise ValueError(f"column '{name}' contains unexpected type {type(bad).__name__}: {bad!r}. "
                                  "Expected bool, int, float, str, or None.")
-            table.add(name, array, self.column_units.get(name))
+            missing = np.fromiter((v is None for v in values), dtype=np.bool_, count=len(values))
+            if all(isinstance(v, bool) or v is None for v in values):  # (a column of nothing but None is a bool column of nulls)
+                array = np.asarray([bool(v) for v in values], dtype=np.bool_)
+            elif all(isinstance(v, int) or v is None for v in values) and not name.endswith(("_x", "_y", "_z")):
+                array = np.asarray([0 if v is None else v for v in values], dtype=np.int64)
+            elif all(isinstance(v, (int, float)) or v is None for v in values):
+                array = np.asarray([np.nan if v is None else float(v) for v in values], dtype=np.float64)
+            else:  # strings, or strings mixed with numbers: a string column
+                array = np.asarray([None if v is None else str(v) for v in values], dtype=object)
+                missing = None
+            table.add(name, array, self.column_units.get(name), missing=missing)
         return table
 
 

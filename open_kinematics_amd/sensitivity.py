@@ -155,17 +155,26 @@ def compute_state_tangents(state, constraints, derived_manager, step_targets: Se
 
 
 def combine_tangents(fields: Sequence[TangentField], coefficients: Sequence[float]) -> dict:
-    """Linear combination of tangent fields (``sensitivity.py:177-196``)."""
-    if len(fields) != len(coefficients):
-        raise ValueError(
-            f"Field/coefficient count mismatch: {len(fields)} fields, {len(coefficients)} coefficients."
-        )
-    combined: dict = {}
-    for field, coefficient in zip(fields, coefficients):
-        for point_id, velocity in field.velocities.items():
-            accumulated = combined.get(point_id)
-            if accumulated is None:
-                combined[point_id] = coefficient * velocity
-            else:
-                accumulated += coefficient * velocity
-    return combined
+    """
+    The velocity field ``sum_k coefficients[k] * fields[k]`` as ``{point key: velocity}`` (the reference's
+    ``combine_tangents``, ``sensitivity.py:177-196``).  The fields of one state hold the rows ``[T, n_points, 3]`` of one
+    device tensor: they are stacked back into that array and contracted in one product; a point that only some fields
+    carry counts as zero in the others.
+    """
+    weights = np.asarray(list(coefficients), dtype=np.float64)
+    if len(fields) != weights.shape[0]:
+        raise ValueError(f"Field/coefficient count mismatch: {len(fields)} fields, {weights.shape[0]} coefficients.")
+    keys: list = []
+    seen = set()
+    for field in fields:
+        for key in field.velocities:
+            if key not in seen:
+                seen.add(key)
+                keys.append(key)
+    stacked = np.zeros((len(fields), len(keys), 3), dtype=np.float64)
+    column = {key: k for k, key in enumerate(keys)}
+    for row, field in zip(stacked, fields):
+        for key, velocity in field.velocities.items():
+            row[column[key]] = velocity
+    combined = np.tensordot(weights, stacked, axes=(0, 0))
+    return {key: combined[k] for k, key in enumerate(keys)}

@@ -110,9 +110,12 @@ def test_solve_steered_against_oracle_and_reference(golden, name):
     assert np.max(np.abs(info["max_residual"] - arrays["ref_tight_maxres"])) <= 1e-8
 
 
-def test_softnorm_rows_on_device_reach_the_same_point(golden):
-    """The reference's own (degenerate) row set also runs on device; looser step tolerance."""
-    arrays, program = golden("c1_dw_corner")
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c3_axle_grid", "c4_macpherson_grid"])
+def test_softnorm_rows_on_device_reach_the_same_point(golden, name):
+    """The reference's own (degenerate) row set also runs on device - corner, composed axle (pair mode) and MacPherson;
+    looser step tolerance: along the zero-gradient line row the iteration converges linearly."""
+    arrays, program = golden(name)
+    assert any(int(t) == 8 for t in program.row_type)  # the literal point-on-line row
     pos_s, info_s = _solve(program, arrays["targets_abs"], step_tol=1e-8, max_iter=200)
     pos_p, _ = _solve(program.with_line_mode("pinned"), arrays["targets_abs"])
     assert np.all((info_s["flags"] & 1) == 1)

@@ -194,3 +194,35 @@ def test_a_million_row_ensemble_goes_to_parquet_in_seconds(tmp_path):
     meta = pq.read_metadata(tmp_path / "c5.parquet")
     assert meta.num_rows == n and meta.num_columns == 4 + 2 + 3 * program.n_out
     assert elapsed < 5.0, f"{elapsed:.1f} s"
+
+
+def test_none_is_missing_and_nan_is_a_value_like_the_reference(tmp_path):
+    """cli/io/results_writer.py:316-335: None -> empty cell / null; a NaN stays a NaN; a column of nothing but None is a
+    bool column of nulls; strings mixed with numbers fall back to a string column."""
+    import pyarrow.parquet as pq
+
+    frames = [
+        SolutionFrame({"p": (0.0, 0.0, 0.0)}, SolverInfo(False, 7, float("nan")), {"camber": None, "never": None, "mixed": "left", "anti": 1.5}),
+        SolutionFrame({"p": (0.0, 0.0, 1.0)}, SolverInfo(True, 3, 1e-9), {"camber": -0.5, "never": None, "mixed": 2, "anti": float("nan")}),
+    ]
+    for cls, path in ((CsvWriter, tmp_path / "out.csv"), (ParquetWriter, tmp_path / "out.parquet")):
+        writer = cls(path, None, None)
+        for k, frame in enumerate(frames):
+            writer.add_frame(k, frame)
+        writer.write()
+    rows = [r for r in csv.reader(l for l in open(tmp_path / "out.csv") if not l.startswith("#"))]
+    head, first, second = rows[0], dict(zip(rows[0], rows[1])), dict(zip(rows[0], rows[2]))
+    assert first["solver_max_residual"] == "nan" and second["solver_max_residual"] == "1e-09"   # a failed solve's NaN is a value
+    assert first["camber"] == "" and second["camber"] == "-0.5"                                  # None is a missing cell
+    assert first["never"] == "" and second["never"] == ""
+    assert first["mixed"] == "left" and second["mixed"] == "2"
+    assert first["anti"] == "1.5" and second["anti"] == "nan"
+    table = pq.read_table(tmp_path / "out.parquet")
+    assert str(table.schema.field("never").type) == "bool" and table["never"].null_count == 2
+    assert str(table.schema.field("mixed").type) == "string" and table["mixed"].to_pylist() == ["left", "2"]
+    assert table["camber"].to_pylist() == [None, -0.5]
+    residual = table["solver_max_residual"].to_pylist()
+    assert residual[0] != residual[0] and table["solver_max_residual"].null_count == 0
+    anti = table["anti"].to_pylist()
+    assert anti[0] == 1.5 and anti[1] != anti[1] and table["anti"].null_count == 0
+    assert head[:4] == ["step_index", "solver_converged", "solver_max_residual", "solver_nfev"]
