@@ -95,6 +95,8 @@ struct okx_program {
   hipFunction_t lane_fn_u, lane_fn_g, lane_fn_eval;  // independent solves (chain_len 1), parity kernel
   hipFunction_t lane_chain_u, lane_chain_g;          // chains
   hipFunction_t lane_compact[4];                     // the same four with compact outputs (solve_u, solve_g, chain_u, chain_g)
+  hipFunction_t lane_nest[4];                        // nested start mode: u, g, u compact, g compact (null: none)
+  int lane_nest_scratch;
   long long lane_min_problems;
   int lane_cold_scratch, lane_chain_scratch;  // private-segment bytes of the two bodies (code object metadata)
   bool lane_cold_ok, lane_chain_ok;           // bodies that auto selection may use
@@ -223,7 +225,9 @@ int resident_blocks_per_cu(const void* fn, size_t lds_bytes, int threads = okx::
 }
 
 int quad_waves_per_simd() {
-  return 1;
+  // (developer switch quad_two_waves: __launch_bounds__(64, 2), i.e. at most 256 registers per lane - what a second resident
+  //  wavefront per SIMD would need; profiles/r05/EXPERIMENTS.md section 4 has what the compiler makes of it)
+  return okx::dev_switch("quad_two_waves") ? 2 : 1;
 }
 
 // The first-step table of the program's own geometry for `lambda0`: found, or filled by one wavefront of okx_quad_head_u
@@ -411,6 +415,7 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
   p->lane_extra_mods = nullptr;
   p->lane_fn_u = p->lane_fn_g = p->lane_fn_eval = nullptr;
   p->lane_chain_u = p->lane_chain_g = nullptr;
+  p->lane_nest[0] = p->lane_nest[1] = p->lane_nest[2] = p->lane_nest[3] = nullptr;
   p->lane_note[0] = 0;
   // The quad kernel runs 16 problems per wavefront, one wavefront per SIMD: up to n_cu * 4 * 16 problems (16384) are ONE
   // round of it (~21 us for the double wishbone).  One problem more is a second round (~38 us), while the lane kernel
@@ -507,6 +512,16 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
     p->lane_extra_mods->push_back(extra);
     *slot = fn;
   }
+  // the nested start mode (chain_len = -1 on large sweeps): kept while it does not spill more than the independent-solve body may
+  static const char* const kNest[4] = {"okx_lane_nest_u", "okx_lane_nest_g", "okx_lane_nest_u_c", "okx_lane_nest_g_c"};
+  p->lane_nest_scratch = okx::quad_code_scratch_bytes(code, "okx_lane_nest");
+  for (int k = 0; k < 4; ++k)
+    if (hipModuleGetFunction(&p->lane_nest[k], mod, kNest[k]) != hipSuccess) {
+      (void)hipGetLastError();
+      p->lane_nest[k] = nullptr;
+    }
+  if (p->lane_nest_scratch < 0 || p->lane_nest_scratch > (okx::dev_switch("lane_timeline") ? 1 << 20 : 256) || !p->lane_nest[0] || !p->lane_nest[1] || !p->lane_nest[2] || !p->lane_nest[3])
+    p->lane_nest[0] = p->lane_nest[1] = p->lane_nest[2] = p->lane_nest[3] = nullptr;
   p->lane_mod = mod;
   std::atomic_thread_fence(std::memory_order_release);
   p->lane_fn_u = lane_u;  // the gate of the lane kernel's launch path, published last
@@ -978,7 +993,14 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
   bool use_lane = p->lane_fn_u != nullptr && use_quad && opts->predictor == 0 && (p->quad_trace == nullptr || okx::dev_switch("lane_timeline")) &&
                   (opts->kernel == 4 || (opts->kernel == 0 && n_problems >= p->lane_min_problems && lane_pays()));
   bool lane_auto_cold = false;  // chain_len = -1 resolved to independent solves on the lane kernel
-  if (use_lane && opts->kernel == 0) {
+  bool lane_nested = false;     // ... or to the nested start mode (okx_lane_nest_*: four steps per lane, 256 per wave unit)
+  if (use_lane && (opts->kernel == 0 || opts->kernel == 4) && opts->chain_len == -1 && p->lane_nest[0] && !evaluated) {
+    // "auto" on a sweep that fills wave units of 256 consecutive steps: the nested start mode - every step but a lane's
+    // first starts from the interpolant of already solved neighbours (one full pass + the confirming evaluation)
+    const long long span0 = spg > 0 ? spg : n_problems;
+    lane_nested = span0 >= 256 && (span0 % 256 == 0 || span0 >= 2048);
+  }
+  if (use_lane && opts->kernel == 0 && !lane_nested) {
     const long long span0 = spg > 0 ? spg : n_problems;
     long long len0 = opts->chain_len;
     if (len0 == 0) len0 = opts->chain ? span0 : 1;
@@ -1030,6 +1052,7 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
       }
     }
     if (lane_auto_cold) len = 1;
+    if (lane_nested) len = okx::kLaneNestSteps;
     if (len < 1) len = 1;
     if (len > span) len = span;
     a.chain_len = len;
@@ -1136,7 +1159,11 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
       if (opts->output != OKX_OUTPUT_RECORDS) fn = p->lane_compact[(a.chain_len == 1 ? 0 : 2) + (d_geom_pos ? 1 : 0)];
       if (evaluated) fn = d_geom_pos ? p->ev_lane_g : p->ev_lane_u;
       void* ring = nullptr;
-      if (a.chain_len != 1 && okx::lane_chain_is_flat(p->host.n)) {
+      if (lane_nested) {
+        fn = p->lane_nest[(opts->output != OKX_OUTPUT_RECORDS ? 2 : 0) + (d_geom_pos ? 1 : 0)];
+        HIP_TRY(hipMallocAsync(&ring, sizeof(double) * (size_t)okx::lane_nest_doubles(p->host.n) * (size_t)lane_grid, (hipStream_t)stream));
+        q.predictor = static_cast<const double*>(ring);
+      } else if (a.chain_len != 1 && okx::lane_chain_is_flat(p->host.n)) {
         // what a flat chain body carries from step to step (okx_quad.hpp lane_chain_is_flat): scratch of this launch,
         // allocated and freed in stream order (legal under stream capture, no device-wide synchronisation)
         HIP_TRY(hipMallocAsync(&ring, sizeof(double) * (size_t)okx::lane_flat_chain_doubles(p->host.n) * (size_t)lane_grid, (hipStream_t)stream));

@@ -1527,7 +1527,15 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   LGen& evc_ = evc;
   const PassSrc& pass_cold_ = pass_cold;
   // `gb`: the independent-solve body of per-geometry launches (tables and first-step table staged in LDS, see split_g)
-  auto body = [&](bool ch, bool fl, bool gb) -> bool {
+  // `ns` (with `fl`): the NESTED start mode - the warm-started form of a sweep for a kernel whose lanes run in lockstep.
+  // A lane owns four consecutive steps of its span, as in a flat chain of four, and a wave unit therefore 256 consecutive
+  // steps of one geometry; but the four are solved in the order 0, 2, 1, 3, and every one after the first starts from the
+  // Lagrange interpolant (in the step index) of the up to six nearest steps the wave unit has already solved - its own and
+  // its neighbour lanes', read from the launch's scratch [step of four][slot][lane].  Step 0 of every lane is a cold start
+  // (first-step table); steps 2, 1 and 3 start ~1e-8 mm from their solutions instead of a secant's ~1e-4: one full pass
+  // and one confirming evaluation.  What a chain carries beside the point - the damping it ended with, the contraction
+  // constant it observed - comes from the lane's own step 0.
+  auto body = [&](bool ch, bool fl, bool gb, bool ns = false) -> bool {
     LGen& evc = gb ? evg : evc_;
     const PassSrc& pass_cold = gb ? pass_g : pass_cold_;
     int n_slots = 0;
@@ -1547,7 +1555,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     const int state_doubles_before_l = 64 * n_slots;  // x, dx (and the chain history): live from the prologue on
     if (!ch) n_slots = evc.l_lds_base + evc.l_lds_slots > n_slots + (int)evc.j_home.size() ? evc.l_lds_base + evc.l_lds_slots : n_slots + (int)evc.j_home.size();  // + the rows' gradients / the factor's first rows
     const int state_doubles = 64 * n_slots;
-    const int stage_doubles = ch || fl ? 0 : 64 * 3 * P.n_out;
+    const int stage_doubles = (ch || fl) && !ns ? 0 : 64 * 3 * P.n_out;
     int lds_doubles = state_doubles > stage_doubles ? state_doubles : stage_doubles;
     if (EV && lds_doubles < 64 * ((3 * P.n_out) | 1)) lds_doubles = 64 * ((3 * P.n_out) | 1);  // (tangent rows [lane][record | 1]; result rows [lane][25])
     if (EV && lds_doubles < 64 * 25) lds_doubles = 64 * 25;
@@ -1564,9 +1572,9 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       lds_why = "per-wavefront LDS state exceeds 40 KiB";
       return false;
     }
-    const bool tl = timeline && !ch && !fl;
+    const bool tl = timeline && ((!ch && !fl) || ns);  // (nested mode: one row per unit-step, `it`)
     auto stamp = [&](int slot) {
-      if (tl) g.f("    if (a.trace && lane == 0) a.trace[wu * 32 + %d] = (double)__builtin_readcyclecounter();", slot);
+      if (tl) g.f("    if (a.trace && lane == 0) a.trace[%s * 32 + %d] = (double)__builtin_readcyclecounter();", ns ? "it" : "wu", slot);
     };
     auto mark = [&](int k) {
       if (marks && !ch && !fl) g.f("    __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop %d\"); __builtin_amdgcn_sched_barrier(0);", 10 + k);
@@ -1584,7 +1592,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
           ev.gl_gq0, ev.gl_tq0, ev.gl_gq0, ev.gl_dp0, ev.gl_tq0 - 8 * P.n_crows, ev.gl_dp0);
     } else
       g.f("#define GL(o) gl[(o) + kz]");
-    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a%s) {", ch || fl ? "chain" : gb ? "coldg" : "cold", EV ? ", const QEvArgs& ea" : "");
+    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a%s) {", ns ? (gb ? "nestg" : "nest") : ch || fl ? "chain" : gb ? "coldg" : "cold", EV ? ", const QEvArgs& ea" : "");
     g.f("  const int lane = threadIdx.x;");
     g.f("  __shared__ double lds[%d];", lds_doubles);
     if (sc) g.f("  int kzs = 0;  // an opaque zero in a scalar register: a table read inside a pass is a load of that pass, not a loop invariant");
@@ -1609,11 +1617,14 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       // lane's chain are consecutive iterations of ONE loop whose body carries nothing from one iteration to the next
       g.f("  const long long wu_per_wave = (n_wave_units + gridDim.x - 1) / gridDim.x;");
       g.f("  const long long wu_lo = blockIdx.x * wu_per_wave, wu_hi = wu_lo + wu_per_wave < n_wave_units ? wu_lo + wu_per_wave : n_wave_units;");
-      g.f("  double* const ring = const_cast<double*>(a.predictor) + (long long)blockIdx.x * %lld + lane;  // [entry][slot][lane]", lane_flat_chain_doubles(n));
+      g.f("  double* const ring = const_cast<double*>(a.predictor) + (long long)blockIdx.x * %lld + lane;  // [entry][slot][lane]", ns ? lane_nest_doubles(n) : lane_flat_chain_doubles(n));
       g.f("  long long staged_span = -1;");
+      if (gb) g.f("  const bool with_head_all = a.head != nullptr && a.grad_tol <= 0.0;");
       g.f("  for (long long it = wu_lo * unit_len; it < wu_hi * unit_len; ++it) {");
       g.f("    const long long wu = uni64(it / unit_len);");
       g.f("    const int step = (int)uni64(it - wu * unit_len);  // wave-uniform: every lane of the wave unit is at this step of its chain");
+      if (ns) g.f("    const int sidx = step == 1 ? 2 : step == 2 ? 1 : step;  // which of its four steps a lane solves now: 0, 2, 1, 3");
+      else g.f("    const int sidx = step;");
     } else if (cold) {
       // Own geometry: the tables are staged once per wavefront, the wave units dealt out round-robin (a unit's cost goes with
       // its place in the sweep: neighbours to different wavefronts).  Per-geometry tables: every wavefront takes a contiguous
@@ -1651,8 +1662,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     if (ch)
       for (int t = 0; t < T; ++t) g.f("    double tn%d = a.targets[first_b * %d + %d], tp%d = 0.0, tq%d = 0.0, tr%d = 0.0;", t, T, t, t, t, t);
     else if (fl) {
-      g.f("    const bool valid = have && first_b + step < last_b;");
-      g.f("    const long long bb = valid ? first_b + step : last_b - 1;");
+      g.f("    const bool valid = have && first_b + sidx < last_b;");
+      g.f("    const long long bb = valid ? first_b + sidx : last_b - 1;");
       for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[bb * %d + %d];", t, T, t);
     } else
       for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[first_b * %d + %d];", t, T, t);
@@ -1664,7 +1675,15 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     } else {
     g.f("    // the geometry's tables (and its first-step table) into LDS, lane k fetching entry k");
     g.f("    WAVE_SYNC();  // (the previous wave unit's last reads of these areas are done)");
-    if (fl) {
+    if (fl && gb) {  // (the nested mode's per-geometry kernels: tables and first-step table staged once per geometry, like coldg)
+      g.f("    if (span_idx != staged_span) {  // wave-uniform: the tables stay while the geometry does");
+      g.f("      const bool with_head = with_head_all;");
+      g.f("      const double* hsrc = a.head + span_idx * %d;", head_stride);
+      stage_tables_batched(g, "      ", gl_size);
+      g.f("      staged_span = span_idx;");
+      g.f("    }");
+      g.f("    const bool with_head = with_head_all && step == 0;");
+    } else if (fl) {
       g.f("    if (span_idx != staged_span) {  // wave-uniform: the tables stay while the geometry does");
       stage_tables(g, "      ");
       g.f("      staged_span = span_idx;");
@@ -1776,6 +1795,95 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      } else {");
       for (int i = 0; i < n; ++i) g.f("        { const double xo = x%d; xq%d = xp%d; xp%d = xo; }", i, i, i, i);
       g.f("      }");
+    } else if (fl && ns) {
+      // Nested start: the Lagrange interpolant, in the step index, of the nearest steps this wave unit has solved (own and
+      // neighbour lanes'), over whichever of eight candidates exist - four on either side inside the wave unit, so that the
+      // lanes at its ends still have four or five on one side: a unit-step takes the passes of its slowest lane.  Entry
+      // [step of four]: n coordinates, converged?, damping, contraction constant.  No candidate (a neighbourhood that
+      // failed): the design state, like a chain that restarts.
+      const int E = (n + 3) * 64, K = 8;
+      struct Cand { int dl, q, o; };
+      const Cand cand[3][K] = {
+          {{-3, 0, -14}, {-2, 0, -10}, {-1, 0, -6}, {0, 0, -2}, {1, 0, 2}, {2, 0, 6}, {3, 0, 10}, {4, 0, 14}},          // second step (third of the four)
+          {{-2, 0, -9}, {-2, 1, -7}, {-1, 0, -5}, {-1, 1, -3}, {0, 0, -1}, {0, 1, 1}, {1, 0, 3}, {1, 1, 5}},            // third step (second of the four)
+          {{-1, 2, -6}, {-1, 1, -5}, {0, 0, -3}, {0, 2, -2}, {0, 1, -1}, {1, 0, 1}, {1, 2, 2}, {1, 1, 3}}};             // fourth step
+      g.f("    {");
+      for (int t = 0; t < T; ++t) g.f("      const double tv%d = tn%d;", t, t);
+      g.f("      double lambda_carry = 0.0, cq_carry = 0.0;");
+      g.f("      if (step > 0) {");
+      // (entries stored by other lanes of THIS wavefront, through the same L1: its vector-memory instructions execute in
+      //  order, so what separates the stores from these loads is an ordering for the compiler - an agent-scope release
+      //  would wait for every record store in flight)
+      g.f("        WAVE_SYNC();");
+      // (opaque: derived from a loop invariant, every candidate address of every coordinate would be hoisted out of the
+      //  unit-step loop, kept alive across the passes and spilled - a kilobyte of scratch, read back at memory latency)
+      g.f("        const double* rb = ring - lane;  // this wavefront's entries [step][slot][lane]");
+      g.f("        asm volatile(\"\" : \"+v\"(rb));");
+      // Few round trips per unit-step: the lane's own first entry (damping, contraction constant), the candidates' flags and
+      // their coordinates - half of the coordinates at a time - are loaded unconditionally (clamped lane indices: every
+      // address is a valid entry) and pinned as a batch; flags, weights and selects afterwards.  (As written first - flags,
+      // then per coordinate the loads under `v ? load : 0` - the compiler issued 20-odd dependent round trips to the
+      // Infinity Cache: 14 us per unit-step, tools/lane_timeline.py c5nest.)
+      g.f("        const double own_ok = rb[%d + lane], own_lambda = rb[%d + lane], own_cq = rb[%d + lane];", 64 * n, 64 * (n + 1), 64 * (n + 2));
+      g.f("        bool v0 = false, v1 = false, v2 = false, v3 = false, v4 = false, v5 = false, v6 = false, v7 = false;");
+      g.f("        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0, w7 = 0.0;");
+      for (int q = 1; q <= 3; ++q) {
+        g.f("        %sif (step == %d) {", q > 1 ? "else " : "", q);
+        std::string fpin = "          asm volatile(\"\" : ";
+        for (int j = 0; j < K; ++j) {
+          const Cand& c = cand[q - 1][j];
+          g.f("          const int lc%d = lane + (%d) < 0 ? 0 : (lane + (%d) > 63 ? 63 : lane + (%d));", j, c.dl, c.dl, c.dl);
+          g.f("          const double* en%d = rb + %d + lc%d;", j, c.q * E, j);
+          g.f("          double f%d = en%d[%d];", j, j, 64 * n);
+          fpin += std::string(j ? ", " : "") + "\"+v\"(f" + std::to_string(j) + ")";
+        }
+        for (int half = 0; half < 2; ++half) {
+          const int i0 = half * ((n + 1) / 2), i1 = half ? n : (n + 1) / 2;
+          g.f("          __builtin_amdgcn_sched_barrier(0);");
+          g.f("          {");
+          for (int i = i0; i < i1; ++i)
+            for (int j = 0; j < K; ++j) g.f("            double t%d_%d = en%d[%d];", j, i, j, 64 * i);
+          if (half == 0) g.out += fpin + ");\n";
+          for (int i = i0; i < i1; i += 3) {  // (an asm statement takes 30 operands)
+            std::string pin = "            asm volatile(\"\" : ";
+            bool first = true;
+            for (int k = i; k < i + 3 && k < i1; ++k)
+              for (int j = 0; j < K; ++j) {
+                pin += std::string(first ? "" : ", ") + "\"+v\"(t" + std::to_string(j) + "_" + std::to_string(k) + ")";
+                first = false;
+              }
+            g.out += pin + ");\n";
+          }
+          if (half == 0) {
+            for (int j = 0; j < K; ++j) {
+              const Cand& c = cand[q - 1][j];
+              g.f("            v%d = lane + (%d) >= 0 && lane + (%d) < 64 && f%d > 0.5;", j, c.dl, c.dl, j);
+            }
+            for (int j = 0; j < K; ++j) {
+              std::string w = "1.0";
+              for (int k = 0; k < K; ++k) {
+                if (k == j) continue;
+                char buf[96];
+                std::snprintf(buf, sizeof(buf), " * (v%d ? %.17g : 1.0)", k, (0.0 - cand[q - 1][k].o) / (double)(cand[q - 1][j].o - cand[q - 1][k].o));
+                w += buf;
+              }
+              g.f("            w%d = v%d ? %s : 0.0;", j, j, w.c_str());
+            }
+          }
+          g.f("            if (v0 || v1 || v2 || v3 || v4 || v5 || v6 || v7) {");
+          for (int i = i0; i < i1; ++i) {
+            std::string e;
+            for (int j = 0; j < K; ++j) e += std::string(j ? " + " : "") + "w" + std::to_string(j) + " * (v" + std::to_string(j) + " ? t" + std::to_string(j) + "_" + std::to_string(i) + " : 0.0)";
+            g.f("              x%d = %s;", i, e.c_str());
+          }
+          g.f("            }");
+          g.f("          }");
+          if (half == 0) continue;
+        }
+        g.f("        }");
+      }
+      g.f("        if (own_ok > 0.5) { lambda_carry = own_lambda; cq_carry = own_cq; }  // (the lane's own first step)");
+      g.f("      }");
     } else if (fl) {
       // Start of a chain step: from the ring of this lane's chain - the last three steps' solutions, whether each
       // converged, the damping the last one ended with - exactly what the looping chain body keeps in x / xp / xq, hist
@@ -1827,6 +1935,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("      int mode = 0;  // 0 first evaluation, 1 trial point, 2 re-evaluation of the accepted point");
     g.f("      bool done = !valid, want_light = false;");
     g.f("      double prev_sl = 0.0, piv_lo = 0.0, piv_hi = 0.0;");
+    if (ns) g.f("      double cq_seen = 0.0;");
     g.f("      if (head_ready%s) {", ch ? " && b == first_b" : "");
     g.f("        const bool at_design = valid%s && hs4 > 0.5;", ch ? " && hist == 1" : "");
     g.f("        if (at_design) {");
@@ -1973,9 +2082,28 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("        step_len = sl; pred = pr;");
     g.f("        if (sl <= a.step_tol) { flags |= INFO_CONVERGED; last_step = sl; done = true; }");
     g.f("        else {");
+    if (ns) {
+      // (a warm-started step has no earlier step of its own to read the quadratic contraction from: the constant its lane
+      //  observed on the first of its four steps - same mechanism, same place on the solution manifold - stands in for
+      //  the 1 / mm a cold problem's first step is given)
+      g.f("          const double cq = prev_sl > 0.0 ? fmax(3.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : (cq_carry > 0.0 ? cq_carry : 1.0);");
+      g.f("          if (prev_sl > 0.0) cq_seen = fmax(cq_seen, cq);");
+    } else
     g.f("          const double cq = prev_sl > 0.0 ? fmax(3.0 * sl * fast_rcp(prev_sl * prev_sl), 1e-3) : 1.0;");
     g.f("          const double rho_lin = 100.0 * lambda * fast_rcp(pmin);");
     g.f("          want_light = sl <= 1e-3 && (rho_lin + cq * sl) * sl <= a.step_tol;");
+    if (ns) {
+      // Nested mode, interpolated starts: the start is ~1e-8 mm from the solution and this Gauss-Newton step lands within
+      // a THOUSANDTH of step_tol of it by the same prediction that otherwise asks for a confirming evaluation.  With that
+      // margin the step is taken as it is - one pass per step instead of a pass and a confirming pass (which costs a lone
+      // wavefront most of a full pass: tools/lane_timeline.py c5nest); cost and max_residual in the info record are then
+      // those of the point the step started from (~1e-8 off the rows' final values).  okx_solve_opts.confirm_full_pass
+      // switches it off with the confirming evaluations.
+      g.f("          if (step > 0 && a.confirm == 0 && sl <= 1e-5 && (rho_lin + cq * sl) * sl <= 1e-3 * a.step_tol) {");
+      for (int i = 0; i < n; ++i) g.f("            x%d = x%d + nx%d;", i, i, i);
+      g.f("            last_step = sl; flags |= INFO_CONVERGED; done = true; want_light = false;");
+      g.f("          }");
+    }
     g.f("          prev_sl = sl;");
     g.f("        }");
     g.f("        mode = 1;");
@@ -1991,7 +2119,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("      }  // LM passes");
     stamp(3);
     if (tl) {
-      g.f("    if (a.trace && lane == 0) { double* tr = a.trace + wu * 32; tr[4] = tl_full; tr[5] = tl_light; tr[6] = tl_sec1; tr[7] = tl_sec2;");
+      g.f("    if (a.trace && lane == 0) { double* tr = a.trace + %s * 32; tr[4] = tl_full; tr[5] = tl_light; tr[6] = tl_sec1; tr[7] = tl_sec2;", ns ? "it" : "wu");
       g.f("      tr[8] = tl_sec3; tr[9] = tl_sec4; tr[10] = tl_sec5; tr[11] = tl_sec6; }");
     }
     // final state and output
@@ -2019,7 +2147,13 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      lambda_carry = lambda;");
       g.f("    }");
     }
-    if (fl) {
+    if (fl && ns) {
+      g.f("    { double* r0 = ring + step * %d;  // this step's entry: solution, converged?, damping, contraction constant", (n + 3) * 64);
+      g.f("      _Pragma(\"unroll 6\")");
+      g.f("      for (int i = 0; i < %d; ++i) r0[64 * i] = lds[128 * i + lane];  // (x{i})", n);
+      g.f("      r0[%d] = ((flags & INFO_CONVERGED) && !(flags & INFO_FAILED)) ? 1.0 : 0.0; r0[%d] = lambda; r0[%d] = cq_seen > 0.0 ? cq_seen : cq_carry;", 64 * n, 64 * (n + 1), 64 * (n + 2));
+      g.f("      WAVE_SYNC(); }");
+    } else if (fl) {
       g.f("    { double* r0 = ring + (step %% 3) * %d;  // this step's entry: solution, converged?, damping", (n + 2) * 64);
       for (int i = 0; i < n; ++i) g.f("      r0[%d] = x%d;", 64 * i, i);
       g.f("      r0[%d] = ((flags & INFO_CONVERGED) && !(flags & INFO_FAILED)) ? 1.0 : 0.0; r0[%d] = lambda; }", 64 * n, 64 * (n + 1));
@@ -2170,6 +2304,38 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
         g.f("      }");
         g.f("      }");
       }
+    } else if (ns) {
+      // nested mode: the wave unit's records of this step lie four problems apart - each one a contiguous run of `rec`
+      // doubles: through LDS (which the state no longer needs), every record written by consecutive lanes
+      g.f("    if (FULL || a.out_mode == 1) {");
+      g.f("      constexpr int rec = FULL ? %d : %d;", 3 * P.n_out, n);
+      g.f("      WAVE_SYNC();");
+      g.f("      if (FULL) {");
+      g.f("      double* st = lds + lane * %d;", 3 * P.n_out);
+      for (int k = 0; k < P.n_out; ++k)
+        for (int c = 0; c < 3; ++c) g.f("      st[%d] = p%d_%d;", 3 * k + c, P.out_point[k], c);
+      g.f("      } else {");
+      g.f("      double* st = lds + lane * %d;", n);
+      for (int i = 0; i < n; ++i) g.f("      st[%d] = %s;", 3 * ev.perm[i / 3] + i % 3, PF(i).c_str());
+      g.f("      }");
+      g.f("      WAVE_SYNC();");
+      stamp(17);
+      g.f("      const long long base_b = span_idx * span + wave_in_span * 64 * unit_len + sidx, lim_b = (span_idx + 1) * span;");
+      // lane l copies column l % rec of record (l / rec) of every group of 64 / rec records: one LDS read, one store and a
+      // pointer bump per group (no division, no address arithmetic inside the loop); a record leaves as one contiguous run
+      g.f("      constexpr int per = 64 / rec > 0 ? 64 / rec : 1;  // records per group");
+      g.f("      const int sub = lane / rec, col = lane - sub * rec;");
+      g.f("      const long long n_rows = (lim_b - base_b + unit_len - 1) / unit_len;  // records of this step inside the span");
+      g.f("      const int rows = (int)(n_rows < 64 ? (n_rows > 0 ? n_rows : 0) : 64);");
+      g.f("      double* op = a.out_pos + (base_b + (long long)sub * unit_len) * rec + col;");
+      g.f("      const double* ip = lds + sub * rec + col;");
+      g.f("      if (sub < per) {");
+      g.f("        _Pragma(\"unroll 8\")");
+      g.f("        for (int r = sub; r < rows; r += per) { *op = *ip; op += (long long)per * unit_len * rec; ip += per * rec; }");
+      g.f("      }");
+      g.f("      WAVE_SYNC();");
+      g.f("    }");
+      stamp(15);
     } else {
       // chains: a lane's problems are far apart in memory, every lane stores its own record
       g.f("    if (valid && FULL) {");
@@ -2199,6 +2365,18 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     return true;
   }
   if (!body(false, false, false) || (split_g && !body(false, false, true)) || !(flat_chain ? body(false, true, false) : body(true, false, false))) {
+    *why = lds_why;
+    return false;
+  }
+  // The nested start mode is generated on request only (developer switch lane_nested): measured on BASELINE config 5 it
+  // halves the evaluations per solve (2.97 -> 1.5) and does not shorten the launch (0.47 -> 0.49 ms) - a wave unit steps at
+  // the pace of its slowest lane, a confirming pass costs a lone wavefront most of a full one, and every unit-step carries
+  // ~19 k cycles that are not passes (profiles/r05/EXPERIMENTS.md section 5).  chain_len = -1 keeps resolving to
+  // independent solves on the lane kernel.
+  const bool nested = light_ok && dev_switch("lane_nested");
+  // (two bodies: own geometry reads its tables through the scalar cache; per-geometry launches stage each geometry's tables
+  //  and first-step table in LDS once per wave unit - its four unit-steps share them - like the independent-solve body)
+  if (nested && (!body(false, true, false, true) || (split_g && !body(false, true, true, true)))) {
     *why = lds_why;
     return false;
   }
@@ -2267,6 +2445,11 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       for (const char* out : {"", "_c"})   // _c: compact outputs (free coordinates or nothing)
         g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_%s_%s%s(QArgs a) { okx_lane_body_%s<%s, %s>(a); }", body, geo,
             out, body[0] != 's' ? "chain" : (split_g && geo[0] == 'g') ? "coldg" : "cold", geo[0] == 'g' ? "true" : "false", out[0] ? "false" : "true");
+  if (nested)
+    for (const char* geo : {"u", "g"})
+      for (const char* out : {"", "_c"})
+        g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_nest_%s%s(QArgs a) { okx_lane_body_%s<%s, %s>(a); }", geo, out,
+            split_g && geo[0] == 'g' ? "nestg" : "nest", geo[0] == 'g' ? "true" : "false", out[0] ? "false" : "true");
   (void)ev.undefs;  // (the macros live to the end of the translation unit: one program per module)
   *src = g.out;
   return true;

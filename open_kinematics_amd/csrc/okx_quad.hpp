@@ -14,8 +14,8 @@ namespace okx {
 // kept - and OKX_VERBOSE).  The names that exist are listed in tools/README.md, each is covered by
 // tests/test_dev_switches.py (generated source still compiles and is deterministic); the switches that change generated
 // source are part of its text and therefore of the kernel cache key.
-//   generators   quad_mark, quad_timeline, quad_no_light, quad_no_head, quad_no_fast, pair_no_head, pair_first_order_head,
-//                pair_lds_homes, lane_mark
+//   generators   quad_mark, quad_timeline, quad_no_light, quad_no_head, quad_no_fast, quad_two_waves, pair_no_head, pair_first_order_head,
+//                pair_lds_homes, lane_mark, lane_timeline, lane_lds_tables, lane_nested
 //   library      no_quad, no_lane, no_cold, tangent_generic, keep_source
 bool dev_switch(const char* name);
 
@@ -192,6 +192,11 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
 // QuadArgs.predictor (the lane kernel has no fitted model).  OKX_LANE_FLAT_CHAIN=0/1 forces either.
 bool lane_chain_is_flat(int n_vars);
 inline long long lane_flat_chain_doubles(int n_vars) { return 3LL * (n_vars + 2) * 64; }
+// The NESTED start mode of the lane kernel (okx_lane_nest_*; okx_lanegen.cpp): a lane owns four consecutive steps, solved in
+// the order 0, 2, 1, 3, each after the first started from the interpolant of the steps its wave unit has already solved;
+// the launch's scratch holds, per wavefront, four entries of (n_vars + 3) slots x 64 lanes.
+constexpr int kLaneNestSteps = 4;
+inline long long lane_nest_doubles(int n_vars) { return (long long)kLaneNestSteps * (n_vars + 3) * 64; }
 int lane_variant_count();
 bool lane_variants_same_arithmetic(int a, int b);  // same operations in the same order: bit-identical results
 // lane_generate + quad_compile over the emission variants: keeps the first variant whose independent-solve bodies

@@ -45,12 +45,14 @@ GENERATOR_SWITCHES = [
     ("quad_no_light", "c1_dw_corner", "okx_quad_source", "-want_light)) {"),
     ("quad_no_head", "c1_dw_corner", "okx_quad_source", "-okx_quad_head_u(QHeadArgs"),
     ("quad_no_fast", "c1_dw_corner", "okx_quad_source", "-bool hand_over ="),
+    ("quad_two_waves", "c1_dw_corner", "okx_quad_source", "+__launch_bounds__(64, 2)"),
     ("pair_no_head", "c3_axle_grid", "okx_quad_source", "-okx_quad_head_u(QHeadArgs"),
     ("pair_first_order_head", "c3_axle_grid", "okx_quad_source", "-hS0_"),
     ("pair_lds_homes", "c3_axle_grid", "okx_quad_source", "+psl["),
     ("lane_mark", "c1_dw_corner", "okx_lane_source", "+s_nop 1"),
     ("lane_timeline", "c1_dw_corner", "okx_lane_source", "+__builtin_readcyclecounter"),
     ("lane_lds_tables", "c1_dw_corner", "okx_lane_source", "-okx_cptr gpc"),
+    ("lane_nested", "c1_dw_corner", "okx_lane_source", "+okx_lane_nest_u"),
 ]
 
 

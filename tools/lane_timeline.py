@@ -18,6 +18,9 @@ from open_kinematics_amd.batch import DeviceProgram
 from open_kinematics_amd.workloads import bump_sweep_problem, ensemble_problem, macpherson_grid_problem
 
 what = sys.argv[1] if len(sys.argv) > 1 else "c4"
+nest = what.endswith("nest")   # c5nest / c2x16nest: the nested start mode (chain_len = -1; one trace row per unit-step)
+what = what[:-4] if nest else what
+chain_len = -1 if nest else 1
 dev = torch.device("cuda:0")
 kw = {}
 if what == "c5":
@@ -39,15 +42,17 @@ out = torch.empty((n, program.n_out, 3), dtype=torch.float64, device=dev)
 info = torch.empty((n, 40), dtype=torch.uint8, device=dev)
 spg = kw.get("steps_per_geometry", 0)
 units = (n // spg) * ((spg + 63) // 64) if spg else (n + 63) // 64
+if nest:
+    units = 4 * ((n // spg) * ((spg // 4 + 63) // 64) if spg else (n // 4 + 63) // 64)
 print(f"{what}: {n} problems, {units} wave units, lane kernel from {dp.lane_threshold} problems, bodies {dp.lane_bodies}")
 
-launch = dp.plan(t, out=out, info_out=info, chain_len=1, predictor=False, kernel="lane", **kw)
+launch = dp.plan(t, out=out, info_out=info, chain_len=chain_len, predictor=False, kernel="lane", **kw)
 for _ in range(20):
     launch()
 wall, ms = bench.time_launches(launch, 50, 5, dev)
 print(f"{1e3 * ms:.1f} us per launch ({n / (ms * 1e-3):.3e} solves/s)")
 free = torch.empty((n, program.n_vars // 3, 3), dtype=torch.float64, device=dev)
-launch_free = dp.plan(t, out=free, info_out=info, chain_len=1, predictor=False, kernel="lane", output="free", **kw)
+launch_free = dp.plan(t, out=free, info_out=info, chain_len=chain_len, predictor=False, kernel="lane", output="free", **kw)
 for _ in range(20):
     launch_free()
 wall, ms_free = bench.time_launches(launch_free, 50, 5, dev)
@@ -56,7 +61,7 @@ if "lane_timeline" not in os.environ.get("OKX_DEV", ""):
     sys.exit(0)
 tr = torch.zeros((units, 32), dtype=torch.float64, device=dev)
 dp.lib.okx_debug_quad_trace(dp._handle, C.c_void_p(tr.data_ptr()), -1)
-launch = dp.plan(t, out=out, info_out=info, chain_len=1, predictor=False, kernel="lane", **kw)
+launch = dp.plan(t, out=out, info_out=info, chain_len=chain_len, predictor=False, kernel="lane", **kw)
 for _ in range(5):
     launch()
 torch.cuda.synchronize()
