@@ -809,6 +809,8 @@ def main() -> None:
     ap.add_argument("--c5-chunks", type=int, default=0, help="--config c5, N > 1: chunks of the pipelined exchange per rank (0: auto, up to 8)")
     ap.add_argument("--c5-gather", choices=("records", "free"), default="records",
                     help="--config c5, N > 1: every rank ends with all output records (default) or with the free coordinates only (no expand)")
+    ap.add_argument("--c5-info", choices=("full", "status"), default="status",
+                    help="--config c5, N > 1: what travels beside the coordinates - the 40-byte info records or one status byte per solve")
     ap.add_argument("--rccl-world-one", action="store_true",
                     help="one rank, but with an RCCL process group and the all-gather in the step: what a one-GPU box can "
                          "rehearse of the N > 1 path (communicator, stream ordering of the pipeline, expand of the gathered block)")
@@ -1219,7 +1221,7 @@ def run_c5(args, world: int, rank: int, device) -> dict:
     pipe = None
     if world > 1:
         pipe = ShardedEnsemble(dp, table_dev, rel, spg, chunks=args.c5_chunks or None, records=args.c5_gather == "records",
-                               chain_len=args.chain_len if args.chain_len != -1 else 1, predictor=False)
+                               info=args.c5_info, chain_len=args.chain_len if args.chain_len != -1 else 1, predictor=False)
 
     def step(k, start, end):
         if start is not None:
@@ -1235,7 +1237,7 @@ def run_c5(args, world: int, rank: int, device) -> dict:
     kernel_ms = step_ms
     if pipe is not None:  # the solve alone, for `solve_only`: the whole shard as one launch, outside the timed region
         _, kernel_ms = time_launches(launch, max(3, min(args.steps, 10)), 2, device)
-        info = pipe.info_full[glo * spg : ghi * spg]
+        info = pipe.info_local if pipe.status_only else pipe.info_full[glo * spg : ghi * spg]
     nfev_mean, ok = info_summary(info)
     if rank != 0:
         return {}
@@ -1265,7 +1267,7 @@ def run_c5(args, world: int, rank: int, device) -> dict:
         "solve_only": {"value": n_total / (kernel_ms * 1e-3) if world > 1 else n_local / (kernel_ms * 1e-3),
                        "kernel_ms_max_over_ranks": kernel_ms},
         "exchange": {"bytes_sent_per_rank_per_step": pipe.exchange_bytes_per_rank if world > 1 else 0,
-                     "bytes_received_per_rank_per_step": (n_total - n_local) * (program.n_free * 24 + 40) if world > 1 else 0,
+                     "bytes_received_per_rank_per_step": (n_total - n_local) * (program.n_free * 24 + (1 if args.c5_info == "status" else 40)) if world > 1 else 0,
                      "chunks": pipe.chunks if world > 1 else 0, "step_ms_with_exchange": step_ms if world > 1 else None},
     }
 

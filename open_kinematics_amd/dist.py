@@ -184,8 +184,9 @@ class EnsembleShard:
     local: object                      # BatchResult of this rank's geometries (exchange="free" with N > 1: free coordinates, no records)
     geometry_range: tuple              # [lo, hi) of the geometries this rank solved
     free_full: torch.Tensor | None     # gathered free coordinates [G * S, n_free, 3] (exchange="free")
-    info_full: torch.Tensor | None     # gathered okx_info records [G * S, 40] uint8
+    info_full: torch.Tensor | None     # gathered okx_info records [G * S, 40] uint8 (None with info="status")
     exchange_bytes_per_rank: int       # payload this rank contributed to the all-gather(s)
+    status_full: torch.Tensor | None = None  # info="status": one byte per solve [G * S], the low byte of okx_info.flags
 
 
 @dataclass
@@ -235,12 +236,15 @@ class ShardedEnsemble:
 
     A step therefore costs about ``max(solve, exchange, expand)`` of the whole batch plus one chunk of each, instead of
     their sum.  ``records=False`` returns the gathered free coordinates (what a consumer that evaluates metrics per rank,
-    or writes per-rank result files, needs) and skips the expand altogether.  Chunked and unchunked runs give the same
-    bits: a chunk is just a smaller launch of the same independent solves.
+    or writes per-rank result files, needs) and skips the expand altogether.  ``info="status"`` exchanges ONE status byte
+    per solve (the low byte of ``okx_info.flags``: converged / residual exceeded / failed / ill-conditioned) instead of the
+    40-byte record - 145 instead of 184 bytes per double-wishbone solve on the links; the full records of the rank's own
+    shard stay in ``info_local``.  Chunked and unchunked runs give the same bits: a chunk is just a smaller launch of the
+    same independent solves.
     """
 
     def __init__(self, device_program, hardpoints, targets, steps_per_geometry: int, *, group=None, chunks: int | None = None,
-                 records: bool = True, relative_targets: bool = True, **solve_kw):
+                 records: bool = True, relative_targets: bool = True, info: str = "full", **solve_kw):
         self.dp = device_program
         self.group = group
         self.world, self.rank = _world(group)
@@ -270,11 +274,18 @@ class ShardedEnsemble:
         else:
             self.local_targets = targets[glo * self.steps : ghi * self.steps]
         device = self.my_pos.device
+        if info not in ("full", "status"):
+            raise ValueError("info must be 'full' or 'status'")
+        self.status_only = info == "status"
         self.free_full = torch.empty((self.n_total, program.n_free, 3), dtype=torch.float64, device=device)
-        self.info_full = torch.empty((self.n_total, 40), dtype=torch.uint8, device=device)
+        # what travels beside the coordinates: the 40-byte info records, or one status byte per solve (then the records of
+        # this rank's own shard are kept in `info_local`)
+        self.info_full = None if self.status_only else torch.empty((self.n_total, 40), dtype=torch.uint8, device=device)
+        self.status_full = torch.empty((self.n_total,), dtype=torch.uint8, device=device) if self.status_only else None
+        self.info_local = torch.empty(((ghi - glo) * self.steps, 40), dtype=torch.uint8, device=device) if self.status_only else None
         self.positions = torch.empty((self.n_total, program.n_out, 3), dtype=torch.float64, device=device) if self.records else None
         self.expand_stream = torch.cuda.Stream(device=device) if device.type == "cuda" and self.records else None
-        self.exchange_bytes_per_rank = (ghi - glo) * self.steps * (program.n_free * 24 + 40) if self.world > 1 else 0
+        self.exchange_bytes_per_rank = (ghi - glo) * self.steps * (program.n_free * 24 + (1 if self.status_only else 40)) if self.world > 1 else 0
 
     def _rows(self, span):
         return slice(span[0] * self.steps, span[1] * self.steps)
@@ -286,7 +297,8 @@ class ShardedEnsemble:
             return
         rows = self._rows((a, b))
         local = slice((a - glo) * self.steps, (b - glo) * self.steps)
-        out, info = self.free_full[rows], self.info_full[rows]
+        out = self.free_full[rows]
+        info = self.info_local[local] if self.status_only else self.info_full[rows]
         res = self.dp.solve(self.local_targets[local], geom_pos=self.my_pos[a - glo : b - glo], geom_row_param=self.my_param[a - glo : b - glo],
                             steps_per_geometry=self.steps, output="free", out=out, info_out=info, **self.solve_kw)
         # (a stand-in program of the CPU tests returns fresh tensors instead of filling the buffers it was given)
@@ -294,6 +306,8 @@ class ShardedEnsemble:
             out.copy_(res.free)
         if res.info_raw.data_ptr() != info.data_ptr():
             info.copy_(res.info_raw)
+        if self.status_only:
+            self.status_full[rows] = info[:, 32]  # (okx_info.flags is the int32 at byte 32: its low byte carries every flag)
 
     def _exchange_chunk(self, k: int) -> list:
         if self.world == 1:
@@ -307,12 +321,13 @@ class ShardedEnsemble:
                 continue
             dst = dist.get_global_rank(self.group, peer) if self.group is not None else peer
             theirs = self.pieces[k][peer]
+            beside = self.status_full if self.status_only else self.info_full
             if mine[1] > mine[0]:
                 ops.append(dist.P2POp(dist.isend, self.free_full[self._rows(mine)], dst, self.group))
-                ops.append(dist.P2POp(dist.isend, self.info_full[self._rows(mine)], dst, self.group))
+                ops.append(dist.P2POp(dist.isend, beside[self._rows(mine)], dst, self.group))
             if theirs[1] > theirs[0]:
                 ops.append(dist.P2POp(dist.irecv, self.free_full[self._rows(theirs)], dst, self.group))
-                ops.append(dist.P2POp(dist.irecv, self.info_full[self._rows(theirs)], dst, self.group))
+                ops.append(dist.P2POp(dist.irecv, beside[self._rows(theirs)], dst, self.group))
         return dist.batch_isend_irecv(ops) if ops else []
 
     def _exchange_chunk_through_the_host(self, k: int) -> list:
@@ -325,7 +340,7 @@ class ShardedEnsemble:
                 continue
             dst = dist.get_global_rank(self.group, peer) if self.group is not None else peer
             theirs = self.pieces[k][peer]
-            for full in (self.free_full, self.info_full):
+            for full in (self.free_full, self.status_full if self.status_only else self.info_full):
                 if mine[1] > mine[0]:
                     ops.append(dist.P2POp(dist.isend, full[self._rows(mine)].cpu(), dst, self.group))
                 if theirs[1] > theirs[0]:
@@ -378,7 +393,7 @@ class ShardedEnsemble:
 
 def solve_sharded(device_program, targets_full: torch.Tensor, gather=True, group=None, *, hardpoints=None,
                   steps_per_geometry: int = 0, exchange: str = "free", relative_targets: bool | None = None,
-                  chunks: int | None = None, **solve_kw):
+                  chunks: int | None = None, info: str = "full", **solve_kw):
     """
     Solve this rank's index block and (optionally) all-gather the solved positions.
 
@@ -399,7 +414,9 @@ def solve_sharded(device_program, targets_full: torch.Tensor, gather=True, group
     geometries (default: up to 8), chunk k + 1 solves while chunk k travels - coordinates and info records in one grouped
     point-to-point call, straight from and into their final place - and chunk k - 1 is expanded on a third stream.
     ``gather="free"`` skips the expand and returns the gathered free coordinates ``[G * S, n_free, 3]`` instead of the
-    records (``EnsembleShard.free_full`` holds them either way).  Uneven geometry counts need no padding.
+    records (``EnsembleShard.free_full`` holds them either way); ``info="status"`` exchanges one status byte per solve
+    instead of the 40-byte record (``EnsembleShard.status_full``; ``local.info_raw`` keeps this rank's full records).
+    Uneven geometry counts need no padding.
     """
     world, rank = _world(group)
     if hardpoints is None:
@@ -425,10 +442,12 @@ def solve_sharded(device_program, targets_full: torch.Tensor, gather=True, group
         raise ValueError("targets must be [S, T] relative displacements or [G * S, T] absolute values")
     if gather and world > 1 and exchange == "free":
         pipe = ShardedEnsemble(device_program, hardpoints, targets_full, steps, group=group, chunks=chunks,
-                               records=gather != "free", relative_targets=relative, **solve_kw)
+                               records=gather != "free", relative_targets=relative, info=info, **solve_kw)
         result = pipe.step()
-        local = _LocalShard(pipe.free_full[pipe._rows(pipe.geometry_range)], pipe.info_full[pipe._rows(pipe.geometry_range)])
-        return result, EnsembleShard(local, pipe.geometry_range, pipe.free_full, pipe.info_full, pipe.exchange_bytes_per_rank)
+        own = pipe._rows(pipe.geometry_range)
+        local = _LocalShard(pipe.free_full[own], pipe.info_local if pipe.status_only else pipe.info_full[own])
+        return result, EnsembleShard(local, pipe.geometry_range, pipe.free_full, pipe.info_full, pipe.exchange_bytes_per_rank,
+                                     pipe.status_full)
     # Per-geometry emission.  The expand on the receiving side needs every geometry's fixed points, so with the
     # compact exchange the (small: G x P x 24 B) hardpoint table is rebound in full on every rank — replicated
     # inputs, as SURVEY.md section 8e allows; otherwise only this rank's slice.

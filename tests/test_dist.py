@@ -173,6 +173,14 @@ def _ensemble_worker(rank: int, world: int, port: int, n_geom: int, steps: int, 
     for tag, chunks, fill, gather in (("chunk3", 3, True, True), ("chunk8", 8, False, True), ("coords", 2, True, "free")):
         dp = _StandInProgram(fill_buffers=fill)
         got, shard = solve_sharded(dp, relative, gather=gather, hardpoints=table, steps_per_geometry=steps, chunks=chunks)
+        if tag == "coords":  # ... and with one status byte per solve beside the coordinates instead of the 40-byte record
+            lean, lean_shard = solve_sharded(_StandInProgram(), relative, gather="free", hardpoints=table, steps_per_geometry=steps,
+                                             chunks=chunks, info="status")
+            assert torch.equal(lean, got) and lean_shard.info_full is None
+            assert torch.equal(lean_shard.status_full, shard.info_full[:, 32])
+            lo, hi = shard.geometry_range
+            assert torch.equal(lean_shard.local.info_raw, shard.info_full[lo * steps : hi * steps])
+            assert lean_shard.exchange_bytes_per_rank == (hi - lo) * steps * (2 * 24 + 1)
         torch.save({"result": got, "info": shard.info_full, "free": shard.free_full, "range": shard.geometry_range,
                     "rebound": dp.rebound, "sent": shard.exchange_bytes_per_rank, "launch_rows": dp.launch_rows,
                     "local_free": shard.local.free, "outputs": dp.outputs}, os.path.join(out_dir, f"{tag}{rank}.pt"))

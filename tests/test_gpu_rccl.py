@@ -74,5 +74,5 @@ def test_two_rank_c5_pipeline_rehearsal_on_one_gpu():
         assert line["n_gpus"] == 2 and line["config"]["all_converged"] and line["scaling"] == "strong"
         assert line["config"]["problems_per_gpu"] == 2048 * 256
         assert line["exchange"]["chunks"] == (5 if extra else 8)
-        assert line["exchange"]["bytes_sent_per_rank_per_step"] == 2048 * 256 * (6 * 24 + 40)   # coordinates + info records
+        assert line["exchange"]["bytes_sent_per_rank_per_step"] == 2048 * 256 * (6 * 24 + 1)   # coordinates + one status byte
         assert line["solve_only"]["value"] > 0.0 and line["value"] > 0.0
