@@ -165,32 +165,7 @@ print(json.dumps({{"one": one, "all_wall": best[0], "all_parts": best[1]}}))
 """
 
 
-def host_cores() -> tuple:
-    """Cores this process can really use: the affinity mask, cut to the cgroup's CPU quota when there is one (a GPU box
-    hands a one-GPU job a share of the host, not all of it).  No other cap."""
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        cores = os.cpu_count() or 1
-    how = f"affinity mask of {cores}"
-    try:
-        with open("/sys/fs/cgroup/cpu.max", "r", encoding="utf-8") as fh:   # cgroup v2: "<quota> <period>" or "max <period>"
-            quota, period = fh.read().split()[:2]
-        if quota != "max":
-            share = max(1, int(round(int(quota) / int(period))))
-            if share < cores:
-                cores, how = share, f"cgroup CPU quota of {share} inside an affinity mask of {cores}"
-    except (OSError, ValueError):
-        try:
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r", encoding="utf-8") as fq, \
-                    open("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r", encoding="utf-8") as fp:
-                quota, period = int(fq.read()), int(fp.read())
-            if quota > 0 and max(1, round(quota / period)) < cores:
-                share = max(1, int(round(quota / period)))
-                cores, how = share, f"cgroup CPU quota of {share} inside an affinity mask of {cores}"
-        except (OSError, ValueError):
-            pass
-    return cores, how
+from open_kinematics_amd.hostcpu import fit_host_threads, host_cores  # noqa: E402  (re-exported: tests/test_host_api.py)
 
 
 def cpu_baseline(n_steps: int) -> dict:
@@ -372,11 +347,15 @@ def measure_e2e(dp, targets_host: np.ndarray, device, steps: int, cold_kw: dict)
     for _ in range(3):
         once()
     torch.cuda.synchronize(device)
+    per_sweep = np.empty(steps)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
         once()
         torch.cuda.synchronize(device)  # the caller owns the host buffers again after every sweep
-    wall = (time.perf_counter() - t0) / steps
+        t1 = time.perf_counter()
+        per_sweep[k], t0 = t1 - t0, t1
+    wall = float(per_sweep.mean())
+    median = float(np.median(per_sweep))
     legs = np.zeros(3)
     for _ in range(steps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -387,6 +366,13 @@ def measure_e2e(dp, targets_host: np.ndarray, device, steps: int, cold_kw: dict)
     return {
         "value": n / wall,
         "ms_per_sweep": wall * 1e3,
+        # the spread of the sweeps of this one run: a stalled copy command (tens of ms, the copy engine's completion signal
+        # on a shared host) inside a window of a few ms of work moves the mean by multiples and the median not at all
+        "value_at_median": n / median,
+        "ms_per_sweep_median": median * 1e3,
+        "ms_per_sweep_max": float(per_sweep.max() * 1e3),
+        "sweeps_over_3x_median": int(np.sum(per_sweep > 3.0 * median)),
+        "slowest_sweep_index": int(np.argmax(per_sweep)),
         "h2d_ms": float(legs[0]),
         "kernel_ms": float(legs[1]),
         "d2h_ms": float(legs[2]),
@@ -839,6 +825,7 @@ def main() -> None:
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback for the solve path)")
+    host_threads = fit_host_threads(processes=world)  # before the first parallel host op (hostcpu.py: the cgroup quota)
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -1143,7 +1130,8 @@ def run_c2(args, world: int, rank: int, device) -> dict:
                                   "note": "shared_first_step=0: every problem evaluates the design state itself (round-1 behaviour)"}
         line["pipelined"] = measure_pipelined(dp, targets, device, max(args.steps, 60))
         line["with_model"] = measure_with_model(program, targets, device, args.steps, args.warmup)
-        line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, extra_steps, dict(chain_len=args.chain_len, predictor=False))
+        line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, max(extra_steps, 200), dict(chain_len=args.chain_len, predictor=False))
+        line["e2e"]["host_threads"] = host_threads
         line["e2e"]["compact"] = measure_e2e_compact(dp, targets_all[lo:hi], device, max(extra_steps, 200),
                                                      dict(chain_len=args.chain_len, predictor=False))
         # (last of the host-to-host legs on purpose: round 3 measured this leg at a fifth of its rate whenever another leg had

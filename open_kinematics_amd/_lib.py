@@ -91,6 +91,10 @@ def load() -> C.CDLL:
         )
     try:
         import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; see module docstring)
+
+        from .hostcpu import fit_host_threads
+
+        fit_host_threads()  # a thread pool wider than the cgroup's CPU quota gets the whole process throttled (hostcpu.py)
     except Exception:  # pragma: no cover - torch is part of the image
         pass
     lib = C.CDLL(LIB_PATH)

@@ -16,6 +16,8 @@ for c in (3, 8, 67, 100):
     assert torch.equal(pa, pb) and torch.equal(fa, b.free_full) and torch.equal(ia, b.info_full), c
     f = ShardedEnsemble(dp, t, rel, 64, chunks=c, records=False, chain_len=1, predictor=False)
     assert torch.equal(f.step(), fa)
+    lean = ShardedEnsemble(dp, t, rel, 64, chunks=c, records=False, info="status", chain_len=1, predictor=False)
+    assert torch.equal(lean.step(), fa) and torch.equal(lean.status_full, ia[:, 32]) and torch.equal(lean.info_local, ia)
 ref = dp.solve(dp.ensemble_targets(*[dp.rebind(t)[0]], rel), geom_pos=dp.rebind(t)[0], geom_row_param=dp.rebind(t)[1], steps_per_geometry=64, chain_len=1, predictor=False)
 assert torch.equal(ref.positions, pa)
 print("chunked == unchunked == plain solve, bit for bit")
