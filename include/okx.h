@@ -254,6 +254,18 @@ int32_t okx_solve_batch(okx_program* prog, const okx_solve_opts* opts, int64_t n
                         void* stream);
 
 /*
+ * Which kernel family and chain length okx_solve_batch (evaluated != 0: okx_solve_evaluated_batch) would use for a launch
+ * of n_problems with these options, with (geometry_tables != 0) or without per-geometry tables; nothing is launched.
+ * out2[0]: the okx_solve_opts.kernel value that forces the same family (1 interpreter, 2 packed interpreter, 3 quad, 4 lane);
+ * out2[1]: the chain length the launch resolves chain / chain_len to (-1: the lane kernel's nested start mode, which sizes
+ * itself from steps_per_geometry alone).  The selection depends on the problem count: a caller that cuts one batch into
+ * several launches and needs the BITS of the single launch (the multi-GPU ensemble's chunks, dist.py) asks once for the
+ * whole batch and passes the answer to every piece.  No reference counterpart (the reference has one code path).
+ */
+int32_t okx_plan_launch(okx_program* prog, const okx_solve_opts* opts, int64_t n_problems, int32_t geometry_tables,
+                        int32_t evaluated, int32_t* out2);
+
+/*
  * Replaces ResidualComputer.compute / compute_jacobian (solver.py:226-275, :502-581)
  * for B free-coordinate vectors: d_x [B][n] -> d_r [B][m], d_jac [B][m][n] (row-major,
  * dense).  d_jac may be NULL.  Used by the parity tests (rung R1).

@@ -53,6 +53,7 @@ EXPORTS = (
     "okx_solve_evaluated_batch",
     "okx_evaluate_batch",
     "okx_precompile_evaluation",
+    "okx_plan_launch",
 )
 
 # include/okx_debug.h: test hooks and profiling aids, not part of the drop-in boundary
@@ -180,6 +181,8 @@ def load() -> C.CDLL:
     lib.okx_evaluate_batch.restype = i32
     lib.okx_precompile_evaluation.argtypes = [C.POINTER(ProgramDesc), vp]
     lib.okx_precompile_evaluation.restype = i32
+    lib.okx_plan_launch.argtypes = [vp, C.POINTER(SolveOpts), i64, i32, i32, C.POINTER(i32 * 2)]
+    lib.okx_plan_launch.restype = i32
     if lib.okx_abi_version() != ABI_VERSION:
         raise RuntimeError("libokx.so ABI version mismatch")
     _lib = lib

@@ -429,6 +429,30 @@ class DeviceProgram:
         _lib.check(rc, "okx_solve_batch")
         return result
 
+    def plan_launch(self, n_problems: int, *, steps_per_geometry: int = 0, geometry_tables: bool = False, evaluated: bool = False,
+                    chain: bool = False, chain_len: int | None = None, kernel: int | str | None = None,
+                    predictor: bool | str | None = False, **_ignored) -> tuple:
+        """
+        ``okx_plan_launch``: ``(kernel, chain_len)`` a launch of ``n_problems`` with these keywords would resolve to -
+        the values to pass as ``kernel=`` / ``chain_len=`` to every piece of a batch that is cut into several launches
+        and must keep the bits of the single launch (auto selection depends on the problem count).
+        """
+        opts = self.default_opts()
+        opts.chain = 1 if chain else 0
+        opts.steps_per_geometry = int(steps_per_geometry)
+        if chain_len is not None:
+            opts.chain_len = int(chain_len)
+        if kernel is not None:
+            opts.kernel = {"auto": 0, "single": 1, "packed": 2, "quad": 3, "lane": 4}.get(kernel, kernel)
+        if predictor not in (False, None) or (predictor is None and self._predictor):
+            opts.predictor = 1
+        out2 = (C.c_int32 * 2)()
+        with torch.cuda.device(self.device):
+            rc = self.lib.okx_plan_launch(self._handle, C.byref(opts), int(n_problems), 1 if geometry_tables else 0,
+                                          1 if evaluated else 0, C.byref(out2))
+        _lib.check(rc, "okx_plan_launch")
+        return {1: "single", 2: "packed", 3: "quad", 4: "lane"}[out2[0]], int(out2[1])
+
     def plan(self, targets, **kw):
         """
         Pre-bound launch for a hot loop: validates and converts the arguments once (same keywords

@@ -919,7 +919,7 @@ static int32_t check_corner_roles(const okx_corner_roles* roles, int32_t n_out, 
 static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_problems,
                           const double* d_targets, const double* d_geom_pos,
                           const double* d_geom_row_param, double* d_out_pos, okx_info* d_info,
-                          void* stream, bool evaluated, double* d_tangents, double* d_eval) {
+                          void* stream, bool evaluated, double* d_tangents, double* d_eval, int32_t* plan_only = nullptr) {
   if (!p || !opts) return fail(OKX_ERR_INVALID, "null program or options");
   {
     const hipStream_t launch_stream = (hipStream_t)stream;
@@ -1056,6 +1056,11 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
     if (len < 1) len = 1;
     if (len > span) len = span;
     a.chain_len = len;
+  }
+  if (plan_only) {  // okx_plan_launch: what this launch would run, nothing launched
+    plan_only[0] = use_lane ? 4 : use_quad ? 3 : use_packed ? 2 : 1;
+    plan_only[1] = lane_nested ? -1 : (int32_t)(a.chain_len > 0x7fffffffll ? 0x7fffffffll : a.chain_len);
+    return OKX_OK;
   }
   a.step_tol = opts->step_tol;
   a.grad_tol = opts->grad_tol;
@@ -1221,6 +1226,17 @@ int32_t okx_solve_evaluated_batch(okx_program* p, const okx_solve_opts* opts, in
                                   const double* d_targets, const double* d_geom_pos, const double* d_geom_row_param,
                                   double* d_out_pos, okx_info* d_info, double* d_tangents, double* d_eval, void* stream) {
   return solve_impl(p, opts, n_problems, d_targets, d_geom_pos, d_geom_row_param, d_out_pos, d_info, stream, true, d_tangents, d_eval);
+}
+
+int32_t okx_plan_launch(okx_program* p, const okx_solve_opts* opts, int64_t n_problems, int32_t geometry_tables, int32_t evaluated,
+                        int32_t* out2) {
+  if (!out2) return fail(OKX_ERR_INVALID, "null output pointer");
+  // the selection reads no batch array: placeholders stand for the pointers a launch of this shape would pass
+  double* const some = reinterpret_cast<double*>(uintptr_t(64));
+  out2[0] = out2[1] = 0;
+  if (n_problems <= 0) return fail(OKX_ERR_INVALID, "a launch plan needs a positive problem count");
+  return solve_impl(p, opts, n_problems, some, geometry_tables ? some : nullptr, geometry_tables ? some : nullptr, some,
+                    reinterpret_cast<okx_info*>(some), nullptr, evaluated != 0, nullptr, evaluated ? some : nullptr, out2);
 }
 
 static void release_evaluation(okx_program* p) {

@@ -161,6 +161,21 @@ class LGen {
     }
     return r;
   }
+  // |v|^2 in the QUAD kernels' order of operations (qsum of the per-lane squares: (x x + y y) + z z, every product and sum
+  // rounded, okx_quadgen.cpp) - the final state's derived points are written with it, so that a record never depends on
+  // which kernel family wrote it: lane solve, quad solve and okx_expand_positions_batch of the same free coordinates give
+  // the same bits (what dist.ShardedEnsemble relies on: one rank writes records, N ranks gather coordinates and expand)
+  bool quad_order = false;
+  std::string norm2(const S3& v) {
+    if (!quad_order) return dot(v, v);
+    std::string e;
+    for (int k = 0; k < 3; ++k) {
+      if (v.c[k].empty()) continue;
+      const std::string sq = "okx_mul_rn(" + v.c[k] + ", " + v.c[k] + ")";
+      e = e.empty() ? sq : "okx_add_rn(" + e + ", " + sq + ")";
+    }
+    return e.empty() ? std::string("0.0") : emit("d", e);
+  }
   std::string dot(const S3& a, const S3& b, const std::string& init = "") {
     std::vector<std::pair<std::string, std::string>> pr;
     const int sg = a.sg * b.sg;
@@ -341,7 +356,7 @@ class LGen {
     }
     if (type == OKX_DOP_ALONG) {  // definitions.py:24-33, :92-155: out = base + normalize(a - b) * c
       const S3 v = sub(pt(pts[1]), pt(pts[2]));
-      const std::string s2 = dot(v, v);
+      const std::string s2 = norm2(v);
       const std::string nrm = tmp("nr"), inrm = tmp("in");
       f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", nrm.c_str(), inrm.c_str(), s2.c_str(), nrm.c_str(), inrm.c_str());
       const S3 u = scale(inrm, v);
@@ -386,7 +401,7 @@ class LGen {
     }
     if (type == OKX_DOP_CONTACT_PATCH) {  // definitions.py:36-73, :158-180
       const S3 v = sub(pt(pts[2]), pt(pts[1]));
-      const std::string vv = dot(v, v);
+      const std::string vv = norm2(v);
       const std::string vn = tmp("vn"), ivn = tmp("iv");
       f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", vn.c_str(), ivn.c_str(), vv.c_str(), vn.c_str(), ivn.c_str());
       const S3 ax = scale(ivn, v);
@@ -395,11 +410,16 @@ class LGen {
       wd.c[0] = emit("wd", az + " * " + ax.c[0]);
       wd.c[1] = emit("wd", az + " * " + ax.c[1]);
       wd.c[2] = emit("wd", "fma(" + az + ", " + ax.c[2] + ", -1.0)");
-      const std::string ww = dot(wd, wd);
+      const std::string ww = norm2(wd);
       const std::string wn = tmp("wn"), iwn = tmp("iw");
       f("    double %s, %s; fast_sqrt_rsqrt(%s, &%s, &%s);", wn.c_str(), iwn.c_str(), ww.c_str(), wn.c_str(), iwn.c_str());
       const S3 wc = pt(pts[0]);
       const std::string rk = emit("rk", iwn + " * " + dp(e));
+      if (quad_order && !with_blocks) {  // (wd / |wd|) * R + wc, the unit vector rounded first (okx_quadgen.cpp)
+        const S3 wu = scale(iwn, wd);
+        for (int k = 0; k < 3; ++k) f("    %s = fma(%s, %s, %s);", o.c[k].c_str(), wu.c[k].c_str(), dp(e).c_str(), wc.c[k].c_str());
+        return true;
+      }
       for (int k = 0; k < 3; ++k) f("    %s = fma(%s, %s, %s);", o.c[k].c_str(), wd.c[k].c_str(), rk.c_str(), wc.c[k].c_str());
       if (with_blocks) {
         // d out / d axo = T = R Nw Wa Na (axi: -T, wheel centre: I), Na = (I - a a^T)/|v|, Wa = a_z I + a e_z^T,
@@ -1152,6 +1172,16 @@ DEV double pivot_rcp(double x) {
   const double r = __builtin_amdgcn_rcp(x);
   return fma(fma(-x, r, 1.0), r, r);
 }
+// a product / a sum that is rounded where it stands (never fused into a neighbour): the final state's squared norms are
+// summed in the quad kernels' order with them
+DEV double okx_mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+DEV double okx_add_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 // sqrt(x) to the last bit or so and 1 / sqrt(x) to 4e-15: one Goldschmidt step, then the residual correction.
 DEV void fast_sqrt_rsqrt(double x, double* root, double* inv) {
   const double y = __builtin_amdgcn_rsq(x);
@@ -1414,6 +1444,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   }
   // final state: every derived point
   LGen fin(P);
+  fin.quad_order = true;
   fin.uid = 100000;
   fin.hoisted_names = ev.hoisted_names;
   for (int e = 0; e < P.n_derived; ++e)

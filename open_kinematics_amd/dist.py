@@ -244,21 +244,35 @@ class ShardedEnsemble:
     """
 
     def __init__(self, device_program, hardpoints, targets, steps_per_geometry: int, *, group=None, chunks: int | None = None,
-                 records: bool = True, relative_targets: bool = True, info: str = "full", **solve_kw):
+                 records: bool = True, relative_targets: bool = True, info: str = "full", direct: bool | None = None, **solve_kw):
         self.dp = device_program
         self.group = group
         self.world, self.rank = _world(group)
         self.steps = int(steps_per_geometry)
         self.records = bool(records)
-        self.solve_kw = solve_kw
         program = device_program.program
         self.n_geom = int(hardpoints.shape[0])
         self.n_total = self.n_geom * self.steps
         glo, ghi = shard_range(self.n_geom, self.rank, self.world)
         self.geometry_range = (glo, ghi)
-        if chunks is None:  # at least 8 chunks once a rank has 8 x 4096 problems to cut; never below one geometry per chunk
-            chunks = max(1, min(8, ((ghi - glo) * self.steps) // 4096, ghi - glo)) if self.world > 1 else 1
+        if chunks is None:
+            # Up to 8 chunks, but never a chunk below ONE FULL ROUND of the solve kernel over the chip (one 64-problem
+            # wavefront on each of the 4 x CUs SIMDs: 65536 problems on an MI355X) - a smaller launch takes the same ~45 us
+            # with most SIMDs idle, and the pipeline loses more on its solve stage than it hides of the exchange
+            # (tools/c5_pipeline_model.py: a rank's 131072 problems at N = 8 solve in 0.09 ms as one launch or two halves, in
+            # 0.40 ms as 8 eighths).  Without a GPU (the CPU tests' stand-in) a round is 4096.
+            dev = torch.as_tensor(hardpoints).device
+            one_round = torch.cuda.get_device_properties(dev).multi_processor_count * 256 if dev.type == "cuda" else 4096
+            chunks = max(1, min(8, ((ghi - glo) * self.steps) // one_round, ghi - glo)) if self.world > 1 else 1
         self.chunks = max(1, int(chunks))
+        # Kernel family and chain length are chosen ONCE, for the whole ensemble as one launch on one GPU (auto selection
+        # goes by the problem count: a 16384-problem chunk of a million-problem ensemble would otherwise run the quad kernel
+        # where the ensemble runs the lane kernel - same answers to 1e-9, other bits): every chunk on every rank is forced
+        # to that choice, so chunked, unchunked, one-GPU and N-GPU runs of an ensemble agree bit for bit.
+        if hasattr(device_program, "plan_launch"):
+            kernel, chain_len = device_program.plan_launch(self.n_total, steps_per_geometry=self.steps, geometry_tables=True, **solve_kw)
+            solve_kw = {**solve_kw, "kernel": kernel, "chain_len": chain_len}
+        self.solve_kw = solve_kw
         self.pieces = chunk_pieces(self.n_geom, self.world, self.chunks)
         # per-geometry emission: the expand on the receiving side needs every geometry's fixed points (a small table,
         # replicated as SURVEY.md section 8e allows); without records only this rank's slice is rebound
@@ -276,7 +290,12 @@ class ShardedEnsemble:
         device = self.my_pos.device
         if info not in ("full", "status"):
             raise ValueError("info must be 'full' or 'status'")
-        self.status_only = info == "status"
+        self.status_only = info == "status" and self.world > 1  # (one rank exchanges nothing: full records, a view of their flag byte)
+        # ONE rank that wants records has nothing to exchange: its solves write the records themselves (`direct`; the gathered
+        # free coordinates are then not kept - direct=False keeps the two-stage form, e.g. to compare the stages' bits)
+        self.direct = (self.world == 1 and self.records and not self.status_only) if direct is None else bool(direct)
+        if self.direct and (self.world > 1 or not self.records or self.status_only):
+            raise ValueError("direct records need a world of one, records=True and info='full'")
         self.free_full = torch.empty((self.n_total, program.n_free, 3), dtype=torch.float64, device=device)
         # what travels beside the coordinates: the 40-byte info records, or one status byte per solve (then the records of
         # this rank's own shard are kept in `info_local`)
@@ -284,8 +303,17 @@ class ShardedEnsemble:
         self.status_full = torch.empty((self.n_total,), dtype=torch.uint8, device=device) if self.status_only else None
         self.info_local = torch.empty(((ghi - glo) * self.steps, 40), dtype=torch.uint8, device=device) if self.status_only else None
         self.positions = torch.empty((self.n_total, program.n_out, 3), dtype=torch.float64, device=device) if self.records else None
-        self.expand_stream = torch.cuda.Stream(device=device) if device.type == "cuda" and self.records else None
+        self.expand_stream = torch.cuda.Stream(device=device) if device.type == "cuda" and self.records and not self.direct else None
+        if self.direct:
+            self.free_full = None
+        if info == "status" and not self.status_only:
+            self.status_full, self.info_local = self.info_full[:, 32], self.info_full
         self.exchange_bytes_per_rank = (ghi - glo) * self.steps * (program.n_free * 24 + (1 if self.status_only else 40)) if self.world > 1 else 0
+        # host time per chunk: the solve as a pre-bound launch (DeviceProgram.plan), the expands of a chunk's pieces (one per
+        # rank) as ONE HIP graph replayed from the second step on
+        self._plans = {}
+        self._expand_graphs = {}
+        self.use_graphs = device.type == "cuda"
 
     def _rows(self, span):
         return slice(span[0] * self.steps, span[1] * self.steps)
@@ -297,13 +325,27 @@ class ShardedEnsemble:
             return
         rows = self._rows((a, b))
         local = slice((a - glo) * self.steps, (b - glo) * self.steps)
-        out = self.free_full[rows]
+        out = self.positions[rows] if self.direct else self.free_full[rows]
         info = self.info_local[local] if self.status_only else self.info_full[rows]
+        shape = "records" if self.direct else "free"
+        if out.is_cuda and hasattr(self.dp, "plan"):
+            stream = torch.cuda.current_stream(out.device).cuda_stream
+            bound = self._plans.get(k)
+            if bound is None or bound[0] != stream:  # (a plan launches on the stream that was current when it was made)
+                bound = (stream, self.dp.plan(self.local_targets[local], geom_pos=self.my_pos[a - glo : b - glo],
+                                              geom_row_param=self.my_param[a - glo : b - glo], steps_per_geometry=self.steps,
+                                              output=shape, out=out, info_out=info, **self.solve_kw))
+                self._plans[k] = bound
+            bound[1]()
+            if self.status_only:
+                self.status_full[rows] = info[:, 32]
+            return
         res = self.dp.solve(self.local_targets[local], geom_pos=self.my_pos[a - glo : b - glo], geom_row_param=self.my_param[a - glo : b - glo],
-                            steps_per_geometry=self.steps, output="free", out=out, info_out=info, **self.solve_kw)
+                            steps_per_geometry=self.steps, output=shape, out=out, info_out=info, **self.solve_kw)
         # (a stand-in program of the CPU tests returns fresh tensors instead of filling the buffers it was given)
-        if res.free.data_ptr() != out.data_ptr():
-            out.copy_(res.free)
+        got = res.positions if self.direct else res.free
+        if got.data_ptr() != out.data_ptr():
+            out.copy_(got)
         if res.info_raw.data_ptr() != info.data_ptr():
             info.copy_(res.info_raw)
         if self.status_only:
@@ -357,6 +399,9 @@ class ShardedEnsemble:
         def run():
             for w in works:
                 w.wait()  # NCCL: this stream waits for the transfers; gloo: the host does
+            pieces()
+
+        def pieces():
             for r in range(self.world):
                 a, b = self.pieces[k][r]
                 if b <= a:
@@ -372,7 +417,27 @@ class ShardedEnsemble:
             return
         self.expand_stream.wait_stream(torch.cuda.current_stream(self.expand_stream.device))  # (the own piece was solved there)
         with torch.cuda.stream(self.expand_stream):
-            run()
+            graph = self._expand_graphs.get(k)
+            if not self.use_graphs or self.world == 1:
+                run()
+            elif graph is None:
+                run()  # the first step: plain launches (nothing lazy inside a capture), the second step captures
+                self._expand_graphs[k] = "warm"
+            else:
+                for w in works:
+                    w.wait()
+                if graph == "warm":
+                    try:
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph, stream=self.expand_stream, capture_error_mode="thread_local"):
+                            pieces()
+                    except Exception:  # capture refused: stay with plain launches
+                        self.use_graphs = False
+                        torch.cuda.synchronize(self.expand_stream.device)
+                        pieces()
+                        return
+                    self._expand_graphs[k] = graph
+                graph.replay()
 
     def step(self):
         """One pass over the whole ensemble: returns ``positions`` (``records=True``) or the gathered free coordinates."""
@@ -380,7 +445,7 @@ class ShardedEnsemble:
         for k in range(self.chunks):
             self._solve_chunk(k)
             works = self._exchange_chunk(k)
-            if self.records:
+            if self.records and not self.direct:
                 self._expand_chunk(k, works)
             else:
                 pending += works

@@ -189,3 +189,68 @@ def test_auto_selection_uses_the_lane_kernel_for_batches_that_fill_the_chip(gold
     et = edp.ensemble_targets(gpos, rel)
     kw = dict(geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=8, chain_len=1, predictor=False)
     assert torch.equal(edp.solve(et, **kw).positions, edp.solve(et, kernel="quad", **kw).positions)
+
+
+def test_chunked_ensemble_keeps_the_bits_of_the_single_launch(monkeypatch):
+    """dist.ShardedEnsemble cuts a rank's shard into chunks; auto selection goes by the problem count, so the ensemble asks
+    okx_plan_launch ONCE for the whole batch and forces every chunk to that kernel family and chain length: a 8192-problem
+    chunk of a lane-sized ensemble runs the lane kernel too.  Rank 0 of a world of 4, alone (the exchange stubbed, the
+    peers' rows put in place by hand): pre-bound solve launches, the expands of a chunk as one replayed HIP graph."""
+    import open_kinematics_amd.dist as okd
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.workloads import ensemble_problem
+
+    program, table, rel = ensemble_problem(128, 256)
+    dp = DeviceProgram(program, "cuda:0")
+    table = torch.as_tensor(table, device="cuda:0")
+    n = 128 * 256
+    assert dp.plan_launch(n, steps_per_geometry=256, geometry_tables=True, chain_len=1, predictor=False) == ("lane", 1)
+    assert dp.plan_launch(n // 4, steps_per_geometry=256, geometry_tables=True, chain_len=1, predictor=False)[0] == "quad"
+    assert dp.plan_launch(n, steps_per_geometry=256, geometry_tables=True, kernel="quad", chain_len=7)== ("quad", 7)
+    whole = okd.ShardedEnsemble(dp, table, rel, 256, chunks=1, direct=False, chain_len=1, predictor=False)
+    ref = whole.step().clone()
+    alone = okd.ShardedEnsemble(dp, table, rel, 256, chain_len=1, predictor=False)  # one rank: the solves write the records
+    assert alone.direct and alone.free_full is None and torch.equal(alone.step(), ref)
+    coords, info = whole.free_full.clone(), whole.info_full.clone()
+    torch.cuda.synchronize()
+
+    class RankZero(okd.ShardedEnsemble):
+        def _exchange_chunk(self, k):
+            return []
+
+    monkeypatch.setattr(okd, "_world", lambda group: (4, 0))
+    for chunks, kind in ((4, "full"), (2, "status")):
+        pipe = RankZero(dp, table, rel, 256, chunks=chunks, info=kind, chain_len=1, predictor=False)
+        assert pipe.solve_kw["kernel"] == "lane" and pipe.chunks == chunks
+        lo, hi = pipe.geometry_range
+        own = slice(lo * 256, hi * 256)
+        for step in range(3):  # plain launches, the capture, a replay
+            pipe.free_full.copy_(coords)
+            pipe.free_full[own] = 0.0  # what this rank has to produce itself
+            got = pipe.step()
+            torch.cuda.synchronize()
+            assert torch.equal(pipe.free_full, coords), (chunks, step)
+            assert torch.equal(got, ref), (chunks, step)
+        assert all(isinstance(g, torch.cuda.CUDAGraph) for g in pipe._expand_graphs.values()) and len(pipe._expand_graphs) == chunks
+        if kind == "status":
+            assert torch.equal(pipe.info_local, info[own]) and torch.equal(pipe.status_full[own], info[own, 32])
+        else:
+            assert torch.equal(pipe.info_full[own], info[own])
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid"])
+def test_a_record_does_not_depend_on_the_kernel_that_wrote_it(golden, name):
+    """The lane kernel's records == okx_expand_positions_batch of its free coordinates, bit for bit (the final state's
+    derived points are evaluated in the quad kernels' order of operations): one rank writing records and N ranks
+    gathering coordinates and expanding them hold the same ensemble."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden(name)
+    dp = DeviceProgram(program.with_line_mode("pinned"), "cuda:0")
+    t = np.concatenate([arrays["targets_abs"]] * 3)[:300]
+    for kernel in ("lane", "quad"):
+        rec = dp.solve(t, kernel=kernel, chain_len=1, predictor=False)
+        free = dp.solve(t, kernel=kernel, chain_len=1, predictor=False, output="free")
+        torch.cuda.synchronize()
+        assert torch.equal(rec.positions[:, dp.free_out_index], free.free), kernel
+        assert torch.equal(dp.expand(free.free), rec.positions), kernel

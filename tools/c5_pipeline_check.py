@@ -8,10 +8,10 @@ from open_kinematics_amd.workloads import ensemble_problem
 program, table, rel = ensemble_problem(67, 64)
 dp = DeviceProgram(program, "cuda:0")
 t = torch.as_tensor(table, device="cuda:0")
-a = ShardedEnsemble(dp, t, rel, 64, chunks=1, chain_len=1, predictor=False)
+a = ShardedEnsemble(dp, t, rel, 64, chunks=1, direct=False, chain_len=1, predictor=False)
 pa = a.step().clone(); fa = a.free_full.clone(); ia = a.info_full.clone()
 for c in (3, 8, 67, 100):
-    b = ShardedEnsemble(dp, t, rel, 64, chunks=c, chain_len=1, predictor=False)
+    b = ShardedEnsemble(dp, t, rel, 64, chunks=c, direct=False, chain_len=1, predictor=False)
     pb = b.step(); torch.cuda.synchronize()
     assert torch.equal(pa, pb) and torch.equal(fa, b.free_full) and torch.equal(ia, b.info_full), c
     f = ShardedEnsemble(dp, t, rel, 64, chunks=c, records=False, chain_len=1, predictor=False)
@@ -20,4 +20,6 @@ for c in (3, 8, 67, 100):
     assert torch.equal(lean.step(), fa) and torch.equal(lean.status_full, ia[:, 32]) and torch.equal(lean.info_local, ia)
 ref = dp.solve(dp.ensemble_targets(*[dp.rebind(t)[0]], rel), geom_pos=dp.rebind(t)[0], geom_row_param=dp.rebind(t)[1], steps_per_geometry=64, chain_len=1, predictor=False)
 assert torch.equal(ref.positions, pa)
+d = ShardedEnsemble(dp, t, rel, 64, chain_len=1, predictor=False)
+assert d.direct and torch.equal(d.step(), pa) and torch.equal(d.info_full, ia)
 print("chunked == unchunked == plain solve, bit for bit")
