@@ -1131,7 +1131,7 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["pipelined"] = measure_pipelined(dp, targets, device, max(args.steps, 60))
         line["with_model"] = measure_with_model(program, targets, device, args.steps, args.warmup)
         line["e2e"] = measure_e2e(dp, targets_all[lo:hi], device, max(extra_steps, 200), dict(chain_len=args.chain_len, predictor=False))
-        line["e2e"]["host_threads"] = host_threads
+        line["e2e"]["host_threads"] = fit_host_threads()  # (what main() decided: the first call's answer is kept)
         line["e2e"]["compact"] = measure_e2e_compact(dp, targets_all[lo:hi], device, max(extra_steps, 200),
                                                      dict(chain_len=args.chain_len, predictor=False))
         # (last of the host-to-host legs on purpose: round 3 measured this leg at a fifth of its rate whenever another leg had

@@ -430,7 +430,8 @@ class ShardedEnsemble:
                     try:
                         graph = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph, stream=self.expand_stream, capture_error_mode="thread_local"):
-                            pieces()
+                            pieces()  # (a linear graph: forking the pieces onto side streams inside the capture made the
+                            #  replay SLOWER on this runtime - 0.39 against 0.31 ms for 16 nodes, EXPERIMENTS.md section 2)
                     except Exception:  # capture refused: stay with plain launches
                         self.use_graphs = False
                         torch.cuda.synchronize(self.expand_stream.device)

@@ -4,8 +4,8 @@ BASELINE config 5 on N GPUs, what ONE GPU can measure of it: rank 0's side of th
 world sizes 1, 2, 4, 8 with the exchange stubbed out (no peer exists here) - the solve of the rank's shard chunk by chunk
 into the gathered arrays, and the expand of EVERY rank's pieces on the third stream - against the link model for the
 exchange those chunks would ride (one xGMI link per peer, ~60 GB/s sustained per direction, ~20 us per
-grouped point-to-point call).  The predicted step is max(measured compute side, modelled exchange) + one chunk of the
-other; the table in DESIGN.md section 8 is this tool's output.
+grouped point-to-point call).  The predicted step is the pipeline's schedule (`simulate`) with those stage times; the
+table in DESIGN.md section 8 is this tool's output.
 
   python tools/c5_pipeline_model.py [--reps 10]
 """
@@ -31,6 +31,22 @@ class RankZeroOf(okd.ShardedEnsemble):
 
     def _exchange_chunk(self, k):
         return []
+
+
+def simulate(chunks: int, s: float, x: float, e: float) -> float:
+    """The pipeline's schedule with measured stage times per chunk: solves back to back on the GPU, chunk k's exchange on
+    the links once it is solved and chunk k - 1 has gone, chunk k's expand on the GPU once it has arrived and the GPU is
+    free (the solves come first: nothing holds them back)."""
+    solved = [(k + 1) * s for k in range(chunks)]
+    gpu_free, link_free, end = solved[-1], 0.0, solved[-1]
+    for k in range(chunks):
+        arrived = max(solved[k], link_free) + x
+        link_free = arrived
+        end = arrived
+        if e > 0.0:
+            gpu_free = max(arrived, gpu_free) + e
+            end = gpu_free
+    return end
 
 
 def ms(fn, device, reps):
@@ -76,8 +92,7 @@ def main():
                     sent = pipe.exchange_bytes_per_rank if world > 1 else 0
                     # every peer over its own link at once: one copy of this rank's shard per link
                     exchange = (sent / (LINK_GBS * 1e9) * 1e3 + chunks * CALL_US * 1e-3) if world > 1 else 0.0
-                    per_chunk = (exchange + compute) / chunks / 2 if world > 1 else 0.0
-                    step = max(compute, exchange) + (per_chunk if world > 1 else 0.0)
+                    step = simulate(chunks, solve / chunks, exchange / chunks, max(compute - solve, 0.0) / chunks if records else 0.0)
                     rows.append({"world": world, "records": records, "info": info, "chunks": chunks, "auto": auto,
                                  "solve_ms": round(solve, 4), "compute_side_ms": round(compute, 4),
                                  "bytes_sent_per_link": sent, "exchange_model_ms": round(exchange, 4),
