@@ -62,7 +62,8 @@ def fit_host_threads(reserve: int = 2, processes: int | None = None) -> dict:
         except ValueError:
             processes = 1
     want = max(1, cores // processes - reserve)
-    if os.environ.get("OKX_KEEP_HOST_THREADS") == "1" or want >= before:
+    quota_binds = how.startswith("cgroup") or processes > 1  # (an affinity mask alone already sized torch's pool)
+    if os.environ.get("OKX_KEEP_HOST_THREADS") == "1" or want >= before or not quota_binds:
         _fitted = {"torch_threads": before, "was": before, "host_cores": cores, "how": how, "changed": False}
         return _fitted
     torch.set_num_threads(want)
