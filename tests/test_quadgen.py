@@ -73,7 +73,8 @@ def test_axle_is_generated_in_pair_mode(golden):
     for f in range(10):
         assert f"double A{f}_{f}_0" in src                           # ten free points per half
     assert "double A10_10_0" not in src
-    assert "okx_quad_eval" not in src and "okx_quad_expand" not in src  # parity / expand kernels: interpreter serves those
+    assert "okx_quad_eval" not in src            # the parity hook: the interpreter serves it
+    assert "okx_quad_expand(" in src and "fin[" in src  # round 5: the expand is generated (input rows staged through LDS)
     assert "okx_quad_tangent_u(" in src and "sm_det" in src          # tangents are generated (regularised halves)
     assert "xsl[" in src and "a.predictor[" not in src               # chain state in LDS; no chain-head model in pair mode
 
