@@ -106,6 +106,7 @@ struct okx_program {
   hipModule_t ev_mod, ev_lane_mod;
   hipFunction_t ev_solve_u, ev_solve_g, ev_cold_u, ev_pos_u, ev_pos_g;  // quad form (single mode)
   hipFunction_t ev_lane_u, ev_lane_g;                                   // lane form: independent solves (null: none)
+  hipFunction_t ev_lane_pos_u = nullptr, ev_lane_pos_g = nullptr;       // lane form of okx_evaluate_batch (null: none)
   int ev_lane_scratch;
   okx::EvalSpec ev_spec;     // the role points compiled into them
   okx::EvalScalars ev_cfg;   // the roles' numeric part, a kernel argument
@@ -1245,6 +1246,7 @@ static void release_evaluation(okx_program* p) {
   p->ev_mod = p->ev_lane_mod = nullptr;
   p->ev_solve_u = p->ev_solve_g = p->ev_cold_u = p->ev_pos_u = p->ev_pos_g = nullptr;
   p->ev_lane_u = p->ev_lane_g = nullptr;
+  p->ev_lane_pos_u = p->ev_lane_pos_g = nullptr;
 }
 
 int32_t okx_program_enable_evaluation(okx_program* p, const okx_corner_roles* roles) {
@@ -1322,10 +1324,17 @@ int32_t okx_program_enable_evaluation(okx_program* p, const okx_corner_roles* ro
         hipModuleGetFunction(&p->ev_lane_g, lmod, "okx_lane_evsolve_g") == hipSuccess) {
       p->ev_lane_mod = lmod;
       p->ev_lane_scratch = lane_scratch;
+      // the same epilogue on given states (optional: programs whose free points are not all output points have none)
+      if (hipModuleGetFunction(&p->ev_lane_pos_u, lmod, "okx_lane_evaluate_u") != hipSuccess ||
+          hipModuleGetFunction(&p->ev_lane_pos_g, lmod, "okx_lane_evaluate_g") != hipSuccess) {
+        (void)hipGetLastError();
+        p->ev_lane_pos_u = p->ev_lane_pos_g = nullptr;
+      }
     } else {
       (void)hipGetLastError();
       if (lmod) (void)hipModuleUnload(lmod);
       p->ev_lane_u = p->ev_lane_g = nullptr;
+      p->ev_lane_pos_u = p->ev_lane_pos_g = nullptr;
       std::snprintf(p->ev_note, sizeof(p->ev_note), "the lane form's code object did not load");
     }
   }
@@ -1350,6 +1359,49 @@ int32_t okx_evaluate_batch(okx_program* p, int64_t n_problems, int64_t steps_per
   if (steps_per_geometry < 0 || (d_geom_pos && steps_per_geometry == 0) ||
       (steps_per_geometry > 0 && n_problems % steps_per_geometry != 0))
     return fail(OKX_ERR_INVALID, "bad steps_per_geometry");
+  const char* base = reinterpret_cast<const char*>(p->dev);
+  {
+    // Lane form (one lane per state, 64 per wavefront: a third of the quad form's instructions per state) once the batch
+    // gives every SIMD a wave unit; an ensemble's wave units hold states of ONE geometry, so few steps per geometry leave
+    // lanes idle and stay with the quad form.
+    const long long span = steps_per_geometry > 0 ? steps_per_geometry : n_problems;
+    const long long units = (n_problems / span) * ((span + 63) / 64);
+    const bool fills = units >= (long long)p->n_cu * 4 && n_problems >= 48 * units;
+    if (p->ev_lane_pos_u && !okx::dev_switch("evaluate_quad") && (fills || okx::dev_switch("evaluate_lane"))) {
+      okx::QuadEvArgs qe{};
+      okx::QuadArgs& a = qe.q;
+      a.targets = d_pos;  // (the GIVEN bodies read the records through this pointer: okx_lanegen.cpp)
+      a.geom_pos = d_geom_pos;
+      a.geom_row_param = d_geom_row_param;
+      a.out_pos = nullptr;
+      a.info = nullptr;
+      a.n_problems = n_problems;
+      a.steps_per_geometry = steps_per_geometry;
+      a.chain_len = 1;
+      a.max_iter = 0;
+      a.confirm = 0;
+      a.step_tol = a.ftol = a.lambda0 = a.residual_tolerance = 0.0;
+      a.grad_tol = 0.0;
+      a.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
+      a.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
+      a.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
+      a.trace = nullptr;
+      a.trace_problem = 0;
+      a.predictor = nullptr;
+      a.predictor_mode = 0;
+      a.predictor_len = 0;
+      a.head = nullptr;
+      a.out_mode = OKX_OUTPUT_NONE;
+      qe.tan = d_tangents;
+      qe.ev = d_eval;
+      qe.cfg = p->ev_cfg;
+      const long long cap = (long long)p->n_cu * 4;
+      void* kargs[] = {(void*)&qe};
+      HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->ev_lane_pos_g : p->ev_lane_pos_u, (int)(units < cap ? units : cap), 1, 1, okx::kWave, 1, 1,
+                                    0, (hipStream_t)stream, kargs, nullptr));
+      return OKX_OK;
+    }
+  }
   okx::QuadEvPosArgs q;
   q.pos = d_pos;
   q.geom_pos = d_geom_pos;
@@ -1358,7 +1410,6 @@ int32_t okx_evaluate_batch(okx_program* p, int64_t n_problems, int64_t steps_per
   q.ev = d_eval;
   q.n_problems = n_problems;
   q.steps_per_geometry = steps_per_geometry > 0 ? steps_per_geometry : n_problems;
-  const char* base = reinterpret_cast<const char*>(p->dev);
   q.design_pos = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, design_pos));
   q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
   q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));

@@ -1623,7 +1623,10 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
           ev.gl_gq0, ev.gl_tq0, ev.gl_gq0, ev.gl_dp0, ev.gl_tq0 - 8 * P.n_crows, ev.gl_dp0);
     } else
       g.f("#define GL(o) gl[(o) + kz]");
-    g.f("template <bool PG, bool FULL> DEV void okx_lane_body_%s(const QArgs& a%s) {", ns ? (gb ? "nestg" : "nest") : ch || fl ? "chain" : gb ? "coldg" : "cold", EV ? ", const QEvArgs& ea" : "");
+    // (evaluated module: GIVEN = the wave unit's states are read from records - a.targets points at them - instead of solved;
+    //  the body is then its final state and the epilogue: okx_evaluate_batch's lane form)
+    g.f("template <bool PG, bool FULL%s> DEV void okx_lane_body_%s(const QArgs& a%s) {", EV ? ", bool GIVEN" : "", ns ? (gb ? "nestg" : "nest") : ch || fl ? "chain" : gb ? "coldg" : "cold", EV ? ", const QEvArgs& ea" : "");
+    if (!EV) g.f("  constexpr bool GIVEN = false;");
     g.f("  const int lane = threadIdx.x;");
     g.f("  __shared__ double lds[%d];", lds_doubles);
     if (sc) g.f("  int kzs = 0;  // an opaque zero in a scalar register: a table read inside a pass is a load of that pass, not a loop invariant");
@@ -1664,7 +1667,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("  const long long wu_lo = PG ? blockIdx.x * wu_per_wave : blockIdx.x, wu_step = PG ? 1 : gridDim.x;");
       g.f("  const long long wu_hi = PG ? (wu_lo + wu_per_wave < n_wave_units ? wu_lo + wu_per_wave : n_wave_units) : n_wave_units;");
       if (gb) {
-        g.f("  const bool with_head = a.head != nullptr && a.grad_tol <= 0.0;");
+        g.f("  const bool with_head = !GIVEN && a.head != nullptr && a.grad_tol <= 0.0;");
         g.f("  long long staged_span = -1;");
       }
       {  // (own geometry: round k gives wavefront w the unit k G + (w + 131 k) mod G, see okx_quadgen.cpp; C4 cold +1.3 %)
@@ -1697,11 +1700,11 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("    const long long bb = valid ? first_b + sidx : last_b - 1;");
       for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[bb * %d + %d];", t, T, t);
     } else
-      for (int t = 0; t < T; ++t) g.f("    const double tn%d = a.targets[first_b * %d + %d];", t, T, t);
+      for (int t = 0; t < T; ++t) g.f("    const double tn%d = GIVEN ? 0.0 : a.targets[first_b * %d + %d];", t, T, t);
     if (sc) {
       g.f("    const okx_cptr gpc = (okx_cptr)gp, gqc = (okx_cptr)gq, rpc = (okx_cptr)a.row_param, dpc = (okx_cptr)a.dop_param;");
       g.f("    (void)gqc; (void)rpc; (void)dpc;");
-      g.f("    const bool with_head = a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
+      g.f("    const bool with_head = !GIVEN && a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
       g.f("    WAVE_SYNC();  // (the previous wave unit's last LDS reads are done)");
     } else {
     g.f("    // the geometry's tables (and its first-step table) into LDS, lane k fetching entry k");
@@ -1728,7 +1731,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     } else
     stage_tables(g, "    ");
     if (!gb) {
-    g.f("    const bool with_head = a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
+    g.f("    const bool with_head = !GIVEN && a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
     g.f("    if (with_head) {");
     g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
     g.f("      for (int k = lane; k < %d; k += 64) lds[%d + k] = hp[k];", head_stride, head_l0);
@@ -1748,6 +1751,22 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     for (int i = 0; i < n; ++i) {
       g.f("    x%d = %s; dx%d = 0.0;", i, PF(i).c_str(), i);
       if (ch) g.f("    xp%d = %s; xq%d = %s;", i, PF(i).c_str(), i, PF(i).c_str());
+    }
+    if (EV && !ch && !fl) {
+      // given states: the free coordinates from the lane's record (18 loads in flight; the wave unit's records are one
+      // contiguous block, so every line fetched is used by the unit)
+      std::vector<int> oi(NP, -1);
+      for (int k = 0; k < P.n_out; ++k) oi[P.out_point[k]] = k;
+      bool all_out = true;
+      for (int F = 0; F < nf; ++F) all_out = all_out && oi[ev.fp(F)] >= 0;
+      if (all_out) {
+        g.f("    if (GIVEN) {");
+        g.f("      const double* rec = a.targets + first_b * %d;  // (okx_lane_evaluate_*: a.targets points at the records)", 3 * P.n_out);
+        for (int i = 0; i < n; ++i) g.f("      x%d = rec[%d];", i, 3 * oi[ev.fp(i / 3)] + i % 3);
+        g.f("    }");
+      } else {
+        g.f("    static_assert(!GIVEN, \"a free point is not among the output points\");");
+      }
     }
     stamp(16);
     // the design state is a solved state of its own design targets: it seeds the chain's history
@@ -1964,7 +1983,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("      double Fc = 0.0, lambda = 0.0, nu = 2.0, dmax = 0.0, step_len = 0.0, last_step = 0.0, mres = 0.0, pred = 0.0;");
     g.f("      int nfev = 0, iters = 0, flags = 0, nfail = 0;");
     g.f("      int mode = 0;  // 0 first evaluation, 1 trial point, 2 re-evaluation of the accepted point");
-    g.f("      bool done = !valid, want_light = false;");
+    g.f("      bool done = GIVEN || !valid, want_light = false;");
     g.f("      double prev_sl = 0.0, piv_lo = 0.0, piv_hi = 0.0;");
     if (ns) g.f("      double cq_seen = 0.0;");
     g.f("      if (head_ready%s) {", ch ? " && b == first_b" : "");
@@ -2190,7 +2209,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      r0[%d] = ((flags & INFO_CONVERGED) && !(flags & INFO_FAILED)) ? 1.0 : 0.0; r0[%d] = lambda; }", 64 * n, 64 * (n + 1));
     }
     stamp(13);
-    g.f("    if (valid) {");
+    g.f("    if (valid && !GIVEN) {");
     g.f("      okx_info inf; inf.max_residual = mres; inf.cost = Fc; inf.last_step = last_step;");
     g.f("      inf.iterations = iters; inf.nfev = nfev; inf.flags = flags; inf.reserved = 0;");
     g.f("      a.info[bb] = inf;");
@@ -2390,8 +2409,18 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       *why = lds_why;
       return false;
     }
-    g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_evsolve_u(QEvArgs ea) { okx_lane_body_cold<false, true>(ea.q, ea); }");
-    g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_evsolve_g(QEvArgs ea) { okx_lane_body_%s<true, true>(ea.q, ea); }", split_g ? "coldg" : "cold");
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_evsolve_u(QEvArgs ea) { okx_lane_body_cold<false, true, false>(ea.q, ea); }");
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_evsolve_g(QEvArgs ea) { okx_lane_body_%s<true, true, false>(ea.q, ea); }", split_g ? "coldg" : "cold");
+    {  // okx_evaluate_batch's lane form (reference core/sweep.py:217-245 evaluate_solved_sweep): the epilogue on given states
+      bool all_out = true;
+      std::vector<bool> is_out(NP, false);
+      for (int k = 0; k < P.n_out; ++k) is_out[P.out_point[k]] = true;
+      for (int F = 0; F < nf; ++F) all_out = all_out && is_out[evc.fp(F)];
+      if (all_out) {
+        g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_evaluate_u(QEvArgs ea) { okx_lane_body_cold<false, true, true>(ea.q, ea); }");
+        g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_evaluate_g(QEvArgs ea) { okx_lane_body_%s<true, true, true>(ea.q, ea); }", split_g ? "coldg" : "cold");
+      }
+    }
     *src = g.out;
     return true;
   }

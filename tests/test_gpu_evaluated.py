@@ -204,3 +204,40 @@ def test_solve_evaluated_sweep_is_solve_sweep_plus_compute_sweep_metrics(golden,
     assert [list(r.items()) for r in again.metrics.rows] == [list(r.items()) for r in ref.rows]
     with pytest.raises(ValueError, match="counts must match"):
         evaluate_solved_sweep(sus, sweep, states, stats[:-1])
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "c4_macpherson_grid"])
+def test_evaluate_lane_form_matches_the_quad_form_and_the_reference(golden, name, monkeypatch):
+    """okx_evaluate_batch's lane form (one lane per state; batches that fill the chip take it by themselves) against the
+    quad form and the reference's goldens: ragged batch, tangents on request, per-geometry tables."""
+    dp, program, roles, ridx, mg = _evaluated_program(golden, name)
+    assert dp.evaluation & 2, dp.evaluation_note
+    pos = np.concatenate([mg["pos"], mg["pos"][::-1], mg["pos"]])[:131]
+    want = np.concatenate([mg["values"], mg["values"][::-1], mg["values"]])[:131]
+    monkeypatch.setenv("OKX_DEV", "evaluate_quad")
+    quad = dp.evaluate(pos, tangents=True)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("OKX_DEV", "evaluate_lane")
+    lane = dp.evaluate(pos, tangents=True)
+    lean = dp.evaluate(pos)
+    torch.cuda.synchronize()
+    assert close(lane.metrics.cpu().numpy(), want, 1e-9)
+    assert close(lane.eval.cpu().numpy(), quad.eval.cpu().numpy(), 1e-9)
+    assert np.max(np.abs(lane.tangents.cpu().numpy() - quad.tangents.cpu().numpy())) <= 1e-9
+    assert torch.equal(torch.nan_to_num(lean.eval), torch.nan_to_num(lane.eval)) and lean.tangents is None
+    assert np.all(lane.tangent_info()["flags"] == 1)
+    # an ensemble: every geometry's own design references, wave units of one geometry each (70 steps: a ragged second unit)
+    rng = np.random.default_rng(5)
+    g, s = 3, 70
+    hard = np.repeat(program.design_pos[None], g, axis=0) + rng.normal(0.0, 0.5, size=(g, program.n_points, 3))
+    gpos, grow = dp.rebind(hard)
+    rel = np.zeros((s, program.n_targets))
+    rel[:, -1] = np.linspace(-20.0, 25.0, s)
+    kw = dict(geom_pos=gpos, geom_row_param=grow, steps_per_geometry=s)
+    solved = dp.solve(dp.ensemble_targets(gpos, rel), chain_len=1, **kw)
+    lane_g = dp.evaluate(solved.positions, tangents=True, **kw)
+    monkeypatch.setenv("OKX_DEV", "evaluate_quad")
+    quad_g = dp.evaluate(solved.positions, tangents=True, **kw)
+    torch.cuda.synchronize()
+    assert close(lane_g.eval.cpu().numpy(), quad_g.eval.cpu().numpy(), 1e-9)
+    assert np.max(np.abs(lane_g.tangents.cpu().numpy() - quad_g.tangents.cpu().numpy())) <= 1e-9

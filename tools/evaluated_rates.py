@@ -87,6 +87,11 @@ def measure(which: str, device, reps: int, only: str = "") -> dict:
     rows["evaluated_with_records"] = ev_ms(dp.plan_evaluated(targets, out=out, info_out=info, eval_out=evb, **skw), device, reps)
     del tan
     rows["evaluate_given_states"] = ev_ms(lambda: dp.evaluate(out, eval_out=evb, **kw), device, reps)
+    os.environ["OKX_DEV"] = "evaluate_quad"   # (the quad form, 16 states per wavefront: what small batches get)
+    rows["evaluate_given_states_quad_form"] = ev_ms(lambda: dp.evaluate(out, eval_out=evb, **kw), device, reps)
+    os.environ["OKX_DEV"] = "evaluate_lane"
+    rows["evaluate_given_states_lane_form"] = ev_ms(lambda: dp.evaluate(out, eval_out=evb, **kw), device, reps)
+    del os.environ["OKX_DEV"]
     res = {"workload": which, "states": n, "evaluation": dp.evaluation, "evaluation_note": dp.evaluation_note, "ms": rows,
            "states_per_s": {k: n / v * 1e3 for k, v in rows.items()},
            "bytes_per_state_out": {"evaluated_metrics_only": 8 * 24 * (1 + T) + 40 + 8 * T,
