@@ -793,8 +793,10 @@ def main() -> None:
                          "(profiling runs of the predictor path; never the default)")
     ap.add_argument("--chain-len", type=int, default=-1, help="-1 auto (16384 steps fit the chip: independent solves), 1 = independent")
     ap.add_argument("--c5-chunks", type=int, default=0, help="--config c5, N > 1: chunks of the pipelined exchange per rank (0: auto, up to 8)")
-    ap.add_argument("--c5-gather", choices=("records", "free"), default="records",
-                    help="--config c5, N > 1: every rank ends with all output records (default) or with the free coordinates only (no expand)")
+    ap.add_argument("--c5-gather", choices=("records", "free", "metrics"), default="records",
+                    help="--config c5, N > 1: every rank ends with all output records (default), with the free coordinates only (no expand), "
+                         "or - the EVALUATED ensemble - with four metric columns of every state (camber, camber gain and bump steer "
+                         "along the bump target, the hub's rise rate): each rank evaluates its shard, 33 bytes per state travel")
     ap.add_argument("--c5-info", choices=("full", "status"), default="status",
                     help="--config c5, N > 1: what travels beside the coordinates - the 40-byte info records or one status byte per solve")
     ap.add_argument("--rccl-world-one", action="store_true",
@@ -1207,9 +1209,19 @@ def run_c5(args, world: int, rank: int, device) -> dict:
     # chunk k travels (coordinates + info records, one grouped point-to-point call, from and into their final place) and
     # chunk k - 1 is expanded on a third stream; --c5-gather free leaves the expand out (coordinates on every rank)
     pipe = None
-    if world > 1:
+    metric_columns = None
+    if args.c5_gather == "metrics":
+        from open_kinematics_amd.input import load_geometry
+        from open_kinematics_amd.metrics import corner_roles
+        from open_kinematics_amd.workloads import geometry_path
+
+        dp.enable_evaluation(corner_roles(load_geometry(geometry_path("geometry.yaml")), program))
+        bump = program.n_targets - 1
+        metric_columns = [("camber", None), ("camber", bump), ("roadwheel_angle", bump), (21, bump)]  # (21: the wheel centre's z rate)
+    if world > 1 or metric_columns:
         pipe = ShardedEnsemble(dp, table_dev, rel, spg, chunks=args.c5_chunks or None, records=args.c5_gather == "records",
-                               info=args.c5_info, chain_len=args.chain_len if args.chain_len != -1 else 1, predictor=False)
+                               info=args.c5_info, metric_columns=metric_columns,
+                               chain_len=args.chain_len if args.chain_len != -1 else 1, predictor=False)
 
     def step(k, start, end):
         if start is not None:
@@ -1224,16 +1236,22 @@ def run_c5(args, world: int, rank: int, device) -> dict:
     elapsed, step_ms = timed_region(step, lambda: None, args.steps, args.warmup, world, device, per_launch_events=True)
     kernel_ms = step_ms
     if pipe is not None:  # the solve alone, for `solve_only`: the whole shard as one launch, outside the timed region
+        if metric_columns:  # (the evaluated solve of the shard, no positions written)
+            evb = torch.empty((n_local, 1 + program.n_targets, 24), dtype=torch.float64, device=device)
+            launch = dp.plan_evaluated(targets, info_out=info, eval_out=evb, output="none", chain_len=1, predictor=False,
+                                       geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=spg)
         _, kernel_ms = time_launches(launch, max(3, min(args.steps, 10)), 2, device)
         info = pipe.info_local if pipe.status_only else pipe.info_full[glo * spg : ghi * spg]
     nfev_mean, ok = info_summary(info)
     if rank != 0:
         return {}
     bytes_per = algorithmic_bytes_per_solve(program, spg)
+    if metric_columns:  # targets in, the info record and the [1 + T][24] evaluation rows out, no positions
+        bytes_per = 8 * program.n_targets + 40 + 8 * 24 * (1 + program.n_targets)
     gbs = bytes_per * n_local / (kernel_ms * 1e-3) / 1e9
     free_bytes = n_local * program.n_free * 24
     return {
-        "metric": "constraint solves/sec (sweep steps/sec), double-wishbone sensitivity ensemble",
+        "metric": "constraint solves/sec (sweep steps/sec), double-wishbone sensitivity ensemble" + (", every solve evaluated (tangents, 19 metrics, their derivatives)" if metric_columns else ""),
         "value": n_total * args.steps / elapsed,
         "unit": "constraint solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -1244,19 +1262,24 @@ def run_c5(args, world: int, rank: int, device) -> dict:
                    "start": "independent cold starts from each geometry's design state (SURVEY.md section 8d)" if args.chain_len in (-1, 1)
                             else f"chains of {args.chain_len}",
                    "lm_evaluations_mean": nfev_mean, "all_converged": ok, "rebind_ms": rebind_ms,
-                   "exchange": ("pipelined: the shard in %d chunks of whole geometries, chunk k + 1 solving while chunk k travels "
+                   "exchange": ("evaluated ensemble: every rank solves AND evaluates its shard (one launch per chunk, no positions "
+                                "written); %d metric columns of every state (8 B each) + a status byte travel, %d chunk(s)"
+                                % (len(metric_columns), pipe.chunks)) if metric_columns else
+                               ("pipelined: the shard in %d chunks of whole geometries, chunk k + 1 solving while chunk k travels "
                                 "(coordinates + info records in one grouped point-to-point call, from and into their final place)%s"
                                 % (pipe.chunks, " and chunk k - 1 is expanded into records on a third stream" if pipe.records else
                                    "; coordinates only, no expand (--c5-gather free)")) if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("okx_lane_solve_g" if 0 < dp.lane_threshold <= n_local and (dp.lane_bodies & 1) else
+                     "kernel": ("okx_lane_evsolve_g" if metric_columns and (dp.evaluation & 2) else
+                                "okx_lane_solve_g" if 0 < dp.lane_threshold <= n_local and (dp.lane_bodies & 1) else
                                 "okx_quad_solve_g" if dp.kernel == "quad" else "okx_solve_kernel"),
                      "kernel_ms": kernel_ms, "algorithmic_bytes_per_solve": bytes_per},
         "solve_only": {"value": n_total / (kernel_ms * 1e-3) if world > 1 else n_local / (kernel_ms * 1e-3),
                        "kernel_ms_max_over_ranks": kernel_ms},
-        "exchange": {"bytes_sent_per_rank_per_step": pipe.exchange_bytes_per_rank if world > 1 else 0,
-                     "bytes_received_per_rank_per_step": (n_total - n_local) * (program.n_free * 24 + (1 if args.c5_info == "status" else 40)) if world > 1 else 0,
-                     "chunks": pipe.chunks if world > 1 else 0, "step_ms_with_exchange": step_ms if world > 1 else None},
+        "exchange": {"bytes_sent_per_rank_per_step": pipe.exchange_bytes_per_rank if pipe is not None else 0,
+                     "bytes_received_per_rank_per_step": (n_total - n_local) * ((8 * len(metric_columns) if metric_columns else program.n_free * 24)
+                                                                                + (1 if args.c5_info == "status" or metric_columns else 40)) if world > 1 else 0,
+                     "chunks": pipe.chunks if pipe is not None else 0, "step_ms_with_exchange": step_ms if world > 1 else None},
     }
 
 

@@ -241,10 +241,22 @@ class ShardedEnsemble:
     40-byte record - 145 instead of 184 bytes per double-wishbone solve on the links; the full records of the rank's own
     shard stay in ``info_local``.  Chunked and unchunked runs give the same bits: a chunk is just a smaller launch of the
     same independent solves.
+
+    ``metric_columns=[(metric, target), ...]`` turns the ensemble into an EVALUATED one (the program must have
+    ``enable_evaluation`` done): every rank runs the evaluated solve on its shard - solve, tangents, metric catalog and
+    derivative columns in one launch, no positions written (``okx_solve_evaluated_batch``) - and what travels is the
+    chosen columns alone, 8 bytes each per state, beside the status byte: ``(metric, None)`` the value of a metric (name
+    from ``metrics.METRIC_NAMES`` or column index of the evaluation row), ``(metric, t)`` its derivative along target
+    ``t``.  ``step()`` then returns ``metric_full [G * S, K]``; the rank's own complete evaluation rows stay in
+    ``eval_local [n_local, 1 + T, 24]``.  This is the form of the sharded ensemble that scales: a sensitivity study wants
+    camber gain and bump steer of every perturbed geometry, not 144 bytes of coordinates per state on every rank.
     """
 
     def __init__(self, device_program, hardpoints, targets, steps_per_geometry: int, *, group=None, chunks: int | None = None,
-                 records: bool = True, relative_targets: bool = True, info: str = "full", direct: bool | None = None, **solve_kw):
+                 records: bool = True, relative_targets: bool = True, info: str = "full", direct: bool | None = None,
+                 metric_columns=None, **solve_kw):
+        if metric_columns is not None:
+            records, info = False, "status"   # nothing of the positions travels or is written
         self.dp = device_program
         self.group = group
         self.world, self.rank = _world(group)
@@ -263,14 +275,18 @@ class ShardedEnsemble:
             # 0.40 ms as 8 eighths).  Without a GPU (the CPU tests' stand-in) a round is 4096.
             dev = torch.as_tensor(hardpoints).device
             one_round = torch.cuda.get_device_properties(dev).multi_processor_count * 256 if dev.type == "cuda" else 4096
-            chunks = max(1, min(8, ((ghi - glo) * self.steps) // one_round, ghi - glo)) if self.world > 1 else 1
+            # (the evaluated ensemble sends 33 B instead of 145 B per state and computes 1.5 x as long: its exchange hides
+            #  behind the solve with two chunks, more only lengthen the solve - tools/c5_pipeline_model.py)
+            most = 2 if metric_columns is not None else 8
+            chunks = max(1, min(most, ((ghi - glo) * self.steps) // one_round, ghi - glo)) if self.world > 1 else 1
         self.chunks = max(1, int(chunks))
         # Kernel family and chain length are chosen ONCE, for the whole ensemble as one launch on one GPU (auto selection
         # goes by the problem count: a 16384-problem chunk of a million-problem ensemble would otherwise run the quad kernel
         # where the ensemble runs the lane kernel - same answers to 1e-9, other bits): every chunk on every rank is forced
         # to that choice, so chunked, unchunked, one-GPU and N-GPU runs of an ensemble agree bit for bit.
         if hasattr(device_program, "plan_launch"):
-            kernel, chain_len = device_program.plan_launch(self.n_total, steps_per_geometry=self.steps, geometry_tables=True, **solve_kw)
+            kernel, chain_len = device_program.plan_launch(self.n_total, steps_per_geometry=self.steps, geometry_tables=True,
+                                                           evaluated=metric_columns is not None, **solve_kw)
             solve_kw = {**solve_kw, "kernel": kernel, "chain_len": chain_len}
         self.solve_kw = solve_kw
         self.pieces = chunk_pieces(self.n_geom, self.world, self.chunks)
@@ -287,16 +303,37 @@ class ShardedEnsemble:
             self.local_targets = device_program.ensemble_targets(self.my_pos, targets)
         else:
             self.local_targets = targets[glo * self.steps : ghi * self.steps]
-        device = self.my_pos.device
+        device = self.device = self.my_pos.device
         if info not in ("full", "status"):
             raise ValueError("info must be 'full' or 'status'")
+        self.metric_index = None
+        if metric_columns is not None:
+            from .metrics import METRIC_NAMES
+
+            flat = []
+            for metric, target in metric_columns:
+                col = METRIC_NAMES.index(metric) if isinstance(metric, str) else int(metric)
+                row = 0 if target is None else 1 + int(target)
+                if not (0 <= col < 24 and 0 <= row <= program.n_targets):
+                    raise ValueError(f"no evaluation entry ({metric!r}, {target!r})")
+                flat.append(row * 24 + col)
+            if not flat:
+                raise ValueError("metric_columns is empty")
+            self.metric_index = torch.tensor(flat, dtype=torch.int64, device=device)
+
         self.status_only = info == "status" and self.world > 1  # (one rank exchanges nothing: full records, a view of their flag byte)
         # ONE rank that wants records has nothing to exchange: its solves write the records themselves (`direct`; the gathered
         # free coordinates are then not kept - direct=False keeps the two-stage form, e.g. to compare the stages' bits)
         self.direct = (self.world == 1 and self.records and not self.status_only) if direct is None else bool(direct)
         if self.direct and (self.world > 1 or not self.records or self.status_only):
             raise ValueError("direct records need a world of one, records=True and info='full'")
-        self.free_full = torch.empty((self.n_total, program.n_free, 3), dtype=torch.float64, device=device)
+        if self.metric_index is not None:
+            if self.direct:
+                raise ValueError("direct records and metric_columns exclude each other")
+            n_local = (ghi - glo) * self.steps
+            self.eval_local = torch.empty((n_local, 1 + program.n_targets, 24), dtype=torch.float64, device=device)
+            self.metric_full = torch.empty((self.n_total, len(self.metric_index)), dtype=torch.float64, device=device)
+        self.free_full = None if self.metric_index is not None else torch.empty((self.n_total, program.n_free, 3), dtype=torch.float64, device=device)
         # what travels beside the coordinates: the 40-byte info records, or one status byte per solve (then the records of
         # this rank's own shard are kept in `info_local`)
         self.info_full = None if self.status_only else torch.empty((self.n_total, 40), dtype=torch.uint8, device=device)
@@ -308,7 +345,8 @@ class ShardedEnsemble:
             self.free_full = None
         if info == "status" and not self.status_only:
             self.status_full, self.info_local = self.info_full[:, 32], self.info_full
-        self.exchange_bytes_per_rank = (ghi - glo) * self.steps * (program.n_free * 24 + (1 if self.status_only else 40)) if self.world > 1 else 0
+        payload = program.n_free * 24 if self.metric_index is None else 8 * len(self.metric_index)
+        self.exchange_bytes_per_rank = (ghi - glo) * self.steps * (payload + (1 if self.status_only else 40)) if self.world > 1 else 0
         # host time per chunk: the solve as a pre-bound launch (DeviceProgram.plan), the expands of a chunk's pieces (one per
         # rank) as ONE HIP graph replayed from the second step on
         self._plans = {}
@@ -325,6 +363,9 @@ class ShardedEnsemble:
             return
         rows = self._rows((a, b))
         local = slice((a - glo) * self.steps, (b - glo) * self.steps)
+        if self.metric_index is not None:
+            self._solve_chunk_evaluated(k, a, b, rows, local)
+            return
         out = self.positions[rows] if self.direct else self.free_full[rows]
         info = self.info_local[local] if self.status_only else self.info_full[rows]
         shape = "records" if self.direct else "free"
@@ -351,10 +392,34 @@ class ShardedEnsemble:
         if self.status_only:
             self.status_full[rows] = info[:, 32]  # (okx_info.flags is the int32 at byte 32: its low byte carries every flag)
 
+    def _solve_chunk_evaluated(self, k: int, a: int, b: int, rows, local) -> None:
+        """The evaluated solve of one chunk (no positions written) and its chosen columns into their place in the gathered table."""
+        glo = self.geometry_range[0]
+        info = self.info_local[local] if self.status_only else self.info_full[rows]
+        ev = self.eval_local[local]
+        kw = dict(geom_pos=self.my_pos[a - glo : b - glo], geom_row_param=self.my_param[a - glo : b - glo], steps_per_geometry=self.steps,
+                  output="none", info_out=info, eval_out=ev, **self.solve_kw)
+        if ev.is_cuda and hasattr(self.dp, "plan_evaluated"):
+            stream = torch.cuda.current_stream(ev.device).cuda_stream
+            bound = self._plans.get(k)
+            if bound is None or bound[0] != stream:
+                bound = (stream, self.dp.plan_evaluated(self.local_targets[local], **kw))
+                self._plans[k] = bound
+            bound[1]()
+        else:
+            res = self.dp.solve_evaluated(self.local_targets[local], **kw)
+            if res.eval.data_ptr() != ev.data_ptr():  # (the CPU tests' stand-in returns fresh tensors)
+                ev.copy_(res.eval)
+            if res.info_raw.data_ptr() != info.data_ptr():
+                info.copy_(res.info_raw)
+        torch.index_select(ev.view(ev.shape[0], -1), 1, self.metric_index, out=self.metric_full[rows])
+        if self.status_only:
+            self.status_full[rows] = info[:, 32]
+
     def _exchange_chunk(self, k: int) -> list:
         if self.world == 1:
             return []
-        if self.free_full.is_cuda and dist.get_backend(self.group) == "gloo":
+        if self.device.type == "cuda" and dist.get_backend(self.group) == "gloo":
             return self._exchange_chunk_through_the_host(k)
         ops = []
         mine = self.pieces[k][self.rank]
@@ -364,11 +429,12 @@ class ShardedEnsemble:
             dst = dist.get_global_rank(self.group, peer) if self.group is not None else peer
             theirs = self.pieces[k][peer]
             beside = self.status_full if self.status_only else self.info_full
+            payload = self.free_full if self.metric_index is None else self.metric_full
             if mine[1] > mine[0]:
-                ops.append(dist.P2POp(dist.isend, self.free_full[self._rows(mine)], dst, self.group))
+                ops.append(dist.P2POp(dist.isend, payload[self._rows(mine)], dst, self.group))
                 ops.append(dist.P2POp(dist.isend, beside[self._rows(mine)], dst, self.group))
             if theirs[1] > theirs[0]:
-                ops.append(dist.P2POp(dist.irecv, self.free_full[self._rows(theirs)], dst, self.group))
+                ops.append(dist.P2POp(dist.irecv, payload[self._rows(theirs)], dst, self.group))
                 ops.append(dist.P2POp(dist.irecv, beside[self._rows(theirs)], dst, self.group))
         return dist.batch_isend_irecv(ops) if ops else []
 
@@ -382,7 +448,7 @@ class ShardedEnsemble:
                 continue
             dst = dist.get_global_rank(self.group, peer) if self.group is not None else peer
             theirs = self.pieces[k][peer]
-            for full in (self.free_full, self.status_full if self.status_only else self.info_full):
+            for full in (self.free_full if self.metric_index is None else self.metric_full, self.status_full if self.status_only else self.info_full):
                 if mine[1] > mine[0]:
                     ops.append(dist.P2POp(dist.isend, full[self._rows(mine)].cpu(), dst, self.group))
                 if theirs[1] > theirs[0]:
@@ -454,6 +520,8 @@ class ShardedEnsemble:
             w.wait()
         if self.expand_stream is not None:
             torch.cuda.current_stream(self.expand_stream.device).wait_stream(self.expand_stream)
+        if self.metric_index is not None:
+            return self.metric_full
         return self.positions if self.records else self.free_full
 
 

@@ -139,6 +139,24 @@ class _StandInProgram:
 
         return _Result
 
+    def solve_evaluated(self, targets, *, geom_pos, geom_row_param, steps_per_geometry, output="none", info_out=None, eval_out=None, **kw):
+        """Evaluation rows [B, 1 + T, 24] of the stand-in: entry (r, c) = (1 + r) * target + c + the geometry's fixed x."""
+        assert output == "none"
+        res = self.solve(targets, geom_pos=geom_pos, geom_row_param=geom_row_param, steps_per_geometry=steps_per_geometry,
+                         output="free", info_out=info_out)
+        fixed = geom_pos[:, 0, 0].repeat_interleave(steps_per_geometry)
+        rows = (1.0 + torch.arange(2, dtype=torch.float64))[None, :, None] * targets[:, :1, None] \
+            + torch.arange(24, dtype=torch.float64)[None, None, :] + fixed[:, None, None]
+        if self.fill_buffers and eval_out is not None:
+            eval_out.copy_(rows)
+            rows = eval_out
+
+        class _Result:
+            eval = rows
+            info_raw = res.info_raw
+
+        return _Result
+
     def expand(self, free, out=None, geom_pos=None, steps_per_geometry=0):
         full = self._assemble(free, geom_pos[:, 0].repeat_interleave(steps_per_geometry, dim=0))
         if out is not None and self.fill_buffers:
@@ -184,6 +202,15 @@ def _ensemble_worker(rank: int, world: int, port: int, n_geom: int, steps: int, 
         torch.save({"result": got, "info": shard.info_full, "free": shard.free_full, "range": shard.geometry_range,
                     "rebound": dp.rebound, "sent": shard.exchange_bytes_per_rank, "launch_rows": dp.launch_rows,
                     "local_free": shard.local.free, "outputs": dp.outputs}, os.path.join(out_dir, f"{tag}{rank}.pt"))
+    # the EVALUATED ensemble: every rank evaluates its shard, chosen metric columns travel (8 B each) beside the status byte
+    from open_kinematics_amd.dist import ShardedEnsemble
+
+    for fill in (True, False):
+        dp = _StandInProgram(fill_buffers=fill)
+        pipe = ShardedEnsemble(dp, table, relative, steps, chunks=2, metric_columns=[(3, None), (0, 0), (23, 0)])
+        table_k = pipe.step().clone()
+        torch.save({"metrics": table_k, "status": pipe.status_full.clone(), "eval_local": pipe.eval_local.clone(),
+                    "sent": pipe.exchange_bytes_per_rank, "range": pipe.geometry_range}, os.path.join(out_dir, f"metrics{int(fill)}_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -227,6 +254,17 @@ def test_two_rank_gloo_ensemble_is_geometry_major(tmp_path, n_geom):
         got = torch.load(os.path.join(tmp_path, f"coords{rank}.pt"))  # gather="free": the coordinates, no expand, own slice rebound only
         assert torch.equal(got["result"], free_expect) and torch.equal(got["info"], expect.info_raw)
         assert got["rebound"] == [hi - lo]
+    # evaluated ensemble: the chosen columns of every state on every rank, the complete rows of the own shard locally
+    whole = ref.solve_evaluated(targets, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=steps, output="none")
+    want = whole.eval.reshape(targets.shape[0], -1)[:, [3, 24 + 0, 24 + 23]]
+    for rank in range(2):
+        lo, hi = spans[rank]
+        for fill in (0, 1):
+            got = torch.load(os.path.join(tmp_path, f"metrics{fill}_{rank}.pt"))
+            assert torch.equal(got["metrics"], want)
+            assert torch.equal(got["status"], expect.info_raw[:, 32])
+            assert torch.equal(got["eval_local"], whole.eval[lo * steps : hi * steps])
+            assert got["sent"] == (hi - lo) * steps * (3 * 8 + 1)
 
 
 def test_single_process_ensemble_needs_no_collective():

@@ -241,3 +241,50 @@ def test_evaluate_lane_form_matches_the_quad_form_and_the_reference(golden, name
     torch.cuda.synchronize()
     assert close(lane_g.eval.cpu().numpy(), quad_g.eval.cpu().numpy(), 1e-9)
     assert np.max(np.abs(lane_g.tangents.cpu().numpy() - quad_g.tangents.cpu().numpy())) <= 1e-9
+
+
+def test_evaluated_ensemble_gathers_metric_columns(golden, monkeypatch):
+    """dist.ShardedEnsemble(metric_columns=...): every rank evaluates its shard (one launch per chunk, no positions), the
+    chosen columns land in the gathered table.  One rank, and rank 0 of a world of 4 alone (exchange stubbed): its own rows
+    equal the unsharded evaluated solve's, bit for bit, whatever the chunk count."""
+    import open_kinematics_amd.dist as okd
+    from open_kinematics_amd.metrics import METRIC_NAMES
+
+    dp, program, roles, ridx, mg = _evaluated_program(golden, "c1_dw_corner")
+    rng = np.random.default_rng(11)
+    g, s = 64, 64
+    table = np.repeat(program.design_pos[None], g, axis=0) + rng.normal(0.0, 0.5, size=(g, program.n_points, 3))
+    table = torch.as_tensor(table, device="cuda:0")
+    rel = np.stack([np.zeros(s), np.linspace(-30.0, 40.0, s)], axis=1)
+    gpos, grow = dp.rebind(table)
+    plan = dp.plan_launch(g * s, steps_per_geometry=s, geometry_tables=True, evaluated=True, chain_len=1, predictor=False)
+    whole = dp.solve_evaluated(dp.ensemble_targets(gpos, rel), geom_pos=gpos, geom_row_param=grow, steps_per_geometry=s,
+                               output="none", kernel=plan[0], chain_len=plan[1], predictor=False)
+    torch.cuda.synchronize()
+    cols = [("camber", None), ("camber", 1), ("roadwheel_angle", 1), (21, 1)]
+    flat = whole.eval.reshape(g * s, -1)
+    want = flat[:, [METRIC_NAMES.index("camber"), 48 + METRIC_NAMES.index("camber"), 48 + METRIC_NAMES.index("roadwheel_angle"), 48 + 21]]
+    alone = okd.ShardedEnsemble(dp, table, rel, s, metric_columns=cols, chain_len=1, predictor=False)
+    got = alone.step()
+    torch.cuda.synchronize()
+    assert got.shape == (g * s, 4) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
+    assert torch.equal(torch.nan_to_num(alone.eval_local), torch.nan_to_num(whole.eval)) and alone.positions is None and alone.free_full is None
+    assert torch.equal(alone.status_full, whole.info_raw[:, 32])
+
+    class RankZero(okd.ShardedEnsemble):
+        def _exchange_chunk(self, k):
+            return []
+
+    monkeypatch.setattr(okd, "_world", lambda group: (4, 0))
+    pipe = RankZero(dp, table, rel, s, chunks=3, metric_columns=cols, chain_len=1, predictor=False)
+    lo, hi = pipe.geometry_range
+    own = slice(lo * s, hi * s)
+    for _ in range(2):
+        pipe.metric_full.zero_()
+        got = pipe.step()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(got[own]), torch.nan_to_num(want[own]))
+        assert torch.equal(torch.nan_to_num(pipe.eval_local), torch.nan_to_num(whole.eval[own]))
+    assert pipe.exchange_bytes_per_rank == (hi - lo) * s * (4 * 8 + 1)
+    with pytest.raises(ValueError, match="no evaluation entry"):
+        okd.ShardedEnsemble(dp, table, rel, s, metric_columns=[("camber", 5)])

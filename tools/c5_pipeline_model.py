@@ -22,6 +22,7 @@ import open_kinematics_amd.dist as okd  # noqa: E402
 from open_kinematics_amd.batch import DeviceProgram  # noqa: E402
 from open_kinematics_amd.workloads import ensemble_problem  # noqa: E402
 
+METRIC_COLUMNS = [("camber", None), ("camber", 1), ("roadwheel_angle", 1), (21, 1)]   # what bench.py --c5-gather metrics sends
 LINK_GBS = 60.0     # sustained per direction per link (153.6 GB/s per link both ways = 76.8 per direction peak)
 CALL_US = 20.0      # launch + synchronisation of one grouped point-to-point call
 
@@ -70,6 +71,11 @@ def main():
     table = torch.as_tensor(table, device=device)
     spg = rel.shape[0]
     n_total = table.shape[0] * spg
+    from open_kinematics_amd.input import load_geometry
+    from open_kinematics_amd.metrics import corner_roles
+    from open_kinematics_amd.workloads import geometry_path
+
+    dp.enable_evaluation(corner_roles(load_geometry(geometry_path("geometry.yaml")), program))
     whole = okd.ShardedEnsemble(dp, table, rel, spg, chunks=1, records=False, chain_len=1, predictor=False)
     coords = whole.step().clone()
     records_ref = dp.expand(coords, geom_pos=dp.rebind(table)[0], steps_per_geometry=spg)
@@ -78,22 +84,25 @@ def main():
     for world in (1, 2, 4, 8):
         okd._world = lambda group, w=world: (w, 0)
         try:
-            for records, info in ((True, "full"), (True, "status"), (False, "status")):
+            for mode, info in ((True, "full"), (True, "status"), (False, "status"), ("metrics", "status")):
                 for chunks in ((1,) if world == 1 else (1, 2, 4, 8, None)):
-                    pipe = RankZeroOf(dp, table, rel, spg, chunks=chunks, records=records, info=info, chain_len=1, predictor=False)
+                    metric_mode = mode == "metrics"
+                    mkw = dict(metric_columns=METRIC_COLUMNS) if metric_mode else {}
+                    records = False if metric_mode else mode
+                    pipe = RankZeroOf(dp, table, rel, spg, chunks=chunks, records=records, info=info, chain_len=1, predictor=False, **mkw)
                     auto, chunks = chunks is None, pipe.chunks
                     if pipe.free_full is not None:
                         pipe.free_full.copy_(coords)   # what the peers would have sent
                     compute = ms(pipe.step, device, reps)
                     if records:  # plans and graph replays: still the same bits
                         assert torch.equal(pipe.step(), records_ref)
-                    solve_only = RankZeroOf(dp, table, rel, spg, chunks=chunks, records=False, info=info, chain_len=1, predictor=False)
+                    solve_only = RankZeroOf(dp, table, rel, spg, chunks=chunks, records=False, info=info, chain_len=1, predictor=False, **mkw)
                     solve = ms(solve_only.step, device, reps)
                     sent = pipe.exchange_bytes_per_rank if world > 1 else 0
                     # every peer over its own link at once: one copy of this rank's shard per link
                     exchange = (sent / (LINK_GBS * 1e9) * 1e3 + chunks * CALL_US * 1e-3) if world > 1 else 0.0
                     step = simulate(chunks, solve / chunks, exchange / chunks, max(compute - solve, 0.0) / chunks if records else 0.0)
-                    rows.append({"world": world, "records": records, "info": info, "chunks": chunks, "auto": auto,
+                    rows.append({"world": world, "records": "metrics" if metric_mode else records, "info": info, "chunks": chunks, "auto": auto,
                                  "solve_ms": round(solve, 4), "compute_side_ms": round(compute, 4),
                                  "bytes_sent_per_link": sent, "exchange_model_ms": round(exchange, 4),
                                  "predicted_step_ms": round(step, 4), "predicted_solves_per_s": n_total / step * 1e3,
