@@ -59,13 +59,14 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
 def test_two_rank_c5_pipeline_rehearsal_on_one_gpu():
     """BASELINE config 5's N = 2 step on a one-GPU box (both ranks on cuda:0, gloo in place of RCCL): geometry-major shards
     cut into chunks, every chunk's solve writing coordinates and info records into their final place, the grouped
-    point-to-point exchange, the expand of the pieces on a third stream - and the same with coordinates only."""
+    point-to-point exchange, the expand of the pieces on a third stream - the same with coordinates only, and the
+    evaluated ensemble (every rank evaluates its shard, metric columns travel)."""
     if not gpu_available():
         pytest.skip("no GPU")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(key, None)
-    for extra in ([], ["--c5-gather", "free", "--c5-chunks", "5"]):
+    for extra in ([], ["--c5-gather", "free", "--c5-chunks", "5"], ["--c5-gather", "metrics"]):
         proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--config", "c5", "--gpus", "2", "--rehearse-on-one-gpu",
                                "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"] + extra, env=env,
                               capture_output=True, text=True, timeout=900)
@@ -73,6 +74,10 @@ def test_two_rank_c5_pipeline_rehearsal_on_one_gpu():
         line = [json.loads(l) for l in proc.stdout.splitlines() if l.startswith("{")][-1]
         assert line["n_gpus"] == 2 and line["config"]["all_converged"] and line["scaling"] == "strong"
         assert line["config"]["problems_per_gpu"] == 2048 * 256
+        if "metrics" in extra:  # the evaluated ensemble: four metric columns and the status byte per state
+            assert line["exchange"]["chunks"] == 2 and line["exchange"]["bytes_sent_per_rank_per_step"] == 2048 * 256 * (4 * 8 + 1)
+            assert "evaluated" in line["metric"] and line["roofline"]["kernel"] == "okx_lane_evsolve_g"
+            continue
         assert line["exchange"]["chunks"] == (5 if extra else 8)
         assert line["exchange"]["bytes_sent_per_rank_per_step"] == 2048 * 256 * (6 * 24 + 1)   # coordinates + one status byte
         assert line["solve_only"]["value"] > 0.0 and line["value"] > 0.0
