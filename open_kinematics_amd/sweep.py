@@ -112,6 +112,27 @@ def _driver_ratio(response_rate, driver_rate, candidates, column: str = ""):
     it).  Two candidates of equal strength (within ``EPS_GEOMETRIC``) are the reference's "Ambiguous derivative driver"
     ``ValueError`` (``derivatives.py:296-305``).
     """
+    import numpy as np
+
+    if isinstance(response_rate, np.ndarray):  # host arrays (a sweep's rows: a handful of values - no launches for them)
+        b = response_rate.shape[0]
+        if not candidates or driver_rate is None:
+            return np.full((b,), np.nan)
+        rates = driver_rate[:, candidates]                               # [B, C]
+        strength = np.abs(rates)
+        pick = strength.argmax(axis=1)[:, None]
+        rate = np.take_along_axis(rates, pick, axis=1)[:, 0]
+        if len(candidates) > 1:
+            best = np.take_along_axis(strength, pick, axis=1)
+            tied = (np.abs(best - strength) <= EPS_GEOMETRIC) & (strength >= EPS_GEOMETRIC)
+            if bool((tied.sum(axis=1) > 1).any()):
+                raise ValueError(f"Ambiguous derivative driver for column '{column}': "
+                                 "multiple matching tangents have equal strength")
+        resp = np.take_along_axis(response_rate[:, candidates], pick, axis=1)[:, 0]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out = resp / rate
+        return np.where(np.abs(rate) >= EPS_GEOMETRIC, out, np.nan)
+
     import torch
 
     b = response_rate.shape[0]
@@ -149,22 +170,29 @@ def _corner_rows(corner, program, positions, tangents, side=None, rotation=None,
     rack_point = corner.rack_attachment_point()
     rack_idx = out_keys.index(key(rack_point)) if rack_point is not None else -1
     if evaluated is not None:
-        values = evaluated.metrics.cpu().numpy()
-        derivatives, wc_rates = evaluated.derivatives, evaluated.wheel_center_rates
-        rack_rates = evaluated.rack_rates if rack_point is not None else None
+        from ._abi import EVAL_RATE_RACK_Y, EVAL_RATE_WHEEL_CENTER_X
+
+        block = evaluated.eval.cpu().numpy()   # [B, 1 + T, 24]: ONE copy, the ratios below are host arithmetic
+        values = block[:, 0, : len(METRIC_NAMES)]
+        derivatives = block[:, 1:, : len(METRIC_NAMES)]
+        wc_rates = block[:, 1:, EVAL_RATE_WHEEL_CENTER_X : EVAL_RATE_WHEEL_CENTER_X + 3]
+        rack_rates = block[:, 1:, EVAL_RATE_RACK_Y] if rack_point is not None else None
         have_rates = True
     else:
         roles = corner_roles(corner, program, side)
         res = corner_state_metrics(roles, positions, tangents)
         values = res.values.cpu().numpy()
         have_rates = tangents is not None
-        derivatives = res.derivatives
-        wc_rates = tangents[:, :, out_keys.index(key(PointID.WHEEL_CENTER)), :] if have_rates else None
-        rack_rates = tangents[:, :, rack_idx, 1] if have_rates and rack_point is not None else None
+        derivatives = res.derivatives.cpu().numpy() if have_rates else None
+        wc_rates = tangents[:, :, out_keys.index(key(PointID.WHEEL_CENTER)), :].cpu().numpy() if have_rates else None
+        rack_rates = tangents[:, :, rack_idx, 1].cpu().numpy() if have_rates and rack_point is not None else None
     columns: "OrderedDict[str, Any]" = OrderedDict((n, values[:, METRIC_NAMES.index(n)]) for n in CATALOG_ORDER)
     rot_names, rot_values, rot_derivs = rotation if rotation is not None else ([], None, None)
-    for k, name in enumerate(rot_names):
-        columns[name] = rot_values[:, k].cpu().numpy()
+    if rot_names:
+        rot_host = rot_values.cpu().numpy()
+        for k, name in enumerate(rot_names):
+            columns[name] = rot_host[:, k]
+        rot_derivs = rot_derivs.cpu().numpy() if have_rates and rot_derivs is not None else rot_derivs
     if have_rates:
         tgt_keys = [program.point_keys[p] for p in program.tgt_point]
         hub = [t for t, k in enumerate(tgt_keys) if k == key(PointID.WHEEL_CENTER)]
@@ -180,7 +208,7 @@ def _corner_rows(corner, program, positions, tangents, side=None, rotation=None,
         def add(response: str, driver: str, rate):
             driver_rate, cand = drivers[driver]
             column = f"deriv_{response}_wrt_{driver}"
-            columns[column] = _driver_ratio(rate, driver_rate, cand, column).cpu().numpy()
+            columns[column] = _driver_ratio(rate, driver_rate, cand, column)
 
         for response, driver in _CORNER_DERIVATIVES:
             if driver == "rack_displacement" and rack_point is None:
@@ -196,8 +224,22 @@ def _corner_rows(corner, program, positions, tangents, side=None, rotation=None,
         for k, name in enumerate(rot_names):
             if name != "rocker_angle":
                 add(name, "hub_z", rot_derivs[:, :, k])
-    n = values.shape[0]
-    return [OrderedDict((name, _none_if_nan(col[s])) for name, col in columns.items()) for s in range(n)]
+    return _rows_from_columns(columns)
+
+
+def _rows_from_columns(columns) -> list:
+    """``{name: values [n]}`` -> one OrderedDict per state, NaN read as None (the reference's "not defined here")."""
+    from collections import OrderedDict
+
+    import numpy as np
+
+    names = list(columns)
+    if not names:
+        return []
+    table = np.stack([np.asarray(columns[name], dtype=np.float64) for name in names], axis=1)   # [n, columns]
+    cells = table.astype(object)
+    cells[np.isnan(table)] = None
+    return [OrderedDict(zip(names, row)) for row in cells.tolist()]
 
 
 def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> SweepMetricsResult:
@@ -273,6 +315,9 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
     from .enums import PointID, PointRef
     from .metrics import axle_hardware_metrics
 
+    hub_rates = {side: tangents[:, :, out_keys.index(PointRef(side, PointID.WHEEL_CENTER)), 2].cpu().numpy()
+                 for side in (Side.LEFT, Side.RIGHT)} if tangents is not None else {}
+
     def hub_z_columns(response: str, rate) -> dict:
         """``deriv_<response>_wrt_hub_z_<side>`` per side from the response's rate along every target's tangent."""
         columns = OrderedDict()
@@ -280,7 +325,7 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
             key = PointRef(side, PointID.WHEEL_CENTER)
             cand = [t for t, k in enumerate(tgt_keys) if k == key]
             column = f"deriv_{response}_wrt_hub_z_{side.name.lower()}"
-            columns[column] = _driver_ratio(rate, tangents[:, :, out_keys.index(key), 2], cand, column).cpu().numpy()
+            columns[column] = _driver_ratio(rate.cpu().numpy(), hub_rates[side], cand, column)
         return columns
 
     # the shared hardware's state metrics, then its derivative columns: anti-roll bar first, heave link second
