@@ -76,6 +76,11 @@ def measure(which: str, device, reps: int, only: str = "") -> dict:
                 "roofline": {"kernel_ms": rows[only]},  # (the field tools/save_profile.py reads)
                 "algorithmic_bytes_per_state": 8 * T + 8 * 24 * (1 + T) + 16}
     solve = dp.plan(targets, out=out, info_out=info, **skw)
+    if only == "evaluate_given_states":  # okx_evaluate_batch alone (its lane form on a batch that fills the chip)
+        solve()
+        rows[only] = ev_ms(lambda: dp.evaluate(out, eval_out=evb, **kw), device, reps)
+        return {"workload": which, "states": n, "ms": rows, "states_per_s": {k: n / v * 1e3 for k, v in rows.items()},
+                "roofline": {"kernel_ms": rows[only]}, "algorithmic_bytes_per_state": 24 * program.n_out + 8 * 24 * (1 + T)}
     rows["solve_records"] = ev_ms(solve, device, reps)
     rows["solve_output_none"] = ev_ms(dp.plan(targets, info_out=info, output="none", **skw), device, reps)
     solve()
