@@ -203,3 +203,51 @@ def test_bench_helpers():
     assert bench.algorithmic_bytes_per_solve(SimpleNamespace(n_targets=3, n_out=38)) == 952.0
     assert bench.algorithmic_bytes_per_solve(SimpleNamespace(n_targets=2, n_out=14)) == 368.0
     assert bench.committed_traffic("no_such_tag") == (None, None)
+
+
+def test_host_thread_pool_is_fitted_to_a_cgroup_quota(monkeypatch, tmp_path):
+    """hostcpu.fit_host_threads: torch's intra-op pool is cut to the cgroup's CPU quota (shared between the ranks of a
+    node), never raised, left alone without a binding quota or with OKX_KEEP_HOST_THREADS=1; the first call decides."""
+    import builtins
+
+    import torch
+
+    from open_kinematics_amd import hostcpu
+
+    real_open = builtins.open
+    quota = {"text": "400000 100000"}
+
+    def fake_open(path, *a, **kw):
+        if path == "/sys/fs/cgroup/cpu.max":
+            fake = tmp_path / "cpu.max"
+            fake.write_text(quota["text"])
+            return real_open(fake, *a, **kw)
+        return real_open(path, *a, **kw)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    monkeypatch.setattr(hostcpu.os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    assert hostcpu.host_cores() == (4, "cgroup CPU quota of 4 inside an affinity mask of 64")
+    quota["text"] = "max 100000"
+    assert hostcpu.host_cores() == (64, "affinity mask of 64")
+    quota["text"] = "1600000 100000"
+    before = torch.get_num_threads()
+    calls = []
+    monkeypatch.setattr(torch, "get_num_threads", lambda: 128)
+    monkeypatch.setattr(torch, "set_num_threads", calls.append)
+    try:
+        monkeypatch.setattr(hostcpu, "_fitted", None)
+        monkeypatch.setenv("OKX_KEEP_HOST_THREADS", "1")
+        assert hostcpu.fit_host_threads()["changed"] is False and calls == []
+        monkeypatch.delenv("OKX_KEEP_HOST_THREADS")
+        monkeypatch.setattr(hostcpu, "_fitted", None)
+        did = hostcpu.fit_host_threads()
+        assert did["changed"] and did["host_cores"] == 16 and calls == [14]       # the quota minus two
+        assert hostcpu.fit_host_threads(processes=8) is did and calls == [14]     # the first call decides
+        monkeypatch.setattr(hostcpu, "_fitted", None)
+        assert hostcpu.fit_host_threads(processes=4)["changed"] and calls[-1] == 2   # four ranks share the quota
+        monkeypatch.setattr(hostcpu, "_fitted", None)
+        quota["text"] = "max 100000"
+        assert hostcpu.fit_host_threads()["changed"] is False                      # an affinity mask alone sized the pool already
+    finally:
+        monkeypatch.setattr(hostcpu, "_fitted", None)
+    assert torch.get_num_threads() in (before, 128)
