@@ -288,3 +288,35 @@ def test_evaluated_ensemble_gathers_metric_columns(golden, monkeypatch):
     assert pipe.exchange_bytes_per_rank == (hi - lo) * s * (4 * 8 + 1)
     with pytest.raises(ValueError, match="no evaluation entry"):
         okd.ShardedEnsemble(dp, table, rel, s, metric_columns=[("camber", 5)])
+
+
+@pytest.mark.parametrize("kernel", ["quad", "lane"])
+def test_evaluated_solve_beyond_the_reach_flags_what_the_separate_launches_flag(golden, kernel):
+    """Targets walked past lock-out (the reference's "did not reach an acceptable residual"): the solve's flags and
+    positions stay those of the plain solve, and the tangent solve's health - ok / rank-deficient, NaN rows where the
+    factorisation fails - is what okx_tangent_batch reports at the same states."""
+    dp, program, roles, ridx, mg = _evaluated_program(golden, "c1_dw_corner")
+    arrays, _ = golden("c1_dw_corner")
+    base = arrays["targets_abs"][len(arrays["targets_abs"]) // 2]
+    t = np.repeat(base[None], 192, axis=0)
+    t[:, -1] += np.linspace(-400.0, 400.0, 192)      # far past either end of the bump travel
+    kw = dict(kernel=kernel, chain_len=1)
+    plain = dp.solve(t, **kw)
+    fused = dp.solve_evaluated(t, tangents=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.positions, fused.positions) and torch.equal(plain.info_raw, fused.info_raw)
+    info = fused.info()
+    assert np.any((info["flags"] & 7) != 1) and np.any((info["flags"] & 7) == 1)    # both kinds of state are in the batch
+    tan, tinfo = dp.tangents(plain.positions)
+    torch.cuda.synchronize()
+    ti, fi = dp.tangent_info(tinfo), fused.tangent_info()
+    agree = ti["flags"] == fi["flags"]
+    # (a pivot test at the rounding floor may fall either way between two orders of summation: allow it on states the solve flagged)
+    assert np.all(agree | ((info["flags"] & 7) != 1)), np.flatnonzero(~agree)
+    good = (ti["flags"] == 1) & (fi["flags"] == 1) & ((info["flags"] & 7) == 1)
+    assert good.sum() >= 20
+    a, b = fused.tangents.cpu().numpy()[good], tan.cpu().numpy()[good]
+    assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) <= 1e-7
+    failed = (fi["flags"] & 1) == 0
+    if failed.any():  # a failed factorisation reads NaN in every derivative, never a number
+        assert np.all(np.isnan(fused.derivatives.cpu().numpy()[failed]))
