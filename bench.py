@@ -708,6 +708,8 @@ def measure_downstream(dp, suspension_yaml: str, positions, device, reps: int = 
                 8 * T + 8 * 24 * (1 + T) + 16)
             three = solve_ms + rows["tangents"]["ms"] + rows["corner_metrics_with_derivatives"]["ms"]
             rows["evaluated_three_launches"] = {"ms": three, "states_per_s": n_big / three * 1e3}
+            # okx_evaluate_batch: tangents + metrics + derivative columns of GIVEN states in one launch (its lane form here)
+            row("evaluate_given_states", ev(lambda: dp.evaluate(out, eval_out=evb)), 24 * n_out + 8 * 24 * (1 + T))
             rows["evaluated_one_launch"]["speedup_over_three_launches"] = three / rows["evaluated_one_launch"]["ms"]
         except Exception as exc:  # noqa: BLE001
             rows["evaluated_one_launch"] = {"error": f"{type(exc).__name__}: {exc}"}
