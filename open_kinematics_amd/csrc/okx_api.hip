@@ -96,6 +96,7 @@ struct okx_program {
   hipFunction_t lane_chain_u, lane_chain_g;          // chains
   hipFunction_t lane_compact[4];                     // the same four with compact outputs (solve_u, solve_g, chain_u, chain_g)
   hipFunction_t lane_nest[4];                        // nested start mode: u, g, u compact, g compact (null: none)
+  hipFunction_t lane_refine[8] = {};                 // coarse-to-fine start (developer switch lane_refine): coarse u, g, u compact, g compact; warm likewise
   int lane_nest_scratch;
   long long lane_min_problems;
   int lane_cold_scratch, lane_chain_scratch;  // private-segment bytes of the two bodies (code object metadata)
@@ -523,6 +524,19 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
     }
   if (p->lane_nest_scratch < 0 || p->lane_nest_scratch > (okx::dev_switch("lane_timeline") ? 1 << 20 : 256) || !p->lane_nest[0] || !p->lane_nest[1] || !p->lane_nest[2] || !p->lane_nest[3])
     p->lane_nest[0] = p->lane_nest[1] = p->lane_nest[2] = p->lane_nest[3] = nullptr;
+  {  // coarse-to-fine start: present only in modules generated with the developer switch
+    static const char* const kRefine[8] = {"okx_lane_refc_u", "okx_lane_refc_g", "okx_lane_refc_u_c", "okx_lane_refc_g_c",
+                                           "okx_lane_refw_u", "okx_lane_refw_g", "okx_lane_refw_u_c", "okx_lane_refw_g_c"};
+    bool all = true;
+    for (int k = 0; k < 8; ++k)
+      if (hipModuleGetFunction(&p->lane_refine[k], mod, kRefine[k]) != hipSuccess) {
+        (void)hipGetLastError();
+        all = false;
+      }
+    const int refine_scratch = all ? okx::quad_code_scratch_bytes(code, "okx_lane_ref") : -1;
+    if (!all || refine_scratch < 0 || refine_scratch > 512)
+      for (int k = 0; k < 8; ++k) p->lane_refine[k] = nullptr;
+  }
   p->lane_mod = mod;
   std::atomic_thread_fence(std::memory_order_release);
   p->lane_fn_u = lane_u;  // the gate of the lane kernel's launch path, published last
@@ -1001,6 +1015,13 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
     const long long span0 = spg > 0 ? spg : n_problems;
     lane_nested = span0 >= 256 && (span0 % 256 == 0 || span0 >= 2048);
   }
+  bool lane_refined = false;    // ... or to the coarse-to-fine start (okx_lane_refc_* / okx_lane_refw_*)
+  if (use_lane && !lane_nested && (opts->kernel == 0 || opts->kernel == 4) && opts->chain_len == -1 && p->lane_refine[0] && !evaluated &&
+      opts->output != OKX_OUTPUT_NONE && opts->grad_tol <= 0.0) {
+    // every fourth step cold, the steps between from the cubic interpolant of those: spans of at least 64 coarse steps
+    const long long span0 = spg > 0 ? spg : n_problems;
+    lane_refined = span0 >= 256 && span0 % 4 == 0;
+  }
   if (use_lane && opts->kernel == 0 && !lane_nested) {
     const long long span0 = spg > 0 ? spg : n_problems;
     long long len0 = opts->chain_len;
@@ -1052,7 +1073,7 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
         len = (span + per_span - 1) / per_span;
       }
     }
-    if (lane_auto_cold) len = 1;
+    if (lane_auto_cold || (lane_refined && use_lane)) len = 1;
     if (lane_nested) len = okx::kLaneNestSteps;
     if (len < 1) len = 1;
     if (len > span) len = span;
@@ -1174,6 +1195,18 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
         // allocated and freed in stream order (legal under stream capture, no device-wide synchronisation)
         HIP_TRY(hipMallocAsync(&ring, sizeof(double) * (size_t)okx::lane_flat_chain_doubles(p->host.n) * (size_t)lane_grid, (hipStream_t)stream));
         q.predictor = static_cast<const double*>(ring);
+      }
+      if (lane_refined && a.chain_len == 1) {
+        // four launches on the stream: the coarse steps (offset 0), then offsets 1, 2, 3 from their interpolant
+        const int variant = (opts->output != OKX_OUTPUT_RECORDS ? 2 : 0) + (d_geom_pos ? 1 : 0);
+        for (int off = 0; off < 4; ++off) {
+          q.chain_len = off;  // (the strided bodies read their offset here)
+          const long long per_span = (span_ - off + 3) / 4;
+          const long long units4 = (n_problems / span_) * ((per_span + 63) / 64);
+          const int grid4 = (int)(units4 < lane_cap ? (units4 < 1 ? 1 : units4) : lane_cap);
+          HIP_TRY(hipModuleLaunchKernel(p->lane_refine[(off ? 4 : 0) + variant], grid4, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));
+        }
+        return OKX_OK;
       }
       qe.q = q;
       HIP_TRY(hipModuleLaunchKernel(fn, lane_grid, 1, 1, okx::kWave, 1, 1, 0, (hipStream_t)stream, kargs, nullptr));

@@ -1566,6 +1566,12 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   // (first-step table); steps 2, 1 and 3 start ~1e-8 mm from their solutions instead of a secant's ~1e-4: one full pass
   // and one confirming evaluation.  What a chain carries beside the point - the damping it ended with, the contraction
   // constant it observed - comes from the lane's own step 0.
+  // Coarse-to-fine start (developer switch lane_refine; okx_api.hip solve_impl): two more instantiations of the
+  // independent-solve bodies with a compile-time STRIDE - SUB = 4: lane l of a wave unit solves step 4 l + offset of its
+  // span (offset = a.chain_len, 0 .. 3) - one as it is (the coarse launch: every fourth step, cold from the first-step
+  // table) and one WARM: the start is the cubic Lagrange interpolant, in the step index, of the four nearest coarse steps,
+  // read from the OUTPUT buffer the coarse launch wrote; no first-step table, the first pass evaluates the guess.
+  const bool refine = !EV && dev_switch("lane_refine");
   auto body = [&](bool ch, bool fl, bool gb, bool ns = false) -> bool {
     LGen& evc = gb ? evg : evc_;
     const PassSrc& pass_cold = gb ? pass_g : pass_cold_;
@@ -1625,8 +1631,11 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("#define GL(o) gl[(o) + kz]");
     // (evaluated module: GIVEN = the wave unit's states are read from records - a.targets points at them - instead of solved;
     //  the body is then its final state and the epilogue: okx_evaluate_batch's lane form)
-    g.f("template <bool PG, bool FULL%s> DEV void okx_lane_body_%s(const QArgs& a%s) {", EV ? ", bool GIVEN" : "", ns ? (gb ? "nestg" : "nest") : ch || fl ? "chain" : gb ? "coldg" : "cold", EV ? ", const QEvArgs& ea" : "");
+    const bool sub_body = refine && !ch && !fl;  // (the independent-solve bodies carry the stride / warm-start parameters)
+    g.f("template <bool PG, bool FULL%s> DEV void okx_lane_body_%s(const QArgs& a%s) {", EV ? ", bool GIVEN" : sub_body ? ", int SUB, bool WARM" : "",
+        ns ? (gb ? "nestg" : "nest") : ch || fl ? "chain" : gb ? "coldg" : "cold", EV ? ", const QEvArgs& ea" : "");
     if (!EV) g.f("  constexpr bool GIVEN = false;");
+    if (!sub_body) g.f("  constexpr int SUB = 1; constexpr bool WARM = false;");
     g.f("  const int lane = threadIdx.x;");
     g.f("  __shared__ double lds[%d];", lds_doubles);
     if (sc) g.f("  int kzs = 0;  // an opaque zero in a scalar register: a table read inside a pass is a load of that pass, not a loop invariant");
@@ -1642,7 +1651,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("  const long long chains_per_span = (span + unit_len - 1) / unit_len;");
     } else {
       g.f("  const long long unit_len = 1;");
-      g.f("  const long long chains_per_span = span;");
+      g.f("  const long long sub_off = SUB == 1 ? 0 : a.chain_len;  // (strided bodies: the offset rides in the unused chain length)");
+      g.f("  const long long chains_per_span = SUB == 1 ? span : (span - sub_off + SUB - 1) / SUB;");
     }
     g.f("  const long long waves_per_span = (chains_per_span + 63) / 64;");
     g.f("  const long long n_wave_units = n_spans * waves_per_span;");
@@ -1667,7 +1677,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("  const long long wu_lo = PG ? blockIdx.x * wu_per_wave : blockIdx.x, wu_step = PG ? 1 : gridDim.x;");
       g.f("  const long long wu_hi = PG ? (wu_lo + wu_per_wave < n_wave_units ? wu_lo + wu_per_wave : n_wave_units) : n_wave_units;");
       if (gb) {
-        g.f("  const bool with_head = !GIVEN && a.head != nullptr && a.grad_tol <= 0.0;");
+        g.f("  const bool with_head = !GIVEN && !WARM && a.head != nullptr && a.grad_tol <= 0.0;");
         g.f("  long long staged_span = -1;");
       }
       {  // (own geometry: round k gives wavefront w the unit k G + (w + 131 k) mod G, see okx_quadgen.cpp; C4 cold +1.3 %)
@@ -1688,6 +1698,8 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("    long long chain_in_span = wave_in_span * 64 + lane;");
     g.f("    const bool have = chain_in_span < chains_per_span;");
     g.f("    if (!have) chain_in_span = chains_per_span - 1;");
+    if (!ch && !fl) g.f("    const long long first_b = span_idx * span + (SUB == 1 ? chain_in_span : chain_in_span * SUB + sub_off);");
+    else
     g.f("    const long long first_b = span_idx * span + chain_in_span * unit_len;");
     if (ch || fl) g.f("    const long long last_b = first_b + unit_len < (span_idx + 1) * span ? first_b + unit_len : (span_idx + 1) * span;");
     g.f("    const double* gp = PG ? a.geom_pos + span_idx * %d : a.design_pos;", 3 * NP);
@@ -1704,7 +1716,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     if (sc) {
       g.f("    const okx_cptr gpc = (okx_cptr)gp, gqc = (okx_cptr)gq, rpc = (okx_cptr)a.row_param, dpc = (okx_cptr)a.dop_param;");
       g.f("    (void)gqc; (void)rpc; (void)dpc;");
-      g.f("    const bool with_head = !GIVEN && a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
+      g.f("    const bool with_head = !GIVEN && !WARM && a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
       g.f("    WAVE_SYNC();  // (the previous wave unit's last LDS reads are done)");
     } else {
     g.f("    // the geometry's tables (and its first-step table) into LDS, lane k fetching entry k");
@@ -1731,7 +1743,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     } else
     stage_tables(g, "    ");
     if (!gb) {
-    g.f("    const bool with_head = !GIVEN && a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
+    g.f("    const bool with_head = !GIVEN && !WARM && a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
     g.f("    if (with_head) {");
     g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
     g.f("      for (int k = lane; k < %d; k += 64) lds[%d + k] = hp[k];", head_stride, head_l0);
@@ -1767,6 +1779,27 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       } else {
         g.f("    static_assert(!GIVEN, \"a free point is not among the output points\");");
       }
+    }
+    if (sub_body) {
+      // warm start: cubic Lagrange through the four nearest coarse steps (steps 4 m of this span, already in the output
+      // buffer), the stencil shifted inwards at the ends of the span; loads unconditional, from clamped node indices
+      std::vector<int> oi(NP, -1);
+      for (int k = 0; k < P.n_out; ++k) oi[P.out_point[k]] = k;
+      g.f("    if (WARM) {");
+      g.f("      const long long n_nodes = (span + SUB - 1) / SUB;");
+      g.f("      long long nb0 = chain_in_span - 1; if (nb0 > n_nodes - 4) nb0 = n_nodes - 4; if (nb0 < 0) nb0 = 0;");
+      g.f("      const double wu_ = (double)(chain_in_span - nb0) + (double)sub_off * %.17g;", 0.25);
+      g.f("      const double lw0 = -(wu_ - 1.0) * (wu_ - 2.0) * (wu_ - 3.0) * %.17g, lw1 = wu_ * (wu_ - 2.0) * (wu_ - 3.0) * 0.5;", 1.0 / 6.0);
+      g.f("      const double lw2 = -wu_ * (wu_ - 1.0) * (wu_ - 3.0) * 0.5, lw3 = wu_ * (wu_ - 1.0) * (wu_ - 2.0) * %.17g;", 1.0 / 6.0);
+      g.f("      const int wrec = FULL ? %d : %d;", 3 * P.n_out, n);
+      g.f("      const double* nd0 = a.out_pos + (span_idx * span + nb0 * SUB) * wrec;");
+      g.f("      const double* nd1 = nd0 + SUB * wrec; const double* nd2 = nd1 + SUB * wrec; const double* nd3 = nd2 + SUB * wrec;");
+      for (int i = 0; i < n; ++i) {
+        const int full_idx = oi[ev.fp(i / 3)] >= 0 ? 3 * oi[ev.fp(i / 3)] + i % 3 : 0;
+        const int free_idx = 3 * ev.perm[i / 3] + i % 3;
+        g.f("      { const int wi = FULL ? %d : %d; x%d = fma(lw0, nd0[wi], fma(lw1, nd1[wi], fma(lw2, nd2[wi], lw3 * nd3[wi]))); }", full_idx, free_idx, i);
+      }
+      g.f("    }");
     }
     stamp(16);
     // the design state is a solved state of its own design targets: it seeds the chain's history
@@ -2240,6 +2273,22 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      }");
       g.f("      WAVE_SYNC();");
       stamp(17);
+      if (sub_body) {
+        // strided bodies: the wave unit's records lie SUB problems apart - lane = column of a record, pointer bumps
+        g.f("      if (SUB != 1) {");
+        g.f("        const int per = 64 / rec > 0 ? 64 / rec : 1;");
+        g.f("        const int sub = lane / rec, col = lane - sub * rec;");
+        g.f("        const long long sb = span_idx * span + wave_in_span * 64 * SUB + sub_off, sl_ = (span_idx + 1) * span;");
+        g.f("        const long long n_rows = (sl_ - sb + SUB - 1) / SUB;");
+        g.f("        const int rows = (int)(n_rows < 64 ? (n_rows > 0 ? n_rows : 0) : 64);");
+        g.f("        double* op = a.out_pos + (sb + (long long)sub * SUB) * rec + col;");
+        g.f("        const double* ip = lds + sub * rec + col;");
+        g.f("        if (sub < per) {");
+        g.f("          _Pragma(\"unroll 8\")");
+        g.f("          for (int r = sub; r < rows; r += per) { *op = *ip; op += (long long)per * SUB * rec; ip += per * rec; }");
+        g.f("        }");
+        g.f("      } else {");
+      }
       g.f("      const long long base_b = span_idx * span + wave_in_span * 64;");
       g.f("      const long long rem = (span_idx + 1) * span - base_b;");
       g.f("      const int n_doubles = (int)(rem < 64 ? rem : 64) * rec;");
@@ -2254,6 +2303,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("      } else {");
       g.f("        for (int i = lane; i < n_doubles; i += 64) dst[i] = lds[i];");
       g.f("      }");
+      if (sub_body) g.f("      }");
       g.f("      WAVE_SYNC();");
       g.f("      }");
       stamp(15);
@@ -2503,8 +2553,15 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
   for (const char* body : {"solve", "chain"})
     for (const char* geo : {"u", "g"})
       for (const char* out : {"", "_c"})   // _c: compact outputs (free coordinates or nothing)
-        g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_%s_%s%s(QArgs a) { okx_lane_body_%s<%s, %s>(a); }", body, geo,
-            out, body[0] != 's' ? "chain" : (split_g && geo[0] == 'g') ? "coldg" : "cold", geo[0] == 'g' ? "true" : "false", out[0] ? "false" : "true");
+        g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_%s_%s%s(QArgs a) { okx_lane_body_%s<%s, %s%s>(a); }", body, geo,
+            out, body[0] != 's' ? "chain" : (split_g && geo[0] == 'g') ? "coldg" : "cold", geo[0] == 'g' ? "true" : "false", out[0] ? "false" : "true",
+            refine && body[0] == 's' ? ", 1, false" : "");
+  if (refine)
+    for (const char* kind : {"refc", "refw"})   // coarse launch (every fourth step, cold) / warm launches (the steps between)
+      for (const char* geo : {"u", "g"})
+        for (const char* out : {"", "_c"})
+          g.f("extern \"C\" __global__ void __launch_bounds__(64, 1) okx_lane_%s_%s%s(QArgs a) { okx_lane_body_%s<%s, %s, 4, %s>(a); }", kind, geo, out,
+              (split_g && geo[0] == 'g') ? "coldg" : "cold", geo[0] == 'g' ? "true" : "false", out[0] ? "false" : "true", kind[3] == 'w' ? "true" : "false");
   if (nested)
     for (const char* geo : {"u", "g"})
       for (const char* out : {"", "_c"})

@@ -53,6 +53,7 @@ GENERATOR_SWITCHES = [
     ("lane_timeline", "c1_dw_corner", "okx_lane_source", "+__builtin_readcyclecounter"),
     ("lane_lds_tables", "c1_dw_corner", "okx_lane_source", "-okx_cptr gpc"),
     ("lane_nested", "c1_dw_corner", "okx_lane_source", "+okx_lane_nest_u"),
+    ("lane_refine", "c1_dw_corner", "okx_lane_source", "+okx_lane_refw_u"),
 ]
 
 
