@@ -139,3 +139,58 @@ def test_c5_ensemble_4096_geometries_x_256_steps():
     alone = dp.solve(targets.reshape(4096, 256, -1)[1777].contiguous(), geom_pos=gpos[1777:1778].contiguous(),
                      geom_row_param=gparam[1777:1778].contiguous(), steps_per_geometry=256, chain_len=1).positions
     assert float((alone - res.positions.reshape(4096, 256, -1, 3)[1777]).abs().max()) <= 1e-9
+
+
+def test_c5_ensemble_evaluated_at_full_size():
+    """BASELINE config 5, every state EVALUATED in the solve's launch (okx_solve_evaluated_batch) - size-independent
+    properties of the 1 048 576 evaluation rows, the separate launches on a sample, and okx_evaluate_batch (lane form) on
+    the solved states against the fused rows."""
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.input import load_geometry
+    from open_kinematics_amd.metrics import METRIC_NAMES, corner_roles, corner_state_metrics
+    from open_kinematics_amd.workloads import ensemble_problem, geometry_path
+
+    program, table, rel = ensemble_problem(4096, 256)
+    dp = DeviceProgram(program, "cuda:0")
+    roles = corner_roles(load_geometry(geometry_path("geometry.yaml")), program)
+    dp.enable_evaluation(roles)
+    assert dp.evaluation == 3, dp.evaluation_note
+    gpos, gparam = dp.rebind(torch.as_tensor(table, device="cuda:0"))
+    targets = dp.ensemble_targets(gpos, rel)
+    kw = dict(geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=256)
+    plain = dp.solve(targets, chain_len=1, **kw)
+    fused = dp.solve_evaluated(targets, chain_len=1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.positions, fused.positions) and torch.equal(plain.info_raw, fused.info_raw)
+    info = fused.tangent_info()
+    assert np.all(info["flags"] == 1) and np.all(info["min_pivot"] > 0.0)
+    ev = fused.eval
+    bump = program.n_targets - 1
+    travel = ev[:, 0, METRIC_NAMES.index("wheel_travel")].reshape(4096, 256)
+    want = torch.as_tensor(rel[:, bump], device="cuda:0")[None].expand(4096, -1)
+    assert float((travel - want).abs().max()) <= 1e-8                    # the bump target IS the wheel centre's rise
+    # wheel travel = z - z0: its derivative along a target is the wheel centre's z rate, and along the bump target that is 1
+    d_travel = ev[:, 1:, METRIC_NAMES.index("wheel_travel")]
+    assert float((d_travel - ev[:, 1:, 21]).abs().max()) <= 1e-12
+    assert float((ev[:, 1 + bump, 21] - 1.0).abs().max()) <= 1e-9
+    assert float(ev[:, 1, 21].abs().max()) <= 1e-9                     # ... and the rack target does not lift the wheel centre
+    assert bool(torch.isfinite(ev[:, :, :8]).all())                      # angles, travel, track, scrub, trail: defined everywhere here
+    # the separate launches on four whole geometries
+    for g in (0, 1234, 2048, 4095):
+        rows = slice(g * 256, (g + 1) * 256)
+        gk = dict(geom_pos=gpos[g : g + 1], geom_row_param=gparam[g : g + 1], steps_per_geometry=256)
+        tan, _ = dp.tangents(plain.positions[rows], **gk)
+        sep = corner_state_metrics(roles, plain.positions[rows], tan)
+        cols = [k for k, n in enumerate(METRIC_NAMES) if n != "wheel_travel"]   # (that one is measured from the geometry's own design state)
+        a, b = ev[rows, 0][:, cols].cpu().numpy(), sep.values[:, cols].cpu().numpy()
+        both = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), both)   # (instant centres lie up to 1e4 mm away: the bound is relative there)
+        assert np.max(np.abs(a[both] - b[both]) / np.maximum(1.0, np.abs(b[both]))) <= 1e-9
+        da, db = ev[rows, 1:, :19].cpu().numpy(), sep.derivatives.cpu().numpy()
+        both = np.isfinite(db)
+        assert np.max(np.abs(da[both] - db[both]) / np.maximum(1.0, np.abs(db[both]))) <= 1e-7
+    # the same epilogue on the given states, lane form (a batch that fills the chip takes it by itself)
+    given = dp.evaluate(plain.positions, **kw)
+    torch.cuda.synchronize()
+    a, b = torch.nan_to_num(given.eval), torch.nan_to_num(ev)
+    assert float(((a - b).abs() / b.abs().clamp(min=1.0)).max()) <= 1e-9
