@@ -194,3 +194,53 @@ def test_c5_ensemble_evaluated_at_full_size():
     torch.cuda.synchronize()
     a, b = torch.nan_to_num(given.eval), torch.nan_to_num(ev)
     assert float(((a - b).abs() / b.abs().clamp(min=1.0)).max()) <= 1e-9
+
+
+@pytest.mark.parametrize("which", ["c4", "c2"])
+def test_own_geometry_configs_evaluated_at_full_size(which):
+    """BASELINE config 4 (MacPherson 512 x 512, lane kernels) and config 2 (one 16384-step sweep, quad cold body) with
+    every state evaluated in the solve's launch: positions bit for bit the plain solve's, the tangent solves healthy, the
+    wheel-travel identities, and a strided sample against the separate launches."""
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.input import load_geometry
+    from open_kinematics_amd.metrics import METRIC_NAMES, corner_roles, corner_state_metrics
+    from open_kinematics_amd.workloads import bump_sweep_problem, geometry_path, macpherson_grid_problem
+
+    if which == "c4":
+        program, targets = macpherson_grid_problem(512, 512)
+        yaml_name = "macpherson_geometry.yaml"
+    else:
+        program, targets = bump_sweep_problem(16384)
+        yaml_name = "geometry.yaml"
+    dp = DeviceProgram(program, "cuda:0")
+    roles = corner_roles(load_geometry(geometry_path(yaml_name)), program)
+    dp.enable_evaluation(roles)
+    t = torch.as_tensor(targets, device="cuda:0")
+    plain = dp.solve(t, chain_len=1, predictor=False)
+    fused = dp.solve_evaluated(t, chain_len=1, predictor=False)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.positions, fused.positions) and torch.equal(plain.info_raw, fused.info_raw)
+    assert np.all(fused.tangent_info()["flags"] == 1)
+    ev = fused.eval
+    bump = program.n_targets - 1
+    wc = list(program.out_point).index(int(program.tgt_point[bump]))
+    z0 = float(program.design_pos[program.tgt_point[bump]][2])
+    travel = ev[:, 0, METRIC_NAMES.index("wheel_travel")]
+    assert float((travel - (plain.positions[:, wc, 2] - z0)).abs().max()) <= 1e-12
+    assert float((travel - (t[:, bump] - z0)).abs().max()) <= 1e-8
+    assert float((ev[:, 1:, METRIC_NAMES.index("wheel_travel")] - ev[:, 1:, 21]).abs().max()) <= 1e-12
+    assert float((ev[:, 1 + bump, 21] - 1.0).abs().max()) <= 1e-9
+    pick = torch.arange(0, t.shape[0], 257 if which == "c4" else 31, device="cuda:0")
+    tan, _ = dp.tangents(plain.positions[pick].contiguous())
+    sep = corner_state_metrics(roles, plain.positions[pick].contiguous(), tan)
+    a, b = ev[pick, 0, :19].cpu().numpy(), sep.values.cpu().numpy()
+    both = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), both)
+    assert np.max(np.abs(a[both] - b[both]) / np.maximum(1.0, np.abs(b[both]))) <= 1e-9
+    da, db = ev[pick, 1:, :19].cpu().numpy(), sep.derivatives.cpu().numpy()
+    both = np.isfinite(db)
+    assert np.max(np.abs(da[both] - db[both]) / np.maximum(1.0, np.abs(db[both]))) <= 1e-7
+    given = dp.evaluate(plain.positions)   # (c4: the lane form; c2: 16384 states stay on the quad form)
+    torch.cuda.synchronize()
+    a, b = torch.nan_to_num(given.eval), torch.nan_to_num(ev)
+    assert float(((a - b).abs() / b.abs().clamp(min=1.0)).max()) <= 1e-9
