@@ -139,7 +139,10 @@ typedef struct okx_solve_opts {
                              0 = take the length from `chain` (0 -> 1, 1 -> whole sweep),
                              -1 = auto: one chain per resident wavefront.                  */
   double step_tol;        /* stop when max|dx| <= step_tol (mm, default 1e-11)             */
-  double grad_tol;        /* stop when max|J^T r| <= grad_tol (default 0: unused)          */
+  double grad_tol;        /* > 0: stop when max|J^T r| <= grad_tol.  < 0: MINPACK's gtol (what SolverConfig.gtol means,
+                             solver.py:158-169): stop when max_j |(J^T r)_j| / (|J_j| |r|) <= -grad_tol (lmder's gnorm:
+                             the cosine between the residual and the Jacobian's columns).  0 (default): unused.  A launch
+                             with a gradient stop runs the general bodies without the shared first step. */
   double ftol;            /* stop when an accepted step reduces the cost by <= ftol*cost,
                              actual and predicted (MINPACK's ftol test; default 1e-10):
                              terminates infeasible targets at their compromise point so

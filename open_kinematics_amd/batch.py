@@ -215,6 +215,7 @@ class DeviceProgram:
         step_tol: float | None = None,
         lambda0: float | None = None,
         ftol: float | None = None,
+        grad_tol: float | None = None,
         kernel: int | str | None = None,
         residual_tolerance: float | None = None,
         out: torch.Tensor | None = None,
@@ -275,6 +276,8 @@ class DeviceProgram:
             opts.lambda0 = float(lambda0)
         if ftol is not None:
             opts.ftol = float(ftol)
+        if grad_tol is not None:   # > 0: max |J^T r|; < 0: MINPACK's gtol, max_j |(J^T r)_j| / (|J_j| |r|) <= -grad_tol (okx.h)
+            opts.grad_tol = float(grad_tol)
         if kernel is not None:
             opts.kernel = {"auto": 0, "single": 1, "packed": 2, "quad": 3, "lane": 4}.get(kernel, kernel)
         if residual_tolerance is not None:

@@ -1017,7 +1017,7 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
   }
   bool lane_refined = false;    // ... or to the coarse-to-fine start (okx_lane_refc_* / okx_lane_refw_*)
   if (use_lane && !lane_nested && (opts->kernel == 0 || opts->kernel == 4) && opts->chain_len == -1 && p->lane_refine[0] && !evaluated &&
-      opts->output != OKX_OUTPUT_NONE && opts->grad_tol <= 0.0) {
+      opts->output != OKX_OUTPUT_NONE && opts->grad_tol == 0.0) {
     // every fourth step cold, the steps between from the cubic interpolant of those: spans of at least 64 coarse steps
     const long long span0 = spg > 0 ? spg : n_problems;
     lane_refined = span0 >= 256 && span0 % 4 == 0;
@@ -1121,7 +1121,7 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
     q.predictor_len = p->predictor_len;
     q.head = nullptr;
     q.out_mode = opts->output;
-    if (p->quad_fn_head_u && opts->shared_first_step != 0 && opts->grad_tol <= 0.0 && p->host.n_targets > 0) {
+    if (p->quad_fn_head_u && opts->shared_first_step != 0 && opts->grad_tol == 0.0 && p->host.n_targets > 0) {
       // Shared first step: the design state's Jacobian, J^T J and damped factorisation are common to every problem
       // of a geometry, so they are evaluated once per geometry (one quad each) instead of once per chain head.
       okx::QuadHeadArgs h;
@@ -1222,7 +1222,7 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
     // (not for programs with the reference's zero-gradient line row: their solves reject steps as a matter of course,
     //  which the cold body answers by starting over in its general loop - measured 4 % slower than the general body)
     if (p->quad_fn_cold_u && !degenerate_line && !d_geom_pos && a.chain_len == 1 && q.head != nullptr && q.predictor == nullptr && (q.trace == nullptr || okx::dev_switch("quad_timeline")) &&
-        opts->grad_tol <= 0.0 && !okx::dev_switch("no_cold"))
+        opts->grad_tol == 0.0 && !okx::dev_switch("no_cold"))
       fn = p->quad_fn_cold_u;
     if (evaluated) fn = fn == p->quad_fn_cold_u && p->ev_cold_u ? p->ev_cold_u : d_geom_pos ? p->ev_solve_g : p->ev_solve_u;
     qe.q = q;

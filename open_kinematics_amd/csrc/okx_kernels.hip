@@ -1106,7 +1106,14 @@ __global__ void __launch_bounds__(GroupWidth<NREG>::value, NREG <= 24 ? OKX_WAVE
               lambda *= rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t);
             }
             nu = 2.0;
-            if (args.grad_tol > 0.0 && grp_max<W>(S.red, lane < n ? fabs(g) : 0.0) <= args.grad_tol) {
+            // gradient stop: > 0 the absolute form, < 0 MINPACK's scaled form max_j |(J^T r)_j| / (|J_j| |r|) (lmder's gnorm)
+            double gmeasure = 0.0;
+            if (args.grad_tol > 0.0) gmeasure = lane < n ? fabs(g) : 0.0;
+            else if (args.grad_tol < 0.0) {
+              const double cn = lane < n ? S.dA[lane] * 2.0 * F : 0.0;
+              gmeasure = cn > 0.0 ? fabs(g) / sqrt(cn) : 0.0;
+            }
+            if (args.grad_tol != 0.0 && grp_max<W>(S.red, gmeasure) <= fabs(args.grad_tol)) {
               flags |= OKX_INFO_CONVERGED;
               stop = true;
             }

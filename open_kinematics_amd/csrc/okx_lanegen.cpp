@@ -1663,7 +1663,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("  const long long wu_lo = blockIdx.x * wu_per_wave, wu_hi = wu_lo + wu_per_wave < n_wave_units ? wu_lo + wu_per_wave : n_wave_units;");
       g.f("  double* const ring = const_cast<double*>(a.predictor) + (long long)blockIdx.x * %lld + lane;  // [entry][slot][lane]", ns ? lane_nest_doubles(n) : lane_flat_chain_doubles(n));
       g.f("  long long staged_span = -1;");
-      if (gb) g.f("  const bool with_head_all = a.head != nullptr && a.grad_tol <= 0.0;");
+      if (gb) g.f("  const bool with_head_all = a.head != nullptr && a.grad_tol == 0.0;");
       g.f("  for (long long it = wu_lo * unit_len; it < wu_hi * unit_len; ++it) {");
       g.f("    const long long wu = uni64(it / unit_len);");
       g.f("    const int step = (int)uni64(it - wu * unit_len);  // wave-uniform: every lane of the wave unit is at this step of its chain");
@@ -1677,7 +1677,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       g.f("  const long long wu_lo = PG ? blockIdx.x * wu_per_wave : blockIdx.x, wu_step = PG ? 1 : gridDim.x;");
       g.f("  const long long wu_hi = PG ? (wu_lo + wu_per_wave < n_wave_units ? wu_lo + wu_per_wave : n_wave_units) : n_wave_units;");
       if (gb) {
-        g.f("  const bool with_head = !GIVEN && !WARM && a.head != nullptr && a.grad_tol <= 0.0;");
+        g.f("  const bool with_head = !GIVEN && !WARM && a.head != nullptr && a.grad_tol == 0.0;");
         g.f("  long long staged_span = -1;");
       }
       {  // (own geometry: round k gives wavefront w the unit k G + (w + 131 k) mod G, see okx_quadgen.cpp; C4 cold +1.3 %)
@@ -1716,7 +1716,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     if (sc) {
       g.f("    const okx_cptr gpc = (okx_cptr)gp, gqc = (okx_cptr)gq, rpc = (okx_cptr)a.row_param, dpc = (okx_cptr)a.dop_param;");
       g.f("    (void)gqc; (void)rpc; (void)dpc;");
-      g.f("    const bool with_head = !GIVEN && !WARM && a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
+      g.f("    const bool with_head = !GIVEN && !WARM && a.head != nullptr && a.grad_tol == 0.0%s;", fl ? " && step == 0" : "");
       g.f("    WAVE_SYNC();  // (the previous wave unit's last LDS reads are done)");
     } else {
     g.f("    // the geometry's tables (and its first-step table) into LDS, lane k fetching entry k");
@@ -1743,7 +1743,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     } else
     stage_tables(g, "    ");
     if (!gb) {
-    g.f("    const bool with_head = !GIVEN && !WARM && a.head != nullptr && a.grad_tol <= 0.0%s;", fl ? " && step == 0" : "");
+    g.f("    const bool with_head = !GIVEN && !WARM && a.head != nullptr && a.grad_tol == 0.0%s;", fl ? " && step == 0" : "");
     g.f("    if (with_head) {");
     g.f("      const double* hp = a.head + (PG ? span_idx * %d : 0);", head_stride);
     g.f("      for (int k = lane; k < %d; k += 64) lds[%d + k] = hp[k];", head_stride, head_l0);
@@ -2111,8 +2111,16 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
       for (int i = 0; i < n; ++i) g.f("      diag = fmax(diag, %s);", LGen::A(i, i).c_str());
     }
     g.f("    }");
+    // gradient stop (okx_solve_opts.grad_tol): > 0 the absolute form max |J^T r|; < 0 MINPACK's scaled form
+    // max_j |(J^T r)_j| / (|J_j| |r|) (lmder's gnorm, what the reference's gtol means: solver.py:158-169)
     g.f("    if (a.grad_tol > 0.0) {");
     for (int i = 0; i < n; ++i) g.f("      gm = fmax(gm, fabs(%s));", LGen::gn(i).c_str());
+    g.f("    } else if (a.grad_tol < 0.0) {");
+    g.f("      const double rr = 2.0 * Ft;");
+    for (int i = 0; i < n; ++i) {
+      const std::string aii = (!ch && evc.late_diag) ? evc.diag_expr(i, [](const std::string& nm) { return nm; }) : LGen::A(i, i);
+      g.f("      { const double cn = %s * rr; gm = fmax(gm, cn > 0.0 ? fabs(%s) * __builtin_amdgcn_rsq(cn) : 0.0); }", aii.c_str(), LGen::gn(i).c_str());
+    }
     g.f("    }");
     g.f("    if (!done) {");
     g.f("      ++nfev;");
@@ -2135,7 +2143,7 @@ bool lane_generate(const DevProgram& P, std::string* src, std::string* why, int 
     g.f("            const double t = 2.0 * rho - 1.0;");
     g.f("            lambda *= (rho > 0.99 && (step_len <= 1.0 || Ft <= 1e-2)) ? 1e-3 : (rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t));");
     g.f("          }");
-    g.f("          if (a.grad_tol > 0.0 && gm <= a.grad_tol) { flags |= INFO_CONVERGED; stop = true; }");
+    g.f("          if (a.grad_tol != 0.0 && gm <= fabs(a.grad_tol)) { flags |= INFO_CONVERGED; stop = true; }");
     g.f("        }");
     g.f("      } else if (!stop) {");
     g.f("        lambda *= nu; nu *= 2.0;");

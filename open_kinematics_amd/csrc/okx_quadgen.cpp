@@ -2033,7 +2033,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("    __shared__ double hxl[%d];  // first step of the unit's head problem [block][lane]", 64 * nf);
     g.f("    __shared__ double hsc[%d];  // its scalars [slot][quad]: step length, dx.g, |dx|^2, cost x 2, max |r|, dmax, min / max pivot, ok", 16 * 9);
     g.f("    bool head_ready = false;");
-    g.f("    if (a.head != nullptr && a.grad_tol <= 0.0 && (PG || a.predictor == nullptr)) {");
+    g.f("    if (a.head != nullptr && a.grad_tol == 0.0 && (PG || a.predictor == nullptr)) {");
     }
     if (!CD) {
     g.f("      const double* hp = a.head + (PG ? geom * %d : 0);", head_stride);
@@ -2473,8 +2473,16 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
         Gen::A(F, F, 1).c_str(), Gen::A(F, F, 2).c_str());
   g.f("      diag = PMAX(diag);");
   g.f("    }");
+  // gradient stop (okx_solve_opts.grad_tol): > 0 the absolute form max |J^T r|; < 0 MINPACK's scaled form
+  // max_j |(J^T r)_j| / (|J_j| |r|) (lmder's gnorm, what the reference's gtol means: solver.py:158-169)
   g.f("    if (a.grad_tol > 0.0) {");
   for (int F = 0; F < nf; ++F) g.f("      gm = fmax(gm, fabs(gn%d));", F);
+  g.f("      gm = PMAX(gm);");
+  g.f("    } else if (a.grad_tol < 0.0) {");
+  g.f("      const double rr = 2.0 * Ft;");
+  for (int F = 0; F < nf; ++F)
+    g.f("      { const double cn = (c == 0 ? %s : (c == 1 ? %s : (c == 2 ? %s : 0.0))) * rr; gm = fmax(gm, cn > 0.0 ? fabs(gn%d) * __builtin_amdgcn_rsq(cn) : 0.0); }",
+        Gen::A(F, F, 0).c_str(), Gen::A(F, F, 1).c_str(), Gen::A(F, F, 2).c_str(), F);
   g.f("      gm = PMAX(gm);");
   g.f("    }");
   g.f("    if (!done) {");
@@ -2513,7 +2521,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   g.f("            const double t = 2.0 * rho - 1.0;");
   g.f("            lambda *= (rho > 0.99 && (step_len <= 1.0 || Ft <= 1e-2)) ? 1e-3 : (rho > 0.9 ? 0.1 : fmax(1.0 / 3.0, 1.0 - t * t * t));");
   g.f("          }");
-  g.f("          if (a.grad_tol > 0.0 && gm <= a.grad_tol) { flags |= INFO_CONVERGED; stop = true; }");
+  g.f("          if (a.grad_tol != 0.0 && gm <= fabs(a.grad_tol)) { flags |= INFO_CONVERGED; stop = true; }");
   g.f("        }");
   g.f("      } else if (!stop) {");
   g.f("        lambda *= nu; nu *= 2.0;");

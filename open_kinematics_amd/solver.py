@@ -57,9 +57,10 @@ def device_tolerances(cfg: "SolverConfig", program: ConstraintProgram) -> dict:
     change, ``ftol`` relative).  A caller who loosens ``xtol`` / ``ftol`` beyond the reference's defaults gets them:
     ``step_tol = max(cfg.step_tol, xtol * ||x0||_2)`` with ``x0`` the free coordinates of the design state, and
     ``ftol`` passed through - the solve stops earlier, with fewer evaluations, like the reference's would.  Defaults and
-    tighter values leave the device's fixed-point stop (``cfg.step_tol``, device ``ftol`` 1e-10) in charge.  ``gtol``
-    has no device counterpart (MINPACK's is a scaled cosine, ``okx_solve_opts.grad_tol`` an absolute gradient): a
-    loosened ``gtol`` is reported with a warning and otherwise ignored - the solve only ends closer to the solution.
+    tighter values leave the device's fixed-point stop (``cfg.step_tol``, device ``ftol`` 1e-10) in charge.  A loosened
+    ``gtol`` is passed on as MINPACK's own test - ``okx_solve_opts.grad_tol < 0``: stop when
+    ``max_j |(J^T r)_j| / (|J_j| |r|) <= gtol`` (``lmder``'s ``gnorm``) - which, as in the reference, only ever ends a solve
+    whose residual does not vanish (a compromise point beyond the reach); such launches run without the shared first step.
     """
     tolerances = {"step_tol": float(cfg.step_tol)}
     if cfg.xtol > SOLVE_TOLERANCE_STEP:
@@ -68,10 +69,7 @@ def device_tolerances(cfg: "SolverConfig", program: ConstraintProgram) -> dict:
     if cfg.ftol > SOLVE_TOLERANCE_VALUE:
         tolerances["ftol"] = float(cfg.ftol)
     if cfg.gtol > SOLVE_TOLERANCE_GRAD:
-        import warnings
-
-        warnings.warn(f"SolverConfig.gtol = {cfg.gtol:g} is looser than the reference's default {SOLVE_TOLERANCE_GRAD:g}: the device "
-                      "solver has no orthogonality stop and iterates to its step / cost tolerances instead", RuntimeWarning, stacklevel=3)
+        tolerances["grad_tol"] = -float(cfg.gtol)
     return tolerances
 
 

@@ -322,3 +322,50 @@ def test_compact_exchange_pipeline_on_the_device(golden, monkeypatch):
     full = pipe.drain()
     torch.cuda.synchronize()
     assert full.shape == ref.shape and float((full - ref).abs().max()) <= 1e-11
+
+
+@pytest.mark.parametrize("kernel", ["quad", "lane", "single"])
+def test_minpack_gradient_test_ends_compromise_solves(golden, kernel):
+    """okx_solve_opts.grad_tol < 0 is MINPACK's gtol (lmder's gnorm = max_j |(J^T r)_j| / (|J_j| |r|), what the reference's
+    SolverConfig.gtol means, solver.py:158-169): beyond the reach, where the residual does not vanish, a loosened value ends
+    the solve as soon as the residual is that orthogonal to the Jacobian's columns - earlier than the cost test - and the
+    returned point really meets it; > 0 stays the absolute form; inside the reach neither fires."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    arrays, program = golden("c1_dw_corner")
+    program = program.with_line_mode("pinned")
+    dp = DeviceProgram(program, "cuda:0")
+    base = arrays["targets_abs"][len(arrays["targets_abs"]) // 2]
+    bump = [k for k in range(program.n_targets) if abs(program.tgt_dir[k][2]) > 0.5][0]
+    t = np.repeat(base[None], 128, axis=0)
+    t[:, bump] += np.concatenate([np.linspace(200.0, 500.0, 64), -np.linspace(200.0, 500.0, 64)])   # past either end of the bump travel
+    kw = dict(kernel=kernel, chain_len=1, predictor=False, max_iter=400)
+    probe = dp.solve(t, **kw).info()
+    t = t[probe["max_residual"] > 1e-3]                   # the compromise points: targets that cannot be met
+    assert len(t) >= 32
+
+    def gnorm(res):
+        x = res.positions[:, dp.free_out_index].reshape(len(t), -1)
+        r, jac = dp.eval(x, t)
+        r, jac = r.cpu().numpy(), jac.cpu().numpy()
+        g = np.einsum("bmn,bm->bn", jac, r)
+        cols = np.linalg.norm(jac, axis=1)
+        return np.max(np.abs(g) / np.maximum(cols * np.linalg.norm(r, axis=1)[:, None], 1e-300), axis=1), np.max(np.abs(g), axis=1)
+
+    default = dp.solve(t, **kw)
+    loose = dp.solve(t, grad_tol=-1e-2, **kw)
+    torch.cuda.synchronize()
+    di, li = default.info(), loose.info()
+    assert np.all(li["flags"] & 1) and np.all(default.info()["max_residual"] > 1e-3)       # converged on the test, far from feasible
+    assert li["nfev"].sum() < di["nfev"].sum()
+    scaled, _ = gnorm(loose)
+    assert scaled.max() <= 1e-2 * (1.0 + 1e-6)
+    assert gnorm(default)[0].max() <= 1e-2                   # (the default's cost test ends at least as orthogonal)
+    absolute = dp.solve(t, grad_tol=5.0, **kw)               # the absolute form: max |J^T r| <= 5
+    torch.cuda.synchronize()
+    assert gnorm(absolute)[1].max() <= 5.0 * (1.0 + 1e-9) and np.all(absolute.info()["flags"] & 1)
+    inside = arrays["targets_abs"]
+    a = dp.solve(inside, kernel=kernel, chain_len=1, predictor=False)
+    b = dp.solve(inside, kernel=kernel, chain_len=1, predictor=False, grad_tol=-1e-3)
+    torch.cuda.synchronize()
+    assert float((a.positions - b.positions).abs().max()) <= 1e-9
