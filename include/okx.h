@@ -617,7 +617,9 @@ int32_t okx_program_has_cold_body(const okx_program* prog);
  * thread; never the compiler, never a synchronise of the legacy stream) while holding the program's kernel state
  * exclusively - launches of the same program from other threads wait for it, launches in progress finish first.  A call
  * whose stream is recording a HIP graph never switches over (module loads are illegal in a capture): the interpreter
- * serves it and a later call does.  okx_program_ready returns 1 when nothing is pending any more and 0 while the job
+ * serves it and a later call does.  The switch-over has two stages: the quad module is attached as soon as IT is compiled
+ * (it serves every batch size), the lane module when the whole job is done.  okx_program_ready returns 1 when nothing is
+ * pending any more and 0 while the job
  * runs; wait != 0 blocks until it has finished and switches over before returning (benchmarks and tests that must know
  * which kernel they time).  okx_program_kernel() / okx_program_kernel_note() report the current state. */
 int32_t okx_program_ready(okx_program* prog, int32_t wait);

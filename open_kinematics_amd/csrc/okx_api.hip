@@ -73,6 +73,8 @@ struct okx_program {
   struct JitJob {
     std::thread thread;
     std::atomic<int> finished{0};
+    std::atomic<int> quad_ready{0};   // the quad module is compiled (the lane module may still be in the works)
+    std::atomic<int> quad_attached{0};  // ... and already switched over to (written under the program's jit_mutex)
     okx::DevProgram host;
     bool want_quad = false, want_lane = false;   // what was not in the cache at create
     bool quad_ok = false, lane_ok = false;
@@ -548,6 +550,7 @@ void attach_lane_kernel(okx_program* p, bool cache_only = false, bool* pending =
 void jit_job(okx_program::JitJob* job) {
   std::string src;
   if (job->want_quad) job->quad_ok = okx::quad_build(job->host, quad_waves_per_simd(), &src, &job->quad_code, &job->quad_why);
+  job->quad_ready.store(1, std::memory_order_release);  // (a launch may switch over to the quad kernels now: two stages)
   if (job->want_lane && (job->quad_ok || !job->want_quad) && job->host.n_free <= okx::kQuadMaxFree && !okx::dev_switch("no_lane")) {
     std::string lsrc;
     job->lane_ok = okx::lane_build(job->host, &lsrc, &job->lane_code, &job->lane_why, false, nullptr, 256, false, &job->lane_overrides);
@@ -584,11 +587,32 @@ void reap_orphans_at_exit() { reap_orphans(true); }
 void attach_when_ready(okx_program* p, bool wait, const hipStream_t* stream = nullptr) {
   okx_program::JitJob* job = p->jit.load(std::memory_order_acquire);
   if (!job) return;
-  if (!wait && !job->finished.load(std::memory_order_acquire)) return;
+  const bool all_done = wait || job->finished.load(std::memory_order_acquire);
+  // first stage: the quad module alone is ready (the lane module's variants take another minute) - switch over to it now,
+  // it serves every batch size until the lane kernels arrive
+  const bool quad_stage = !all_done && job->want_quad && job->want_lane && job->quad_ready.load(std::memory_order_acquire) && !job->quad_attached.load(std::memory_order_acquire);
+  if (!all_done && !quad_stage) return;
   if (!wait && stream && stream_is_capturing(*stream)) return;
   std::lock_guard<std::mutex> lock(*p->jit_mutex);
   job = p->jit.load(std::memory_order_acquire);
   if (!job) return;  // another caller got here first
+  if (!all_done) {
+    if (job->quad_attached.load(std::memory_order_acquire)) return;  // (another caller did the first stage meanwhile)
+    int current = p->device;
+    (void)hipGetDevice(&current);
+    if (current != p->device) (void)hipSetDevice(p->device);
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool exchanged = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+    {
+      std::unique_lock<std::shared_mutex> kernels(*p->kern_mutex);
+      attach_quad_kernel(p, false, nullptr, job);   // (reads job->quad_code / quad_why only: written before quad_ready)
+      job->quad_attached.store(1, std::memory_order_release);
+    }
+    if (exchanged) (void)hipThreadExchangeStreamCaptureMode(&mode);
+    (void)hipGetLastError();
+    if (current != p->device) (void)hipSetDevice(current);
+    return;
+  }
   job->thread.join();
   int current = p->device;
   (void)hipGetDevice(&current);
@@ -599,7 +623,7 @@ void attach_when_ready(okx_program* p, bool wait, const hipStream_t* stream = nu
   const bool exchanged = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
   {
     std::unique_lock<std::shared_mutex> kernels(*p->kern_mutex);  // launches in progress finish first, later ones see the new set
-    if (job->want_quad) attach_quad_kernel(p, false, nullptr, job);
+    if (job->want_quad && !job->quad_attached.load(std::memory_order_acquire)) attach_quad_kernel(p, false, nullptr, job);
     if (job->want_lane) attach_lane_kernel(p, false, nullptr, job);
   }
   if (exchanged) (void)hipThreadExchangeStreamCaptureMode(&mode);

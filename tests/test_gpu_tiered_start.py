@@ -133,3 +133,39 @@ def test_switch_over_under_concurrent_launches_and_without_a_writable_cache(gold
     assert os.listdir(locked) == []
     locked.chmod(stat.S_IRWXU)
     dp.close()
+
+
+def test_quad_kernels_serve_while_the_lane_module_still_compiles(golden, monkeypatch, tmp_path):
+    """Two stages: the quad module is switched over to as soon as IT is compiled; the lane module (its emission variants
+    take the compiler another while) follows when the whole job is done.  Same answers in all three phases."""
+    from open_kinematics_amd.batch import DeviceProgram
+
+    monkeypatch.setenv("OKX_KERNEL_CACHE", str(tmp_path))
+    monkeypatch.delenv("OKX_DEV", raising=False)
+    arrays, program = golden("c4_macpherson_grid")
+    program = program.with_line_mode("pinned")
+    targets = torch.as_tensor(arrays["targets_abs"], device="cuda:0")
+    dp = DeviceProgram(program, "cuda:0", wait_for_kernels=False)
+    assert not dp.ready and dp.kernel == "wave"
+    first = dp.solve(targets, chain_len=1, predictor=False).positions.clone()
+    torch.cuda.synchronize()
+    quad_while_pending = False
+    deadline = time.perf_counter() + 300.0
+    while time.perf_counter() < deadline:
+        res = dp.solve(targets, chain_len=1, predictor=False)    # (every launch looks for a finished stage)
+        torch.cuda.synchronize()
+        assert float((res.positions - first).abs().max()) <= 1e-9
+        kernel, pending = dp.kernel, not dp.ready
+        if kernel == "quad" and pending:
+            quad_while_pending = True
+        if not pending:
+            break
+        time.sleep(0.25)
+    assert dp.ready and dp.kernel == "quad", dp.kernel_note
+    assert quad_while_pending, "the quad kernels were only attached together with the lane module"
+    assert dp.lane_bodies & 1, dp.lane_note                      # ... and the lane kernels did arrive
+    big = targets.repeat(80, 1)[:20000].contiguous()             # a batch the lane kernel takes
+    res = dp.solve(big, chain_len=1, predictor=False)
+    torch.cuda.synchronize()
+    assert res.accepted(res.info()).all()
+    dp.close()
