@@ -251,3 +251,18 @@ def test_host_thread_pool_is_fitted_to_a_cgroup_quota(monkeypatch, tmp_path):
     finally:
         monkeypatch.setattr(hostcpu, "_fitted", None)
     assert torch.get_num_threads() in (before, 128)
+
+
+def test_precompile_entry_point_for_a_users_geometry(capsys):
+    """python -m open_kinematics_amd.precompile geometry.yaml sweep.yaml: the drop-in's programs of a suspension into the
+    kernel cache (the packaged fixtures' are there already: nothing is compiled here), usage text without arguments."""
+    from open_kinematics_amd import precompile
+    from open_kinematics_amd.workloads import geometry_path
+
+    assert precompile.main([]) == 2 and "geometry.yaml sweep.yaml" in capsys.readouterr().out
+    assert precompile.main([geometry_path("geometry.yaml"), geometry_path("sweep.yaml"), geometry_path("bump_sweep.yaml")]) == 0
+    out = capsys.readouterr().out
+    assert "drop-in solve: ok, with the evaluated modules" in out
+    assert precompile.main([geometry_path("axle_geometry.yaml"), geometry_path("axle_sweep.yaml")]) == 0
+    out = capsys.readouterr().out
+    assert "drop-in solve: ok" in out and "evaluated" not in out      # axles: the solve kernels (pair mode) only
