@@ -783,6 +783,8 @@ def main() -> None:
                          "geometries x 256 steps, geometry-major shards (strong scaling)")
     ap.add_argument("--preheat-ms", type=float, default=40.0,
                     help="milliseconds of untimed launches ahead of the warm-up steps (GPU clocks leave their idle state); 0 = none")
+    ap.add_argument("--torch-submit", action="store_true",
+                    help="one GPU, graph submission: record / launch / record / poll through torch's own calls instead of the HIP runtime directly")
     ap.add_argument("--no-graph", action="store_true",
                     help="one GPU: submit the K timed steps as K stream launches instead of ONE HIP graph of K kernel nodes "
                          "(measured on a quiet host: 16.09 against 16.30 us per step at K = 2000, no difference at K = 20; the graph "
@@ -939,26 +941,55 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
+    # Graph submission through the HIP runtime directly (the same three calls torch makes - record, launch, record - and
+    # the poll, without torch's per-call Python layers: ~15 us less host time inside a 0.35 ms region; --torch-submit: off)
+    direct = None
+    if graph is not None and not per_launch_events and not getattr(timed_region, "torch_submit", False):
+        try:
+            import ctypes as C
+
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+            hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+            hip.hipEventQuery.argtypes = [C.c_void_p]
+            direct = (hip, C.c_void_p(graph.raw_cuda_graph_exec()), C.c_void_p(torch.cuda.current_stream(device).cuda_stream),
+                      C.c_void_p(starts[0].cuda_event), C.c_void_p(ends[0].cuda_event))
+        except Exception:  # noqa: BLE001 - a torch without the raw handles: its own calls
+            direct = None
+    timed_region.direct = direct is not None
     t0 = time.perf_counter()
-    if not per_launch_events:
-        starts[0].record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for k in range(steps):
-            step(k, starts[k] if per_launch_events else None, ends[k] if per_launch_events else None)
-    if not per_launch_events:
-        ends[0].record()
-        # (the host polls the end event before it synchronises: a poll sees the end of the GPU's work within microseconds, an
-        #  interrupt-driven wait wakes the host later; the synchronize below then finds an idle GPU - profiles/r04/EXPERIMENTS.md section 10)
-        while not ends[0].query():
+    if direct is not None:
+        hip, exec_h, stream_h, ev0, ev1 = direct
+        rc = hip.hipEventRecord(ev0, stream_h) or hip.hipGraphLaunch(exec_h, stream_h) or hip.hipEventRecord(ev1, stream_h)
+        if rc != 0:
+            raise RuntimeError(f"HIP error {rc} submitting the timed graph")
+        t_sub = time.perf_counter()
+        while hip.hipEventQuery(ev1) != 0:
             pass
+        t_poll = time.perf_counter()
+        timed_region.breakdown = [t_sub - t0, t_poll - t_sub]
+    else:
+        if not per_launch_events:
+            starts[0].record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for k in range(steps):
+                step(k, starts[k] if per_launch_events else None, ends[k] if per_launch_events else None)
+        if not per_launch_events:
+            ends[0].record()
+            # (the host polls the end event before it synchronises: a poll sees the end of the GPU's work within microseconds, an
+            #  interrupt-driven wait wakes the host later; the synchronize below then finds an idle GPU - profiles/r04/EXPERIMENTS.md section 10)
+            while not ends[0].query():
+                pass
     drain()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    if getattr(timed_region, "breakdown", None) and len(timed_region.breakdown) == 2:
+        timed_region.breakdown.append(elapsed - sum(timed_region.breakdown))   # drain + synchronize
     kernel_ms = float(np.sum([s.elapsed_time(e) for s, e in zip(starts, ends)])) / steps
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=device)
@@ -977,6 +1008,7 @@ def run_c2(args, world: int, rank: int, device) -> dict:
     program, targets_all = bump_sweep_problem(n_total)
     lo, hi = shard_range(n_total, rank, world)
     use_graph = world == 1 and not args.rccl_world_one and not args.no_graph
+    timed_region.torch_submit = bool(args.torch_submit)
     if world == 1:
         # one GPU: everything below (plans, events, the extra legs) runs on a stream of its own - stream capture, which the
         # graph submission of the timed steps needs, is not allowed on the default stream
@@ -1039,7 +1071,11 @@ def run_c2(args, world: int, rank: int, device) -> dict:
                     "note": "untimed launches of the same step ahead of the W warm-up steps, so that the K timed steps run at the "
                             "clocks of a GPU under load rather than of one leaving idle (--preheat-ms 0 switches it off)"},
         "submission": ({"mode": "hip graph", "note": "the K timed steps are K kernel nodes of ONE HIP graph, captured ahead of the timed "
-                        "region and launched once inside it (--no-graph: K stream launches, as `sustained` below)"}
+                        "region and launched once inside it (--no-graph: K stream launches, as `sustained` below)",
+                        "host_us": dict(zip(("submit", "poll_until_done", "drain_and_synchronize"),
+                                            [round(x * 1e6, 1) for x in getattr(timed_region, "breakdown", None) or []])),
+                        "calls": "hipEventRecord / hipGraphLaunch / hipEventRecord / hipEventQuery through the HIP runtime directly"
+                                 if getattr(timed_region, "direct", False) else "torch.cuda.Event.record / CUDAGraph.replay / Event.query"}
                        if getattr(timed_region, "graph", False) else
                        {"mode": "stream launches", **({"note": timed_region.graph_note} if getattr(timed_region, "graph_note", None) else {})}),
         "ms_per_step": elapsed / args.steps * 1e3,
