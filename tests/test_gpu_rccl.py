@@ -81,3 +81,39 @@ def test_two_rank_c5_pipeline_rehearsal_on_one_gpu():
         assert line["exchange"]["chunks"] == (5 if extra else 8)
         assert line["exchange"]["bytes_sent_per_rank_per_step"] == 2048 * 256 * (6 * 24 + 1)   # coordinates + one status byte
         assert line["solve_only"]["value"] > 0.0 and line["value"] > 0.0
+
+
+def test_one_gpu_bench_line_keeps_the_contract():
+    """`python bench.py --steps 20 --warmup 5` as the driver runs it: one JSON line with the contract's fields, the roofline
+    and cpu_baseline objects, the K timed steps as one HIP graph submitted through the HIP runtime directly - and the same
+    through torch's own calls (--torch-submit)."""
+    if not gpu_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ)
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    for extra in ([], ["--torch-submit", "--no-cpu-baseline"]):
+        proc = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-extras"] + extra,
+                              env=env, capture_output=True, text=True, timeout=900)
+        assert proc.returncode == 0, (proc.stdout + proc.stderr)[-3000:]
+        lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        line = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                    "data", "config", "roofline"):
+            assert key in line, key
+        assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["dtype"] == "f64" and line["vs_baseline"] is None
+        assert line["config"]["all_converged"] and "workload" in line["config"]
+        roof = line["roofline"]
+        assert roof["bound"] == "hbm" and roof["kernel"] == "okx_quad_cold_u" and 0.0 < roof["frac"] < 1.0
+        assert abs(roof["achieved"] - 392.0 * 16384 / (roof["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * roof["achieved"]
+        assert roof["kernel_ms"] <= line["ms_per_step"]                       # the kernel cannot take longer than the step that holds it
+        assert abs(line["value"] - 16384 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+        sub = line["submission"]
+        assert sub["mode"] == "hip graph"
+        if extra:
+            assert sub["calls"].startswith("torch")
+        else:
+            assert sub["calls"].startswith("hipEventRecord") and set(sub["host_us"]) == {"submit", "poll_until_done", "drain_and_synchronize"}
+            base = line["cpu_baseline"]
+            assert base["kind"] == "port" and base["cores"] >= 1 and base["value"] > 0.0
