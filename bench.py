@@ -948,7 +948,13 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
         try:
             import ctypes as C
 
-            hip = C.CDLL("libamdhip64.so")
+            # (the runtime object this process already runs on - torch's own copy -, by its mapped path: a second copy of the
+            #  library would not know torch's events and graphs)
+            with open("/proc/self/maps", "r", encoding="utf-8") as maps:
+                mapped = sorted({line.split()[-1] for line in maps if "libamdhip64" in line})
+            if len(mapped) != 1:
+                raise RuntimeError(f"{len(mapped)} HIP runtimes mapped")
+            hip = C.CDLL(mapped[0])
             hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
             hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
             hip.hipEventQuery.argtypes = [C.c_void_p]
