@@ -880,6 +880,29 @@ def self_launch(n_ranks: int, argv: list, dry: bool = False) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _direct_hip_submission(graph, stream, start_event, end_event):
+    """
+    Handles for submitting a captured graph through the HIP runtime this process already maps (torch's own copy: a second
+    copy of the library would not know torch's events and graphs): (``(hip, graph_exec, stream, ev0, ev1)``, None), or
+    (None, reason) when this torch / ROCm does not expose them - the caller then uses torch's calls and says so in the line.
+    """
+    import ctypes as C
+
+    try:
+        with open("/proc/self/maps", "r", encoding="utf-8") as maps:
+            mapped = sorted({line.split()[-1] for line in maps if "libamdhip64" in line})
+        if len(mapped) != 1:
+            return None, f"{len(mapped)} HIP runtimes mapped"
+        hip = C.CDLL(mapped[0])
+        hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
+        hip.hipEventQuery.argtypes = [C.c_void_p]
+        return (hip, C.c_void_p(graph.raw_cuda_graph_exec()), C.c_void_p(stream.cuda_stream),
+                C.c_void_p(start_event.cuda_event), C.c_void_p(end_event.cuda_event)), None
+    except Exception as exc:  # noqa: BLE001 - a torch without the raw handles
+        return None, f"{type(exc).__name__}: {exc}"
+
+
 def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_launch_events: bool, preheat_ms: float = 0.0,
                  graph_steps: bool = False):
     """The contract's timed region: W warm-up steps, barrier + synchronize, K steps, synchronize + barrier, MAX over
@@ -943,25 +966,9 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
     torch.cuda.synchronize(device)
     # Graph submission through the HIP runtime directly (the same three calls torch makes - record, launch, record - and
     # the poll, without torch's per-call Python layers: ~15 us less host time inside a 0.35 ms region; --torch-submit: off)
-    direct = None
+    direct, timed_region.direct_note = None, None
     if graph is not None and not per_launch_events and not getattr(timed_region, "torch_submit", False):
-        try:
-            import ctypes as C
-
-            # (the runtime object this process already runs on - torch's own copy -, by its mapped path: a second copy of the
-            #  library would not know torch's events and graphs)
-            with open("/proc/self/maps", "r", encoding="utf-8") as maps:
-                mapped = sorted({line.split()[-1] for line in maps if "libamdhip64" in line})
-            if len(mapped) != 1:
-                raise RuntimeError(f"{len(mapped)} HIP runtimes mapped")
-            hip = C.CDLL(mapped[0])
-            hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
-            hip.hipGraphLaunch.argtypes = [C.c_void_p, C.c_void_p]
-            hip.hipEventQuery.argtypes = [C.c_void_p]
-            direct = (hip, C.c_void_p(graph.raw_cuda_graph_exec()), C.c_void_p(torch.cuda.current_stream(device).cuda_stream),
-                      C.c_void_p(starts[0].cuda_event), C.c_void_p(ends[0].cuda_event))
-        except Exception:  # noqa: BLE001 - a torch without the raw handles: its own calls
-            direct = None
+        direct, timed_region.direct_note = _direct_hip_submission(graph, torch.cuda.current_stream(device), starts[0], ends[0])
     timed_region.direct = direct is not None
     t0 = time.perf_counter()
     if direct is not None:
@@ -970,8 +977,11 @@ def timed_region(step, drain, steps: int, warmup: int, world: int, device, per_l
         if rc != 0:
             raise RuntimeError(f"HIP error {rc} submitting the timed graph")
         t_sub = time.perf_counter()
-        while hip.hipEventQuery(ev1) != 0:
-            pass
+        rc = hip.hipEventQuery(ev1)
+        while rc == 600:  # hipErrorNotReady; anything else that is not success is a device error: raise, never spin on it
+            rc = hip.hipEventQuery(ev1)
+        if rc != 0:
+            raise RuntimeError(f"HIP error {rc} while waiting for the timed graph")
         t_poll = time.perf_counter()
         timed_region.breakdown = [t_sub - t0, t_poll - t_sub]
     else:
@@ -1081,7 +1091,8 @@ def run_c2(args, world: int, rank: int, device) -> dict:
                         "host_us": dict(zip(("submit", "poll_until_done", "drain_and_synchronize"),
                                             [round(x * 1e6, 1) for x in getattr(timed_region, "breakdown", None) or []])),
                         "calls": "hipEventRecord / hipGraphLaunch / hipEventRecord / hipEventQuery through the HIP runtime directly"
-                                 if getattr(timed_region, "direct", False) else "torch.cuda.Event.record / CUDAGraph.replay / Event.query"}
+                                 if getattr(timed_region, "direct", False) else "torch.cuda.Event.record / CUDAGraph.replay / Event.query",
+                        **({"direct_fallback": timed_region.direct_note} if getattr(timed_region, "direct_note", None) else {})}
                        if getattr(timed_region, "graph", False) else
                        {"mode": "stream launches", **({"note": timed_region.graph_note} if getattr(timed_region, "graph_note", None) else {})}),
         "ms_per_step": elapsed / args.steps * 1e3,

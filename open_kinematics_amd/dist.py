@@ -278,13 +278,18 @@ class ShardedEnsemble:
             # (the evaluated ensemble sends 33 B instead of 145 B per state and computes 1.5 x as long: its exchange hides
             #  behind the solve with two chunks, more only lengthen the solve - tools/c5_pipeline_model.py)
             most = 2 if metric_columns is not None else 8
-            chunks = max(1, min(most, ((ghi - glo) * self.steps) // one_round, ghi - glo)) if self.world > 1 else 1
+            # (from the SMALLEST shard, a rank-independent number: the piece tables and the grouped send / receive calls
+            #  must have the same chunk count on every rank, and uneven shards differ by one geometry)
+            least = min(hi - lo for lo, hi in (shard_range(self.n_geom, r, self.world) for r in range(self.world)))
+            chunks = max(1, min(most, (least * self.steps) // one_round, least)) if self.world > 1 else 1
         self.chunks = max(1, int(chunks))
         # Kernel family and chain length are chosen ONCE, for the whole ensemble as one launch on one GPU (auto selection
         # goes by the problem count: a 16384-problem chunk of a million-problem ensemble would otherwise run the quad kernel
         # where the ensemble runs the lane kernel - same answers to 1e-9, other bits): every chunk on every rank is forced
         # to that choice, so chunked, unchunked, one-GPU and N-GPU runs of an ensemble agree bit for bit.
         if hasattr(device_program, "plan_launch"):
+            if hasattr(device_program, "wait_ready"):
+                device_program.wait_ready()  # (a program still on its interpreter kernels would pin every chunk to them)
             kernel, chain_len = device_program.plan_launch(self.n_total, steps_per_geometry=self.steps, geometry_tables=True,
                                                            evaluated=metric_columns is not None, **solve_kw)
             solve_kw = {**solve_kw, "kernel": kernel, "chain_len": chain_len}

@@ -272,7 +272,7 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     program, table = dropin_program(initial_state, constraints, sweep_config, derived_manager, cfg, output_points)
     dp = _device_program(program, device)
     n_steps = table.shape[0]
-    solve, evaluated = dp.solve, None
+    solve, evaluated, fused = dp.solve, None, False
     if evaluation is not None and program.n_targets > 0:
         try:
             roles, want_tangents = evaluation(program)
@@ -280,8 +280,10 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
 
             def solve(targets, **kw):  # noqa: F811 - the same launch, ending in the evaluation epilogue
                 return dp.solve_evaluated(targets, tangents=want_tangents, **kw)
+
+            fused = True
         except (ValueError, RuntimeError):  # no evaluated kernels for this program: solve now, evaluate after
-            solve = dp.solve
+            solve, fused = dp.solve, False
     solve_kw = dict(max_iter=cfg.max_iter, residual_tolerance=cfg.residual_tolerance, predictor=False,
                     **device_tolerances(cfg, program))  # (one sweep = a few chains or explicit cold starts: nothing for a fitted model to save)
     targets = torch.as_tensor(table)
@@ -309,7 +311,7 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
             positions_from_segments, segment = True, 1  # every step is a chain head
     _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg)
     states = _states_from_positions(initial_state, program, positions)
-    if solve is not dp.solve:
+    if fused:  # (never `solve is not dp.solve`: a bound method is a new object on every attribute access)
         evaluated = (program, result)
     return with_extra(states, _solver_infos(info, dp, segment if positions_from_segments else n_steps), evaluated)
 
