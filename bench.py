@@ -582,7 +582,8 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
             res[tag]["quad_kernel"] = {"value": n / q_wall, "kernel_ms": q_ms, "lm_evaluations_mean": info_summary(info)[0]}
     if roles_geometry is not None and dp.kernel == "quad":
         try:
-            res["evaluated"] = measure_evaluated(dp, roles_geometry, targets, out, info, kw, device, steps, warmup)
+            measure = measure_evaluated_axle if "axle" in os.path.basename(roles_geometry) else measure_evaluated
+            res["evaluated"] = measure(dp, roles_geometry, targets, out, info, kw, device, steps, warmup)
         except Exception as exc:  # (an extra leg must not take the line down with it)
             res["evaluated"] = {"error": f"{type(exc).__name__}: {exc}"}
     if "cold" in res:
@@ -592,6 +593,57 @@ def measure_config(name: str, make, device, steps: int, warmup: int, modes=("col
                                    "extrapolation along the chain (reference warm start, solver.py:774); no fitted model")
     dp.close()
     return res
+
+
+def measure_evaluated_axle(dp, suspension_yaml: str, targets, out, info, kw: dict, device, steps: int, warmup: int) -> dict:
+    """What an EVALUATED state of a COMPOSED AXLE costs (reference core/sweep.py:217-270 for an AxleSuspension): the solve, its
+    solution-manifold tangents, both corners' metric catalogs with their derivative columns, the axle-scope metrics and the
+    rotation roles - as six launches (solve, tangents, 2 x corner metrics, axle metrics, rotations) and as ONE
+    (okx_solve_evaluated_batch on the pair-mode evaluated module)."""
+    from open_kinematics_amd.input import load_geometry
+    from open_kinematics_amd.metrics import (axis_rotation_metrics, axle_evaluation_roles, axle_roles, axle_state_metrics,
+                                             corner_state_metrics, topology_rotation_roles)
+
+    program = dp.program
+    axle = load_geometry(suspension_yaml)
+    roles, rot_names, hw_names = axle_evaluation_roles(axle, program)
+    dp.enable_evaluation(roles)
+    columns = dp.eval_columns
+    n, T = targets.shape[0], program.n_targets
+    evb = torch.empty((n, 1 + T, columns), dtype=torch.float64, device=device)
+    skw = dict(chain_len=1, predictor=False, **kw)
+    solve = dp.plan(targets, out=out, info_out=info, **skw)
+    _, solve_ms = time_launches(solve, steps, warmup, device)
+    solve()
+    tan, _ = dp.tangents(out)
+    left, right = axle_roles(axle, program)
+    names, rroles = topology_rotation_roles(axle, program)
+    _, tan_ms = time_launches(lambda: dp.tangents(out), steps, warmup, device)
+    _, met_ms = time_launches(lambda: (corner_state_metrics(left, out, tan), corner_state_metrics(right, out, tan)), steps, warmup, device)
+    _, axle_ms = time_launches(lambda: axle_state_metrics(left, right, out), steps, warmup, device)
+    rot_ms = time_launches(lambda: axis_rotation_metrics(rroles, out, tan), steps, warmup, device)[1] if names else 0.0
+    del tan
+    fused = dp.plan_evaluated(targets, info_out=info, eval_out=evb, output="none", **skw)
+    wall, fused_ms = time_launches(fused, steps, warmup, device)
+    nfev, ok = info_summary(info)
+    _, fused_rec_ms = time_launches(dp.plan_evaluated(targets, out=out, info_out=info, eval_out=evb, **skw), steps, warmup, device)
+    given_ms = time_launches(lambda: dp.evaluate(out, eval_out=evb), steps, warmup, device)[1]
+    flags = evb[:, 0, 21]
+    bytes_out = 8 * T + 8 * columns * (1 + T) + 16
+    separate = solve_ms + tan_ms + met_ms + axle_ms + rot_ms
+    return {"unit": "evaluated states/s", "value": n / (fused_ms * 1e-3), "kernel_ms": fused_ms, "wall_value": n / wall,
+            "kernel": "pair mode: one quad per half; lane c of each quad evaluates direction c - 1 of its corner's catalog, the left "
+                      "quad the axle-scope metrics, both the rotation roles",
+            "roles": sorted(set(rot_names) | set(hw_names)),
+            "with_records_kernel_ms": fused_rec_ms, "given_states_kernel_ms": given_ms,
+            "separate_launches": {"solve_ms": solve_ms, "tangents_ms": tan_ms, "two_corner_metrics_with_derivatives_ms": met_ms,
+                                  "axle_metrics_ms": axle_ms, "rotation_roles_ms": rot_ms, "total_ms": separate,
+                                  "value": n / (separate * 1e-3)},
+            "speedup": separate / fused_ms, "all_converged": ok, "lm_evaluations_mean": nfev,
+            "tangent_solves_ok": bool((flags == 1.0).all().item()),
+            "algorithmic_bytes_per_state": bytes_out, "algorithmic_gbs": bytes_out * n / (fused_ms * 1e-3) / 1e9,
+            "hbm_frac": bytes_out * n / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": f"HIP events; output = none: 8 T in, {columns} (1 + T) doubles + 16 B of info out per state; issue-bound like the solve"}
 
 
 def measure_evaluated(dp, suspension_yaml: str, targets, out, info, kw: dict, device, steps: int, warmup: int) -> dict:
@@ -1200,7 +1252,7 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         dp.close()
         line["other_configs"] = [
             measure_config("C3 rocker + U-bar axle, 256x256 heave x roll grid (n = 60, pair mode)",
-                           lambda: axle_grid_problem(256, 256), device, 20, 3),
+                           lambda: axle_grid_problem(256, 256), device, 20, 3, roles_geometry=geometry_path("axle_geometry_rocker.yaml")),
             measure_config("C4 MacPherson corner, 512x512 bump x rack grid", lambda: macpherson_grid_problem(512, 512), device, 20, 3,
                            roles_geometry=geometry_path("macpherson_geometry.yaml")),
             measure_config("C5 4096 perturbed double-wishbone geometries x 256-step bump sweep (one GPU)",

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OKX_ABI_VERSION 5   /* 5: the evaluated solve (okx_program_enable_evaluation, okx_solve_evaluated_batch, okx_evaluate_batch, okx_precompile_evaluation).  4: okx_rotation_role.kind / point_b (hardware metrics of composed axles), okx_program_has_cold_body, okx_program_ready.  3: okx_solve_opts.output (+ reserved); lane kernel entry points.  2: confirm_full_pass; diagnostics moved to okx_debug.h */
+#define OKX_ABI_VERSION 6   /* 6: the evaluated solve of composed axles (okx_axle_roles, okx_program_enable_axle_evaluation, okx_precompile_axle_evaluation, okx_program_eval_columns).  5: the evaluated solve (okx_program_enable_evaluation, okx_solve_evaluated_batch, okx_evaluate_batch, okx_precompile_evaluation).  4: okx_rotation_role.kind / point_b (hardware metrics of composed axles), okx_program_has_cold_body, okx_program_ready.  3: okx_solve_opts.output (+ reserved); lane kernel entry points.  2: confirm_full_pass; diagnostics moved to okx_debug.h */
 
 /* Hard limits of one problem (one wavefront owns one problem). */
 #define OKX_MAX_VARS 126     /* n = 3 * free points (one thread per variable: one wavefront up to 63, two beyond) */
@@ -513,6 +513,41 @@ int32_t okx_axis_rotation_batch(const okx_rotation_role* roles, int32_t n_roles,
                                 double* d_angles,          /* [B][n_roles] */
                                 double* d_dangles,         /* [B][T][n_roles] or NULL */
                                 void* stream);
+
+/*
+ * The evaluated solve of a COMPOSED AXLE (two identical corners joined by rack / anti-roll bar / heave-link rows; the
+ * generated kernels' pair mode): okx_solve_evaluated_batch / okx_evaluate_batch on a program enabled with
+ * okx_program_enable_axle_evaluation end every problem with ONE epilogue for the whole axle - one undamped refactorisation
+ * through the halves' factors and the joining rows' Woodbury system, one substitution per target (sensitivity.py:57-174,
+ * the partner half's share exchanged inside the wavefront), derived-point velocities, then
+ *   - BOTH corners' metric catalogs with their derivative along every target's tangent (metrics/main.py:63-185 per side),
+ *   - the axle-scope metrics (metrics/axle_metrics.py:21-95) and their derivatives,
+ *   - up to OKX_MAX_ROTATIONS roles of okx_rotation_role's kinds (rocker angles, U-bar arm angles, a T-bar's heave angle,
+ *     twist and centre travel, a heave link's length: corner/mechanisms.py:378-407, axle/mechanisms.py:402-430,718-815,903-944)
+ * - what solve -> okx_tangent_batch -> okx_corner_metrics_batch x 2 -> okx_axle_metrics_batch -> okx_axis_rotation_batch
+ * compute in six launches.  Reference: core/sweep.py:113-173,217-270 for an AxleSuspension.
+ * d_eval is [B][1 + T][OKX_EVAL_AXLE_COLUMNS]; T = the PROGRAM's targets.  Per row:
+ *   columns OKX_EVAL_AXLE_LEFT  + 0 .. 23 : the left corner's block in the corner layout above (row 0: metric values, the
+ *                                            tangent solve's pivots and flags; row 1 + t: derivatives, wheel-centre and rack rates),
+ *   columns OKX_EVAL_AXLE_RIGHT + 0 .. 23 : the right corner's (its pivot columns are 0),
+ *   columns OKX_EVAL_AXLE_METRICS + OKX_AXLE_METRIC_* : the axle-scope metrics (row 0) / their derivatives (row 1 + t),
+ *   columns OKX_EVAL_AXLE_ROLES + k       : role k's value (row 0) / its rate along target t's tangent (row 1 + t).
+ * The role POINTS (both corners' and the roles' `point` / `point_b`, and the roles' kinds) are compiled into the module;
+ * every number (side signs, design references, vehicle data, the roles' axes, design positions and scales) is a kernel
+ * argument.  The two corners must use the same instant-axis construction and both or neither carry damper / rack roles.
+ */
+#define OKX_EVAL_AXLE_COLUMNS 64
+enum { OKX_EVAL_AXLE_LEFT = 0, OKX_EVAL_AXLE_RIGHT = 24, OKX_EVAL_AXLE_METRICS = 48, OKX_EVAL_AXLE_ROLES = 56 };
+typedef struct okx_axle_roles {
+  okx_corner_roles left, right;  /* indices into the AXLE program's output points */
+  int32_t n_roles;               /* 0 .. OKX_MAX_ROTATIONS */
+  int32_t reserved;
+  okx_rotation_role roles[OKX_MAX_ROTATIONS];
+} okx_axle_roles;
+int32_t okx_program_enable_axle_evaluation(okx_program* prog, const okx_axle_roles* roles);
+int32_t okx_precompile_axle_evaluation(const okx_program_desc* desc, const okx_axle_roles* roles);
+/* Columns per row of d_eval for the evaluation last enabled: OKX_EVAL_COLUMNS (corner), OKX_EVAL_AXLE_COLUMNS (axle), 0 (none). */
+int32_t okx_program_eval_columns(const okx_program* prog);
 
 /*
  * Output positions from free-point coordinates: fixed points come from the program's design state (or the

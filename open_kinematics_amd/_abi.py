@@ -8,7 +8,7 @@ import numpy as np
 
 from .program import ConstraintProgram
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -93,6 +93,9 @@ TANGENT_RANK_DEFICIENT = 2
 EVAL_COLUMNS = 24
 EVAL_MIN_PIVOT, EVAL_MAX_PIVOT, EVAL_TANGENT_FLAGS = 19, 20, 21                      # row 0
 EVAL_RATE_WHEEL_CENTER_X, EVAL_RATE_WHEEL_CENTER_Z, EVAL_RATE_RACK_Y = 19, 21, 22    # rows 1 + t
+# a composed axle's rows (okx_program_enable_axle_evaluation): [left corner block | right corner block | axle metrics | roles]
+EVAL_AXLE_COLUMNS = 64
+EVAL_AXLE_LEFT, EVAL_AXLE_RIGHT, EVAL_AXLE_METRICS, EVAL_AXLE_ROLES = 0, 24, 48, 56
 
 INFO_CONVERGED = 1
 INFO_RESIDUAL_EXCEEDED = 2

@@ -54,6 +54,9 @@ EXPORTS = (
     "okx_evaluate_batch",
     "okx_precompile_evaluation",
     "okx_plan_launch",
+    "okx_program_enable_axle_evaluation",
+    "okx_precompile_axle_evaluation",
+    "okx_program_eval_columns",
 )
 
 # include/okx_debug.h: test hooks and profiling aids, not part of the drop-in boundary
@@ -92,12 +95,14 @@ def load() -> C.CDLL:
         )
     try:
         import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; see module docstring)
-
-        from .hostcpu import fit_host_threads
-
-        fit_host_threads()  # a thread pool wider than the cgroup's CPU quota gets the whole process throttled (hostcpu.py)
     except Exception:  # pragma: no cover - torch is part of the image
         pass
+    if os.environ.get("OKX_FIT_HOST_THREADS") == "1":
+        # opt-in: size torch's host thread pool to the cgroup's CPU quota.  Loading the library
+        # changes nothing about the host process otherwise; bench.py and the tools call hostcpu.fit_host_threads() themselves.
+        from .hostcpu import fit_host_threads
+
+        fit_host_threads()
     lib = C.CDLL(LIB_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
     lib.okx_abi_version.restype = i32
@@ -183,6 +188,12 @@ def load() -> C.CDLL:
     lib.okx_precompile_evaluation.restype = i32
     lib.okx_plan_launch.argtypes = [vp, C.POINTER(SolveOpts), i64, i32, i32, C.POINTER(i32 * 2)]
     lib.okx_plan_launch.restype = i32
+    lib.okx_program_enable_axle_evaluation.argtypes = [vp, vp]
+    lib.okx_program_enable_axle_evaluation.restype = i32
+    lib.okx_precompile_axle_evaluation.argtypes = [C.POINTER(ProgramDesc), vp]
+    lib.okx_precompile_axle_evaluation.restype = i32
+    lib.okx_program_eval_columns.argtypes = [vp]
+    lib.okx_program_eval_columns.restype = i32
     if lib.okx_abi_version() != ABI_VERSION:
         raise RuntimeError("libokx.so ABI version mismatch")
     _lib = lib

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._abi import (EVAL_COLUMNS, EVAL_MAX_PIVOT, EVAL_MIN_PIVOT, EVAL_RATE_RACK_Y, EVAL_RATE_WHEEL_CENTER_X,
-                   EVAL_TANGENT_FLAGS, INFO_CONVERGED, INFO_DTYPE, INFO_FAILED, INFO_RESIDUAL_EXCEEDED, TANGENT_INFO_DTYPE,
+                   EVAL_AXLE_METRICS, EVAL_AXLE_ROLES, EVAL_TANGENT_FLAGS, INFO_CONVERGED, INFO_DTYPE, INFO_FAILED, INFO_RESIDUAL_EXCEEDED, TANGENT_INFO_DTYPE,
                    HostProgram, SolveOpts)
 from .program import ConstraintProgram
 
@@ -57,6 +57,26 @@ class EvaluatedResult(BatchResult):
 
     eval: torch.Tensor | None = None
     tangents: torch.Tensor | None = None
+
+    def corner(self, side_index: int) -> "EvaluatedResult":
+        """Of a composed axle's result (``eval [B, 1 + T, 64]``, ``okx.h`` OKX_EVAL_AXLE_*): one corner's block as a
+        corner-shaped result (a view; 0 = left, 1 = right; the tangent solve's pivots sit in the left block)."""
+        lo = EVAL_COLUMNS * side_index
+        return EvaluatedResult(self.positions, self.info_raw, self.free, self.eval[:, :, lo:lo + EVAL_COLUMNS], self.tangents)
+
+    @property
+    def axle_metrics(self) -> torch.Tensor:
+        """``[B, 7]`` axle-scope metrics in ``metrics.AXLE_METRIC_NAMES`` order (a composed axle's result)."""
+        return self.eval[:, 0, EVAL_AXLE_METRICS:EVAL_AXLE_METRICS + 7]
+
+    @property
+    def role_values(self) -> torch.Tensor:
+        """``[B, 8]`` rotation / hardware role values; ``role_rates`` ``[B, T, 8]`` their rates along every target's tangent."""
+        return self.eval[:, 0, EVAL_AXLE_ROLES:EVAL_AXLE_ROLES + 8]
+
+    @property
+    def role_rates(self) -> torch.Tensor:
+        return self.eval[:, 1:, EVAL_AXLE_ROLES:EVAL_AXLE_ROLES + 8]
 
     @property
     def metrics(self) -> torch.Tensor:
@@ -326,8 +346,13 @@ class DeviceProgram:
         role points compiles for 10 - 60 s unless ``__graft_entry__.build()`` has filled the cache); the numbers of the
         roles are kernel arguments, a call that only changes them costs nothing.
         """
+        from .metrics import AxleRoles
+
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.okx_program_enable_evaluation(self._handle, C.byref(roles)), "okx_program_enable_evaluation")
+            if isinstance(roles, AxleRoles):  # a composed axle: both corners' roles + rotation / hardware roles (okx_axle_roles)
+                _lib.check(self.lib.okx_program_enable_axle_evaluation(self._handle, C.byref(roles)), "okx_program_enable_axle_evaluation")
+            else:
+                _lib.check(self.lib.okx_program_enable_evaluation(self._handle, C.byref(roles)), "okx_program_enable_evaluation")
         self._roles = roles
 
     @property
@@ -339,12 +364,18 @@ class DeviceProgram:
     def evaluation_note(self) -> str:
         return self.lib.okx_program_evaluation_note(self._handle).decode()
 
+    @property
+    def eval_columns(self) -> int:
+        """Columns per row of ``eval`` for the evaluation last enabled: 24 (a corner), 64 (a composed axle), 0 (none)."""
+        return int(self.lib.okx_program_eval_columns(self._handle))
+
     def _eval_buffers(self, b: int, tangents, eval_out):
         p = self.program
+        columns = self.eval_columns or EVAL_COLUMNS
         if eval_out is None:
-            eval_out = torch.empty((b, 1 + p.n_targets, EVAL_COLUMNS), dtype=torch.float64, device=self.device)
-        elif eval_out.shape != (b, 1 + p.n_targets, EVAL_COLUMNS) or eval_out.dtype != torch.float64 or not eval_out.is_contiguous():
-            raise ValueError(f"eval_out must be a contiguous float64 [B, 1 + T, {EVAL_COLUMNS}] tensor")
+            eval_out = torch.empty((b, 1 + p.n_targets, columns), dtype=torch.float64, device=self.device)
+        elif eval_out.shape != (b, 1 + p.n_targets, columns) or eval_out.dtype != torch.float64 or not eval_out.is_contiguous():
+            raise ValueError(f"eval_out must be a contiguous float64 [B, 1 + T, {columns}] tensor")
         tan = None
         if isinstance(tangents, torch.Tensor):
             tan = tangents

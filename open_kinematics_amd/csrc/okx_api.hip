@@ -113,6 +113,12 @@ struct okx_program {
   int ev_lane_scratch;
   okx::EvalSpec ev_spec;     // the role points compiled into them
   okx::EvalScalars ev_cfg;   // the roles' numeric part, a kernel argument
+  // a composed axle's evaluated module (okx_program_enable_axle_evaluation): the same kernel slots, specialised to both
+  // corners' role points and the roles' points and kinds
+  bool ev_axle = false;
+  okx::AxleEvalSpec ev_axle_spec;
+  okx::EvalScalars ev_cfg_r;        // the right corner's numbers
+  okx::EvalRoleNum ev_roles[8];     // the roles' numbers
   char ev_note[256];         // why there are none / no lane form
 };
 
@@ -1200,6 +1206,8 @@ static int32_t solve_impl(okx_program* p, const okx_solve_opts* opts, int64_t n_
     qe.tan = d_tangents;
     qe.ev = d_eval;
     qe.cfg = p->ev_cfg;
+    qe.cfg_r = p->ev_cfg_r;
+    std::memcpy(qe.roles, p->ev_roles, sizeof(qe.roles));
     void* kargs[] = {evaluated ? (void*)&qe : (void*)&q};
     if (use_lane) {
       const long long chains_per_span = (span_ + a.chain_len - 1) / a.chain_len;
@@ -1368,6 +1376,7 @@ int32_t okx_program_enable_evaluation(okx_program* p, const okx_corner_roles* ro
   }
   p->ev_mod = mod;
   p->ev_spec = spec;
+  p->ev_axle = false;
   okx::eval_scalars_from_roles(*roles, &p->ev_cfg);
   // the lane form, for programs whose solves have one (failure only means the quad form serves every batch size)
   if (with_lane && !lane_built) {
@@ -1401,6 +1410,108 @@ int32_t okx_program_enable_evaluation(okx_program* p, const okx_corner_roles* ro
 
 int32_t okx_program_evaluation(const okx_program* p) { return p && p->ev_solve_u ? 1 | (p->ev_lane_u ? 2 : 0) : 0; }
 const char* okx_program_evaluation_note(const okx_program* p) { return p ? p->ev_note : ""; }
+int32_t okx_program_eval_columns(const okx_program* p) {
+  return p && p->ev_solve_u ? (p->ev_axle ? OKX_EVAL_AXLE_COLUMNS : OKX_EVAL_COLUMNS) : 0;
+}
+
+static int32_t check_axle_roles(const okx_axle_roles* roles, int32_t n_out) {
+  if (int32_t rc = check_corner_roles(&roles->left, n_out, "left")) return rc;
+  if (int32_t rc = check_corner_roles(&roles->right, n_out, "right")) return rc;
+  if (roles->n_roles < 0 || roles->n_roles > OKX_MAX_ROTATIONS) return fail(OKX_ERR_INVALID, "n_roles must be 0 .. %d", OKX_MAX_ROTATIONS);
+  return OKX_OK;
+}
+
+static void axle_numbers_from_roles(okx_program* p, const okx_axle_roles* roles) {
+  okx::eval_scalars_from_roles(roles->left, &p->ev_cfg);
+  okx::eval_scalars_from_roles(roles->right, &p->ev_cfg_r);
+  std::memset(p->ev_roles, 0, sizeof(p->ev_roles));
+  for (int k = 0; k < roles->n_roles; ++k) {
+    const okx_rotation_role& r = roles->roles[k];
+    okx::EvalRoleNum& n = p->ev_roles[k];
+    for (int i = 0; i < 3; ++i) n.design[i] = r.design[i], n.axis_point[i] = r.axis_point[i], n.axis_dir[i] = r.axis_dir[i];
+    n.scale = r.scale;
+  }
+}
+
+/* okx_program_enable_evaluation for a composed axle (pair-mode program): see okx.h. */
+int32_t okx_program_enable_axle_evaluation(okx_program* p, const okx_axle_roles* roles) {
+  if (!p || !roles) return fail(OKX_ERR_INVALID, "null program or roles");
+  if (int32_t rc = check_axle_roles(roles, p->host.n_out)) return rc;
+  attach_when_ready(p, true);
+  okx::AxleEvalSpec spec;
+  std::memset(&spec, 0, sizeof(spec));
+  std::string why;
+  if (!okx::axle_eval_spec_from_roles(p->host, *roles, &spec, &why)) return fail(OKX_ERR_INVALID, "%s", why.c_str());
+  {
+    std::shared_lock<std::shared_mutex> readers(*p->kern_mutex);
+    if (!p->quad_fn_u || p->quad_ppw != 8) {
+      const std::string note = p->quad_note[0] ? p->quad_note : "a single-mode program (use okx_program_enable_evaluation)";
+      readers.unlock();
+      std::unique_lock<std::shared_mutex> writer(*p->kern_mutex);
+      std::snprintf(p->ev_note, sizeof(p->ev_note), "no pair-mode quad kernel (%.180s)", note.c_str());
+      return fail(OKX_ERR_INVALID, "an axle's evaluated solves need the program's pair-mode quad kernel: %s", p->ev_note);
+    }
+    if (p->ev_solve_u && p->ev_axle && std::memcmp(&spec, &p->ev_axle_spec, sizeof(spec)) == 0) {
+      readers.unlock();
+      std::unique_lock<std::shared_mutex> writer(*p->kern_mutex);
+      axle_numbers_from_roles(p, roles);  // same points: only the numbers change (launches read them as kernel arguments)
+      return OKX_OK;
+    }
+  }
+  std::string code;
+  if (!okx::quad_axle_eval_build(p->host, spec, quad_waves_per_simd(), &code, &why)) {
+    std::unique_lock<std::shared_mutex> writer(*p->kern_mutex);
+    std::snprintf(p->ev_note, sizeof(p->ev_note), "%.250s", why.c_str());
+    return fail(OKX_ERR_LIMIT, "no evaluated kernels for this program: %s", why.c_str());
+  }
+  std::unique_lock<std::shared_mutex> kernels(*p->kern_mutex);
+  if (p->ev_mod) {
+    HIP_TRY(hipDeviceSynchronize());  // launches in flight may still run the modules about to be replaced
+    release_evaluation(p);
+  }
+  p->ev_note[0] = 0;
+  hipModule_t mod = nullptr;
+  if (hipModuleLoadData(&mod, code.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(OKX_ERR_DEVICE, "hipModuleLoadData failed for the evaluated module");
+  }
+  hipFunction_t su = nullptr;
+  if (hipModuleGetFunction(&su, mod, "okx_quad_evsolve_u") != hipSuccess ||
+      hipModuleGetFunction(&p->ev_solve_g, mod, "okx_quad_evsolve_g") != hipSuccess ||
+      hipModuleGetFunction(&p->ev_pos_u, mod, "okx_quad_evaluate_u") != hipSuccess ||
+      hipModuleGetFunction(&p->ev_pos_g, mod, "okx_quad_evaluate_g") != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipModuleUnload(mod);
+    p->ev_solve_g = p->ev_pos_u = p->ev_pos_g = nullptr;
+    return fail(OKX_ERR_DEVICE, "kernel symbols missing in the evaluated module");
+  }
+  if (hipModuleGetFunction(&p->ev_cold_u, mod, "okx_quad_evcold_u") != hipSuccess) {
+    (void)hipGetLastError();
+    p->ev_cold_u = nullptr;
+  }
+  p->ev_mod = mod;
+  p->ev_axle = true;
+  p->ev_axle_spec = spec;
+  axle_numbers_from_roles(p, roles);
+  p->ev_solve_u = su;  // the gate of the evaluated launch paths
+  return OKX_OK;
+}
+
+int32_t okx_precompile_axle_evaluation(const okx_program_desc* desc, const okx_axle_roles* roles) {
+  if (!desc || !roles) return fail(OKX_ERR_INVALID, "null pointer");
+  okx::DevProgram* tmp = new (std::nothrow) okx::DevProgram;
+  if (!tmp) return fail(OKX_ERR_ALLOC, "out of host memory");
+  int rc = okx::build_dev_program(desc, tmp, g_err, (int)sizeof(g_err));
+  if (rc == OKX_OK) rc = check_axle_roles(roles, tmp->n_out);
+  okx::AxleEvalSpec spec;
+  std::memset(&spec, 0, sizeof(spec));
+  std::string why, code;
+  if (rc == OKX_OK && !okx::axle_eval_spec_from_roles(*tmp, *roles, &spec, &why)) rc = fail(OKX_ERR_INVALID, "%s", why.c_str());
+  if (rc == OKX_OK && !okx::quad_axle_eval_build(*tmp, spec, quad_waves_per_simd(), &code, &why))
+    rc = fail(why.compare(0, 14, "compile failed") == 0 ? OKX_ERR_DEVICE : OKX_ERR_LIMIT, "no evaluated kernels for this program: %s", why.c_str());
+  delete tmp;
+  return rc;
+}
 
 int32_t okx_evaluate_batch(okx_program* p, int64_t n_problems, int64_t steps_per_geometry, const double* d_pos,
                            const double* d_geom_pos, const double* d_geom_row_param, double* d_tangents, double* d_eval,
@@ -1471,7 +1582,9 @@ int32_t okx_evaluate_batch(okx_program* p, int64_t n_problems, int64_t steps_per
   q.row_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, row_param));
   q.dop_param = reinterpret_cast<const double*>(base + offsetof(okx::DevProgram, dop_param));
   q.cfg = p->ev_cfg;
-  const long long waves = (n_problems + 15) / 16;
+  q.cfg_r = p->ev_cfg_r;
+  std::memcpy(q.roles, p->ev_roles, sizeof(q.roles));
+  const long long waves = (n_problems + p->quad_ppw - 1) / p->quad_ppw;
   const long long cap = (long long)p->n_cu * p->quad_waves_per_cu * 8;  // (a streaming launch: several rounds' worth of workgroups)
   void* kargs[] = {(void*)&q};
   HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->ev_pos_g : p->ev_pos_u, (int)(waves < cap ? waves : cap), 1, 1, okx::kWave, 1, 1, 0,

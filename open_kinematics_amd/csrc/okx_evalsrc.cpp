@@ -277,6 +277,81 @@ template <int N> DEV void ev_corner_metrics(const EvCfg& R, const DV<N>* P, Du<N
 )SRC";
 }  // namespace
 
+bool axle_eval_spec_from_roles(const DevProgram& P, const okx_axle_roles& R, AxleEvalSpec* spec, std::string* why) {
+  if (!eval_spec_from_roles(P, R.left, &spec->side[0], why)) {
+    *why = "left corner: " + *why;
+    return false;
+  }
+  if (!eval_spec_from_roles(P, R.right, &spec->side[1], why)) {
+    *why = "right corner: " + *why;
+    return false;
+  }
+  const EvalSpec &a = spec->side[0], &b = spec->side[1];
+  if (a.ia_kind != b.ia_kind || (a.damper_top < 0) != (b.damper_top < 0) || (a.rack < 0) != (b.rack < 0)) {
+    *why = "the two corners of an evaluated axle must share the instant-axis construction and the damper / rack roles";
+    return false;
+  }
+  if (R.n_roles < 0 || R.n_roles > 8) {
+    *why = "n_roles out of range";
+    return false;
+  }
+  spec->n_roles = R.n_roles;
+  for (int k = 0; k < 8; ++k) spec->role[k] = {0, -1, -1};
+  for (int k = 0; k < R.n_roles; ++k) {
+    const okx_rotation_role& r = R.roles[k];
+    if (r.kind < OKX_ROLE_AXIS_ROTATION || r.kind > OKX_ROLE_MIDPOINT_COORDINATE) {
+      *why = "unknown role kind";
+      return false;
+    }
+    const bool two = r.kind != OKX_ROLE_AXIS_ROTATION;
+    if (r.point < 0 || r.point >= P.n_out || (two && (r.point_b < 0 || r.point_b >= P.n_out))) {
+      *why = "role " + std::to_string(k) + " names a point outside the output list";
+      return false;
+    }
+    spec->role[k] = {r.kind, r.point, two ? r.point_b : -1};
+  }
+  return true;
+}
+
+namespace {
+// okx_metrics.hip axis_rotation_deg on the evaluated modules' duals (metrics/kernels.py:58-76, geometric.py:31-52;
+// axle/mechanisms.py:718-815,903-944 for the two-point kinds).  KIND is a compile-time constant of the call site.
+const char* kRolesBody = R"SRC(
+struct EvRoleNum { double design[3], axis_point[3], axis_dir[3], scale; };
+template <int N> DEV DV<N> dv_const(double x, double y, double z) { DV<N> r; r.x = du_const<N>(x); r.y = du_const<N>(y); r.z = du_const<N>(z); return r; }
+template <int KIND, int N> DEV Du<N> ev_role(const EvRoleNum& R, DV<N> moving, DV<N> other) {
+  const double kDeg = 57.29577951308232;
+  const DV<N> a = dv_const<N>(R.axis_dir[0], R.axis_dir[1], R.axis_dir[2]);
+  const DV<N> origin = dv_const<N>(R.axis_point[0], R.axis_point[1], R.axis_point[2]);
+  if (KIND != 0) {
+    const DV<N> span = dv_sub(moving, other);
+    if (KIND == 3) return du_sqrt(dv_dot(span, span));
+    const DV<N> mid = dv_add(moving, dv_scale(du_const<N>(0.5), dv_sub(other, moving)));
+    if (KIND == 4) return dv_dot(a, dv_sub(mid, origin));
+    if (KIND == 2) {
+      DV<N> stem = dv_sub(mid, origin);
+      const Du<N> len = du_sqrt(dv_dot(stem, stem));
+      if (!(len.v >= EV_EPS_GEOMETRIC)) return du_nan<N>();
+      stem = dv_unit(stem, len);
+      const DV<N> crossbar = dv_sub(span, dv_scale(dv_dot(span, stem), stem));
+      Du<N> twist = kDeg * du_atan2(dv_dot(stem, dv_cross(a, crossbar)), dv_dot(crossbar, a));
+      twist.v -= R.design[0];
+      return twist;
+    }
+    moving = mid;
+  }
+  const DV<N> dr = dv_const<N>(R.design[0] - R.axis_point[0], R.design[1] - R.axis_point[1], R.design[2] - R.axis_point[2]);
+  const DV<N> cr = dv_sub(moving, origin);
+  const DV<N> dperp = dv_sub(dr, dv_scale(dv_dot(dr, a), a)), cperp = dv_sub(cr, dv_scale(dv_dot(cr, a), a));
+  const double dn = dv_dot(dperp, dperp).v, cn = dv_dot(cperp, cperp).v;
+  if (!(dn >= EV_EPS_GEOMETRIC * EV_EPS_GEOMETRIC) || !(cn >= EV_EPS_GEOMETRIC * EV_EPS_GEOMETRIC)) return du_nan<N>();
+  return (R.scale * kDeg) * du_atan2(dv_dot(a, dv_cross(dr, cr)), dv_dot(dperp, cperp));
+}
+)SRC";
+}  // namespace
+
+std::string eval_roles_source() { return kRolesBody; }
+
 std::string eval_metrics_source(const EvalSpec& spec) {
   char line[128];
   std::string out;

@@ -330,6 +330,16 @@ bool quad_eval_build(const DevProgram& P, const EvalSpec& spec, int waves_per_si
   return true;
 }
 
+bool quad_axle_eval_build(const DevProgram& P, const AxleEvalSpec& spec, int waves_per_simd, std::string* code, std::string* why, bool cache_only) {
+  std::string src, err;
+  if (!quad_generate(P, waves_per_simd, &src, why, false, nullptr, &spec)) return false;
+  if (!quad_compile(src, code, &err, false, cache_only)) {
+    *why = err == kNotCached ? err : "compile failed: " + err;
+    return false;
+  }
+  return true;
+}
+
 // The lane form of the evaluated module: the emission variant whose okx_lane_evsolve_* kernels spill least (the search stops
 // at the first one without scratch); the choice is remembered next to the code objects like lane_build's.
 bool lane_eval_build(const DevProgram& P, const EvalSpec& spec, std::string* code, std::string* why, bool cache_only, int* scratch_out) {

@@ -123,13 +123,30 @@ bool eval_spec_from_roles(const DevProgram& P, const okx_corner_roles& roles, Ev
 void eval_scalars_from_roles(const okx_corner_roles& roles, EvalScalars* scalars);
 int eval_slot_point(const EvalSpec& spec, int slot);         // output-list index of a role slot (-1: absent)
 std::string eval_metrics_source(const EvalSpec& spec);       // role #defines + the catalog on duals
+// ---- composed axles (pair mode): both corners' catalogs, the axle-scope metrics and the hardware / rotation roles ----
+// The evaluated module of a pair-mode program (okx_program_enable_axle_evaluation) is specialised to BOTH corners' role
+// points and to the points (and kinds) of up to OKX_MAX_ROTATIONS roles of the kinds of okx_rotation_role; their numbers
+// travel as kernel arguments.  Row layout of d_eval: OKX_EVAL_AXLE_COLUMNS per row (okx.h).
+constexpr int kEvalAxleColumns = 64;
+struct EvalRoleSpec { int kind, point, point_b; };
+struct AxleEvalSpec {
+  EvalSpec side[2];
+  int n_roles;
+  EvalRoleSpec role[8];
+};
+struct EvalRoleNum { double design[3], axis_point[3], axis_dir[3], scale; };  // mirrors `struct EvRoleNum` of the generated source
+bool axle_eval_spec_from_roles(const DevProgram& P, const okx_axle_roles& roles, AxleEvalSpec* spec, std::string* why);
+std::string eval_roles_source();  // the role kinds of okx_rotation_role on duals (pair-mode modules only)
 // Arguments of the evaluated solve kernels okx_quad_evsolve_u/_g, okx_quad_evcold_u, okx_lane_evsolve_u/_g (mirrors
-// `struct QEvArgs`): the solve's own arguments, then what the epilogue writes and the roles' numeric part.
+// `struct QEvArgs`): the solve's own arguments, then what the epilogue writes and the roles' numeric part.  The generated
+// corner modules declare the struct up to `cfg`; pair-mode modules read the right corner's numbers and the roles' as well.
 struct QuadEvArgs {
   QuadArgs q;
   double* tan;    // [B][T][n_out][3] or null
-  double* ev;     // [B][1 + T][OKX_EVAL_COLUMNS] or null
+  double* ev;     // [B][1 + T][OKX_EVAL_COLUMNS] (pair mode: OKX_EVAL_AXLE_COLUMNS) or null
   EvalScalars cfg;
+  EvalScalars cfg_r;
+  EvalRoleNum roles[8];
 };
 // Arguments of okx_quad_evaluate_u/_g (mirrors `struct QEvPosArgs`): the same epilogue on given solved states.
 struct QuadEvPosArgs {
@@ -143,6 +160,8 @@ struct QuadEvPosArgs {
   const double* row_param;
   const double* dop_param;
   EvalScalars cfg;
+  EvalScalars cfg_r;       // (pair-mode modules only, like QuadEvArgs)
+  EvalRoleNum roles[8];
 };
 
 // A program made of two structurally identical halves joined by one distance row (the composed
@@ -175,8 +194,10 @@ bool build_pair_view(const DevProgram& P, PairView* pv, std::string* why);
 // `eval` non-null: the EVALUATED module of the program instead - the solve bodies with the tangent / metric epilogue
 // (kernels okx_quad_evsolve_u/_g, okx_quad_evcold_u) and the same epilogue on given states (okx_quad_evaluate_u/_g);
 // single mode only.
+// `axle_eval` non-null (pair-mode programs only): the evaluated module of a composed axle - the same kernel names; each half's
+// quad evaluates its own corner's catalog, the left one also the axle-scope metrics, both the roles.
 bool quad_generate(const DevProgram& P, int waves_per_simd, std::string* src, std::string* why, bool lds_homes = false,
-                   const EvalSpec* eval = nullptr);
+                   const EvalSpec* eval = nullptr, const AxleEvalSpec* axle_eval = nullptr);
 
 // Emits the HIP source of the LANE kernel specialised to `P` (okx_lanegen.cpp): one lane per problem, 64 problems per
 // wavefront, for batches that fill the chip several times over.  Kernels okx_lane_solve_u/_g (arguments: QuadArgs) and
@@ -243,5 +264,6 @@ bool quad_build(const DevProgram& P, int waves_per_simd, std::string* src, std::
 // kernel, lane (the emission variant with the least scratch in okx_lane_evsolve_*; remembered in the cache like lane_build's).
 bool quad_eval_build(const DevProgram& P, const EvalSpec& spec, int waves_per_simd, std::string* code, std::string* why, bool cache_only = false);
 bool lane_eval_build(const DevProgram& P, const EvalSpec& spec, std::string* code, std::string* why, bool cache_only = false, int* scratch_out = nullptr);
+bool quad_axle_eval_build(const DevProgram& P, const AxleEvalSpec& spec, int waves_per_simd, std::string* code, std::string* why, bool cache_only = false);
 
 }  // namespace okx

@@ -1199,16 +1199,23 @@ int quad_head_stride(const DevProgram& program) {
 }
 
 bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* src, std::string* why, bool lds_homes,
-                   const EvalSpec* es) {
+                   const EvalSpec* es, const AxleEvalSpec* aes) {
   // Small programs: one quad per problem.  Larger ones only when they are two identical halves
   // joined by one distance row (composed axle): one quad per half, a 2 x 2 Woodbury correction for the joint.
   PairView pair_store;
   const PairView* pv = nullptr;
   // EV: the evaluated module (okx_solve_evaluated_batch) - the solve bodies end in an epilogue that solves for the
   // solution-manifold tangents at the converged state and evaluates the metric catalog along them (okx_evalsrc.cpp)
+  // EVP: the evaluated module of a composed axle (pair mode): both corners' catalogs, the axle-scope metrics and the roles
+  const bool EVP = aes != nullptr;
+  if (EVP) es = &aes->side[0];  // (the catalog's compile-time switches: the same for both corners, axle_eval_spec_from_roles)
   const bool EV = es != nullptr;
-  if (EV && program.n_free > kQuadMaxFree) {
-    *why = "pair-mode programs have no evaluated module (their tangents and metrics run as separate launches)";
+  if (EV && !EVP && program.n_free > kQuadMaxFree) {
+    *why = "a pair-mode program takes its metric roles through okx_program_enable_axle_evaluation (both corners')";
+    return false;
+  }
+  if (EVP && program.n_free <= kQuadMaxFree) {
+    *why = "axle roles need a pair-mode program (two identical halves)";
     return false;
   }
   if (program.n_free > kQuadMaxFree) {
@@ -1509,9 +1516,40 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   for (int k = 0; k < nf; ++k) used[P.free_point[k]] = true;
 
+  // ---- evaluated pair module: where a program output point lives (which half, which of that half's MOVING points) ----
+  // The epilogue stages the velocities of the moving points only - [problem][target][half][moving point][3] - fixed points'
+  // are zero; a program record element maps to an offset in one problem-target block (kVelMap, -1: a fixed point).
+  std::vector<int> mov_index(NP, -1);  // side point -> index among the half's moving (free or derived) points
+  int MVN = 0;
+  if (EVP)
+    for (int p = 0; p < NP; ++p)
+      if (used[p] && (g.blk_of_point[p] >= 0 || g.dop_of_point[p] >= 0)) mov_index[p] = MVN++;
+  const int MV = 3 * MVN;
+  struct OutLoc { int side, point; };  // of a program output index (side -1: a fixed point neither half moves)
+  std::vector<OutLoc> out_loc(prog_out, OutLoc{-1, -1});
+  if (EVP)
+    for (int sd = 0; sd < 2; ++sd)
+      for (int k = 0; k < P.n_out; ++k)
+        if (pv->out[sd][k] >= 0 && (sd == 0 || pv->out[1][k] != pv->out[0][k])) out_loc[pv->out[sd][k]] = {sd, P.out_point[k]};
+  auto vel_offset = [&](int k) {  // offset of output point k's velocity inside a [half][moving point][3] block, -1: fixed
+    const OutLoc& l = out_loc[k];
+    if (l.side < 0 || mov_index[l.point] < 0) return -1;
+    return l.side * MV + 3 * mov_index[l.point];
+  };
   g.out += kPreamble;
   if (EV) {
     g.out += eval_metrics_source(*es);
+    if (EVP) {
+      g.out += eval_roles_source();
+      g.f("struct QEvArgs { QArgs q; double* tan; double* ev; EvCfg cfg; EvCfg cfg_r; EvRoleNum roles[8]; };");
+      std::string table = "__constant__ short kVelMap[" + std::to_string(3 * prog_out) + "] = {";
+      for (int k = 0; k < prog_out; ++k)
+        for (int cc2 = 0; cc2 < 3; ++cc2) {
+          const int off = vel_offset(k);
+          table += (k || cc2 ? ", " : "") + std::to_string(off < 0 ? -1 : off + cc2);
+        }
+      g.out += table + "};  // record element -> offset in a problem-target block of the staged velocities\n";
+    } else
     g.f("struct QEvArgs { QArgs q; double* tan; double* ev; EvCfg cfg; };");
     g.f("#define EV_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\"); } while (0)");
   }
@@ -1526,6 +1564,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("  int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x101F);");
     g.f("  return __hiloint2double(hi, lo);");
     g.f("}");
+    if (EVP) g.f("DEV Du<1> du_xq(Du<1> a) { Du<1> r; r.v = xq(a.v); r.d[0] = xq(a.d[0]); return r; }");
     g.f("DEV double PSUM(double v) { const double s = qsum(v); return s + xq(s); }");
     g.f("DEV double PMAX(double v) { const double s = qmax(v); return fmax(s, xq(s)); }");
     g.f("#define PJOIN_SUM(v) ((v) + xq(v))");
@@ -1574,7 +1613,236 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     epi_factor_src = ev.out;
     ev.out.clear();
   }
+  // ---- pair mode (a composed axle): ONE epilogue for the whole axle ----
+  // Each half's quad evaluates its half of J at the solved state; the undamped system is solved as in the passes (each
+  // half's own factor with its share of the joining rows' rank-one terms, the 2k x 2k Woodbury system for the rest), one
+  // substitution per PROGRAM target; the moving points' velocities are staged in LDS [problem][target][half][point][3].
+  // Then lane c of EACH quad evaluates direction c - 1 (lane 0 the values) of ITS corner's catalog - role points from the
+  // staged record, the left / right role indices selected on the side bit -; the left quad combines both corners'
+  // travel, contact patch and front-view instant centre (the partner's through ds_swizzle) into the axle-scope metrics
+  // (metrics/axle_metrics.py:21-95); the roles of okx_rotation_role's kinds are evaluated on the same duals.  Every lane
+  // stores its own row segment of d_eval [problem][1 + T][OKX_EVAL_AXLE_COLUMNS].
+  const int TP = prog_targets, RECP = 3 * prog_out, EVA = kEvalAxleColumns;
+  struct EvJob { int t, side, prog_t; };
+  std::vector<EvJob> ev_jobs;
+  if (EVP)
+    for (int t = 0; t < T; ++t)
+      for (int sd = 0; sd < 2; ++sd)
+        if (pv->tgt[sd][t] >= 0) ev_jobs.push_back({t, sd, pv->tgt[sd][t]});
+  auto pair_epilogue_src = [&](const std::string& contig) -> std::string {
+    ev.out.clear();
+    ev.reset_caches();
+    ev.f("    {  // ---- evaluated epilogue (axle): tangents at the solved state, both corners' metrics, axle metrics, roles ----");
+    ev.out += eval_src;
+    ev.out += couple_eval;
+    ev.f("    const double lambda = 0.0;  // (an undamped factorisation; shadows the solve's damping)");
+    for (int F = 0; F < nf; ++F)
+      for (int G = 0; G <= F; ++G)
+        if (ev.fillf[F][G])
+          for (int k = 0; k < 3; ++k) {
+            if (!(F == G && k == 2)) ev.f("    double %s;", Gen::Ln(F, G, k).c_str());
+            if (!ev.nz[F][G]) ev.f("    double %s = 0.0;", Gen::A(F, G, k).c_str());
+          }
+    if (NK > 1) ev.out += join_rank_one_src();
+    else
+      for (int k = 0; k < 3; ++k)
+        ev.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
+    ev.out += epi_factor_src;
+    ev.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
+    ev.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
+    if (NK > 1) {
+      const std::string keep = ev.out;  // (join_z_src works through ev.out)
+      const std::string z = join_z_src();
+      ev.out = keep + z;
+    } else {
+      std::vector<std::string> rhs_w;
+      for (int F = 0; F < nf; ++F) rhs_w.push_back(F == FU ? "cu" : "0.0");
+      for (int F = 0; F < nf; ++F) ev.f("    double nz%d;", F);
+      ev.f("    {");
+      ev.emit_substitute(rhs_w, "sz");
+      for (int F = 0; F < nf; ++F) ev.f("    nz%d = sz%d;", F, F);
+      ev.f("    }");
+      ev.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g);", FU);
+      ev.f("    const double sm_det = 1.0 - sm_g * sm_gp;");
+    }
+    ev.f("    if (c == 0 && !q1) vok[quad] = ok ? 0.0 : __builtin_nan(\"\");  // a fixed point's velocity: zero, or NaN with the rest");
+    for (const EvJob& job : ev_jobs) {
+      const int t = job.t;
+      ev.f("    {  // program target %d: (J^T J) q = J^T e_t, then the velocity of every moving point", job.prog_t);
+      ev.f("    const double ms = q1 == %d ? 1.0 : 0.0;  // the half that carries this target", job.side);
+      std::vector<std::string> rhs(nf, "0.0");
+      auto it = ev.target_j.find(t);
+      if (it != ev.target_j.end())
+        for (auto& fv : it->second) rhs[fv.first] = "(ms * " + Gen::sx(fv.second) + ")";
+      ev.emit_substitute(rhs, "ty");
+      if (NK > 1) {
+        ev.out += join_correct_src([&](int F) { return "ty" + std::to_string(F); },
+                                   [&](int F, const std::string& e) { return sfmt("    const double tq%d = %s;\n", F, e.c_str()); });
+      } else {
+        ev.f("    const double sm_s = qsum(cu * ty%d);", FU);
+        ev.f("    const double sm_c = (xq(sm_s) - sm_gp * sm_s) / sm_det;");
+        for (int F = 0; F < nf; ++F) ev.f("    const double tq%d = fma(-nz%d, sm_c, ty%d);", F, F, F);
+      }
+      const std::string vp = "w" + std::to_string(job.prog_t) + "_";
+      for (int p = 0; p < NP; ++p) {
+        if (!used[p] || ev.dop_of_point[p] >= 0) continue;
+        if (ev.blk_of_point[p] >= 0) ev.f("    const double %s%d = tq%d;", vp.c_str(), p, ev.blk_of_point[p]);
+        else ev.f("    const double %s%d = 0.0;", vp.c_str(), p);
+      }
+      for (int e = 0; e < P.n_derived; ++e)
+        if (!ev.derived_jvp(e, vp)) return std::string();
+      ev.f("    if (c < 3) {");
+      ev.f("      double* vs = vst + ((quad * %d + %d) * 2 + q1) * %d + c;", TP, job.prog_t, MV);
+      for (int p = 0; p < NP; ++p)
+        if (mov_index[p] >= 0) ev.f("      vs[%d] = ok ? %s%d : __builtin_nan(\"\");", 3 * mov_index[p], vp.c_str(), p);
+      ev.f("    }");
+      ev.f("    }");
+    }
+    ev.f("    EV_WAVE_SYNC();");
+    // tangents [B][T][n_out][3], when asked for: the staged velocities expanded to whole records (fixed points: zero)
+    ev.f("    if (ea.tan != nullptr) {");
+    ev.f("      if (%s) {", contig.c_str());
+    ev.f("        const long long ev_rem = a.n_problems - wu * %d;", PPW);
+    ev.f("        const int n_el = (int)(ev_rem < %d ? ev_rem : %d) * %d;", PPW, PPW, TP * RECP);
+    ev.f("        double* dst = ea.tan + wu * %d * %d;", PPW, TP * RECP);
+    ev.f("        for (int i = lane; i < n_el; i += 64) {");
+    ev.f("          const int blk = i / %d, el = i - blk * %d, off = kVelMap[el];  // blk = problem * T + target", RECP, RECP);
+    ev.f("          dst[i] = off >= 0 ? vst[blk * %d + off] : vok[blk / %d];", 2 * MV, TP);
+    ev.f("        }");
+    ev.f("      } else if (valid) {  // chains: a problem's tangents by its own eight lanes");
+    ev.f("        double* dst = ea.tan + bb * %d;", TP * RECP);
+    ev.f("        for (int i = lane & 7; i < %d; i += 8) {", TP * RECP);
+    ev.f("          const int blk = i / %d, el = i - blk * %d, off = kVelMap[el];", RECP, RECP);
+    ev.f("          dst[i] = off >= 0 ? vst[(quad * %d + blk) * %d + off] : vok[quad];", TP, 2 * MV);
+    ev.f("        }");
+    ev.f("      }");
+    ev.f("    }");
+    ev.f("    if (ea.ev != nullptr) {");
+    ev.f("      EvCfg cfg = ea.cfg;");
+    for (const char* field : {"side_sign", "design_wheel_center_z", "design_contact_patch_z", "design_rack_y", "wheelbase", "cg_z", "front_brake_bias"})
+      ev.f("      cfg.%s = q1 ? ea.cfg_r.%s : ea.cfg.%s;", field, field, field);
+    {
+      const EvalSpec &sl = aes->side[0], &sr = aes->side[1];
+      auto gp3 = [&](int kL, int kR, int comp) {  // a design coordinate of this half's role point in the geometry table
+        return Gen::sel(3 * program.out_point[kL] + comp, 3 * program.out_point[kR] + comp);
+      };
+      ev.f("      if (PG) {  // an ensemble's design references are its geometry's own");
+      ev.f("        cfg.design_wheel_center_z = gp[%s]; cfg.design_contact_patch_z = gp[%s];", gp3(sl.wheel_center, sr.wheel_center, 2).c_str(),
+           gp3(sl.contact_patch, sr.contact_patch, 2).c_str());
+      if (sl.rack >= 0) ev.f("        cfg.design_rack_y = gp[%s];", gp3(sl.rack, sr.rack, 1).c_str());
+      ev.f("      }");
+    }
+    ev.f("      const double ev_flags = (ok ? 1.0 : 0.0) + ((!ok || pmin <= %d * 2.220446049250313e-16 * pmax) ? 2.0 : 0.0);", 3 * nf * 2);
+    ev.f("      _Pragma(\"unroll 1\")");
+    ev.f("      for (int ep = 0; 4 * ep <= %d; ++ep) {", TP);
+    ev.f("        const int evt = 4 * ep + c - 1;  // this lane's direction: -1 the values, t the derivative along program target t");
+    ev.f("        const bool dir = evt >= 0 && evt < %d;", TP);
+    ev.f("        const double* ps = stage + quad * %d;", RECP);
+    ev.f("        const double* vq = vst + (quad * %d + (dir ? evt : 0)) * %d;  // this direction's block: [half][moving point][3]", TP, 2 * MV);
+    // a point as a dual vector: position from the staged record, velocity from the staged block (zero for the value lane
+    // and for fixed points); kL / kR = the output index this lane reads when it sits in the left / right half
+    auto load_point = [&](const std::string& dst, int kL, int kR) {
+      const int oL = vel_offset(kL), oR = vel_offset(kR);
+      for (int cc2 = 0; cc2 < 3; ++cc2) {
+        const std::string pos = kL == kR ? sfmt("ps[%d]", 3 * kL + cc2) : sfmt("ps[q1 ? %d : %d]", 3 * kR + cc2, 3 * kL + cc2);
+        std::string vel;
+        if (oL < 0 && oR < 0) vel = "0.0";
+        else if (oL == oR) vel = sfmt("dir ? vq[%d] : 0.0", oL + cc2);
+        else if (oL >= 0 && oR >= 0) vel = sfmt("dir ? vq[q1 ? %d : %d] : 0.0", oR + cc2, oL + cc2);
+        else vel = sfmt("(dir && (q1 ? %s : %s)) ? vq[%d] : 0.0", oR >= 0 ? "true" : "false", oL >= 0 ? "true" : "false", (oL >= 0 ? oL : oR) + cc2);
+        ev.f("        %s.%c.v = %s; %s.%c.d[0] = %s;", dst.c_str(), "xyz"[cc2], pos.c_str(), dst.c_str(), "xyz"[cc2], vel.c_str());
+      }
+    };
+    ev.f("        DV<1> RP[EV_SLOTS];");
+    for (int sl = 0; sl < kEvalSlots; ++sl) {
+      const int kL = eval_slot_point(aes->side[0], sl), kR = eval_slot_point(aes->side[1], sl);
+      if (kL < 0 || kR < 0) {
+        ev.f("        RP[%d].x = du_const<1>(0.0); RP[%d].y = du_const<1>(0.0); RP[%d].z = du_const<1>(0.0);", sl, sl, sl);
+        continue;
+      }
+      load_point("RP[" + std::to_string(sl) + "]", kL, kR);
+    }
+    ev.f("        Du<1> em[%d];", OKX_METRIC_COUNT);
+    ev.f("        ev_corner_metrics<1>(cfg, RP, em);");
+    // axle-scope metrics: own corner = this lane's half, partner = the other half's lane of the same direction
+    ev.f("        Du<1> am[8];");
+    ev.f("        {");
+    ev.f("          const Du<1> ow = em[%d], oc = RP[EV_SLOT_CONTACT_PATCH].z - du_const<1>(cfg.design_contact_patch_z);", OKX_METRIC_WHEEL_TRAVEL);
+    ev.f("          const Du<1> oy = RP[EV_SLOT_CONTACT_PATCH].y, oz = RP[EV_SLOT_CONTACT_PATCH].z;");
+    ev.f("          const Du<1> ofy = em[%d] - oy, ofz = em[%d] - oz;  // contact patch -> front-view instant centre (NaN: none)", OKX_METRIC_FVIC_Y, OKX_METRIC_FVIC_Z);
+    ev.f("          const Du<1> pw = du_xq(ow), pc = du_xq(oc), py = du_xq(oy), pz = du_xq(oz), pfy = du_xq(ofy), pfz = du_xq(ofz);");
+    ev.f("          const Du<1> trk = du_abs(oy - py);");
+    ev.f("          am[%d] = 0.5 * (ow + pw);", OKX_AXLE_METRIC_HEAVE);
+    ev.f("          am[%d] = 57.29577951308232 * du_atan2(ow - pw, trk);", OKX_AXLE_METRIC_ROLL);
+    ev.f("          am[%d] = (-0.5) * (oc + pc);", OKX_AXLE_METRIC_RIDE_HEIGHT_CHANGE);
+    ev.f("          am[%d] = trk;", OKX_AXLE_METRIC_TRACK);
+    ev.f("          am[%d] = du_nan<1>(); am[%d] = du_nan<1>(); am[7] = du_const<1>(0.0);", OKX_AXLE_METRIC_ROLL_CENTER_Y, OKX_AXLE_METRIC_ROLL_CENTER_Z);
+    ev.f("          const Du<1> den = ofy * pfz - ofz * pfy;");
+    ev.f("          if (fabs(den.v) >= EV_EPS_GEOMETRIC) {  // (false for NaN: a corner without a front-view instant centre)");
+    ev.f("            const Du<1> tt = ((py - oy) * pfz - (pz - oz) * pfy) / den;");
+    ev.f("            am[%d] = oy + tt * ofy; am[%d] = oz + tt * ofz;", OKX_AXLE_METRIC_ROLL_CENTER_Y, OKX_AXLE_METRIC_ROLL_CENTER_Z);
+    ev.f("          }");
+    if (aes->side[0].rack >= 0) ev.f("          am[%d] = RP[EV_SLOT_RACK].y - du_const<1>(cfg.design_rack_y);", OKX_AXLE_METRIC_RACK_DISPLACEMENT);
+    else ev.f("          am[%d] = du_nan<1>();", OKX_AXLE_METRIC_RACK_DISPLACEMENT);
+    ev.f("        }");
+    // roles: two consecutive roles of one kind are evaluated side by side (the left quad the first, the right quad the
+    // second); a role without such a partner is evaluated by both quads and stored by the left one
+    ev.f("        Du<1> rv[8];");
+    ev.f("        for (int k = 0; k < 8; ++k) rv[k] = du_const<1>(0.0);");
+    std::vector<std::pair<int, bool>> role_slots;  // (first role, paired)
+    for (int k = 0; k < aes->n_roles;) {
+      const bool paired = k + 1 < aes->n_roles && aes->role[k].kind == aes->role[k + 1].kind;
+      role_slots.push_back({k, paired});
+      k += paired ? 2 : 1;
+    }
+    for (auto& rs : role_slots) {
+      const int k = rs.first, k2 = rs.second ? k + 1 : k;
+      const EvalRoleSpec &ra = aes->role[k], &rb = aes->role[k2];
+      ev.f("        {  // role %d%s (kind %d)", k, rs.second ? " / the next" : "", ra.kind);
+      ev.f("          DV<1> ra_, rb_;");
+      load_point("ra_", ra.point, rb.point);
+      if (ra.kind != OKX_ROLE_AXIS_ROTATION) load_point("rb_", ra.point_b, rb.point_b);
+      else ev.f("          rb_ = ra_;");
+      if (rs.second) ev.f("          const EvRoleNum rn = q1 ? ea.roles[%d] : ea.roles[%d];", k2, k);
+      else ev.f("          const EvRoleNum rn = ea.roles[%d];", k);
+      ev.f("          rv[%d] = ev_role<%d, 1>(rn, ra_, rb_);", k, ra.kind);
+      ev.f("        }");
+    }
+    ev.f("        if (valid && evt < %d) {", TP);
+    ev.f("          double* eo = ea.ev + (bb * %d + evt + 1) * %d;", 1 + TP, EVA);
+    ev.f("          double* co = eo + (q1 ? %d : 0);  // this half's corner block", OKX_EVAL_COLUMNS);
+    ev.f("          if (evt < 0) {");
+    for (int k = 0; k < OKX_METRIC_COUNT; ++k) ev.f("            co[%d] = em[%d].v;", k, k);
+    ev.f("            co[19] = q1 ? 0.0 : pmin; co[20] = q1 ? 0.0 : pmax; co[21] = q1 ? 0.0 : ev_flags; co[22] = 0.0; co[23] = 0.0;");
+    ev.f("          } else {");
+    for (int k = 0; k < OKX_METRIC_COUNT; ++k) ev.f("            co[%d] = em[%d].d[0];", k, k);
+    ev.f("            co[19] = RP[EV_SLOT_WHEEL_CENTER].x.d[0]; co[20] = RP[EV_SLOT_WHEEL_CENTER].y.d[0]; co[21] = RP[EV_SLOT_WHEEL_CENTER].z.d[0];");
+    ev.f("            co[22] = %s; co[23] = 0.0;", aes->side[0].rack >= 0 ? "RP[EV_SLOT_RACK].y.d[0]" : "__builtin_nan(\"\")");
+    ev.f("          }");
+    ev.f("          if (!q1) {");
+    ev.f("            for (int k = 0; k < 8; ++k) eo[%d + k] = evt < 0 ? am[k].v : am[k].d[0];", 48);
+    for (int k = aes->n_roles; k < 8; ++k) ev.f("            eo[%d] = 0.0;  // (no such role)", 56 + k);
+    ev.f("          }");
+    ev.f("        }");
+    // (the role columns after the zero fill: the left quad's stores are ordered, the right quad writes other columns)
+    for (auto& rs : role_slots) {
+      const int k = rs.first;
+      if (rs.second)
+        ev.f("        if (valid && evt < %d) ea.ev[(bb * %d + evt + 1) * %d + %d + q1] = evt < 0 ? rv[%d].v : rv[%d].d[0];", TP, 1 + TP, EVA, 56 + k, k, k);
+      else
+        ev.f("        if (valid && evt < %d && !q1) ea.ev[(bb * %d + evt + 1) * %d + %d] = evt < 0 ? rv[%d].v : rv[%d].d[0];", TP, 1 + TP, EVA, 56 + k, k, k);
+    }
+    ev.f("      }");
+    ev.f("    }");
+    ev.f("    EV_WAVE_SYNC();  // (stage / vst are reused by the next problem of this wavefront)");
+    ev.f("    }");
+    std::string text = ev.out;
+    ev.out.clear();
+    ev.reset_caches();
+    return text;
+  };
   auto epilogue_src = [&](const std::string& contig) -> std::string {
+    if (EVP) return pair_epilogue_src(contig);
     ev.out.clear();
     ev.reset_caches();
     ev.f("    {  // ---- evaluated epilogue: tangents at the solved state, metrics and their derivatives along them ----");
@@ -1857,7 +2125,27 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   (void)cs_head;
   if (ev.lds_constants) {
     g.out += lds_decl;
+    if (EVP && CD) {
+      // evaluated axle, cold body: the epilogue's staged velocities take the place of what the passes no longer need once a
+      // unit is solved and stored - x / dx, the per-quad scalars, the free-coordinate stage - so that the kernel stays within
+      // the 40 KB that let four wavefronts share a CU (every unit re-initialises all of it)
+      auto even = [](int n) { return (n + 1) / 2 * 2; };
+      const int stage_n = even(PPW * RECP), xsl_n = even(64 * 2 * nf), lms_n = even(16 * (5 * T + 12)), fst_n = even(PPW * 3 * program.n_free);
+      const int vst_n = even(PPW * TP * 2 * MV);
+      const int union_n = xsl_n + lms_n + fst_n > vst_n ? xsl_n + lms_n + fst_n : vst_n;
+      g.f("  __shared__ __attribute__((aligned(16))) double arena[%d];  // [record stage | x, dx, per-quad scalars, free-coordinate stage  /  staged velocities]", stage_n + union_n);
+      g.f("  double* const stage = arena; double* const xsl = arena + %d; double* const lms = arena + %d; double* const fstage = arena + %d;",
+          stage_n, stage_n + xsl_n, stage_n + xsl_n + lms_n);
+      g.f("  double* const vst = arena + %d;  // velocities [problem][target][half][moving point][3] (%d doubles)", stage_n, vst_n);
+      g.f("  __shared__ double vok[%d];", PPW);
+    } else {
+    if (EVP) {
+      g.f("  __shared__ __attribute__((aligned(16))) double stage[%d];", PPW * RECP);
+      g.f("  __shared__ __attribute__((aligned(16))) double vst[%d];  // velocities [problem][target][half][moving point][3]", PPW * TP * 2 * MV);
+      g.f("  __shared__ double vok[%d];", PPW);
+    }
     g.f("  __shared__ double xsl[%d];  // accepted point, chain history and the step in hand [block][lane]", 64 * (CD ? 2 : 4) * nf);
+    }
     int n_fixed = 0;
     for (int p = 0; p < NP; ++p) n_fixed += ev.blk_of_point[p] < 0 && ev.dop_of_point[p] < 0;
     if (!fixed_in_regs) g.f("  __shared__ double psl[%d];  // fixed points [point][lane]", 64 * (n_fixed > 0 ? n_fixed : 1));
@@ -1936,7 +2224,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   // Every load of the prologue is issued before the first dependent instruction: first-step targets, chain
   // constants, points and (single mode) the predictor table's copy into LDS share one round trip.
-  if (pair_state_lds) g.f("    __shared__ double lms[%d];  // per-quad scalars [slot][quad side]", 16 * (5 * T + 12));
+  if (pair_state_lds && !(EVP && CD)) g.f("    __shared__ double lms[%d];  // per-quad scalars [slot][quad side]", 16 * (5 * T + 12));
   for (int t = 0; t < T; ++t) {
     char init[160];
     if (CD)  // the first unit's targets came with the staged tables; later units of the grid-stride loop load theirs here
@@ -2614,7 +2902,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       // cold body: the wavefront's free coordinates form one contiguous block (16 consecutive problems): through LDS and out in
       // 16-byte-per-lane rows like the records - whole cache lines for HBM, whole packets for a caller's pinned host buffer
       // (lane-by-lane 8-byte stores leave 24-byte fragments whose merging on the way out depends on timing)
-      g.f("    __shared__ __attribute__((aligned(16))) double fstage[%d * %d];", PPW, 3 * program.n_free);
+      if (!EVP) g.f("    __shared__ __attribute__((aligned(16))) double fstage[%d * %d];", PPW, 3 * program.n_free);
       g.f("    if (a.out_mode == 1) {");
       g.f("      if (c < 3) {");
       if (pv) g.f("        int q1f = q1; asm volatile(\"\" : \"+v\"(q1f));");
@@ -2647,7 +2935,36 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     }
     g.f("    }");
   }
-  if (EV) {
+  if (EVP) {
+    // evaluated axle: both halves' records are staged in any case (the epilogue gathers both corners' roles from them) and
+    // written as the output mode says - whole rows where the wavefront's eight records are contiguous
+    g.f("    if (c < 3) {");
+    g.f("      int q1s = q1; asm volatile(\"\" : \"+v\"(q1s));");
+    g.f("      double* st = stage + quad * %d + c;", RECP);
+    for (int k = 0; k < P.n_out; ++k) {
+      const int k0 = pv->out[0][k], k1 = pv->out[1][k];
+      if (k1 >= 0) g.f("      st[q1s ? %d : %d] = p%d;", 3 * k1, 3 * k0, P.out_point[k]);
+      else g.f("      if (!q1s) st[%d] = p%d;", 3 * k0, P.out_point[k]);
+    }
+    for (size_t k = 0; k < pv->shared_out.size(); ++k)
+      g.f("      if (!q1s) st[%d] = gp[%d + c];", 3 * pv->shared_out[k], 3 * pv->shared_pt[k]);
+    g.f("    }");
+    g.f("    EV_WAVE_SYNC();");
+    g.f("    if (a.out_mode == 0) {");
+    g.f("      if (unit_len == 1) {");
+    g.f("        const long long rem = a.n_problems - wu * %d;", PPW);
+    g.f("        const int n_doubles = (int)(rem < %d ? rem : %d) * %d;", PPW, PPW, RECP);
+    g.f("        double2* dst = reinterpret_cast<double2*>(a.out_pos + wu * %d * %d);", PPW, RECP);
+    g.f("        const double2* src = reinterpret_cast<const double2*>(stage);");
+    g.f("        for (int i = lane; i < n_doubles / 2; i += 64) dst[i] = src[i];");
+    g.f("        if ((n_doubles & 1) && lane == 0) a.out_pos[wu * %d * %d + n_doubles - 1] = stage[n_doubles - 1];", PPW, RECP);
+    g.f("      } else if (valid) {  // chains: a problem's record by its own eight lanes");
+    g.f("        double* o = a.out_pos + bb * %d;", RECP);
+    g.f("        for (int i = lane & 7; i < %d; i += 8) o[i] = stage[quad * %d + i];", RECP, RECP);
+    g.f("      }");
+    g.f("    }");
+    g.f("    if (false) {");
+  } else if (EV) {
     // evaluated module: the record is staged in any case (the epilogue gathers the metric roles from it) and written as
     // the output mode says - whole rows where the wavefront's records are contiguous
     g.f("    __shared__ __attribute__((aligned(16))) double stage[16 * %d];", 3 * P.n_out);
@@ -2827,6 +3144,77 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   const bool cold_body = head_ok;
   if (cold_body) emit_body(true);
   if (body_failed) return false;
+  if (EVP) {
+    // ---- the axle epilogue on GIVEN solved states (okx_evaluate_batch; reference core/sweep.py:217-245 for an AxleSuspension):
+    //      one quad per half - its fixed points from the geometry, its free points from the record, its derived points
+    //      re-evaluated by the solve kernel's own final-state code -, both halves' records staged, then the epilogue ----
+    std::vector<int> oi(NP, -1);
+    for (int k = 0; k < P.n_out; ++k) oi[P.out_point[k]] = k;
+    for (int F = 0; F < nf; ++F) {
+      const int k = oi[ev.fp(F)];
+      if (k < 0 || pv->out[0][k] < 0 || pv->out[1][k] < 0) {
+        *why = "an evaluated module needs every free point of both halves among the output points";
+        return false;
+      }
+    }
+    g.f("struct QEvPosArgs { const double* pos; const double* geom_pos; const double* geom_row_param; double* tan; double* ev;");
+    g.f("  long long n_problems, steps_per_geometry; const double* design_pos; const double* row_param; const double* dop_param; EvCfg cfg; EvCfg cfg_r; EvRoleNum roles[8]; };");
+    g.f("template <bool PG> DEV void okx_quad_evaluate_body(const QEvPosArgs& a) {");
+    g.f("  const QEvPosArgs& ea = a;");
+    g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1 = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
+    g.out += atan_decl;
+    g.out += lds_decl;
+    g.f("  const double e0 = c == 0 ? 1.0 : 0.0, e1 = c == 1 ? 1.0 : 0.0, e2 = c == 2 ? 1.0 : 0.0;");
+    g.f("  __shared__ __attribute__((aligned(16))) double stage[%d];", PPW * RECP);
+    g.f("  __shared__ __attribute__((aligned(16))) double vst[%d];  // velocities [problem][target][half][moving point][3]", PPW * TP * 2 * MV);
+    g.f("  __shared__ double vok[%d];", PPW);
+    g.f("  for (long long wu = blockIdx.x; wu * %d < a.n_problems; wu += gridDim.x) {", PPW);
+    g.f("    long long bb = wu * %d + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;", PPW);
+    g.f("    const long long geom = PG ? bb / a.steps_per_geometry : 0;");
+    g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * prog_points);
+    g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * prog_crows);
+    g.out += ev.hoisted;
+    g.out += couple_hoist;
+    for (int p = 0; p < NP; ++p)
+      if (used[p]) g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
+    for (int F = 0; F < nf; ++F) {
+      const int k = oi[ev.fp(F)];
+      g.f("    p%d = ld3(a.pos + bb * %d + %s + cc, c);", ev.fp(F), RECP, Gen::sel(3 * pv->out[0][k], 3 * pv->out[1][k]).c_str());
+    }
+    for (int t = 0; t < T; ++t) g.f("    const double tv%d = 0.0;  // target values do not enter the Jacobian", t);
+    g.f("    {");
+    g.out += final_src;
+    g.f("    }");
+    g.f("    if (c < 3) {");
+    g.f("      double* st = stage + quad * %d + c;", RECP);
+    for (int k = 0; k < P.n_out; ++k) {
+      const int k0 = pv->out[0][k], k1 = pv->out[1][k];
+      if (k1 >= 0) g.f("      st[q1 ? %d : %d] = p%d;", 3 * k1, 3 * k0, P.out_point[k]);
+      else g.f("      if (!q1) st[%d] = p%d;", 3 * k0, P.out_point[k]);
+    }
+    for (size_t k = 0; k < pv->shared_out.size(); ++k)
+      g.f("      if (!q1) st[%d] = gp[%d + c];", 3 * pv->shared_out[k], 3 * pv->shared_pt[k]);
+    g.f("    }");
+    g.f("    EV_WAVE_SYNC();");
+    {
+      const std::string epi = epilogue_src("true");
+      if (epi.empty()) {
+        *why = ev.why;
+        return false;
+      }
+      g.out += epi;
+    }
+    g.f("  }");
+    g.f("}");
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evaluate_u(QEvPosArgs a) { okx_quad_evaluate_body<false>(a); }", waves_per_simd);
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evaluate_g(QEvPosArgs a) { okx_quad_evaluate_body<true>(a); }", waves_per_simd);
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evsolve_u(QEvArgs ea) { okx_quad_body<false>(ea.q, ea); }", waves_per_simd);
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evsolve_g(QEvArgs ea) { okx_quad_body<true>(ea.q, ea); }", waves_per_simd);
+    if (cold_body)
+      g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evcold_u(QEvArgs ea) { okx_quad_cold_body(ea.q, ea); }", waves_per_simd);
+    *src = g.out;
+    return true;
+  }
   if (EV) {
     // ---- the same epilogue on GIVEN solved states (okx_evaluate_batch; reference core/sweep.py:217-245,
     //      evaluate_solved_sweep): free points from the records, fixed points from the geometry, every derived point

@@ -81,6 +81,34 @@ def make_roles(*, wheel_center: int, contact_patch: int, axle_inboard: int, axle
     )
 
 
+def roles_from_arrays(names, design, arrays, prefix: str = "", side_tag: str = "") -> tuple[CornerRoles, dict]:
+    """
+    ``okx_corner_roles`` from role NAMES kept as arrays (``roles`` = wheel-axis inboard / outboard and steering-axis lower /
+    upper point names, ``axis_kind`` / ``axis_points``, ``damper``, ``rack``, ``side_sign`` and the vehicle numbers - the
+    layout of the committed metric fixtures, ``oracle/gen_golden_metrics.py``): ``names`` = lower-case names of the
+    program's output points, ``design`` their design positions.  Returns the roles and the six basic role indices.
+    Used by the parity tests and by ``__graft_entry__.build()`` to precompile exactly the modules those tests ask for.
+    """
+    axle_in, axle_out, lower, upper = (side_tag + str(v).lower() for v in arrays[prefix + "roles"])
+    r = {"wheel_center": names.index(side_tag + "wheel_center"), "contact_patch": names.index(side_tag + "contact_patch_center"),
+         "axle_inboard": names.index(axle_in), "axle_outboard": names.index(axle_out),
+         "steer_lower": names.index(lower), "steer_upper": names.index(upper)}
+    local = [n[len(side_tag):] if side_tag and n.startswith(side_tag) else ("-" if side_tag else n) for n in names]
+    text = lambda key: str(arrays[prefix + key])  # noqa: E731
+    damper = [local.index(str(n)) for n in arrays[prefix + "damper"]]
+    bias = float(arrays[prefix + "front_brake_bias"])
+    rack = text("rack") if prefix + "rack" in arrays else ""
+    rack_idx = names.index(side_tag + rack) if rack else -1
+    roles = make_roles(
+        **r, side_sign=float(arrays[prefix + "side_sign"]), design_wheel_center_z=float(design[r["wheel_center"]][2]),
+        instant_axis=(text("axis_kind"), [local.index(str(n)) for n in arrays[prefix + "axis_points"]]),
+        damper=damper or None, rack_attachment=rack_idx, design_contact_patch_z=float(design[r["contact_patch"]][2]),
+        design_rack_y=float(design[rack_idx][1]) if rack else 0.0, wheelbase=float(arrays[prefix + "wheelbase"]),
+        cg_z=float(arrays[prefix + "cg_z"]), front_brake_bias=None if np.isnan(bias) else bias,
+        axle_position=text("axle_position") or None, driven_axle=text("driven_axle") or None)
+    return roles, r
+
+
 def corner_roles(suspension, program, side=None) -> CornerRoles:
     """
     Role indices into ``program.out_point`` from the corner's role hooks
@@ -292,6 +320,51 @@ def axle_hardware_metrics(axle, program, positions: torch.Tensor, tangents: torc
     if rates is not None:
         out.update({f"d_{n}": rates[:, :, k] for k, n in enumerate(names)})
     return out
+
+
+MAX_ROTATIONS = 8  # OKX_MAX_ROTATIONS
+
+
+class AxleRoles(C.Structure):
+    """ctypes mirror of ``okx_axle_roles``: both corners' roles and up to eight rotation / hardware roles."""
+
+    _fields_ = [("left", CornerRoles), ("right", CornerRoles), ("n_roles", C.c_int32), ("reserved", C.c_int32),
+                ("roles", RotationRole * MAX_ROTATIONS)]
+
+
+def _role_key(role: RotationRole) -> tuple:
+    return (role.kind, role.point, role.point_b, tuple(role.design), tuple(role.axis_point), tuple(role.axis_dir), role.scale)
+
+
+def axle_evaluation_roles(axle, program) -> tuple["AxleRoles", list, list]:
+    """
+    What ``DeviceProgram.enable_evaluation`` takes for a composed axle: ``(okx_axle_roles, rotation names, hardware
+    names)`` - both corners' roles, then the DISTINCT roles behind ``topology_rotation_roles`` (rocker angles, torsion-bar
+    twists - the same role as the rocker's -, U-bar arm angles) and ``hardware_roles`` (a T-bar's heave angle, twist and
+    centre travel, a heave link's length).  ``AxleRoles.column_of[name]`` is the role column of every name.
+    Raises ``ValueError`` when there are more than eight distinct roles.
+    """
+    left, right = axle_roles(axle, program)
+    rot_names, rot_roles = topology_rotation_roles(axle, program)
+    hw_names, hw_roles = hardware_roles(axle, program)
+    unique, column_of = [], {}
+    for name, role in zip(rot_names + hw_names, rot_roles + hw_roles):
+        key = _role_key(role)
+        for k, other in enumerate(unique):
+            if _role_key(other) == key:
+                column_of[name] = k
+                break
+        else:
+            column_of[name] = len(unique)
+            unique.append(role)
+    if len(unique) > MAX_ROTATIONS:
+        raise ValueError(f"an evaluated axle takes at most {MAX_ROTATIONS} rotation / hardware roles, got {len(unique)}")
+    # two consecutive roles of one kind are evaluated side by side (one per half): keep left / right partners adjacent
+    roles = AxleRoles(left=left, right=right, n_roles=len(unique))
+    for k, role in enumerate(unique):
+        roles.roles[k] = role
+    roles.column_of = column_of
+    return roles, rot_names, hw_names
 
 
 def axle_roles(axle, program) -> tuple[CornerRoles, CornerRoles]:

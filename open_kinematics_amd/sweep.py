@@ -172,7 +172,8 @@ def _corner_rows(corner, program, positions, tangents, side=None, rotation=None,
     if evaluated is not None:
         from ._abi import EVAL_RATE_RACK_Y, EVAL_RATE_WHEEL_CENTER_X
 
-        block = evaluated.eval.cpu().numpy()   # [B, 1 + T, 24]: ONE copy, the ratios below are host arithmetic
+        # [B, 1 + T, 24]: ONE copy, the ratios below are host arithmetic (an axle's caller hands over its corner's block)
+        block = evaluated if isinstance(evaluated, np.ndarray) else evaluated.eval.cpu().numpy()
         values = block[:, 0, : len(METRIC_NAMES)]
         derivatives = block[:, 1:, : len(METRIC_NAMES)]
         wc_rates = block[:, 1:, EVAL_RATE_WHEEL_CENTER_X : EVAL_RATE_WHEEL_CENTER_X + 3]
@@ -189,10 +190,10 @@ def _corner_rows(corner, program, positions, tangents, side=None, rotation=None,
     columns: "OrderedDict[str, Any]" = OrderedDict((n, values[:, METRIC_NAMES.index(n)]) for n in CATALOG_ORDER)
     rot_names, rot_values, rot_derivs = rotation if rotation is not None else ([], None, None)
     if rot_names:
-        rot_host = rot_values.cpu().numpy()
+        rot_host = _host(rot_values)
         for k, name in enumerate(rot_names):
             columns[name] = rot_host[:, k]
-        rot_derivs = rot_derivs.cpu().numpy() if have_rates and rot_derivs is not None else rot_derivs
+        rot_derivs = _host(rot_derivs) if have_rates and rot_derivs is not None else rot_derivs
     if have_rates:
         tgt_keys = [program.point_keys[p] for p in program.tgt_point]
         hub = [t for t, k in enumerate(tgt_keys) if k == key(PointID.WHEEL_CENTER)]
@@ -225,6 +226,11 @@ def _corner_rows(corner, program, positions, tangents, side=None, rotation=None,
             if name != "rocker_angle":
                 add(name, "hub_z", rot_derivs[:, :, k])
     return _rows_from_columns(columns)
+
+
+def _host(array):
+    """A device tensor's host copy; host arrays pass through."""
+    return array if isinstance(array, np.ndarray) else array.cpu().numpy()
 
 
 def _rows_from_columns(columns) -> list:
@@ -282,6 +288,14 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
             rows = _corner_rows(suspension, program, positions, evaluated.tangents, None, (names, rot_values, rot_derivs),
                                 evaluated=evaluated)
             return SweepMetricsResult(rows, None, solve_infos_from_records(evaluated.tangent_info(), program.n_vars))
+    if is_axle and program.n_targets > 0:
+        # a composed axle: tangents, both corners' catalogs, the axle-scope metrics and the rotation / hardware roles in ONE
+        # launch on the given states (the pair-mode evaluated module)
+        enabled = _enable_axle_evaluation(dp, suspension, program)
+        if enabled is not None:
+            evaluated = dp.evaluate(positions)
+            rows = _axle_rows_from_evaluated(suspension, program, evaluated, *enabled)
+            return SweepMetricsResult(rows, None, solve_infos_from_records(evaluated.tangent_info(), program.n_vars))
     if program.n_targets > 0:
         try:
             tangents, tinfo = dp.tangents(positions)
@@ -305,18 +319,37 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
                                       suspension.actuator_dofs())
     left, right = axle_roles(suspension, program)
     axle_values = axle_state_metrics(left, right, positions).cpu().numpy()
-    arm = {side: names.index(f"arb_arm_angle_{side.name.lower()}") for side in (Side.LEFT, Side.RIGHT)} \
-        if "arb_arm_angle_left" in names else None
-    tgt_keys = [program.point_keys[p] for p in program.tgt_point]
-    rows = []
-    for s in range(len(states)):
-        axle_row = OrderedDict((n, _none_if_nan(axle_values[s, k])) for k, n in enumerate(AXLE_METRIC_NAMES))
-        rows.append(AxleMetricRows(axle_row, {side: per_side[side][s] for side in (Side.LEFT, Side.RIGHT)}))
     from .enums import PointID, PointRef
     from .metrics import axle_hardware_metrics
 
     hub_rates = {side: tangents[:, :, out_keys.index(PointRef(side, PointID.WHEEL_CENTER)), 2].cpu().numpy()
                  for side in (Side.LEFT, Side.RIGHT)} if tangents is not None else {}
+    hardware = {k: _host(v) for k, v in axle_hardware_metrics(suspension, program, positions, tangents).items()}
+    rows = _axle_rows(program, len(states), per_side, axle_values, names, None if rot_values is None else _host(rot_values),
+                      None if rot_derivs is None else _host(rot_derivs), hardware, hub_rates)
+    return SweepMetricsResult(rows, derivative_error, tangent_infos)
+
+
+def _axle_rows(program, n_states: int, per_side: dict, axle_values, names, rot_values, rot_derivs, hardware: dict, hub_rates: dict) -> list:
+    """
+    ``AxleMetricRows`` per state from host arrays: the two corners' rows, the axle-scope metrics ``[B, 7]``, the rotation
+    roles (``names`` / ``rot_values [B, K]`` / ``rot_derivs [B, T, K]`` of ``topology_rotation_roles``), the shared
+    hardware's values and rates (``axle_hardware_metrics``' dictionary) and each side's wheel-centre z rate ``[B, T]``
+    (empty: no derivative columns).  Order: ``axle/suspension.py:213-238``.
+    """
+    from collections import OrderedDict
+
+    from .enums import PointID, PointRef, Side
+    from .metrics import AXLE_METRIC_NAMES
+
+    arm = {side: names.index(f"arb_arm_angle_{side.name.lower()}") for side in (Side.LEFT, Side.RIGHT)} \
+        if "arb_arm_angle_left" in names else None
+    tgt_keys = [program.point_keys[p] for p in program.tgt_point]
+    rows = []
+    for s in range(n_states):
+        axle_row = OrderedDict((n, _none_if_nan(axle_values[s, k])) for k, n in enumerate(AXLE_METRIC_NAMES))
+        rows.append(AxleMetricRows(axle_row, {side: per_side[side][s] for side in (Side.LEFT, Side.RIGHT)}))
+    have_rates = bool(hub_rates)
 
     def hub_z_columns(response: str, rate) -> dict:
         """``deriv_<response>_wrt_hub_z_<side>`` per side from the response's rate along every target's tangent."""
@@ -325,37 +358,79 @@ def compute_sweep_metrics(suspension, sweep_config, states, *, device=None) -> S
             key = PointRef(side, PointID.WHEEL_CENTER)
             cand = [t for t, k in enumerate(tgt_keys) if k == key]
             column = f"deriv_{response}_wrt_hub_z_{side.name.lower()}"
-            columns[column] = _driver_ratio(rate.cpu().numpy(), hub_rates[side], cand, column)
+            columns[column] = _driver_ratio(rate, hub_rates[side], cand, column)
         return columns
 
     # the shared hardware's state metrics, then its derivative columns: anti-roll bar first, heave link second
     # (axle/suspension.py:213-238)
     state_columns: OrderedDict = OrderedDict()
     deriv_columns: OrderedDict = OrderedDict()
-    hardware = axle_hardware_metrics(suspension, program, positions, tangents)
     if arm is not None:  # U-bar: arm angles about the bar's axis; the twist is their difference
-        state_columns["arb_twist"] = (rot_values[:, arm[Side.LEFT]] - rot_values[:, arm[Side.RIGHT]]).cpu().numpy()
-        if tangents is not None:
+        state_columns["arb_twist"] = rot_values[:, arm[Side.LEFT]] - rot_values[:, arm[Side.RIGHT]]
+        if have_rates:
             deriv_columns.update(hub_z_columns("arb_twist", rot_derivs[:, :, arm[Side.LEFT]] - rot_derivs[:, :, arm[Side.RIGHT]]))
     if "t_bar_heave_angle" in hardware:  # rigid T-bar (axle/mechanisms.py:718-797)
-        state_columns["t_bar_heave_angle"] = hardware["t_bar_heave_angle"].cpu().numpy()
-        state_columns["arb_twist"] = hardware["arb_twist"].cpu().numpy()
-        if tangents is not None:
+        state_columns["t_bar_heave_angle"] = hardware["t_bar_heave_angle"]
+        state_columns["arb_twist"] = hardware["arb_twist"]
+        if have_rates:
             center, twist = hub_z_columns("t_bar_center_x", hardware["d_t_bar_center_x"]), hub_z_columns("arb_twist", hardware["d_arb_twist"])
             for side in ("left", "right"):  # per driver: centre travel, then twist
                 for columns in (center, twist):
                     deriv_columns.update({k: v for k, v in columns.items() if k.endswith("_" + side)})
     if "heave_link_length" in hardware:  # mechanisms.py:903-944
-        state_columns["heave_link_length"] = hardware["heave_link_length"].cpu().numpy()
-        if tangents is not None:
+        state_columns["heave_link_length"] = hardware["heave_link_length"]
+        if have_rates:
             deriv_columns.update(hub_z_columns("heave_link_length", hardware["d_heave_link_length"]))
-    arm_values = {side: rot_values[:, arm[side]].cpu().numpy() for side in arm} if arm is not None else {}
+    arm_values = {side: rot_values[:, arm[side]] for side in arm} if arm is not None else {}
     for s, row in enumerate(rows):
         for name, col in (*state_columns.items(), *deriv_columns.items()):
             row.axle[name] = _none_if_nan(col[s])
         for side, col in arm_values.items():
             row.corners[side]["arb_arm_angle"] = _none_if_nan(col[s])
-    return SweepMetricsResult(rows, derivative_error, tangent_infos)
+    return rows
+
+
+def _axle_rows_from_evaluated(suspension, program, evaluated, roles, rot_names, hw_names) -> list:
+    """The rows of ``compute_sweep_metrics`` for a composed axle from ONE evaluated launch (``okx.h`` OKX_EVAL_AXLE_*):
+    both corners' blocks, the axle-scope metrics and the role columns of ``metrics.axle_evaluation_roles``."""
+    from ._abi import (EVAL_AXLE_LEFT, EVAL_AXLE_METRICS, EVAL_AXLE_RIGHT, EVAL_AXLE_ROLES, EVAL_COLUMNS,
+                       EVAL_RATE_WHEEL_CENTER_Z)
+    from .enums import Side
+
+    block = evaluated.eval.cpu().numpy()  # [B, 1 + T, 64]: ONE copy
+    column = lambda name: EVAL_AXLE_ROLES + roles.column_of[name]  # noqa: E731
+    rot_values = np.stack([block[:, 0, column(n)] for n in rot_names], axis=1) if rot_names else None
+    rot_derivs = np.stack([block[:, 1:, column(n)] for n in rot_names], axis=2) if rot_names else None
+    per_side, hub_rates = {}, {}
+    for side, lo in ((Side.LEFT, EVAL_AXLE_LEFT), (Side.RIGHT, EVAL_AXLE_RIGHT)):
+        tag = side.name.lower()
+        mine = [k for k, n in enumerate(rot_names) if n.endswith("_" + tag) and not n.startswith("arb_arm_angle")]
+        sub = ([rot_names[k][: -len(tag) - 1] for k in mine],
+               None if rot_values is None else rot_values[:, mine], None if rot_derivs is None else rot_derivs[:, :, mine])
+        corner_block = block[:, :, lo:lo + EVAL_COLUMNS]
+        per_side[side] = _corner_rows(suspension.corners[side], program, None, None, side, sub, suspension.actuator_dofs(),
+                                      evaluated=corner_block)
+        hub_rates[side] = corner_block[:, 1:, EVAL_RATE_WHEEL_CENTER_Z]
+    hardware = {}
+    for n in hw_names:
+        hardware[n] = block[:, 0, column(n)]
+        hardware["d_" + n] = block[:, 1:, column(n)]
+    return _axle_rows(program, block.shape[0], per_side, block[:, 0, EVAL_AXLE_METRICS:EVAL_AXLE_METRICS + 7], rot_names,
+                      rot_values, rot_derivs, hardware, hub_rates)
+
+
+def _enable_axle_evaluation(dp, suspension, program):
+    """``(roles, rotation names, hardware names)`` once the program's axle evaluated kernels are loaded; None when it has
+    none (no pair-mode kernel, more than eight roles, a role point outside the outputs, no compiler)."""
+    from .metrics import axle_evaluation_roles
+
+    try:
+        roles, rot_names, hw_names = axle_evaluation_roles(suspension, program)
+        dp.wait_ready()  # (the evaluated module is the generated pair kernel's: not while the interpreter still serves)
+        dp.enable_evaluation(roles)
+    except (ValueError, RuntimeError):
+        return None
+    return roles, rot_names, hw_names
 
 
 def _evaluate_states(dp, suspension, program, positions, want_tangents: bool):
@@ -440,21 +515,33 @@ def solve_evaluated_sweep(suspension, sweep_config, solver_config: SolverConfig 
     its metric rows.  For a corner whose program has evaluated kernels the whole of it - every step's solve, its
     solution-manifold tangents, the metric catalog and the derivative columns - is ONE kernel launch
     (``okx_solve_evaluated_batch``: the tangents and metrics are the solve kernel's epilogue, taken at the converged state
-    while it is still in registers); axles and programs without such kernels solve first and evaluate after
-    (``evaluate_solved_sweep``).  Same states, same error behaviour as ``solve_sweep``.
+    while it is still in registers); so is a composed axle's (both corners' catalogs, the axle-scope metrics and the
+    rotation / hardware roles: the pair-mode evaluated module); programs without such kernels solve first and evaluate
+    after (``evaluate_solved_sweep``).  Same states, same error behaviour as ``solve_sweep``.
     """
-    from .metrics import axis_rotation_metrics, corner_roles, topology_rotation_roles
+    from .metrics import axis_rotation_metrics, axle_evaluation_roles, corner_roles, topology_rotation_roles
     from .sensitivity import solve_infos_from_records
 
     validate_sweep_controls(sweep_config, suspension.actuator_dofs())
-    fused = not hasattr(suspension, "corners") and getattr(suspension, "config", True) is not None and sweep_config.n_steps > 0
+    is_axle = hasattr(suspension, "corners")
+    fused = getattr(suspension, "config", True) is not None and sweep_config.n_steps > 0
     if fused:
+        axle_parts = []
+
         def roles_of(program):
+            if is_axle:  # both corners' roles and the rotation / hardware roles: everything a row needs, no tangent tensor
+                axle_parts[:] = axle_evaluation_roles(suspension, program)
+                return axle_parts[0], False
             return corner_roles(suspension, program), bool(topology_rotation_roles(suspension, program)[0])
 
         states, stats, extra = solve_suspension_sweep(
             initial_state=suspension.initial_state(), constraints=suspension.constraints(), sweep_config=sweep_config,
             derived_manager=suspension.derived_spec(), solver_config=solver_config, device=device, evaluation=roles_of)
+        if extra is not None and is_axle:
+            program, evaluated = extra
+            rows = _axle_rows_from_evaluated(suspension, program, evaluated, *axle_parts)
+            metrics = SweepMetricsResult(rows, None, solve_infos_from_records(evaluated.tangent_info(), program.n_vars))
+            return EvaluatedSweep(states, stats, metrics, _derivative_issues(metrics))
         if extra is not None:
             program, evaluated = extra
             names, roles = topology_rotation_roles(suspension, program)

@@ -29,20 +29,9 @@ def _need_gpu():
 
 def _roles_from(names, design, mg, prefix="", side_tag=""):
     """okx_corner_roles from a metrics golden's role names (design = design positions of the output points)."""
-    from open_kinematics_amd.metrics import make_roles
+    from open_kinematics_amd.metrics import roles_from_arrays
 
-    r = role_indices_by_name(names, mg, prefix, side_tag)
-    local = [n[len(side_tag):] if side_tag and n.startswith(side_tag) else ("-" if side_tag else n) for n in names]
-    g = geometry_kwargs(local, mg, prefix)
-    rack = str(mg[prefix + "rack"]) if prefix + "rack" in mg else ""
-    rack_idx = names.index(side_tag + rack) if rack else -1
-    roles = make_roles(
-        **r, side_sign=float(mg[prefix + "side_sign"]), design_wheel_center_z=float(design[r["wheel_center"]][2]),
-        instant_axis=(g["axis_kind"], g["axis_idx"]), damper=g["damper_idx"], rack_attachment=rack_idx,
-        design_contact_patch_z=float(design[r["contact_patch"]][2]),
-        design_rack_y=float(design[rack_idx][1]) if rack else 0.0, wheelbase=g["wheelbase"], cg_z=g["cg_z"],
-        front_brake_bias=g["front_brake_bias"], axle_position=g["axle_position"], driven_axle=g["driven_axle"])
-    return roles, r
+    return roles_from_arrays(names, design, mg, prefix, side_tag)
 
 
 def _roles(program, mg):
