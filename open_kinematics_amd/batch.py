@@ -427,7 +427,7 @@ class DeviceProgram:
         return launch
 
     def evaluate(self, positions, *, roles=None, tangents=False, eval_out=None, geom_pos=None, geom_row_param=None,
-                 steps_per_geometry: int = 0) -> EvaluatedResult:
+                 steps_per_geometry: int = 0, info_raw=None) -> EvaluatedResult:
         """
         ``okx_evaluate_batch``: the same epilogue on GIVEN solved states ``positions [B, n_out, 3]`` - the reference's
         ``evaluate_solved_sweep`` (``core/sweep.py:217-245``) in one launch instead of tangents -> metrics.
@@ -452,7 +452,8 @@ class DeviceProgram:
             rc = self.lib.okx_evaluate_batch(self._handle, b, int(steps_per_geometry), _ptr(pos), _ptr(geom_pos),
                                              _ptr(geom_row_param), _ptr(tan), _ptr(ev), C.c_void_p(stream))
         _lib.check(rc, "okx_evaluate_batch")
-        info = torch.zeros((0, INFO_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
+        # (``info_raw``: the info records of the solve these states came from, carried through to the result)
+        info = info_raw if info_raw is not None else torch.zeros((0, INFO_DTYPE.itemsize), dtype=torch.uint8, device=self.device)
         return EvaluatedResult(pos, info, None, ev, tan)
 
     def solve(self, targets, **kw) -> BatchResult:

@@ -245,7 +245,8 @@ def dropin_program(initial_state, constraints, sweep_config, derived_manager, so
 
 
 def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_manager,
-                           solver_config=SolverConfig(), *, output_points=None, device=None, evaluation=None):
+                           solver_config=SolverConfig(), *, output_points=None, device=None, evaluation=None,
+                           evaluation_fused: bool | None = None):
     """
     Solve every step of a sweep on the GPU (reference ``solver.py:654-776``).
 
@@ -258,6 +259,11 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     want_tangents)``.  The launch that solves the sweep then also evaluates it (``okx_solve_evaluated_batch``: tangents
     and metrics as the solve kernel's epilogue) and a third value is returned: ``(program, EvaluatedResult)``, or ``None``
     when this sweep had to be solved without (no evaluated kernels for the program, target rows that change between steps).
+    ``evaluation_fused``: True = that one launch; False = two launches, the solve and then ``okx_evaluate_batch`` on its
+    records still in HBM - a warm-started sweep is a CHAIN, whose steps one quad walks one after the other, and the fused
+    epilogue lengthens every step of it, while the given-states kernel evaluates all steps side by side: for the sweeps
+    the drop-in sees (tens of steps) the two launches finish sooner (``tools/dropin_latency.py``).  None (default): two
+    launches for warm-started sweeps, one for independent cold starts (``warm_start=False``).
     """
     import torch
 
@@ -273,13 +279,17 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     dp = _device_program(program, device)
     n_steps = table.shape[0]
     solve, evaluated, fused = dp.solve, None, False
+    one_launch = (not cfg.warm_start) if evaluation_fused is None else bool(evaluation_fused)
     if evaluation is not None and program.n_targets > 0:
         try:
             roles, want_tangents = evaluation(program)
             dp.enable_evaluation(roles)
 
             def solve(targets, **kw):  # noqa: F811 - the same launch, ending in the evaluation epilogue
-                return dp.solve_evaluated(targets, tangents=want_tangents, **kw)
+                if one_launch:
+                    return dp.solve_evaluated(targets, tangents=want_tangents, **kw)
+                plain = dp.solve(targets, **kw)   # (both launches are asynchronous: the records never leave HBM in between)
+                return dp.evaluate(plain.positions, tangents=want_tangents, info_raw=plain.info_raw)
 
             fused = True
         except (ValueError, RuntimeError):  # no evaluated kernels for this program: solve now, evaluate after

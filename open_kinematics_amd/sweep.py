@@ -509,7 +509,8 @@ def evaluate_solved_sweep(suspension, sweep_config, states, solver_stats, *, dev
     return EvaluatedSweep(states, solver_stats, metrics, _derivative_issues(metrics))
 
 
-def solve_evaluated_sweep(suspension, sweep_config, solver_config: SolverConfig = SolverConfig(), *, device=None) -> EvaluatedSweep:
+def solve_evaluated_sweep(suspension, sweep_config, solver_config: SolverConfig = SolverConfig(), *, device=None,
+                          fused: bool | None = None) -> EvaluatedSweep:
     """
     Drop-in for ``kinematics.core.sweep.solve_evaluated_sweep`` (``core/sweep.py:248-270``): solve one sweep and compute
     its metric rows.  For a corner whose program has evaluated kernels the whole of it - every step's solve, its
@@ -517,15 +518,17 @@ def solve_evaluated_sweep(suspension, sweep_config, solver_config: SolverConfig 
     (``okx_solve_evaluated_batch``: the tangents and metrics are the solve kernel's epilogue, taken at the converged state
     while it is still in registers); so is a composed axle's (both corners' catalogs, the axle-scope metrics and the
     rotation / hardware roles: the pair-mode evaluated module); programs without such kernels solve first and evaluate
-    after (``evaluate_solved_sweep``).  Same states, same error behaviour as ``solve_sweep``.
+    after (``evaluate_solved_sweep``).  ``fused``: see ``solver.solve_suspension_sweep(evaluation_fused=)`` - by default a
+    warm-started sweep is solved as its chain and then evaluated by ONE more launch on the records in HBM (every step side by
+    side), independent cold starts (``warm_start=False``) in the one fused launch; no host round trip either way.  Same states, same error behaviour as ``solve_sweep``.
     """
     from .metrics import axis_rotation_metrics, axle_evaluation_roles, corner_roles, topology_rotation_roles
     from .sensitivity import solve_infos_from_records
 
     validate_sweep_controls(sweep_config, suspension.actuator_dofs())
     is_axle = hasattr(suspension, "corners")
-    fused = getattr(suspension, "config", True) is not None and sweep_config.n_steps > 0
-    if fused:
+    with_metrics = getattr(suspension, "config", True) is not None and sweep_config.n_steps > 0
+    if with_metrics:
         axle_parts = []
 
         def roles_of(program):
@@ -536,7 +539,8 @@ def solve_evaluated_sweep(suspension, sweep_config, solver_config: SolverConfig 
 
         states, stats, extra = solve_suspension_sweep(
             initial_state=suspension.initial_state(), constraints=suspension.constraints(), sweep_config=sweep_config,
-            derived_manager=suspension.derived_spec(), solver_config=solver_config, device=device, evaluation=roles_of)
+            derived_manager=suspension.derived_spec(), solver_config=solver_config, device=device, evaluation=roles_of,
+            evaluation_fused=fused)
         if extra is not None and is_axle:
             program, evaluated = extra
             rows = _axle_rows_from_evaluated(suspension, program, evaluated, *axle_parts)

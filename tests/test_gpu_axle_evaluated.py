@@ -181,7 +181,8 @@ def test_per_geometry_tables_use_each_geometrys_design_references(golden):
 
 @pytest.mark.parametrize("name,metrics_name", [("c3_axle_grid", "axle_c3"), ("t_axle_heave_link", "axle_heave_link")])
 def test_solve_evaluated_sweep_of_an_axle_is_one_launch_and_matches_the_reference(golden, name, metrics_name, monkeypatch):
-    """The drop-in: solve_evaluated_sweep(AxleSuspension) = solve_sweep + compute_sweep_metrics, from ONE kernel launch."""
+    """The drop-in: solve_evaluated_sweep(AxleSuspension) = solve_sweep + compute_sweep_metrics, from ONE kernel launch
+    (fused=True) or from the solve and one evaluation launch on its records (the default for a warm-started chain)."""
     from open_kinematics_amd import batch, sweep as sweep_mod
     from open_kinematics_amd.enums import Side
     from open_kinematics_amd.input import build_suspension, build_sweep
@@ -194,8 +195,14 @@ def test_solve_evaluated_sweep_of_an_axle_is_one_launch_and_matches_the_referenc
     for fn in ("tangents", "evaluate", "solve"):
         original = getattr(batch.DeviceProgram, fn)
         monkeypatch.setattr(batch.DeviceProgram, fn, lambda self, *a, _o=original, _n=fn, **k: (calls.append(_n), _o(self, *a, **k))[1])
-    evaluated = sweep_mod.solve_evaluated_sweep(axle, sweep)
+    evaluated = sweep_mod.solve_evaluated_sweep(axle, sweep, fused=True)
     assert calls == []  # neither a plain solve nor a separate evaluation: the fused launch only
+    two = sweep_mod.solve_evaluated_sweep(axle, sweep)  # a warm-started sweep by default: its chain, then ONE launch on its records
+    assert calls == ["solve", "evaluate"]
+    for row, ref in zip(two.metrics.rows, evaluated.metrics.rows):
+        assert all(_same(row.axle[n], ref.axle[n]) for n in ref.axle)
+        assert all(_same(row.corners[side][n], ref.corners[side][n]) for side in ref.corners for n in ref.corners[side])
+    calls.clear()
     states, stats = sweep_mod.solve_sweep(axle, sweep)
     separate = sweep_mod.compute_sweep_metrics(axle, sweep, states)
     assert len(evaluated.states) == len(states) == len(evaluated.metrics.rows)

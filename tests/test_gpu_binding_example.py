@@ -39,7 +39,7 @@ def test_raw_ctypes_binding_of_the_solve_and_the_evaluated_solve(golden):
     lib.okx_solve_batch.argtypes = [C.c_void_p, C.POINTER(SolveOpts), C.c_int64] + [C.c_void_p] * 6
     lib.okx_program_enable_evaluation.argtypes = [C.c_void_p, C.POINTER(CornerRoles)]
     lib.okx_solve_evaluated_batch.argtypes = [C.c_void_p, C.POINTER(SolveOpts), C.c_int64] + [C.c_void_p] * 8
-    assert lib.okx_abi_version() == _abi.ABI_VERSION == 5
+    assert lib.okx_abi_version() == _abi.ABI_VERSION == 6
 
     program, targets_host = bump_sweep_problem(512)
     host = _abi.HostProgram(program)                  # fills okx_program_desc from the flattened program

@@ -47,9 +47,11 @@ def main():
         solve_ms, (states, stats) = best(lambda: solve_sweep(sus, sweep))
         metrics_ms, _ = best(lambda: compute_sweep_metrics(sus, sweep, states))
         evaluated_ms, ev = best(lambda: solve_evaluated_sweep(sus, sweep))
+        fused_ms, _ = best(lambda: solve_evaluated_sweep(sus, sweep, fused=True))
         print(json.dumps({"fixture": name, "steps": len(states), "axle": hasattr(sus, "corners"), "metric_columns": len(ev.metrics.rows[0]) if isinstance(ev.metrics.rows[0], dict) else None,
                           "solve_sweep_ms": round(solve_ms, 3), "compute_sweep_metrics_ms": round(metrics_ms, 3),
-                          "solve_evaluated_sweep_ms": round(evaluated_ms, 3)}), flush=True)
+                          "solve_evaluated_sweep_ms": round(evaluated_ms, 3),
+                          "solve_evaluated_sweep_one_launch_ms": round(fused_ms, 3)}), flush=True)
 
 
 if __name__ == "__main__":
