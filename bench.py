@@ -842,6 +842,8 @@ def main() -> None:
                          "(measured on a quiet host: 16.09 against 16.30 us per step at K = 2000, no difference at K = 20; the graph "
                          "keeps 0.3 ms of GPU work independent of the host's launch loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5-sharded", action="store_true",
+                    help="leave out the c5_sharded leg (BASELINE config 5 through dist.ShardedEnsemble in this process group)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip with_model / e2e / other_configs / dropin (what the profiling runs use)")
     ap.add_argument("--start", choices=("design", "model"), default="design",
@@ -1118,6 +1120,14 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         if not torch.equal(gathered, records):
             raise SystemExit("rccl-world-one: the gathered and re-expanded positions differ from the solver's own records")
     nfev_mean, ok = info_summary(info)
+    # BASELINE config 5 through the sharded pipeline, in this process group (every rank takes part): the workload of north_star
+    # that is "sharded across 8 x MI355X" rides in the default line at every N, beside the xGMI-bound per-step gather of C2
+    c5_sharded = None
+    if not args.no_c5_sharded and not args.rccl_world_one:
+        try:
+            c5_sharded = measure_c5_sharded(world, rank, device)
+        except Exception as exc:  # noqa: BLE001 - an extra leg must not take the line down (every rank fails alike or none does)
+            c5_sharded = {"error": f"{type(exc).__name__}: {exc}"}
     if rank != 0:
         return {}
 
@@ -1263,6 +1273,9 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         line["cpu_baseline"] = cpu_baseline(STEPS_PER_RANK)
     # the figures a reader of the line's first 2000 characters should not miss, right behind the contract's own fields:
     # what the same launch gives without the amortised design-state pass, a fresh program's first launch, the evaluated rates
+    if c5_sharded:
+        line["rccl"] = c5_sharded.pop("rccl", None)
+        line["c5_sharded"] = c5_sharded
     digest = {}
     if "own_first_pass" in line:
         digest["own_first_pass"] = line["own_first_pass"]["value"]
@@ -1281,7 +1294,113 @@ def run_c2(args, world: int, rank: int, device) -> dict:
         head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data")
         line = {**{k: line[k] for k in head if k in line}, "digest": digest, **{k: v for k, v in line.items() if k not in head}}
+    # ... and once more as the line's LAST key, for a reader who only sees its tail: headline, roofline, CPU baseline, the
+    # sharded config-5 figures and the evaluated rates, in under a screen
+    tail = {"value": line["value"], "unit": line["unit"], "n_gpus": world, "ms_per_step": line["ms_per_step"],
+            "roofline": {k: line["roofline"].get(k) for k in ("kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic")}}
+    if "cpu_baseline" in line:
+        tail["cpu_baseline"] = {k: line["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind")}
+    if isinstance(line.get("c5_sharded"), dict):
+        tail["c5_sharded"] = {form: {k: v.get(k) for k in ("value", "solve_only", "exchange_ms", "chunks", "bytes_per_rank", "predicted")}
+                              for form, v in line["c5_sharded"].items() if isinstance(v, dict) and "value" in v}
+        tail["rccl"] = {k: (line.get("rccl") or {}).get(k) for k in ("world", "backend", "p2p_groups")}
+    tail.update({k: v for k, v in digest.items() if k != "note"})
+    line["summary"] = tail
     return line
+
+
+# what a SCALE run should find for BASELINE config 5 (whole-job solves/s; model: measured compute stages
+# of one GPU, 60 GB/s per xGMI link and direction, 20 us per grouped call) - printed beside the measurement so that the first
+# measured curve can be checked against it
+C5_PREDICTED = {"free": {1: 2.4e9, 2: 7.0e8, 4: 1.35e9, 8: 2.48e9}, "metrics": {1: 1.33e9, 2: 1.73e9, 4: 3.04e9, 8: 4.7e9}}
+
+
+def measure_c5_sharded(world: int, rank: int, device, steps: int = 5, warmup: int = 2) -> dict:
+    """
+    BASELINE config 5 (4096 perturbed double-wishbone geometries x 256 steps, "batch sharded across 8 x MI355X") through
+    dist.ShardedEnsemble in THIS process group, in the two forms north_star's exchange can take: `free` - every rank ends up
+    with every solved state's free coordinates + status byte (145 B per solve over the links, pipelined in chunks) - and
+    `metrics` - the evaluated ensemble: every rank solves AND evaluates its shard in one launch per chunk and four metric
+    columns + the status byte travel (33 B per state).  Collective: every rank calls it; rank 0 gets the numbers.
+    `value` = all 1048576 problems / the slowest rank's step (barrier + synchronize on both sides, like the headline).
+    At world == 1 the same keys come from the one-GPU pipeline (nothing travels).
+    """
+    import torch.distributed as dist
+
+    from open_kinematics_amd.batch import DeviceProgram
+    from open_kinematics_amd.dist import ShardedEnsemble, shard_range
+    from open_kinematics_amd.input import load_geometry
+    from open_kinematics_amd.metrics import corner_roles
+    from open_kinematics_amd.workloads import ensemble_problem, geometry_path
+
+    n_geom, spg = 4096, 256
+    program, table, rel = ensemble_problem(n_geom, spg)
+    dp = DeviceProgram(program, device)
+    dp.enable_evaluation(corner_roles(load_geometry(geometry_path("geometry.yaml")), program))
+    table_dev = torch.as_tensor(table, device=device)
+    bump = program.n_targets - 1
+    columns = [("camber", None), ("camber", bump), ("roadwheel_angle", bump), (21, bump)]  # (21: the wheel centre's z rate)
+    glo, ghi = shard_range(n_geom, rank, world)
+    out = {}
+
+    def timed(fn) -> float:
+        """ms per call, max over ranks: barrier + synchronize on both sides of `steps` calls."""
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        if world > 1:
+            t = torch.tensor([ms], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t.item())
+        return ms
+
+    for form, kw in (("free", dict(records=False, info="status")), ("metrics", dict(metric_columns=columns))):
+        pipe = ShardedEnsemble(dp, table_dev, rel, spg, chain_len=1, predictor=False, **kw)
+        step_ms = timed(pipe.step)
+        groups_per_step = 0
+        if world > 1:
+            before = pipe.p2p_groups
+            pipe.step()
+            groups_per_step = pipe.p2p_groups - before
+        exchange_ms = timed(pipe.exchange_only) if world > 1 else 0.0
+        # the compute stage alone: this rank's shard as ONE launch (what `solve_only` means everywhere in this file)
+        n_local = (ghi - glo) * spg
+        info = torch.empty((n_local, 40), dtype=torch.uint8, device=device)
+        skw = dict(info_out=info, chain_len=1, predictor=False, geom_pos=pipe.my_pos, geom_row_param=pipe.my_param, steps_per_geometry=spg)
+        if form == "metrics":
+            evb = torch.empty((n_local, 1 + program.n_targets, 24), dtype=torch.float64, device=device)
+            launch = dp.plan_evaluated(pipe.local_targets, eval_out=evb, output="none", **skw)
+        else:
+            free = torch.empty((n_local, program.n_free, 3), dtype=torch.float64, device=device)
+            launch = dp.plan(pipe.local_targets, out=free, output="free", **skw)
+        solve_ms = timed(launch)
+        _, ok = info_summary(info)
+        out[form] = {"value": pipe.n_total / (step_ms * 1e-3), "unit": "constraint solves/s" + (", every solve evaluated" if form == "metrics" else ""),
+                     "step_ms": step_ms, "solve_only": pipe.n_total / (solve_ms * 1e-3), "solve_only_ms_per_rank": solve_ms,
+                     "exchange_ms": exchange_ms, "chunks": pipe.chunks, "bytes_per_rank": pipe.exchange_bytes_per_rank,
+                     "p2p_groups_per_step": groups_per_step, "all_converged": ok,
+                     "predicted": C5_PREDICTED[form].get(world), "predicted_from": "DESIGN.md section 8"}
+        del pipe
+    backend = dist.get_backend() if world > 1 else None
+    out["rccl"] = {"world": world, "backend": backend, "p2p_groups": sum(out[f]["p2p_groups_per_step"] for f in ("free", "metrics")),
+                   "note": "grouped point-to-point calls (batch_isend_irecv = one ncclGroup each: every peer over its own link at once) "
+                           "issued per step of the two forms; backend nccl = RCCL over xGMI" if world > 1 else
+                           "one rank: nothing travels (the same keys as a multi-GPU line, from the one-GPU pipeline)"}
+    out["workload"] = ("BASELINE config 5: 4096 perturbed double-wishbone geometries (sigma = 1 mm, seed 0) x 256-step bump sweep = "
+                       "1048576 problems, geometry-major shards, strong scaling")
+    dp.close()
+    return out if rank == 0 else {}
 
 
 def run_c5(args, world: int, rank: int, device) -> dict:

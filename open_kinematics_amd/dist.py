@@ -357,6 +357,7 @@ class ShardedEnsemble:
         self._plans = {}
         self._expand_graphs = {}
         self.use_graphs = device.type == "cuda"
+        self.p2p_groups = self.p2p_ops = 0  # grouped point-to-point calls / operations issued so far
 
     def _rows(self, span):
         return slice(span[0] * self.steps, span[1] * self.steps)
@@ -441,6 +442,9 @@ class ShardedEnsemble:
             if theirs[1] > theirs[0]:
                 ops.append(dist.P2POp(dist.irecv, payload[self._rows(theirs)], dst, self.group))
                 ops.append(dist.P2POp(dist.irecv, beside[self._rows(theirs)], dst, self.group))
+        if ops:  # (what a bench line / a test reports: grouped calls issued and operations inside them, since construction)
+            self.p2p_groups += 1
+            self.p2p_ops += len(ops)
         return dist.batch_isend_irecv(ops) if ops else []
 
     def _exchange_chunk_through_the_host(self, k: int) -> list:
@@ -460,6 +464,9 @@ class ShardedEnsemble:
                     host = torch.empty_like(full[self._rows(theirs)], device="cpu")
                     ops.append(dist.P2POp(dist.irecv, host, dst, self.group))
                     landing.append((full[self._rows(theirs)], host))
+        if ops:
+            self.p2p_groups += 1
+            self.p2p_ops += len(ops)
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
         for device_rows, host in landing:
@@ -510,6 +517,15 @@ class ShardedEnsemble:
                         return
                     self._expand_graphs[k] = graph
                 graph.replay()
+
+    def exchange_only(self):
+        """The exchange stage alone (every chunk's grouped point-to-point call on whatever the buffers hold, waited for): what
+        a step costs beyond its compute when nothing overlaps - a bench figure, not part of a step."""
+        pending = []
+        for k in range(self.chunks):
+            pending += self._exchange_chunk(k)
+        for w in pending:
+            w.wait()
 
     def step(self):
         """One pass over the whole ensemble: returns ``positions`` (``records=True``) or the gathered free coordinates."""

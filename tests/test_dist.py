@@ -209,8 +209,15 @@ def _ensemble_worker(rank: int, world: int, port: int, n_geom: int, steps: int, 
         dp = _StandInProgram(fill_buffers=fill)
         pipe = ShardedEnsemble(dp, table, relative, steps, chunks=2, metric_columns=[(3, None), (0, 0), (23, 0)])
         table_k = pipe.step().clone()
+        groups = pipe.p2p_groups
+        pipe.exchange_only()  # (the exchange stage alone: the same grouped calls once more, nothing solved)
         torch.save({"metrics": table_k, "status": pipe.status_full.clone(), "eval_local": pipe.eval_local.clone(),
-                    "sent": pipe.exchange_bytes_per_rank, "range": pipe.geometry_range}, os.path.join(out_dir, f"metrics{int(fill)}_{rank}.pt"))
+                    "sent": pipe.exchange_bytes_per_rank, "range": pipe.geometry_range, "groups": (groups, pipe.p2p_groups),
+                    "same_after_exchange_only": torch.equal(pipe.metric_full, table_k)}, os.path.join(out_dir, f"metrics{int(fill)}_{rank}.pt"))
+    # the default chunk count comes from the SMALLEST shard: the same on every rank, uneven shards included
+    auto = ShardedEnsemble(_StandInProgram(), table, relative, steps, records=False, info="status")
+    auto_free = auto.step().clone()
+    torch.save({"chunks": auto.chunks, "free": auto_free, "groups": auto.p2p_groups}, os.path.join(out_dir, f"auto{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -254,6 +261,9 @@ def test_two_rank_gloo_ensemble_is_geometry_major(tmp_path, n_geom):
         got = torch.load(os.path.join(tmp_path, f"coords{rank}.pt"))  # gather="free": the coordinates, no expand, own slice rebound only
         assert torch.equal(got["result"], free_expect) and torch.equal(got["info"], expect.info_raw)
         assert got["rebound"] == [hi - lo]
+    autos = [torch.load(os.path.join(tmp_path, f"auto{rank}.pt")) for rank in range(2)]
+    assert autos[0]["chunks"] == autos[1]["chunks"] >= 1 and autos[0]["groups"] == autos[1]["groups"] == autos[0]["chunks"]
+    assert torch.equal(autos[0]["free"], free_expect) and torch.equal(autos[1]["free"], free_expect)
     # evaluated ensemble: the chosen columns of every state on every rank, the complete rows of the own shard locally
     whole = ref.solve_evaluated(targets, geom_pos=gpos, geom_row_param=gparam, steps_per_geometry=steps, output="none")
     want = whole.eval.reshape(targets.shape[0], -1)[:, [3, 24 + 0, 24 + 23]]
@@ -265,6 +275,7 @@ def test_two_rank_gloo_ensemble_is_geometry_major(tmp_path, n_geom):
             assert torch.equal(got["status"], expect.info_raw[:, 32])
             assert torch.equal(got["eval_local"], whole.eval[lo * steps : hi * steps])
             assert got["sent"] == (hi - lo) * steps * (3 * 8 + 1)
+            assert got["groups"] == (2, 4) and got["same_after_exchange_only"]   # one grouped call per chunk and step
 
 
 def test_single_process_ensemble_needs_no_collective():

@@ -54,6 +54,14 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert line["exchange"]["bytes_sent_per_rank_per_step"] == 16384 * 6 * 24      # the free coordinates, not the records
     assert line["exchange"]["bytes_received_per_rank_per_step"] == 16384 * 6 * 24
     assert line["solve_only"]["value"] >= line["value"] > 0.0
+    # the default line carries BASELINE config 5 through the sharded pipeline of the SAME process group, in both forms
+    assert line["rccl"]["world"] == 2 and line["rccl"]["backend"] == "gloo" and line["rccl"]["p2p_groups"] >= 2
+    for form, per_state in (("free", 6 * 24 + 1), ("metrics", 4 * 8 + 1)):
+        leg = line["c5_sharded"][form]
+        assert leg["all_converged"] and leg["value"] > 0.0 and leg["solve_only"] >= leg["value"]
+        assert leg["bytes_per_rank"] == 2048 * 256 * per_state and leg["chunks"] >= 1 and leg["exchange_ms"] > 0.0
+        assert leg["p2p_groups_per_step"] == leg["chunks"] and leg["predicted"] is not None
+    assert line["summary"]["c5_sharded"]["free"]["value"] == line["c5_sharded"]["free"]["value"]
 
 
 def test_two_rank_c5_pipeline_rehearsal_on_one_gpu():
@@ -117,3 +125,10 @@ def test_one_gpu_bench_line_keeps_the_contract():
             assert sub["calls"].startswith("hipEventRecord") and set(sub["host_us"]) == {"submit", "poll_until_done", "drain_and_synchronize"}
             base = line["cpu_baseline"]
             assert base["kind"] == "port" and base["cores"] >= 1 and base["value"] > 0.0
+            # the one-GPU line has the multi-GPU line's keys (from the one-GPU pipeline: nothing travels), and ends in a summary
+            assert line["rccl"] == {**line["rccl"], "world": 1, "backend": None, "p2p_groups": 0}
+            for form in ("free", "metrics"):
+                leg = line["c5_sharded"][form]
+                assert leg["all_converged"] and leg["value"] > 1e8 and leg["bytes_per_rank"] == 0 and leg["exchange_ms"] == 0.0
+            assert list(line)[-1] == "summary" and line["summary"]["roofline"]["frac"] == roof["frac"]
+            assert line["summary"]["cpu_baseline"]["value"] == base["value"]
