@@ -23,6 +23,19 @@ def main():
     n = t.shape[0]
     out = torch.empty((n, program.n_out, 3), dtype=torch.float64, device=device)
     info = torch.empty((n, 40), dtype=torch.uint8, device=device)
+    if "--only" in sys.argv:  # the one fused launch alone (what tools/profile_run.sh wraps in rocprofv3)
+        from open_kinematics_amd.input import load_geometry
+        from open_kinematics_amd.metrics import axle_evaluation_roles
+
+        roles, _, _ = axle_evaluation_roles(load_geometry(geometry_path("axle_geometry_rocker.yaml")), program)
+        dp.enable_evaluation(roles)
+        evb = torch.empty((n, 1 + program.n_targets, dp.eval_columns), dtype=torch.float64, device=device)
+        launch = dp.plan_evaluated(t, info_out=info, eval_out=evb, output="none", chain_len=1, predictor=False)
+        _, ms = bench.time_launches(launch, 20, 5, device)
+        print(json.dumps({"workload": "C3 rocker + U-bar axle, 256x256 heave x roll grid, evaluated in one launch (output = none)",
+                          "states": n, "roofline": {"kernel_ms": ms}, "states_per_s": n / ms * 1e3,
+                          "algorithmic_bytes_per_state": 8 * program.n_targets + 8 * dp.eval_columns * (1 + program.n_targets) + 16}))
+        return
     res = bench.measure_evaluated_axle(dp, geometry_path("axle_geometry_rocker.yaml"), t, out, info, {}, device, 20, 5)
     print(json.dumps(res))
 
