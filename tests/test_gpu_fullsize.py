@@ -45,9 +45,16 @@ def _lengths_preserved(program, pos, pairs, tol=5e-6):
         assert np.max(np.abs(d - np.linalg.norm(design[ia] - design[ib]))) <= tol, (a, b)  # softnorm bias ~1e-6
 
 
-def _oracle_jobs(jobs, tol=1e-9):
-    """Every job ``(program, targets [k, T], device positions [k, n_out, 3])`` through the oracle's MINPACK at tight
-    tolerances, cold start per problem, on every host core (the C oracle is re-entrant, ctypes releases the GIL)."""
+def _oracle_jobs(jobs, tol=1e-9, raw_tol=3e-9, polished_share=0.01):
+    """
+    Every job ``(program, targets [k, T], device positions [k, n_out, 3])`` through the oracle's MINPACK at tight
+    tolerances, cold start per problem, on every host core (the C oracle is re-entrant, ctypes releases the GIL).
+    ``|device - oracle| <= tol`` (1e-9 mm, north_star's figure).  MINPACK itself stops up to ~1.3e-9 mm short of the
+    minimiser on a fraction of a percent of the rack-steered problems (``tools/c4_oracle_gap.py``: a Gauss-Newton step on
+    the oracle's OWN residuals and Jacobian moves its answer by that much and the device's by 2e-13): where the raw gap
+    exceeds ``tol`` (never ``raw_tol``) the oracle's answer is polished with such steps - same objective, its fixed point -
+    and the device must then agree with it to ``tol``; at most ``polished_share`` of the problems may need that.
+    """
     from concurrent.futures import ThreadPoolExecutor
 
     from open_kinematics_amd.hostcpu import host_cores
@@ -55,14 +62,27 @@ def _oracle_jobs(jobs, tol=1e-9):
 
     def run(job):
         program, t, pos = job
-        ref = Oracle(program).sweep(t, 1e-15, 1e-15, 1e-15, warm_start=False)
-        return ref.first_failed_step, float(np.max(np.abs(pos - ref.positions)))
+        orc = Oracle(program)
+        ref = orc.sweep(t, 1e-15, 1e-15, 1e-15, warm_start=False)
+        err = np.abs(pos - ref.positions).reshape(len(t), -1).max(axis=1)
+        raw, polished = float(err.max()), 0
+        for k in np.nonzero(err > tol)[0]:
+            x = ref.x[k].copy()
+            for _ in range(3):  # Gauss-Newton on the oracle's own rows: x <- x - J^+ r
+                r, jac = orc.eval(x[None], t[k][None], jac=True)
+                x = x - np.linalg.lstsq(jac[0], r[0], rcond=None)[0]
+            err[k] = float(np.abs(pos[k] - orc.positions(x)[program.out_point]).max())
+            polished += 1
+        return ref.first_failed_step, raw, float(err.max()), polished, len(t)
 
     with ThreadPoolExecutor(max_workers=max(1, min(32, host_cores()[0]))) as pool:
         results = list(pool.map(run, jobs))
-    assert all(failed == -1 for failed, _ in results)
-    worst = max(err for _, err in results)
+    assert all(r[0] == -1 for r in results)
+    raw, worst = max(r[1] for r in results), max(r[2] for r in results)
+    n_polished, n = sum(r[3] for r in results), sum(r[4] for r in results)
+    assert raw <= raw_tol, raw
     assert worst <= tol, worst
+    assert n_polished <= polished_share * n, (n_polished, n)
     return worst
 
 
@@ -337,7 +357,9 @@ def test_c3_axle_grid_evaluated_at_full_size():
     tinfo = fused.tangent_info()
     assert np.all(tinfo["flags"] == 1) and np.all(tinfo["min_pivot"] > 0.0)
     ev = fused.eval
-    base = torch.as_tensor([float(program.design_pos[p] @ d) for p, d in zip(program.tgt_point, program.tgt_dir)], device="cuda:0")
+    # the metrics' design references are each CORNER's own initial state (axle_metrics.py:29-37), microns from the axle program's
+    base = torch.as_tensor([roles.left.design_wheel_center_z, roles.right.design_wheel_center_z, roles.left.design_rack_y],
+                           dtype=torch.float64, device="cuda:0")
     rise = t - base[None]                                                     # [B, 3]: left hub, right hub, rack
     travel = METRIC_NAMES.index("wheel_travel")
     assert float((ev[:, 0, travel] - rise[:, 0]).abs().max()) <= 1e-8          # the hub targets ARE the wheel centres' rises
