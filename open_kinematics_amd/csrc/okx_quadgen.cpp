@@ -83,10 +83,19 @@ class Gen {
           if (a != b) adj[P.row_blk[i][a]].insert(P.row_blk[i][b]);
     std::vector<bool> gone(nf, false);
     perm.clear();
+    // Pair mode with ONE joining row: the joined point's block is eliminated LAST.  The right-hand side of the joining row's
+    // own system (D~ z = w) is then zero everywhere but in the last block, so z needs no substitution of its own: the
+    // coupling correction touches the last block only and rides on the backward substitution of the step itself
+    // (emit_substitute's `last_block_hook`; round 6 - a pass of the axle kernel: two substitutions -> one).
+    int held_back = -1;
+    if (pv && pv->joins.size() == 1)
+      for (int k = 0; k < nf; ++k)
+        if (P.free_point[k] == pv->couple_point) held_back = k;
     for (int step = 0; step < nf; ++step) {
       int best = -1;
       for (int k = 0; k < nf; ++k)
-        if (!gone[k] && (best < 0 || adj[k].size() < adj[best].size())) best = k;
+        if (!gone[k] && k != held_back && (best < 0 || adj[k].size() < adj[best].size())) best = k;
+      if (best < 0) best = held_back;
       perm.push_back(best);
       gone[best] = true;
       for (int u : adj[best]) {
@@ -960,7 +969,9 @@ class Gen {
 
   // Forward / diagonal / backward substitution with the factor in registers:
   // {out}{F} = (J^T J + lambda I)^-1 rhs[F]   (rhs: expression per free block, lane component).
-  void emit_substitute(const std::vector<std::string>& rhs, const char* out) {
+  // `last_block_hook` (may be null): text placed right after block nf - 1 of the backward pass is finished - {out}{nf-1} then
+  // holds the last block of the solution and may still be corrected before the earlier blocks are substituted from it.
+  void emit_substitute(const std::vector<std::string>& rhs, const char* out, const std::string* last_block_hook = nullptr) {
     const int nf = P.n_free;
     f("    // ---- L y = rhs (unit lower, block by block) ----");
     for (int F = 0; F < nf; ++F) f("    double y%d = %s;", F, rhs[F].c_str());
@@ -993,7 +1004,25 @@ class Gen {
       f("      %s%d = fma(-fma(e1, l21, e0 * l20), xb2, %s%d);", out, G, out, G);
       f("      const double xb1 = QB1(%s%d), l10 = QB1(%s);", out, G, Ln(G, G, 0).c_str());
       f("      %s%d = fma(-(e0 * l10), xb1, %s%d); }", out, G, out, G);
+      if (G == nf - 1 && last_block_hook) this->out += *last_block_hook;
     }
+  }
+  // D~_FF-only solve of a right-hand side that lives in the LAST block alone (everything before it is zero, nothing comes
+  // after it): the in-block forward, diagonal and backward steps of emit_substitute for block nf - 1, result in `name`.
+  std::string last_block_solve(const std::string& rhs, const std::string& name) {
+    const int G = P.n_free - 1;
+    std::string t;
+    char line[512];
+    auto add = [&](const char* fmt, auto... args) { std::snprintf(line, sizeof(line), fmt, args...); t += line; t += "\n"; };
+    add("    double %s = %s;", name.c_str(), rhs.c_str());
+    add("    { const double zb0 = QB0(%s); %s = fma(-%s, zb0, %s);", name.c_str(), name.c_str(), Ln(G, G, 0).c_str(), name.c_str());
+    add("      const double zb1 = QB1(%s); %s = fma(-%s, zb1, %s); }", name.c_str(), name.c_str(), Ln(G, G, 1).c_str(), name.c_str());
+    add("    %s = %s * dinv%d;", name.c_str(), name.c_str(), G);
+    add("    { const double xb2 = QB2(%s), l21 = QB2(%s), l20 = QB2(%s);", name.c_str(), Ln(G, G, 1).c_str(), Ln(G, G, 0).c_str());
+    add("      %s = fma(-fma(e1, l21, e0 * l20), xb2, %s);", name.c_str(), name.c_str());
+    add("      const double xb1 = QB1(%s), l10 = QB1(%s);", name.c_str(), Ln(G, G, 0).c_str());
+    add("      %s = fma(-(e0 * l10), xb1, %s); }", name.c_str(), name.c_str());
+    return t;
   }
 
   // Directional derivative of one derived op (forward mode, closed form): velocity of the output
@@ -2007,24 +2036,20 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.out += ev.out;
     g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
     g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
-    std::vector<std::string> rhs_g, rhs_w;
-    for (int F = 0; F < nf; ++F) rhs_g.push_back("-gn" + std::to_string(F)), rhs_w.push_back(F == FU ? "cu" : "0.0");
-    for (int F = 0; F < nf; ++F) g.f("    double ny%d, nz%d;", F, F);
+    // ONE substitution: D~ y = -g as it stands; the joining row's own system D~ z = w has its right-hand side in the last
+    // block alone (the joined point is eliminated last), so z's last block is a 3 x 3 solve, the correction x = y - z c is
+    // made in that block the moment the backward pass has produced it, and the earlier blocks substitute from the corrected
+    // block (L^-T is linear: x = L^-T (yh - c zh), zh zero but in its last block).
+    std::vector<std::string> rhs_g;
+    for (int F = 0; F < nf; ++F) rhs_g.push_back("-gn" + std::to_string(F));
+    std::string hook = ev.last_block_solve("cu", "smz");
+    hook += sfmt("    const double sm_g = qsum(cu * smz), sm_gp = xq(sm_g), sm_s = qsum(cu * nx%d);\n", FU);
+    hook += "    const double sm_k = (xq(sm_s) - sm_gp * sm_s) * fast_rcp(1.0 - sm_g * sm_gp);\n";
+    hook += sfmt("    nx%d = fma(-smz, sm_k, nx%d);\n", FU, FU);
     ev.out.clear();
-    ev.emit_substitute(rhs_g, "sy");
-    g.f("    {");
+    ev.emit_substitute(rhs_g, "nx", &hook);
     g.out += ev.out;
-    for (int F = 0; F < nf; ++F) g.f("    ny%d = sy%d;", F, F);
-    g.f("    }");
     ev.out.clear();
-    ev.emit_substitute(rhs_w, "sz");
-    g.f("    {");
-    g.out += ev.out;
-    for (int F = 0; F < nf; ++F) g.f("    nz%d = sz%d;", F, F);
-    g.f("    }");
-    g.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g), sm_s = qsum(cu * ny%d);", FU, FU);
-    g.f("    const double sm_k = (xq(sm_s) - sm_gp * sm_s) * fast_rcp(1.0 - sm_g * sm_gp);");
-    for (int F = 0; F < nf; ++F) g.f("    const double nx%d = fma(-nz%d, sm_k, ny%d);", F, F, F);
     // Conditioning of the COUPLED system.  Each half was regularised with its own part of the joining row (Dt = D + w w^T,
     // |w| = 1), so the halves' pivots say nothing about the one mode the joining row ties together: both joined points
     // moving along w.  With s = w^T D^-1 w of a half (the compliance of that half along w), g = w^T Dt^-1 w = s / (1 + s),
