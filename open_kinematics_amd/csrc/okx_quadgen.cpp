@@ -2032,7 +2032,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     for (int k = 0; k < 3; ++k)
       g.f("    %s = fma(cu, QB%d(cu), %s);", Gen::A(FU, FU, k).c_str(), k, Gen::A(FU, FU, k).c_str());
     ev.out.clear();
+    ev.mark(5);
     ev.emit_factor();
+    ev.mark(6);
     g.out += ev.out;
     g.f("    ok = ok && xq(ok ? 1.0 : 0.0) > 0.5;  // both halves must factor");
     g.f("    pmin = fmin(pmin, xq(pmin)); pmax = fmax(pmax, xq(pmax));");
@@ -2048,6 +2050,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     hook += sfmt("    nx%d = fma(-smz, sm_k, nx%d);\n", FU, FU);
     ev.out.clear();
     ev.emit_substitute(rhs_g, "nx", &hook);
+    ev.mark(7);
     g.out += ev.out;
     ev.out.clear();
     // Conditioning of the COUPLED system.  Each half was regularised with its own part of the joining row (Dt = D + w w^T,

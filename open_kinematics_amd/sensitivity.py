@@ -86,6 +86,22 @@ def solve_infos_from_records(info: np.ndarray, n_variables: int) -> list:
 
 def _positions_array(states, out_keys) -> np.ndarray:
     rows = []
+    # states straight from solve_sweep whose points nobody has touched: their blocks ARE the array (state.RowPositions)
+    picks, cached_index = [], None
+    for state in states:
+        untouched = getattr(state.positions, "rows_if_untouched", None)
+        block = untouched() if untouched is not None else None
+        if block is None:
+            picks = None
+            break
+        if block[1] is not cached_index:
+            cached_index, take = block[1], [block[1].get(k) for k in out_keys]
+            if any(i is None for i in take):
+                picks = None
+                break
+        picks.append(block[0] if take == list(range(block[0].shape[0])) else block[0][take])
+    if picks is not None and (picks or not states):
+        return np.asarray(picks, dtype=np.float64).reshape(len(states), len(out_keys), 3)
     for state in states:
         rows.append([np.asarray(getattr(state.positions[k], "data", state.positions[k]), dtype=np.float64)
                      for k in out_keys])

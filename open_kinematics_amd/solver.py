@@ -244,9 +244,51 @@ def dropin_program(initial_state, constraints, sweep_config, derived_manager, so
     return program, table
 
 
+PROGRAM_MEMO_SIZE = 8
+
+
+def memoized_program(suspension, sweep_config, kind: str, line_mode: str, build, one_run: bool = False) -> tuple:
+    """
+    ``(program, absolute target table [S, T], initial state)`` of a suspension OBJECT and a one-run sweep, the flattened
+    program taken from a small memo kept on the object when it has been flattened before.  Flattening re-emits every
+    constraint (``Suspension.constraints()``) and walks the derived-point graph: 0.3 - 1 ms of host time per call, as
+    much as the sweep's GPU work and more (``tools/dropin_profile.py``).  The key covers what a program depends on:
+    the kind of output list, the line-row form, every design position of the initial state (bytes), and each
+    dimension's target point and direction - so a suspension whose hardpoints were edited between calls flattens
+    afresh.  (Edits that change the constraint SET without moving a point are not seen: build a new suspension, or
+    ``clear_program_memo(suspension)``.)  ``build(state, heads) -> ConstraintProgram`` flattens on a miss.
+    """
+    state = suspension.initial_state()
+    # (`one_run`: the caller has already seen that every dimension keeps its point and direction - target_segments is a
+    #  Python loop over all steps, not worth running twice per call)
+    heads, table = absolute_target_table(sweep_config, state, (0, sweep_config.n_steps) if one_run else None)
+    store = getattr(suspension, "__dict__", None)
+    if store is None:
+        return build(state, heads), table, state
+    points = state.positions
+    fingerprint = hash(np.asarray([getattr(v, "data", v) for v in points.values()], dtype=np.float64).tobytes())
+    key = (kind, line_mode, len(points), fingerprint,
+           tuple((pid, resolve_direction(direction).tobytes()) for pid, direction in heads))
+    memo = store.setdefault("_okx_program_memo", OrderedDict())
+    program = memo.get(key)
+    if program is None:
+        program = build(state, heads)
+        memo[key] = program
+        while len(memo) > PROGRAM_MEMO_SIZE:
+            memo.popitem(last=False)
+    else:
+        memo.move_to_end(key)
+    return program, table, state
+
+
+def clear_program_memo(suspension) -> None:
+    """Forget the flattened programs remembered on this suspension object (``memoized_program``)."""
+    getattr(suspension, "__dict__", {}).pop("_okx_program_memo", None)
+
+
 def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_manager,
                            solver_config=SolverConfig(), *, output_points=None, device=None, evaluation=None,
-                           evaluation_fused: bool | None = None):
+                           evaluation_fused: bool | None = None, _flattened=None):
     """
     Solve every step of a sweep on the GPU (reference ``solver.py:654-776``).
 
@@ -271,11 +313,13 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     with_extra = (lambda states, infos, extra=None: (states, infos, extra)) if evaluation is not None else (lambda states, infos, extra=None: (states, infos))
     if sweep_config.n_steps == 0:
         return with_extra([], [])
-    segments = target_segments(sweep_config)
+    segments = [(0, sweep_config.n_steps)] if _flattened is not None else target_segments(sweep_config)  # (a memo hit is a one-run sweep)
     if len(segments) > 1:
         return with_extra(*_solve_sweep_in_runs(initial_state, constraints, sweep_config, derived_manager, cfg, segments,
                                                 output_points, device))
-    program, table = dropin_program(initial_state, constraints, sweep_config, derived_manager, cfg, output_points)
+    # (`_flattened`: the program and target table sweep.solve_sweep found in its per-suspension memo - `constraints` is then unused)
+    program, table = _flattened if _flattened is not None else dropin_program(initial_state, constraints, sweep_config, derived_manager,
+                                                                             cfg, output_points)
     dp = _device_program(program, device)
     n_steps = table.shape[0]
     solve, evaluated, fused = dp.solve, None, False
@@ -458,18 +502,29 @@ def _raise_on_first_failure(program, dp, table, positions, info, sweep_config, i
 
 
 def _states_from_positions(initial_state, program: ConstraintProgram, positions: np.ndarray) -> list:
-    """One independent state per step, typed like the input state (``solver.py:763``)."""
+    """One independent state per step, typed like the input state (``solver.py:763``).  The points of a state are made
+    when they are first read (``state.RowPositions``): a 101-step sweep hands back 101 small objects, not 2000."""
+    from .state import RowPositions
+
     sample = next(iter(initial_state.positions.values()))
     point_cls = type(sample) if hasattr(sample, "data") else Point3
-    state_cls = type(initial_state) if hasattr(initial_state, "free_points_order") else SuspensionState
+    own_state = not hasattr(initial_state, "free_points_order") or type(initial_state) is SuspensionState
+    state_cls = SuspensionState if own_state else type(initial_state)
     keys = [program.point_keys[k] for k in program.out_point]
+    index = {k: i for i, k in enumerate(keys)}
     free = set(initial_state.free_points) & set(keys)
+    order = sorted(free)
     # one contiguous copy of the whole sweep; every point of every state is its own view into it
     # (independent of the device buffer and of every other state, like the reference's per-step copies)
     block = np.array(positions, dtype=np.float64, order="C", copy=True)
     make = getattr(point_cls, "from_trusted", point_cls)  # this package's Point3: adopt the view, no second copy
     states = []
     for step in range(block.shape[0]):
-        rows = block[step]
-        states.append(state_cls(positions={k: make(rows[i]) for i, k in enumerate(keys)}, free_points=set(free)))
+        lazy = RowPositions(block[step], index, make)
+        if own_state:  # (what the dataclass's __init__ / __post_init__ do, without sorting the same keys once per step)
+            state = SuspensionState.__new__(SuspensionState)
+            state.positions, state.free_points, state.free_points_order = lazy, set(free), list(order)
+        else:
+            state = state_cls(positions=lazy, free_points=set(free))
+        states.append(state)
     return states

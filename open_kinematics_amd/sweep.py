@@ -24,23 +24,49 @@ def solve_sweep(suspension, sweep_config, solver_config: SolverConfig = SolverCo
     reference's own models work unchanged.
     """
     validate_sweep_controls(sweep_config, suspension.actuator_dofs())
+    state, flattened = _dropin_flattened(suspension, sweep_config, solver_config)
     return solve_suspension_sweep(
-        initial_state=suspension.initial_state(),
-        constraints=suspension.constraints(),
+        initial_state=state,
+        constraints=None if flattened is not None else suspension.constraints(),
         sweep_config=sweep_config,
-        derived_manager=suspension.derived_spec(),
+        derived_manager=None if flattened is not None else suspension.derived_spec(),
         solver_config=solver_config,
         device=device,
+        _flattened=flattened,
     )
+
+
+def _dropin_flattened(suspension, sweep_config, solver_config):
+    """``(initial state, (program, table) or None)``: the drop-in's program - every point of a state an output, ``solver.py:763`` -
+    from the suspension's memo (``solver.memoized_program``); None for sweeps that are solved run by run or have no step."""
+    from .solver import (_coerce_config, memoized_program, target_segments, validate_least_squares_dimensions)
+
+    if sweep_config.n_steps == 0 or len(target_segments(sweep_config)) > 1:
+        return suspension.initial_state(), None
+    cfg = _coerce_config(solver_config)
+
+    def build(state, heads):
+        constraints = suspension.constraints()
+        validate_least_squares_dimensions(3 * len(state.free_points), len(constraints) + len(heads))
+        spec = suspension.derived_spec()
+        return flatten_problem(state, constraints, getattr(spec, "spec", spec), heads, output_points=None,
+                               line_mode="softnorm").with_line_mode(cfg.line_mode)
+
+    program, table, state = memoized_program(suspension, sweep_config, "dropin", cfg.line_mode, build, one_run=True)
+    return state, (program, table)
 
 
 def sweep_program(suspension, sweep_config, line_mode: str = "pinned") -> tuple[ConstraintProgram, np.ndarray]:
     """Constraint program (outputs = ``suspension.output_points()``) and absolute targets ``[S, T]``."""
+    from .solver import memoized_program
+
     validate_sweep_controls(sweep_config, suspension.actuator_dofs())
-    state = suspension.initial_state()
-    heads, table = absolute_target_table(sweep_config, state)
-    program = flatten_problem(state, suspension.constraints(), suspension.derived_spec(), heads,
-                              suspension.output_points(), line_mode="softnorm").with_line_mode(line_mode)
+
+    def build(state, heads):
+        return flatten_problem(state, suspension.constraints(), suspension.derived_spec(), heads,
+                               suspension.output_points(), line_mode="softnorm").with_line_mode(line_mode)
+
+    program, table, _ = memoized_program(suspension, sweep_config, "sweep", line_mode, build)
     return program, table
 
 
@@ -537,10 +563,11 @@ def solve_evaluated_sweep(suspension, sweep_config, solver_config: SolverConfig 
                 return axle_parts[0], False
             return corner_roles(suspension, program), bool(topology_rotation_roles(suspension, program)[0])
 
+        state, flattened = _dropin_flattened(suspension, sweep_config, solver_config)
         states, stats, extra = solve_suspension_sweep(
-            initial_state=suspension.initial_state(), constraints=suspension.constraints(), sweep_config=sweep_config,
-            derived_manager=suspension.derived_spec(), solver_config=solver_config, device=device, evaluation=roles_of,
-            evaluation_fused=fused)
+            initial_state=state, constraints=None if flattened is not None else suspension.constraints(), sweep_config=sweep_config,
+            derived_manager=None if flattened is not None else suspension.derived_spec(), solver_config=solver_config, device=device,
+            evaluation=roles_of, evaluation_fused=fused, _flattened=flattened)
         if extra is not None and is_axle:
             program, evaluated = extra
             rows = _axle_rows_from_evaluated(suspension, program, evaluated, *axle_parts)
