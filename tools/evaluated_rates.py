@@ -80,7 +80,11 @@ def measure(which: str, device, reps: int, only: str = "") -> dict:
         solve()
         rows[only] = ev_ms(lambda: dp.evaluate(out, eval_out=evb, **kw), device, reps)
         return {"workload": which, "states": n, "ms": rows, "states_per_s": {k: n / v * 1e3 for k, v in rows.items()},
-                "roofline": {"kernel_ms": rows[only]}, "algorithmic_bytes_per_state": 24 * program.n_out + 8 * 24 * (1 + T)}
+                "roofline": {"kernel_ms": rows[only]},
+                # what the kernel must move: the FREE points of a record (fixed points come with the geometry, derived points
+                # are re-evaluated) in, the evaluation rows out; `with_whole_records`: had it to read all 24 n_out bytes
+                "algorithmic_bytes_per_state": 24 * program.n_free + 8 * 24 * (1 + T),
+                "with_whole_records_bytes_per_state": 24 * program.n_out + 8 * 24 * (1 + T)}
     rows["solve_records"] = ev_ms(solve, device, reps)
     rows["solve_output_none"] = ev_ms(dp.plan(targets, info_out=info, output="none", **skw), device, reps)
     solve()

@@ -5,6 +5,10 @@
 import json, os, shutil, sys, glob
 rnd, tag, units, bytes_per = sys.argv[1], sys.argv[2], int(sys.argv[3]), float(sys.argv[4])
 note = sys.argv[5] if len(sys.argv) > 5 else ""
+# FETCH_SIZE correction for this kernel's READ SHAPE, calibrated on 1.07 GB of 360-byte records (tools/micro/fetch_calib.hip,
+# profiles/r06/fetch_calib.json): contiguous reads report exactly 1/2 of the bytes at 16 B AND at 8 B per lane (factor 2.000);
+# one lane per record with 8-byte loads at a 360-byte lane stride reports 1/1.73 of the record bytes (factor 1.73)
+fetch_factor = float(sys.argv[6]) if len(sys.argv) > 6 else 2.0
 O, P = f"gpurun_out/profile_{tag}", f"profiles/{rnd}"
 os.makedirs(P, exist_ok=True)
 s = json.load(open(f"{O}/summary.json"))
@@ -22,7 +26,8 @@ for d, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", "SQ"), 
         # per-dispatch medians in <tag>_pmc_traffic.json are taken over ALL dispatches, from summary.json
         with open(src) as f, open(f"{P}/{tag}_pmc_{name}.csv", "w") as g:
             g.writelines(line for i, line in enumerate(f) if i <= 6000)
-fetch = s["FETCH_SIZE"]["per_dispatch_kib_median"] * 1024
+fetch_raw = s["FETCH_SIZE"]["per_dispatch_kib_median"] * 1024
+fetch = fetch_raw * fetch_factor
 write = s["WRITE_SIZE"]["per_dispatch_kib_median"] * 1024
 sq, w = s["SQ"], s["SQ"]["SQ_WAVES"]
 kms = lambda r: r.get("roofline", {}).get("kernel_ms") or next((r[m]["kernel_ms"] for m in ("cold", "chained") if m in r), None)
@@ -33,11 +38,13 @@ out = {
     "units_per_launch": units,
     "command": "tools/profile_run.sh: rocprofv3 --kernel-trace --stats; then --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in "
                "SEPARATE passes, --output-format csv; per-dispatch MEDIANS over the dispatches of the solve kernel",
-    "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
-    "corrections": "counter unit = KiB (x1024). The gfx950 x2 FETCH_SIZE correction of MI355X_MICROARCH.md applies to wide (16 B/lane) "
-                   "coalesced streaming reads; these kernels read 8-byte targets and L2-resident parameter tables (and, for ensembles, "
-                   "8-byte per-lane geometry entries), so FETCH_SIZE is reported uncorrected (uncalibrated width per the guide). "
-                   "WRITE_SIZE is exact for the 16-byte-per-lane record stores.",
+    "fetch_bytes_per_launch": fetch, "fetch_size_counter_bytes": fetch_raw, "fetch_correction_factor": fetch_factor,
+    "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
+    "corrections": "counter unit = KiB (x1024).  FETCH_SIZE x fetch_correction_factor: calibrated for this repository's read shapes "
+                   "on a 1.07 GB buffer of 360-byte records (tools/micro/fetch_calib.hip -> profiles/r06/fetch_calib.json): contiguous "
+                   "reads, 16 B or 8 B per lane, report exactly half of the bytes (x 2.000, the guide's gfx950 correction holds at 8 B per "
+                   "lane too); one lane per record, 8-byte loads at a 360-byte lane stride: x 1.73.  WRITE_SIZE is exact for the "
+                   "16-byte-per-lane record stores.",
     "algorithmic_bytes_per_launch": bytes_per * units,
     "traffic_over_algorithmic": (fetch + write) / (bytes_per * units),
     "sq_counters_per_wavefront": {
