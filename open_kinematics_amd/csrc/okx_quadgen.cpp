@@ -1684,14 +1684,10 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       const std::string z = join_z_src();
       ev.out = keep + z;
     } else {
-      std::vector<std::string> rhs_w;
-      for (int F = 0; F < nf; ++F) rhs_w.push_back(F == FU ? "cu" : "0.0");
-      for (int F = 0; F < nf; ++F) ev.f("    double nz%d;", F);
-      ev.f("    {");
-      ev.emit_substitute(rhs_w, "sz");
-      for (int F = 0; F < nf; ++F) ev.f("    nz%d = sz%d;", F, F);
-      ev.f("    }");
-      ev.f("    const double sm_g = qsum(cu * nz%d), sm_gp = xq(sm_g);", FU);
+      // (the joined point is eliminated last: the joining row's own system is a solve in the last block, and every target's
+      //  coupling correction is made in that block as the backward substitution delivers it - see the passes' solve step)
+      ev.out += ev.last_block_solve("cu", "smz");
+      ev.f("    const double sm_g = qsum(cu * smz), sm_gp = xq(sm_g);");
       ev.f("    const double sm_det = 1.0 - sm_g * sm_gp;");
     }
     ev.f("    if (c == 0 && !q1) vok[quad] = ok ? 0.0 : __builtin_nan(\"\");  // a fixed point's velocity: zero, or NaN with the rest");
@@ -1703,14 +1699,15 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       auto it = ev.target_j.find(t);
       if (it != ev.target_j.end())
         for (auto& fv : it->second) rhs[fv.first] = "(ms * " + Gen::sx(fv.second) + ")";
-      ev.emit_substitute(rhs, "ty");
       if (NK > 1) {
+        ev.emit_substitute(rhs, "ty");
         ev.out += join_correct_src([&](int F) { return "ty" + std::to_string(F); },
                                    [&](int F, const std::string& e) { return sfmt("    const double tq%d = %s;\n", F, e.c_str()); });
       } else {
-        ev.f("    const double sm_s = qsum(cu * ty%d);", FU);
-        ev.f("    const double sm_c = (xq(sm_s) - sm_gp * sm_s) / sm_det;");
-        for (int F = 0; F < nf; ++F) ev.f("    const double tq%d = fma(-nz%d, sm_c, ty%d);", F, F, F);
+        std::string hook = sfmt("    const double sm_s = qsum(cu * tq%d);\n", FU);
+        hook += "    const double sm_c = (xq(sm_s) - sm_gp * sm_s) / sm_det;\n";
+        hook += sfmt("    tq%d = fma(-smz, sm_c, tq%d);\n", FU, FU);
+        ev.emit_substitute(rhs, "tq", &hook);
       }
       const std::string vp = "w" + std::to_string(job.prog_t) + "_";
       for (int p = 0; p < NP; ++p) {
