@@ -1585,7 +1585,9 @@ int32_t okx_evaluate_batch(okx_program* p, int64_t n_problems, int64_t steps_per
   q.cfg_r = p->ev_cfg_r;
   std::memcpy(q.roles, p->ev_roles, sizeof(q.roles));
   const long long waves = (n_problems + p->quad_ppw - 1) / p->quad_ppw;
-  const long long cap = (long long)p->n_cu * p->quad_waves_per_cu * 8;  // (a streaming launch: several rounds' worth of workgroups)
+  // (a streaming launch: several rounds' worth of workgroups - but an axle's own-geometry body keeps its chain constants and
+  //  fixed points across a persistent loop: one wavefront per SIMD)
+  const long long cap = (long long)p->n_cu * p->quad_waves_per_cu * (p->ev_axle && !d_geom_pos ? 1 : 8);
   void* kargs[] = {(void*)&q};
   HIP_TRY(hipModuleLaunchKernel(d_geom_pos ? p->ev_pos_g : p->ev_pos_u, (int)(waves < cap ? waves : cap), 1, 1, okx::kWave, 1, 1, 0,
                                 (hipStream_t)stream, kargs, nullptr));

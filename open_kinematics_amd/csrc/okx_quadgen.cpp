@@ -3184,7 +3184,12 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     }
     g.f("struct QEvPosArgs { const double* pos; const double* geom_pos; const double* geom_row_param; double* tan; double* ev;");
     g.f("  long long n_problems, steps_per_geometry; const double* design_pos; const double* row_param; const double* dop_param; EvCfg cfg; EvCfg cfg_r; EvRoleNum roles[8]; };");
-    g.f("template <bool PG> DEV void okx_quad_evaluate_body(const QEvPosArgs& a) {");
+    // two bodies: on the program's own geometry the chain constants and the fixed points are the same for every state - read
+    // once per wavefront, ahead of a persistent loop over its wave units (okx_evaluate_batch caps that grid at one wavefront
+    // per SIMD); with geometry tables they belong to the wave unit
+    for (const bool pg : {false, true}) {
+    g.f("DEV void okx_quad_evaluate_body_%s(const QEvPosArgs& a) {", pg ? "g" : "u");
+    g.f("  constexpr bool PG = %s;", pg ? "true" : "false");
     g.f("  const QEvPosArgs& ea = a;");
     g.f("  const int lane = threadIdx.x, c = lane & 3, quad = lane >> 3, q1 = (lane >> 2) & 1, cc = c < 3 ? c : 2;");
     g.out += atan_decl;
@@ -3193,15 +3198,25 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     g.f("  __shared__ __attribute__((aligned(16))) double stage[%d];", PPW * RECP);
     g.f("  __shared__ __attribute__((aligned(16))) double vst[%d];  // velocities [problem][target][half][moving point][3]", PPW * TP * 2 * MV);
     g.f("  __shared__ double vok[%d];", PPW);
+    auto constants = [&]() {
+      g.out += ev.hoisted;
+      g.out += couple_hoist;
+      for (int p = 0; p < NP; ++p)
+        if (used[p]) g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
+    };
+    if (!pg) {
+      g.f("  const double* gp = a.design_pos;");
+      g.f("  const double* gq = a.row_param;");
+      constants();
+    }
     g.f("  for (long long wu = blockIdx.x; wu * %d < a.n_problems; wu += gridDim.x) {", PPW);
     g.f("    long long bb = wu * %d + quad; const bool valid = bb < a.n_problems; if (!valid) bb = a.n_problems - 1;", PPW);
-    g.f("    const long long geom = PG ? bb / a.steps_per_geometry : 0;");
-    g.f("    const double* gp = PG ? a.geom_pos + geom * %d : a.design_pos;", 3 * prog_points);
-    g.f("    const double* gq = PG ? a.geom_row_param + geom * %d : a.row_param;", 8 * prog_crows);
-    g.out += ev.hoisted;
-    g.out += couple_hoist;
-    for (int p = 0; p < NP; ++p)
-      if (used[p]) g.f("    double p%d = ld3(gp + %s + cc, c);", p, ev.point3(p).c_str());
+    if (pg) {
+      g.f("    const long long geom = bb / a.steps_per_geometry;");
+      g.f("    const double* gp = a.geom_pos + geom * %d;", 3 * prog_points);
+      g.f("    const double* gq = a.geom_row_param + geom * %d;", 8 * prog_crows);
+      constants();
+    }
     for (int F = 0; F < nf; ++F) {
       const int k = oi[ev.fp(F)];
       g.f("    p%d = ld3(a.pos + bb * %d + %s + cc, c);", ev.fp(F), RECP, Gen::sel(3 * pv->out[0][k], 3 * pv->out[1][k]).c_str());
@@ -3231,8 +3246,9 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     }
     g.f("  }");
     g.f("}");
-    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evaluate_u(QEvPosArgs a) { okx_quad_evaluate_body<false>(a); }", waves_per_simd);
-    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evaluate_g(QEvPosArgs a) { okx_quad_evaluate_body<true>(a); }", waves_per_simd);
+    }
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evaluate_u(QEvPosArgs a) { okx_quad_evaluate_body_u(a); }", waves_per_simd);
+    g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evaluate_g(QEvPosArgs a) { okx_quad_evaluate_body_g(a); }", waves_per_simd);
     g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evsolve_u(QEvArgs ea) { okx_quad_body<false>(ea.q, ea); }", waves_per_simd);
     g.f("extern \"C\" __global__ void __launch_bounds__(64, %d) okx_quad_evsolve_g(QEvArgs ea) { okx_quad_body<true>(ea.q, ea); }", waves_per_simd);
     if (cold_body)
