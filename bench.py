@@ -49,7 +49,7 @@ import torch.distributed as dist
 STEPS_PER_RANK = 16384
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s HBM3E spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # vendor fp64 vector peak, secondary ceiling
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 INFO_FIELDS = np.dtype([("max_residual", "<f8"), ("cost", "<f8"), ("last_step", "<f8"), ("iterations", "<i4"),
                         ("nfev", "<i4"), ("flags", "<i4"), ("reserved", "<i4")])
 
