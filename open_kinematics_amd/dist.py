@@ -315,13 +315,15 @@ class ShardedEnsemble:
         if metric_columns is not None:
             from .metrics import METRIC_NAMES
 
+            # (columns per evaluation row: 24 for a corner, 64 for a composed axle - left block | right block | axle metrics | roles)
+            self.eval_columns = int(getattr(device_program, "eval_columns", 0) or 24)
             flat = []
             for metric, target in metric_columns:
                 col = METRIC_NAMES.index(metric) if isinstance(metric, str) else int(metric)
                 row = 0 if target is None else 1 + int(target)
-                if not (0 <= col < 24 and 0 <= row <= program.n_targets):
+                if not (0 <= col < self.eval_columns and 0 <= row <= program.n_targets):
                     raise ValueError(f"no evaluation entry ({metric!r}, {target!r})")
-                flat.append(row * 24 + col)
+                flat.append(row * self.eval_columns + col)
             if not flat:
                 raise ValueError("metric_columns is empty")
             self.metric_index = torch.tensor(flat, dtype=torch.int64, device=device)
@@ -336,7 +338,7 @@ class ShardedEnsemble:
             if self.direct:
                 raise ValueError("direct records and metric_columns exclude each other")
             n_local = (ghi - glo) * self.steps
-            self.eval_local = torch.empty((n_local, 1 + program.n_targets, 24), dtype=torch.float64, device=device)
+            self.eval_local = torch.empty((n_local, 1 + program.n_targets, self.eval_columns), dtype=torch.float64, device=device)
             self.metric_full = torch.empty((self.n_total, len(self.metric_index)), dtype=torch.float64, device=device)
         self.free_full = None if self.metric_index is not None else torch.empty((self.n_total, program.n_free, 3), dtype=torch.float64, device=device)
         # what travels beside the coordinates: the 40-byte info records, or one status byte per solve (then the records of

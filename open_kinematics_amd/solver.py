@@ -269,15 +269,17 @@ def memoized_program(suspension, sweep_config, kind: str, line_mode: str, build,
     fingerprint = hash(np.asarray([getattr(v, "data", v) for v in points.values()], dtype=np.float64).tobytes())
     key = (kind, line_mode, len(points), fingerprint,
            tuple((pid, resolve_direction(direction).tobytes()) for pid, direction in heads))
-    memo = store.setdefault("_okx_program_memo", OrderedDict())
-    program = memo.get(key)
+    with _PROGRAM_CACHE_LOCK:
+        memo = store.setdefault("_okx_program_memo", OrderedDict())
+        program = memo.get(key)
+        if program is not None:
+            memo.move_to_end(key)
     if program is None:
-        program = build(state, heads)
-        memo[key] = program
-        while len(memo) > PROGRAM_MEMO_SIZE:
-            memo.popitem(last=False)
-    else:
-        memo.move_to_end(key)
+        program = build(state, heads)  # (outside the lock: flattening is the slow part; two threads may both flatten once)
+        with _PROGRAM_CACHE_LOCK:
+            memo[key] = program
+            while len(memo) > PROGRAM_MEMO_SIZE:
+                memo.popitem(last=False)
     return program, table, state
 
 
