@@ -15,7 +15,7 @@ namespace okx {
 // tests/test_dev_switches.py (generated source still compiles and is deterministic); the switches that change generated
 // source are part of its text and therefore of the kernel cache key.
 //   generators   quad_mark, quad_timeline, quad_no_light, quad_no_head, quad_no_fast, quad_two_waves, pair_no_head, pair_first_order_head,
-//                pair_lds_homes, lane_mark, lane_timeline, lane_lds_tables, lane_nested, lane_refine
+//                pair_lds_homes, pair_cold_lds, lane_mark, lane_timeline, lane_lds_tables, lane_nested, lane_refine
 //   library      no_quad, no_lane, no_cold, tangent_generic, evaluate_quad, evaluate_lane, keep_source
 bool dev_switch(const char* name);
 

@@ -1362,7 +1362,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   // Pair mode: the quad-uniform Levenberg-Marquardt scalars and the chain's target history live in LDS, one slot per
   // quad side like the chain constants (all lanes of a quad write the same value).  Left in registers the compiler
   // spills them to scratch, and the pass re-reads ~60 of them from there at memory latency (profiles/r02/c3_*).
-  const bool pair_state_lds = pv != nullptr;
+  bool pair_state_lds = pv != nullptr;  // (set per body at the top of emit_body)
   int n_state_slots = 0;
   auto state_ref = [&](const std::string& name, const std::string& init) {
     // declaration of one per-quad scalar: a register, or a reference into lms[slot][quad side]
@@ -2064,6 +2064,13 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
   }
   };
   n_state_slots = 0;  // (pair mode: each body numbers its LDS homes from zero)
+  // Pair mode keeps the quad-uniform Levenberg-Marquardt scalars in LDS in the GENERAL body (chains: in registers the compiler
+  // spills them and the pass re-reads ~60 of them from scratch).  The cold body has no chain history to carry and keeps them
+  // in registers since round 6: its "LM decision" and "step norms" sections were chains of dependent LDS round trips, 3.3 k of
+  // a 22 k-cycle pass (C3 cold 0.3057 -> 0.2962 ms, A/B on one box; 0 B scratch, 34 KB LDS).  Only where it measured a gain:
+  // one joining row, halves of up to ten free points, the plain module (the T-bar and heave-link axles lost 2 - 6 % with it,
+  // the evaluated cold body 2 %: their register files are full).  pair_cold_lds: the old layout everywhere.
+  pair_state_lds = pv != nullptr && !(CD && NK == 1 && nf <= 10 && !EV && !dev_switch("pair_cold_lds"));
   const bool tl_body = CD && ev.tl_marks;
   if (tl_body)  // sections of the SECOND full pass of a wavefront go to a second table behind the first: a.trace[16 (waves + w) + k]
     g.f("#undef OKX_TL\n#define OKX_TL(k) if (a.trace && tl_pass == 4 && (threadIdx.x & 63) == 0) a.trace[(gridDim.x + blockIdx.x) * 16 + (k)] = (double)__builtin_readcyclecounter();");
@@ -2155,7 +2162,7 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
       // unit is solved and stored - x / dx, the per-quad scalars, the free-coordinate stage - so that the kernel stays within
       // the 40 KB that let four wavefronts share a CU (every unit re-initialises all of it)
       auto even = [](int n) { return (n + 1) / 2 * 2; };
-      const int stage_n = even(PPW * RECP), xsl_n = even(64 * 2 * nf), lms_n = even(16 * (5 * T + 12)), fst_n = even(PPW * 3 * program.n_free);
+      const int stage_n = even(PPW * RECP), xsl_n = even(64 * 2 * nf), lms_n = pair_state_lds ? even(16 * (5 * T + 12)) : 0, fst_n = even(PPW * 3 * program.n_free);
       const int vst_n = even(PPW * TP * 2 * MV);
       const int union_n = xsl_n + lms_n + fst_n > vst_n ? xsl_n + lms_n + fst_n : vst_n;
       g.f("  __shared__ __attribute__((aligned(16))) double arena[%d];  // [record stage | x, dx, per-quad scalars, free-coordinate stage  /  staged velocities]", stage_n + union_n);

@@ -49,6 +49,7 @@ GENERATOR_SWITCHES = [
     ("pair_no_head", "c3_axle_grid", "okx_quad_source", "-okx_quad_head_u(QHeadArgs"),
     ("pair_first_order_head", "c3_axle_grid", "okx_quad_source", "-hS0_"),
     ("pair_lds_homes", "c3_axle_grid", "okx_quad_source", "+psl["),
+    ("pair_cold_lds", "c3_axle_grid", "okx_quad_source", "-double Fc = 0.0, lambda = 0.0, nu = 2.0"),
     ("lane_mark", "c1_dw_corner", "okx_lane_source", "+s_nop 1"),
     ("lane_timeline", "c1_dw_corner", "okx_lane_source", "+__builtin_readcyclecounter"),
     ("lane_lds_tables", "c1_dw_corner", "okx_lane_source", "-okx_cptr gpc"),
