@@ -911,10 +911,14 @@ def main() -> None:
     else:
         line = run_c2(args, world, rank, device)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1 or args.rccl_world_one:
-        dist.barrier()
-        dist.destroy_process_group()
+        if getattr(run_c2, "leg_timed_out", False):
+            os._exit(0)  # (a rank is stuck in an exchange: no further collective, the line is out)
+        # the closing barrier under a deadline too: a peer that gave up on the c5 leg has left without it
+        _, late = _with_deadline(lambda: (dist.barrier(), dist.destroy_process_group()) and None, 60.0 if world > 1 else None, device)
+        if late:
+            os._exit(0)
 
 
 def self_launch(n_ranks: int, argv: list, dry: bool = False) -> int:
@@ -1124,10 +1128,10 @@ def run_c2(args, world: int, rank: int, device) -> dict:
     # that is "sharded across 8 x MI355X" rides in the default line at every N, beside the xGMI-bound per-step gather of C2
     c5_sharded = None
     if not args.no_c5_sharded and not args.rccl_world_one:
-        try:
-            c5_sharded = measure_c5_sharded(world, rank, device)
-        except Exception as exc:  # noqa: BLE001 - an extra leg must not take the line down (every rank fails alike or none does)
-            c5_sharded = {"error": f"{type(exc).__name__}: {exc}"}
+        # (under a deadline when ranks exchange: the headline above is measured; a point-to-point exchange that never
+        #  completes on some node must cost this leg, not the line - main() then leaves without another collective)
+        c5_sharded, timed_out = _with_deadline(lambda: measure_c5_sharded(world, rank, device), C5_LEG_DEADLINE_S if world > 1 else None, device)
+        run_c2.leg_timed_out = timed_out
     if rank != 0:
         return {}
 
@@ -1313,6 +1317,35 @@ def run_c2(args, world: int, rank: int, device) -> dict:
 # of one GPU, 60 GB/s per xGMI link and direction, 20 us per grouped call) - printed beside the measurement so that the first
 # measured curve can be checked against it
 C5_PREDICTED = {"free": {1: 2.4e9, 2: 7.0e8, 4: 1.35e9, 8: 2.48e9}, "metrics": {1: 1.33e9, 2: 1.73e9, 4: 3.04e9, 8: 4.7e9}}
+
+
+C5_LEG_DEADLINE_S = 240.0
+
+
+def _with_deadline(fn, seconds, device) -> tuple:
+    """``(fn(), False)``; an exception becomes ``{"error": ...}``.  With ``seconds``: run on a helper thread and give up after
+    that long - ``({"error": "timed out ..."}, True)`` (the thread is a daemon: the caller is expected to leave the process)."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            torch.cuda.set_device(device)
+            box["value"] = fn()
+        except Exception as exc:  # noqa: BLE001 - an extra leg must not take the line down
+            box["value"] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    if seconds is None:
+        run()
+        return box["value"], False
+    stream = torch.cuda.current_stream(device)
+    worker = threading.Thread(target=lambda: (torch.cuda.set_stream(stream), run()), daemon=True)
+    worker.start()
+    worker.join(seconds)
+    if worker.is_alive():
+        return {"error": f"timed out after {seconds:.0f} s (the exchange did not complete on this node)"}, True
+    return box["value"], False
 
 
 def measure_c5_sharded(world: int, rank: int, device, steps: int = 5, warmup: int = 2) -> dict:

@@ -2041,9 +2041,13 @@ bool quad_generate(const DevProgram& program, int waves_per_simd, std::string* s
     // block (L^-T is linear: x = L^-T (yh - c zh), zh zero but in its last block).
     std::vector<std::string> rhs_g;
     for (int F = 0; F < nf; ++F) rhs_g.push_back("-gn" + std::to_string(F));
-    std::string hook = ev.last_block_solve("cu", "smz");
-    hook += sfmt("    const double sm_g = qsum(cu * smz), sm_gp = xq(sm_g), sm_s = qsum(cu * nx%d);\n", FU);
-    hook += "    const double sm_k = (xq(sm_s) - sm_gp * sm_s) * fast_rcp(1.0 - sm_g * sm_gp);\n";
+    // (what does not depend on y - z's last block, the halves' g = w . z, the 2 x 2 system's determinant - ahead of the
+    //  substitution, where its exchange with the partner half overlaps the forward pass; the hook keeps one exchange)
+    g.out += ev.last_block_solve("cu", "smz");
+    g.f("    const double sm_g = qsum(cu * smz), sm_gp = xq(sm_g);");
+    g.f("    const double sm_idet = fast_rcp(1.0 - sm_g * sm_gp);");
+    std::string hook = sfmt("    const double sm_s = qsum(cu * nx%d);\n", FU);
+    hook += "    const double sm_k = (xq(sm_s) - sm_gp * sm_s) * sm_idet;\n";
     hook += sfmt("    nx%d = fma(-smz, sm_k, nx%d);\n", FU, FU);
     ev.out.clear();
     ev.emit_substitute(rhs_g, "nx", &hook);
