@@ -320,3 +320,40 @@ def test_evaluated_solve_beyond_the_reach_flags_what_the_separate_launches_flag(
     failed = (fi["flags"] & 1) == 0
     if failed.any():  # a failed factorisation reads NaN in every derivative, never a number
         assert np.all(np.isnan(fused.derivatives.cpu().numpy()[failed]))
+
+
+@pytest.mark.parametrize("name", ["c1_dw_corner", "t_axle_dw"])
+def test_solve_evaluated_sweep_without_evaluated_kernels_falls_back_to_solve_then_evaluate(golden, name, monkeypatch):
+    """A program whose evaluated kernels cannot be had (no single-mode / pair-mode quad kernel, more role points than fit, a
+    compile failure: enable_evaluation raises) is solved first and evaluated after by the separate launches - the documented
+    fallback, with the rows of the fused path.  (Round 5 compared two bound methods with `is` there and died with an
+    AttributeError instead.)"""
+    import yaml
+
+    from open_kinematics_amd import batch
+    from open_kinematics_amd.input import build_suspension, build_sweep
+    from open_kinematics_amd.sweep import solve_evaluated_sweep
+
+    arrays, _ = golden(name)
+    sus = build_suspension(yaml.safe_load(str(arrays["geometry_yaml"])))
+    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)
+    fused = solve_evaluated_sweep(sus, sweep)
+
+    def refuse(self, roles):
+        raise ValueError("no evaluated kernels for this program: (test)")
+
+    monkeypatch.setattr(batch.DeviceProgram, "enable_evaluation", refuse)
+    plain = solve_evaluated_sweep(sus, sweep)
+    assert len(plain.states) == len(fused.states) == len(plain.metrics.rows) and plain.metrics.derivative_error is None
+    for a, b in zip(plain.states, fused.states):
+        for key, p in a.positions.items():
+            assert np.array_equal(np.asarray(p.data), np.asarray(b.positions[key].data)), key
+
+    def flat(row):
+        return row.flat_row() if hasattr(row, "flat_row") else row
+
+    for got, want in zip(plain.metrics.rows, fused.metrics.rows):
+        got, want = flat(got), flat(want)
+        assert list(got) == list(want)
+        for key, value in want.items():
+            assert (got[key] is None and value is None) or abs(got[key] - value) <= 1e-7 * max(1.0, abs(value)), key
