@@ -4,8 +4,8 @@ Fill the kernel cache for a user's own suspension ahead of time (no GPU needed):
     python -m open_kinematics_amd.precompile geometry.yaml sweep.yaml [more_sweeps.yaml ...]
 
 compiles what the drop-in entry points make of the geometry - ``solve_sweep`` / ``solve_evaluated_sweep`` (every point of a
-state an output), ``compute_sweep_metrics`` / ``compute_sweep_tangents`` (the suspension's own output list) and, for a corner,
-the evaluated modules of both - so that the first sweep of a fresh process runs the generated kernels instead of the
+state an output), ``compute_sweep_metrics`` / ``compute_sweep_tangents`` (the suspension's own output list) and the evaluated modules of
+both (a corner's, or a composed axle's pair-mode module) - so that the first sweep of a fresh process runs the generated kernels instead of the
 interpreter while a compile thread works (``include/okx.h``: tiered start).  A program's target rows come from the sweep
 (which actuators it drives), hence the sweep files: sweeps that drive the same actuators share their programs.  Honours
 ``OKX_KERNEL_CACHE``.  Exit status: the number of programs that could not be compiled.
@@ -22,7 +22,7 @@ def precompile_suspension(suspension, sweeps) -> list:
     """``[(what, status, seconds)]`` for every program of the suspension under the given sweeps."""
     from . import _lib
     from ._abi import HostProgram
-    from .metrics import CornerRoles, corner_roles
+    from .metrics import AxleRoles, CornerRoles, axle_evaluation_roles, corner_roles
     from .solver import dropin_program
     from .sweep import sweep_program
 
@@ -45,6 +45,14 @@ def precompile_suspension(suspension, sweeps) -> list:
                 roles = corner_roles(suspension, program)
                 rc = lib.okx_precompile_evaluation(host.byref(), C.byref(CornerRoles.from_buffer_copy(bytes(roles))))
                 note = "ok, with the evaluated modules" if rc == 0 else "solve kernels ok; evaluated modules: " + _lib.last_error()
+            elif rc == 0:  # a composed axle: the pair-mode evaluated module (both corners' roles + rotation / hardware roles)
+                try:
+                    roles = axle_evaluation_roles(suspension, program)[0]
+                    rc = lib.okx_precompile_axle_evaluation(host.byref(), C.byref(AxleRoles.from_buffer_copy(bytes(roles))))
+                    note = "ok, with the axle's evaluated module" if rc == 0 else "solve kernels ok; evaluated module: " + _lib.last_error()
+                    rc = 0 if rc == -2 else rc  # (no pair-mode kernel for this axle: it evaluates in separate launches)
+                except ValueError as error:
+                    note = f"solve kernels ok; no evaluated module ({error})"
             done.append((f"{label}: {what}", note, time.perf_counter() - t0, rc))
     return done
 

@@ -265,4 +265,4 @@ def test_precompile_entry_point_for_a_users_geometry(capsys):
     assert "drop-in solve: ok, with the evaluated modules" in out
     assert precompile.main([geometry_path("axle_geometry.yaml"), geometry_path("axle_sweep.yaml")]) == 0
     out = capsys.readouterr().out
-    assert "drop-in solve: ok" in out and "evaluated" not in out      # axles: the solve kernels (pair mode) only
+    assert "drop-in solve: ok, with the axle's evaluated module" in out   # axles: the pair-mode solve kernels and (round 6) their evaluated module
