@@ -72,16 +72,15 @@ def solve_infos_from_records(info: np.ndarray, n_variables: int) -> list:
     """
     from ._abi import TANGENT_RANK_DEFICIENT
 
-    out = []
-    for flags, lo, hi in zip(info["flags"].tolist(), info["min_pivot"].tolist(), info["max_pivot"].tolist()):
-        deficient = bool(flags & TANGENT_RANK_DEFICIENT)
-        out.append(TangentSolveInfo(
-            n_variables=n_variables,
-            rank=n_variables - 1 if deficient else n_variables,
-            smallest_singular_value=float(np.sqrt(max(lo, 0.0))),
-            condition_number=float(np.sqrt(hi / lo)) if lo > 0.0 else float("inf"),
-        ))
-    return out
+    lo, hi = info["min_pivot"].astype(np.float64), info["max_pivot"].astype(np.float64)
+    positive = lo > 0.0
+    smallest = np.sqrt(np.maximum(lo, 0.0)).tolist()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        condition = np.where(positive, np.sqrt(hi / np.where(positive, lo, 1.0)), np.inf).tolist()
+    deficient = ((info["flags"] & TANGENT_RANK_DEFICIENT) != 0).tolist()
+    return [TangentSolveInfo(n_variables=n_variables, rank=n_variables - 1 if d else n_variables,
+                             smallest_singular_value=s, condition_number=c)
+            for d, s, c in zip(deficient, smallest, condition)]
 
 
 def _positions_array(states, out_keys) -> np.ndarray:

@@ -44,7 +44,7 @@ class SolverConfig(NamedTuple):
     warm_start: bool = True     # reference semantics: step k starts from step k-1 (solver.py:774)
     step_tol: float = 1e-11     # mm
     max_iter: int = 100
-    parallel_chains: bool = True  # long warm-started sweeps: several chains at once, verified against the sequential path
+    parallel_chains: bool = True  # warm-started sweeps of eight steps and more: short chains side by side, verified against the sequential path
 
 
 def device_tolerances(cfg: "SolverConfig", program: ConstraintProgram) -> dict:
@@ -164,7 +164,10 @@ def absolute_target_table(sweep_config, initial_state, steps: tuple | None = Non
         unit0 = resolve_direction(first.direction)
         position = initial_state.positions[first.point_id]
         base = float(np.dot(np.asarray(getattr(position, "data", position)), unit0))
-        columns.append([t.value if _is_absolute(t.mode) else base + t.value for t in dim[lo:hi]])
+        mode0 = first.mode  # (a dimension's targets nearly always share ONE mode object: the identity test settles them)
+        shift0 = 0.0 if _is_absolute(mode0) else base
+        columns.append([shift0 + t.value if t.mode is mode0 else (t.value if _is_absolute(t.mode) else base + t.value)
+                        for t in dim[lo:hi]])
         heads.append((first.point_id, first.direction))
     table = np.asarray(columns, dtype=np.float64).T.reshape(hi - lo, len(dims))
     return heads, np.ascontiguousarray(table)
@@ -187,7 +190,7 @@ _PROGRAM_CACHE_LOCK = threading.Lock()
 PROGRAM_CACHE_SIZE = 8
 
 
-def _program_key(program: ConstraintProgram, device) -> tuple:
+def _program_digest(program: ConstraintProgram) -> str:
     digest = hashlib.blake2b(digest_size=16)
     for array in (program.role, program.free_point, program.dop_type, program.dop_out, program.dop_pts,
                   program.dop_param, program.row_type, program.row_pts, program.row_param, program.tgt_point,
@@ -195,7 +198,14 @@ def _program_key(program: ConstraintProgram, device) -> tuple:
         data = np.ascontiguousarray(array)
         digest.update(str(data.dtype).encode() + str(data.shape).encode())
         digest.update(data.tobytes())
-    return digest.hexdigest(), program.line_mode, str(device)
+    return digest.hexdigest()
+
+
+def _program_key(program: ConstraintProgram, device) -> tuple:
+    # (`_okx_digest`: left on the programs of `memoized_program` - this module's own objects, flattened once and never
+    #  edited - so that a repeated sweep does not hash thirteen arrays per call; any other program is hashed here)
+    digest = program.__dict__.get("_okx_digest") or _program_digest(program)
+    return digest, program.line_mode, str(device)
 
 
 def _device_program(program: ConstraintProgram, device=None):
@@ -276,6 +286,7 @@ def memoized_program(suspension, sweep_config, kind: str, line_mode: str, build,
             memo.move_to_end(key)
     if program is None:
         program = build(state, heads)  # (outside the lock: flattening is the slow part; two threads may both flatten once)
+        program.__dict__["_okx_digest"] = _program_digest(program)
         with _PROGRAM_CACHE_LOCK:
             memo[key] = program
             while len(memo) > PROGRAM_MEMO_SIZE:
@@ -347,8 +358,8 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     positions_from_segments = False
     segment = _segment_length(n_steps) if cfg.warm_start and cfg.parallel_chains else 0
     if segment:
-        # One chain is one quad walking the sweep step by step: 1/16384 of the chip and ~12 us per step.  A long sweep
-        # is therefore cut into a few chains that run side by side (chain heads start at the design state) and the
+        # One chain is one quad walking the sweep step by step: 1/16384 of the chip and ~12 us per step.  A sweep
+        # is therefore cut into short chains that run side by side (chain heads start at the design state) and the
         # result is kept only if it is what the sequential warm start would have produced: every step accepted and
         # every chain head where the extrapolation of the chain before it says it should be.
         result = solve(targets, chain_len=segment, **solve_kw)
@@ -420,10 +431,16 @@ def _solve_sweep_in_runs(initial_state, constraints, sweep_config, derived_manag
 
 
 def _segment_length(n_steps: int) -> int:
-    """Chain length for a warm-started sweep solved as several chains at once (0: keep it one chain)."""
-    if n_steps < 32:
-        return 0
-    return max(8, int(np.ceil(np.sqrt(n_steps))))
+    """
+    Chain length for a warm-started sweep solved as several chains at once (0: keep it one chain).  One chain step is
+    ~12 us of ONE wavefront (~40 us in a composed axle's pair mode) whatever else the chip does, so the sweep's time on
+    the device is the length of its longest chain: chains of four (a head's cold start, then the three steps that still
+    pay for the short history - `tools/c3_chain_steps.py`) brought the 101-step corner sweep from 0.47 to 0.38 ms per
+    call and a 31-step T-bar axle from 1.4 to 0.5 ms (`tools/dropin_phases.py --segment=k`, `tools/dropin_latency.py`);
+    shorter chains gain little more and put a cold start - each one a chance of falling back to the sequential chain -
+    at every second step.
+    """
+    return 4 if n_steps >= 8 else 0
 
 
 def _chains_are_continuous(program: ConstraintProgram, table: np.ndarray, positions: np.ndarray, info: np.ndarray,
@@ -437,24 +454,32 @@ def _chains_are_continuous(program: ConstraintProgram, table: np.ndarray, positi
     flags = info["flags"]
     if np.any((flags & 1) == 0) or np.any((flags & 6) != 0):
         return False
-    out = [int(k) for k in program.out_point]
-    try:
-        free = positions[:, [out.index(int(p)) for p in program.free_point], :].reshape(positions.shape[0], -1)
-    except ValueError:  # a free point is not among the outputs: nothing to check against
+    heads = np.arange(segment, positions.shape[0], segment)
+    if heads.size == 0:
+        return True
+    if heads[0] < 2:
         return False
-    for k in range(segment, positions.shape[0], segment):
-        if k < 2:
-            return False
-        d_prev = table[k - 1] - table[k - 2]
-        d_new = table[k] - table[k - 1]
-        den = float(d_prev @ d_prev)
-        alpha = float(d_new @ d_prev) / den if den > 0.0 else 0.0
-        step = free[k - 1] - free[k - 2]
-        predicted = free[k - 1] + alpha * step
-        scale = float(np.abs(step).max()) * max(abs(alpha), 1.0)
-        if float(np.abs(free[k] - predicted).max()) > 0.5 * scale + 1e-6:
-            return False
-    return True
+    rows = program.__dict__.get("_okx_free_rows", False)  # (where the free points sit among the outputs: kept on the program)
+    if rows is False:
+        out = [int(k) for k in program.out_point]
+        try:
+            rows = np.asarray([out.index(int(p)) for p in program.free_point], dtype=np.intp)
+        except ValueError:  # a free point is not among the outputs: nothing to check against
+            rows = None
+        program.__dict__["_okx_free_rows"] = rows
+    if rows is None:
+        return False
+    # every boundary at once (a loop over the heads cost as much host time as the launch); only the three states a
+    # boundary looks at are gathered
+    head, last, before = (positions[k][:, rows, :].reshape(heads.size, -1) for k in (heads, heads - 1, heads - 2))
+    d_prev = table[heads - 1] - table[heads - 2]
+    d_new = table[heads] - table[heads - 1]
+    den = (d_prev * d_prev).sum(axis=1)
+    alpha = np.where(den > 0.0, (d_new * d_prev).sum(axis=1) / np.where(den > 0.0, den, 1.0), 0.0)
+    step = last - before
+    predicted = last + alpha[:, None] * step
+    scale = np.abs(step).max(axis=1) * np.maximum(np.abs(alpha), 1.0)
+    return bool(np.all(np.abs(head - predicted).max(axis=1) <= 0.5 * scale + 1e-6))
 
 
 def _coerce_config(config) -> SolverConfig:

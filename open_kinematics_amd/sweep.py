@@ -144,6 +144,10 @@ def _driver_ratio(response_rate, driver_rate, candidates, column: str = ""):
         b = response_rate.shape[0]
         if not candidates or driver_rate is None:
             return np.full((b,), np.nan)
+        if len(candidates) == 1:  # the usual case (one hub target, one rack target): nothing to choose between
+            rate, resp = driver_rate[:, candidates[0]], response_rate[:, candidates[0]]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return np.where(np.abs(rate) >= EPS_GEOMETRIC, resp / rate, np.nan)
         rates = driver_rate[:, candidates]                               # [B, C]
         strength = np.abs(rates)
         pick = strength.argmax(axis=1)[:, None]

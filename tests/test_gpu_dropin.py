@@ -164,14 +164,14 @@ def test_parallel_chains_give_the_sequential_answer_or_fall_back(golden):
 
     arrays, _ = golden("c1_dw_corner")
     sus = _dw()
-    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)  # 101 steps: chains of 11
-    assert solver._segment_length(101) == 11 and solver._segment_length(31) == 0
+    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)  # 101 steps: chains of 4
+    assert solver._segment_length(101) == 4 and solver._segment_length(7) == 0
     fast, fast_info = solve_sweep(sus, sweep)
     slow, slow_info = solve_sweep(sus, sweep, SolverConfig(parallel_chains=False))
     for a, b in zip(fast, slow):
         for key in a.positions:
             assert np.max(np.abs(a.positions[key].data - b.positions[key].data)) <= 1e-9
-    # ten chain heads started cold: a few evaluations more than one chain, far fewer than 101 cold starts
+    # twenty-six chain heads started cold: more evaluations than one chain, fewer than 101 cold starts
     cold = solve_sweep(sus, sweep, SolverConfig(warm_start=False))[1]
     assert sum(i.nfev for i in slow_info) <= sum(i.nfev for i in fast_info) < sum(i.nfev for i in cold)
 

@@ -170,7 +170,7 @@ def test_parallel_chain_policy_and_continuity_check():
 
     from open_kinematics_amd import solver
 
-    assert [solver._segment_length(n) for n in (1, 31, 32, 36, 101, 1000)] == [0, 0, 8, 8, 11, 32]
+    assert [solver._segment_length(n) for n in (1, 7, 8, 36, 101, 1000)] == [0, 0, 4, 4, 4, 4]
     program = SimpleNamespace(out_point=np.arange(4), free_point=np.array([1, 3]))
     steps = 40
     table = np.stack([np.linspace(0.0, 39.0, steps), np.zeros(steps)], axis=1)
