@@ -814,8 +814,9 @@ def measure_dropin(device) -> dict:
         out[f"{name}_nfev_mean"] = float(np.mean([i.nfev for i in infos]))
     out["note"] = ("solve_sweep(suspension, sweep) -> (states, infos), host objects in and out; first call = flatten + "
                    "program upload + kernel generation + code-object load (in-tree cache) + solve, later calls reuse "
-                   "the cached device program (solver._PROGRAM_CACHE); a sweep is a handful of warm-started chains of four "
-                   "steps, one quad each (one chain below eight steps), so this is a latency figure, not a throughput figure")
+                   "the cached device program (solver._PROGRAM_CACHE); a sweep of four steps and more is solved as cold "
+                   "starts side by side and kept when it is the sequential warm start's path (one chain otherwise): a "
+                   "latency figure, not a throughput figure")
     clear_program_cache()
     return out
 

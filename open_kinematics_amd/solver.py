@@ -44,7 +44,7 @@ class SolverConfig(NamedTuple):
     warm_start: bool = True     # reference semantics: step k starts from step k-1 (solver.py:774)
     step_tol: float = 1e-11     # mm
     max_iter: int = 100
-    parallel_chains: bool = True  # warm-started sweeps of eight steps and more: short chains side by side, verified against the sequential path
+    parallel_chains: bool = True  # warm-started sweeps of four steps and more: every step a cold start, side by side, kept when it is the sequential path
 
 
 def device_tolerances(cfg: "SolverConfig", program: ConstraintProgram) -> dict:
@@ -318,7 +318,8 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     records still in HBM - a warm-started sweep is a CHAIN, whose steps one quad walks one after the other, and the fused
     epilogue lengthens every step of it, while the given-states kernel evaluates all steps side by side: for the sweeps
     the drop-in sees (tens of steps) the two launches finish sooner (``tools/dropin_latency.py``).  None (default): two
-    launches for warm-started sweeps, one for independent cold starts (``warm_start=False``).
+    launches for a warm-started CHAIN, one for independent cold starts - ``warm_start=False``, and the cold starts a
+    warm-started sweep is first solved as (``SolverConfig.parallel_chains``, ``_segment_length``).
     """
     import torch
 
@@ -342,7 +343,7 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
             roles, want_tangents = evaluation(program)
             dp.enable_evaluation(roles)
 
-            def solve(targets, **kw):  # noqa: F811 - the same launch, ending in the evaluation epilogue
+            def solve(targets, one_launch=one_launch, **kw):  # noqa: F811 - the same launch, ending in the evaluation epilogue
                 if one_launch:
                     return dp.solve_evaluated(targets, tangents=want_tangents, **kw)
                 plain = dp.solve(targets, **kw)   # (both launches are asynchronous: the records never leave HBM in between)
@@ -359,10 +360,12 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     segment = _segment_length(n_steps) if cfg.warm_start and cfg.parallel_chains else 0
     if segment:
         # One chain is one quad walking the sweep step by step: 1/16384 of the chip and ~12 us per step.  A sweep
-        # is therefore cut into short chains that run side by side (chain heads start at the design state) and the
+        # is therefore cut into chains (of one step) that run side by side (chain heads start at the design state) and the
         # result is kept only if it is what the sequential warm start would have produced: every step accepted and
         # every chain head where the extrapolation of the chain before it says it should be.
-        result = solve(targets, chain_len=segment, **solve_kw)
+        # (single-step chains are independent cold starts: their evaluation rides in the solve's launch unless the caller chose)
+        attempt_kw = {"one_launch": True} if fused and evaluation_fused is None and segment == 1 else {}
+        result = solve(targets, chain_len=segment, **attempt_kw, **solve_kw)
         positions = result.positions.cpu().numpy()
         info = result.info()
         positions_from_segments = True
@@ -433,14 +436,15 @@ def _solve_sweep_in_runs(initial_state, constraints, sweep_config, derived_manag
 def _segment_length(n_steps: int) -> int:
     """
     Chain length for a warm-started sweep solved as several chains at once (0: keep it one chain).  One chain step is
-    ~12 us of ONE wavefront (~40 us in a composed axle's pair mode) whatever else the chip does, so the sweep's time on
-    the device is the length of its longest chain: chains of four (a head's cold start, then the three steps that still
-    pay for the short history - `tools/c3_chain_steps.py`) brought the 101-step corner sweep from 0.47 to 0.38 ms per
-    call and a 31-step T-bar axle from 1.4 to 0.5 ms (`tools/dropin_phases.py --segment=k`, `tools/dropin_latency.py`);
-    shorter chains gain little more and put a cold start - each one a chance of falling back to the sequential chain -
-    at every second step.
+    ~12 us of ONE wavefront (~40 us in a composed axle's pair mode) whatever else the chip does, so a sweep's time on
+    the device is the length of its longest chain - and a sweep the drop-in sees (tens to hundreds of steps) leaves the
+    chip empty either way.  Every step therefore starts cold from the design state (chains of ONE: the cold body, the
+    shared first step) and the continuity test decides whether that is the path the sequential warm start walks:
+    101-step corner sweep 0.47 ms per call as ten chains of eleven, 0.38 as chains of four, 0.34 as cold starts; a
+    31-step T-bar axle 1.39 (one chain) / 0.47 / 0.33 ms (`tools/dropin_phases.py --segment=k`,
+    `tools/dropin_latency.py --segment=k`).  Below four steps the test has nothing to hold the second state against.
     """
-    return 4 if n_steps >= 8 else 0
+    return 1 if n_steps >= 4 else 0
 
 
 def _chains_are_continuous(program: ConstraintProgram, table: np.ndarray, positions: np.ndarray, info: np.ndarray,
@@ -454,10 +458,14 @@ def _chains_are_continuous(program: ConstraintProgram, table: np.ndarray, positi
     flags = info["flags"]
     if np.any((flags & 1) == 0) or np.any((flags & 6) != 0):
         return False
-    heads = np.arange(segment, positions.shape[0], segment)
+    n = positions.shape[0]
+    heads = np.arange(segment, n, segment)
     if heads.size == 0:
         return True
-    if heads[0] < 2:
+    # a head is held against the secant through the two states BEFORE it; the second state of a sweep of single-step
+    # chains has only one state before it and is held against the two states AFTER it (the same test, mirrored)
+    toward = np.where(heads >= 2, -1, 1)
+    if np.any((heads + 2 * toward < 0) | (heads + 2 * toward >= n)):
         return False
     rows = program.__dict__.get("_okx_free_rows", False)  # (where the free points sit among the outputs: kept on the program)
     if rows is False:
@@ -471,9 +479,10 @@ def _chains_are_continuous(program: ConstraintProgram, table: np.ndarray, positi
         return False
     # every boundary at once (a loop over the heads cost as much host time as the launch); only the three states a
     # boundary looks at are gathered
-    head, last, before = (positions[k][:, rows, :].reshape(heads.size, -1) for k in (heads, heads - 1, heads - 2))
-    d_prev = table[heads - 1] - table[heads - 2]
-    d_new = table[heads] - table[heads - 1]
+    near, far = heads + toward, heads + 2 * toward
+    head, last, before = (positions[k][:, rows, :].reshape(heads.size, -1) for k in (heads, near, far))
+    d_prev = table[near] - table[far]
+    d_new = table[heads] - table[near]
     den = (d_prev * d_prev).sum(axis=1)
     alpha = np.where(den > 0.0, (d_new * d_prev).sum(axis=1) / np.where(den > 0.0, den, 1.0), 0.0)
     step = last - before

@@ -548,9 +548,11 @@ def solve_evaluated_sweep(suspension, sweep_config, solver_config: SolverConfig 
     (``okx_solve_evaluated_batch``: the tangents and metrics are the solve kernel's epilogue, taken at the converged state
     while it is still in registers); so is a composed axle's (both corners' catalogs, the axle-scope metrics and the
     rotation / hardware roles: the pair-mode evaluated module); programs without such kernels solve first and evaluate
-    after (``evaluate_solved_sweep``).  ``fused``: see ``solver.solve_suspension_sweep(evaluation_fused=)`` - by default a
-    warm-started sweep is solved as its chain and then evaluated by ONE more launch on the records in HBM (every step side by
-    side), independent cold starts (``warm_start=False``) in the one fused launch; no host round trip either way.  Same states, same error behaviour as ``solve_sweep``.
+    after (``evaluate_solved_sweep``).  ``fused``: see ``solver.solve_suspension_sweep(evaluation_fused=)`` - by default
+    independent cold starts (``warm_start=False``, and the cold starts side by side a warm-started sweep of four steps and
+    more is first solved as) take the one fused launch; a warm-started CHAIN (shorter sweeps, the fallback when the cold
+    starts are not the sequential path) is solved as such and then evaluated by ONE more launch on the records in HBM (every
+    step side by side); no host round trip either way.  Same states, same error behaviour as ``solve_sweep``.
     """
     from .metrics import axis_rotation_metrics, axle_evaluation_roles, corner_roles, topology_rotation_roles
     from .sensitivity import solve_infos_from_records

@@ -182,7 +182,8 @@ def test_per_geometry_tables_use_each_geometrys_design_references(golden):
 @pytest.mark.parametrize("name,metrics_name", [("c3_axle_grid", "axle_c3"), ("t_axle_heave_link", "axle_heave_link")])
 def test_solve_evaluated_sweep_of_an_axle_is_one_launch_and_matches_the_reference(golden, name, metrics_name, monkeypatch):
     """The drop-in: solve_evaluated_sweep(AxleSuspension) = solve_sweep + compute_sweep_metrics, from ONE kernel launch
-    (fused=True) or from the solve and one evaluation launch on its records (the default for a warm-started chain)."""
+    (fused=True, and the default: a warm-started sweep is first solved as cold starts side by side) or from the solve and one
+    evaluation launch on its records (fused=False; what the sequential chain takes when the cold starts are not kept)."""
     from open_kinematics_amd import batch, sweep as sweep_mod
     from open_kinematics_amd.enums import Side
     from open_kinematics_amd.input import build_suspension, build_sweep
@@ -197,7 +198,9 @@ def test_solve_evaluated_sweep_of_an_axle_is_one_launch_and_matches_the_referenc
         monkeypatch.setattr(batch.DeviceProgram, fn, lambda self, *a, _o=original, _n=fn, **k: (calls.append(_n), _o(self, *a, **k))[1])
     evaluated = sweep_mod.solve_evaluated_sweep(axle, sweep, fused=True)
     assert calls == []  # neither a plain solve nor a separate evaluation: the fused launch only
-    two = sweep_mod.solve_evaluated_sweep(axle, sweep)  # a warm-started sweep by default: its chain, then ONE launch on its records
+    default = sweep_mod.solve_evaluated_sweep(axle, sweep)
+    assert calls == [] and len(default.states) == len(evaluated.states)
+    two = sweep_mod.solve_evaluated_sweep(axle, sweep, fused=False)  # the solve, then ONE launch on its records
     assert calls == ["solve", "evaluate"]
     for row, ref in zip(two.metrics.rows, evaluated.metrics.rows):
         assert all(_same(row.axle[n], ref.axle[n]) for n in ref.axle)

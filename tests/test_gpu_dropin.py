@@ -44,11 +44,13 @@ def test_solve_sweep_returns_reference_shaped_results(golden):
     pos = np.array([[s.positions[k].data for k in out] for s in states])
     diff = np.abs(pos - arrays["ref_tight_pos"])
     assert diff.max() <= 6e-8 and np.abs(pos - arrays["ref_default_pos"]).max() <= 5e-5
-    # warm start (reference semantics) needs fewer evaluations than independent cold starts
+    # the sequential warm start (reference semantics) needs fewer evaluations than independent cold starts - which is what
+    # the default solves the sweep as, side by side, before checking that they are the sequential path
     from open_kinematics_amd.solver import SolverConfig
 
     _, cold = solve_sweep(sus, sweep, SolverConfig(warm_start=False))
-    assert sum(i.nfev for i in infos) < sum(i.nfev for i in cold)
+    _, chain = solve_sweep(sus, sweep, SolverConfig(parallel_chains=False))
+    assert sum(i.nfev for i in chain) < sum(i.nfev for i in cold) == sum(i.nfev for i in infos)
 
 
 def test_infeasible_step_raises_like_the_reference():
@@ -164,16 +166,18 @@ def test_parallel_chains_give_the_sequential_answer_or_fall_back(golden):
 
     arrays, _ = golden("c1_dw_corner")
     sus = _dw()
-    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)  # 101 steps: chains of 4
-    assert solver._segment_length(101) == 4 and solver._segment_length(7) == 0
+    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)  # 101 steps: 101 cold starts side by side
+    assert solver._segment_length(101) == 1 and solver._segment_length(3) == 0
     fast, fast_info = solve_sweep(sus, sweep)
     slow, slow_info = solve_sweep(sus, sweep, SolverConfig(parallel_chains=False))
     for a, b in zip(fast, slow):
         for key in a.positions:
             assert np.max(np.abs(a.positions[key].data - b.positions[key].data)) <= 1e-9
-    # twenty-six chain heads started cold: more evaluations than one chain, fewer than 101 cold starts
+    # every step started cold: the evaluations of 101 independent solves (so the parallel result was the one kept, not
+    # the sequential fallback), more than one chain's
     cold = solve_sweep(sus, sweep, SolverConfig(warm_start=False))[1]
-    assert sum(i.nfev for i in slow_info) <= sum(i.nfev for i in fast_info) < sum(i.nfev for i in cold)
+    assert [i.nfev for i in fast_info] == [i.nfev for i in cold]
+    assert sum(i.nfev for i in slow_info) <= sum(i.nfev for i in fast_info)
 
     # the continuity test itself: a chain head on another branch, a rejected step and a kinked target path all fail it
     program, table = solver.dropin_program(sus.initial_state(), sus.constraints(), sweep, sus.derived_spec())
@@ -190,6 +194,30 @@ def test_parallel_chains_give_the_sequential_answer_or_fall_back(golden):
     kinked = table.copy()
     kinked[33:] = kinked[33:][::-1]
     assert not solver._chains_are_continuous(program, kinked, pos, info, 11)
+
+
+@pytest.mark.parametrize("name", ["t_corner_rocker", "e2e_sweep", "t_axle_dw", "t_axle_macpherson", "t_axle_heave_link",
+                                  "t_axle_t_bar_bump", "t_axle_t_bar_roll", "t_axle_t_bar_heave"])
+def test_parallel_cold_starts_are_the_sequential_path_on_the_reference_fixtures(golden, name):
+    """Every fixture sweep of the reference, corners and composed axles: the cold starts side by side are kept (they pass
+    the continuity test) and are the sequential warm start's states to 1e-9 mm."""
+    import yaml
+
+    from open_kinematics_amd.input import build_suspension, build_sweep
+    from open_kinematics_amd.solver import SolverConfig
+    from open_kinematics_amd.sweep import solve_sweep
+
+    arrays, _ = golden(name)
+    sus = build_suspension(yaml.safe_load(str(arrays["geometry_yaml"])))
+    sweep = build_sweep(yaml.safe_load(str(arrays["sweep_yaml"])), sus)
+    fast, fast_info = solve_sweep(sus, sweep)
+    slow, _ = solve_sweep(sus, sweep, SolverConfig(parallel_chains=False))
+    cold = solve_sweep(sus, sweep, SolverConfig(warm_start=False))[1]
+    assert len(fast) == len(slow) == sweep.n_steps
+    if sweep.n_steps >= 4:
+        assert [i.nfev for i in fast_info] == [i.nfev for i in cold], "fell back to the sequential chain"
+    worst = max(float(np.max(np.abs(a.positions[key].data - b.positions[key].data))) for a, b in zip(fast, slow) for key in a.positions)
+    assert worst <= 1e-9, worst
 
 
 def test_infeasible_long_sweep_raises_at_the_sequential_step():
@@ -296,7 +324,9 @@ def test_solver_info_counts_the_shared_design_state_evaluation_for_chain_heads()
     solver.clear_program_cache()
     sweep = SweepConfig([rack, bump])
     _, cold = solve_suspension_sweep(sus.initial_state(), sus.constraints(), sweep, sus.derived_spec(), SolverConfig(warm_start=False))
-    _, warm = solve_suspension_sweep(sus.initial_state(), sus.constraints(), sweep, sus.derived_spec())
+    _, warm = solve_suspension_sweep(sus.initial_state(), sus.constraints(), sweep, sus.derived_spec(), SolverConfig(parallel_chains=False))
+    _, default = solve_suspension_sweep(sus.initial_state(), sus.constraints(), sweep, sus.derived_spec())
+    assert [i.nfev for i in default] == [i.nfev for i in cold]  # six steps: solved as cold starts side by side, and kept
     dp = next(iter(solver._PROGRAM_CACHE.values()))
     assert dp.shares_first_step
     _, table = solver.absolute_target_table(sweep, sus.initial_state())

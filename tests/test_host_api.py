@@ -170,7 +170,7 @@ def test_parallel_chain_policy_and_continuity_check():
 
     from open_kinematics_amd import solver
 
-    assert [solver._segment_length(n) for n in (1, 7, 8, 36, 101, 1000)] == [0, 0, 4, 4, 4, 4]
+    assert [solver._segment_length(n) for n in (1, 3, 4, 36, 101, 1000)] == [0, 0, 1, 1, 1, 1]
     program = SimpleNamespace(out_point=np.arange(4), free_point=np.array([1, 3]))
     steps = 40
     table = np.stack([np.linspace(0.0, 39.0, steps), np.zeros(steps)], axis=1)
@@ -187,6 +187,14 @@ def test_parallel_chain_policy_and_continuity_check():
     flagged = info.copy()
     flagged["flags"][5] = 0
     assert not solver._chains_are_continuous(program, table, pos, flagged, 8)
+    # chains of one step (every state a cold start): the second state is held against the two states after it
+    assert solver._chains_are_continuous(program, table, pos, info, 1)
+    for k in (1, 2, 17, steps - 1):
+        off = pos.copy()
+        off[k, 3, 2] += 3.0
+        assert not solver._chains_are_continuous(program, table, off, info, 1), k
+    assert not solver._chains_are_continuous(program, table[:3], pos[:3], info[:3], 1)   # nothing to hold state 1 against
+    assert solver._chains_are_continuous(program, table[:4], pos[:4], info[:4], 1)
     missing = SimpleNamespace(out_point=np.arange(3), free_point=np.array([1, 3]))  # a free point that is not an output
     assert not solver._chains_are_continuous(missing, table, pos[:, :3], info, 8)
 

@@ -22,7 +22,11 @@ def main():
     from open_kinematics_amd.input import build_suspension, build_sweep
     from open_kinematics_amd.sweep import compute_sweep_metrics, solve_evaluated_sweep, solve_sweep
 
-    names = sys.argv[1:] or ["c1_dw_corner", "c4_macpherson_grid", "t_corner_rocker", "e2e_sweep", "t_axle_dw", "t_axle_macpherson", "t_axle_heave_link", "t_axle_t_bar_bump", "t_axle_t_bar_roll", "t_axle_t_bar_heave"]
+    forced = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--segment=")]
+    if forced:  # another chain length for the parallel chains of a warm-started sweep (solver._segment_length)
+        from open_kinematics_amd import solver as _solver
+        _solver._segment_length = lambda n_steps: forced[0] if n_steps >= 4 else 0
+    names = [a for a in sys.argv[1:] if not a.startswith("--segment=")] or ["c1_dw_corner", "c4_macpherson_grid", "t_corner_rocker", "e2e_sweep", "t_axle_dw", "t_axle_macpherson", "t_axle_heave_link", "t_axle_t_bar_bump", "t_axle_t_bar_roll", "t_axle_t_bar_heave"]
     for name in names:
         path = os.path.join(REPO, "tests", "golden", name + ".npz")
         if not os.path.exists(path):
