@@ -32,6 +32,27 @@ class BatchResult:
         """Host copy of the per-problem records as a structured array (``_abi.INFO_DTYPE``)."""
         return self.info_raw.cpu().numpy().view(INFO_DTYPE).reshape(-1)
 
+    def host(self) -> tuple:
+        """
+        ``(positions [B, n_out, 3] or None, info records)`` on the host after ONE wait: both copies are queued behind the
+        launch (torch's current stream, where the solve was put) into pinned buffers - the host allocator caches the blocks,
+        so a repeated sweep allocates nothing - and the stream is synchronised once, instead of ``.cpu()`` twice (each a
+        synchronous copy through a staging buffer).  The arrays own their memory for as long as they live.
+        """
+        if self.info_raw.device.type != "cuda":
+            return (None if self.positions is None else self.positions.numpy()), self.info()
+        staged = []
+        for tensor in (self.positions, self.info_raw):
+            if tensor is None:
+                staged.append(None)
+                continue
+            pinned = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+            pinned.copy_(tensor, non_blocking=True)
+            staged.append(pinned)
+        torch.cuda.current_stream(self.info_raw.device).synchronize()
+        positions = None if staged[0] is None else staged[0].numpy()
+        return positions, staged[1].numpy().view(INFO_DTYPE).reshape(-1)
+
     @staticmethod
     def converged(info: np.ndarray) -> np.ndarray:
         return (info["flags"] & INFO_CONVERGED) != 0

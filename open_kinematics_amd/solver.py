@@ -366,17 +366,14 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
         # (single-step chains are independent cold starts: their evaluation rides in the solve's launch unless the caller chose)
         attempt_kw = {"one_launch": True} if fused and evaluation_fused is None and segment == 1 else {}
         result = solve(targets, chain_len=segment, **attempt_kw, **solve_kw)
-        positions = result.positions.cpu().numpy()
-        info = result.info()
+        positions, info = result.host()  # (one wait for both copies)
         positions_from_segments = True
         if not _chains_are_continuous(program, table, positions, info, segment):
             positions = info = None
             positions_from_segments = False
     if positions is None:
         result = solve(targets, chain=bool(cfg.warm_start), **solve_kw)
-        # one D2H copy each; .cpu() synchronises with the launch stream
-        positions = result.positions.cpu().numpy()
-        info = result.info()
+        positions, info = result.host()
         if not cfg.warm_start:
             positions_from_segments, segment = True, 1  # every step is a chain head
     _raise_on_first_failure(program, dp, table, positions, info, sweep_config, initial_state, cfg)
@@ -455,40 +452,44 @@ def _chains_are_continuous(program: ConstraintProgram, table: np.ndarray, positi
     half a step of the secant extrapolation of the previous chain's last two states (a head that fell onto another
     assembly branch is many steps away from it).
     """
-    flags = info["flags"]
-    if np.any((flags & 1) == 0) or np.any((flags & 6) != 0):
+    if not np.all((info["flags"] & 7) == 1):  # converged, neither residual-exceeded nor failed - every step
         return False
     n = positions.shape[0]
-    heads = np.arange(segment, n, segment)
-    if heads.size == 0:
+    if segment >= n:
         return True
-    # a head is held against the secant through the two states BEFORE it; the second state of a sweep of single-step
-    # chains has only one state before it and is held against the two states AFTER it (the same test, mirrored)
-    toward = np.where(heads >= 2, -1, 1)
-    if np.any((heads + 2 * toward < 0) | (heads + 2 * toward >= n)):
-        return False
     rows = program.__dict__.get("_okx_free_rows", False)  # (where the free points sit among the outputs: kept on the program)
     if rows is False:
         out = [int(k) for k in program.out_point]
         try:
             rows = np.asarray([out.index(int(p)) for p in program.free_point], dtype=np.intp)
+            if rows.size and np.array_equal(rows, np.arange(rows[0], rows[0] + rows.size)):
+                rows = slice(int(rows[0]), int(rows[0]) + rows.size)  # (a view instead of a gather)
         except ValueError:  # a free point is not among the outputs: nothing to check against
             rows = None
         program.__dict__["_okx_free_rows"] = rows
     if rows is None:
         return False
-    # every boundary at once (a loop over the heads cost as much host time as the launch); only the three states a
-    # boundary looks at are gathered
-    near, far = heads + toward, heads + 2 * toward
-    head, last, before = (positions[k][:, rows, :].reshape(heads.size, -1) for k in (heads, near, far))
-    d_prev = table[near] - table[far]
-    d_new = table[heads] - table[near]
-    den = (d_prev * d_prev).sum(axis=1)
-    alpha = np.where(den > 0.0, (d_new * d_prev).sum(axis=1) / np.where(den > 0.0, den, 1.0), 0.0)
-    step = last - before
-    predicted = last + alpha[:, None] * step
-    scale = np.abs(step).max(axis=1) * np.maximum(np.abs(alpha), 1.0)
-    return bool(np.all(np.abs(head - predicted).max(axis=1) <= 0.5 * scale + 1e-6))
+    free = positions[:, rows, :].reshape(n, -1)
+
+    def deviates(head, last, before, t_head, t_last, t_before) -> bool:
+        """Any head further than half a step from the secant through `before` and `last` (rows of states / target rows)."""
+        d_prev, d_new = t_last - t_before, t_head - t_last
+        den = (d_prev * d_prev).sum(axis=1)
+        alpha = (d_new * d_prev).sum(axis=1) / np.where(den > 0.0, den, np.inf)
+        step = last - before
+        scale = np.abs(step).max(axis=1) * np.maximum(np.abs(alpha), 1.0)
+        return bool(np.any(np.abs(head - last - alpha[:, None] * step).max(axis=1) > 0.5 * scale + 1e-6))
+
+    # a head is held against the secant through the two states BEFORE it; the second state of a sweep of single-step
+    # chains has only one state before it and is held against the two states AFTER it (the same test, mirrored).
+    # Every boundary at once (a loop over the heads cost as much host time as the launch).
+    if segment == 1:  # every state a head: consecutive rows, no gathers
+        if n < 4:
+            return False
+        return not (deviates(free[2:], free[1:-1], free[:-2], table[2:], table[1:-1], table[:-2])
+                    or deviates(free[1:2], free[2:3], free[3:4], table[1:2], table[2:3], table[3:4]))
+    heads = np.arange(segment, n, segment)
+    return not deviates(free[heads], free[heads - 1], free[heads - 2], table[heads], table[heads - 1], table[heads - 2])
 
 
 def _coerce_config(config) -> SolverConfig:

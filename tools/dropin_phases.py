@@ -51,8 +51,7 @@ def main():
         kw = dict(max_iter=cfg.max_iter, residual_tolerance=cfg.residual_tolerance, predictor=False, **SV.device_tolerances(cfg, program))
         targets = timed("as_tensor", lambda: torch.as_tensor(table))
         result = timed("dp.solve (upload + launch)", lambda: dp.solve(targets, chain_len=segment, **kw) if segment else dp.solve(targets, chain=True, **kw))
-        positions = timed("positions.cpu() (waits for the launch)", lambda: result.positions.cpu().numpy())
-        info = timed("info()", lambda: result.info())
+        positions, info = timed("result.host() (waits for the launch, both copies)", lambda: result.host())
         if segment:
             timed("_chains_are_continuous", lambda: SV._chains_are_continuous(program, table, positions, info, segment))
         timed("_raise_on_first_failure", lambda: SV._raise_on_first_failure(program, dp, table, positions, info, sweep, state, cfg))
