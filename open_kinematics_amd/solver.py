@@ -480,14 +480,16 @@ def _chains_are_continuous(program: ConstraintProgram, table: np.ndarray, positi
         scale = np.abs(step).max(axis=1) * np.maximum(np.abs(alpha), 1.0)
         return bool(np.any(np.abs(head - last - alpha[:, None] * step).max(axis=1) > 0.5 * scale + 1e-6))
 
-    # a head is held against the secant through the two states BEFORE it; the second state of a sweep of single-step
-    # chains has only one state before it and is held against the two states AFTER it (the same test, mirrored).
+    # a head is held against the secant through the two states BEFORE it; the first two states of a sweep of single-step
+    # chains are held against the two states AFTER them (the same test, mirrored).
     # Every boundary at once (a loop over the heads cost as much host time as the launch).
     if segment == 1:  # every state a head: consecutive rows, no gathers
         if n < 4:
             return False
+        # (the first state too: it is the sequential path's own cold start, and holding it against the two states after
+        #  it is what ties the rest to its branch when the first target increment is much larger than the second)
         return not (deviates(free[2:], free[1:-1], free[:-2], table[2:], table[1:-1], table[:-2])
-                    or deviates(free[1:2], free[2:3], free[3:4], table[1:2], table[2:3], table[3:4]))
+                    or deviates(free[0:2], free[1:3], free[2:4], table[0:2], table[1:3], table[2:4]))
     heads = np.arange(segment, n, segment)
     return not deviates(free[heads], free[heads - 1], free[heads - 2], table[heads], table[heads - 1], table[heads - 2])
 

@@ -193,6 +193,18 @@ def test_parallel_chain_policy_and_continuity_check():
         off = pos.copy()
         off[k, 3, 2] += 3.0
         assert not solver._chains_are_continuous(program, table, off, info, 1), k
+    # everything after the first state on another branch, behind a first target increment ten times the others (the
+    # secant through states 0 and 1 is then too long to notice): the first state, held against the two after it, does
+    uneven = table.copy()
+    uneven[1:, 0] += 9.0
+    s2 = uneven[:, 0]
+    path = np.zeros((steps, 4, 3))
+    path[:, 1, 0] = 2.0 * s2
+    path[:, 3, 2] = -s2
+    assert solver._chains_are_continuous(program, uneven, path, info, 1)
+    away = path.copy()
+    away[1:, 3, 2] += 30.0   # (the tolerance is half the extrapolated step: 10 here)
+    assert not solver._chains_are_continuous(program, uneven, away, info, 1)
     assert not solver._chains_are_continuous(program, table[:3], pos[:3], info[:3], 1)   # nothing to hold state 1 against
     assert solver._chains_are_continuous(program, table[:4], pos[:4], info[:4], 1)
     missing = SimpleNamespace(out_point=np.arange(3), free_point=np.array([1, 3]))  # a free point that is not an output
