@@ -359,11 +359,12 @@ def solve_suspension_sweep(initial_state, constraints, sweep_config, derived_man
     positions_from_segments = False
     segment = _segment_length(n_steps) if cfg.warm_start and cfg.parallel_chains else 0
     if segment:
-        # One chain is one quad walking the sweep step by step: 1/16384 of the chip and ~12 us per step.  A sweep
-        # is therefore cut into chains (of one step) that run side by side (chain heads start at the design state) and the
-        # result is kept only if it is what the sequential warm start would have produced: every step accepted and
-        # every chain head where the extrapolation of the chain before it says it should be.
-        # (single-step chains are independent cold starts: their evaluation rides in the solve's launch unless the caller chose)
+        # One chain is one quad walking the sweep step by step: 1/16384 of the chip and ~12 us per step.  The sweep
+        # is therefore solved as chains of `segment` steps side by side (`_segment_length`: one step - every state a
+        # cold start from the design state) and the result is kept only if it is what the sequential warm start would
+        # have produced: every step accepted and every head where the secant through its neighbours says it should be.
+        # Single-step chains are independent cold starts: their evaluation rides in the solve's launch unless the
+        # caller chose a form.
         attempt_kw = {"one_launch": True} if fused and evaluation_fused is None and segment == 1 else {}
         result = solve(targets, chain_len=segment, **attempt_kw, **solve_kw)
         positions, info = result.host()  # (one wait for both copies)
